@@ -1,0 +1,132 @@
+"""Differential tests: the C restatement (oracle/) against algorithm-independent textbook DPs
+(tests/textbook.py).  Every kernel in the reference is exact, so for ANY input
+  distance == textbook value, and with a cutoff: Some(d) iff d <= cutoff (src/common.rs:43-45).
+Replaces the reference's crash-only fuzz targets (fuzz/fuzz_targets/*.rs) with value oracles.
+"""
+import numpy as np
+import pytest
+
+import textbook as tb
+from oracle import oracle as o
+
+RNG = np.random.default_rng(0xC0FFEE)
+
+
+def _rand(n, alphabet):
+    return bytes(RNG.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n).tolist())
+
+
+def _mutate(s, edits, alphabet):
+    s = bytearray(s)
+    for _ in range(edits):
+        op = RNG.integers(0, 3)
+        pos = int(RNG.integers(0, len(s) + 1))
+        ch = int(RNG.choice(np.frombuffer(alphabet, dtype=np.uint8)))
+        if op == 0 and len(s):
+            s[min(pos, len(s) - 1)] = ch
+        elif op == 1:
+            s.insert(pos, ch)
+        elif len(s):
+            del s[min(pos, len(s) - 1)]
+    return bytes(s)
+
+
+def _pairs(n, max_len, alphabet=b"abc"):
+    out = []
+    for i in range(n):
+        l1 = int(RNG.integers(0, max_len + 1))
+        a = _rand(l1, alphabet)
+        if i % 2:
+            b = _mutate(a, int(RNG.integers(0, 8)), alphabet)
+        else:
+            b = _rand(int(RNG.integers(0, max_len + 1)), alphabet)
+        out.append((a, b))
+    return out
+
+
+SHORT = _pairs(300, 20) + _pairs(200, 70, b"ab") + _pairs(100, 64, b"abcdefghijklmnopqrstuvwxyz0123456789")
+LONG = _pairs(60, 300, b"abcd") + _pairs(20, 700, b"ab")
+
+
+@pytest.mark.parametrize("pairs", [SHORT, LONG], ids=["short", "long"])
+def test_levenshtein_exact_and_cutoff(pairs):
+    for a, b in pairs:
+        d = tb.levenshtein_unit(a, b)
+        bc = o.levenshtein.BatchComparator(a)
+        assert o.levenshtein.distance(a, b) == d
+        assert bc.distance(b) == d
+        for k in sorted({0, 1, 2, 3, 4, 5, max(d - 1, 0), d, d + 1, 31, 32, 2 * d}):
+            exp = d if d <= k else None
+            assert o.levenshtein.distance(a, b, score_cutoff=k) == exp, (a, b, k)
+            assert bc.distance(b, score_cutoff=k) == exp, (a, b, k, o.last_lev_path())
+        for h in (0, 1, d, 100):
+            # results never depend on the hint (levenshtein.rs:2153) -- except in the upstream corner
+            # pinned by test_reference_quirk_small_hint_vs_length_difference below
+            if len(a) <= 64 or abs(len(a) - len(b)) <= max(h, 31):
+                assert bc.distance(b, score_hint=h) == d
+        m = max(len(a), len(b))
+        assert bc.similarity(b) == m - d
+        if m:
+            assert abs(bc.normalized_distance(b) - d / m) < 1e-15
+
+
+def test_levenshtein_weighted():
+    for a, b in SHORT[:200]:
+        for w in [(1, 1, 2), (2, 2, 2), (1, 2, 3), (3, 1, 1), (2, 2, 5), (0, 0, 1)]:
+            d = tb.levenshtein(a, b, w)
+            assert o.levenshtein.distance(a, b, weights=w) == d, (a, b, w)
+            assert o.levenshtein.BatchComparator(a).distance(b, weights=w) == d, (a, b, w)
+
+
+@pytest.mark.parametrize("pairs", [SHORT, LONG], ids=["short", "long"])
+def test_lcs_and_indel(pairs):
+    for a, b in pairs:
+        l = tb.lcs_len(a, b)
+        ind = len(a) + len(b) - 2 * l
+        lb, ib = o.lcs_seq.BatchComparator(a), o.indel.BatchComparator(a)
+        assert o.lcs_seq.similarity(a, b) == l and lb.similarity(b) == l
+        assert o.indel.distance(a, b) == ind and ib.distance(b) == ind
+        assert lb.distance(b) == max(len(a), len(b)) - l
+        for k in sorted({0, 1, 2, l - 1 if l else 0, l, l + 1}):
+            exp = l if l >= k else None
+            assert o.lcs_seq.similarity(a, b, score_cutoff=k) == exp
+            assert lb.similarity(b, score_cutoff=k) == exp
+        for k in sorted({0, 1, 2, 3, 4, 5, max(ind - 1, 0), ind, ind + 1}):
+            exp = ind if ind <= k else None
+            assert o.indel.distance(a, b, score_cutoff=k) == exp
+            assert ib.distance(b, score_cutoff=k) == exp
+        # levenshtein weights (1,1,>=2) is Indel (levenshtein.rs:1321-1327)
+        assert o.levenshtein.BatchComparator(a).distance(b, weights=(1, 1, 2)) == ind
+
+
+@pytest.mark.parametrize("pairs", [SHORT, LONG[:40]], ids=["short", "long"])
+def test_jaro_and_winkler(pairs):
+    for a, b in pairs:
+        j, jw = tb.jaro(a, b), tb.jaro_winkler(a, b)
+        jb, wb = o.jaro.BatchComparator(a), o.jaro_winkler.BatchComparator(a)
+        assert abs(o.jaro.similarity(a, b) - j) < 1e-12, (a, b)
+        assert abs(jb.similarity(b) - j) < 1e-12, (a, b)
+        assert abs(o.jaro_winkler.similarity(a, b) - jw) < 1e-12
+        assert abs(wb.similarity(b) - jw) < 1e-12
+        for c in (0.0, 0.3, 0.7, 0.71, 0.9, 1.0):
+            got = jb.similarity(b, score_cutoff=c)
+            assert (got is not None) == (jb.similarity(b) >= c)
+            got = wb.similarity(b, score_cutoff=c)
+            assert (got is not None) == (wb.similarity(b) >= c), (a, b, c)
+
+
+def test_reference_quirk_small_hint_vs_length_difference():
+    """Quirk Q7 (found by this differential test, not documented upstream): the hint-doubling loop at
+    levenshtein.rs:1069-1088 calls hyrroe2003_small_band_with_pm(score_hint) WITHOUT the
+    `score_cutoff < |len1-len2|` guard that hyrroe2003_block has (:786); for len1 > 64 and an explicit
+    score_hint with 2*max(hint,31) < len1 - len2 the band's break_score (:535-536) goes negative, wraps,
+    and the function returns its start value -- so the reference's result depends on the hint there.
+    The oracle restates that faithfully; the GPU path ignores hints and returns the exact distance."""
+    a = b"ab" * 35
+    b = b"baa"
+    d = tb.levenshtein_unit(a, b)
+    assert d == 67
+    bc = o.levenshtein.BatchComparator(a)
+    assert bc.distance(b) == d  # no hint: exact
+    assert bc.distance(b, score_hint=100) == d
+    assert bc.distance(b, score_hint=0) != d  # upstream bug reproduced (value 31..34)
