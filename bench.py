@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline one-vs-many scan of BASELINE.json on MI355X.
+
+A "step" is ONE pass of the hot path over the whole device-resident corpus: 1 query x n candidates
+through `levenshtein::BatchComparator` semantics (rf_many_u32, RF_OP_DISTANCE), one u32 per candidate.
+Workload at N=1 = BASELINE.json configs[1]: query len 64 vs 100 M random alphanumeric len-64 candidates.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own 100 M-candidate
+shard (weak scaling), there is no data-path collective, and each step ends with the top-k all-gather the
+north star names (k entries per rank over RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--candidates", type=int, default=100_000_000, help="candidates per GPU")
+    ap.add_argument("--cand-len", type=int, default=64)
+    ap.add_argument("--query-len", type=int, default=64)
+    ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq"])
+    ap.add_argument("--cutoff", type=int, default=None)
+    ap.add_argument("--topk", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import rapidfuzz_rs_amd as rf
+    from rapidfuzz_rs_amd import _native as N
+    from rapidfuzz_rs_amd.utils import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if N.lib().rf_device_count() < 1:
+        raise RuntimeError("no HIP device visible to librfgpu.so")
+
+    n, ln = args.candidates, args.cand_len
+    q = synth.query(args.query_len, 0xC0FFEE02)
+    mod = getattr(rf.distance, args.metric)
+    scorer = mod.BatchComparator(q)
+
+    # synthetic corpus, generated and packed on the device (excluded from the timed region)
+    t0 = time.time()
+    rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev)
+    sample_rows = min(n, 32_000_000)
+    host_sample = None
+    if rank == 0 and not args.no_cpu_baseline:
+        host_sample = rows[:sample_rows].cpu().numpy()
+    corpus = rf.Corpus.from_device_rows(rows)
+    del rows
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    call_args = rf.Args()
+    if args.cutoff is not None:
+        call_args = call_args.score_cutoff(args.cutoff)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        scorer.distance_many(corpus, call_args, out=out, stream=stream.cuda_stream)
+
+    def exchange():
+        # per-shard top-k under (distance, global index), then the k-entry all-gather over xGMI
+        if world == 1:
+            return
+        k = args.topk
+        d = out.view(torch.int32)[:n]
+        # distances are < 2^31: order by (distance, global index) through one int64 key
+        key = d.to(torch.int64) * (1 << 40) + (torch.arange(n, device=dev, dtype=torch.int64) + rank * n)
+        loc = torch.topk(key, k, largest=False).values
+        gathered = [torch.empty_like(loc) for _ in range(world)]
+        dist.all_gather(gathered, loc)
+        torch.sort(torch.cat(gathered)).values[:k]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record(stream)
+        step()
+        ev[s][1].record(stream)
+        if world > 1 and s == args.steps - 1:
+            exchange()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_ms = float(km.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    pairs_per_step = n * world
+    ms_per_step = elapsed * 1e3 / args.steps
+    gpairs = pairs_per_step / (elapsed / args.steps) / 1e9
+    # algorithmic bytes per pair: candidate bytes at bucket length + one u32 result
+    bytes_per_pair = ln + 4
+    achieved = n * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
+
+    result = {
+        "metric": "Gpairs/s (1 query x N candidates, Levenshtein BatchComparator semantics)" if args.metric == "levenshtein" else f"Gpairs/s ({args.metric})",
+        "value": round(gpairs, 3),
+        "unit": "Gpairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64 bit-vectors (u32 results)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.metric}::BatchComparator, 1 query len-{args.query_len} x {n} random alphanumeric len-{ln} candidates per GPU, "
+            + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
+            + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64 and args.cutoff is None) else ""),
+            "candidates_per_gpu": n,
+            "candidate_len": ln,
+            "query_len": args.query_len,
+            "output": "u32 per candidate, device-resident",
+            "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if world > 1 else "1 GPU",
+            "setup_s": round(t_setup, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_bytes_per_pair": bytes_per_pair,
+        },
+    }
+
+    if host_sample is not None:
+        result["cpu_baseline"] = cpu_baseline(args, q, host_sample)
+        # parity on the sample, in the same run
+        from oracle import oracle as o
+
+        chk = min(len(host_sample), 2_000_000)
+        exp = getattr(o, args.metric).BatchComparator(q).rows(N.OP_DISTANCE, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)
+        got = out[:chk].cpu().numpy().view(np.uint32)
+        exp32 = np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
+        result["parity"] = {"checked": int(chk), "mismatches": int((got != exp32).sum())}
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, q, host_sample):
+    """The oracle (kind = "port": the C restatement of the reference's BatchComparator loop) timed on the
+    GPU box's host cores over a bounded prefix of the SAME corpus."""
+    from oracle import oracle as o
+    from rapidfuzz_rs_amd import _native as N
+
+    bc = getattr(o, args.metric).BatchComparator(q)
+    probe = host_sample[:200_000]
+    t0 = time.perf_counter()
+    bc.rows(N.OP_DISTANCE, probe, nthreads=1, score_cutoff=args.cutoff)
+    rate = len(probe) / (time.perf_counter() - t0)
+    n1 = int(min(len(host_sample), max(200_000, rate * args.cpu_seconds * 0.5)))
+    t0 = time.perf_counter()
+    bc.rows(N.OP_DISTANCE, host_sample[:n1], nthreads=1, score_cutoff=args.cutoff)
+    t1 = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    nall = int(min(len(host_sample), max(n1, rate * cores * args.cpu_seconds * 0.3)))
+    t0 = time.perf_counter()
+    bc.rows(N.OP_DISTANCE, host_sample[:nall], nthreads=cores, score_cutoff=args.cutoff)
+    tall = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": round(n1 / t1 / 1e9, 6),
+        "unit": "Gpairs/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {n1} candidates of the same corpus, oracle/ (C restatement of the reference's single-threaded BatchComparator loop), 1 thread, {t1:.1f} s",
+        "all_cores": {"value": round(nall / tall / 1e9, 6), "cores": cores, "sample": f"first {nall} candidates, {tall:.1f} s"},
+        "cpu_model": model,
+    }
+
+
+if __name__ == "__main__":
+    main()

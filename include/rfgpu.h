@@ -1,0 +1,180 @@
+/*
+ * rfgpu.h -- C ABI of the MI355X (gfx950) one-vs-many fuzzy matching engine.
+ *
+ * Drop-in boundary for the batch path of rapidfuzz-rs v0.5.0 (`rapidfuzz::distance::*::BatchComparator`
+ * and `rapidfuzz::fuzz::RatioBatchComparator`).  The reference has no FFI of its own -- its boundary is
+ * the generic Rust API -- so each entry point below names the reference item it replaces
+ * (file:line relative to the reference root).  INTEGRATION.md shows the Rust `extern "C"` block and the
+ * safe wrapper a maintainer would put behind the original signatures.
+ *
+ * Plain pointers and sizes only; no torch / HIP types (a `hipStream_t` travels as `void*`).
+ * Elements are `u8` (the `HashableChar` case `u8 -> Hash::UNSIGNED`, src/details/common.rs:34).
+ *
+ * Error model: metric evaluation never fails in the reference (no `Result` on this path; "above the
+ * cutoff" is `None`, src/common.rs:43-45).  rf_status reports ENGINE failures only (bad argument, HIP
+ * error, shape the device kernels do not cover).  There is NO CPU fallback: a shape that has no kernel
+ * returns RF_ERR_UNSUPPORTED instead of silently computing on the host.
+ *
+ * Threading: handles are immutable after creation and may be shared between host threads (the
+ * reference's comparators are Send + Sync and take &self); each call uses the stream it is given.
+ */
+#ifndef RFGPU_H
+#define RFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t rf_status;
+enum {
+    RF_OK = 0,
+    RF_ERR_INVALID_ARG = 1,
+    RF_ERR_HIP = 2,         /* a HIP runtime call failed; rf_last_error() has the text */
+    RF_ERR_UNSUPPORTED = 3, /* no device kernel for this shape / weight table (never falls back to the CPU) */
+    RF_ERR_NO_DEVICE = 4,
+    RF_ERR_OOM = 5
+};
+
+/* the metric modules of src/distance.rs:1-10 that have a bit-parallel batch path, + src/fuzz.rs */
+typedef enum rf_metric {
+    RF_LEVENSHTEIN = 0,  /* src/distance/levenshtein.rs */
+    RF_INDEL = 1,        /* src/distance/indel.rs */
+    RF_LCS_SEQ = 2,      /* src/distance/lcs_seq.rs */
+    RF_JARO = 3,         /* src/distance/jaro.rs */
+    RF_JARO_WINKLER = 4, /* src/distance/jaro_winkler.rs */
+    RF_FUZZ_RATIO = 5    /* src/fuzz.rs RatioBatchComparator */
+} rf_metric;
+
+/* the four methods every BatchComparator has (e.g. levenshtein.rs:1660-1817) */
+typedef enum rf_op {
+    RF_OP_DISTANCE = 0,
+    RF_OP_SIMILARITY = 1,
+    RF_OP_NORMALIZED_DISTANCE = 2,
+    RF_OP_NORMALIZED_SIMILARITY = 3
+} rf_op;
+
+typedef enum rf_mem { RF_MEM_HOST = 0, RF_MEM_DEVICE = 1 } rf_mem;
+
+#define RF_NO_CUTOFF UINT64_MAX   /* Args::default(): NoScoreCutoff (src/common.rs:3-30) */
+#define RF_NONE_U32 0xFFFFFFFFu   /* Option::None in a u32 result slot */
+/* Option::None in an f64 result slot is a quiet NaN (test with isnan) */
+
+/*
+ * Flattened `Args` builders: levenshtein.rs:86-126 (score_cutoff, score_hint, weights),
+ * jaro_winkler.rs:25-62 (prefix_weight), and the identical score_cutoff/score_hint pairs of
+ * lcs_seq / indel / jaro / fuzz.  Use rf_args_default() and then set fields.
+ *   cutoff_usize : RF_NO_CUTOFF = NoScoreCutoff, else WithScoreCutoff(v) for the usize-valued ops
+ *   cutoff_f64   : NaN = NoScoreCutoff, else WithScoreCutoff(v) for the f64-valued ops
+ *   score_hint_* : accepted and ignored -- in the reference a hint only steers the CPU band search
+ *                  (levenshtein.rs:1069-1088); results never depend on it (levenshtein.rs:2153-2160)
+ */
+typedef struct rf_args {
+    uint64_t cutoff_usize;
+    uint64_t score_hint_usize;
+    double cutoff_f64;
+    double score_hint_f64;
+    uint64_t insertion_cost, deletion_cost, substitution_cost; /* WeightTable, levenshtein only */
+    double prefix_weight;                                       /* jaro_winkler only (default 0.1) */
+    uint32_t flags;                                             /* RF_FLAG_* */
+    uint32_t reserved;
+} rf_args;
+
+/* RatioBatchComparator: compute the documented Indel ratio 1 - indel/(len1+len2) instead of reproducing
+ * src/fuzz.rs:141, which normalises through the inner lcs_seq comparator (LCS/max(len1,len2)). */
+#define RF_FLAG_RATIO_INDEL_NORMALIZATION 0x1u
+
+void rf_args_default(rf_args *a);
+
+typedef struct rf_comparator rf_comparator; /* = <metric>::BatchComparator<u8> */
+typedef struct rf_corpus rf_corpus;         /* a device-resident, length-bucketed packed candidate set */
+
+/* text of the last failure on the calling thread ("" if none) */
+const char *rf_last_error(void);
+/* number of visible HIP devices (0 if none / no driver) */
+int rf_device_count(void);
+
+/* ---- comparator -------------------------------------------------------------------------------
+ * rf_comparator_new = BatchComparator::new: copies the query and builds its BlockPatternMatchVector
+ * (256 x ceil(len/64) u64, row-major [c * blocks + b]; src/details/pattern_match_vector.rs:203-224).
+ *   levenshtein.rs:1645-1657, lcs_seq.rs:800-812, indel.rs:375-383, jaro.rs:830-842,
+ *   jaro_winkler.rs:413-425, fuzz.rs:102-113 */
+rf_status rf_comparator_new(rf_metric metric, const uint8_t *s1, size_t len1, rf_comparator **out);
+/* #[derive(Clone)] (levenshtein.rs:1635): deep copy */
+rf_status rf_comparator_clone(const rf_comparator *c, rf_comparator **out);
+void rf_comparator_free(rf_comparator *c);
+rf_metric rf_comparator_metric(const rf_comparator *c);
+size_t rf_comparator_query_len(const rf_comparator *c);
+/* the host copy of the PM table; *block_count = ceil(len/64) */
+const uint64_t *rf_comparator_pm(const rf_comparator *c, size_t *block_count);
+
+/* ---- corpus -----------------------------------------------------------------------------------
+ * The candidates a user would feed one by one to `scorer.distance(candidate)` (the loop in
+ * rapidfuzz-benches/benches/bench_levenshtein.rs:51-60), packed once and kept in HBM.
+ * Layout: candidates are grouped by exact length into tiles of 64 (one candidate per wavefront lane);
+ * inside a tile the 16-byte chunk k of lane r sits at tile_base + (k*64 + r)*16, so a wavefront's
+ * `global_load_dwordx4` of "my chunk k" is one contiguous 1 KiB read.  Results always come back in
+ * the ORIGINAL candidate order.
+ *
+ * rf_corpus_pack: ragged host input, candidate i = bytes[offsets[i] .. offsets[i+1]) (n+1 offsets).
+ * rf_corpus_pack_rows_device: n rows of `len` bytes already in device memory at d_rows + i*stride.
+ * Inputs are borrowed for the duration of the call only.  n < 2^32 - 1 per corpus. */
+rf_status rf_corpus_pack(const uint8_t *bytes, const uint64_t *offsets, size_t n, int device, rf_corpus **out);
+rf_status rf_corpus_pack_rows_device(const void *d_rows, size_t n, size_t len, size_t stride, int device,
+                                     void *stream, rf_corpus **out);
+void rf_corpus_free(rf_corpus *c);
+/* The same layout computed on the host only (no device needed): for tools and for the CPU-side tests of the
+ * packer.  Arrays are malloc'ed; release with rf_host_layout_free. */
+typedef struct rf_host_layout {
+    uint8_t *packed;       /* packed_bytes: tile payloads (+ one zero chunk row of tail padding) */
+    uint64_t *tile_off;    /* n_tiles: byte offset of each tile's payload */
+    uint32_t *tile_len;    /* n_tiles: candidate length of each tile (ascending) */
+    uint32_t *tile_slot0;  /* n_tiles: first slot of each tile */
+    uint32_t *orig;        /* n_slots: slot -> original index, 0xFFFFFFFF = padding lane (empty if identity) */
+    uint64_t packed_bytes, n_slots;
+    uint32_t n_tiles, identity;
+} rf_host_layout;
+rf_status rf_corpus_layout_host(const uint8_t *bytes, const uint64_t *offsets, size_t n, rf_host_layout *out);
+void rf_host_layout_free(rf_host_layout *l);
+size_t rf_corpus_count(const rf_corpus *c);          /* n */
+uint64_t rf_corpus_payload_bytes(const rf_corpus *c); /* sum of candidate lengths */
+uint64_t rf_corpus_device_bytes(const rf_corpus *c);  /* HBM held by the packed form */
+int rf_corpus_device(const rf_corpus *c);
+
+/* ---- one-vs-many ------------------------------------------------------------------------------
+ * out[i] = scorer.<op>_with_args(candidate_i, &args) for every candidate, original order.
+ *
+ * rf_many_u32: the usize-valued methods of levenshtein / indel / lcs_seq
+ *   (distance_with_args levenshtein.rs:1750-1777, similarity_with_args :1790-1817; indel.rs:464-521;
+ *    lcs_seq.rs:893-949).  RF_NONE_U32 = None.
+ * rf_many_f64: normalized_* of those metrics (levenshtein.rs:1670-1737 ...), all four methods of
+ *   jaro / jaro_winkler (jaro.rs:845-977, jaro_winkler.rs:428-575) and
+ *   RatioBatchComparator::similarity_with_args (fuzz.rs:127-149; pass RF_OP_SIMILARITY).  NaN = None.
+ *
+ * out_mem says whether `out` is host or device memory.  With RF_MEM_DEVICE the call only enqueues work
+ * on `stream` (hipStream_t, NULL = default stream); with RF_MEM_HOST it returns after the copy. */
+rf_status rf_many_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args,
+                      uint32_t *out, rf_mem out_mem, void *stream);
+rf_status rf_many_f64(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args,
+                      double *out, rf_mem out_mem, void *stream);
+
+/* ---- top-k ------------------------------------------------------------------------------------
+ * The reference has no extract/top-k API; this is the engine's own reduction over the scores above,
+ * defined as: evaluate every candidate with `op`/`args`, drop None, order by
+ *   (score ascending for RF_OP_DISTANCE / descending for RF_OP_SIMILARITY, index ascending)
+ * and keep the first k.  index = index_base + original candidate index, so shards of one logical
+ * corpus produce globally comparable entries.  Outputs are HOST arrays of k entries; *out_count <= k.
+ * rf_topk_merge_u32 merges `lists` such results (e.g. after an all-gather across GPUs). */
+rf_status rf_topk_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint32_t k,
+                      uint64_t index_base, uint32_t *out_score, uint64_t *out_index, uint32_t *out_count,
+                      void *stream);
+rf_status rf_topk_merge_u32(rf_op op, const uint32_t *scores, const uint64_t *indices, const uint32_t *counts,
+                            uint32_t lists, uint32_t k, uint32_t *out_score, uint64_t *out_index,
+                            uint32_t *out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFGPU_H */

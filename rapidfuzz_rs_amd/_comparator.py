@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's `BatchComparator` types and `Args` builders over the C ABI.
+
+Names, argument meaning and `None` behaviour follow rapidfuzz-rs v0.5.0
+(e.g. src/distance/levenshtein.rs:86-148 `Args`/`WeightTable`, :1636-1818 `BatchComparator`), so code and
+tests written against the reference read the same here.  Every score is computed by the HIP kernels --
+a single-candidate call is a one-candidate corpus -- and the module raises if the extension is missing.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import math
+from typing import NamedTuple, Optional
+
+import numpy as np
+
+from . import _native as N
+from .corpus import Corpus, _to_bytes
+
+
+class WeightTable(NamedTuple):
+    """src/distance/levenshtein.rs:128-148"""
+
+    insertion_cost: int = 1
+    deletion_cost: int = 1
+    substitution_cost: int = 1
+
+
+class Args:
+    """`Args::default().score_cutoff(x).score_hint(y).weights(&w).prefix_weight(p)` (levenshtein.rs:86-126,
+    jaro_winkler.rs:25-62).  Builder methods return a new object, like the Rust typestate builders."""
+
+    def __init__(self):
+        self._cutoff = None
+        self._hint = None
+        self._weights = WeightTable()
+        self._prefix_weight = 0.1
+        self._flags = 0
+
+    def _with(self, **kw) -> "Args":
+        a = copy.copy(self)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    def score_cutoff(self, v) -> "Args":
+        return self._with(_cutoff=v)
+
+    def score_hint(self, v) -> "Args":
+        return self._with(_hint=v)
+
+    def weights(self, w) -> "Args":
+        return self._with(_weights=WeightTable(*w))
+
+    def prefix_weight(self, p: float) -> "Args":
+        return self._with(_prefix_weight=float(p))
+
+    def ratio_indel_normalization(self, on: bool = True) -> "Args":
+        """RatioBatchComparator only: the documented Indel ratio instead of the fuzz.rs:141 behaviour."""
+        return self._with(_flags=N.FLAG_RATIO_INDEL_NORMALIZATION if on else 0)
+
+    def to_c(self, is_float: bool) -> N.RfArgs:
+        a = N.RfArgs()
+        N.lib().rf_args_default(C.byref(a))
+        if self._cutoff is not None:
+            if is_float:
+                a.cutoff_f64 = float(self._cutoff)
+            else:
+                a.cutoff_usize = min(int(self._cutoff), N.NO_CUTOFF - 1)
+        if self._hint is not None:
+            if is_float:
+                a.score_hint_f64 = float(self._hint)
+            else:
+                a.score_hint_usize = min(int(self._hint), N.NO_CUTOFF - 1)
+        a.insertion_cost, a.deletion_cost, a.substitution_cost = (int(x) for x in self._weights)
+        a.prefix_weight = self._prefix_weight
+        a.flags = self._flags
+        return a
+
+
+def _mk_args(args: Optional[Args], score_cutoff, score_hint, weights, prefix_weight) -> Args:
+    a = args if args is not None else Args()
+    if score_cutoff is not None:
+        a = a.score_cutoff(score_cutoff)
+    if score_hint is not None:
+        a = a.score_hint(score_hint)
+    if weights is not None:
+        a = a.weights(weights)
+    if prefix_weight is not None:
+        a = a.prefix_weight(prefix_weight)
+    return a
+
+
+def default_device() -> int:
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except Exception:
+        pass
+    return 0
+
+
+class BatchComparator:
+    """`<metric>::BatchComparator::new(s1)`: owns a copy of the query and its pattern-match table."""
+
+    METRIC = -1
+    FLOAT = False  # jaro / jaro_winkler / ratio: every method is f64-valued
+
+    def __init__(self, s1):
+        self._s1 = _to_bytes(s1)
+        h = C.c_void_p()
+        buf = (C.c_uint8 * max(1, len(self._s1))).from_buffer_copy(self._s1 or b"\0")
+        N.check(N.lib().rf_comparator_new(self.METRIC, buf, len(self._s1), C.byref(h)))
+        self._h = h.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                N.lib().rf_comparator_free(h)
+            except Exception:
+                pass
+
+    def clone(self) -> "BatchComparator":  # #[derive(Clone)]
+        return type(self)(self._s1)
+
+    def pm(self) -> np.ndarray:
+        """The cached BlockPatternMatchVector as uint64 [256, max(1, ceil(len/64))]."""
+        n = C.c_size_t()
+        p = N.lib().rf_comparator_pm(self._h, C.byref(n))
+        w = max(1, n.value)
+        return np.ctypeslib.as_array(p, shape=(256 * w,)).copy().reshape(256, w)
+
+    # ------------------------------------------------------------------ one-vs-many (the GPU path)
+    def many(self, op: int, corpus: Corpus, args: Optional[Args] = None, out=None, stream=None, *, score_cutoff=None,
+             score_hint=None, weights=None, prefix_weight=None):
+        """scores of every candidate of `corpus`, original order.  Returns a numpy array (uint32 with
+        0xFFFFFFFF = None, or float64 with NaN = None); pass a CUDA torch tensor as `out` to keep the result
+        on the device (the call is then asynchronous on `stream` / torch's current stream)."""
+        a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
+        is_f = self.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
+        ca = a.to_c(is_f)
+        n = len(corpus)
+        fn = N.lib().rf_many_f64 if is_f else N.lib().rf_many_u32
+        if out is not None and hasattr(out, "is_cuda") and out.is_cuda:
+            import torch
+
+            want = torch.float64 if is_f else (torch.uint32 if out.dtype == torch.uint32 else torch.int32)
+            assert out.dtype == want and out.numel() >= n and out.is_contiguous(), "out tensor has the wrong dtype/shape"
+            st = stream if stream is not None else torch.cuda.current_stream(out.device).cuda_stream
+            N.check(fn(self._h, corpus._h, op, C.byref(ca), out.data_ptr(), N.MEM_DEVICE, st))
+            return out
+        res = np.empty(n, dtype=np.float64 if is_f else np.uint32) if out is None else out
+        N.check(fn(self._h, corpus._h, op, C.byref(ca), res.ctypes.data, N.MEM_HOST, stream))
+        return res
+
+    def distance_many(self, corpus, args=None, **kw):
+        return self.many(N.OP_DISTANCE, corpus, args, **kw)
+
+    def similarity_many(self, corpus, args=None, **kw):
+        return self.many(N.OP_SIMILARITY, corpus, args, **kw)
+
+    def normalized_distance_many(self, corpus, args=None, **kw):
+        return self.many(N.OP_NORMALIZED_DISTANCE, corpus, args, **kw)
+
+    def normalized_similarity_many(self, corpus, args=None, **kw):
+        return self.many(N.OP_NORMALIZED_SIMILARITY, corpus, args, **kw)
+
+    def topk(self, corpus: Corpus, k: int, op: int = N.OP_DISTANCE, args: Optional[Args] = None, index_base: int = 0,
+             stream=None, **kw):
+        """(scores uint32[m], indices uint64[m]), m <= k, ordered by (score, index); see rf_topk_u32."""
+        a = _mk_args(args, kw.get("score_cutoff"), kw.get("score_hint"), kw.get("weights"), kw.get("prefix_weight"))
+        ca = a.to_c(False)
+        scores = np.empty(k, dtype=np.uint32)
+        idx = np.empty(k, dtype=np.uint64)
+        cnt = C.c_uint32()
+        N.check(N.lib().rf_topk_u32(self._h, corpus._h, op, C.byref(ca), k, index_base, scores.ctypes.data, idx.ctypes.data, C.byref(cnt), stream))
+        return scores[: cnt.value], idx[: cnt.value]
+
+    # ------------------------------------------------------------------ the reference's per-candidate methods
+    def _one(self, op: int, s2, args, kw):
+        corpus = Corpus.from_list([s2], device=default_device())
+        r = self.many(op, corpus, args, **kw)[0]
+        if r.dtype == np.uint32:
+            return None if int(r) == N.NONE_U32 else int(r)
+        return None if math.isnan(float(r)) else float(r)
+
+    def distance(self, s2, args=None, **kw):
+        return self._one(N.OP_DISTANCE, s2, args, kw)
+
+    def similarity(self, s2, args=None, **kw):
+        return self._one(N.OP_SIMILARITY, s2, args, kw)
+
+    def normalized_distance(self, s2, args=None, **kw):
+        return self._one(N.OP_NORMALIZED_DISTANCE, s2, args, kw)
+
+    def normalized_similarity(self, s2, args=None, **kw):
+        return self._one(N.OP_NORMALIZED_SIMILARITY, s2, args, kw)
+
+    # the Rust spellings
+    distance_with_args = distance
+    similarity_with_args = similarity
+    normalized_distance_with_args = normalized_distance
+    normalized_similarity_with_args = normalized_similarity
+
+
+class MetricModule:
+    """One `rapidfuzz::distance::<metric>` module: `Args`, `BatchComparator` and the free functions.
+    The free functions evaluate `BatchComparator(s1).<op>(s2)` on the device: in the reference both forms
+    return the same value (its tests assert exactly that, levenshtein.rs:1847-1875)."""
+
+    def __init__(self, name: str, metric: int, is_float: bool):
+        self.__name__ = name
+        self.Args = Args
+        self.WeightTable = WeightTable
+        self.BatchComparator = type("BatchComparator", (BatchComparator,), {"METRIC": metric, "FLOAT": is_float, "__doc__": BatchComparator.__doc__})
+
+    def distance(self, s1, s2, args=None, **kw):
+        return self.BatchComparator(s1).distance(s2, args, **kw)
+
+    def similarity(self, s1, s2, args=None, **kw):
+        return self.BatchComparator(s1).similarity(s2, args, **kw)
+
+    def normalized_distance(self, s1, s2, args=None, **kw):
+        return self.BatchComparator(s1).normalized_distance(s2, args, **kw)
+
+    def normalized_similarity(self, s1, s2, args=None, **kw):
+        return self.BatchComparator(s1).normalized_similarity(s2, args, **kw)
+
+    distance_with_args = distance
+    similarity_with_args = similarity
+    normalized_distance_with_args = normalized_distance
+    normalized_similarity_with_args = normalized_similarity

@@ -1,0 +1,582 @@
+// rf_api.hip -- host side of the C ABI declared in include/rfgpu.h.
+//
+// What runs on the host here is what the reference's host would do around the kernels: copy the query and
+// build its BlockPatternMatchVector (src/details/pattern_match_vector.rs:203-224), bucket the candidates by
+// length and lay them out for the wavefronts, translate `Args` (levenshtein.rs:1285-1331 weight dispatch)
+// into kernel parameters.  No metric is ever evaluated on the host: a shape without a device kernel is
+// RF_ERR_UNSUPPORTED.  Product code: never includes or links anything from oracle/.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "rf_internal.hpp"
+
+namespace rf {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+#define RF_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                              \
+            return _e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;                                \
+        }                                                                                              \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace rf
+
+using namespace rf;
+
+struct rf_comparator {
+    rf_metric metric;
+    std::vector<uint8_t> s1;
+    std::vector<uint64_t> pm;  // 256 x words, row-major [c * words + w]; words = max(1, block_count)
+    size_t block_count = 0;
+    size_t words = 1;
+    mutable std::mutex mu;
+    mutable std::map<int, uint64_t*> d_pm;  // lazily uploaded per device
+};
+
+struct rf_corpus {
+    int device = 0;
+    size_t n = 0;
+    uint64_t payload_bytes = 0;
+    uint64_t device_bytes = 0;
+    uint8_t* d_data = nullptr;
+    TileDesc* d_tiles = nullptr;
+    uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
+    uint32_t n_tiles = 0;
+    uint32_t max_len = 0;
+    bool uniform = false;        // single length bucket: no descriptors, tile t at t * tile_bytes(uniform_len)
+    uint32_t uniform_len = 0;
+};
+
+extern "C" {
+
+const char* rf_last_error(void) { return g_last_error.c_str(); }
+
+int rf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rf_args_default(rf_args* a)
+{
+    if (!a) return;
+    std::memset(a, 0, sizeof(*a));
+    a->cutoff_usize = RF_NO_CUTOFF;
+    a->score_hint_usize = RF_NO_CUTOFF;
+    a->cutoff_f64 = std::nan("");
+    a->score_hint_f64 = std::nan("");
+    a->insertion_cost = a->deletion_cost = a->substitution_cost = 1;  // WeightTable::default(), levenshtein.rs:139-148
+    a->prefix_weight = 0.1;                                           // jaro_winkler.rs:36
+}
+
+// ---------------------------------------------------------------------------------------------------
+// comparator
+// ---------------------------------------------------------------------------------------------------
+rf_status rf_comparator_new(rf_metric metric, const uint8_t* s1, size_t len1, rf_comparator** out)
+{
+    if (!out || (len1 && !s1) || (int)metric < 0 || (int)metric > (int)RF_FUZZ_RATIO) {
+        set_error("rf_comparator_new: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    rf_comparator* c = new (std::nothrow) rf_comparator();
+    if (!c) return RF_ERR_OOM;
+    c->metric = metric;
+    c->s1.assign(s1, s1 + len1);
+    // BlockPatternMatchVector::new + insert (pattern_match_vector.rs:203-224): block = i / 64, the mask
+    // rotates left once per position; u8 keys land in extended_ascii[c][block] (:262-265).
+    c->block_count = (len1 + 63) / 64;
+    c->words = std::max<size_t>(1, c->block_count);
+    c->pm.assign(256 * c->words, 0);
+    uint64_t mask = 1;
+    for (size_t i = 0; i < len1; ++i) {
+        c->pm[(size_t)s1[i] * c->words + i / 64] |= mask;
+        mask = (mask << 1) | (mask >> 63);
+    }
+    *out = c;
+    return RF_OK;
+}
+
+rf_status rf_comparator_clone(const rf_comparator* c, rf_comparator** out)
+{
+    if (!c || !out) return RF_ERR_INVALID_ARG;
+    return rf_comparator_new(c->metric, c->s1.data(), c->s1.size(), out);
+}
+
+void rf_comparator_free(rf_comparator* c)
+{
+    if (!c) return;
+    for (auto& kv : c->d_pm) {
+        DeviceGuard g(kv.first);
+        (void)hipFree(kv.second);
+    }
+    delete c;
+}
+
+rf_metric rf_comparator_metric(const rf_comparator* c) { return c->metric; }
+size_t rf_comparator_query_len(const rf_comparator* c) { return c->s1.size(); }
+const uint64_t* rf_comparator_pm(const rf_comparator* c, size_t* block_count)
+{
+    if (block_count) *block_count = c->block_count;
+    return c->pm.data();
+}
+
+static rf_status comparator_device_pm(const rf_comparator* c, int device, const uint64_t** d_out)
+{
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->d_pm.find(device);
+    if (it != c->d_pm.end()) {
+        *d_out = it->second;
+        return RF_OK;
+    }
+    uint64_t* d = nullptr;
+    RF_HIP(hipMalloc(&d, c->pm.size() * sizeof(uint64_t)));
+    RF_HIP(hipMemcpy(d, c->pm.data(), c->pm.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    c->d_pm[device] = d;
+    *d_out = d;
+    return RF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// corpus
+// ---------------------------------------------------------------------------------------------------
+constexpr size_t kTailPad = (size_t)kWave * kChunk;  // one readable chunk row past the last tile
+static inline uint64_t tile_bytes(uint32_t len) { return (uint64_t)((len + kChunk - 1) / kChunk) * kWave * kChunk; }
+
+// Host-side layout of a ragged candidate set (no device needed): the exact bytes rf_corpus_pack uploads.
+struct HostLayout {
+    std::vector<uint8_t> packed;   // tile payloads + one chunk row of tail padding
+    std::vector<TileDesc> tiles;   // ascending length, every length padded to whole tiles
+    std::vector<uint32_t> orig;    // slot -> original index (kPad = padding lane); empty when identity
+    uint64_t payload = 0;
+    uint32_t max_len = 0;
+    bool identity = true;          // a single length bucket: slot i is candidate i
+};
+
+static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, size_t n, HostLayout* L)
+{
+    if ((n && !offsets) || n >= 0xFFFFFFFFull) {
+        set_error("rf_corpus_pack: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    // 1. length histogram
+    uint32_t max_len = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0xFFFFFFF0ull) {
+            set_error("rf_corpus_pack: offsets must be non-decreasing and candidates shorter than 4 GiB");
+            return RF_ERR_INVALID_ARG;
+        }
+        max_len = std::max<uint32_t>(max_len, (uint32_t)(offsets[i + 1] - offsets[i]));
+    }
+    std::vector<uint64_t> count((size_t)max_len + 1, 0);
+    for (size_t i = 0; i < n; ++i) count[offsets[i + 1] - offsets[i]]++;
+
+    // 2. one group of tiles per distinct length, ascending; every group is padded to whole tiles
+    std::vector<uint64_t> group_slot((size_t)max_len + 1, 0), group_off((size_t)max_len + 1, 0);
+    uint64_t slots = 0, data_bytes = 0;
+    size_t distinct = 0;
+    for (uint32_t len = 0; len <= max_len && n; ++len) {
+        if (!count[len]) continue;
+        ++distinct;
+        group_slot[len] = slots;
+        group_off[len] = data_bytes;
+        const uint64_t nt = (count[len] + kWave - 1) / kWave;
+        for (uint64_t t = 0; t < nt; ++t) {
+            L->tiles.push_back(TileDesc{data_bytes, len, (uint32_t)slots});
+            slots += kWave;
+            data_bytes += tile_bytes(len);
+        }
+    }
+    if (slots >= 0xFFFFFFFFull) {
+        set_error("rf_corpus_pack: too many candidates for one corpus");
+        return RF_ERR_INVALID_ARG;
+    }
+    L->identity = distinct <= 1;
+    L->max_len = max_len;
+
+    // 3. scatter the candidates into the chunk-interleaved tiles (+ kTailPad readable bytes at the end: the
+    //    scan kernel prefetches one chunk row ahead, also across the last tile)
+    L->packed.assign(data_bytes + kTailPad, 0);
+    if (!L->identity) L->orig.assign(slots, kPad);
+    std::vector<uint64_t> cursor((size_t)max_len + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+        const uint64_t k = cursor[len]++;  // k-th candidate of this length, original order preserved
+        if (!L->identity) L->orig[group_slot[len] + k] = (uint32_t)i;
+        const uint64_t tile = k / kWave, lane = k % kWave;
+        uint8_t* dst = L->packed.data() + group_off[len] + tile * tile_bytes(len) + lane * kChunk;
+        const uint8_t* src = bytes + offsets[i];
+        for (uint32_t b = 0; b < len; b += kChunk)
+            std::memcpy(dst + (uint64_t)(b / kChunk) * kWave * kChunk, src + b, std::min<uint32_t>(kChunk, len - b));
+        L->payload += len;
+    }
+    return RF_OK;
+}
+
+rf_status rf_corpus_layout_host(const uint8_t* bytes, const uint64_t* offsets, size_t n, rf_host_layout* out)
+{
+    if (!out) return RF_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    HostLayout L;
+    rf_status s = build_layout(bytes, offsets, n, &L);
+    if (s != RF_OK) return s;
+    out->n_tiles = (uint32_t)L.tiles.size();
+    out->packed_bytes = L.packed.size();
+    out->n_slots = L.identity ? 0 : L.orig.size();
+    out->identity = L.identity ? 1 : 0;
+    out->packed = (uint8_t*)std::malloc(std::max<size_t>(1, L.packed.size()));
+    out->tile_off = (uint64_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint64_t));
+    out->tile_len = (uint32_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint32_t));
+    out->tile_slot0 = (uint32_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint32_t));
+    out->orig = (uint32_t*)std::malloc(std::max<size_t>(1, L.orig.size()) * sizeof(uint32_t));
+    if (!out->packed || !out->tile_off || !out->tile_len || !out->tile_slot0 || !out->orig) {
+        rf_host_layout_free(out);
+        return RF_ERR_OOM;
+    }
+    std::memcpy(out->packed, L.packed.data(), L.packed.size());
+    for (size_t t = 0; t < L.tiles.size(); ++t) {
+        out->tile_off[t] = L.tiles[t].data_off;
+        out->tile_len[t] = L.tiles[t].len;
+        out->tile_slot0[t] = L.tiles[t].slot0;
+    }
+    if (!L.orig.empty()) std::memcpy(out->orig, L.orig.data(), L.orig.size() * sizeof(uint32_t));
+    return RF_OK;
+}
+
+void rf_host_layout_free(rf_host_layout* l)
+{
+    if (!l) return;
+    std::free(l->packed);
+    std::free(l->tile_off);
+    std::free(l->tile_len);
+    std::free(l->tile_slot0);
+    std::free(l->orig);
+    std::memset(l, 0, sizeof(*l));
+}
+
+#define RF_HIP_C(expr)                                                                                 \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                              \
+            return fail(_e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP);                          \
+        }                                                                                              \
+    } while (0)
+
+rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n, int device, rf_corpus** out)
+{
+    if (!out) {
+        set_error("rf_corpus_pack: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    HostLayout L;
+    rf_status s = build_layout(bytes, offsets, n, &L);
+    if (s != RF_OK) return s;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("rf_corpus_pack: cannot select device");
+        return RF_ERR_NO_DEVICE;
+    }
+    rf_corpus* c = new (std::nothrow) rf_corpus();
+    if (!c) return RF_ERR_OOM;
+    c->device = device;
+    c->n = n;
+    c->payload_bytes = L.payload;
+    c->n_tiles = (uint32_t)L.tiles.size();
+    c->max_len = L.max_len;
+    auto fail = [&](rf_status st) {
+        rf_corpus_free(c);
+        return st;
+    };
+    RF_HIP_C(hipMalloc(&c->d_data, L.packed.size()));
+    RF_HIP_C(hipMemcpy(c->d_data, L.packed.data(), L.packed.size(), hipMemcpyHostToDevice));
+    c->device_bytes = L.packed.size();
+    if (L.identity) {  // one length bucket in original order: tiles are addressed arithmetically
+        c->uniform = true;
+        c->uniform_len = L.max_len;
+    } else {
+        RF_HIP_C(hipMalloc(&c->d_tiles, L.tiles.size() * sizeof(TileDesc)));
+        RF_HIP_C(hipMemcpy(c->d_tiles, L.tiles.data(), L.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        RF_HIP_C(hipMalloc(&c->d_orig, L.orig.size() * sizeof(uint32_t)));
+        RF_HIP_C(hipMemcpy(c->d_orig, L.orig.data(), L.orig.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->device_bytes += L.tiles.size() * sizeof(TileDesc) + L.orig.size() * sizeof(uint32_t);
+    }
+    *out = c;
+    return RF_OK;
+}
+
+rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, size_t stride, int device, void* stream,
+                                     rf_corpus** out)
+{
+    if (!out || (n && len && !d_rows) || n >= 0xFFFFFFFFull - kWave || len > 0xFFFFFFF0ull || stride < len) {
+        set_error("rf_corpus_pack_rows_device: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("rf_corpus_pack_rows_device: cannot select device");
+        return RF_ERR_NO_DEVICE;
+    }
+    rf_corpus* c = new (std::nothrow) rf_corpus();
+    if (!c) return RF_ERR_OOM;
+    c->device = device;
+    c->n = n;
+    c->payload_bytes = (uint64_t)n * len;
+    c->max_len = (uint32_t)len;
+    c->n_tiles = (uint32_t)((n + kWave - 1) / kWave);
+    auto fail = [&](rf_status s) {
+        rf_corpus_free(c);
+        return s;
+    };
+    const uint64_t tb = tile_bytes((uint32_t)len);
+    const uint64_t data_bytes = tb * c->n_tiles;
+    if (tb > 0xFFFFFFFFull) {
+        set_error("rf_corpus_pack_rows_device: rows too long");
+        return fail(RF_ERR_INVALID_ARG);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    c->uniform = true;
+    c->uniform_len = (uint32_t)len;
+    RF_HIP_C(hipMalloc(&c->d_data, data_bytes + kTailPad));
+    RF_HIP_C(hipMemsetAsync(c->d_data + data_bytes, 0, kTailPad, st));
+    if (data_bytes) RF_HIP_C(launch_pack_rows((const uint8_t*)d_rows, n, (uint32_t)len, stride, c->d_data, c->n_tiles, st));
+    RF_HIP_C(hipStreamSynchronize(st));  // the input is only borrowed for the duration of the call
+    c->device_bytes = data_bytes + kTailPad;
+    *out = c;
+    return RF_OK;
+}
+
+void rf_corpus_free(rf_corpus* c)
+{
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    if (c->d_data) (void)hipFree(c->d_data);
+    if (c->d_tiles) (void)hipFree(c->d_tiles);
+    if (c->d_orig) (void)hipFree(c->d_orig);
+    delete c;
+}
+
+size_t rf_corpus_count(const rf_corpus* c) { return c->n; }
+uint64_t rf_corpus_payload_bytes(const rf_corpus* c) { return c->payload_bytes; }
+uint64_t rf_corpus_device_bytes(const rf_corpus* c) { return c->device_bytes; }
+int rf_corpus_device(const rf_corpus* c) { return c->device; }
+
+// ---------------------------------------------------------------------------------------------------
+// one-vs-many
+// ---------------------------------------------------------------------------------------------------
+static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, bool f64_out,
+                      ScanParams* p, RawKind* raw)
+{
+    if (!c || !corpus || !args) {
+        set_error("null handle or args");
+        return RF_ERR_INVALID_ARG;
+    }
+    std::memset(p, 0, sizeof(*p));
+    p->len1 = (uint32_t)c->s1.size();
+    p->words = (uint32_t)c->words;
+    p->op = (uint32_t)op;
+    p->out_f64 = f64_out ? 1 : 0;
+    p->factor = 1;
+    p->w_ins = p->w_del = p->w_sub = 1;
+    p->prefix_weight = args->prefix_weight;
+    p->data = corpus->d_data;
+    p->tiles = corpus->uniform ? nullptr : corpus->d_tiles;
+    p->uniform_len = corpus->uniform_len;
+    p->uniform_tile_bytes = (uint32_t)tile_bytes(corpus->uniform_len);
+    p->orig = corpus->d_orig;
+    p->n_tiles = corpus->n_tiles;
+    p->n = (uint32_t)corpus->n;
+
+    const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ;
+    const bool norm_op = op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY;
+    if ((int)op < 0 || (int)op > (int)RF_OP_NORMALIZED_SIMILARITY) {
+        set_error("unknown rf_op");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (usize_metric && (norm_op != f64_out)) {
+        set_error("levenshtein/indel/lcs_seq: distance and similarity are u32-valued (rf_many_u32), normalized_* are "
+                  "f64-valued (rf_many_f64)");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (!usize_metric && !f64_out) {
+        set_error("jaro / jaro_winkler / fuzz ratio are f64-valued: use rf_many_f64");
+        return RF_ERR_INVALID_ARG;
+    }
+
+    if (f64_out) {
+        p->has_cutoff = std::isnan(args->cutoff_f64) ? 0 : 1;
+        p->cutoff_f64 = args->cutoff_f64;
+    } else {
+        p->has_cutoff = args->cutoff_usize != RF_NO_CUTOFF;
+        p->cutoff_u32 = (uint32_t)std::min<uint64_t>(args->cutoff_usize, 0xFFFFFFFFull);
+    }
+
+    switch (c->metric) {
+    case RF_LEVENSHTEIN: {
+        // _distance_with_pm weight dispatch, levenshtein.rs:1285-1331
+        const uint64_t ins = args->insertion_cost, del = args->deletion_cost, sub = args->substitution_cost;
+        if (ins > 0xFFFF || del > 0xFFFF || sub > 0xFFFF) {
+            set_error("levenshtein weights above 65535 are not supported on the device");
+            return RF_ERR_UNSUPPORTED;
+        }
+        p->w_ins = (uint32_t)ins;
+        p->w_del = (uint32_t)del;
+        p->w_sub = (uint32_t)sub;
+        if (ins == del && (ins == 0 || ins == sub)) {  // :1303-1316 (ins == del == 0 -> every distance is 0)
+            *raw = RAW_LEV;
+            p->finish = FIN_LEV;
+            p->factor = (uint32_t)ins;
+        } else if (ins == del && sub >= ins + del) {  // :1321-1327: Indel distance times the common factor
+            *raw = RAW_LCS;
+            p->finish = FIN_LEV_INDEL;
+            p->factor = (uint32_t)ins;
+        } else {
+            set_error("levenshtein: this weight table needs the generalized Wagner-Fischer path "
+                      "(levenshtein.rs:212-259), which has no device kernel");
+            return RF_ERR_UNSUPPORTED;
+        }
+        break;
+    }
+    case RF_INDEL:
+        *raw = RAW_LCS;
+        p->finish = FIN_INDEL;
+        break;
+    case RF_LCS_SEQ:
+        *raw = RAW_LCS;
+        p->finish = FIN_LCS;
+        break;
+    case RF_FUZZ_RATIO:
+        // RatioBatchComparator::similarity_with_args, fuzz.rs:127-149: normalized similarity of the inner
+        // lcs_seq comparator (quirk Q1), or of Indel when the caller asks for the documented ratio.
+        if (op != RF_OP_SIMILARITY && op != RF_OP_NORMALIZED_SIMILARITY) {
+            set_error("RatioBatchComparator only has similarity (fuzz.rs:115-149)");
+            return RF_ERR_INVALID_ARG;
+        }
+        *raw = RAW_LCS;
+        p->finish = (args->flags & RF_FLAG_RATIO_INDEL_NORMALIZATION) ? FIN_INDEL : FIN_LCS;
+        p->op = RF_OP_NORMALIZED_SIMILARITY;
+        break;
+    case RF_JARO:
+    case RF_JARO_WINKLER:
+        *raw = RAW_JARO;
+        p->finish = c->metric == RF_JARO ? FIN_JARO : FIN_JW;
+        break;
+    }
+
+    if (c->words > (size_t)kMaxWords) {
+        set_error("query longer than 512 symbols: no register-resident kernel (RF_ERR_UNSUPPORTED)");
+        return RF_ERR_UNSUPPORTED;
+    }
+    return RF_OK;
+}
+
+static rf_status run_many(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, void* out,
+                          rf_mem out_mem, void* stream, bool f64_out)
+{
+    ScanParams p;
+    RawKind raw = RAW_LEV;
+    rf_status s = plan(c, corpus, op, args, f64_out, &p, &raw);
+    if (s != RF_OK) return s;
+    if (corpus->n == 0) return RF_OK;
+    if (!out) {
+        set_error("null output");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    s = comparator_device_pm(c, corpus->device, &p.pm);
+    if (s != RF_OK) return s;
+
+    hipStream_t st = (hipStream_t)stream;
+    const size_t out_bytes = corpus->n * (f64_out ? sizeof(double) : sizeof(uint32_t));
+    void* d_out = out;
+    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
+    p.out = d_out;
+    hipError_t e = launch_scan(raw, p, st, nullptr);
+    if (e == hipSuccess && out_mem == RF_MEM_HOST) {
+        e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+    if (e != hipSuccess) {
+        set_error(std::string("scan launch: ") + hipGetErrorString(e));
+        return e == hipErrorInvalidValue ? RF_ERR_UNSUPPORTED : RF_ERR_HIP;
+    }
+    return RF_OK;
+}
+
+rf_status rf_many_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t* out,
+                      rf_mem out_mem, void* stream)
+{
+    return run_many(c, corpus, op, args, out, out_mem, stream, false);
+}
+
+rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, double* out,
+                      rf_mem out_mem, void* stream)
+{
+    return run_many(c, corpus, op, args, out, out_mem, stream, true);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// top-k
+// ---------------------------------------------------------------------------------------------------
+rf_status rf_topk_u32(const rf_comparator*, const rf_corpus*, rf_op, const rf_args*, uint32_t, uint64_t, uint32_t*,
+                      uint64_t*, uint32_t*, void*)
+{
+    set_error("rf_topk_u32: not implemented yet");
+    return RF_ERR_UNSUPPORTED;
+}
+
+rf_status rf_topk_merge_u32(rf_op op, const uint32_t* scores, const uint64_t* indices, const uint32_t* counts,
+                            uint32_t lists, uint32_t k, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count)
+{
+    if (!scores || !indices || !counts || !out_score || !out_index || !out_count) return RF_ERR_INVALID_ARG;
+    struct E {
+        uint32_t s;
+        uint64_t i;
+    };
+    std::vector<E> all;
+    for (uint32_t l = 0; l < lists; ++l)
+        for (uint32_t j = 0; j < std::min(counts[l], k); ++j) all.push_back(E{scores[(size_t)l * k + j], indices[(size_t)l * k + j]});
+    const bool desc = op == RF_OP_SIMILARITY;
+    std::sort(all.begin(), all.end(), [desc](const E& a, const E& b) {
+        if (a.s != b.s) return desc ? a.s > b.s : a.s < b.s;
+        return a.i < b.i;
+    });
+    const uint32_t m = (uint32_t)std::min<size_t>(all.size(), k);
+    for (uint32_t j = 0; j < m; ++j) {
+        out_score[j] = all[j].s;
+        out_index[j] = all[j].i;
+    }
+    *out_count = m;
+    return RF_OK;
+}
+
+}  // extern "C"

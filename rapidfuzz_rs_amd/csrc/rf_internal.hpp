@@ -1,0 +1,82 @@
+// rf_internal.hpp -- shared between the host side of the C ABI (rf_api.hip) and the gfx950 kernels
+// (rf_kernels.hip).  Product code: never includes or links anything from oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/rfgpu.h"
+
+namespace rf {
+
+constexpr int kWave = 64;          // CDNA4 wavefront: one candidate per lane
+constexpr int kChunk = 16;         // bytes per lane per global_load_dwordx4
+constexpr int kWavesPerBlock = 4;  // 256-thread workgroups, one wave per SIMD
+constexpr int kMaxWords = 8;       // query <= 512 symbols keeps VP/VN register-resident
+constexpr uint32_t kPad = 0xFFFFFFFFu;
+
+// One tile = 64 candidates of identical length `len`, stored chunk-interleaved:
+// byte b of lane r lives at data_off + ((b / 16) * 64 + r) * 16 + (b % 16).
+struct TileDesc {
+    uint64_t data_off;  // byte offset of the tile payload in the packed buffer
+    uint32_t len;       // candidate length (same for every lane of the tile)
+    uint32_t slot0;     // index of lane 0 in the slot arrays (orig[])
+};
+
+enum RawKind : uint32_t {
+    RAW_LEV = 0,   // uniform Levenshtein distance (Myers/Hyyro)
+    RAW_LCS = 1,   // LCS length (Hyyro)
+    RAW_JARO = 2   // Jaro flags + transpositions
+};
+
+// how the raw per-candidate primitive becomes the reference's return value
+enum Finish : uint32_t {
+    FIN_LEV = 0,    // dist = d * factor,             maximum = lev _maximum(len1, len2, weights)
+    FIN_LCS = 1,    // dist = max(len1,len2) - l,     maximum = max(len1, len2)
+    FIN_INDEL = 2,  // dist = len1+len2 - 2l,         maximum = len1 + len2
+    FIN_JARO = 3,
+    FIN_JW = 4,
+    FIN_LEV_INDEL = 5  // levenshtein with weights (f, f, >= 2f): dist = (len1+len2-2l)*f, maximum = lev _maximum
+};
+
+struct ScanParams {
+    const uint8_t* data;
+    const TileDesc* tiles;  // nullptr: every tile has length uniform_len and sits at t * uniform_tile_bytes
+    const uint32_t* orig;  // slot -> original index (kPad for padding lanes); nullptr = identity
+    const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w]
+    void* out;             // uint32_t* or double*
+    uint32_t n_tiles;
+    uint32_t n;            // number of real candidates
+    uint32_t uniform_len;
+    uint32_t uniform_tile_bytes;
+    uint32_t len1;
+    uint32_t words;
+    uint32_t finish;       // Finish
+    uint32_t op;           // rf_op
+    uint32_t out_f64;      // 1: out is double*, 0: uint32_t*
+    uint32_t has_cutoff;
+    uint32_t cutoff_u32;   // usize cutoff clipped to u32 (valid when has_cutoff and !out_f64)
+    uint32_t factor;       // common weight factor (levenshtein.rs:1307-1327)
+    uint32_t w_ins, w_del, w_sub;  // for _maximum (levenshtein.rs:263-277)
+    double cutoff_f64;
+    double prefix_weight;
+    // top-k mode (out == nullptr): per-block candidate lists
+    uint32_t topk_k;
+    uint32_t topk_desc;    // 1: larger score is better (similarity)
+    uint64_t index_base;
+    uint32_t* topk_scores; // [grid][k]
+    uint64_t* topk_index;  // [grid][k]
+    uint32_t* topk_counts; // [grid]
+};
+
+// kernels (rf_kernels.hip)
+hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
+hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,
+                            uint32_t n_tiles, hipStream_t stream);
+int scan_max_grid();
+
+void set_error(const std::string& msg);
+
+}  // namespace rf

@@ -1,0 +1,125 @@
+"""CPU-side checks of the product library (no GPU, no compute): the C-ABI library loads, exports every
+symbol include/rfgpu.h declares, builds the same pattern-match table as the oracle, and its host-side
+corpus layout round-trips."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rapidfuzz_rs_amd as rf
+from rapidfuzz_rs_amd import _native as N
+from rapidfuzz_rs_amd.utils import synth
+from oracle import oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rfgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    L = N.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under rapidfuzz_rs_amd/ may import, include or link it."""
+    pkg = os.path.join(ROOT, "rapidfuzz_rs_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="replace").read()
+                code = "\n".join(l for l in txt.splitlines() if not l.strip().startswith(("//", "#", "*", "/*", '"""')))
+                assert "rf_oracle" not in code and "librf_oracle" not in code and "import oracle" not in code and "from oracle" not in code, f
+    import subprocess
+
+    needed = subprocess.run(["readelf", "-d", N.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
+
+
+def test_args_default_matches_reference_defaults():
+    a = N.RfArgs()
+    N.lib().rf_args_default(C.byref(a))
+    assert a.cutoff_usize == N.NO_CUTOFF and np.isnan(a.cutoff_f64)
+    assert (a.insertion_cost, a.deletion_cost, a.substitution_cost) == (1, 1, 1)  # levenshtein.rs:139-148
+    assert a.prefix_weight == 0.1  # jaro_winkler.rs:36
+
+
+@pytest.mark.parametrize("qlen", [0, 1, 5, 63, 64, 65, 128, 150, 256, 513])
+def test_pm_table_equals_oracle(qlen):
+    q = bytes((i * 37 + 11) % 256 for i in range(qlen))
+    pm = rf.distance.levenshtein.BatchComparator(q).pm()
+    ref = o.levenshtein.BatchComparator(q).pm()
+    assert pm.shape == ref.shape and (pm == ref).all()
+
+
+def test_comparator_clone_and_accessors():
+    bc = rf.distance.jaro.BatchComparator(b"hello")
+    cl = bc.clone()
+    assert (bc.pm() == cl.pm()).all()
+    assert N.lib().rf_comparator_query_len(cl._h) == 5
+    assert N.lib().rf_comparator_metric(cl._h) == N.JARO
+
+
+def _unpack(lay, n):
+    """Invert the chunk-interleaved layout: returns the list of candidates in ORIGINAL order."""
+    out = [None] * n
+    packed = lay["packed"]
+    for t in range(len(lay["tile_len"])):
+        ln, off, slot0 = int(lay["tile_len"][t]), int(lay["tile_off"][t]), int(lay["tile_slot0"][t])
+        for lane in range(64):
+            idx = slot0 + lane if lay["identity"] else int(lay["orig"][slot0 + lane])
+            if lay["identity"] and idx >= n:
+                continue
+            if idx == 0xFFFFFFFF:
+                continue
+            b = bytearray()
+            for k in range((ln + 15) // 16):
+                base = off + (k * 64 + lane) * 16
+                b += bytes(packed[base : base + min(16, ln - 16 * k)])
+            assert out[idx] is None
+            out[idx] = bytes(b)
+    return out
+
+
+@pytest.mark.parametrize("n,max_len", [(0, 0), (1, 0), (1, 5), (200, 0), (300, 40), (1000, 70), (130, 300)])
+def test_host_layout_roundtrip(n, max_len):
+    data, offsets = synth.ragged_host(n, max_len, seed=n * 31 + max_len)
+    lay = rf.host_layout(data, offsets)
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(n)]
+    assert _unpack(lay, n) == cands
+    lens = lay["tile_len"]
+    assert (np.diff(lens.astype(np.int64)) >= 0).all()  # length buckets ascend
+    assert len(lay["packed"]) == (int(lay["tile_off"][-1]) + ((int(lens[-1]) + 15) // 16) * 1024 if len(lens) else 0) + 1024
+
+
+def test_host_layout_single_length_is_identity():
+    rows = synth.rows_host(150, 64, seed=5)
+    lay = rf.host_layout(rows.reshape(-1), np.arange(151, dtype=np.uint64) * 64)
+    assert lay["identity"] and len(lay["orig"]) == 0 and list(lay["tile_len"]) == [64, 64, 64]
+    assert _unpack(lay, 150) == [bytes(r) for r in rows]
+
+
+def test_no_device_fails_loudly_not_silently():
+    """Without a GPU the scoring entry points must raise -- there is no CPU fallback in the product."""
+    if N.lib().rf_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(rf.RfError):
+        rf.Corpus.from_list([b"abc"])
+    with pytest.raises(rf.RfError):
+        rf.distance.levenshtein.distance(b"kitten", b"sitting")
+
+
+def test_topk_merge_orders_by_score_then_index():
+    k = 3
+    scores = np.array([1, 4, 9, 1, 2, 7], dtype=np.uint32)
+    idx = np.array([50, 3, 8, 7, 99, 1], dtype=np.uint64)
+    counts = np.array([3, 3], dtype=np.uint32)
+    os_, oi = np.zeros(k, np.uint32), np.zeros(k, np.uint64)
+    cnt = C.c_uint32()
+    N.check(N.lib().rf_topk_merge_u32(N.OP_DISTANCE, scores.ctypes.data, idx.ctypes.data, counts.ctypes.data, 2, k, os_.ctypes.data, oi.ctypes.data, C.byref(cnt)))
+    assert cnt.value == 3 and list(os_) == [1, 1, 2] and list(oi) == [7, 50, 99]

@@ -1,0 +1,259 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Bit-exact for the integer metrics (u32 scores and None positions).
+
+Nothing here reads /root/reference: inputs are synthetic (seeded) or the committed golden fixtures.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rapidfuzz_rs_amd as rf
+from rapidfuzz_rs_amd import _native as N
+from rapidfuzz_rs_amd.utils import synth
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+NONE32 = np.uint32(0xFFFFFFFF)
+U64MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+AB = np.frombuffer(b"ab", dtype=np.uint8)
+ABCD = np.frombuffer(b"abcd", dtype=np.uint8)
+
+GPU = {"levenshtein": rf.distance.levenshtein, "indel": rf.distance.indel, "lcs_seq": rf.distance.lcs_seq}
+ORA = {"levenshtein": o.levenshtein, "indel": o.indel, "lcs_seq": o.lcs_seq}
+OPS = {"distance": N.OP_DISTANCE, "similarity": N.OP_SIMILARITY, "normalized_distance": N.OP_NORMALIZED_DISTANCE, "normalized_similarity": N.OP_NORMALIZED_SIMILARITY}
+
+
+def _expect_u32(ora_out):
+    return np.where(ora_out == U64MAX, NONE32, ora_out.astype(np.uint32))
+
+
+def _check_many(metric, q, data, offsets, op, **kw):
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    got = GPU[metric].BatchComparator(q).many(OPS[op], corpus, **kw)
+    exp = ORA[metric].BatchComparator(q).many(OPS[op], data, offsets, nthreads=8, **kw)
+    if got.dtype == np.uint32:
+        exp = _expect_u32(exp)
+        bad = np.nonzero(got != exp)[0]
+    else:
+        bad = np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
+    assert len(bad) == 0, (metric, op, kw, len(q), bad[:5], got[bad[:5]], exp[bad[:5]])
+    return got
+
+
+def test_extension_is_loaded_and_device_present():
+    assert N.lib().rf_device_count() >= 1
+    import torch
+
+    assert torch.cuda.is_available()
+
+
+# ---------------------------------------------------------------- config 1 of BASELINE.json
+def test_c1_levenshtein_query32_vs_10k_len_le_64():
+    q = synth.query(32, 0xC0FFEE01)
+    data, offsets = synth.ragged_host(10_000, 64, seed=0xC0FFEE01)
+    d = _check_many("levenshtein", q, data, offsets, "distance")
+    assert d.min() >= 0 and d.max() <= 64
+    for op in ("similarity", "normalized_distance", "normalized_similarity"):
+        _check_many("levenshtein", q, data, offsets, op)
+    for k in (0, 1, 3, 4, 20, 28, 32, 64, 1000, 2**40):
+        _check_many("levenshtein", q, data, offsets, "distance", score_cutoff=k)
+        _check_many("levenshtein", q, data, offsets, "similarity", score_cutoff=min(k, 64))
+    for c in (0.0, 0.2, 0.5, 0.75, 1.0):
+        _check_many("levenshtein", q, data, offsets, "normalized_distance", score_cutoff=c)
+        _check_many("levenshtein", q, data, offsets, "normalized_similarity", score_cutoff=c)
+
+
+# ---------------------------------------------------------------- every word count, ragged lengths, all three metrics
+@pytest.mark.parametrize("qlen", [0, 1, 2, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 256, 300, 449, 512])
+@pytest.mark.parametrize("metric", ["levenshtein", "indel", "lcs_seq"])
+def test_query_lengths_ragged(metric, qlen):
+    rng = np.random.default_rng(qlen * 7 + len(metric))
+    alpha = ABCD if qlen % 2 else synth.ALNUM
+    q = alpha[rng.integers(0, len(alpha), size=qlen)].tobytes()
+    data, offsets = synth.ragged_host(3000, max(80, min(2 * qlen, 600)), seed=qlen + 1, alphabet=alpha)
+    # plant some near-duplicates of the query so small distances / large LCS occur
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+    for i in range(0, len(cands), 50):
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 6))):
+            if len(b):
+                b[int(rng.integers(0, len(b)))] = int(alpha[int(rng.integers(0, len(alpha)))])
+        cands[i] = bytes(b[: int(rng.integers(0, len(b) + 1))]) if i % 100 else bytes(b)
+    data, offsets = rf.ragged(cands)
+    _check_many(metric, q, data, offsets, "distance")
+    _check_many(metric, q, data, offsets, "similarity")
+    _check_many(metric, q, data, offsets, "normalized_similarity")
+    for k in (0, 2, 5, qlen // 2 + 1):
+        _check_many(metric, q, data, offsets, "distance", score_cutoff=k)
+        _check_many(metric, q, data, offsets, "similarity", score_cutoff=k)
+
+
+def test_query_longer_than_512_is_refused_not_computed_elsewhere():
+    corpus = rf.Corpus.from_list([b"abc", b"abcd"])
+    with pytest.raises(rf.RfError) as e:
+        rf.distance.levenshtein.BatchComparator(b"a" * 513).distance_many(corpus)
+    assert e.value.status == N.RF_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------- weights (levenshtein.rs:1285-1331)
+@pytest.mark.parametrize("w", [(1, 1, 1), (2, 2, 2), (5, 5, 5), (1, 1, 2), (1, 1, 3), (2, 2, 4), (3, 3, 7), (0, 0, 1), (0, 0, 0)])
+def test_levenshtein_weights(w):
+    q = synth.query(40, 11)
+    data, offsets = synth.ragged_host(2000, 64, seed=12, alphabet=ABCD)
+    q = ABCD[np.random.default_rng(3).integers(0, 4, size=40)].tobytes()
+    for op in ("distance", "similarity", "normalized_distance", "normalized_similarity"):
+        _check_many("levenshtein", q, data, offsets, op, weights=w)
+    _check_many("levenshtein", q, data, offsets, "distance", weights=w, score_cutoff=30)
+
+
+@pytest.mark.parametrize("w", [(1, 2, 3), (1, 2, 1), (2, 2, 3), (1, 1, 0)])
+def test_levenshtein_generalized_weights_unsupported(w):
+    corpus = rf.Corpus.from_list([b"abc", b"abcd"])
+    with pytest.raises(rf.RfError) as e:
+        rf.distance.levenshtein.BatchComparator(b"abd").distance_many(corpus, weights=w)
+    assert e.value.status == N.RF_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------- fixed-length rows packed on the device
+@pytest.mark.parametrize("n,ln,qlen", [(1, 64, 64), (63, 64, 64), (64, 64, 48), (65, 64, 64), (100_000, 64, 64), (20_000, 256, 256), (5000, 37, 20), (4097, 16, 64), (1000, 0, 10)])
+def test_device_rows(n, ln, qlen):
+    import torch
+
+    q = synth.query(qlen, 100 + n)
+    rows = synth.rows_device(n, ln, seed=n + ln)
+    host = rows.cpu().numpy()
+    idx = synth.plant_near_duplicates(host, q, every=97, seed=5) if ln else np.zeros(0, dtype=np.int64)
+    rows = torch.from_numpy(host).cuda()
+    corpus = rf.Corpus.from_device_rows(rows)
+    assert len(corpus) == n
+    for metric in ("levenshtein", "indel", "lcs_seq"):
+        bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+        got = bc.distance_many(corpus)
+        exp = _expect_u32(ob.rows(N.OP_DISTANCE, host, nthreads=8))
+        assert (got == exp).all(), (metric, np.nonzero(got != exp)[0][:5])
+        got = bc.distance_many(corpus, score_cutoff=3)
+        exp = _expect_u32(ob.rows(N.OP_DISTANCE, host, nthreads=8, score_cutoff=3))
+        assert (got == exp).all()
+        if len(idx) and metric == "levenshtein":
+            assert (got[idx] != NONE32).sum() > 0  # the planted near-duplicates are found under the cutoff
+    # device-resident output
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    GPU["levenshtein"].BatchComparator(q).distance_many(corpus, out=out)
+    torch.cuda.synchronize()
+    exp = _expect_u32(ORA["levenshtein"].BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=8))
+    assert (out.cpu().numpy().view(np.uint32) == exp).all()
+
+
+# ---------------------------------------------------------------- the reference's known answers, through the GPU
+KAT = [
+    ("levenshtein", "distance", "", "", {}, 0), ("levenshtein", "distance", "aaaa", "", {}, 4),
+    ("levenshtein", "distance", "aaaa", "aaa", {}, 1), ("levenshtein", "distance", "abaa", "baaa", {}, 2),
+    ("levenshtein", "distance", "aaaa", "bbbb", {}, 4), ("levenshtein", "distance", "aaaa", "bbbb", {"weights": (1, 1, 2)}, 8),
+    ("levenshtein", "distance", "South Korea", "North Korea", {}, 2), ("levenshtein", "distance", "South Korea", "North Korea", {"score_cutoff": 2}, 2),
+    ("levenshtein", "distance", "South Korea", "North Korea", {"score_cutoff": 1}, None), ("levenshtein", "distance", "South Korea", "North Korea", {"score_cutoff": 0}, None),
+    ("levenshtein", "distance", "South Korea", "North Korea", {"weights": (1, 1, 2)}, 4), ("levenshtein", "distance", "South Korea", "North Korea", {"weights": (1, 1, 2), "score_cutoff": 3}, None),
+    ("levenshtein", "distance", "aabc", "cccd", {}, 4), ("levenshtein", "distance", "aabc", "cccd", {"score_cutoff": 3}, None),
+    ("levenshtein", "distance", "aabc", "cccd", {"weights": (1, 1, 2)}, 6), ("levenshtein", "distance", "a" * 128, "b" * 128, {}, 128),
+    ("levenshtein", "distance", "kitten", "sitting", {}, 3), ("levenshtein", "distance", "kitten", "sitting", {"score_cutoff": 2}, None),
+    ("levenshtein", "distance", "kitten", "sitting", {"score_hint": 2}, 3), ("levenshtein", "distance", "CA", "ABC", {}, 3),
+    ("lcs_seq", "similarity", "South Korea", "North Korea", {}, 9), ("lcs_seq", "similarity", "South Korea", "North Korea", {"score_cutoff": 10}, None),
+    ("lcs_seq", "distance", "South Korea", "North Korea", {"score_cutoff": 1}, None), ("lcs_seq", "distance", "aabc", "cccd", {}, 3),
+    ("lcs_seq", "similarity", "001", "220", {}, 1), ("lcs_seq", "distance", "ab", "ac", {}, 1),
+    ("lcs_seq", "distance", "lewenstein", "levenshtein", {}, 2), ("lcs_seq", "similarity", "lewenstein", "levenshtein", {}, 9),
+    ("indel", "distance", "aaaa", "bbbb", {}, 8), ("indel", "similarity", "aaaa", "aaaa", {}, 8),
+    ("indel", "distance", "South Korea", "North Korea", {"score_cutoff": 4}, 4), ("indel", "distance", "South Korea", "North Korea", {"score_cutoff": 3}, None),
+    ("indel", "distance", "aabc", "cccd", {}, 6), ("indel", "distance", "ab", "ac", {}, 2),
+    ("indel", "distance", "lewenstein", "levenshtein", {}, 3), ("indel", "distance", "lewenstein", "levenshtein", {"score_cutoff": 2}, None),
+]
+
+
+@pytest.mark.parametrize("metric,op,a,b,kw,exp", KAT)
+def test_reference_known_answers_on_gpu(metric, op, a, b, kw, exp):
+    """SURVEY App. B vectors, both BatchComparator orders (the GPU leg of the reference's 4-way helper)."""
+    assert getattr(GPU[metric].BatchComparator(a), op)(b, **kw) == exp
+    assert getattr(GPU[metric].BatchComparator(b), op)(a, **kw) == exp
+    assert getattr(GPU[metric], op)(a, b, **kw) == exp  # free-function spelling
+
+
+def test_banded_known_answers_on_gpu():
+    from test_oracle_known_answers import BANDED, INDEL_LONG_S2
+
+    for s1, s2, dist, cut in BANDED:
+        if len(s1) <= 512:
+            assert GPU["levenshtein"].BatchComparator(s1).distance(s2) == dist
+            for k, e in cut.items():
+                assert GPU["levenshtein"].BatchComparator(s1).distance(s2, score_cutoff=k) == e
+    bc = GPU["indel"].BatchComparator("ddccbccc")
+    assert bc.distance(INDEL_LONG_S2) == 508
+    assert bc.distance(INDEL_LONG_S2, score_cutoff=507) is None
+    assert bc.distance(INDEL_LONG_S2, score_cutoff=2**64 - 1) == 508
+
+
+def test_ocr_fixture_candidate_side(golden_dir):
+    """The 107 244-byte OCR text as a CANDIDATE against 512-byte windows of the other text as queries
+    (the full 106 514-symbol query exceeds the register-resident kernels)."""
+    e1 = open(os.path.join(golden_dir, "ocr_example1.bin"), "rb").read()
+    e2 = open(os.path.join(golden_dir, "ocr_example2.bin"), "rb").read()
+    corpus = rf.Corpus.from_list([e2, e2[:5000], e1[:700]])
+    for start in (0, 50_000):
+        q = e1[start : start + 512]
+        got = GPU["levenshtein"].BatchComparator(q).distance_many(corpus)
+        exp = [o.levenshtein.BatchComparator(q).distance(c) for c in (e2, e2[:5000], e1[:700])]
+        assert list(got) == exp
+
+
+# ---------------------------------------------------------------- fuzz::RatioBatchComparator
+def test_fuzz_ratio_batch():
+    q = b"this is a test"
+    cands = [b"this is a test!", b"", b"this is a test", b"completely different", b"new york mets", b"the wonderful new york mets"]
+    corpus = rf.Corpus.from_list(cands)
+    bc = rf.fuzz.RatioBatchComparator(q)
+    got = bc.similarity_many(corpus)
+    exp = np.array([o.fuzz.RatioBatchComparator(q).similarity(c) for c in cands])
+    assert (got == exp).all()  # reproduces fuzz.rs:141 (LCS / max(len)), bit for bit
+    got2 = bc.similarity_many(corpus, rf.Args().ratio_indel_normalization())
+    exp2 = np.array([o.indel.BatchComparator(q).normalized_similarity(c) for c in cands])
+    assert (got2 == exp2).all()
+    assert abs(got2[0] - 28 / 29) < 1e-15 and abs(got[0] - 14 / 15) < 1e-15
+    got3 = bc.similarity_many(corpus, score_cutoff=0.5)
+    exp3 = np.array([o.fuzz.RatioBatchComparator(q).similarity(c, score_cutoff=0.5) for c in cands], dtype=object)
+    assert all((np.isnan(g) and e is None) or g == e for g, e in zip(got3, exp3))
+
+
+# ---------------------------------------------------------------- larger scan: size-independent properties + sampled oracle
+def test_large_scan_properties_and_sample():
+    import torch
+
+    n, ln = 4_000_000, 64
+    q = synth.query(64, 0xC0FFEE02)
+    rows = synth.rows_device(n, ln, seed=0xC0FFEE02)
+    corpus = rf.Corpus.from_device_rows(rows)
+    bc = GPU["levenshtein"].BatchComparator(q)
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    bc.distance_many(corpus, out=out)
+    torch.cuda.synchronize()
+    d = out.cpu().numpy().view(np.uint32)
+    assert d.min() >= 0 and d.max() <= 64  # |len1 - len2| <= d <= max(len1, len2)
+    # idempotence: a second pass gives the same array
+    out2 = torch.empty_like(out)
+    bc.distance_many(corpus, out=out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    # Indel >= Levenshtein >= LCS distance, and indel parity == (len1 + len2) parity
+    ind = GPU["indel"].BatchComparator(q).distance_many(corpus)
+    lcs = GPU["lcs_seq"].BatchComparator(q).distance_many(corpus)
+    assert (ind >= d).all() and (d >= lcs).all() and ((ind % 2) == 0).all() and (ind == 2 * lcs).all()
+    # cutoff consistency: Some(d) iff d <= k
+    for k in (40, 50, 55):
+        dk = bc.distance_many(corpus, score_cutoff=k)
+        assert ((dk == NONE32) == (d > k)).all() and (dk[d <= k] == d[d <= k]).all()
+    # strided sample + a full 200k prefix against the oracle
+    host = rows[:: 1009].cpu().numpy()
+    exp = _expect_u32(o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=8))
+    assert (d[::1009] == exp).all()
+    host = rows[:200_000].cpu().numpy()
+    exp = _expect_u32(o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=8))
+    assert (d[:200_000] == exp).all()
