@@ -33,13 +33,27 @@ __device__ __forceinline__ uint64_t lut3(uint64_t a, uint64_t b, uint64_t c)
 constexpr uint32_t T_XOR_OR = (TA ^ TB) | TC;       // (a ^ b) | c
 constexpr uint32_t T_OR_NOR = TA | (~(TB | TC));    // a | ~(b | c)
 
-// (x << 1) | carry_in on a register pair: v_lshl_or_b32 + v_alignbit_b32
-__device__ __forceinline__ uint64_t shl1_or(uint64_t x, uint32_t cin)
+// (x << 1) | carry_in.  Measured on gfx950 (tools/microbench.hip, profiles/microbench_r01.txt): the 64-bit VALU
+// forms v_lshl_add_u64 / v_lshlrev_b64 issue at the same (half) rate as ONE v_alignbit_b32 / v_lshl_or_b32, so a
+// single 64-bit instruction beats the two-instruction 32-bit pair hipcc otherwise builds from split halves.
+// Plain VALU on VGPR pairs: no memory counters, no hazard padding needed (guide 5.7).
+// (hipcc canonicalises x + x + 1 back into shift-or on split halves, hence the asm; it is plain VALU on VGPR
+// pairs: nothing to count, no hazard padding needed -- guide 5.7.)
+template <int CIN>
+__device__ __forceinline__ uint64_t shl1_const(uint64_t x)
 {
-    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    const uint32_t nlo = (lo << 1) | cin;
-    const uint32_t nhi = __builtin_amdgcn_alignbit(hi, lo, 31);
-    return ((uint64_t)nhi << 32) | nlo;
+    uint64_t r;
+    if (CIN)
+        asm("v_lshl_add_u64 %0, %1, 1, 1" : "=v"(r) : "v"(x));
+    else
+        asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint64_t shl1_var(uint64_t x, uint32_t cin)
+{
+    uint64_t r;
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r | cin;
 }
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -75,8 +89,8 @@ struct LevState {
             const uint64_t d0 = e | n;                       // :848
             const uint64_t hn = e & p;                       // == d0 & vp because vp & vn == 0   (:852)
             const uint64_t hp = lut3<T_OR_NOR>(n, d0, p);    // vn | ~(d0 | vp)                  (:851)
-            const uint64_t hps = shl1_or(hp, hp_c);          // :865-866
-            const uint64_t hns = shl1_or(hn, hn_c);
+            const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_var(hp, hp_c);  // :865-866
+            const uint64_t hns = w == 0 ? shl1_const<0>(hn) : shl1_var(hn, hn_c);
             if (w + 1 < W) {                                 // :857-858
                 hp_c = (uint32_t)(hp >> 63);
                 hn_c = (uint32_t)(hn >> 63);

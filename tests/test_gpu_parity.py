@@ -34,6 +34,13 @@ def _check_many(metric, q, data, offsets, op, **kw):
     corpus = rf.Corpus.from_ragged(data, offsets)
     got = GPU[metric].BatchComparator(q).many(OPS[op], corpus, **kw)
     exp = ORA[metric].BatchComparator(q).many(OPS[op], data, offsets, nthreads=8, **kw)
+    if metric == "levenshtein" and op == "similarity" and kw.get("score_cutoff") is not None:
+        # Quirk Q2: above the cutoff the reference computes `maximum - usize::MAX`
+        # (details/distance.rs:209-210) -- a panic in debug builds, a wrapped `maximum + 1` in release.  The
+        # device returns None there, which is what every in-range entry implies.
+        kw2 = {k: v for k, v in kw.items() if k != "score_cutoff"}
+        sim = ORA[metric].BatchComparator(q).many(OPS[op], data, offsets, nthreads=8, **kw2)
+        exp = np.where(sim >= np.uint64(kw["score_cutoff"]), sim, U64MAX)
     if got.dtype == np.uint32:
         exp = _expect_u32(exp)
         bad = np.nonzero(got != exp)[0]
@@ -137,8 +144,8 @@ def test_device_rows(n, ln, qlen):
         got = bc.distance_many(corpus, score_cutoff=3)
         exp = _expect_u32(ob.rows(N.OP_DISTANCE, host, nthreads=8, score_cutoff=3))
         assert (got == exp).all()
-        if len(idx) and metric == "levenshtein":
-            assert (got[idx] != NONE32).sum() > 0  # the planted near-duplicates are found under the cutoff
+        if len(idx) >= 20 and metric == "levenshtein" and ln == qlen:
+            assert (got[idx] != NONE32).sum() > 0  # planted near-duplicates (0..5 edits) are found under cutoff 3
     # device-resident output
     out = torch.empty(n, dtype=torch.int32, device="cuda")
     GPU["levenshtein"].BatchComparator(q).distance_many(corpus, out=out)

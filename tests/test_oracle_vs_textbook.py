@@ -130,3 +130,16 @@ def test_reference_quirk_small_hint_vs_length_difference():
     assert bc.distance(b) == d  # no hint: exact
     assert bc.distance(b, score_hint=100) == d
     assert bc.distance(b, score_hint=0) != d  # upstream bug reproduced (value 31..34)
+
+
+def test_reference_quirk_levenshtein_similarity_cutoff_sentinel():
+    """Quirk Q2: levenshtein `similarity_with_args` above the cutoff evaluates
+    `maximum - usize::MAX` (details/distance.rs:209-210): a panic in debug builds; the oracle mirrors a
+    release build's wrap (maximum + 1, which `score()` then keeps).  The GPU path returns None."""
+    a, b = b"a" * 10, b"b" * 10  # distance 10, similarity 0
+    assert o.levenshtein.BatchComparator(a).similarity(b) == 0
+    assert o.levenshtein.BatchComparator(a).similarity(b, score_cutoff=0) == 0
+    # cutoff 2 -> distance cutoff 8 -> hyrroe2003 returns usize::MAX -> 10 - MAX wraps to 11 >= 2 -> Some(11)
+    assert o.levenshtein.BatchComparator(a).similarity(b, score_cutoff=2) == 11  # a sentinel, not a similarity
+    # below 4 the mbleven path returns cutoff + 1 instead of usize::MAX and the value stays in range
+    assert o.levenshtein.BatchComparator(b"aaaa").similarity(b"bbbb", score_cutoff=2) is None
