@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--candidates", type=int, default=100_000_000, help="candidates per GPU")
     ap.add_argument("--cand-len", type=int, default=64)
     ap.add_argument("--query-len", type=int, default=64)
-    ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq"])
+    ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq", "jaro", "jaro_winkler"])
     ap.add_argument("--cutoff", type=int, default=None)
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,14 +81,18 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t0
 
-    out = torch.empty(n, dtype=torch.int32, device=dev)
+    is_f64 = args.metric in ("jaro", "jaro_winkler")
+    out = torch.empty(n, dtype=torch.float64 if is_f64 else torch.int32, device=dev)
     call_args = rf.Args()
     if args.cutoff is not None:
         call_args = call_args.score_cutoff(args.cutoff)
     stream = torch.cuda.current_stream(dev)
 
     def step():
-        scorer.distance_many(corpus, call_args, out=out, stream=stream.cuda_stream)
+        if is_f64:  # BASELINE.json configs[3]: similarity, f64 per candidate
+            scorer.similarity_many(corpus, call_args, out=out, stream=stream.cuda_stream)
+        else:
+            scorer.distance_many(corpus, call_args, out=out, stream=stream.cuda_stream)
 
     def exchange():
         # per-shard top-k under (distance, global index), then the k-entry all-gather over xGMI
@@ -142,7 +146,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     gpairs = pairs_per_step / (elapsed / args.steps) / 1e9
     # algorithmic bytes per pair: candidate bytes at bucket length + one u32 result
-    bytes_per_pair = ln + 4
+    bytes_per_pair = ln + (8 if is_f64 else 4)
     achieved = n * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
 
     result = {
@@ -187,10 +191,15 @@ def main():
         from oracle import oracle as o
 
         chk = min(len(host_sample), 2_000_000)
-        exp = getattr(o, args.metric).BatchComparator(q).rows(N.OP_DISTANCE, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)
-        got = out[:chk].cpu().numpy().view(np.uint32)
-        exp32 = np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
-        result["parity"] = {"checked": int(chk), "mismatches": int((got != exp32).sum())}
+        op = N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE
+        exp = getattr(o, args.metric).BatchComparator(q).rows(op, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)
+        if is_f64:
+            got = out[:chk].cpu().numpy()
+            bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
+        else:
+            got = out[:chk].cpu().numpy().view(np.uint32)
+            bad = got != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
+        result["parity"] = {"checked": int(chk), "mismatches": int(bad.sum())}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
@@ -203,18 +212,19 @@ def cpu_baseline(args, q, host_sample):
     from rapidfuzz_rs_amd import _native as N
 
     bc = getattr(o, args.metric).BatchComparator(q)
+    OP = N.OP_SIMILARITY if args.metric in ("jaro", "jaro_winkler") else N.OP_DISTANCE
     probe = host_sample[:200_000]
     t0 = time.perf_counter()
-    bc.rows(N.OP_DISTANCE, probe, nthreads=1, score_cutoff=args.cutoff)
+    bc.rows(OP, probe, nthreads=1, score_cutoff=args.cutoff)
     rate = len(probe) / (time.perf_counter() - t0)
     n1 = int(min(len(host_sample), max(200_000, rate * args.cpu_seconds * 0.5)))
     t0 = time.perf_counter()
-    bc.rows(N.OP_DISTANCE, host_sample[:n1], nthreads=1, score_cutoff=args.cutoff)
+    bc.rows(OP, host_sample[:n1], nthreads=1, score_cutoff=args.cutoff)
     t1 = time.perf_counter() - t0
     cores = os.cpu_count() or 1
     nall = int(min(len(host_sample), max(n1, rate * cores * args.cpu_seconds * 0.3)))
     t0 = time.perf_counter()
-    bc.rows(N.OP_DISTANCE, host_sample[:nall], nthreads=cores, score_cutoff=args.cutoff)
+    bc.rows(OP, host_sample[:nall], nthreads=cores, score_cutoff=args.cutoff)
     tall = time.perf_counter() - t0
     model = ""
     try:

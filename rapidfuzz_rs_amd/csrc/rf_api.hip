@@ -69,6 +69,7 @@ struct rf_corpus {
     uint32_t max_len = 0;
     bool uniform = false;        // single length bucket: no descriptors, tile t at t * tile_bytes(uniform_len)
     uint32_t uniform_len = 0;
+    std::vector<uint32_t> lengths;  // the distinct candidate lengths (host copy, ascending)
 };
 
 extern "C" {
@@ -308,6 +309,8 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     c->payload_bytes = L.payload;
     c->n_tiles = (uint32_t)L.tiles.size();
     c->max_len = L.max_len;
+    for (const TileDesc& td : L.tiles)
+        if (c->lengths.empty() || c->lengths.back() != td.len) c->lengths.push_back(td.len);
     auto fail = [&](rf_status st) {
         rf_corpus_free(c);
         return st;
@@ -348,6 +351,7 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
     c->payload_bytes = (uint64_t)n * len;
     c->max_len = (uint32_t)len;
     c->n_tiles = (uint32_t)((n + kWave - 1) / kWave);
+    if (n) c->lengths.push_back((uint32_t)len);
     auto fail = [&](rf_status s) {
         rf_corpus_free(c);
         return s;
@@ -403,6 +407,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->factor = 1;
     p->w_ins = p->w_del = p->w_sub = 1;
     p->prefix_weight = args->prefix_weight;
+    for (size_t i = 0; i < std::min<size_t>(4, c->s1.size()); ++i) p->query_head |= (uint32_t)c->s1[i] << (8 * i);
     p->data = corpus->d_data;
     p->tiles = corpus->uniform ? nullptr : corpus->d_tiles;
     p->uniform_len = corpus->uniform_len;
@@ -481,10 +486,30 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         p->op = RF_OP_NORMALIZED_SIMILARITY;
         break;
     case RF_JARO:
-    case RF_JARO_WINKLER:
+    case RF_JARO_WINKLER: {
         *raw = RAW_JARO;
         p->finish = c->metric == RF_JARO ? FIN_JARO : FIN_JW;
-        break;
+        // the device kernel is the single-word path of jaro.rs:574-583: both strings <= 64 symbols AFTER the
+        // window truncation of jaro.rs:550-565.  Check every candidate length of the corpus up front.
+        const uint64_t len1 = c->s1.size();
+        for (uint32_t l2 : corpus->lengths) {
+            uint64_t a = len1, b = l2;
+            if (b > a) {
+                const uint64_t bound = b / 2 - 1;
+                if (b > a + bound) b = a + bound;
+            } else if (a >= 2) {
+                const uint64_t bound = a / 2 - 1;
+                if (a > b + bound) a = b + bound;
+            }
+            if (a == 0 || b == 0) continue;  // decided by the length filter, no flags needed
+            if (a > 64 || b > 64) {
+                set_error("jaro / jaro_winkler: a (query, candidate) pair needs the multi-word path "
+                          "(jaro.rs:286-337), which has no device kernel yet");
+                return RF_ERR_UNSUPPORTED;
+            }
+        }
+        return RF_OK;  // the PM row stride may exceed kMaxWords: only block 0 is read
+    }
     }
 
     if (c->words > (size_t)kMaxWords) {

@@ -14,6 +14,7 @@
 //   count_transpositions_word          src/distance/jaro.rs:147-190, :339-368
 //   MetricUsize / Metricf64 defaults   src/details/distance.rs:154-385
 #include <algorithm>
+#include <cstdlib>
 
 #include "rf_internal.hpp"
 
@@ -76,7 +77,7 @@ struct LevState {
             vn[w] = 0;
         }
     }
-    __device__ __forceinline__ void step(const uint64_t* __restrict__ pm_row)
+    __device__ __forceinline__ void step(const uint64_t (&pm_row)[W])
     {
         uint32_t hp_c = 1, hn_c = 0;  // levenshtein.rs:824-825
 #pragma unroll
@@ -125,7 +126,7 @@ struct LcsState {
 #pragma unroll
         for (int w = 0; w < W; ++w) s[w] = ~0ull;  // lcs_seq.rs:215
     }
-    __device__ __forceinline__ void step(const uint64_t* __restrict__ pm_row)
+    __device__ __forceinline__ void step(const uint64_t (&pm_row)[W])
     {
         uint64_t carry = 0;
 #pragma unroll
@@ -223,17 +224,43 @@ __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, ui
 // ---------------------------------------------------------------------------------------------------
 // the scan kernel
 // ---------------------------------------------------------------------------------------------------
+// PM row of one symbol: W consecutive u64 in LDS (ds_read_b64 / ds_read_b128)
+template <int W>
+__device__ __forceinline__ void load_pm(uint64_t (&dst)[W], const uint64_t* lds_pm, uint32_t ch)
+{
+    const uint64_t* row = lds_pm + ch * W;
+#pragma unroll
+    for (int w = 0; w < W; ++w) dst[w] = row[w];
+}
+
+// 16 columns in groups of kGroup symbols.  The LDS reads of group g+1 are issued BEFORE the recurrence of group g
+// (pinned with sched_barrier, otherwise the scheduler sinks them back next to their first use), so their latency
+// -- including the 2-4 way bank conflicts of 64 random 8-byte slots -- hides behind ~18 VALU instructions per column.
 template <class State, int W>
 __device__ __forceinline__ void process_chunk_full(State& st, const uint64_t* lds_pm, const uint4& c)
 {
+    constexpr int kGroup = W == 1 ? 4 : (W == 2 ? 2 : 1);
+    constexpr int kGroups = kChunk / kGroup;
     const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    uint64_t cur[kGroup][W], nxt[kGroup][W];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int j = 0; j < kGroup; ++j) load_pm<W>(cur[j], lds_pm, (dw[j / 4] >> (8 * (j % 4))) & 0xFFu);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ch = (dw[d] >> (8 * k)) & 0xFFu;
-            st.step(lds_pm + ch * W);
+    for (int g = 0; g < kGroups; ++g) {
+        if (g + 1 < kGroups) {
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                const int n = (g + 1) * kGroup + j;
+                load_pm<W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) st.step(cur[j]);
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+#pragma unroll
+            for (int w = 0; w < W; ++w) cur[j][w] = nxt[j][w];
     }
 }
 
@@ -241,8 +268,9 @@ template <class State, int W>
 __device__ __forceinline__ void process_chunk_tail(State& st, const uint64_t* lds_pm, uint4 c, uint32_t rem)
 {
     for (uint32_t j = 0; j < rem; ++j) {  // rem is wavefront-uniform (tile length)
-        const uint32_t ch = c.x & 0xFFu;
-        st.step(lds_pm + ch * W);
+        uint64_t x[W];
+        load_pm<W>(x, lds_pm, c.x & 0xFFu);
+        st.step(x);
         c.x = __builtin_amdgcn_alignbit(c.y, c.x, 8);
         c.y = __builtin_amdgcn_alignbit(c.z, c.y, 8);
         c.z = __builtin_amdgcn_alignbit(c.w, c.z, 8);
@@ -331,6 +359,207 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Jaro / Jaro-Winkler, single-word path (jaro.rs:516-598 with len1, len2 <= 64 after the window truncation
+// of :550-565).  Per lane: P_flag / T_flag in two VGPR pairs; the candidate's <= 64 bytes stay in 16 VGPRs for
+// the second (transposition) pass.  f64 epilogue in the reference's operation order, -ffp-contract=off.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t blsi64(uint64_t v) { return v & (0 - v); }  // intrinsics.rs:35-37
+__device__ __forceinline__ uint64_t mask_lsb64(uint32_t n) { return n < 64 ? (1ull << n) - 1 : ~0ull; }  // :28-34
+
+struct JaroRaw {
+    uint32_t common, transpositions, prefix;
+    bool eq11;  // the two single characters are equal (only meaningful for 1 x 1)
+};
+
+// jaro.rs:106-119
+__device__ __forceinline__ double jaro_calculate_similarity(uint32_t p_len, uint32_t t_len, uint32_t common, uint32_t transposition)
+{
+    transposition /= 2;
+    double sim = 0.0;
+    sim += (double)common / (double)p_len;
+    sim += (double)common / (double)t_len;
+    sim += ((double)common - (double)transposition) / (double)common;
+    return sim / 3.0;
+}
+// jaro.rs:122-131
+__device__ __forceinline__ bool jaro_length_filter(uint32_t p_len, uint32_t t_len, double cutoff)
+{
+    if (t_len == 0 || p_len == 0) return false;
+    const double min_len = (double)min(p_len, t_len);
+    double sim = min_len / (double)p_len + min_len / (double)t_len + 1.0;
+    sim /= 3.0;
+    return sim >= cutoff;
+}
+// jaro.rs:134-145
+__device__ __forceinline__ bool jaro_common_char_filter(uint32_t p_len, uint32_t t_len, uint32_t common, double cutoff)
+{
+    if (common == 0) return false;
+    double sim = 0.0;
+    sim += (double)common / (double)p_len;
+    sim += (double)common / (double)t_len;
+    sim += 1.0;
+    sim /= 3.0;
+    return sim >= cutoff;
+}
+// jaro::similarity_with_pm (jaro.rs:516-598) given the flag counts; every early `return 0.0` of the reference
+// is a select here because the flags were computed unconditionally.
+__device__ __forceinline__ double jaro_similarity(uint32_t len1, uint32_t len2, const JaroRaw& r, double cutoff)
+{
+    if (cutoff > 1.0) return 0.0;                              // :533-535
+    if (len1 == 0 && len2 == 0) return 1.0;                     // :537-539
+    if (!jaro_length_filter(len1, len2, cutoff)) return 0.0;    // :542-544
+    if (len1 == 1 && len2 == 1) return r.eq11 ? 1.0 : 0.0;      // :546-548
+    if (!jaro_common_char_filter(len1, len2, r.common, cutoff)) return 0.0;  // :579-581
+    return jaro_calculate_similarity(len1, len2, r.common, r.transpositions);
+}
+// jaro_winkler::similarity_with_pm (jaro_winkler.rs:103-141)
+__device__ __forceinline__ double jw_similarity(uint32_t len1, uint32_t len2, const JaroRaw& r, double prefix_weight, double cutoff)
+{
+    double jaro_cutoff = cutoff;
+    if (jaro_cutoff > 0.7) {  // :125-133
+        const double prefix_sim = (double)r.prefix * prefix_weight;
+        jaro_cutoff = prefix_sim >= 1.0 ? 0.7 : fmax(0.7, (prefix_sim - jaro_cutoff) / (prefix_sim - 1.0));
+    }
+    double sim = jaro_similarity(len1, len2, r, jaro_cutoff);
+    if (sim > 0.7) sim += (double)r.prefix * prefix_weight * (1.0 - sim);  // :136-138
+    return sim;
+}
+
+// Metricf64 (details/distance.rs:277-385) with maximum == 1.0, then score() (common.rs:43-45 / :83-85)
+__device__ __forceinline__ double f64_metric_value(const ScanParams& p, uint32_t len2, const JaroRaw& r, bool* keep)
+{
+    const bool has = p.has_cutoff != 0;
+    const double c = p.cutoff_f64;
+    auto sim_with = [&](bool has_c, double cc) {  // _similarity: score_cutoff.unwrap_or(0.0)
+        const double cut = has_c ? cc : 0.0;
+        return p.finish == FIN_JW ? jw_similarity(p.len1, len2, r, p.prefix_weight, cut) : jaro_similarity(p.len1, len2, r, cut);
+    };
+    auto dist_with = [&](bool has_c, double cc) {  // _distance, :280-302
+        const double cs = has_c ? (1.0 >= cc ? 1.0 - cc : 0.0) : 0.0;
+        return 1.0 - sim_with(has_c, cs);
+    };
+    auto ndist_with = [&](bool has_c, double cc) {  // _normalized_distance, :336-361 (maximum = 1.0)
+        const double d = dist_with(has_c, 1.0 * cc);
+        return d / 1.0;
+    };
+    double v;
+    switch (p.op) {
+    case RF_OP_SIMILARITY:
+        v = sim_with(has, c);
+        *keep = !has || v >= c;
+        break;
+    case RF_OP_DISTANCE:
+        v = dist_with(has, c);
+        *keep = !has || v <= c;
+        break;
+    case RF_OP_NORMALIZED_DISTANCE:
+        v = ndist_with(has, c);
+        *keep = !has || v <= c;
+        break;
+    default:  // _normalized_similarity, :363-384
+        v = 1.0 - ndist_with(has, has ? norm_sim_to_norm_dist(c) : 0.0);
+        *keep = !has || v >= c;
+        break;
+    }
+    return v;
+}
+
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
+{
+    const uint32_t W = p.words;  // PM row stride; only block 0 is read on this path (jaro.rs:172, pm.get(0, ..))
+    extern __shared__ uint64_t lds_pm0[];  // 256 entries: block 0 of every row
+    for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm0[i] = p.pm[(size_t)i * W];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t q4 = p.query_head;  // first four query bytes, little endian (Winkler prefix)
+
+    for (uint32_t t = blockIdx.x * kWavesPerBlock + wave; t < p.n_tiles; t += stride) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2_orig = tv.len, len1_orig = p.len1;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+
+        // window truncation, jaro.rs:550-565 (wavefront-uniform)
+        uint32_t len1 = len1_orig, len2 = len2_orig, bound = 0;
+        if (len2 > len1) {
+            bound = len2 / 2 - 1;
+            if (len2 > len1 + bound) len2 = len1 + bound;
+        } else if (len1 > 0) {
+            bound = len1 / 2 > 0 ? len1 / 2 - 1 : 0;
+            if (len1 > len2 + bound) len1 = len2 + bound;
+        }
+        // (len1 == 1 && len2_orig <= 1 never reaches the flags: length filter / 1x1 rule decide; bound is unused then)
+
+        // the candidate's first min(len2, 64) bytes
+        uint4 c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = (uint32_t)(k * kChunk) < len2 ? tv.src[(size_t)k * kWave + lane] : make_uint4(0, 0, 0, 0);
+
+        JaroRaw r;
+        r.eq11 = (c[0].x & 0xFFu) == (q4 & 0xFFu);
+        {  // Winkler prefix: equal leading bytes among the first min(4, len1_orig, len2_orig), jaro_winkler.rs:118-123
+            const uint32_t lim = min(4u, min(len1_orig, len2_orig));
+            const uint32_t diff = c[0].x ^ q4;
+            const uint32_t first_diff = diff ? (uint32_t)(__ffs(diff) - 1) / 8 : 4u;
+            r.prefix = min(first_diff, lim);
+        }
+
+        // pass 1: flag_similar_characters_word, jaro.rs:147-190
+        uint64_t p_flag = 0, t_flag = 0;
+        uint64_t bound_mask = mask_lsb64(bound + 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)(k * kChunk) >= len2) break;
+            const uint32_t dw[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
+#pragma unroll
+            for (int b = 0; b < kChunk; ++b) {
+                const uint32_t j = k * kChunk + b;
+                if (j >= len2) break;
+                const uint32_t ch = (dw[b / 4] >> (8 * (b % 4))) & 0xFFu;
+                const uint64_t pm_j = lds_pm0[ch] & bound_mask & ~p_flag;
+                p_flag |= blsi64(pm_j);
+                t_flag |= (uint64_t)(pm_j != 0) << j;
+                bound_mask = j < bound ? (bound_mask << 1) | 1 : bound_mask << 1;
+            }
+        }
+        r.common = __popcll(p_flag);
+
+        // pass 2: count_transpositions_word, jaro.rs:339-368 -- walk the text in order; every flagged text
+        // character consumes the lowest remaining pattern flag
+        uint32_t transpositions = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)(k * kChunk) >= len2) break;
+            const uint32_t dw[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
+#pragma unroll
+            for (int b = 0; b < kChunk; ++b) {
+                const uint32_t j = k * kChunk + b;
+                if (j >= len2) break;
+                const uint32_t ch = (dw[b / 4] >> (8 * (b % 4))) & 0xFFu;
+                const bool flagged = (t_flag >> j) & 1;
+                const uint64_t m = blsi64(p_flag);
+                const bool miss = (lds_pm0[ch] & m) == 0;
+                transpositions += (flagged && miss) ? 1u : 0u;
+                p_flag ^= flagged ? m : 0ull;
+            }
+        }
+        r.transpositions = transpositions;
+
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            bool keep;
+            const double v = f64_metric_value(p, len2_orig, r, &keep);
+            reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // corpus packing on the device: row-major fixed-length rows -> chunk-interleaved tiles
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t* __restrict__ rows, size_t n, uint32_t len,
@@ -374,7 +603,17 @@ hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t 
 // ---------------------------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------------------------
-int scan_max_grid() { return 256 * 8; }  // 256 CUs x 8 workgroups (32 waves/CU): the whole chip resident
+int scan_max_grid()
+{
+    // 8 workgroups (32 waves) are resident per CU; launching 4x that lets early finishers be replaced and
+    // measured +5% over an exactly-resident grid (profiles/grid_sweep_r01.txt).  RF_SCAN_BLOCKS_PER_CU overrides.
+    static const int per_cu = [] {
+        const char* e = getenv("RF_SCAN_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 32;
+    }();
+    return 256 * per_cu;
+}
 
 template <template <int> class StateT, int W>
 static hipError_t launch_one(const ScanParams& p, hipStream_t stream, int grid)
@@ -410,6 +649,12 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     switch (raw) {
     case RAW_LEV: return launch_words<LevState>(p, stream, grid);
     case RAW_LCS: return launch_words<LcsState>(p, stream, grid);
+    case RAW_JARO:
+        if (p.tiles)
+            hipLaunchKernelGGL(jaro_word_kernel<false>, dim3(grid), dim3(kWave * kWavesPerBlock), 256 * sizeof(uint64_t), stream, p);
+        else
+            hipLaunchKernelGGL(jaro_word_kernel<true>, dim3(grid), dim3(kWave * kWavesPerBlock), 256 * sizeof(uint64_t), stream, p);
+        return hipGetLastError();
     default: return hipErrorInvalidValue;
     }
 }

@@ -21,8 +21,8 @@ U64MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
 AB = np.frombuffer(b"ab", dtype=np.uint8)
 ABCD = np.frombuffer(b"abcd", dtype=np.uint8)
 
-GPU = {"levenshtein": rf.distance.levenshtein, "indel": rf.distance.indel, "lcs_seq": rf.distance.lcs_seq}
-ORA = {"levenshtein": o.levenshtein, "indel": o.indel, "lcs_seq": o.lcs_seq}
+GPU = {"levenshtein": rf.distance.levenshtein, "indel": rf.distance.indel, "lcs_seq": rf.distance.lcs_seq, "jaro": rf.distance.jaro, "jaro_winkler": rf.distance.jaro_winkler}
+ORA = {"levenshtein": o.levenshtein, "indel": o.indel, "lcs_seq": o.lcs_seq, "jaro": o.jaro, "jaro_winkler": o.jaro_winkler}
 OPS = {"distance": N.OP_DISTANCE, "similarity": N.OP_SIMILARITY, "normalized_distance": N.OP_NORMALIZED_DISTANCE, "normalized_similarity": N.OP_NORMALIZED_SIMILARITY}
 
 
@@ -210,6 +210,88 @@ def test_ocr_fixture_candidate_side(golden_dir):
         got = GPU["levenshtein"].BatchComparator(q).distance_many(corpus)
         exp = [o.levenshtein.BatchComparator(q).distance(c) for c in (e2, e2[:5000], e1[:700])]
         assert list(got) == exp
+
+
+# ---------------------------------------------------------------- jaro / jaro_winkler: BIT-exact f64 (the reference's own tests only ask for 1e-4)
+JARO_CUTOFFS = [None, 0.0, 0.3, 0.5, 0.7, 0.71, 0.8, 0.9, 1.0, 1.1]
+
+
+@pytest.mark.parametrize("metric", ["jaro", "jaro_winkler"])
+@pytest.mark.parametrize("qlen", [0, 1, 2, 5, 17, 32, 48, 63, 64])
+def test_jaro_ragged_bit_exact(metric, qlen):
+    rng = np.random.default_rng(qlen + 1000)
+    alpha = ABCD if qlen % 2 else synth.ALNUM
+    q = alpha[rng.integers(0, len(alpha), size=qlen)].tobytes()
+    data, offsets = synth.ragged_host(4000, 64, seed=qlen + 77, alphabet=alpha)
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+    for i in range(0, len(cands), 20):  # near-duplicates and shared prefixes so sim > 0.7 and the Winkler boost occur
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 5))):
+            if len(b):
+                b[int(rng.integers(0, len(b)))] = int(alpha[int(rng.integers(0, len(alpha)))])
+        cands[i] = bytes(b)
+    data, offsets = rf.ragged(cands)
+    for op in ("similarity", "distance", "normalized_similarity", "normalized_distance"):
+        for c in JARO_CUTOFFS:
+            kw = {} if c is None else {"score_cutoff": c}
+            _check_many(metric, q, data, offsets, op, **kw)
+    if metric == "jaro_winkler":
+        for pw in (0.0, 0.2, 0.25, 0.3):
+            _check_many(metric, q, data, offsets, "similarity", prefix_weight=pw)
+            _check_many(metric, q, data, offsets, "similarity", prefix_weight=pw, score_cutoff=0.85)
+
+
+def test_jaro_tables_on_gpu(golden_dir):
+    """The reference's 20x20 Jaro and 22x22 Jaro-Winkler tables (jaro.rs:1094-1189, jaro_winkler.rs:693-798), every
+    name as the query against all names as one corpus; 1e-4 like upstream, and bit-equal to the oracle."""
+    for metric, fn in (("jaro", "jaro_table.json"), ("jaro_winkler", "jaro_winkler_table.json")):
+        t = json.load(open(os.path.join(golden_dir, fn)))
+        names, scores = t["names"], np.array(t["scores"]).reshape(len(t["names"]), -1)
+        corpus = rf.Corpus.from_list(names)
+        data, offsets = rf.ragged(names)
+        for i, n1 in enumerate(names):
+            got = GPU[metric].BatchComparator(n1).similarity_many(corpus)
+            assert np.abs(got - scores[i]).max() <= 1e-4, (metric, n1)
+            exp = ORA[metric].BatchComparator(n1).many(N.OP_SIMILARITY, data, offsets)
+            assert (got == exp).all()
+            for cutoff in (0.3, 0.5, 0.7, 0.9, 1.1):
+                got = GPU[metric].BatchComparator(n1).similarity_many(corpus, score_cutoff=cutoff)
+                assert (np.isnan(got) == (scores[i] < cutoff - 1e-9) | np.isnan(got)).all()
+                exp = ORA[metric].BatchComparator(n1).many(N.OP_SIMILARITY, data, offsets, score_cutoff=cutoff)
+                assert ((got == exp) | (np.isnan(got) & np.isnan(exp))).all()
+    assert GPU["jaro"].BatchComparator("james").similarity("robert") == pytest.approx(0.455556, abs=1e-4)
+    assert GPU["jaro"].distance("james", "robert", score_cutoff=1.0) == pytest.approx(1 - 0.455556, abs=1e-4)
+
+
+def test_jaro_long_query_short_candidates_and_unsupported_block_path():
+    q = synth.query(80, 5)  # bound 39: candidates up to 25 symbols keep the truncated query <= 64
+    data, offsets = synth.ragged_host(2000, 25, seed=9)
+    for metric in ("jaro", "jaro_winkler"):
+        _check_many(metric, q, data, offsets, "similarity")
+        _check_many(metric, q, data, offsets, "similarity", score_cutoff=0.4)
+    corpus = rf.Corpus.from_list([b"a" * 70, b"abc"])
+    with pytest.raises(rf.RfError) as e:
+        GPU["jaro"].BatchComparator(b"a" * 70).similarity_many(corpus)
+    assert e.value.status == N.RF_ERR_UNSUPPORTED
+
+
+def test_jaro_fixed_rows_c4():
+    """BASELINE.json configs[3] shape: the len-64 corpus, Jaro-Winkler (prefix_weight 0.1) -> f64."""
+    import torch
+
+    q = synth.query(64, 0xC0FFEE02)
+    rows = synth.rows_device(300_000, 64, seed=0xC0FFEE02)
+    host = rows.cpu().numpy()
+    synth.plant_near_duplicates(host, q, every=101, seed=6, max_edits=8)
+    corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
+    for metric in ("jaro", "jaro_winkler"):
+        got = GPU[metric].BatchComparator(q).similarity_many(corpus)
+        exp = ORA[metric].BatchComparator(q).rows(N.OP_SIMILARITY, host, nthreads=8)
+        assert (got == exp).all(), np.nonzero(got != exp)[0][:5]
+        got = GPU[metric].BatchComparator(q).distance_many(corpus, score_cutoff=0.45)
+        exp = ORA[metric].BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=8, score_cutoff=0.45)
+        assert ((got == exp) | (np.isnan(got) & np.isnan(exp))).all()
+        assert (~np.isnan(got)).sum() > 0
 
 
 # ---------------------------------------------------------------- fuzz::RatioBatchComparator

@@ -141,6 +141,7 @@ static int run(const char* name, kern_t k, int iters, double instr_per_iter_per_
     return 0;
 }
 
+int main_lev();
 int main()
 {
     uint32_t* d_out;
@@ -159,5 +160,85 @@ int main()
     run("add_co+addc", k_add_co_pair, iters, 32, d_out);
     run("ds_read_b64 rnd", k_lds_b64, iters / 10, 32, d_out);
     run("ds_read_b64 lin", k_lds_same, iters / 10, 32, d_out);
+    return main_lev();
+}
+
+// ---- the Levenshtein column itself, without HBM: (a) PM word from registers, (b) PM word from LDS at a random
+//      symbol per lane.  Reports wave-columns per ns (= Gpairs/s-equivalent x 64 columns / 64 lanes).
+constexpr uint32_t TA = 0xF0, TB = 0xCC, TC = 0xAA;
+template <uint32_t TT>
+__device__ __forceinline__ uint64_t lut3(uint64_t a, uint64_t b, uint64_t c)
+{
+    uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, TT & 0xFF);
+    uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), TT & 0xFF);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ void lev_col(uint64_t& vp, uint64_t& vn, uint64_t x)
+{
+    const uint64_t sum = (x & vp) + vp;
+    const uint64_t e = lut3<(TA ^ TB) | TC>(sum, vp, x);
+    const uint64_t d0 = e | vn;
+    const uint64_t hn = e & vp;
+    const uint64_t hp = lut3<TA | (~(TB | TC))>(vn, d0, vp);
+    uint64_t hps, hns;
+    asm("v_lshl_add_u64 %0, %1, 1, 1" : "=v"(hps) : "v"(hp));
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(hns) : "v"(hn));
+    vn = hps & d0;
+    vp = lut3<TA | (~(TB | TC))>(hns, hps, d0);
+}
+__global__ __launch_bounds__(256) void k_lev_regs(uint32_t* out, int iters, uint32_t seed)
+{
+    uint64_t vp = ~0ull, vn = 0;
+    uint64_t x0 = threadIdx.x * 0x9E3779B97F4A7C15ull + seed, x1 = x0 * 3, x2 = x0 * 5, x3 = x0 * 7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lev_col(vp, vn, x0); lev_col(vp, vn, x1); lev_col(vp, vn, x2); lev_col(vp, vn, x3);
+        }
+    }
+    if ((vp ^ vn) == 0x12345678) out[0] = 1;
+}
+__global__ __launch_bounds__(256) void k_lev_lds(uint32_t* out, int iters, uint32_t seed)
+{
+    __shared__ uint64_t tab[256];
+    tab[threadIdx.x] = threadIdx.x * 0x9E3779B97F4A7C15ull;
+    __syncthreads();
+    uint64_t vp = ~0ull, vn = 0;
+    uint32_t w = (threadIdx.x * 2654435761u) ^ seed;
+    for (int i = 0; i < iters; ++i) {
+        // 16 columns from 4 dwords of pseudo-random alphanumeric-like symbols (48 + 0..61)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            w = w * 1664525u + 1013904223u;
+            const uint32_t c0 = 48 + ((w >> 8) & 63) % 62, c1 = 48 + ((w >> 14) & 63) % 62, c2 = 48 + ((w >> 20) & 63) % 62, c3 = 48 + ((w >> 26) & 63) % 62;
+            const uint64_t p0 = tab[c0], p1 = tab[c1], p2 = tab[c2], p3 = tab[c3];
+            lev_col(vp, vn, p0); lev_col(vp, vn, p1); lev_col(vp, vn, p2); lev_col(vp, vn, p3);
+        }
+    }
+    if ((vp ^ vn) == 0x12345678) out[0] = 1;
+}
+static int run_lev(const char* name, kern_t k, int iters, uint32_t* d_out, int blocks_per_cu)
+{
+    const int blocks = 256 * blocks_per_cu, threads = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, d_out, iters / 8, 1u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 2u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double cols = (double)blocks * threads / 64 * iters * 16;
+    printf("%-14s %d blocks/CU %8.3f ms  %7.2f wave-columns/ns (= Gpairs/s for 64-column candidates)\n", name, blocks_per_cu, ms, cols / (ms * 1e6));
+    return 0;
+}
+int main_lev()
+{
+    uint32_t* d_out;
+    hipMalloc(&d_out, 64);
+    for (int b : {2, 4, 8}) run_lev("lev col regs", k_lev_regs, 40000, d_out, b);
+    for (int b : {2, 4, 8}) run_lev("lev col lds", k_lev_lds, 40000, d_out, b);
     return 0;
 }
