@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq", "jaro", "jaro_winkler"])
     ap.add_argument("--cutoff", type=int, default=None)
     ap.add_argument("--topk", type=int, default=16)
+    ap.add_argument("--mode", default="many", choices=["many", "topk"],
+                    help="many: one score per candidate (configs[1]); topk: top-k only, no per-candidate output (configs[4])")
+    ap.add_argument("--plant-every", type=int, default=1_000_000, help="near-duplicates of the query planted 1-in-N (cutoff/top-k runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -71,6 +74,21 @@ def main():
     # synthetic corpus, generated and packed on the device (excluded from the timed region)
     t0 = time.time()
     rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev)
+    if args.cutoff is not None or args.mode == "topk":
+        # 1 in 10^6 candidates is the query with 0..5 random substitutions
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(99 + rank)
+        pidx = torch.arange(args.plant_every // 2, n, args.plant_every, device=dev)
+        if len(pidx):
+            qrow = torch.tensor(list(q[:ln].ljust(ln, b"0")), dtype=torch.uint8, device=dev)
+            planted = qrow.repeat(len(pidx), 1)
+            for _ in range(5):
+                hit = torch.rand(len(pidx), device=dev, generator=gen) < 0.5
+                pos = torch.randint(0, ln, (len(pidx),), device=dev, generator=gen)
+                sub = torch.randint(48, 58, (len(pidx),), device=dev, generator=gen, dtype=torch.int64).to(torch.uint8)
+                sel = torch.nonzero(hit).flatten()
+                planted[sel, pos[sel]] = sub[sel]
+            rows[pidx] = planted
     sample_rows = min(n, 32_000_000)
     host_sample = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -88,24 +106,21 @@ def main():
         call_args = call_args.score_cutoff(args.cutoff)
     stream = torch.cuda.current_stream(dev)
 
+    from rapidfuzz_rs_amd import parallel
+
+    last_topk = [None]
+
     def step():
         if is_f64:  # BASELINE.json configs[3]: similarity, f64 per candidate
             scorer.similarity_many(corpus, call_args, out=out, stream=stream.cuda_stream)
-        else:
+        elif args.mode == "many" and world == 1:
             scorer.distance_many(corpus, call_args, out=out, stream=stream.cuda_stream)
-
-    def exchange():
-        # per-shard top-k under (distance, global index), then the k-entry all-gather over xGMI
-        if world == 1:
-            return
-        k = args.topk
-        d = out.view(torch.int32)[:n]
-        # distances are < 2^31: order by (distance, global index) through one int64 key
-        key = d.to(torch.int64) * (1 << 40) + (torch.arange(n, device=dev, dtype=torch.int64) + rank * n)
-        loc = torch.topk(key, k, largest=False).values
-        gathered = [torch.empty_like(loc) for _ in range(world)]
-        dist.all_gather(gathered, loc)
-        torch.sort(torch.cat(gathered)).values[:k]
+        else:
+            # one pass: per-shard top-k under (distance, global index) [+ every candidate's distance, which stays
+            # on its GPU], then the k-entry all-gather over RCCL/xGMI and the merge -- the only exchange on the path
+            s_, i_ = scorer.topk(corpus, args.topk, N.OP_DISTANCE, call_args, index_base=rank * n,
+                                 out=out if args.mode == "many" else None, stream=stream.cuda_stream)
+            last_topk[0] = parallel.allgather_topk(s_, i_, args.topk, N.OP_DISTANCE, device=dev) if world > 1 else (s_, i_)
 
     for _ in range(args.warmup):
         step()
@@ -120,8 +135,6 @@ def main():
         ev[s][0].record(stream)
         step()
         ev[s][1].record(stream)
-        if world > 1 and s == args.steps - 1:
-            exchange()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -146,7 +159,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     gpairs = pairs_per_step / (elapsed / args.steps) / 1e9
     # algorithmic bytes per pair: candidate bytes at bucket length + one u32 result
-    bytes_per_pair = ln + (8 if is_f64 else 4)
+    bytes_per_pair = ln + (8 if is_f64 else (4 if args.mode == "many" else 0))
     achieved = n * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
 
     result = {
@@ -169,7 +182,7 @@ def main():
             "candidates_per_gpu": n,
             "candidate_len": ln,
             "query_len": args.query_len,
-            "output": "u32 per candidate, device-resident",
+            "output": ("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else f"top-{args.topk} only",
             "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if world > 1 else "1 GPU",
             "setup_s": round(t_setup, 2),
         },
@@ -185,11 +198,15 @@ def main():
         },
     }
 
-    if host_sample is not None:
+    if last_topk[0] is not None:
+        result["config"]["topk_found"] = int(len(last_topk[0][0]))
+        result["config"]["topk_best"] = [int(x) for x in last_topk[0][0][:4]]
+    if host_sample is not None and args.mode == "many":
         result["cpu_baseline"] = cpu_baseline(args, q, host_sample)
         # parity on the sample, in the same run
         from oracle import oracle as o
 
+        torch.cuda.synchronize()
         chk = min(len(host_sample), 2_000_000)
         op = N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE
         exp = getattr(o, args.metric).BatchComparator(q).rows(op, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)

@@ -165,11 +165,14 @@ rf_status rf_many_f64(const rf_comparator *c, const rf_corpus *corpus, rf_op op,
  * defined as: evaluate every candidate with `op`/`args`, drop None, order by
  *   (score ascending for RF_OP_DISTANCE / descending for RF_OP_SIMILARITY, index ascending)
  * and keep the first k.  index = index_base + original candidate index, so shards of one logical
- * corpus produce globally comparable entries.  Outputs are HOST arrays of k entries; *out_count <= k.
+ * corpus produce globally comparable entries.  Outputs are HOST arrays of k entries (k <= 64);
+ * *out_count <= k.  If out_all is not NULL the same pass also writes every candidate's score there (as
+ * rf_many_u32 would; it stays on this GPU).  With a Levenshtein distance cutoff a wavefront stops reading a tile
+ * as soon as all of its 64 candidates are provably beyond the cutoff.
  * rf_topk_merge_u32 merges `lists` such results (e.g. after an all-gather across GPUs). */
 rf_status rf_topk_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint32_t k,
                       uint64_t index_base, uint32_t *out_score, uint64_t *out_index, uint32_t *out_count,
-                      void *stream);
+                      uint32_t *out_all, rf_mem out_all_mem, void *stream);
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t *scores, const uint64_t *indices, const uint32_t *counts,
                             uint32_t lists, uint32_t k, uint32_t *out_score, uint64_t *out_index,
                             uint32_t *out_count);

@@ -169,14 +169,29 @@ class BatchComparator:
         return self.many(N.OP_NORMALIZED_SIMILARITY, corpus, args, **kw)
 
     def topk(self, corpus: Corpus, k: int, op: int = N.OP_DISTANCE, args: Optional[Args] = None, index_base: int = 0,
-             stream=None, **kw):
-        """(scores uint32[m], indices uint64[m]), m <= k, ordered by (score, index); see rf_topk_u32."""
-        a = _mk_args(args, kw.get("score_cutoff"), kw.get("score_hint"), kw.get("weights"), kw.get("prefix_weight"))
+             out=None, stream=None, *, score_cutoff=None, score_hint=None, weights=None, prefix_weight=None):
+        """(scores uint32[m], indices uint64[m]), m <= k <= 64, ordered by (score, index) -- best first; see
+        rf_topk_u32.  `out` (a CUDA int32/uint32 tensor or a numpy uint32 array of len(corpus)) additionally
+        receives every candidate's score from the same pass."""
+        a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
         ca = a.to_c(False)
         scores = np.empty(k, dtype=np.uint32)
         idx = np.empty(k, dtype=np.uint64)
         cnt = C.c_uint32()
-        N.check(N.lib().rf_topk_u32(self._h, corpus._h, op, C.byref(ca), k, index_base, scores.ctypes.data, idx.ctypes.data, C.byref(cnt), stream))
+        out_ptr, out_mem = None, N.MEM_HOST
+        if out is not None:
+            if hasattr(out, "is_cuda") and out.is_cuda:
+                import torch
+
+                assert out.numel() >= len(corpus) and out.is_contiguous() and out.element_size() == 4
+                out_ptr, out_mem = out.data_ptr(), N.MEM_DEVICE
+                if stream is None:
+                    stream = torch.cuda.current_stream(out.device).cuda_stream
+            else:
+                assert out.dtype == np.uint32 and out.size >= len(corpus)
+                out_ptr = out.ctypes.data
+        N.check(N.lib().rf_topk_u32(self._h, corpus._h, op, C.byref(ca), k, index_base, scores.ctypes.data, idx.ctypes.data,
+                                    C.byref(cnt), out_ptr, out_mem, stream))
         return scores[: cnt.value], idx[: cnt.value]
 
     # ------------------------------------------------------------------ the reference's per-candidate methods

@@ -125,7 +125,7 @@ def lib() -> C.CDLL:
     L.rf_corpus_device.argtypes = [vp]
     L.rf_many_u32.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), vp, C.c_int, vp]
     L.rf_many_f64.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), vp, C.c_int, vp]
-    L.rf_topk_u32.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint64, vp, vp, u32p, vp]
+    L.rf_topk_u32.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint64, vp, vp, u32p, vp, C.c_int, vp]
     L.rf_topk_merge_u32.argtypes = [C.c_int, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, u32p]
     _lib = L
     return L

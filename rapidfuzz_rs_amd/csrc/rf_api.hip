@@ -516,6 +516,15 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         set_error("query longer than 512 symbols: no register-resident kernel (RF_ERR_UNSUPPORTED)");
         return RF_ERR_UNSUPPORTED;
     }
+    // Value-preserving early-out for a Levenshtein distance cutoff that can actually prune something
+    // (the reference only applies the cutoff after its loop, levenshtein.rs:492-496).
+    if (p->finish == FIN_LEV && op == RF_OP_DISTANCE && !f64_out && p->has_cutoff && p->factor > 0) {
+        const uint32_t raw_cutoff = p->cutoff_u32 / p->factor;
+        if (raw_cutoff < std::max<uint32_t>(p->len1, corpus->max_len)) {
+            p->early = 1;
+            p->raw_cutoff = raw_cutoff;
+        }
+    }
     return RF_OK;
 }
 
@@ -572,11 +581,75 @@ rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
 // ---------------------------------------------------------------------------------------------------
 // top-k
 // ---------------------------------------------------------------------------------------------------
-rf_status rf_topk_u32(const rf_comparator*, const rf_corpus*, rf_op, const rf_args*, uint32_t, uint64_t, uint32_t*,
-                      uint64_t*, uint32_t*, void*)
+rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
+                      uint64_t index_base, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count,
+                      uint32_t* out_all, rf_mem out_all_mem, void* stream)
 {
-    set_error("rf_topk_u32: not implemented yet");
-    return RF_ERR_UNSUPPORTED;
+    if (!out_score || !out_index || !out_count || k == 0) {
+        set_error("rf_topk_u32: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    *out_count = 0;
+    if (k > (uint32_t)kWave) {
+        set_error("rf_topk_u32: k above 64 is not supported (one list entry per wavefront lane)");
+        return RF_ERR_UNSUPPORTED;
+    }
+    if (op != RF_OP_DISTANCE && op != RF_OP_SIMILARITY) {
+        set_error("rf_topk_u32: op must be RF_OP_DISTANCE or RF_OP_SIMILARITY");
+        return RF_ERR_INVALID_ARG;
+    }
+    ScanParams p;
+    RawKind raw = RAW_LEV;
+    rf_status s = plan(c, corpus, op, args, false, &p, &raw);
+    if (s != RF_OK) return s;
+    if (raw == RAW_JARO) {
+        set_error("rf_topk_u32: usize-valued metrics only");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (corpus->n == 0) return RF_OK;
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    s = comparator_device_pm(c, corpus->device, &p.pm);
+    if (s != RF_OK) return s;
+
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = scan_grid(corpus->n_tiles);
+    uint64_t *d_keys = nullptr, *d_best = nullptr;
+    RF_HIP(hipMallocAsync((void**)&d_keys, (size_t)grid * k * sizeof(uint64_t), st));
+    RF_HIP(hipMallocAsync((void**)&d_best, (size_t)k * sizeof(uint64_t), st));
+    p.topk_k = k;
+    p.topk_desc = op == RF_OP_SIMILARITY;
+    p.topk_keys = d_keys;
+    // optionally also emit every candidate's score from the same pass (they stay sharded)
+    uint32_t* d_all = out_all;
+    if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
+    p.out = d_all;
+    hipError_t e = launch_scan(raw, p, st, nullptr);
+    if (e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) {
+        e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        (void)hipFreeAsync(d_all, st);
+    }
+    if (e == hipSuccess) e = launch_topk_merge(d_keys, (uint32_t)grid * k, k, d_best, st);
+    std::vector<uint64_t> best(k, ~0ull);
+    if (e == hipSuccess) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    (void)hipFreeAsync(d_keys, st);
+    (void)hipFreeAsync(d_best, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        set_error(std::string("top-k: ") + hipGetErrorString(e));
+        return RF_ERR_HIP;
+    }
+    uint32_t m = 0;
+    for (; m < k && best[m] != ~0ull; ++m) {
+        const uint32_t hi = (uint32_t)(best[m] >> 32);
+        out_score[m] = p.topk_desc ? ~hi : hi;
+        out_index[m] = index_base + (uint32_t)best[m];
+    }
+    *out_count = m;
+    return RF_OK;
 }
 
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t* scores, const uint64_t* indices, const uint32_t* counts,

@@ -63,20 +63,22 @@ struct ScanParams {
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
     double cutoff_f64;
     double prefix_weight;
-    // top-k mode (out == nullptr): per-block candidate lists
-    uint32_t topk_k;
+    // value-preserving early-out under a distance cutoff (levenshtein, u32 distance output / top-k)
+    uint32_t early;
+    uint32_t raw_cutoff;   // cutoff on the raw kernel distance: floor(cutoff / factor)
+    // top-k mode (topk_k != 0): no per-candidate output, one k-entry key list per workgroup
+    uint32_t topk_k;       // <= 64
     uint32_t topk_desc;    // 1: larger score is better (similarity)
-    uint64_t index_base;
-    uint32_t* topk_scores; // [grid][k]
-    uint64_t* topk_index;  // [grid][k]
-    uint32_t* topk_counts; // [grid]
+    uint64_t* topk_keys;   // [grid][k], key = (score or ~score) << 32 | local index, ~0 = empty
 };
 
 // kernels (rf_kernels.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
+hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* out, hipStream_t stream);
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,
                             uint32_t n_tiles, hipStream_t stream);
 int scan_max_grid();
+int scan_grid(uint32_t n_tiles);  // the grid launch_scan uses for n_tiles tiles
 
 void set_error(const std::string& msg);
 

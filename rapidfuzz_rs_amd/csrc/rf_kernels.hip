@@ -100,6 +100,15 @@ struct LevState {
             vp[w] = lut3<T_OR_NOR>(hns, hps, d0);            // hn | ~(d0 | hp)                  (:868)
         }
     }
+    // Early-out bound under a distance cutoff (the reference applies its cutoff only after the loop,
+    // levenshtein.rs:492-496, so this is value-preserving pruning): adjacent cells of the last row differ by at
+    // most 1, hence D[len1][len2] >= D[len1][j] - (len2 - j).  D[len1][j] comes from the same popcount identity
+    // as result().  True = this lane can no longer end at or below `raw_cutoff`.
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    {
+        return (int32_t)result(len1, j) - (int32_t)(len2 - j) > (int32_t)raw_cutoff;
+    }
     // D[len1][len2] from the final column's vertical deltas
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
@@ -144,6 +153,8 @@ struct LcsState {
             s[w] = x | (sw - u);  // lcs_seq.rs:230
         }
     }
+    static constexpr bool kCanPrune = false;
+    __device__ __forceinline__ bool hopeless(uint32_t, uint32_t, uint32_t, uint32_t) const { return false; }
     __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const
     {
         uint32_t sim = 0;
@@ -191,21 +202,28 @@ __device__ __forceinline__ UsizeResult usize_result(const ScanParams& p, uint32_
 // Which value the op yields and whether `score()` (src/common.rs:43-45 / :83-85) keeps it.  All kernels on
 // this path are exact, so the CPU-side cutoff plumbing (details/distance.rs:157-274) reduces to
 // "compute the value, then compare with the user's cutoff" -- see DESIGN.md "cutoff equivalence".
-__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx)
+__device__ __forceinline__ uint32_t usize_value(const ScanParams& p, uint32_t raw, uint32_t len2, bool* keep)
 {
     const UsizeResult r = usize_result(p, raw, len2);
+    uint32_t v;
+    if (p.op == RF_OP_DISTANCE) {
+        v = r.dist;
+        *keep = !p.has_cutoff || v <= p.cutoff_u32;
+    } else {  // similarity = maximum - distance (details/distance.rs:209-210)
+        v = r.maximum - r.dist;
+        *keep = !p.has_cutoff || v >= p.cutoff_u32;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx)
+{
     if (!p.out_f64) {
-        uint32_t v;
         bool keep;
-        if (p.op == RF_OP_DISTANCE) {
-            v = r.dist;
-            keep = !p.has_cutoff || v <= p.cutoff_u32;
-        } else {  // similarity = maximum - distance (details/distance.rs:209-210)
-            v = r.maximum - r.dist;
-            keep = !p.has_cutoff || v >= p.cutoff_u32;
-        }
+        const uint32_t v = usize_value(p, raw, len2, &keep);
         reinterpret_cast<uint32_t*>(p.out)[idx] = keep ? v : RF_NONE_U32;
     } else {
+        const UsizeResult r = usize_result(p, raw, len2);
         // details/distance.rs:246-250: dist / maximum (0.0 when maximum == 0)
         const double nd = r.maximum == 0 ? 0.0 : (double)r.dist / (double)r.maximum;
         double v;
@@ -220,6 +238,41 @@ __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, ui
         reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// wavefront-local top-k (k <= 64): lane l holds the l-th smallest 64-bit key, ~0 = empty.  A key is
+// (score << 32 | local index) for "smaller is better" and (~score << 32 | local index) for similarities, so
+// the order is exactly (score, index) and keys are unique.  Everything stays in two VGPRs per lane.
+// ---------------------------------------------------------------------------------------------------
+struct WaveTopK {
+    uint64_t key;
+    __device__ __forceinline__ void init() { key = ~0ull; }
+    __device__ __forceinline__ uint64_t worst(uint32_t k) const
+    {
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)key, k - 1), hi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), k - 1);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    // x is wavefront-uniform
+    __device__ __forceinline__ void insert(uint64_t x, uint32_t lane)
+    {
+        const uint32_t pos = __popcll(__ballot(key < x));  // sorted ascending: the smaller keys are a lane prefix
+        const uint32_t up_lo = __shfl_up((uint32_t)key, 1), up_hi = __shfl_up((uint32_t)(key >> 32), 1);
+        const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
+        key = lane > pos ? up : (lane == pos ? x : key);
+    }
+    // offer one key per lane (valid lanes only); k is the list length
+    __device__ __forceinline__ void offer(uint64_t mine, bool valid, uint32_t k, uint32_t lane)
+    {
+        uint64_t m = __ballot(valid && mine < worst(k));
+        while (m) {  // rare after the first few tiles: expected k * ln(N / k) insertions per wavefront
+            const uint32_t l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine, l), hi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), l);
+            const uint64_t x = ((uint64_t)hi << 32) | lo;
+            if (x < worst(k)) insert(x, lane);
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // the scan kernel
@@ -307,55 +360,145 @@ template <class State, int W, bool kUniform>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanParams p)
 {
     __shared__ uint64_t lds_pm[256 * W];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
     for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock) lds_pm[i] = p.pm[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const bool topk = p.topk_k != 0;
+    const bool early = State::kCanPrune && p.early != 0;
+    WaveTopK best;
+    best.init();
 
     // Each wavefront walks its tiles as one continuous stream of 16-column chunks.  The load of the NEXT
     // chunk (the next 16 columns of this tile, or the first 16 of the wavefront's next tile) is always issued
     // before the current chunk is processed, so exactly one 1 KiB request per wavefront is in flight and the
     // wait before each chunk is a counted vmcnt(1), never a drain.
+    // With a cutoff (`early`) the bet is the opposite: after 16 columns nearly every wavefront of a random
+    // corpus is past the cutoff, so the prefetch goes to the NEXT TILE and a surviving wavefront fetches its
+    // own next chunk on demand -- a dead tile costs 16 of its 64+ bytes per candidate in HBM traffic.
     uint32_t t = blockIdx.x * kWavesPerBlock + wave;
-    if (t >= p.n_tiles) return;
-    TileView cur_tile = load_tile<kUniform>(p, t);
-    uint4 cur = cur_tile.src[lane];  // the packed buffer carries one chunk of tail padding: always readable
+    if (t < p.n_tiles) {
+        TileView cur_tile = load_tile<kUniform>(p, t);
+        uint4 cur = cur_tile.src[lane];  // the packed buffer carries one chunk of tail padding: always readable
 
-    while (true) {
-        const uint32_t t_next = t + stride;
-        const bool has_next = t_next < p.n_tiles;
-        const TileView next_tile = load_tile<kUniform>(p, has_next ? t_next : t);
+        while (true) {
+            const uint32_t t_next = t + stride;
+            const bool has_next = t_next < p.n_tiles;
+            const TileView next_tile = load_tile<kUniform>(p, has_next ? t_next : t);
 
-        const uint32_t len2 = cur_tile.len;
-        const uint32_t slot = cur_tile.slot0 + lane;
-        uint32_t idx = slot;
-        if (!kUniform) idx = p.orig[slot];  // issued early; consumed after the columns
+            const uint32_t len2 = cur_tile.len;
+            const uint32_t slot = cur_tile.slot0 + lane;
+            uint32_t idx = slot;
+            if (!kUniform) idx = p.orig[slot];  // issued early; consumed after the columns
 
-        State st;
-        st.init();
-        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
-        for (uint32_t c = 0; c < nch; ++c) {
-            const uint4* nsrc = (c + 1 < nch) ? cur_tile.src + (size_t)(c + 1) * kWave : next_tile.src;
-            const uint4 nxt = nsrc[lane];
-            const uint32_t cols = len2 - c * kChunk;
-            if (cols >= kChunk)
-                process_chunk_full<State, W>(st, lds_pm, cur);
-            else
-                process_chunk_tail<State, W>(st, lds_pm, cur, cols);
-            cur = nxt;
+            State st;
+            st.init();
+            const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+            bool dead = false;
+            uint4 ahead = make_uint4(0, 0, 0, 0);
+            if (early || nch == 0) ahead = next_tile.src[lane];
+            for (uint32_t c = 0; c < nch; ++c) {
+                uint4 nxt = ahead;
+                if (!early) {
+                    const uint4* nsrc = (c + 1 < nch) ? cur_tile.src + (size_t)(c + 1) * kWave : next_tile.src;
+                    nxt = nsrc[lane];
+                }
+                const uint32_t cols = len2 - c * kChunk;
+                if (cols >= kChunk)
+                    process_chunk_full<State, W>(st, lds_pm, cur);
+                else
+                    process_chunk_tail<State, W>(st, lds_pm, cur, cols);
+                if (early) {
+                    const uint32_t j = min(len2, (c + 1) * kChunk);
+                    if (__ballot(!st.hopeless(p.len1, j, len2, p.raw_cutoff)) == 0) {
+                        dead = true;  // the whole wavefront is beyond the cutoff: stop reading this tile
+                        break;
+                    }
+                    if (c + 1 < nch) nxt = cur_tile.src[(size_t)(c + 1) * kWave + lane];
+                }
+                cur = nxt;
+            }
+            if (dead || nch == 0) cur = ahead;
+
+            const bool valid = kUniform ? slot < p.n : idx != kPad;
+            const uint32_t raw = st.result(p.len1, len2);
+            if (p.out && valid) {
+                if (dead)
+                    reinterpret_cast<uint32_t*>(p.out)[idx] = RF_NONE_U32;  // early only runs for u32 distance output
+                else
+                    emit_usize(p, raw, len2, idx);
+            }
+            if (topk && !dead) {
+                bool keep;
+                const uint32_t v = usize_value(p, raw, len2, &keep);
+                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | idx;
+                best.offer(mine, valid && keep, p.topk_k, lane);
+            }
+
+            if (!has_next) break;
+            t = t_next;
+            cur_tile = next_tile;
         }
-        if (nch == 0) cur = next_tile.src[lane];
-
-        const uint32_t raw = st.result(p.len1, len2);
-        const bool valid = kUniform ? slot < p.n : idx != kPad;
-        if (valid) emit_usize(p, raw, len2, idx);
-
-        if (!has_next) break;
-        t = t_next;
-        cur_tile = next_tile;
     }
+
+    if (topk) {  // 4 wavefront lists -> one list per workgroup -> global; the final merge is topk_merge_kernel
+        lds_topk[wave][lane] = best.key;
+        __syncthreads();
+        if (wave == 0) {
+            for (uint32_t w = 1; w < kWavesPerBlock; ++w)
+                for (uint32_t j = 0; j < p.topk_k; ++j) {
+                    const uint64_t x = lds_topk[w][j];  // wavefront-uniform address: a broadcast read
+                    if (x < best.worst(p.topk_k)) best.insert(x, lane);
+                }
+            if (lane < p.topk_k) p.topk_keys[(size_t)blockIdx.x * p.topk_k + lane] = best.key;
+        }
+    }
+}
+
+// one workgroup: k rounds of "smallest key above the previous pick" over all workgroup lists (keys are unique)
+__global__ __launch_bounds__(1024) void topk_merge_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t k, uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t red[16];
+    __shared__ uint64_t last_pick;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t last = 0;
+    bool have_last = false;
+    for (uint32_t r = 0; r < k; ++r) {
+        uint64_t m = ~0ull;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t x = keys[i];
+            if ((!have_last || x > last) && x < m) m = x;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)m, off), hi = __shfl_xor((uint32_t)(m >> 32), off);
+            const uint64_t o = ((uint64_t)hi << 32) | lo;
+            m = o < m ? o : m;
+        }
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = ~0ull;
+            for (uint32_t w = 0; w < blockDim.x / 64; ++w) b = red[w] < b ? red[w] : b;
+            last_pick = b;
+            out[r] = b;
+        }
+        __syncthreads();
+        last = last_pick;
+        have_last = true;
+        if (last == ~0ull) {  // fewer than k entries: the rest stay empty
+            for (uint32_t i = r + 1 + threadIdx.x; i < k; i += blockDim.x) out[i] = ~0ull;
+            break;
+        }
+    }
+}
+
+hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(1024), 0, stream, keys, n, k, out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -641,10 +784,15 @@ static hipError_t launch_words(const ScanParams& p, hipStream_t stream, int grid
     }
 }
 
+int scan_grid(uint32_t n_tiles)
+{
+    return (int)std::min<uint32_t>((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)scan_max_grid());
+}
+
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
 {
     if (p.n_tiles == 0) return hipSuccess;
-    const int grid = (int)std::min<uint32_t>((p.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)scan_max_grid());
+    const int grid = scan_grid(p.n_tiles);
     if (grid_used) *grid_used = grid;
     switch (raw) {
     case RAW_LEV: return launch_words<LevState>(p, stream, grid);

@@ -1,0 +1,64 @@
+"""Multi-GPU: one process per GPU, the corpus sharded by contiguous candidate ranges, NO collective on the
+data path.  The only exchange is the one the north star names: every rank's k best entries under the total
+order (score, global index) are all-gathered (RCCL over xGMI when the backend is "nccl") and merged by
+rf_topk_merge_u32 on every rank.  k * 12 bytes per rank: latency-bound, link bandwidth is irrelevant.
+
+The reference has no counterpart (single-threaded library, no top-k API); the oracle for this module is
+"evaluate everything, stable-sort by (score, index), take k" (tests/test_parallel.py, tests/test_gpu_parity.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+_PAD_INDEX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """rank r of R owns candidates [r*n/R, (r+1)*n/R) -- contiguous, balanced to within one candidate."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def merge_topk(op: int, scores: np.ndarray, indices: np.ndarray, counts: np.ndarray, k: int):
+    """Merge `len(counts)` lists (row-major [lists, k]) into the k best by (score, index)."""
+    scores = np.ascontiguousarray(scores, dtype=np.uint32)
+    indices = np.ascontiguousarray(indices, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    out_s, out_i = np.empty(k, dtype=np.uint32), np.empty(k, dtype=np.uint64)
+    cnt = C.c_uint32()
+    N.check(N.lib().rf_topk_merge_u32(op, scores.ctypes.data, indices.ctypes.data, counts.ctypes.data, len(counts), k,
+                                      out_s.ctypes.data, out_i.ctypes.data, C.byref(cnt)))
+    return out_s[: cnt.value], out_i[: cnt.value]
+
+
+def allgather_topk(scores: np.ndarray, indices: np.ndarray, k: int, op: int = N.OP_DISTANCE, group=None, device=None):
+    """All-gather every rank's local top-k (global indices!) and merge.  Works with any initialized
+    torch.distributed backend; tensors live on `device` (a CUDA device for "nccl" = RCCL, CPU for "gloo")."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    m = len(scores)
+    payload = torch.zeros(2 * k + 1, dtype=torch.int64)
+    payload[0] = m
+    payload[1 : 1 + m] = torch.from_numpy(scores.astype(np.int64))
+    payload[1 + k : 1 + k + m] = torch.from_numpy(indices.view(np.int64))
+    if device is not None:
+        payload = payload.to(device)
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload, group=group)
+    g = torch.stack(gathered).cpu().numpy()
+    counts = g[:, 0].astype(np.uint32)
+    return merge_topk(op, g[:, 1 : 1 + k].astype(np.uint32), g[:, 1 + k : 1 + 2 * k].copy().view(np.uint64), counts, k)
+
+
+def sharded_topk(scorer, shard_corpus, k: int, shard_start: int, op: int = N.OP_DISTANCE, args=None, out=None, group=None,
+                 device=None, **kw):
+    """One rank's share of a distributed top-k: scan the local shard (global index = shard_start + local),
+    then the k-entry all-gather.  Every rank returns the same (scores, global indices)."""
+    s, i = scorer.topk(shard_corpus, k, op, args, index_base=shard_start, out=out, **kw)
+    return allgather_topk(s, i, k, op, group=group, device=device)

@@ -294,6 +294,79 @@ def test_jaro_fixed_rows_c4():
         assert (~np.isnan(got)).sum() > 0
 
 
+# ---------------------------------------------------------------- top-k (the engine's own reduction; oracle = evaluate all, sort by (score, index))
+def _oracle_topk(vals, k, desc):
+    idx = np.arange(len(vals), dtype=np.uint64)
+    keep = vals != U64MAX
+    v, i = vals[keep].astype(np.int64), idx[keep]
+    order = np.lexsort((i, -v if desc else v))[:k]
+    return v[order].astype(np.uint32), i[order]
+
+
+@pytest.mark.parametrize("metric", ["levenshtein", "indel", "lcs_seq"])
+@pytest.mark.parametrize("k", [1, 5, 16, 64])
+def test_topk_ragged(metric, k):
+    q = synth.query(40, 21)
+    data, offsets = synth.ragged_host(20_000, 64, seed=22)
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+    rng = np.random.default_rng(5)
+    for i in range(0, len(cands), 307):
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 6))):
+            b[int(rng.integers(0, len(b)))] = int(synth.ALNUM[int(rng.integers(0, 62))])
+        cands[i] = bytes(b)
+    data, offsets = rf.ragged(cands)
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+    for op, desc in ((N.OP_DISTANCE, False), (N.OP_SIMILARITY, True)):
+        for cutoff in (None, 3, 30):
+            kw = {} if cutoff is None else {"score_cutoff": cutoff}
+            if metric == "levenshtein" and desc and cutoff is not None:
+                continue  # quirk Q2: the oracle's values above a levenshtein similarity cutoff are sentinels
+            vals = ob.many(op, data, offsets, nthreads=8, **kw)
+            es, ei = _oracle_topk(vals, k, desc)
+            gs, gi = bc.topk(corpus, k, op, index_base=1000, **kw)
+            assert gs.tolist() == es.tolist() and gi.tolist() == (ei + np.uint64(1000)).tolist(), (metric, k, op, cutoff)
+
+
+def test_topk_small_and_empty_corpora():
+    q = b"kitten"
+    for cands in ([], [b"sitting"], [b"mitten", b"", b"kitten", b"kitchen", b"smitten"]):
+        corpus = rf.Corpus.from_list(cands)
+        s, i = GPU["levenshtein"].BatchComparator(q).topk(corpus, 16)
+        exp = sorted((o.levenshtein.distance(q, c), j) for j, c in enumerate(cands))
+        assert list(zip(s.tolist(), i.tolist())) == exp
+    with pytest.raises(rf.RfError):
+        GPU["levenshtein"].BatchComparator(q).topk(rf.Corpus.from_list([b"a"]), 65)
+
+
+def test_topk_fused_with_full_output_and_cutoff_c5_shape():
+    """BASELINE.json configs[4] shape on one GPU: len-64 corpus with 1-in-N planted near-duplicates,
+    score_cutoff = 3, top-16 -- plus every candidate's distance from the same pass."""
+    import torch
+
+    n = 2_000_000
+    q = synth.query(64, 0xC0FFEE05)
+    rows = synth.rows_device(n, 64, seed=0xC0FFEE05)
+    host = rows.cpu().numpy()
+    planted = synth.plant_near_duplicates(host, q, every=50_021, seed=3)
+    corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    bc = GPU["levenshtein"].BatchComparator(q)
+    gs, gi = bc.topk(corpus, 16, N.OP_DISTANCE, out=out, score_cutoff=3)
+    torch.cuda.synchronize()
+    vals = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=16, score_cutoff=3)
+    es, ei = _oracle_topk(vals, 16, False)
+    assert gs.tolist() == es.tolist() and gi.tolist() == ei.tolist()
+    assert len(gs) > 0 and set(gi.tolist()) <= set(planted.tolist())
+    assert (out.cpu().numpy().view(np.uint32) == _expect_u32(vals)).all()
+    # no cutoff: top-16 of 2M
+    gs, gi = bc.topk(corpus, 16)
+    vals = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=16)
+    es, ei = _oracle_topk(vals, 16, False)
+    assert gs.tolist() == es.tolist() and gi.tolist() == ei.tolist()
+
+
 # ---------------------------------------------------------------- fuzz::RatioBatchComparator
 def test_fuzz_ratio_batch():
     q = b"this is a test"

@@ -1,0 +1,87 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` processes exercise the shard arithmetic and the top-k
+all-gather + merge (the only collective on the path).  No GPU compute happens here; the per-shard top-k lists
+are produced by the oracle, exactly what a rank's rf_topk_u32 call returns on a GPU box."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from rapidfuzz_rs_amd import _native as N
+from rapidfuzz_rs_amd import parallel
+from rapidfuzz_rs_amd.utils import synth
+from oracle import oracle as o
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 64, 1000, 10**9 + 7):
+        for world in (1, 2, 3, 8):
+            edges = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_topk(dist, k, cutoff, base=0, desc=False):
+    idx = np.arange(len(dist), dtype=np.uint64) + np.uint64(base)
+    keep = dist != np.uint64(2**64 - 1)
+    d, i = dist[keep].astype(np.int64), idx[keep]
+    order = np.lexsort((i, -d if desc else d))[:k]
+    return d[order].astype(np.uint32), i[order]
+
+
+def _worker(rank, world, port, q, rows, k, cutoff, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b = parallel.shard_range(len(rows), rank, world)
+        d = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, rows[a:b], score_cutoff=cutoff)
+        s, i = _oracle_topk(d, k, cutoff, base=a)  # what rf_topk_u32(index_base=a) returns for this shard
+        ms, mi = parallel.allgather_topk(s, i, k, N.OP_DISTANCE)
+        ret[rank] = (ms.tolist(), mi.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cutoff,k", [(None, 16), (3, 16), (40, 5), (0, 4)])
+def test_topk_allgather_gloo_world2(cutoff, k):
+    import torch.multiprocessing as mp
+
+    q = synth.query(64, 0xC0FFEE05)
+    rows = synth.rows_host(3001, 64, seed=0xC0FFEE05)
+    synth.plant_near_duplicates(rows, q, every=211, seed=1)
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, rows, k, cutoff, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    d = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, rows, score_cutoff=cutoff)
+    es, ei = _oracle_topk(d, k, cutoff)
+    for r in range(world):  # every rank ends with the same, globally correct list
+        assert ret[r][0] == es.tolist() and ret[r][1] == ei.tolist()
+    if cutoff == 3:
+        assert len(es) > 0  # the planted near-duplicates are found
+
+
+def test_merge_topk_similarity_order():
+    s = np.array([[9, 7, 7, 0], [8, 7, 1, 0]], dtype=np.uint32)  # lists are rows of k entries, `counts` valid each
+    i = np.array([[4, 2, 9, 0], [5, 1, 3, 0]], dtype=np.uint64)
+    ms, mi = parallel.merge_topk(N.OP_SIMILARITY, s, i, np.array([3, 3], dtype=np.uint32), 4)
+    assert ms.tolist() == [9, 8, 7, 7] and mi.tolist() == [4, 5, 1, 2]
