@@ -617,9 +617,12 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
 
     hipStream_t st = (hipStream_t)stream;
     const int grid = scan_grid(corpus->n_tiles);
-    uint64_t *d_keys = nullptr, *d_best = nullptr;
-    RF_HIP(hipMallocAsync((void**)&d_keys, (size_t)grid * k * sizeof(uint64_t), st));
-    RF_HIP(hipMallocAsync((void**)&d_best, (size_t)k * sizeof(uint64_t), st));
+    // one stream-ordered allocation: [workgroup lists | merge scratch | final k keys]
+    const size_t n_keys = (size_t)grid * k, n_scratch = topk_merge_scratch_entries((uint32_t)n_keys, k);
+    uint64_t* d_keys = nullptr;
+    RF_HIP(hipMallocAsync((void**)&d_keys, (n_keys + n_scratch + k) * sizeof(uint64_t), st));
+    uint64_t* d_scratch = d_keys + n_keys;
+    uint64_t* d_best = d_scratch + n_scratch;
     p.topk_k = k;
     p.topk_desc = op == RF_OP_SIMILARITY;
     p.topk_keys = d_keys;
@@ -632,11 +635,10 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         (void)hipFreeAsync(d_all, st);
     }
-    if (e == hipSuccess) e = launch_topk_merge(d_keys, (uint32_t)grid * k, k, d_best, st);
+    if (e == hipSuccess) e = launch_topk_merge(d_keys, (uint32_t)n_keys, k, d_scratch, d_best, st);
     std::vector<uint64_t> best(k, ~0ull);
     if (e == hipSuccess) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
     (void)hipFreeAsync(d_keys, st);
-    (void)hipFreeAsync(d_best, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         set_error(std::string("top-k: ") + hipGetErrorString(e));

@@ -74,7 +74,8 @@ struct ScanParams {
 
 // kernels (rf_kernels.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
-hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* out, hipStream_t stream);
+hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* scratch, uint64_t* out, hipStream_t stream);
+size_t topk_merge_scratch_entries(uint32_t n, uint32_t k);
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,
                             uint32_t n_tiles, hipStream_t stream);
 int scan_max_grid();

@@ -289,21 +289,21 @@ __device__ __forceinline__ void load_pm(uint64_t (&dst)[W], const uint64_t* lds_
 // 16 columns in groups of kGroup symbols.  The LDS reads of group g+1 are issued BEFORE the recurrence of group g
 // (pinned with sched_barrier, otherwise the scheduler sinks them back next to their first use), so their latency
 // -- including the 2-4 way bank conflicts of 64 random 8-byte slots -- hides behind ~18 VALU instructions per column.
-template <class State, int W>
+template <class State, int W, int J0 = 0, int J1 = kChunk>
 __device__ __forceinline__ void process_chunk_full(State& st, const uint64_t* lds_pm, const uint4& c)
 {
     constexpr int kGroup = W == 1 ? 4 : (W == 2 ? 2 : 1);
-    constexpr int kGroups = kChunk / kGroup;
+    constexpr int kGroups = (J1 - J0) / kGroup;
     const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
     uint64_t cur[kGroup][W], nxt[kGroup][W];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) load_pm<W>(cur[j], lds_pm, (dw[j / 4] >> (8 * (j % 4))) & 0xFFu);
+    for (int j = 0; j < kGroup; ++j) load_pm<W>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
         if (g + 1 < kGroups) {
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
-                const int n = (g + 1) * kGroup + j;
+                const int n = J0 + (g + 1) * kGroup + j;
                 load_pm<W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -407,10 +407,21 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
                     nxt = nsrc[lane];
                 }
                 const uint32_t cols = len2 - c * kChunk;
-                if (cols >= kChunk)
-                    process_chunk_full<State, W>(st, lds_pm, cur);
-                else
+                if (cols >= kChunk) {
+                    if (early && c == 0) {
+                        // first chance to stop: after 8 columns a random candidate is already ~6 edits off
+                        process_chunk_full<State, W, 0, kChunk / 2>(st, lds_pm, cur);
+                        if (__ballot(!st.hopeless(p.len1, kChunk / 2, len2, p.raw_cutoff)) == 0) {
+                            dead = true;
+                            break;
+                        }
+                        process_chunk_full<State, W, kChunk / 2, kChunk>(st, lds_pm, cur);
+                    } else {
+                        process_chunk_full<State, W>(st, lds_pm, cur);
+                    }
+                } else {
                     process_chunk_tail<State, W>(st, lds_pm, cur, cols);
+                }
                 if (early) {
                     const uint32_t j = min(len2, (c + 1) * kChunk);
                     if (__ballot(!st.hopeless(p.len1, j, len2, p.raw_cutoff)) == 0) {
@@ -458,20 +469,31 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
     }
 }
 
-// one workgroup: k rounds of "smallest key above the previous pick" over all workgroup lists (keys are unique)
-__global__ __launch_bounds__(1024) void topk_merge_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t k, uint64_t* __restrict__ out)
+// Reduction of many k-entry lists to k entries, in stages: every workgroup takes a slice of <= 4096 keys (4 per
+// thread, in registers) and runs k rounds of "smallest key above the previous pick" (keys are unique), writing k
+// keys; the host repeats until one list is left.  100 M candidates -> 8192 lists -> 32 -> 1: two tiny launches.
+constexpr int kMergeThreads = 1024, kMergePerThread = 4, kMergeSlice = kMergeThreads * kMergePerThread;
+
+__global__ __launch_bounds__(kMergeThreads) void topk_reduce_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t k,
+                                                                    uint64_t* __restrict__ out)
 {
-    __shared__ uint64_t red[16];
-    __shared__ uint64_t last_pick;
+    __shared__ uint64_t red[kMergeThreads / 64];
+    __shared__ uint64_t pick;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * kMergeSlice;
+    uint64_t mine[kMergePerThread];
+#pragma unroll
+    for (int e = 0; e < kMergePerThread; ++e) {
+        const uint32_t i = base + e * kMergeThreads + threadIdx.x;
+        mine[e] = i < n ? keys[i] : ~0ull;
+    }
     uint64_t last = 0;
     bool have_last = false;
     for (uint32_t r = 0; r < k; ++r) {
         uint64_t m = ~0ull;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint64_t x = keys[i];
-            if ((!have_last || x > last) && x < m) m = x;
-        }
+#pragma unroll
+        for (int e = 0; e < kMergePerThread; ++e)
+            if ((!have_last || mine[e] > last) && mine[e] < m) m = mine[e];
         for (int off = 32; off > 0; off >>= 1) {
             const uint32_t lo = __shfl_xor((uint32_t)m, off), hi = __shfl_xor((uint32_t)(m >> 32), off);
             const uint64_t o = ((uint64_t)hi << 32) | lo;
@@ -481,24 +503,42 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const uint64_t* __rest
         __syncthreads();
         if (threadIdx.x == 0) {
             uint64_t b = ~0ull;
-            for (uint32_t w = 0; w < blockDim.x / 64; ++w) b = red[w] < b ? red[w] : b;
-            last_pick = b;
-            out[r] = b;
+            for (int w = 0; w < kMergeThreads / 64; ++w) b = red[w] < b ? red[w] : b;
+            pick = b;
+            out[(size_t)blockIdx.x * k + r] = b;
         }
         __syncthreads();
-        last = last_pick;
+        last = pick;
         have_last = true;
-        if (last == ~0ull) {  // fewer than k entries: the rest stay empty
-            for (uint32_t i = r + 1 + threadIdx.x; i < k; i += blockDim.x) out[i] = ~0ull;
+        if (last == ~0ull) {  // fewer than k entries in this slice: the rest stay empty
+            for (uint32_t i = r + 1 + threadIdx.x; i < k; i += kMergeThreads) out[(size_t)blockIdx.x * k + i] = ~0ull;
             break;
         }
     }
 }
 
-hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* out, hipStream_t stream)
+// keys: n entries; scratch: room for ceil(n / 4096) * k entries; the final k keys land in `out`
+hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* scratch, uint64_t* out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(1024), 0, stream, keys, n, k, out);
-    return hipGetLastError();
+    const uint64_t* src = keys;
+    uint64_t* bufs[2] = {scratch, scratch + (size_t)((n + kMergeSlice - 1) / kMergeSlice) * k};
+    int flip = 0;
+    for (;;) {
+        const uint32_t groups = (n + kMergeSlice - 1) / kMergeSlice;
+        uint64_t* dst = groups == 1 ? out : bufs[flip];
+        hipLaunchKernelGGL(topk_reduce_kernel, dim3(groups), dim3(kMergeThreads), 0, stream, src, n, k, dst);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || groups == 1) return e;
+        src = dst;
+        n = groups * k;
+        flip ^= 1;
+    }
+}
+
+size_t topk_merge_scratch_entries(uint32_t n, uint32_t k)
+{
+    const size_t g = (n + kMergeSlice - 1) / kMergeSlice;
+    return 2 * g * k;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,52 @@
+// Compiles the C++ facade against librfgpu.so.  Without a GPU it checks the handle/PM plumbing and that scoring
+// fails loudly; with a GPU (argv[1] == "gpu") it runs the reference's doc examples through the kernels.
+#include <cstdio>
+#include <cstring>
+
+#include "rapidfuzz_amd.hpp"
+
+using namespace rapidfuzz;
+
+#define EXPECT(c)                                                  \
+    do {                                                           \
+        if (!(c)) {                                                \
+            std::printf("FAILED %s:%d %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                              \
+        }                                                          \
+    } while (0)
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    distance::levenshtein::BatchComparator scorer("kitten");
+    size_t blocks = 0;
+    const uint64_t* pm = rf_comparator_pm(scorer.handle(), &blocks);
+    EXPECT(blocks == 1 && pm['t'] == 0b001100 && pm['k'] == 1);
+    distance::levenshtein::BatchComparator copy(scorer);  // Clone
+    EXPECT(rf_comparator_query_len(copy.handle()) == 6);
+    if (!gpu) {
+        if (rf_device_count() == 0) {
+            try {
+                scorer.distance("sitting");
+                return 1;  // must not silently compute anywhere else
+            } catch (const Error& e) {
+                EXPECT(e.status == RF_ERR_NO_DEVICE);
+            }
+        }
+        std::printf("facade ok (cpu)\n");
+        return 0;
+    }
+    // src/lib.rs:32-71 doc examples
+    EXPECT(distance::levenshtein::distance("kitten", "sitting") == 3);
+    EXPECT(!distance::levenshtein::distance_with_args("kitten", "sitting", distance::levenshtein::Args<size_t>{}.score_cutoff(2)));
+    EXPECT(scorer.distance("kitten") == 0);
+    Corpus corpus({"sitting", "mitten", "kitchen", ""});
+    auto d = scorer.distance_many(corpus, distance::levenshtein::Args<size_t>{}.score_cutoff(2));
+    EXPECT(!d[0] && *d[1] == 1 && *d[2] == 2 && !d[3]);
+    EXPECT(distance::indel::distance("lewenstein", "levenshtein") == 3);
+    EXPECT(distance::lcs_seq::similarity("lewenstein", "levenshtein") == 9);
+    EXPECT(std::fabs(distance::jaro::similarity("james", "robert") - 0.455556) < 1e-4);
+    EXPECT(std::fabs(fuzz::ratio("this is a test", "this is a test!") - 28.0 / 29.0) < 1e-12);
+    std::printf("facade ok (gpu)\n");
+    return 0;
+}
