@@ -55,10 +55,12 @@ def main():
     from rapidfuzz_rs_amd.utils import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    force_dist = os.environ.get("RF_BENCH_FORCE_DIST") == "1"  # exercise the collective path at world size 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
@@ -113,19 +115,40 @@ def main():
     def step():
         if is_f64:  # BASELINE.json configs[3]: similarity, f64 per candidate
             scorer.similarity_many(corpus, call_args, out=out, stream=stream.cuda_stream)
-        elif args.mode == "many" and world == 1:
+        elif args.mode == "many" and world == 1 and not force_dist:
             scorer.distance_many(corpus, call_args, out=out, stream=stream.cuda_stream)
         else:
-            # one pass: per-shard top-k under (distance, global index) [+ every candidate's distance, which stays
-            # on its GPU], then the k-entry all-gather over RCCL/xGMI and the merge -- the only exchange on the path
-            s_, i_ = scorer.topk(corpus, args.topk, N.OP_DISTANCE, call_args, index_base=rank * n,
-                                 out=out if args.mode == "many" else None, stream=stream.cuda_stream)
-            last_topk[0] = parallel.allgather_topk(s_, i_, args.topk, N.OP_DISTANCE, device=dev) if world > 1 else (s_, i_)
+            # one pass: per-shard top-k under (distance, global index) [+ every candidate's distance, which stays on
+            # its GPU]; then the ONLY exchange on the path: the k-entry all-gather (RCCL over xGMI) and the merge.
+            # Everything is stream-ordered on the device -- no host round trip inside a step.
+            buf = step_no[0] & 1
+            step_no[0] += 1
+            scorer.topk_keys_device(corpus, args.topk, local_keys[buf], N.OP_DISTANCE, call_args, index_base=rank * n,
+                                    out=out if args.mode == "many" else None, stream=stream.cuda_stream)
+            if world > 1 or force_dist:
+                finish_exchange()  # merge the PREVIOUS step's gather: it ran on RCCL's stream under this step's scan
+                pending[0] = (dist.all_gather_into_tensor(all_keys[buf], local_keys[buf], async_op=True), buf)
+            else:
+                last_topk[0] = local_keys[buf][: args.topk]
+
+    def finish_exchange():
+        if pending[0] is None:
+            return
+        work, buf = pending[0]
+        pending[0] = None
+        work.wait()
+        last_topk[0] = parallel.merge_keys_device(all_keys[buf], args.topk, merged_keys)  # one small kernel
+
+    step_no, pending = [0], [None]
+    merged_keys = torch.empty(args.topk, dtype=torch.int64, device=dev)
+    local_keys = [torch.empty(args.topk, dtype=torch.int64, device=dev) for _ in range(2)]
+    all_keys = [torch.empty(args.topk * max(world, 1), dtype=torch.int64, device=dev) for _ in range(2)]
 
     for _ in range(args.warmup):
         step()
+    finish_exchange()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -135,14 +158,15 @@ def main():
         ev[s][0].record(stream)
         step()
         ev[s][1].record(stream)
+    finish_exchange()  # the last step's gather + merge is inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -151,7 +175,7 @@ def main():
         kernel_ms = float(km.item())
 
     if rank != 0:
-        if world > 1:
+        if world > 1 or force_dist:
             dist.destroy_process_group()
         return
 
@@ -192,15 +216,18 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": measured_traffic(args, n),
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_pair": bytes_per_pair,
         },
     }
 
     if last_topk[0] is not None:
-        result["config"]["topk_found"] = int(len(last_topk[0][0]))
-        result["config"]["topk_best"] = [int(x) for x in last_topk[0][0][:4]]
+        # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,
+        # and empty entries (all ones = -1) are dropped here
+        keys = [int(x) for x in last_topk[0].cpu().tolist() if x not in (-1, 2**63 - 1)]
+        result["config"]["topk_found"] = len(keys)
+        result["config"]["topk_best"] = [[k >> 32, k & 0xFFFFFFFF] for k in sorted(keys)[:4]]
     if host_sample is not None and args.mode == "many":
         result["cpu_baseline"] = cpu_baseline(args, q, host_sample)
         # parity on the sample, in the same run
@@ -218,8 +245,21 @@ def main():
             bad = got != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
         result["parity"] = {"checked": int(chk), "mismatches": int(bad.sum())}
     print(json.dumps(result))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def measured_traffic(args, n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload
+    (profiles/traffic.json, written by tools/rocpd_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs with the
+    gfx950 2x FETCH_SIZE correction of MI355X_MICROARCH.md).  None when no profile matches the workload."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except OSError:
+        return None
+    key = f"{args.metric}:q{args.query_len}:n{n}:l{args.cand_len}:cut{args.cutoff}:{args.mode}"
+    e = table.get(key)
+    return None if e is None else {"bytes_per_launch": e["total"], "read": e["read"], "write": e["write"], "source": e.get("source", "")}
 
 
 def cpu_baseline(args, q, host_sample):

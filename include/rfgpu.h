@@ -173,6 +173,18 @@ rf_status rf_many_f64(const rf_comparator *c, const rf_corpus *corpus, rf_op op,
 rf_status rf_topk_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint32_t k,
                       uint64_t index_base, uint32_t *out_score, uint64_t *out_index, uint32_t *out_count,
                       uint32_t *out_all, rf_mem out_all_mem, void *stream);
+/* Fully asynchronous variant for pipelines that stay on the device (e.g. an RCCL all-gather right after):
+ * writes k 64-bit keys to DEVICE memory, best first, empty entries = UINT64_MAX.
+ *   key = (score << 32) | (index_base + index)             for RF_OP_DISTANCE   (ascending = best first)
+ *   key = (~score << 32) | (index_base + index)            for RF_OP_SIMILARITY
+ * so keys from different shards of one corpus merge by a plain unsigned sort.  index_base + n must fit 32 bits. */
+rf_status rf_topk_keys_device(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint32_t k,
+                              uint32_t index_base, uint64_t *d_keys_out, uint32_t *out_all, rf_mem out_all_mem,
+                              void *stream);
+/* Device-side merge of n such keys (e.g. the all-gathered lists of all ranks) into the k smallest, best first;
+ * asynchronous on `stream`.  d_out may not alias d_keys. */
+rf_status rf_topk_merge_keys_device(const uint64_t *d_keys, uint32_t n, uint32_t k, uint64_t *d_out, int device,
+                                    void *stream);
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t *scores, const uint64_t *indices, const uint32_t *counts,
                             uint32_t lists, uint32_t k, uint32_t *out_score, uint64_t *out_index,
                             uint32_t *out_count);

@@ -194,6 +194,20 @@ class BatchComparator:
                                     C.byref(cnt), out_ptr, out_mem, stream))
         return scores[: cnt.value], idx[: cnt.value]
 
+    def topk_keys_device(self, corpus: Corpus, k: int, keys_out, op: int = N.OP_DISTANCE, args: Optional[Args] = None,
+                         index_base: int = 0, out=None, stream=None, **kw):
+        """Asynchronous top-k that never leaves the device: fills `keys_out` (CUDA int64 tensor, >= k entries)
+        with (score << 32 | index_base + index) keys, best first, -1 = empty (rf_topk_keys_device)."""
+        import torch
+
+        a = _mk_args(args, kw.get("score_cutoff"), kw.get("score_hint"), kw.get("weights"), kw.get("prefix_weight"))
+        ca = a.to_c(False)
+        assert keys_out.is_cuda and keys_out.dtype == torch.int64 and keys_out.numel() >= k and keys_out.is_contiguous()
+        st = stream if stream is not None else torch.cuda.current_stream(keys_out.device).cuda_stream
+        out_ptr, out_mem = (None, N.MEM_HOST) if out is None else (out.data_ptr(), N.MEM_DEVICE)
+        N.check(N.lib().rf_topk_keys_device(self._h, corpus._h, op, C.byref(ca), k, index_base, keys_out.data_ptr(), out_ptr, out_mem, st))
+        return keys_out
+
     # ------------------------------------------------------------------ the reference's per-candidate methods
     def _one(self, op: int, s2, args, kw):
         corpus = Corpus.from_list([s2], device=default_device())

@@ -581,21 +581,17 @@ rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
 // ---------------------------------------------------------------------------------------------------
 // top-k
 // ---------------------------------------------------------------------------------------------------
-rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
-                      uint64_t index_base, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count,
-                      uint32_t* out_all, rf_mem out_all_mem, void* stream)
+// shared by rf_topk_u32 (host results) and rf_topk_keys_device (device keys, fully asynchronous)
+static rf_status topk_core(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
+                           uint32_t key_index_base, uint64_t* d_best /*device, k entries*/, uint32_t* out_all,
+                           rf_mem out_all_mem, hipStream_t st, bool* desc)
 {
-    if (!out_score || !out_index || !out_count || k == 0) {
-        set_error("rf_topk_u32: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    *out_count = 0;
-    if (k > (uint32_t)kWave) {
-        set_error("rf_topk_u32: k above 64 is not supported (one list entry per wavefront lane)");
-        return RF_ERR_UNSUPPORTED;
+    if (k == 0 || k > (uint32_t)kWave) {
+        set_error("top-k: k must be in 1..64 (one list entry per wavefront lane)");
+        return k == 0 ? RF_ERR_INVALID_ARG : RF_ERR_UNSUPPORTED;
     }
     if (op != RF_OP_DISTANCE && op != RF_OP_SIMILARITY) {
-        set_error("rf_topk_u32: op must be RF_OP_DISTANCE or RF_OP_SIMILARITY");
+        set_error("top-k: op must be RF_OP_DISTANCE or RF_OP_SIMILARITY");
         return RF_ERR_INVALID_ARG;
     }
     ScanParams p;
@@ -603,29 +599,23 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     rf_status s = plan(c, corpus, op, args, false, &p, &raw);
     if (s != RF_OK) return s;
     if (raw == RAW_JARO) {
-        set_error("rf_topk_u32: usize-valued metrics only");
+        set_error("top-k: usize-valued metrics only");
         return RF_ERR_INVALID_ARG;
     }
-    if (corpus->n == 0) return RF_OK;
-    DeviceGuard guard(corpus->device);
-    if (!guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
-    }
+    *desc = op == RF_OP_SIMILARITY;
     s = comparator_device_pm(c, corpus->device, &p.pm);
     if (s != RF_OK) return s;
-
-    hipStream_t st = (hipStream_t)stream;
     const int grid = scan_grid(corpus->n_tiles);
-    // one stream-ordered allocation: [workgroup lists | merge scratch | final k keys]
+    // one stream-ordered allocation: [workgroup lists | merge scratch | shared pruning bound]
     const size_t n_keys = (size_t)grid * k, n_scratch = topk_merge_scratch_entries((uint32_t)n_keys, k);
     uint64_t* d_keys = nullptr;
-    RF_HIP(hipMallocAsync((void**)&d_keys, (n_keys + n_scratch + k) * sizeof(uint64_t), st));
-    uint64_t* d_scratch = d_keys + n_keys;
-    uint64_t* d_best = d_scratch + n_scratch;
+    RF_HIP(hipMallocAsync((void**)&d_keys, (n_keys + n_scratch + 1) * sizeof(uint64_t), st));
+    p.topk_bound = d_keys + n_keys + n_scratch;
+    RF_HIP(hipMemsetAsync(p.topk_bound, 0xFF, sizeof(uint64_t), st));
     p.topk_k = k;
-    p.topk_desc = op == RF_OP_SIMILARITY;
+    p.topk_desc = *desc;
     p.topk_keys = d_keys;
+    p.key_index_base = key_index_base;
     // optionally also emit every candidate's score from the same pass (they stay sharded)
     uint32_t* d_all = out_all;
     if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
@@ -635,11 +625,41 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         (void)hipFreeAsync(d_all, st);
     }
-    if (e == hipSuccess) e = launch_topk_merge(d_keys, (uint32_t)n_keys, k, d_scratch, d_best, st);
-    std::vector<uint64_t> best(k, ~0ull);
-    if (e == hipSuccess) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = launch_topk_merge(d_keys, (uint32_t)n_keys, k, d_keys + n_keys, d_best, st);
     (void)hipFreeAsync(d_keys, st);
+    if (e != hipSuccess) {
+        set_error(std::string("top-k: ") + hipGetErrorString(e));
+        return RF_ERR_HIP;
+    }
+    return RF_OK;
+}
+
+rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
+                      uint64_t index_base, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count,
+                      uint32_t* out_all, rf_mem out_all_mem, void* stream)
+{
+    if (!out_score || !out_index || !out_count || !c || !corpus) {
+        set_error("rf_topk_u32: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    *out_count = 0;
+    if (corpus->n == 0) return k >= 1 && k <= (uint32_t)kWave ? RF_OK : RF_ERR_INVALID_ARG;
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t* d_best = nullptr;
+    RF_HIP(hipMallocAsync((void**)&d_best, (size_t)kWave * sizeof(uint64_t), st));
+    bool desc = false;
+    rf_status s = topk_core(c, corpus, op, args, k, 0, d_best, out_all, out_all_mem, st, &desc);
+    std::vector<uint64_t> best(kWave, ~0ull);
+    hipError_t e = hipSuccess;
+    if (s == RF_OK) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    (void)hipFreeAsync(d_best, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (s != RF_OK) return s;
     if (e != hipSuccess) {
         set_error(std::string("top-k: ") + hipGetErrorString(e));
         return RF_ERR_HIP;
@@ -647,10 +667,57 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     uint32_t m = 0;
     for (; m < k && best[m] != ~0ull; ++m) {
         const uint32_t hi = (uint32_t)(best[m] >> 32);
-        out_score[m] = p.topk_desc ? ~hi : hi;
+        out_score[m] = desc ? ~hi : hi;
         out_index[m] = index_base + (uint32_t)best[m];
     }
     *out_count = m;
+    return RF_OK;
+}
+
+rf_status rf_topk_keys_device(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
+                              uint32_t index_base, uint64_t* d_keys_out, uint32_t* out_all, rf_mem out_all_mem,
+                              void* stream)
+{
+    if (!d_keys_out || !c || !corpus) {
+        set_error("rf_topk_keys_device: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    if ((uint64_t)index_base + corpus->n > 0xFFFFFFFFull) {
+        set_error("rf_topk_keys_device: index_base + n must fit 32 bits (use rf_topk_u32 for larger index spaces)");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (corpus->n == 0) {
+        RF_HIP(hipMemsetAsync(d_keys_out, 0xFF, (size_t)k * sizeof(uint64_t), st));
+        return RF_OK;
+    }
+    bool desc = false;
+    return topk_core(c, corpus, op, args, k, index_base, d_keys_out, out_all, out_all_mem, st, &desc);
+}
+
+rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t k, uint64_t* d_out, int device, void* stream)
+{
+    if (!d_keys || !d_out || k == 0 || k > (uint32_t)kWave || n == 0) {
+        set_error("rf_topk_merge_keys_device: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return RF_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n_scratch = topk_merge_scratch_entries(n, k);
+    uint64_t* d_scratch = nullptr;
+    RF_HIP(hipMallocAsync((void**)&d_scratch, std::max<size_t>(1, n_scratch) * sizeof(uint64_t), st));
+    hipError_t e = launch_topk_merge(d_keys, n, k, d_scratch, d_out, st);
+    (void)hipFreeAsync(d_scratch, st);
+    if (e != hipSuccess) {
+        set_error(std::string("top-k merge: ") + hipGetErrorString(e));
+        return RF_ERR_HIP;
+    }
     return RF_OK;
 }
 

@@ -69,7 +69,9 @@ struct ScanParams {
     // top-k mode (topk_k != 0): no per-candidate output, one k-entry key list per workgroup
     uint32_t topk_k;       // <= 64
     uint32_t topk_desc;    // 1: larger score is better (similarity)
-    uint64_t* topk_keys;   // [grid][k], key = (score or ~score) << 32 | local index, ~0 = empty
+    uint32_t key_index_base;  // added to the local index inside the key (rf_topk_keys_device)
+    uint64_t* topk_bound;  // one u64, initialised to ~0: launch-wide upper bound on the k-th best key
+    uint64_t* topk_keys;   // [grid][k], key = (score or ~score) << 32 | (key_index_base + local index), ~0 = empty
 };
 
 // kernels (rf_kernels.hip)

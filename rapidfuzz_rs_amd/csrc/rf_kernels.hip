@@ -260,11 +260,13 @@ struct WaveTopK {
         const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
         key = lane > pos ? up : (lane == pos ? x : key);
     }
-    // offer one key per lane (valid lanes only); k is the list length
-    __device__ __forceinline__ void offer(uint64_t mine, bool valid, uint32_t k, uint32_t lane)
+    // offer one key per lane (valid lanes only); k is the list length; `bound` is any upper bound on the k-th best
+    // key of the whole launch (keys above it can never be in the answer)
+    __device__ __forceinline__ void offer(uint64_t mine, bool valid, uint32_t k, uint32_t lane, uint64_t bound)
     {
-        uint64_t m = __ballot(valid && mine < worst(k));
-        while (m) {  // rare after the first few tiles: expected k * ln(N / k) insertions per wavefront
+        const uint64_t w0 = worst(k);
+        uint64_t m = __ballot(valid && mine < (w0 < bound ? w0 : bound));
+        while (m) {  // rare: expected k * ln(N / k) insertions over the whole launch thanks to the shared bound
             const uint32_t l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine, l), hi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), l);
@@ -357,10 +359,8 @@ __device__ __forceinline__ TileView load_tile(const ScanParams& p, uint32_t t)
 }
 
 template <class State, int W, bool kUniform>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanParams p)
+__device__ __forceinline__ void scan_body(const ScanParams& p, uint64_t* lds_pm, uint64_t (*lds_topk)[kWave])
 {
-    __shared__ uint64_t lds_pm[256 * W];
-    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
     for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock) lds_pm[i] = p.pm[i];
     __syncthreads();
 
@@ -445,8 +445,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
             if (topk && !dead) {
                 bool keep;
                 const uint32_t v = usize_value(p, raw, len2, &keep);
-                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | idx;
-                best.offer(mine, valid && keep, p.topk_k, lane);
+                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
+                // Launch-wide pruning bound: once ANY wavefront holds k keys, its worst key bounds the global k-th
+                // best.  Wavefronts publish that with a 64-bit atomic min and read it (possibly stale = merely
+                // conservative) before offering, so freshly started wavefronts skip the k*ln(n) warm-up insertions.
+                const uint64_t bound = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t before = best.worst(p.topk_k);
+                best.offer(mine, valid && keep, p.topk_k, lane, bound);
+                const uint64_t after = best.worst(p.topk_k);
+                if (after < before && after < bound && lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)after);
             }
 
             if (!has_next) break;
@@ -467,6 +474,24 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
             if (lane < p.topk_k) p.topk_keys[(size_t)blockIdx.x * p.topk_k + lane] = best.key;
         }
     }
+}
+
+// Two entry points over the same body: the single-word kernels are pinned to 8 wavefronts per SIMD (otherwise the
+// scalar state of the tile loop pushes them to 96 SGPRs = 7 resident workgroups per CU); W >= 2 keeps the
+// compiler's own register budget (forcing 8 would spill VGPRs).
+template <class State, int W, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanParams p)
+{
+    __shared__ uint64_t lds_pm[256 * W];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    scan_body<State, W, kUniform>(p, lds_pm, lds_topk);
+}
+template <class State, int W, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan_kernel_occ8(const ScanParams p)
+{
+    __shared__ uint64_t lds_pm[256 * W];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    scan_body<State, W, kUniform>(p, lds_pm, lds_topk);
 }
 
 // Reduction of many k-entry lists to k entries, in stages: every workgroup takes a slice of <= 4096 keys (4 per
@@ -801,10 +826,17 @@ int scan_max_grid()
 template <template <int> class StateT, int W>
 static hipError_t launch_one(const ScanParams& p, hipStream_t stream, int grid)
 {
-    if (p.tiles)
-        hipLaunchKernelGGL((scan_kernel<StateT<W>, W, false>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
-    else
-        hipLaunchKernelGGL((scan_kernel<StateT<W>, W, true>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+    if constexpr (W == 1) {
+        if (p.tiles)
+            hipLaunchKernelGGL((scan_kernel_occ8<StateT<W>, W, false>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+        else
+            hipLaunchKernelGGL((scan_kernel_occ8<StateT<W>, W, true>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+    } else {
+        if (p.tiles)
+            hipLaunchKernelGGL((scan_kernel<StateT<W>, W, false>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+        else
+            hipLaunchKernelGGL((scan_kernel<StateT<W>, W, true>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

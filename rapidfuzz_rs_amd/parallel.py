@@ -62,3 +62,14 @@ def sharded_topk(scorer, shard_corpus, k: int, shard_start: int, op: int = N.OP_
     then the k-entry all-gather.  Every rank returns the same (scores, global indices)."""
     s, i = scorer.topk(shard_corpus, k, op, args, index_base=shard_start, out=out, **kw)
     return allgather_topk(s, i, k, op, group=group, device=device)
+
+
+def merge_keys_device(all_keys, k: int, out, stream=None):
+    """Device-side merge of all-gathered rf_topk_keys_device lists (CUDA int64 tensors): the k smallest keys of
+    `all_keys` into `out`, best first, -1 = empty; asynchronous on torch's current stream."""
+    import torch
+
+    assert all_keys.is_cuda and out.is_cuda and all_keys.dtype == torch.int64 and out.dtype == torch.int64 and out.numel() >= k
+    st = stream if stream is not None else torch.cuda.current_stream(all_keys.device).cuda_stream
+    N.check(N.lib().rf_topk_merge_keys_device(all_keys.data_ptr(), all_keys.numel(), k, out.data_ptr(), all_keys.device.index or 0, st))
+    return out

@@ -329,6 +329,38 @@ def test_topk_ragged(metric, k):
             assert gs.tolist() == es.tolist() and gi.tolist() == (ei + np.uint64(1000)).tolist(), (metric, k, op, cutoff)
 
 
+def test_topk_keys_device_async():
+    import torch
+
+    q = synth.query(64, 31)
+    rows = synth.rows_device(300_000, 64, seed=32)
+    host = rows.cpu().numpy()
+    synth.plant_near_duplicates(host, q, every=10_007, seed=4)
+    corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
+    bc = GPU["levenshtein"].BatchComparator(q)
+    keys = torch.empty(16, dtype=torch.int64, device="cuda")
+    out = torch.empty(300_000, dtype=torch.int32, device="cuda")
+    for cutoff in (None, 3):
+        kw = {} if cutoff is None else {"score_cutoff": cutoff}
+        bc.topk_keys_device(corpus, 16, keys, index_base=5_000_000, out=out, **kw)
+        torch.cuda.synchronize()
+        vals = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=8, **kw)
+        es, ei = _oracle_topk(vals, 16, False)
+        exp = [(int(s_) << 32) | (int(i_) + 5_000_000) for s_, i_ in zip(es, ei)]
+        got = [k for k in keys.cpu().tolist() if k != -1]
+        assert got == exp
+        assert (out.cpu().numpy().view(np.uint32) == _expect_u32(vals)).all()
+        # device-side merge of several gathered lists (here: this list, an empty one, and a shifted copy)
+        from rapidfuzz_rs_amd import parallel
+
+        other = torch.where(keys < 0, keys, keys + (7 << 32))
+        gathered = torch.cat([other, torch.full((16,), -1, dtype=torch.int64, device="cuda"), keys])
+        merged = parallel.merge_keys_device(gathered, 16, torch.empty(16, dtype=torch.int64, device="cuda"))
+        torch.cuda.synchronize()
+        both = sorted(k for k in gathered.cpu().tolist() if k != -1)[:16]
+        assert [k for k in merged.cpu().tolist() if k != -1] == both
+
+
 def test_topk_small_and_empty_corpora():
     q = b"kitten"
     for cands in ([], [b"sitting"], [b"mitten", b"", b"kitten", b"kitchen", b"smitten"]):

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--match", default="scan_kernel")
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--traffic-key", default=None, help="also record the HBM traffic under this key in --traffic-json")
+    ap.add_argument("--traffic-json", default="profiles/traffic.json")
     a = ap.parse_args()
     lines, summary = [], {"note": a.note}
     if a.kernel_trace:
@@ -45,6 +47,15 @@ def main():
             wr = counters.get("WRITE_SIZE", 0) * 1024
             summary["hbm_traffic_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr, "correction": "read = 2 x FETCH_SIZE KiB (gfx950 wide-stream undercount), write = WRITE_SIZE KiB"}
             lines.append(f"== HBM traffic per launch: read {rd/1e9:.3f} GB (2 x FETCH_SIZE), write {wr/1e9:.3f} GB, total {(rd+wr)/1e9:.3f} GB")
+    if a.traffic_key and "hbm_traffic_bytes_per_launch" in summary:
+        try:
+            table = json.load(open(a.traffic_json))
+        except (OSError, ValueError):
+            table = {}
+        e = dict(summary["hbm_traffic_bytes_per_launch"])
+        e["source"] = a.out + ".json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        table[a.traffic_key] = e
+        json.dump(table, open(a.traffic_json, "w"), indent=1, sort_keys=True)
     open(a.out + ".txt", "w").write("\n".join(lines) + "\n")
     json.dump(summary, open(a.out + ".json", "w"), indent=1)
     print("\n".join(lines))
