@@ -146,6 +146,10 @@ const uint64_t* rf_comparator_pm(const rf_comparator* c, size_t* block_count)
     return c->pm.data();
 }
 
+// row stride (in u64) of the device PM table: the word count, or for patterns beyond the register-resident kernels
+// the word count rounded up to whole groups of 8
+static size_t pm_stride(const rf_comparator* c) { return c->words <= (size_t)kMaxWords ? c->words : (c->words + 7) / 8 * 8; }
+
 static rf_status comparator_device_pm(const rf_comparator* c, int device, const uint64_t** d_out)
 {
     std::lock_guard<std::mutex> lock(c->mu);
@@ -155,8 +159,16 @@ static rf_status comparator_device_pm(const rf_comparator* c, int device, const 
         return RF_OK;
     }
     uint64_t* d = nullptr;
-    RF_HIP(hipMalloc(&d, c->pm.size() * sizeof(uint64_t)));
-    RF_HIP(hipMemcpy(d, c->pm.data(), c->pm.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const size_t stride = pm_stride(c);
+    if (stride == c->words) {
+        RF_HIP(hipMalloc(&d, c->pm.size() * sizeof(uint64_t)));
+        RF_HIP(hipMemcpy(d, c->pm.data(), c->pm.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    } else {  // long pattern: rows padded with zero words to a whole number of 8-word groups
+        std::vector<uint64_t> padded(256 * stride, 0);
+        for (size_t ch = 0; ch < 256; ++ch) std::memcpy(&padded[ch * stride], &c->pm[ch * c->words], c->words * sizeof(uint64_t));
+        RF_HIP(hipMalloc(&d, padded.size() * sizeof(uint64_t)));
+        RF_HIP(hipMemcpy(d, padded.data(), padded.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
     c->d_pm[device] = d;
     *d_out = d;
     return RF_OK;
@@ -401,7 +413,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
     std::memset(p, 0, sizeof(*p));
     p->len1 = (uint32_t)c->s1.size();
-    p->words = (uint32_t)c->words;
+    p->words = (uint32_t)pm_stride(c);  // row stride of the device table
     p->op = (uint32_t)op;
     p->out_f64 = f64_out ? 1 : 0;
     p->factor = 1;
@@ -513,8 +525,18 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
 
     if (c->words > (size_t)kMaxWords) {
-        set_error("query longer than 512 symbols: no register-resident kernel (RF_ERR_UNSUPPORTED)");
-        return RF_ERR_UNSUPPORTED;
+        // beyond 512 symbols: the multi-sweep kernel (8 words per sweep, carries parked in an HBM scratch strip)
+        if (c->words > 0x00FFFFFFu) {
+            set_error("query too long");
+            return RF_ERR_UNSUPPORTED;
+        }
+        p->long_words_pad = (uint32_t)pm_stride(c);
+        p->long_chunks_max = (corpus->max_len + kChunk - 1) / kChunk;
+        const uint64_t strip_bytes = std::max<uint64_t>(1, (uint64_t)p->long_chunks_max * kWave * sizeof(uint32_t));
+        const uint64_t budget = 256ull << 20;
+        const uint64_t waves = std::max<uint64_t>(kWavesPerBlock, budget / strip_bytes);
+        p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves / kWavesPerBlock, (uint64_t)scan_grid(corpus->n_tiles)));
+        return RF_OK;
     }
     // Value-preserving early-out for a Levenshtein distance cutoff that can actually prune something
     // (the reference only applies the cutoff after its loop, levenshtein.rs:492-496).
@@ -553,7 +575,12 @@ static rf_status run_many(const rf_comparator* c, const rf_corpus* corpus, rf_op
     void* d_out = out;
     if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
     p.out = d_out;
+    if (p.long_words_pad) {
+        const size_t scratch = (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t);
+        RF_HIP(hipMallocAsync((void**)&p.long_scratch, scratch, st));
+    }
     hipError_t e = launch_scan(raw, p, st, nullptr);
+    if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
     if (e == hipSuccess && out_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -601,6 +628,10 @@ static rf_status topk_core(const rf_comparator* c, const rf_corpus* corpus, rf_o
     if (raw == RAW_JARO) {
         set_error("top-k: usize-valued metrics only");
         return RF_ERR_INVALID_ARG;
+    }
+    if (p.long_words_pad) {
+        set_error("top-k: queries longer than 512 symbols are served by rf_many_* only");
+        return RF_ERR_UNSUPPORTED;
     }
     *desc = op == RF_OP_SIMILARITY;
     s = comparator_device_pm(c, corpus->device, &p.pm);

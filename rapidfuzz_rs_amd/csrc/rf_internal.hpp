@@ -63,6 +63,11 @@ struct ScanParams {
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
     double cutoff_f64;
     double prefix_weight;
+    // patterns longer than kMaxWords * 64 symbols (long_kernel): PM rows padded to long_words_pad (multiple of 8)
+    uint32_t long_words_pad;  // 0 = register-resident kernels
+    uint32_t long_chunks_max; // scratch strip length per wavefront, in 16-column chunks
+    uint32_t long_grid;       // workgroups (bounded by the scratch budget)
+    uint32_t* long_scratch;   // [grid * 4][long_chunks_max][64]
     // value-preserving early-out under a distance cutoff (levenshtein, u32 distance output / top-k)
     uint32_t early;
     uint32_t raw_cutoff;   // cutoff on the raw kernel distance: floor(cutoff / factor)

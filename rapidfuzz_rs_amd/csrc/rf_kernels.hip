@@ -33,6 +33,7 @@ __device__ __forceinline__ uint64_t lut3(uint64_t a, uint64_t b, uint64_t c)
 }
 constexpr uint32_t T_XOR_OR = (TA ^ TB) | TC;       // (a ^ b) | c
 constexpr uint32_t T_OR_NOR = TA | (~(TB | TC));    // a | ~(b | c)
+constexpr uint32_t T_OR_ANDN = TA | (TB & ~TC);      // a | (b & ~c)
 
 // (x << 1) | carry_in.  Measured on gfx950 (tools/microbench.hip, profiles/microbench_r01.txt): the 64-bit VALU
 // forms v_lshl_add_u64 / v_lshlrev_b64 issue at the same (half) rate as ONE v_alignbit_b32 / v_lshl_or_b32, so a
@@ -68,6 +69,8 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgc
 // ---------------------------------------------------------------------------------------------------
 template <int W>
 struct LevState {
+    using Word = uint64_t;
+    static constexpr int kWords = W;
     uint64_t vp[W], vn[W];
     __device__ __forceinline__ void init()
     {
@@ -100,6 +103,39 @@ struct LevState {
             vp[w] = lut3<T_OR_NOR>(hns, hps, d0);            // hn | ~(d0 | hp)                  (:868)
         }
     }
+    // the same column with the horizontal deltas entering word 0 / leaving word W-1 as variables: one 512-row
+    // group of a longer pattern (long_kernel); levenshtein.rs:838-875 with hp_carry / hn_carry crossing groups
+    __device__ __forceinline__ void step_carry(const uint64_t (&pm_row)[W], uint32_t& hp_c, uint32_t& hn_c)
+    {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t x = pm_row[w] | hn_c;
+            const uint64_t p = vp[w], n = vn[w];
+            const uint64_t sum = (x & p) + p;
+            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
+            const uint64_t d0 = e | n;
+            const uint64_t hn = e & p;
+            const uint64_t hp = lut3<T_OR_NOR>(n, d0, p);
+            const uint64_t hps = shl1_var(hp, hp_c);
+            const uint64_t hns = shl1_var(hn, hn_c);
+            hp_c = (uint32_t)(hp >> 63);
+            hn_c = (uint32_t)(hn >> 63);
+            vn[w] = hps & d0;
+            vp[w] = lut3<T_OR_NOR>(hns, hps, d0);
+        }
+    }
+    // popcount contribution of this group's words to D[len1][j]; word w is absolute word (word0 + w)
+    __device__ __forceinline__ int32_t delta_sum(uint32_t len1, uint32_t word0) const
+    {
+        int32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int32_t bits = (int32_t)len1 - 64 * (int32_t)(word0 + w);
+            const uint64_t valid = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1));
+            d += __popcll(vp[w] & valid) - __popcll(vn[w] & valid);
+        }
+        return d;
+    }
     // Early-out bound under a distance cutoff (the reference applies its cutoff only after the loop,
     // levenshtein.rs:492-496, so this is value-preserving pruning): adjacent cells of the last row differ by at
     // most 1, hence D[len1][len2] >= D[len1][j] - (len2 - j).  D[len1][j] comes from the same popcount identity
@@ -129,6 +165,8 @@ struct LevState {
 // ---------------------------------------------------------------------------------------------------
 template <int W>
 struct LcsState {
+    using Word = uint64_t;
+    static constexpr int kWords = W;
     uint64_t s[W];
     __device__ __forceinline__ void init()
     {
@@ -150,8 +188,28 @@ struct LcsState {
                 x = x2;
             }
             carry = c;
-            s[w] = x | (sw - u);  // lcs_seq.rs:230
+            // lcs_seq.rs:230 `x | (s - u)`: u is a subset of s, so the subtraction never borrows and
+            // s - u == s & ~u -- one v_bitop3 per half instead of a carry-chained 64-bit subtract
+            s[w] = lut3<T_OR_ANDN>(x, sw, u);
         }
+    }
+    // one group of a longer pattern: the adder carry enters word 0 and leaves word W-1 (lcs_seq.rs:313-318)
+    __device__ __forceinline__ void step_carry(const uint64_t (&pm_row)[W], uint32_t& carry_io)
+    {
+        uint64_t carry = carry_io;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t sw = s[w];
+            const uint64_t u = sw & pm_row[w];
+            uint64_t x = sw + u;
+            uint64_t c = x < sw;
+            const uint64_t x2 = x + carry;
+            c |= (uint64_t)(x2 < x);
+            x = x2;
+            carry = c;
+            s[w] = lut3<T_OR_ANDN>(x, sw, u);
+        }
+        carry_io = (uint32_t)carry;
     }
     static constexpr bool kCanPrune = false;
     __device__ __forceinline__ bool hopeless(uint32_t, uint32_t, uint32_t, uint32_t) const { return false; }
@@ -162,6 +220,66 @@ struct LcsState {
         for (int w = 0; w < W; ++w) sim += __popcll(~s[w]);  // lcs_seq.rs:254-257
         return sim;
     }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// 32-bit specialisations for queries of at most 32 symbols (BASELINE.json configs[0] shape, most real-world
+// names/titles): the same recurrences on ONE VGPR per bit-vector -- 10 instead of 18 VALU instructions per column
+// for Levenshtein -- reading the low half of each PM entry from a 1 KiB LDS table.
+// ---------------------------------------------------------------------------------------------------
+template <uint32_t TT>
+__device__ __forceinline__ uint32_t lut3w(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT & 0xFF);
+}
+
+struct Lev32State {
+    using Word = uint32_t;
+    static constexpr int kWords = 1;
+    uint32_t vp, vn;
+    __device__ __forceinline__ void init()
+    {
+        vp = ~0u;
+        vn = 0;
+    }
+    __device__ __forceinline__ void step(const uint32_t (&pm_row)[1])
+    {
+        const uint32_t x = pm_row[0];
+        const uint32_t sum = (x & vp) + vp;
+        const uint32_t e = lut3w<T_XOR_OR>(sum, vp, x);
+        const uint32_t d0 = e | vn;
+        const uint32_t hn = e & vp;
+        const uint32_t hp = lut3w<T_OR_NOR>(vn, d0, vp);
+        const uint32_t hps = (hp << 1) | 1u;
+        const uint32_t hns = hn << 1;
+        vn = hps & d0;
+        vp = lut3w<T_OR_NOR>(hns, hps, d0);
+    }
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    {
+        return (int32_t)result(len1, j) - (int32_t)(len2 - j) > (int32_t)raw_cutoff;
+    }
+    __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
+    {
+        const uint32_t valid = len1 >= 32 ? ~0u : ((1u << len1) - 1);
+        return (uint32_t)((int32_t)len2 + __popc(vp & valid) - __popc(vn & valid));
+    }
+};
+
+struct Lcs32State {
+    using Word = uint32_t;
+    static constexpr int kWords = 1;
+    uint32_t s;
+    __device__ __forceinline__ void init() { s = ~0u; }
+    __device__ __forceinline__ void step(const uint32_t (&pm_row)[1])
+    {
+        const uint32_t u = s & pm_row[0];
+        s = lut3w<T_OR_ANDN>(s + u, s, u);  // (s + u) | (s - u) with s - u == s & ~u
+    }
+    static constexpr bool kCanPrune = false;
+    __device__ __forceinline__ bool hopeless(uint32_t, uint32_t, uint32_t, uint32_t) const { return false; }
+    __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const { return __popc(~s); }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -279,34 +397,36 @@ struct WaveTopK {
 // ---------------------------------------------------------------------------------------------------
 // the scan kernel
 // ---------------------------------------------------------------------------------------------------
-// PM row of one symbol: W consecutive u64 in LDS (ds_read_b64 / ds_read_b128)
-template <int W>
-__device__ __forceinline__ void load_pm(uint64_t (&dst)[W], const uint64_t* lds_pm, uint32_t ch)
+// PM row of one symbol: W consecutive words in LDS (ds_read_b32 / ds_read_b64 / ds_read_b128)
+template <class Word, int W>
+__device__ __forceinline__ void load_pm(Word (&dst)[W], const Word* lds_pm, uint32_t ch)
 {
-    const uint64_t* row = lds_pm + ch * W;
+    const Word* row = lds_pm + ch * W;
 #pragma unroll
     for (int w = 0; w < W; ++w) dst[w] = row[w];
 }
 
 // 16 columns in groups of kGroup symbols.  The LDS reads of group g+1 are issued BEFORE the recurrence of group g
 // (pinned with sched_barrier, otherwise the scheduler sinks them back next to their first use), so their latency
-// -- including the 2-4 way bank conflicts of 64 random 8-byte slots -- hides behind ~18 VALU instructions per column.
-template <class State, int W, int J0 = 0, int J1 = kChunk>
-__device__ __forceinline__ void process_chunk_full(State& st, const uint64_t* lds_pm, const uint4& c)
+// -- including the 2-4 way bank conflicts of 64 random slots -- hides behind the VALU work of the current group.
+template <class State, int J0 = 0, int J1 = kChunk>
+__device__ __forceinline__ void process_chunk_full(State& st, const typename State::Word* lds_pm, const uint4& c)
 {
+    using Word = typename State::Word;
+    constexpr int W = State::kWords;
     constexpr int kGroup = W == 1 ? 4 : (W == 2 ? 2 : 1);
     constexpr int kGroups = (J1 - J0) / kGroup;
     const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
-    uint64_t cur[kGroup][W], nxt[kGroup][W];
+    Word cur[kGroup][W], nxt[kGroup][W];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) load_pm<W>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
+    for (int j = 0; j < kGroup; ++j) load_pm<Word, W>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
         if (g + 1 < kGroups) {
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
                 const int n = J0 + (g + 1) * kGroup + j;
-                load_pm<W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
+                load_pm<Word, W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -319,12 +439,14 @@ __device__ __forceinline__ void process_chunk_full(State& st, const uint64_t* ld
     }
 }
 
-template <class State, int W>
-__device__ __forceinline__ void process_chunk_tail(State& st, const uint64_t* lds_pm, uint4 c, uint32_t rem)
+template <class State>
+__device__ __forceinline__ void process_chunk_tail(State& st, const typename State::Word* lds_pm, uint4 c, uint32_t rem)
 {
+    using Word = typename State::Word;
+    constexpr int W = State::kWords;
     for (uint32_t j = 0; j < rem; ++j) {  // rem is wavefront-uniform (tile length)
-        uint64_t x[W];
-        load_pm<W>(x, lds_pm, c.x & 0xFFu);
+        Word x[W];
+        load_pm<Word, W>(x, lds_pm, c.x & 0xFFu);
         st.step(x);
         c.x = __builtin_amdgcn_alignbit(c.y, c.x, 8);
         c.y = __builtin_amdgcn_alignbit(c.z, c.y, 8);
@@ -358,10 +480,12 @@ __device__ __forceinline__ TileView load_tile(const ScanParams& p, uint32_t t)
     return v;
 }
 
-template <class State, int W, bool kUniform>
-__device__ __forceinline__ void scan_body(const ScanParams& p, uint64_t* lds_pm, uint64_t (*lds_topk)[kWave])
+template <class State, bool kUniform>
+__device__ __forceinline__ void scan_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
 {
-    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock) lds_pm[i] = p.pm[i];
+    constexpr int W = State::kWords;
+    // stage the PM table; the 32-bit states keep the low half of each (single-word) entry
+    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock) lds_pm[i] = (typename State::Word)p.pm[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -410,17 +534,17 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, uint64_t* lds_pm,
                 if (cols >= kChunk) {
                     if (early && c == 0) {
                         // first chance to stop: after 8 columns a random candidate is already ~6 edits off
-                        process_chunk_full<State, W, 0, kChunk / 2>(st, lds_pm, cur);
+                        process_chunk_full<State, 0, kChunk / 2>(st, lds_pm, cur);
                         if (__ballot(!st.hopeless(p.len1, kChunk / 2, len2, p.raw_cutoff)) == 0) {
                             dead = true;
                             break;
                         }
-                        process_chunk_full<State, W, kChunk / 2, kChunk>(st, lds_pm, cur);
+                        process_chunk_full<State, kChunk / 2, kChunk>(st, lds_pm, cur);
                     } else {
-                        process_chunk_full<State, W>(st, lds_pm, cur);
+                        process_chunk_full<State>(st, lds_pm, cur);
                     }
                 } else {
-                    process_chunk_tail<State, W>(st, lds_pm, cur, cols);
+                    process_chunk_tail<State>(st, lds_pm, cur, cols);
                 }
                 if (early) {
                     const uint32_t j = min(len2, (c + 1) * kChunk);
@@ -479,19 +603,19 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, uint64_t* lds_pm,
 // Two entry points over the same body: the single-word kernels are pinned to 8 wavefronts per SIMD (otherwise the
 // scalar state of the tile loop pushes them to 96 SGPRs = 7 resident workgroups per CU); W >= 2 keeps the
 // compiler's own register budget (forcing 8 would spill VGPRs).
-template <class State, int W, bool kUniform>
+template <class State, bool kUniform>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanParams p)
 {
-    __shared__ uint64_t lds_pm[256 * W];
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
-    scan_body<State, W, kUniform>(p, lds_pm, lds_topk);
+    scan_body<State, kUniform>(p, lds_pm, lds_topk);
 }
-template <class State, int W, bool kUniform>
+template <class State, bool kUniform>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan_kernel_occ8(const ScanParams p)
 {
-    __shared__ uint64_t lds_pm[256 * W];
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
-    scan_body<State, W, kUniform>(p, lds_pm, lds_topk);
+    scan_body<State, kUniform>(p, lds_pm, lds_topk);
 }
 
 // Reduction of many k-entry lists to k entries, in stages: every workgroup takes a slice of <= 4096 keys (4 per
@@ -564,6 +688,80 @@ size_t topk_merge_scratch_entries(uint32_t n, uint32_t k)
 {
     const size_t g = (n + kMergeSlice - 1) / kMergeSlice;
     return 2 * g * k;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Patterns longer than 512 symbols (the reference's hyrroe2003_block / lcs_blockwise territory,
+// levenshtein.rs:769-1019, lcs_seq.rs:267-341): the pattern is cut into groups of 8 words (512 rows).  A
+// wavefront sweeps the candidate once per group with that group's 16 bit-vectors in registers; the horizontal
+// deltas crossing the group boundary (2 bits per column and lane for Levenshtein, the adder carry for LCS) wait in
+// a chunk-interleaved HBM scratch strip between sweeps.  PM words come straight from global memory (the table of a
+// long pattern does not fit LDS; it is L2-resident).  Throughput path for completeness, not for the roofline.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLongGroup = 8;
+
+template <bool kLcs, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanParams p)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;  // global wavefront id: owns one scratch strip
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t words_pad = p.long_words_pad;
+    const uint32_t groups = words_pad / kLongGroup;
+    uint32_t* strip = p.long_scratch + (size_t)gw * p.long_chunks_max * kWave;
+
+    for (uint32_t t = gw; t < p.n_tiles; t += stride) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2 = tv.len;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        int32_t acc = 0;
+
+        for (uint32_t g = 0; g < groups; ++g) {
+            LevState<kLongGroup> lev;
+            LcsState<kLongGroup> lcs;
+            if (kLcs)
+                lcs.init();
+            else
+                lev.init();
+            for (uint32_t c = 0; c < nch; ++c) {
+                uint4 data = tv.src[(size_t)c * kWave + lane];
+                // carries entering word 0 of this group for the 16 columns of the chunk:
+                // bits 0..15 = hp (or the LCS adder carry), bits 16..31 = hn
+                uint32_t cin = g == 0 ? (kLcs ? 0u : 0x0000FFFFu) : strip[(size_t)c * kWave + lane];
+                uint32_t cout = 0;
+                const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+                for (uint32_t j = 0; j < cols; ++j) {
+                    const uint32_t ch = data.x & 0xFFu;
+                    const uint64_t* row = p.pm + (size_t)ch * words_pad + (size_t)g * kLongGroup;
+                    uint64_t x[kLongGroup];
+#pragma unroll
+                    for (int w = 0; w < kLongGroup; ++w) x[w] = row[w];
+                    if (kLcs) {
+                        uint32_t carry = (cin >> j) & 1u;
+                        lcs.step_carry(x, carry);
+                        cout |= carry << j;
+                    } else {
+                        uint32_t hp_c = (cin >> j) & 1u, hn_c = (cin >> (16 + j)) & 1u;
+                        lev.step_carry(x, hp_c, hn_c);
+                        cout |= (hp_c << j) | (hn_c << (16 + j));
+                    }
+                    data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                    data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                    data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                    data.w >>= 8;
+                }
+                if (g + 1 < groups) strip[(size_t)c * kWave + lane] = cout;
+            }
+            acc += kLcs ? (int32_t)lcs.result(0, 0) : lev.delta_sum(p.len1, g * kLongGroup);
+        }
+        const uint32_t raw = kLcs ? (uint32_t)acc : (uint32_t)((int32_t)len2 + acc);
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) emit_usize(p, raw, len2, idx);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -823,19 +1021,20 @@ int scan_max_grid()
     return 256 * per_cu;
 }
 
-template <template <int> class StateT, int W>
-static hipError_t launch_one(const ScanParams& p, hipStream_t stream, int grid)
+template <class State>
+static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid)
 {
-    if constexpr (W == 1) {
+    const dim3 g(grid), b(kWave * kWavesPerBlock);
+    if constexpr (State::kWords == 1) {
         if (p.tiles)
-            hipLaunchKernelGGL((scan_kernel_occ8<StateT<W>, W, false>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+            hipLaunchKernelGGL((scan_kernel_occ8<State, false>), g, b, 0, stream, p);
         else
-            hipLaunchKernelGGL((scan_kernel_occ8<StateT<W>, W, true>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+            hipLaunchKernelGGL((scan_kernel_occ8<State, true>), g, b, 0, stream, p);
     } else {
         if (p.tiles)
-            hipLaunchKernelGGL((scan_kernel<StateT<W>, W, false>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+            hipLaunchKernelGGL((scan_kernel<State, false>), g, b, 0, stream, p);
         else
-            hipLaunchKernelGGL((scan_kernel<StateT<W>, W, true>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+            hipLaunchKernelGGL((scan_kernel<State, true>), g, b, 0, stream, p);
     }
     return hipGetLastError();
 }
@@ -844,14 +1043,14 @@ template <template <int> class StateT>
 static hipError_t launch_words(const ScanParams& p, hipStream_t stream, int grid)
 {
     switch (p.words) {
-    case 1: return launch_one<StateT, 1>(p, stream, grid);
-    case 2: return launch_one<StateT, 2>(p, stream, grid);
-    case 3: return launch_one<StateT, 3>(p, stream, grid);
-    case 4: return launch_one<StateT, 4>(p, stream, grid);
-    case 5: return launch_one<StateT, 5>(p, stream, grid);
-    case 6: return launch_one<StateT, 6>(p, stream, grid);
-    case 7: return launch_one<StateT, 7>(p, stream, grid);
-    case 8: return launch_one<StateT, 8>(p, stream, grid);
+    case 1: return launch_state<StateT<1>>(p, stream, grid);
+    case 2: return launch_state<StateT<2>>(p, stream, grid);
+    case 3: return launch_state<StateT<3>>(p, stream, grid);
+    case 4: return launch_state<StateT<4>>(p, stream, grid);
+    case 5: return launch_state<StateT<5>>(p, stream, grid);
+    case 6: return launch_state<StateT<6>>(p, stream, grid);
+    case 7: return launch_state<StateT<7>>(p, stream, grid);
+    case 8: return launch_state<StateT<8>>(p, stream, grid);
     default: return hipErrorInvalidValue;
     }
 }
@@ -864,11 +1063,26 @@ int scan_grid(uint32_t n_tiles)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
 {
     if (p.n_tiles == 0) return hipSuccess;
-    const int grid = scan_grid(p.n_tiles);
+    const int grid = p.long_words_pad ? (int)p.long_grid : scan_grid(p.n_tiles);
     if (grid_used) *grid_used = grid;
+    if (p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS)) {
+        const dim3 g(grid), b(kWave * kWavesPerBlock);
+        if (raw == RAW_LCS) {
+            if (p.tiles)
+                hipLaunchKernelGGL((long_kernel<true, false>), g, b, 0, stream, p);
+            else
+                hipLaunchKernelGGL((long_kernel<true, true>), g, b, 0, stream, p);
+        } else {
+            if (p.tiles)
+                hipLaunchKernelGGL((long_kernel<false, false>), g, b, 0, stream, p);
+            else
+                hipLaunchKernelGGL((long_kernel<false, true>), g, b, 0, stream, p);
+        }
+        return hipGetLastError();
+    }
     switch (raw) {
-    case RAW_LEV: return launch_words<LevState>(p, stream, grid);
-    case RAW_LCS: return launch_words<LcsState>(p, stream, grid);
+    case RAW_LEV: return p.len1 <= 32 ? launch_state<Lev32State>(p, stream, grid) : launch_words<LevState>(p, stream, grid);
+    case RAW_LCS: return p.len1 <= 32 ? launch_state<Lcs32State>(p, stream, grid) : launch_words<LcsState>(p, stream, grid);
     case RAW_JARO:
         if (p.tiles)
             hipLaunchKernelGGL(jaro_word_kernel<false>, dim3(grid), dim3(kWave * kWavesPerBlock), 256 * sizeof(uint64_t), stream, p);

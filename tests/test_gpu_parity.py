@@ -98,10 +98,44 @@ def test_query_lengths_ragged(metric, qlen):
         _check_many(metric, q, data, offsets, "similarity", score_cutoff=k)
 
 
-def test_query_longer_than_512_is_refused_not_computed_elsewhere():
+@pytest.mark.parametrize("metric", ["levenshtein", "indel", "lcs_seq"])
+@pytest.mark.parametrize("qlen", [513, 600, 1024, 1500, 4097])
+def test_long_queries_multi_sweep_kernel(metric, qlen):
+    """Patterns beyond the register-resident kernels (> 512 symbols): 8 words per sweep, carries in HBM scratch."""
+    rng = np.random.default_rng(qlen)
+    alpha = ABCD if qlen % 2 else synth.ALNUM
+    q = alpha[rng.integers(0, len(alpha), size=qlen)].tobytes()
+    data, offsets = synth.ragged_host(300, min(2 * qlen, 1200), seed=qlen + 3, alphabet=alpha)
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+    for i in range(0, len(cands), 10):
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 40))):
+            b[int(rng.integers(0, len(b)))] = int(alpha[int(rng.integers(0, len(alpha)))])
+        cands[i] = bytes(b[: int(rng.integers(qlen // 2, qlen + 1))])
+    cands += [b"", q, q[:700], q + q[:100]]
+    data, offsets = rf.ragged(cands)
+    _check_many(metric, q, data, offsets, "distance")
+    _check_many(metric, q, data, offsets, "similarity")
+    _check_many(metric, q, data, offsets, "normalized_similarity")
+    _check_many(metric, q, data, offsets, "distance", score_cutoff=qlen // 3)
+
+
+def test_ocr_fixture_full_pair_on_gpu(golden_dir):
+    """levenshtein.rs:2139-2161 test_large_band, the reference's long-pattern known answer, through the device:
+    106 514-symbol query (1 665 words = 209 sweeps) against the 107 244-symbol candidate -> 5278; None at 2500."""
+    e1 = open(os.path.join(golden_dir, "ocr_example1.bin"), "rb").read()
+    e2 = open(os.path.join(golden_dir, "ocr_example2.bin"), "rb").read()
+    corpus = rf.Corpus.from_list([e2])
+    bc = GPU["levenshtein"].BatchComparator(e1)
+    assert bc.distance_many(corpus).tolist() == [5278]
+    assert bc.distance_many(corpus, score_cutoff=2500).tolist() == [0xFFFFFFFF]
+    assert bc.distance_many(corpus, score_hint=0).tolist() == [5278]
+
+
+def test_topk_refuses_long_query_loudly():
     corpus = rf.Corpus.from_list([b"abc", b"abcd"])
     with pytest.raises(rf.RfError) as e:
-        rf.distance.levenshtein.BatchComparator(b"a" * 513).distance_many(corpus)
+        GPU["levenshtein"].BatchComparator(b"a" * 600).topk(corpus, 4)
     assert e.value.status == N.RF_ERR_UNSUPPORTED
 
 
