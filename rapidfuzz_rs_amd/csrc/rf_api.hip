@@ -70,6 +70,7 @@ struct rf_corpus {
     bool uniform = false;        // single length bucket: no descriptors, tile t at t * tile_bytes(uniform_len)
     uint32_t uniform_len = 0;
     std::vector<uint32_t> lengths;  // the distinct candidate lengths (host copy, ascending)
+    std::vector<uint32_t> length_first_tile;  // first tile of each distinct length
 };
 
 extern "C" {
@@ -321,8 +322,11 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     c->payload_bytes = L.payload;
     c->n_tiles = (uint32_t)L.tiles.size();
     c->max_len = L.max_len;
-    for (const TileDesc& td : L.tiles)
-        if (c->lengths.empty() || c->lengths.back() != td.len) c->lengths.push_back(td.len);
+    for (size_t t = 0; t < L.tiles.size(); ++t)
+        if (c->lengths.empty() || c->lengths.back() != L.tiles[t].len) {
+            c->lengths.push_back(L.tiles[t].len);
+            c->length_first_tile.push_back((uint32_t)t);
+        }
     auto fail = [&](rf_status st) {
         rf_corpus_free(c);
         return st;
@@ -363,7 +367,10 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
     c->payload_bytes = (uint64_t)n * len;
     c->max_len = (uint32_t)len;
     c->n_tiles = (uint32_t)((n + kWave - 1) / kWave);
-    if (n) c->lengths.push_back((uint32_t)len);
+    if (n) {
+        c->lengths.push_back((uint32_t)len);
+        c->length_first_tile.push_back(0);
+    }
     auto fail = [&](rf_status s) {
         rf_corpus_free(c);
         return s;
@@ -501,11 +508,14 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     case RF_JARO_WINKLER: {
         *raw = RAW_JARO;
         p->finish = c->metric == RF_JARO ? FIN_JARO : FIN_JW;
-        // the device kernel is the single-word path of jaro.rs:574-583: both strings <= 64 symbols AFTER the
-        // window truncation of jaro.rs:550-565.  Check every candidate length of the corpus up front.
+        // Single-word path (jaro.rs:574-583) when both strings are <= 64 symbols AFTER the window truncation of
+        // jaro.rs:550-565, multi-word path (up to 512 symbols each) otherwise.  Tiles ascend by length and the
+        // single-word condition holds for a length prefix, so the corpus splits at one tile index.
         const uint64_t len1 = c->s1.size();
-        for (uint32_t l2 : corpus->lengths) {
-            uint64_t a = len1, b = l2;
+        p->jaro_split = corpus->n_tiles;
+        bool in_block = false;
+        for (size_t i = 0; i < corpus->lengths.size(); ++i) {
+            uint64_t a = len1, b = corpus->lengths[i];
             if (b > a) {
                 const uint64_t bound = b / 2 - 1;
                 if (b > a + bound) b = a + bound;
@@ -513,10 +523,15 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
                 const uint64_t bound = a / 2 - 1;
                 if (a > b + bound) a = b + bound;
             }
-            if (a == 0 || b == 0) continue;  // decided by the length filter, no flags needed
-            if (a > 64 || b > 64) {
-                set_error("jaro / jaro_winkler: a (query, candidate) pair needs the multi-word path "
-                          "(jaro.rs:286-337), which has no device kernel yet");
+            const bool needs_flags = a != 0 && b != 0;  // otherwise decided by the length filter alone
+            const bool word_ok = !needs_flags || (a <= 64 && b <= 64);
+            if (!word_ok && !in_block) {
+                in_block = true;
+                p->jaro_split = corpus->length_first_tile[i];
+            }
+            if (in_block && needs_flags && (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords)) {
+                set_error("jaro / jaro_winkler: strings longer than 512 symbols after the window truncation have no "
+                          "device kernel");
                 return RF_ERR_UNSUPPORTED;
             }
         }

@@ -883,7 +883,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
     const uint32_t stride = gridDim.x * kWavesPerBlock;
     const uint32_t q4 = p.query_head;  // first four query bytes, little endian (Winkler prefix)
 
-    for (uint32_t t = blockIdx.x * kWavesPerBlock + wave; t < p.n_tiles; t += stride) {
+    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
         const TileView tv = load_tile<kUniform>(p, t);
         const uint32_t len2_orig = tv.len, len1_orig = p.len1;
         const uint32_t slot = tv.slot0 + lane;
@@ -952,6 +952,161 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
                 const bool miss = (lds_pm0[ch] & m) == 0;
                 transpositions += (flagged && miss) ? 1u : 0u;
                 p_flag ^= flagged ? m : 0ull;
+            }
+        }
+        r.transpositions = transpositions;
+
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            bool keep;
+            const double v = f64_metric_value(p, len2_orig, r, &keep);
+            reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Jaro / Jaro-Winkler, multi-word path (jaro.rs:192-337 flag_similar_characters_block / _step, :370-420
+// count_transpositions_block) for strings of up to 512 symbols after the window truncation.  P_flag / T_flag are
+// 8 + 8 VGPR pairs per lane; the sliding search window (SearchBoundMask, jaro.rs:99-104) is wavefront-uniform;
+// the candidate is streamed twice (flags, then transpositions).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kJaroWords = 8;
+
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const ScanParams p)
+{
+    const uint32_t W = p.words;  // PM row stride (<= 8 here)
+    extern __shared__ uint64_t lds_pmw[];  // 256 x W (+ one pad row: an exhausted window may index word W)
+    for (uint32_t i = threadIdx.x; i < 256 * W + W + 1; i += kWave * kWavesPerBlock) lds_pmw[i] = i < 256 * W ? p.pm[i] : 0;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t q4 = p.query_head;
+
+    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2_orig = tv.len, len1_orig = p.len1;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+
+        uint32_t len1 = len1_orig, len2 = len2_orig, bound = 0;  // jaro.rs:550-565
+        if (len2 > len1) {
+            bound = len2 / 2 - 1;
+            if (len2 > len1 + bound) len2 = len1 + bound;
+        } else if (len1 >= 2) {
+            bound = len1 / 2 - 1;
+            if (len1 > len2 + bound) len1 = len2 + bound;
+        }
+
+        const uint4 head = len2_orig ? tv.src[lane] : make_uint4(0, 0, 0, 0);
+        JaroRaw r;
+        r.eq11 = (head.x & 0xFFu) == (q4 & 0xFFu);
+        {
+            const uint32_t lim = min(4u, min(len1_orig, len2_orig));
+            const uint32_t diff = head.x ^ q4;
+            const uint32_t first_diff = diff ? (uint32_t)(__ffs(diff) - 1) / 8 : 4u;
+            r.prefix = min(first_diff, lim);
+        }
+
+        uint64_t P[kJaroWords], T[kJaroWords];
+#pragma unroll
+        for (int w = 0; w < kJaroWords; ++w) P[w] = T[w] = 0;
+
+        // ---- pass 1: flag_similar_characters_block (jaro.rs:286-337); window state is wavefront-uniform
+        const uint32_t start_range = min(bound + 1, len1);
+        uint32_t win_words = 1 + start_range / 64, empty_words = 0;
+        uint64_t last_mask = (1ull << (start_range % 64)) - 1, first_mask = ~0ull;
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        uint64_t tcur = 0;
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 data = tv.src[(size_t)c * kWave + lane];
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            for (uint32_t b = 0; b < cols; ++b) {
+                const uint32_t j = c * kChunk + b;
+                const uint32_t ch = data.x & 0xFFu;
+                const uint32_t last_word = empty_words + win_words - 1;
+                bool found = false;
+#pragma unroll
+                for (int w = 0; w < kJaroWords; ++w) {  // flag_similar_characters_step, jaro.rs:192-284
+                    if ((uint32_t)w >= empty_words && (uint32_t)w <= last_word) {
+                        uint64_t mask = ~0ull;
+                        if ((uint32_t)w == empty_words) mask &= first_mask;
+                        if ((uint32_t)w == last_word) mask &= last_mask;
+                        const uint64_t pm_j = lds_pmw[ch * W + w] & mask & ~P[w];
+                        const bool hit = !found && pm_j != 0;
+                        P[w] |= hit ? blsi64(pm_j) : 0ull;
+                        found = found || hit;
+                    }
+                }
+                tcur |= (uint64_t)found << (j & 63);
+                if ((j & 63) == 63 || j + 1 == len2) {
+#pragma unroll
+                    for (int k = 0; k < kJaroWords; ++k)
+                        if ((uint32_t)k == (j >> 6)) T[k] = tcur;
+                    tcur = 0;
+                }
+                if (j + bound + 1 < len1) {  // jaro.rs:318-324
+                    last_mask = (last_mask << 1) | 1;
+                    if (j + bound + 2 < len1 && last_mask == ~0ull) {
+                        last_mask = 0;
+                        win_words += 1;
+                    }
+                }
+                if (j >= bound) {  // jaro.rs:326-333
+                    first_mask <<= 1;
+                    if (first_mask == 0) {
+                        first_mask = ~0ull;
+                        win_words -= 1;
+                        empty_words += 1;
+                    }
+                }
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
+            }
+        }
+        uint32_t common = 0;
+#pragma unroll
+        for (int w = 0; w < kJaroWords; ++w) common += __popcll(P[w]);
+        r.common = common;
+
+        // ---- pass 2: count_transpositions_block (jaro.rs:370-420): every flagged text character, in text order,
+        //      consumes the lowest remaining pattern flag
+        uint32_t transpositions = 0;
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 data = tv.src[(size_t)c * kWave + lane];
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            uint64_t tw = 0;
+#pragma unroll
+            for (int k = 0; k < kJaroWords; ++k)
+                if ((uint32_t)k == ((c * kChunk) >> 6)) tw = T[k];
+            for (uint32_t b = 0; b < cols; ++b) {
+                const uint32_t j = c * kChunk + b;
+                const uint32_t ch = data.x & 0xFFu;
+                const bool flagged = (tw >> (j & 63)) & 1;
+                int sel = -1;
+                uint64_t pw = 0;
+#pragma unroll
+                for (int w = kJaroWords - 1; w >= 0; --w)
+                    if (P[w] != 0) {
+                        sel = w;
+                        pw = P[w];
+                    }
+                const uint64_t m = blsi64(pw);
+                const uint64_t pmv = lds_pmw[ch * W + (sel < 0 ? 0 : sel)];
+                transpositions += (flagged && (pmv & m) == 0) ? 1u : 0u;
+#pragma unroll
+                for (int w = 0; w < kJaroWords; ++w)
+                    if (flagged && w == sel) P[w] ^= m;
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
             }
         }
         r.transpositions = transpositions;
@@ -1083,12 +1238,32 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     switch (raw) {
     case RAW_LEV: return p.len1 <= 32 ? launch_state<Lev32State>(p, stream, grid) : launch_words<LevState>(p, stream, grid);
     case RAW_LCS: return p.len1 <= 32 ? launch_state<Lcs32State>(p, stream, grid) : launch_words<LcsState>(p, stream, grid);
-    case RAW_JARO:
-        if (p.tiles)
-            hipLaunchKernelGGL(jaro_word_kernel<false>, dim3(grid), dim3(kWave * kWavesPerBlock), 256 * sizeof(uint64_t), stream, p);
-        else
-            hipLaunchKernelGGL(jaro_word_kernel<true>, dim3(grid), dim3(kWave * kWavesPerBlock), 256 * sizeof(uint64_t), stream, p);
+    case RAW_JARO: {
+        // tiles [tile_begin, jaro_split) take the single-word path, [jaro_split, tile_end) the multi-word path
+        // (tiles ascend by length, and the single-word condition holds for a length prefix)
+        const dim3 b(kWave * kWavesPerBlock);
+        ScanParams q = p;
+        q.tile_begin = 0;
+        q.tile_end = p.jaro_split;
+        if (q.tile_end > q.tile_begin) {
+            const dim3 g(scan_grid(q.tile_end - q.tile_begin));
+            if (p.tiles)
+                hipLaunchKernelGGL(jaro_word_kernel<false>, g, b, 256 * sizeof(uint64_t), stream, q);
+            else
+                hipLaunchKernelGGL(jaro_word_kernel<true>, g, b, 256 * sizeof(uint64_t), stream, q);
+        }
+        q.tile_begin = p.jaro_split;
+        q.tile_end = p.n_tiles;
+        if (q.tile_end > q.tile_begin) {
+            const dim3 g(scan_grid(q.tile_end - q.tile_begin));
+            const size_t lds = ((size_t)256 * p.words + p.words + 1) * sizeof(uint64_t);
+            if (p.tiles)
+                hipLaunchKernelGGL(jaro_block_kernel<false>, g, b, lds, stream, q);
+            else
+                hipLaunchKernelGGL(jaro_block_kernel<true>, g, b, lds, stream, q);
+        }
         return hipGetLastError();
+    }
     default: return hipErrorInvalidValue;
     }
 }

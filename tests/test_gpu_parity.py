@@ -297,15 +297,59 @@ def test_jaro_tables_on_gpu(golden_dir):
     assert GPU["jaro"].distance("james", "robert", score_cutoff=1.0) == pytest.approx(1 - 0.455556, abs=1e-4)
 
 
-def test_jaro_long_query_short_candidates_and_unsupported_block_path():
+def test_jaro_long_query_short_candidates_word_path():
     q = synth.query(80, 5)  # bound 39: candidates up to 25 symbols keep the truncated query <= 64
     data, offsets = synth.ragged_host(2000, 25, seed=9)
     for metric in ("jaro", "jaro_winkler"):
         _check_many(metric, q, data, offsets, "similarity")
         _check_many(metric, q, data, offsets, "similarity", score_cutoff=0.4)
-    corpus = rf.Corpus.from_list([b"a" * 70, b"abc"])
+
+
+@pytest.mark.parametrize("metric", ["jaro", "jaro_winkler"])
+@pytest.mark.parametrize("qlen", [10, 64, 65, 100, 128, 129, 200, 300, 448, 512])
+def test_jaro_multi_word_path_bit_exact(metric, qlen):
+    """jaro.rs:286-337 / :370-420: strings beyond 64 symbols; a ragged corpus mixes both paths in one call."""
+    rng = np.random.default_rng(qlen + 5000)
+    alpha = ABCD if qlen % 2 else synth.ALNUM
+    q = alpha[rng.integers(0, len(alpha), size=qlen)].tobytes()
+    hi = 512 if qlen <= 340 else min(512, 2 * (512 - qlen // 2))  # keep min(len2, len1 + bound) <= 512
+    data, offsets = synth.ragged_host(1500, hi, seed=qlen + 9, alphabet=alpha)
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+    for i in range(0, len(cands), 15):
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 12))):
+            b[int(rng.integers(0, len(b)))] = int(alpha[int(rng.integers(0, len(alpha)))])
+        if i % 2:
+            rng.shuffle(np.frombuffer(b, dtype=np.uint8)[: len(b) // 2])  # transpositions
+        cands[i] = bytes(b)[: hi]
+    data, offsets = rf.ragged(cands)
+    for op in ("similarity", "distance", "normalized_similarity", "normalized_distance"):
+        for c in (None, 0.5, 0.8):
+            kw = {} if c is None else {"score_cutoff": c}
+            _check_many(metric, q, data, offsets, op, **kw)
+
+
+def test_jaro_reference_fuzz_regression_on_gpu():
+    """jaro.rs:1201-1218 (both strings > 64 symbols; upstream tolerance 0.32144 around 0.1)."""
+    from test_oracle_known_answers import _rename
+
+    s1 = (
+        "afddddddddddddddddddddddddddddddddddddddddadacccccccdddddddddd%,ccaa{1}ccccdccccccccccccccccccccc"
+        "cccccccccccccccccccccccccccccccccccccccccccccccczcecccccccccccccccccccccccccccccccccccccccccccccc"
+        "cccccccccdddddddd\ub514ccc\ub514Gcddddccccccccccccccccccccccccccccccccccccccccccccccccccccccaccccccccccccc"
+        "ccccccccccccccccccccccccccccccccccccccccccccea,ccccccccccccccccccccccccccccccccccccccc"
+    )
+    s2 = "ccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccccddddd" "dddddddddddddddddddddddddddddf,ccccz\u044eec*ce\u0447;e,"
+    a, b = _rename(s1, s2)
+    got = GPU["jaro"].BatchComparator(a).distance(b, score_cutoff=1.0)
+    assert got == o.jaro.BatchComparator(a).distance(b, score_cutoff=1.0)
+    assert abs(got - 0.1) <= 0.32144
+
+
+def test_jaro_beyond_512_is_refused_loudly():
+    corpus = rf.Corpus.from_list([b"a" * 600, b"abc"])
     with pytest.raises(rf.RfError) as e:
-        GPU["jaro"].BatchComparator(b"a" * 70).similarity_many(corpus)
+        GPU["jaro"].BatchComparator(b"a" * 600).similarity_many(corpus)
     assert e.value.status == N.RF_ERR_UNSUPPORTED
 
 
