@@ -870,6 +870,112 @@ __device__ __forceinline__ double f64_metric_value(const ScanParams& p, uint32_t
     return v;
 }
 
+constexpr uint32_t T_AND_ANDN = TA & TB & ~TC;        // a & b & ~c
+constexpr uint32_t T_OR_ANDN_B = TA | (TB & ~TC);     // a | (b & ~c)
+constexpr uint32_t T_ANDN_AND = TA & ~TB & TC;        // a & ~b & c
+constexpr uint32_t T_OR_AND = TA | (TB & TC);         // a | (b & c)
+constexpr uint32_t T_AND_ORN = TA & (TB | ~TC);       // a & (b | ~c)
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v);
+}
+
+// Per-lane state of the single-word Jaro passes.  Pass 1 = flag_similar_characters_word (jaro.rs:147-190); pass 2 =
+// count_transpositions_word (:339-368) restated without data-dependent control flow:
+//   * blsi(x) = x & ~(x - 1): one 64-bit decrement + one v_bitop3 per half instead of a carry-chained negate;
+//   * every flagged text character consumes the lowest remaining pattern flag (P &= P - 1); it is a MATCH when the
+//     PM word of the text character has that bit -- matched bits are OR-ed into `hits`, so
+//     transpositions = common - popcount(hits) with no per-column compare or count.
+struct JaroWordState {
+    uint64_t p_flag, t_flag, hits;
+    uint32_t tacc;  // T bits of the 32 columns currently being processed
+};
+
+// The sliding window mask (jaro.rs:168,176,185) is wavefront-uniform; the asm pins its recurrence
+// bm = (bm << 1) | (j < bound) to the scalar ALU as two 32-bit halves (hipcc otherwise migrates it to VGPRs next to
+// the per-lane flags).  SCC-based: the low bit is free after the shift, so adding the compare's carry sets it.
+__device__ __forceinline__ void window_next(uint32_t& lo, uint32_t& hi, uint32_t j, uint32_t bound)
+{
+    uint32_t tmp;
+    asm("s_lshr_b32 %2, %0, 31\n\t"
+        "s_lshl_b32 %1, %1, 1\n\t"
+        "s_or_b32 %1, %1, %2\n\t"
+        "s_lshl_b32 %0, %0, 1\n\t"
+        "s_cmp_lt_u32 %3, %4\n\t"
+        "s_addc_u32 %0, %0, 0"
+        : "+s"(lo), "+s"(hi), "=&s"(tmp)
+        : "s"(j), "s"(bound)
+        : "scc");
+}
+
+template <bool kFull>
+__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4& c, uint32_t j0, uint32_t cols,
+                                                uint32_t bound, uint32_t& bm_lo_io, uint32_t& bm_hi_io)
+{
+    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    uint32_t bm_lo = uniform(bm_lo_io), bm_hi = uniform(bm_hi_io);  // (re)pin to SGPRs for the asm recurrence
+    bound = uniform(bound);
+    uint64_t cur[4], nxt[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cur[b] = lds_pm0[(dw[0] >> (8 * b)) & 0xFFu];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) nxt[b] = lds_pm0[(dw[g + 1] >> (8 * b)) & 0xFFu];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t j = j0 + g * 4 + b;
+            if (kFull || (uint32_t)(g * 4 + b) < cols) {
+                const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], ((uint64_t)bm_hi << 32) | bm_lo, st.p_flag);  // PM & window & ~P
+                const uint64_t below = pm_j - 1;
+                st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
+                st.tacc |= pm_j != 0 ? (1u << (j & 31)) : 0u;           // jaro.rs:174 / :183
+                window_next(bm_lo, bm_hi, uniform(j), bound);  // :176 / :185
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cur[b] = nxt[b];
+    }
+    bm_lo_io = bm_lo;
+    bm_hi_io = bm_hi;
+}
+
+template <bool kFull>
+__device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4& c, uint32_t j0, uint32_t cols)
+{
+    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    const uint32_t thalf = (j0 & 32) ? (uint32_t)(st.t_flag >> 32) : (uint32_t)st.t_flag;
+    uint64_t cur[4], nxt[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cur[b] = lds_pm0[(dw[0] >> (8 * b)) & 0xFFu];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) nxt[b] = lds_pm0[(dw[g + 1] >> (8 * b)) & 0xFFu];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t j = j0 + g * 4 + b;
+            if (kFull || (uint32_t)(g * 4 + b) < cols) {
+                const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)thalf, j & 31, 1);  // all ones iff T bit j
+                const uint64_t f = ((uint64_t)f32 << 32) | f32;
+                const uint64_t below = st.p_flag - 1;
+                const uint64_t m = lut3<T_ANDN_AND>(st.p_flag, below, f);  // lowest remaining pattern flag, if flagged
+                st.hits = lut3<T_OR_AND>(st.hits, cur[b], m);              // match iff PM[text char] has that bit
+                st.p_flag = lut3<T_AND_ORN>(st.p_flag, below, f);          // consume it, if flagged
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cur[b] = nxt[b];
+    }
+}
+
 template <bool kUniform>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
 {
@@ -895,66 +1001,54 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
         if (len2 > len1) {
             bound = len2 / 2 - 1;
             if (len2 > len1 + bound) len2 = len1 + bound;
-        } else if (len1 > 0) {
-            bound = len1 / 2 > 0 ? len1 / 2 - 1 : 0;
+        } else if (len1 >= 2) {
+            bound = len1 / 2 - 1;
             if (len1 > len2 + bound) len1 = len2 + bound;
         }
-        // (len1 == 1 && len2_orig <= 1 never reaches the flags: length filter / 1x1 rule decide; bound is unused then)
+        // (len1 <= 1 with len2 <= len1 never reaches the flags: the length filter / 1x1 rule decide)
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;  // <= 4 on this path
 
-        // the candidate's first min(len2, 64) bytes
-        uint4 c[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c[k] = (uint32_t)(k * kChunk) < len2 ? tv.src[(size_t)k * kWave + lane] : make_uint4(0, 0, 0, 0);
-
+        // the candidate (<= 64 bytes = 4 chunk rows) is streamed twice: HBM once, the second pass hits L1/L2
+        uint4 cur = tv.src[lane];
         JaroRaw r;
-        r.eq11 = (c[0].x & 0xFFu) == (q4 & 0xFFu);
+        r.eq11 = (cur.x & 0xFFu) == (q4 & 0xFFu);
         {  // Winkler prefix: equal leading bytes among the first min(4, len1_orig, len2_orig), jaro_winkler.rs:118-123
             const uint32_t lim = min(4u, min(len1_orig, len2_orig));
-            const uint32_t diff = c[0].x ^ q4;
+            const uint32_t diff = cur.x ^ q4;
             const uint32_t first_diff = diff ? (uint32_t)(__ffs(diff) - 1) / 8 : 4u;
             r.prefix = min(first_diff, lim);
         }
 
-        // pass 1: flag_similar_characters_word, jaro.rs:147-190
-        uint64_t p_flag = 0, t_flag = 0;
-        uint64_t bound_mask = mask_lsb64(bound + 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((uint32_t)(k * kChunk) >= len2) break;
-            const uint32_t dw[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
-#pragma unroll
-            for (int b = 0; b < kChunk; ++b) {
-                const uint32_t j = k * kChunk + b;
-                if (j >= len2) break;
-                const uint32_t ch = (dw[b / 4] >> (8 * (b % 4))) & 0xFFu;
-                const uint64_t pm_j = lds_pm0[ch] & bound_mask & ~p_flag;
-                p_flag |= blsi64(pm_j);
-                t_flag |= (uint64_t)(pm_j != 0) << j;
-                bound_mask = j < bound ? (bound_mask << 1) | 1 : bound_mask << 1;
+        JaroWordState st;
+        st.p_flag = st.t_flag = st.hits = 0;
+        st.tacc = 0;
+        const uint64_t bm0 = mask_lsb64(bound + 1);
+        uint32_t bm_lo = uniform((uint32_t)bm0), bm_hi = uniform((uint32_t)(bm0 >> 32));
+        for (uint32_t k = 0; k < nch; ++k) {  // pass 1
+            const uint4 nxt = tv.src[(size_t)(k + 1 < nch ? k + 1 : 0) * kWave + lane];  // next chunk, then chunk 0 again
+            const uint32_t cols = len2 - k * kChunk;
+            if (cols >= (uint32_t)kChunk)
+                jaro_flag_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk, bound, bm_lo, bm_hi);
+            else
+                jaro_flag_chunk<false>(st, lds_pm0, cur, k * kChunk, cols, bound, bm_lo, bm_hi);
+            if ((k & 1) || k + 1 == nch) {  // 32 columns (or the tail) done: bank their T bits
+                st.t_flag |= (uint64_t)st.tacc << ((k & 2) ? 32 : 0);
+                st.tacc = 0;
             }
+            cur = nxt;
         }
-        r.common = __popcll(p_flag);
-
-        // pass 2: count_transpositions_word, jaro.rs:339-368 -- walk the text in order; every flagged text
-        // character consumes the lowest remaining pattern flag
-        uint32_t transpositions = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((uint32_t)(k * kChunk) >= len2) break;
-            const uint32_t dw[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
-#pragma unroll
-            for (int b = 0; b < kChunk; ++b) {
-                const uint32_t j = k * kChunk + b;
-                if (j >= len2) break;
-                const uint32_t ch = (dw[b / 4] >> (8 * (b % 4))) & 0xFFu;
-                const bool flagged = (t_flag >> j) & 1;
-                const uint64_t m = blsi64(p_flag);
-                const bool miss = (lds_pm0[ch] & m) == 0;
-                transpositions += (flagged && miss) ? 1u : 0u;
-                p_flag ^= flagged ? m : 0ull;
-            }
+        r.common = __popcll(st.p_flag);
+        for (uint32_t k = 0; k < nch; ++k) {  // pass 2
+            uint4 nxt = cur;
+            if (k + 1 < nch) nxt = tv.src[(size_t)(k + 1) * kWave + lane];
+            const uint32_t cols = len2 - k * kChunk;
+            if (cols >= (uint32_t)kChunk)
+                jaro_transpose_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk);
+            else
+                jaro_transpose_chunk<false>(st, lds_pm0, cur, k * kChunk, cols);
+            cur = nxt;
         }
-        r.transpositions = transpositions;
+        r.transpositions = r.common - __popcll(st.hits);
 
         const bool valid = kUniform ? slot < p.n : idx != kPad;
         if (valid) {
