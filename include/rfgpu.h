@@ -115,8 +115,9 @@ const uint64_t *rf_comparator_pm(const rf_comparator *c, size_t *block_count);
  * rapidfuzz-benches/benches/bench_levenshtein.rs:51-60), packed once and kept in HBM.
  * Layout: candidates are grouped by exact length into tiles of 64 (one candidate per wavefront lane);
  * inside a tile the 16-byte chunk k of lane r sits at tile_base + (k*64 + r)*16, so a wavefront's
- * `global_load_dwordx4` of "my chunk k" is one contiguous 1 KiB read.  Results always come back in
- * the ORIGINAL candidate order.
+ * `global_load_dwordx4` of "my chunk k" is one contiguous 1 KiB read.  Symbols are stored renamed by a
+ * per-corpus permutation (frequency rank), which the kernels undo when they stage the PM table; results always
+ * come back in the ORIGINAL candidate order and never depend on the renaming.
  *
  * rf_corpus_pack: ragged host input, candidate i = bytes[offsets[i] .. offsets[i+1]) (n+1 offsets).
  * rf_corpus_pack_rows_device: n rows of `len` bytes already in device memory at d_rows + i*stride.
@@ -135,6 +136,8 @@ typedef struct rf_host_layout {
     uint32_t *orig;        /* n_slots: slot -> original index, 0xFFFFFFFF = padding lane (empty if identity) */
     uint64_t packed_bytes, n_slots;
     uint32_t n_tiles, identity;
+    uint8_t sigma[256];    /* symbol renaming: the payload stores sigma[c] for candidate byte c (a permutation that
+                              spreads this corpus' frequent symbols over distinct LDS banks) */
 } rf_host_layout;
 rf_status rf_corpus_layout_host(const uint8_t *bytes, const uint64_t *offsets, size_t n, rf_host_layout *out);
 void rf_host_layout_free(rf_host_layout *l);

@@ -55,6 +55,7 @@ class RfHostLayout(C.Structure):
         ("n_slots", C.c_uint64),
         ("n_tiles", C.c_uint32),
         ("identity", C.c_uint32),
+        ("sigma", C.c_uint8 * 256),
     ]
 
 

@@ -104,6 +104,7 @@ def host_layout(data: np.ndarray, offsets: np.ndarray) -> dict:
             "tile_slot0": np.ctypeslib.as_array(lay.tile_slot0, shape=(max(nt, 1),))[:nt].copy(),
             "orig": np.ctypeslib.as_array(lay.orig, shape=(max(lay.n_slots, 1),))[: lay.n_slots].copy(),
             "identity": bool(lay.identity),
+            "sigma": np.frombuffer(bytes(lay.sigma), dtype=np.uint8).copy(),
         }
     finally:
         N.lib().rf_host_layout_free(C.byref(lay))

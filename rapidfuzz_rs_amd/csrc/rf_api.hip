@@ -7,6 +7,7 @@
 // RF_ERR_UNSUPPORTED.  Product code: never includes or links anything from oracle/.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -71,7 +72,24 @@ struct rf_corpus {
     uint32_t uniform_len = 0;
     std::vector<uint32_t> lengths;  // the distinct candidate lengths (host copy, ascending)
     std::vector<uint32_t> length_first_tile;  // first tile of each distinct length
+    uint8_t sigma[256];           // symbol renaming: the packed corpus stores sigma[c] for candidate byte c
+    uint8_t* d_sigma = nullptr;   // device copy
 };
+
+// Symbol renaming.  Every column of every kernel gathers 64 table rows from LDS, one per lane, and LDS bank
+// conflicts between DIFFERENT symbols that share a bank (row index mod 32 for 8-byte rows) are the cost of that
+// gather -- ASCII classes collide systematically ('A'/'a', digits/'P'..'Y').  Renaming symbols by frequency rank
+// gives the 32 most frequent symbols of THIS corpus 32 distinct banks and pairs the rest with them one by one.
+// The packed corpus stores sigma(c); the kernels stage PM row c at LDS row sigma(c); nothing else changes.
+static void make_sigma(const uint64_t* hist, uint8_t* sigma)
+{
+    static const bool disabled = getenv("RF_NO_RENAME") != nullptr;  // tuning / A-B knob
+    int order[256];
+    for (int i = 0; i < 256; ++i) order[i] = i;
+    if (!disabled)
+        std::stable_sort(order, order + 256, [&](int a, int b) { return hist[a] > hist[b]; });
+    for (int r = 0; r < 256; ++r) sigma[order[r]] = (uint8_t)r;
+}
 
 extern "C" {
 
@@ -189,6 +207,7 @@ struct HostLayout {
     uint64_t payload = 0;
     uint32_t max_len = 0;
     bool identity = true;          // a single length bucket: slot i is candidate i
+    uint8_t sigma[256];            // symbol renaming applied to the payload
 };
 
 static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, size_t n, HostLayout* L)
@@ -232,6 +251,14 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
     L->identity = distinct <= 1;
     L->max_len = max_len;
 
+    // 2b. symbol renaming from the byte histogram of the whole payload
+    {
+        uint64_t hist[256] = {0};
+        const uint64_t total = n ? offsets[n] : 0;
+        for (uint64_t b = n ? offsets[0] : 0; b < total; ++b) hist[bytes[b]]++;
+        make_sigma(hist, L->sigma);
+    }
+
     // 3. scatter the candidates into the chunk-interleaved tiles (+ kTailPad readable bytes at the end: the
     //    scan kernel prefetches one chunk row ahead, also across the last tile)
     L->packed.assign(data_bytes + kTailPad, 0);
@@ -244,8 +271,7 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
         const uint64_t tile = k / kWave, lane = k % kWave;
         uint8_t* dst = L->packed.data() + group_off[len] + tile * tile_bytes(len) + lane * kChunk;
         const uint8_t* src = bytes + offsets[i];
-        for (uint32_t b = 0; b < len; b += kChunk)
-            std::memcpy(dst + (uint64_t)(b / kChunk) * kWave * kChunk, src + b, std::min<uint32_t>(kChunk, len - b));
+        for (uint32_t b = 0; b < len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = L->sigma[src[b]];
         L->payload += len;
     }
     return RF_OK;
@@ -278,6 +304,7 @@ rf_status rf_corpus_layout_host(const uint8_t* bytes, const uint64_t* offsets, s
         out->tile_slot0[t] = L.tiles[t].slot0;
     }
     if (!L.orig.empty()) std::memcpy(out->orig, L.orig.data(), L.orig.size() * sizeof(uint32_t));
+    std::memcpy(out->sigma, L.sigma, 256);
     return RF_OK;
 }
 
@@ -334,6 +361,9 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     RF_HIP_C(hipMalloc(&c->d_data, L.packed.size()));
     RF_HIP_C(hipMemcpy(c->d_data, L.packed.data(), L.packed.size(), hipMemcpyHostToDevice));
     c->device_bytes = L.packed.size();
+    std::memcpy(c->sigma, L.sigma, 256);
+    RF_HIP_C(hipMalloc(&c->d_sigma, 256));
+    RF_HIP_C(hipMemcpy(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice));
     if (L.identity) {  // one length bucket in original order: tiles are addressed arithmetically
         c->uniform = true;
         c->uniform_len = L.max_len;
@@ -386,7 +416,21 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
     c->uniform_len = (uint32_t)len;
     RF_HIP_C(hipMalloc(&c->d_data, data_bytes + kTailPad));
     RF_HIP_C(hipMemsetAsync(c->d_data + data_bytes, 0, kTailPad, st));
-    if (data_bytes) RF_HIP_C(launch_pack_rows((const uint8_t*)d_rows, n, (uint32_t)len, stride, c->d_data, c->n_tiles, st));
+    RF_HIP_C(hipMalloc(&c->d_sigma, 256));
+    {   // rename permutation from the byte histogram of (at most) the first 4 Mi rows
+        unsigned long long* d_hist = nullptr;
+        RF_HIP_C(hipMalloc(&d_hist, 256 * sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), st);
+        if (e == hipSuccess) e = launch_histogram_rows((const uint8_t*)d_rows, std::min<size_t>(n, (size_t)4 << 20), (uint32_t)len, stride, d_hist, st);
+        uint64_t hist[256] = {0};
+        if (e == hipSuccess) e = hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_hist);
+        RF_HIP_C(e);
+        make_sigma(hist, c->sigma);
+        RF_HIP_C(hipMemcpyAsync(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice, st));
+    }
+    if (data_bytes) RF_HIP_C(launch_pack_rows((const uint8_t*)d_rows, n, (uint32_t)len, stride, c->d_data, c->n_tiles, c->d_sigma, st));
     RF_HIP_C(hipStreamSynchronize(st));  // the input is only borrowed for the duration of the call
     c->device_bytes = data_bytes + kTailPad;
     *out = c;
@@ -400,6 +444,7 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_data) (void)hipFree(c->d_data);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_orig) (void)hipFree(c->d_orig);
+    if (c->d_sigma) (void)hipFree(c->d_sigma);
     delete c;
 }
 
@@ -426,7 +471,8 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->factor = 1;
     p->w_ins = p->w_del = p->w_sub = 1;
     p->prefix_weight = args->prefix_weight;
-    for (size_t i = 0; i < std::min<size_t>(4, c->s1.size()); ++i) p->query_head |= (uint32_t)c->s1[i] << (8 * i);
+    for (size_t i = 0; i < std::min<size_t>(4, c->s1.size()); ++i) p->query_head |= (uint32_t)corpus->sigma[c->s1[i]] << (8 * i);
+    p->sigma = corpus->d_sigma;
     p->data = corpus->d_data;
     p->tiles = corpus->uniform ? nullptr : corpus->d_tiles;
     p->uniform_len = corpus->uniform_len;

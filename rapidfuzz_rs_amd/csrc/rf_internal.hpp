@@ -45,7 +45,8 @@ struct ScanParams {
     const uint8_t* data;
     const TileDesc* tiles;  // nullptr: every tile has length uniform_len and sits at t * uniform_tile_bytes
     const uint32_t* orig;  // slot -> original index (kPad for padding lanes); nullptr = identity
-    const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w]
+    const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w], indexed by ORIGINAL symbol
+    const uint8_t* sigma;  // device uint8[256]: original symbol -> the symbol stored in the packed corpus
     void* out;             // uint32_t* or double*
     uint32_t n_tiles;
     uint32_t n;            // number of real candidates
@@ -86,7 +87,9 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
 hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* scratch, uint64_t* out, hipStream_t stream);
 size_t topk_merge_scratch_entries(uint32_t n, uint32_t k);
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,
-                            uint32_t n_tiles, hipStream_t stream);
+                            uint32_t n_tiles, const uint8_t* sigma, hipStream_t stream);
+hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,
+                                 hipStream_t stream);
 int scan_max_grid();
 int scan_grid(uint32_t n_tiles);  // the grid launch_scan uses for n_tiles tiles
 

@@ -485,7 +485,9 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
 {
     constexpr int W = State::kWords;
     // stage the PM table; the 32-bit states keep the low half of each (single-word) entry
-    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock) lds_pm[i] = (typename State::Word)p.pm[i];
+    // (the corpus stores renamed symbols sigma(c), see rf_corpus: row c of the table goes to row sigma(c))
+    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock)
+        lds_pm[(uint32_t)p.sigma[i / W] * W + i % W] = (typename State::Word)p.pm[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -710,6 +712,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanP
     const uint32_t words_pad = p.long_words_pad;
     const uint32_t groups = words_pad / kLongGroup;
     uint32_t* strip = p.long_scratch + (size_t)gw * p.long_chunks_max * kWave;
+    __shared__ uint8_t lds_unrename[256];  // stored symbol -> original symbol (the PM table stays in global memory)
+    lds_unrename[p.sigma[threadIdx.x & 255]] = (uint8_t)(threadIdx.x & 255);
+    __syncthreads();
 
     for (uint32_t t = gw; t < p.n_tiles; t += stride) {
         const TileView tv = load_tile<kUniform>(p, t);
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanP
                 uint32_t cout = 0;
                 const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
                 for (uint32_t j = 0; j < cols; ++j) {
-                    const uint32_t ch = data.x & 0xFFu;
+                    const uint32_t ch = lds_unrename[data.x & 0xFFu];
                     const uint64_t* row = p.pm + (size_t)ch * words_pad + (size_t)g * kLongGroup;
                     uint64_t x[kLongGroup];
 #pragma unroll
@@ -981,7 +986,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
 {
     const uint32_t W = p.words;  // PM row stride; only block 0 is read on this path (jaro.rs:172, pm.get(0, ..))
     extern __shared__ uint64_t lds_pm0[];  // 256 entries: block 0 of every row
-    for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm0[i] = p.pm[(size_t)i * W];
+    for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm0[p.sigma[i]] = p.pm[(size_t)i * W];  // renamed rows
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -1072,7 +1077,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const
 {
     const uint32_t W = p.words;  // PM row stride (<= 8 here)
     extern __shared__ uint64_t lds_pmw[];  // 256 x W (+ one pad row: an exhausted window may index word W)
-    for (uint32_t i = threadIdx.x; i < 256 * W + W + 1; i += kWave * kWavesPerBlock) lds_pmw[i] = i < 256 * W ? p.pm[i] : 0;
+    for (uint32_t i = threadIdx.x; i < 256 * W + W + 1; i += kWave * kWavesPerBlock) {
+        if (i < 256 * W)
+            lds_pmw[(uint32_t)p.sigma[i / W] * W + i % W] = p.pm[i];  // renamed rows
+        else
+            lds_pmw[i] = 0;
+    }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -1218,8 +1228,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const
 // corpus packing on the device: row-major fixed-length rows -> chunk-interleaved tiles
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t* __restrict__ rows, size_t n, uint32_t len,
-                                                        size_t stride, uint8_t* __restrict__ packed, uint32_t n_tiles)
+                                                        size_t stride, uint8_t* __restrict__ packed, uint32_t n_tiles,
+                                                        const uint8_t* __restrict__ sigma)
 {
+    __shared__ uint8_t lds_sigma[256];
+    lds_sigma[threadIdx.x] = sigma[threadIdx.x];
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t chunks = (len + kChunk - 1) / kChunk;
     const size_t tile_bytes = (size_t)chunks * kWave * kChunk;
@@ -1231,27 +1245,55 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t* __restric
             uint32_t w[4] = {0, 0, 0, 0};
             if (row < n) {
                 const uint32_t base = c * kChunk;
-                if (base + kChunk <= len && ((reinterpret_cast<uintptr_t>(src + base) & 3) == 0)) {
+                uint32_t raw[4] = {0, 0, 0, 0};
+                uint32_t nb = min((uint32_t)kChunk, len - base);
+                if (nb == kChunk && ((reinterpret_cast<uintptr_t>(src + base) & 3) == 0)) {
                     const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + base);
-                    w[0] = s4[0];
-                    w[1] = s4[1];
-                    w[2] = s4[2];
-                    w[3] = s4[3];
+                    raw[0] = s4[0];
+                    raw[1] = s4[1];
+                    raw[2] = s4[2];
+                    raw[3] = s4[3];
                 } else {
-                    for (uint32_t b = 0; b < kChunk && base + b < len; ++b) w[b / 4] |= (uint32_t)src[base + b] << (8 * (b % 4));
+                    for (uint32_t b = 0; b < nb; ++b) raw[b / 4] |= (uint32_t)src[base + b] << (8 * (b % 4));
                 }
+#pragma unroll
+                for (uint32_t b = 0; b < (uint32_t)kChunk; ++b)  // rename; bytes past the candidate's end stay 0
+                    if (b < nb) w[b / 4] |= (uint32_t)lds_sigma[(raw[b / 4] >> (8 * (b % 4))) & 0xFFu] << (8 * (b % 4));
             }
             *reinterpret_cast<uint4*>(dst + (size_t)c * kWave * kChunk) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
 
+// byte histogram of (a prefix of) device rows, for the rename permutation
+__global__ __launch_bounds__(256) void histogram_rows_kernel(const uint8_t* __restrict__ rows, size_t n, uint32_t len, size_t stride,
+                                                             unsigned long long* __restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (size_t)gridDim.x * blockDim.x) {
+        const uint8_t* src = rows + r * stride;
+        for (uint32_t b = 0; b < len; ++b) atomicAdd(&h[src[b]], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist, hipStream_t stream)
+{
+    if (n == 0 || len == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(histogram_rows_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, len, stride, hist);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed, uint32_t n_tiles,
-                            hipStream_t stream)
+                            const uint8_t* sigma, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<size_t>((n_tiles + 3) / 4, 256 * 16);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, len, stride, packed, n_tiles);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, len, stride, packed, n_tiles, sigma);
     return hipGetLastError();
 }
 

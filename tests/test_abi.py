@@ -68,7 +68,10 @@ def test_comparator_clone_and_accessors():
 def _unpack(lay, n):
     """Invert the chunk-interleaved layout: returns the list of candidates in ORIGINAL order."""
     out = [None] * n
-    packed = lay["packed"]
+    inv = np.zeros(256, dtype=np.uint8)
+    inv[lay["sigma"]] = np.arange(256, dtype=np.uint8)  # the payload stores renamed symbols
+    assert sorted(lay["sigma"].tolist()) == list(range(256))
+    packed = inv[lay["packed"]]
     for t in range(len(lay["tile_len"])):
         ln, off, slot0 = int(lay["tile_len"][t]), int(lay["tile_off"][t]), int(lay["tile_slot0"][t])
         for lane in range(64):
@@ -92,6 +95,9 @@ def test_host_layout_roundtrip(n, max_len):
     lay = rf.host_layout(data, offsets)
     cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(n)]
     assert _unpack(lay, n) == cands
+    if len(data):  # frequency-rank renaming: the most frequent byte is stored as 0, the next as 1, ...
+        hist = np.bincount(data, minlength=256)
+        assert hist[np.argsort(lay["sigma"], kind="stable")].tolist() == sorted(hist.tolist(), reverse=True)
     lens = lay["tile_len"]
     assert (np.diff(lens.astype(np.int64)) >= 0).all()  # length buckets ascend
     assert len(lay["packed"]) == (int(lay["tile_off"][-1]) + ((int(lens[-1]) + 15) // 16) * 1024 if len(lens) else 0) + 1024
