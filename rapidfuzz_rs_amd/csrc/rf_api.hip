@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "rf_internal.hpp"
@@ -216,39 +217,41 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
         set_error("rf_corpus_pack: invalid argument");
         return RF_ERR_INVALID_ARG;
     }
-    // 1. length histogram
+    // 1. distinct lengths and their counts (a sorted map: one 4 GiB candidate must not cost a 32 GiB table)
+    struct Group {
+        uint64_t count = 0, slot0 = 0, off0 = 0, next = 0;
+    };
+    std::map<uint32_t, Group> groups;
     uint32_t max_len = 0;
     for (size_t i = 0; i < n; ++i) {
         if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0xFFFFFFF0ull) {
             set_error("rf_corpus_pack: offsets must be non-decreasing and candidates shorter than 4 GiB");
             return RF_ERR_INVALID_ARG;
         }
-        max_len = std::max<uint32_t>(max_len, (uint32_t)(offsets[i + 1] - offsets[i]));
+        const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+        max_len = std::max(max_len, len);
+        groups[len].count++;
     }
-    std::vector<uint64_t> count((size_t)max_len + 1, 0);
-    for (size_t i = 0; i < n; ++i) count[offsets[i + 1] - offsets[i]]++;
 
     // 2. one group of tiles per distinct length, ascending; every group is padded to whole tiles
-    std::vector<uint64_t> group_slot((size_t)max_len + 1, 0), group_off((size_t)max_len + 1, 0);
     uint64_t slots = 0, data_bytes = 0;
-    size_t distinct = 0;
-    for (uint32_t len = 0; len <= max_len && n; ++len) {
-        if (!count[len]) continue;
-        ++distinct;
-        group_slot[len] = slots;
-        group_off[len] = data_bytes;
-        const uint64_t nt = (count[len] + kWave - 1) / kWave;
+    for (auto& kv : groups) {
+        Group& g = kv.second;
+        g.slot0 = slots;
+        g.off0 = data_bytes;
+        const uint64_t nt = (g.count + kWave - 1) / kWave;
         for (uint64_t t = 0; t < nt; ++t) {
-            L->tiles.push_back(TileDesc{data_bytes, len, (uint32_t)slots});
+            L->tiles.push_back(TileDesc{data_bytes, kv.first, (uint32_t)slots});
             slots += kWave;
-            data_bytes += tile_bytes(len);
+            data_bytes += tile_bytes(kv.first);
         }
     }
     if (slots >= 0xFFFFFFFFull) {
         set_error("rf_corpus_pack: too many candidates for one corpus");
         return RF_ERR_INVALID_ARG;
     }
-    L->identity = distinct <= 1;
+    // a single length bucket is addressed arithmetically (tile t at t * tile_bytes) as long as that fits 32 bits
+    L->identity = groups.size() <= 1 && tile_bytes(max_len) <= 0xFFFFFFFFull;
     L->max_len = max_len;
 
     // 2b. symbol renaming from the byte histogram of the whole payload
@@ -259,20 +262,55 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
         make_sigma(hist, L->sigma);
     }
 
-    // 3. scatter the candidates into the chunk-interleaved tiles (+ kTailPad readable bytes at the end: the
-    //    scan kernel prefetches one chunk row ahead, also across the last tile)
-    L->packed.assign(data_bytes + kTailPad, 0);
+    // 3. slot of every candidate (k-th of its length, original order preserved) -- sequential, cheap
+    std::vector<uint32_t> slot_of(n);
+    {
+        // a direct table when lengths are small, the map otherwise
+        const bool direct = max_len <= (1u << 20);
+        std::vector<Group*> by_len;
+        if (direct) {
+            by_len.assign((size_t)max_len + 1, nullptr);
+            for (auto& kv : groups) by_len[kv.first] = &kv.second;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+            Group& g = direct ? *by_len[len] : groups[len];
+            slot_of[i] = (uint32_t)(g.slot0 + g.next++);
+            L->payload += len;
+        }
+    }
+    L->packed.assign(data_bytes + kTailPad, 0);  // + one readable chunk row: the scan prefetches one row ahead
     if (!L->identity) L->orig.assign(slots, kPad);
-    std::vector<uint64_t> cursor((size_t)max_len + 1, 0);
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
-        const uint64_t k = cursor[len]++;  // k-th candidate of this length, original order preserved
-        if (!L->identity) L->orig[group_slot[len] + k] = (uint32_t)i;
-        const uint64_t tile = k / kWave, lane = k % kWave;
-        uint8_t* dst = L->packed.data() + group_off[len] + tile * tile_bytes(len) + lane * kChunk;
-        const uint8_t* src = bytes + offsets[i];
-        for (uint32_t b = 0; b < len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = L->sigma[src[b]];
-        L->payload += len;
+
+    // 4. scatter the (renamed) bytes into the chunk-interleaved tiles; candidates are independent -> threads
+    std::map<uint32_t, std::pair<uint64_t, uint64_t>> base;  // len -> (slot0, off0)
+    for (auto& kv : groups) base[kv.first] = {kv.second.slot0, kv.second.off0};
+    auto worker = [&](size_t lo, size_t hi) {
+        uint32_t cached_len = 0xFFFFFFFFu;
+        uint64_t c_slot0 = 0, c_off0 = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+            if (len != cached_len) {
+                const auto& b = base.find(len)->second;
+                cached_len = len;
+                c_slot0 = b.first;
+                c_off0 = b.second;
+            }
+            const uint64_t slot = slot_of[i], k = slot - c_slot0;
+            if (!L->identity) L->orig[slot] = (uint32_t)i;
+            uint8_t* dst = L->packed.data() + c_off0 + (k / kWave) * tile_bytes(len) + (k % kWave) * kChunk;
+            const uint8_t* src = bytes + offsets[i];
+            for (uint32_t b = 0; b < len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = L->sigma[src[b]];
+        }
+    };
+    const size_t hw = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 32));
+    const size_t nthreads = L->payload < (8u << 20) ? 1 : hw;
+    if (nthreads == 1) {
+        worker(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(worker, n * t / nthreads, n * (t + 1) / nthreads);
+        for (auto& th : pool) th.join();
     }
     return RF_OK;
 }
