@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--candidates", type=int, default=100_000_000, help="candidates per GPU")
     ap.add_argument("--cand-len", type=int, default=64)
     ap.add_argument("--query-len", type=int, default=64)
-    ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq", "jaro", "jaro_winkler"])
+    ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq", "osa", "jaro", "jaro_winkler"])
     ap.add_argument("--cutoff", type=int, default=None)
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--mode", default="many", choices=["many", "topk"],

@@ -45,7 +45,8 @@ typedef enum rf_metric {
     RF_LCS_SEQ = 2,      /* src/distance/lcs_seq.rs */
     RF_JARO = 3,         /* src/distance/jaro.rs */
     RF_JARO_WINKLER = 4, /* src/distance/jaro_winkler.rs */
-    RF_FUZZ_RATIO = 5    /* src/fuzz.rs RatioBatchComparator */
+    RF_FUZZ_RATIO = 5,   /* src/fuzz.rs RatioBatchComparator */
+    RF_OSA = 6           /* src/distance/osa.rs (widening beyond the north-star path) */
 } rf_metric;
 
 /* the four methods every BatchComparator has (e.g. levenshtein.rs:1660-1817) */
@@ -149,7 +150,7 @@ int rf_corpus_device(const rf_corpus *c);
 /* ---- one-vs-many ------------------------------------------------------------------------------
  * out[i] = scorer.<op>_with_args(candidate_i, &args) for every candidate, original order.
  *
- * rf_many_u32: the usize-valued methods of levenshtein / indel / lcs_seq
+ * rf_many_u32: the usize-valued methods of levenshtein / indel / lcs_seq / osa
  *   (distance_with_args levenshtein.rs:1750-1777, similarity_with_args :1790-1817; indel.rs:464-521;
  *    lcs_seq.rs:893-949).  RF_NONE_U32 = None.
  * rf_many_f64: normalized_* of those metrics (levenshtein.rs:1670-1737 ...), all four methods of

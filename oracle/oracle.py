@@ -19,7 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librf_oracle.so")
 
-LEVENSHTEIN, INDEL, LCS_SEQ, JARO, JARO_WINKLER, FUZZ_RATIO = range(6)
+LEVENSHTEIN, INDEL, LCS_SEQ, JARO, JARO_WINKLER, FUZZ_RATIO, OSA = range(7)
 OP_DISTANCE, OP_SIMILARITY, OP_NORMALIZED_DISTANCE, OP_NORMALIZED_SIMILARITY = range(4)
 PATH_NAMES = ["none", "eq", "lendiff", "empty", "hyrroe2003", "small_band", "block", "mbleven", "wagner_fischer", "affix"]
 
@@ -216,6 +216,7 @@ class _Module:
 levenshtein = _Module(LEVENSHTEIN, False)
 indel = _Module(INDEL, False)
 lcs_seq = _Module(LCS_SEQ, False)
+osa = _Module(OSA, False)
 jaro = _Module(JARO, True)
 jaro_winkler = _Module(JARO_WINKLER, True)
 

@@ -105,6 +105,14 @@ static size_t indel_distance(const mu *m, rfo_str s1, rfo_str s2, rfo_opt_usize 
     return maximum - 2 * lcs_sim;
 }
 
+/* -- osa: IndividualComparator osa.rs:228-268, BatchComparator :431-461 (both ignore cutoff and hint) -- */
+static size_t osa_distance(const mu *m, rfo_str s1, rfo_str s2, rfo_opt_usize c, rfo_opt_usize h)
+{
+    (void)c;
+    (void)h;
+    return m->pm ? rfo_osa_distance_with_pm(m->pm, s1, s2) : rfo_osa_distance_without_pm(s1, s2);
+}
+
 static void mu_make(mu *m, int metric, const rfo_pm *pm, const rfo_weights *w)
 {
     static const rfo_weights unit = {1, 1, 1};
@@ -114,6 +122,11 @@ static void mu_make(mu *m, int metric, const rfo_pm *pm, const rfo_weights *w)
     case RFO_LEVENSHTEIN:
         m->maximum = lev_maximum;
         m->distance = lev_distance;
+        m->similarity = mu_default_similarity;
+        break;
+    case RFO_OSA:
+        m->maximum = lcs_maximum; /* len1.max(len2), osa.rs:231-233, :432-434 */
+        m->distance = osa_distance;
         m->similarity = mu_default_similarity;
         break;
     case RFO_INDEL:

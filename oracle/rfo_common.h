@@ -150,6 +150,9 @@ size_t rfo_lcs_similarity_with_pm(const rfo_pm *pm, rfo_str s1, rfo_str s2, size
 size_t rfo_lcs_similarity_without_pm(rfo_str s1, rfo_str s2, size_t score_cutoff);
 size_t rfo_indel_distance_with_pm(const rfo_pm *pm, rfo_str s1, rfo_str s2, size_t score_cutoff);
 
+size_t rfo_osa_distance_with_pm(const rfo_pm *pm, rfo_str s1, rfo_str s2);
+size_t rfo_osa_distance_without_pm(rfo_str s1, rfo_str s2);
+
 double rfo_jaro_similarity_with_pm(const rfo_pm *pm, rfo_str s1, rfo_str s2, double score_cutoff);
 double rfo_jaro_similarity_without_pm(rfo_str s1, rfo_str s2, double score_cutoff);
 double rfo_jw_similarity_with_pm(const rfo_pm *pm, rfo_str s1, rfo_str s2, double prefix_weight,

@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-enum { RFO_LEVENSHTEIN = 0, RFO_INDEL = 1, RFO_LCS_SEQ = 2, RFO_JARO = 3, RFO_JARO_WINKLER = 4, RFO_FUZZ_RATIO = 5 };
+enum { RFO_LEVENSHTEIN = 0, RFO_INDEL = 1, RFO_LCS_SEQ = 2, RFO_JARO = 3, RFO_JARO_WINKLER = 4, RFO_FUZZ_RATIO = 5, RFO_OSA = 6 };
 enum { RFO_OP_DISTANCE = 0, RFO_OP_SIMILARITY = 1, RFO_OP_NORMALIZED_DISTANCE = 2, RFO_OP_NORMALIZED_SIMILARITY = 3 };
 
 /* flattened `Args` builders (levenshtein.rs:86-126, jaro_winkler.rs:25-62, lcs_seq.rs / indel.rs / jaro.rs /

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librfgpu.so")
 
 RF_OK, RF_ERR_INVALID_ARG, RF_ERR_HIP, RF_ERR_UNSUPPORTED, RF_ERR_NO_DEVICE, RF_ERR_OOM = range(6)
 STATUS_NAMES = ["RF_OK", "RF_ERR_INVALID_ARG", "RF_ERR_HIP", "RF_ERR_UNSUPPORTED", "RF_ERR_NO_DEVICE", "RF_ERR_OOM"]
-LEVENSHTEIN, INDEL, LCS_SEQ, JARO, JARO_WINKLER, FUZZ_RATIO = range(6)
+LEVENSHTEIN, INDEL, LCS_SEQ, JARO, JARO_WINKLER, FUZZ_RATIO, OSA = range(7)
 OP_DISTANCE, OP_SIMILARITY, OP_NORMALIZED_DISTANCE, OP_NORMALIZED_SIMILARITY = range(4)
 MEM_HOST, MEM_DEVICE = 0, 1
 NO_CUTOFF = 2**64 - 1

@@ -120,7 +120,7 @@ void rf_args_default(rf_args* a)
 // ---------------------------------------------------------------------------------------------------
 rf_status rf_comparator_new(rf_metric metric, const uint8_t* s1, size_t len1, rf_comparator** out)
 {
-    if (!out || (len1 && !s1) || (int)metric < 0 || (int)metric > (int)RF_FUZZ_RATIO) {
+    if (!out || (len1 && !s1) || (int)metric < 0 || (int)metric > (int)RF_OSA) {
         set_error("rf_comparator_new: invalid argument");
         return RF_ERR_INVALID_ARG;
     }
@@ -519,7 +519,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->n_tiles = corpus->n_tiles;
     p->n = (uint32_t)corpus->n;
 
-    const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ;
+    const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
     const bool norm_op = op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY;
     if ((int)op < 0 || (int)op > (int)RF_OP_NORMALIZED_SIMILARITY) {
         set_error("unknown rf_op");
@@ -569,6 +569,14 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         }
         break;
     }
+    case RF_OSA:  // osa.rs:431-461; maximum = max(len1, len2) = levenshtein's at unit weights
+        *raw = RAW_OSA;
+        p->finish = FIN_LEV;
+        if (c->words > (size_t)kMaxWords) {
+            set_error("osa: queries longer than 512 symbols have no device kernel");
+            return RF_ERR_UNSUPPORTED;
+        }
+        break;
     case RF_INDEL:
         *raw = RAW_LCS;
         p->finish = FIN_INDEL;

@@ -28,7 +28,8 @@ struct TileDesc {
 enum RawKind : uint32_t {
     RAW_LEV = 0,   // uniform Levenshtein distance (Myers/Hyyro)
     RAW_LCS = 1,   // LCS length (Hyyro)
-    RAW_JARO = 2   // Jaro flags + transpositions
+    RAW_JARO = 2,  // Jaro flags + transpositions
+    RAW_OSA = 3    // optimal string alignment distance (Hyyro + transposition term)
 };
 
 // how the raw per-candidate primitive becomes the reference's return value

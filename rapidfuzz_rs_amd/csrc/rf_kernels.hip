@@ -160,6 +160,74 @@ struct LevState {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// OSA (optimal string alignment, src/distance/osa.rs:60-226): Hyyro's recurrence plus the transposition term
+//   tr = ((~D0_old & PM) << 1 | carry from the word below) & PM_old          (osa.rs:86, :180)
+// OR-ed into D0, which costs two more bit-vectors of state per word (D0 and the previous column's PM).
+// ---------------------------------------------------------------------------------------------------
+template <int W>
+struct OsaState {
+    using Word = uint64_t;
+    static constexpr int kWords = W;
+    uint64_t vp[W], vn[W], d0[W], pm_old[W];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            vp[w] = ~0ull;  // osa.rs:74-77, :125-135
+            vn[w] = 0;
+            d0[w] = 0;
+            pm_old[w] = 0;
+        }
+    }
+    __device__ __forceinline__ void step(const uint64_t (&pm_row)[W])
+    {
+        uint32_t hp_c = 1, hn_c = 0, tr_c = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t pm_j = pm_row[w];
+            const uint64_t t = ~d0[w] & pm_j;                              // candidates for a transposition
+            const uint64_t tr = (w == 0 ? shl1_const<0>(t) : shl1_var(t, tr_c)) & pm_old[w];  // osa.rs:180
+            if (w + 1 < W) tr_c = (uint32_t)(t >> 63);                      // ((~d0_last) & pm_last) >> 63 for the next word
+            uint64_t x = pm_j;
+            if (w > 0) x |= hn_c;                                           // osa.rs:182
+            const uint64_t p = vp[w], n = vn[w];
+            const uint64_t sum = (x & p) + p;
+            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
+            const uint64_t d = e | n | tr;                                  // osa.rs:183
+            const uint64_t hn = d & p;
+            const uint64_t hp = lut3<T_OR_NOR>(n, d, p);
+            const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_var(hp, hp_c);
+            const uint64_t hns = w == 0 ? shl1_const<0>(hn) : shl1_var(hn, hn_c);
+            if (w + 1 < W) {
+                hp_c = (uint32_t)(hp >> 63);
+                hn_c = (uint32_t)(hn >> 63);
+            }
+            vn[w] = hps & d;
+            vp[w] = lut3<T_OR_NOR>(hns, hps, d);
+            d0[w] = d;
+            pm_old[w] = pm_j;
+        }
+    }
+    // the vertical-delta identity and the last-row bound hold for the OSA matrix as well (unit steps)
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    {
+        return (int32_t)result(len1, j) - (int32_t)(len2 - j) > (int32_t)raw_cutoff;
+    }
+    __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
+    {
+        int32_t d = (int32_t)len2;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int32_t bits = (int32_t)len1 - 64 * w;
+            const uint64_t valid = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1));
+            d += __popcll(vp[w] & valid) - __popcll(vn[w] & valid);
+        }
+        return (uint32_t)d;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
 // LCS: Hyyro's bit-parallel LCS length (lcs_seq.rs:222-252): S' = (S + (S & M)) | (S - (S & M)) with the
 // add's carry chained across words; similarity = sum popcount(~S).
 // ---------------------------------------------------------------------------------------------------
@@ -1374,6 +1442,7 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     switch (raw) {
     case RAW_LEV: return p.len1 <= 32 ? launch_state<Lev32State>(p, stream, grid) : launch_words<LevState>(p, stream, grid);
     case RAW_LCS: return p.len1 <= 32 ? launch_state<Lcs32State>(p, stream, grid) : launch_words<LcsState>(p, stream, grid);
+    case RAW_OSA: return launch_words<OsaState>(p, stream, grid);
     case RAW_JARO: {
         // tiles [tile_begin, jaro_split) take the single-word path, [jaro_split, tile_end) the multi-word path
         // (tiles ascend by length, and the single-word condition holds for a length prefix)

@@ -21,8 +21,8 @@ U64MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
 AB = np.frombuffer(b"ab", dtype=np.uint8)
 ABCD = np.frombuffer(b"abcd", dtype=np.uint8)
 
-GPU = {"levenshtein": rf.distance.levenshtein, "indel": rf.distance.indel, "lcs_seq": rf.distance.lcs_seq, "jaro": rf.distance.jaro, "jaro_winkler": rf.distance.jaro_winkler}
-ORA = {"levenshtein": o.levenshtein, "indel": o.indel, "lcs_seq": o.lcs_seq, "jaro": o.jaro, "jaro_winkler": o.jaro_winkler}
+GPU = {"levenshtein": rf.distance.levenshtein, "indel": rf.distance.indel, "lcs_seq": rf.distance.lcs_seq, "jaro": rf.distance.jaro, "jaro_winkler": rf.distance.jaro_winkler, "osa": rf.distance.osa}
+ORA = {"levenshtein": o.levenshtein, "indel": o.indel, "lcs_seq": o.lcs_seq, "jaro": o.jaro, "jaro_winkler": o.jaro_winkler, "osa": o.osa}
 OPS = {"distance": N.OP_DISTANCE, "similarity": N.OP_SIMILARITY, "normalized_distance": N.OP_NORMALIZED_DISTANCE, "normalized_similarity": N.OP_NORMALIZED_SIMILARITY}
 
 
@@ -137,6 +137,49 @@ def test_topk_refuses_long_query_loudly():
     with pytest.raises(rf.RfError) as e:
         GPU["levenshtein"].BatchComparator(b"a" * 600).topk(corpus, 4)
     assert e.value.status == N.RF_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------- OSA (widening row f3)
+@pytest.mark.parametrize("qlen", [0, 1, 2, 17, 63, 64, 65, 128, 200, 512])
+def test_osa_ragged(qlen):
+    rng = np.random.default_rng(qlen + 900)
+    alpha = ABCD if qlen % 2 else synth.ALNUM
+    q = alpha[rng.integers(0, len(alpha), size=qlen)].tobytes()
+    data, offsets = synth.ragged_host(3000, max(80, min(2 * qlen, 600)), seed=qlen + 31, alphabet=alpha)
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+    for i in range(0, len(cands), 8):  # the query with adjacent transpositions and a few substitutions
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 6))):
+            if len(b) > 1:
+                k = int(rng.integers(0, len(b) - 1))
+                b[k], b[k + 1] = b[k + 1], b[k]
+        for _ in range(int(rng.integers(0, 3))):
+            if len(b):
+                b[int(rng.integers(0, len(b)))] = int(alpha[int(rng.integers(0, len(alpha)))])
+        cands[i] = bytes(b)
+    data, offsets = rf.ragged(cands)
+    d = _check_many("osa", q, data, offsets, "distance")
+    lev = GPU["levenshtein"].BatchComparator(q).distance_many(rf.Corpus.from_ragged(data, offsets))
+    assert (d <= lev).all() and (qlen < 2 or (d < lev).any())  # transpositions cost 1 instead of 2
+    for op in ("similarity", "normalized_distance", "normalized_similarity"):
+        _check_many("osa", q, data, offsets, op)
+    for k in (0, 1, 3, qlen // 2 + 1):
+        _check_many("osa", q, data, offsets, "distance", score_cutoff=k)
+        _check_many("osa", q, data, offsets, "similarity", score_cutoff=k)
+
+
+def test_osa_known_answers_and_topk_on_gpu():
+    bc = GPU["osa"].BatchComparator
+    assert bc("CA").distance("ABC") == 3 and bc("CA").distance("AC") == 1 and bc("").distance("") == 0  # osa.rs:669-680
+    assert bc("aaaa").distance("") == 4 and bc("aaaa").distance("", score_cutoff=1) is None
+    filler = "a" * 64
+    s1, s2 = "a" + filler + "CA" + filler + "a", "b" + filler + "AC" + filler + "b"
+    assert bc(s1).distance(s2) == 3 and bc(s2).distance(s1) == 3
+    cands = [b"AC", b"CA", b"ABC", b"", b"CAA", b"ACA"]
+    s, i = bc("CA").topk(rf.Corpus.from_list(cands), 3)
+    assert list(zip(s.tolist(), i.tolist())) == sorted((o.osa.distance("CA", c), j) for j, c in enumerate(cands))[:3]
+    with pytest.raises(rf.RfError):
+        bc(b"a" * 600).distance_many(rf.Corpus.from_list([b"abc"]))
 
 
 # ---------------------------------------------------------------- weights (levenshtein.rs:1285-1331)

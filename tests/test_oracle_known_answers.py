@@ -332,6 +332,22 @@ def test_jaro_winkler_unicode():  # jaro_winkler.rs:800-808
     _approx(0.375, _four_way(o.jaro_winkler, "distance", a, b, tol=1e-4, score_cutoff=1.0))
 
 
+# ---------------------------------------------------------------- osa.rs:618-693 ("next" row f3 of SURVEY 8)
+def test_osa_simple_and_unicode():
+    d = lambda a, b, **kw: _four_way(o.osa, "distance", a, b, **kw)
+    big = 2**64 - 1  # the upstream helper passes score_cutoff = usize::MAX
+    assert d("", "", score_cutoff=big) == 0
+    assert d("aaaa", "", score_cutoff=big) == 4
+    assert d("aaaa", "", score_cutoff=1) is None
+    assert d("CA", "ABC", score_cutoff=big) == 3
+    assert d("CA", "AC", score_cutoff=big) == 1
+    filler = "a" * 64
+    s1, s2 = "a" + filler + "CA" + filler + "a", "b" + filler + "AC" + filler + "b"
+    assert d(s1, s2, score_cutoff=big) == 3  # > 64 symbols: hyrroe2003_block with the cross-word transposition term
+    a, b = _rename("Иванко", "Петрунко")
+    assert d(a, b) == 5
+
+
 # ---------------------------------------------------------------- fuzz.rs:186-301
 def test_fuzz_ratio():
     s1, s3 = "new york mets", "the wonderful new york mets"

@@ -143,3 +143,28 @@ def test_reference_quirk_levenshtein_similarity_cutoff_sentinel():
     assert o.levenshtein.BatchComparator(a).similarity(b, score_cutoff=2) == 11  # a sentinel, not a similarity
     # below 4 the mbleven path returns cutoff + 1 instead of usize::MAX and the value stays in range
     assert o.levenshtein.BatchComparator(b"aaaa").similarity(b"bbbb", score_cutoff=2) is None
+
+
+def test_osa_exact_and_cutoff():
+    rng = np.random.default_rng(77)
+    pairs = SHORT[:250] + LONG[:12]
+    # adjacent transpositions are what separates OSA from Levenshtein: make sure they occur
+    for a, _ in SHORT[250:330]:
+        b = bytearray(a)
+        for _ in range(3):
+            if len(b) > 1:
+                i = int(rng.integers(0, len(b) - 1))
+                b[i], b[i + 1] = b[i + 1], b[i]
+        pairs.append((a, bytes(b)))
+    seen_less = False
+    for a, b in pairs:
+        d = tb.osa(a, b)
+        seen_less |= d < tb.levenshtein_unit(a, b)
+        bc = o.osa.BatchComparator(a)
+        assert o.osa.distance(a, b) == d and bc.distance(b) == d, (a, b)
+        m = max(len(a), len(b))
+        assert bc.similarity(b) == m - d
+        for k in sorted({0, 1, max(d - 1, 0), d, d + 1}):
+            exp = d if d <= k else None
+            assert o.osa.distance(a, b, score_cutoff=k) == exp and bc.distance(b, score_cutoff=k) == exp
+    assert seen_less

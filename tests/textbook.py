@@ -105,3 +105,20 @@ def jaro_winkler(a, b, prefix_weight=0.1) -> float:
     if sim > 0.7:
         sim += prefix * prefix_weight * (1.0 - sim)
     return sim
+
+
+def osa(a, b) -> int:
+    """Optimal string alignment (restricted Damerau-Levenshtein): unit edits + adjacent transposition."""
+    a, b = _b(a), _b(b)
+    la, lb = len(a), len(b)
+    d = np.zeros((la + 1, lb + 1), dtype=np.int64)
+    d[:, 0] = np.arange(la + 1)
+    d[0, :] = np.arange(lb + 1)
+    for i in range(1, la + 1):
+        for j in range(1, lb + 1):
+            cost = 0 if a[i - 1] == b[j - 1] else 1
+            v = min(d[i - 1, j] + 1, d[i, j - 1] + 1, d[i - 1, j - 1] + cost)
+            if i > 1 and j > 1 and a[i - 1] == b[j - 2] and a[i - 2] == b[j - 1]:
+                v = min(v, d[i - 2, j - 2] + 1)
+            d[i, j] = v
+    return int(d[la, lb])
