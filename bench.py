@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--cand-len", type=int, default=64)
     ap.add_argument("--query-len", type=int, default=64)
     ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq", "osa", "jaro", "jaro_winkler"])
+    ap.add_argument("--queries", type=int, default=1, help="Q > 1: Q queries x the corpus through rf_many_multi_u32 (N=1, many mode)")
     ap.add_argument("--cutoff", type=int, default=None)
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--mode", default="many", choices=["many", "topk"],
@@ -72,6 +73,9 @@ def main():
     q = synth.query(args.query_len, 0xC0FFEE02)
     mod = getattr(rf.distance, args.metric)
     scorer = mod.BatchComparator(q)
+    nq = args.queries if (world == 1 and not force_dist and args.mode == "many") else 1
+    queries = [q] + [synth.query(args.query_len, 0xC0FFEE02 + 31 * j) for j in range(1, nq)]
+    scorers = [scorer] + [mod.BatchComparator(x) for x in queries[1:]]
 
     # synthetic corpus, generated and packed on the device (excluded from the timed region)
     t0 = time.time()
@@ -102,7 +106,7 @@ def main():
     t_setup = time.time() - t0
 
     is_f64 = args.metric in ("jaro", "jaro_winkler")
-    out = torch.empty(n, dtype=torch.float64 if is_f64 else torch.int32, device=dev)
+    out = torch.empty(n * nq, dtype=torch.float64 if is_f64 else torch.int32, device=dev)
     call_args = rf.Args()
     if args.cutoff is not None:
         call_args = call_args.score_cutoff(args.cutoff)
@@ -113,7 +117,9 @@ def main():
     last_topk = [None]
 
     def step():
-        if is_f64:  # BASELINE.json configs[3]: similarity, f64 per candidate
+        if nq > 1:
+            mod.BatchComparator.many_multi(scorers, N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE, corpus, call_args, out=out, stream=stream.cuda_stream)
+        elif is_f64:  # BASELINE.json configs[3]: similarity, f64 per candidate
             scorer.similarity_many(corpus, call_args, out=out, stream=stream.cuda_stream)
         elif args.mode == "many" and world == 1 and not force_dist:
             scorer.distance_many(corpus, call_args, out=out, stream=stream.cuda_stream)
@@ -179,12 +185,13 @@ def main():
             dist.destroy_process_group()
         return
 
-    pairs_per_step = n * world
+    pairs_per_step = n * world * nq
     ms_per_step = elapsed * 1e3 / args.steps
     gpairs = pairs_per_step / (elapsed / args.steps) / 1e9
     # algorithmic bytes per pair: candidate bytes at bucket length + one u32 result
-    bytes_per_pair = ln + (8 if is_f64 else (4 if args.mode == "many" else 0))
-    achieved = n * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
+    # (Q fused queries read each candidate once: ln / Q candidate bytes per pair)
+    bytes_per_pair = ln / nq + (8 if is_f64 else (4 if args.mode == "many" else 0))
+    achieved = n * nq * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
 
     result = {
         "metric": "Gpairs/s (1 query x N candidates, Levenshtein BatchComparator semantics)" if args.metric == "levenshtein" else f"Gpairs/s ({args.metric})",
@@ -206,6 +213,7 @@ def main():
             "candidates_per_gpu": n,
             "candidate_len": ln,
             "query_len": args.query_len,
+            "queries": nq,
             "output": ("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else f"top-{args.topk} only",
             "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if world > 1 else "1 GPU",
             "setup_s": round(t_setup, 2),
@@ -236,14 +244,17 @@ def main():
         torch.cuda.synchronize()
         chk = min(len(host_sample), 2_000_000)
         op = N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE
-        exp = getattr(o, args.metric).BatchComparator(q).rows(op, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)
-        if is_f64:
-            got = out[:chk].cpu().numpy()
-            bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
-        else:
-            got = out[:chk].cpu().numpy().view(np.uint32)
-            bad = got != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
-        result["parity"] = {"checked": int(chk), "mismatches": int(bad.sum())}
+        mism = 0
+        for j in range(nq):
+            exp = getattr(o, args.metric).BatchComparator(queries[j]).rows(op, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)
+            if is_f64:
+                got = out[j * n : j * n + chk].cpu().numpy()
+                bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
+            else:
+                got = out[j * n : j * n + chk].cpu().numpy().view(np.uint32)
+                bad = got != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
+            mism += int(bad.sum())
+        result["parity"] = {"checked": int(chk) * nq, "mismatches": mism}
     print(json.dumps(result))
     if world > 1 or force_dist:
         dist.destroy_process_group()

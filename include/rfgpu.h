@@ -164,6 +164,19 @@ rf_status rf_many_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op,
 rf_status rf_many_f64(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args,
                       double *out, rf_mem out_mem, void *stream);
 
+/* ---- many queries x one corpus ------------------------------------------------------------------
+ * The reference's user loop one level up: `for q in queries { let scorer = BatchComparator::new(q);
+ * for c in corpus { scorer.<op>_with_args(c, &args) } }`.  out is row-major [q][n]: row j is exactly what
+ * rf_many_u32 / rf_many_f64 writes for cs[j] (same op, same args for every query).  All comparators must
+ * be usable with `op` the way rf_many_* requires.  Neighbouring comparators of one metric whose queries
+ * are <= 64 symbols (levenshtein / indel / lcs_seq / fuzz ratio) are evaluated 4 (or 2) at a time by one
+ * kernel that reads each candidate once per group; everything else falls back to one launch per query.
+ * Memory/stream conventions as rf_many_*. */
+rf_status rf_many_multi_u32(const rf_comparator *const *cs, uint32_t q, const rf_corpus *corpus, rf_op op,
+                            const rf_args *args, uint32_t *out, rf_mem out_mem, void *stream);
+rf_status rf_many_multi_f64(const rf_comparator *const *cs, uint32_t q, const rf_corpus *corpus, rf_op op,
+                            const rf_args *args, double *out, rf_mem out_mem, void *stream);
+
 /* ---- top-k ------------------------------------------------------------------------------------
  * The reference has no extract/top-k API; this is the engine's own reduction over the scores above,
  * defined as: evaluate every candidate with `op`/`args`, drop None, order by

@@ -10,7 +10,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import math
-from typing import NamedTuple, Optional
+from typing import NamedTuple, Optional, Sequence
 
 import numpy as np
 
@@ -154,6 +154,29 @@ class BatchComparator:
             return out
         res = np.empty(n, dtype=np.float64 if is_f else np.uint32) if out is None else out
         N.check(fn(self._h, corpus._h, op, C.byref(ca), res.ctypes.data, N.MEM_HOST, stream))
+        return res
+
+    @classmethod
+    def many_multi(cls, comparators: Sequence["BatchComparator"], op: int, corpus: Corpus, args: Optional[Args] = None, out=None,
+                   stream=None, *, score_cutoff=None, score_hint=None, weights=None, prefix_weight=None):
+        """[len(comparators), len(corpus)] scores: row j is `comparators[j].many(op, corpus, ...)` (rf_many_multi_*).
+        Queries of <= 64 symbols are fused 4 at a time into one pass over the corpus."""
+        a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
+        is_f = cls.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
+        ca = a.to_c(is_f)
+        q, n = len(comparators), len(corpus)
+        hs = (C.c_void_p * max(q, 1))(*[c._h for c in comparators])
+        fn = N.lib().rf_many_multi_f64 if is_f else N.lib().rf_many_multi_u32
+        if out is not None and hasattr(out, "is_cuda") and out.is_cuda:
+            import torch
+
+            want = torch.float64 if is_f else (torch.uint32 if out.dtype == torch.uint32 else torch.int32)
+            assert out.dtype == want and out.numel() >= q * n and out.is_contiguous(), "out tensor has the wrong dtype/shape"
+            st = stream if stream is not None else torch.cuda.current_stream(out.device).cuda_stream
+            N.check(fn(hs, q, corpus._h, op, C.byref(ca), out.data_ptr(), N.MEM_DEVICE, st))
+            return out
+        res = np.empty((q, n), dtype=np.float64 if is_f else np.uint32) if out is None else out
+        N.check(fn(hs, q, corpus._h, op, C.byref(ca), res.ctypes.data, N.MEM_HOST, stream))
         return res
 
     def distance_many(self, corpus, args=None, **kw):

@@ -713,6 +713,109 @@ rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// many queries x one corpus
+// ---------------------------------------------------------------------------------------------------
+// Queries whose recurrences fit one machine word and agree on the kernel family are fused kMaxMulti (then 2) at a
+// time into scan_multi_kernel launches, which read every candidate byte once per group; the rest go through the
+// single-query launch.  Either way row q of `out` is exactly what rf_many_* gives for cs[q].
+static rf_status run_many_multi(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+                                void* out, rf_mem out_mem, void* stream, bool f64_out)
+{
+    if (!cs || !corpus || !args) {
+        set_error("null handle or args");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (q == 0 || corpus->n == 0) return RF_OK;
+    if (!out) {
+        set_error("null output");
+        return RF_ERR_INVALID_ARG;
+    }
+    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
+    const size_t row_bytes = corpus->n * elem;
+    std::vector<ScanParams> ps(q);
+    std::vector<RawKind> raws(q, RAW_LEV);
+    for (uint32_t i = 0; i < q; ++i) {
+        const rf_status s = plan(cs[i], corpus, op, args, f64_out, &ps[i], &raws[i]);
+        if (s != RF_OK) return s;
+    }
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* d_out = static_cast<char*>(out);
+    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc((void**)&d_out, row_bytes * q));
+
+    // fusable: single-word Levenshtein / LCS-family recurrences; the group key is what the kernel cannot vary per query
+    auto fusable = [&](uint32_t i) { return (raws[i] == RAW_LEV || raws[i] == RAW_LCS) && cs[i]->words == 1 && !ps[i].long_words_pad; };
+    auto same_group = [&](uint32_t a, uint32_t b) {
+        return raws[a] == raws[b] && ps[a].finish == ps[b].finish && ps[a].factor == ps[b].factor && ps[a].op == ps[b].op &&
+               (ps[a].len1 <= 32) == (ps[b].len1 <= 32);
+    };
+    std::vector<char> done(q, 0);
+    rf_status status = RF_OK;
+    hipError_t e = hipSuccess;
+    for (uint32_t i = 0; i < q && status == RF_OK && e == hipSuccess; ++i) {
+        if (done[i]) continue;
+        std::vector<uint32_t> group{i};
+        if (fusable(i))
+            for (uint32_t j = i + 1; j < q && group.size() < (size_t)kMaxMulti; ++j)
+                if (!done[j] && fusable(j) && same_group(i, j) && j == group.back() + 1) group.push_back(j);  // contiguous rows of out
+        if (group.size() == 3) group.pop_back();
+        for (uint32_t g : group) done[g] = 1;
+        ScanParams p = ps[i];
+        p.out = d_out + (size_t)i * row_bytes;
+        if (group.size() == 1) {
+            status = comparator_device_pm(cs[i], corpus->device, &p.pm);
+            if (status != RF_OK) break;
+            if (p.long_words_pad) {
+                const size_t scratch = (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t);
+                e = hipMallocAsync((void**)&p.long_scratch, scratch, st);
+                if (e != hipSuccess) break;
+            }
+            e = launch_scan(raws[i], p, st, nullptr);
+            if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
+        } else {
+            p.early = 0;  // the fused kernel always runs every column (values are the same either way)
+            p.multi_q = (uint32_t)group.size();
+            for (size_t k = 0; k < group.size() && status == RF_OK; ++k) {
+                p.multi_len1[k] = ps[group[k]].len1;
+                status = comparator_device_pm(cs[group[k]], corpus->device, &p.multi_pm[k]);
+            }
+            if (status != RF_OK) break;
+            e = launch_scan_multi(raws[i], p.len1 <= 32, p, st);
+        }
+    }
+    if (status == RF_OK && e == hipSuccess && out_mem == RF_MEM_HOST) {
+        e = hipMemcpyAsync(out, d_out, row_bytes * q, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (out_mem == RF_MEM_HOST) {
+        if (status != RF_OK || e != hipSuccess) (void)hipStreamSynchronize(st);
+        (void)hipFree(d_out);
+    }
+    if (status != RF_OK) return status;
+    if (e != hipSuccess) {
+        set_error(std::string("multi-query scan: ") + hipGetErrorString(e));
+        return e == hipErrorInvalidValue ? RF_ERR_UNSUPPORTED : RF_ERR_HIP;
+    }
+    return RF_OK;
+}
+
+rf_status rf_many_multi_u32(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+                            uint32_t* out, rf_mem out_mem, void* stream)
+{
+    return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, false);
+}
+
+rf_status rf_many_multi_f64(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+                            double* out, rf_mem out_mem, void* stream)
+{
+    return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, true);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // top-k
 // ---------------------------------------------------------------------------------------------------
 // shared by rf_topk_u32 (host results) and rf_topk_keys_device (device keys, fully asynchronous)

@@ -16,6 +16,7 @@ constexpr int kChunk = 16;         // bytes per lane per global_load_dwordx4
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups, one wave per SIMD
 constexpr int kMaxWords = 8;       // query <= 512 symbols keeps VP/VN register-resident
 constexpr uint32_t kPad = 0xFFFFFFFFu;
+constexpr int kMaxMulti = 4;       // queries fused into one scan_multi_kernel launch
 
 // One tile = 64 candidates of identical length `len`, stored chunk-interleaved:
 // byte b of lane r lives at data_off + ((b / 16) * 64 + r) * 16 + (b % 16).
@@ -67,6 +68,10 @@ struct ScanParams {
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
     double cutoff_f64;
     double prefix_weight;
+    // many queries x one corpus (scan_multi_kernel): Q single-word tables, out is [Q][n]
+    uint32_t multi_q;
+    uint32_t multi_len1[kMaxMulti];
+    const uint64_t* multi_pm[kMaxMulti];
     // patterns longer than kMaxWords * 64 symbols (long_kernel): PM rows padded to long_words_pad (multiple of 8)
     uint32_t long_words_pad;  // 0 = register-resident kernels
     uint32_t long_chunks_max; // scratch strip length per wavefront, in 16-column chunks
@@ -85,6 +90,7 @@ struct ScanParams {
 
 // kernels (rf_kernels.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
+hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipStream_t stream);
 hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* scratch, uint64_t* out, hipStream_t stream);
 size_t topk_merge_scratch_entries(uint32_t n, uint32_t k);
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,

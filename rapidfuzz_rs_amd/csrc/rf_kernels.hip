@@ -368,10 +368,9 @@ struct UsizeResult {
     uint32_t dist, maximum;
 };
 
-__device__ __forceinline__ UsizeResult usize_result(const ScanParams& p, uint32_t raw, uint32_t len2)
+__device__ __forceinline__ UsizeResult usize_result(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t len1)
 {
     UsizeResult r;
-    const uint32_t len1 = p.len1;
     if (p.finish == FIN_LEV) {  // uniform weights: distance * factor (levenshtein.rs:1308-1316)
         r.dist = raw * p.factor;
         r.maximum = lev_maximum(p, len1, len2);
@@ -388,9 +387,9 @@ __device__ __forceinline__ UsizeResult usize_result(const ScanParams& p, uint32_
 // Which value the op yields and whether `score()` (src/common.rs:43-45 / :83-85) keeps it.  All kernels on
 // this path are exact, so the CPU-side cutoff plumbing (details/distance.rs:157-274) reduces to
 // "compute the value, then compare with the user's cutoff" -- see DESIGN.md "cutoff equivalence".
-__device__ __forceinline__ uint32_t usize_value(const ScanParams& p, uint32_t raw, uint32_t len2, bool* keep)
+__device__ __forceinline__ uint32_t usize_value(const ScanParams& p, uint32_t raw, uint32_t len2, bool* keep, uint32_t len1)
 {
-    const UsizeResult r = usize_result(p, raw, len2);
+    const UsizeResult r = usize_result(p, raw, len2, len1);
     uint32_t v;
     if (p.op == RF_OP_DISTANCE) {
         v = r.dist;
@@ -402,14 +401,15 @@ __device__ __forceinline__ uint32_t usize_value(const ScanParams& p, uint32_t ra
     return v;
 }
 
-__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx)
+// `out` / `len1` default to the launch's single query; the multi-query kernel passes its own per query
+__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx, void* out, uint32_t len1)
 {
     if (!p.out_f64) {
         bool keep;
-        const uint32_t v = usize_value(p, raw, len2, &keep);
-        reinterpret_cast<uint32_t*>(p.out)[idx] = keep ? v : RF_NONE_U32;
+        const uint32_t v = usize_value(p, raw, len2, &keep, len1);
+        reinterpret_cast<uint32_t*>(out)[idx] = keep ? v : RF_NONE_U32;
     } else {
-        const UsizeResult r = usize_result(p, raw, len2);
+        const UsizeResult r = usize_result(p, raw, len2, len1);
         // details/distance.rs:246-250: dist / maximum (0.0 when maximum == 0)
         const double nd = r.maximum == 0 ? 0.0 : (double)r.dist / (double)r.maximum;
         double v;
@@ -421,8 +421,12 @@ __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, ui
             v = 1.0 - nd;
             keep = !p.has_cutoff || v >= p.cutoff_f64;
         }
-        reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
+        reinterpret_cast<double*>(out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
     }
+}
+__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx)
+{
+    emit_usize(p, raw, len2, idx, p.out, p.len1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -638,7 +642,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
             }
             if (topk && !dead) {
                 bool keep;
-                const uint32_t v = usize_value(p, raw, len2, &keep);
+                const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
                 const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
                 // Launch-wide pruning bound: once ANY wavefront holds k keys, its worst key bounds the global k-th
                 // best.  Wavefronts publish that with a 64-bit atomic min and read it (possibly stale = merely
@@ -686,6 +690,104 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_
     __shared__ typename State::Word lds_pm[256 * State::kWords];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
     scan_body<State, kUniform>(p, lds_pm, lds_topk);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Many queries x one corpus: Q pattern-match tables sit side by side in LDS and every 16-column
+// chunk a wavefront loads from HBM is run through Q recurrences before the next chunk is touched, so the candidate
+// bytes are read ONCE for Q queries -- the arithmetic intensity per HBM byte rises Q-fold, which is what the
+// HBM-bound kernels (LCS / Indel / the 32-bit forms) need.  out is [Q][n], original candidate order per query.
+// ---------------------------------------------------------------------------------------------------
+template <class State, int Q, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_multi_kernel(const ScanParams p)
+{
+    using Word = typename State::Word;
+    static_assert(State::kWords == 1, "multi-query kernels are single-word");
+    __shared__ Word lds_pm[Q][256];
+    for (int i = threadIdx.x; i < Q * 256; i += kWave * kWavesPerBlock) {
+        const int q = i / 256, c = i % 256;
+        lds_pm[q][p.sigma[c]] = (Word)p.multi_pm[q][c];  // single-word tables: row stride 1
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
+    if (t >= p.n_tiles) return;
+    TileView cur_tile = load_tile<kUniform>(p, t);
+    uint4 cur = cur_tile.src[lane];
+
+    while (true) {
+        const uint32_t t_next = t + stride;
+        const bool has_next = t_next < p.n_tiles;
+        const TileView next_tile = load_tile<kUniform>(p, has_next ? t_next : t);
+        const uint32_t len2 = cur_tile.len;
+        const uint32_t slot = cur_tile.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+
+        State st[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) st[q].init();
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint4* nsrc = (c + 1 < nch) ? cur_tile.src + (size_t)(c + 1) * kWave : next_tile.src;
+            const uint4 nxt = nsrc[lane];
+            const uint32_t cols = len2 - c * kChunk;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (cols >= kChunk)
+                    process_chunk_full<State>(st[q], lds_pm[q], cur);
+                else
+                    process_chunk_tail<State>(st[q], lds_pm[q], cur, cols);
+            }
+            cur = nxt;
+        }
+        if (nch == 0) cur = next_tile.src[lane];
+
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t raw = st[q].result(p.multi_len1[q], len2);
+                char* out = reinterpret_cast<char*>(p.out) + (size_t)q * p.n * (p.out_f64 ? sizeof(double) : sizeof(uint32_t));
+                emit_usize(p, raw, len2, idx, out, p.multi_len1[q]);
+            }
+        }
+        if (!has_next) break;
+        t = t_next;
+        cur_tile = next_tile;
+    }
+}
+
+template <class State, int Q>
+static hipError_t launch_multi_q(const ScanParams& p, hipStream_t stream, int grid)
+{
+    const dim3 g(grid), b(kWave * kWavesPerBlock);
+    if (p.tiles)
+        hipLaunchKernelGGL((scan_multi_kernel<State, Q, false>), g, b, 0, stream, p);
+    else
+        hipLaunchKernelGGL((scan_multi_kernel<State, Q, true>), g, b, 0, stream, p);
+    return hipGetLastError();
+}
+template <class State>
+static hipError_t launch_multi_state(const ScanParams& p, hipStream_t stream, int grid)
+{
+    switch (p.multi_q) {
+    case 2: return launch_multi_q<State, 2>(p, stream, grid);
+    case 4: return launch_multi_q<State, 4>(p, stream, grid);
+    default: return hipErrorInvalidValue;
+    }
+}
+// raw: RAW_LEV or RAW_LCS; all queries single-word; `narrow` = every query <= 32 symbols
+hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipStream_t stream)
+{
+    if (p.n_tiles == 0) return hipSuccess;
+    const int grid = scan_grid(p.n_tiles);
+    if (raw == RAW_LEV) return narrow ? launch_multi_state<Lev32State>(p, stream, grid) : launch_multi_state<LevState<1>>(p, stream, grid);
+    if (raw == RAW_LCS) return narrow ? launch_multi_state<Lcs32State>(p, stream, grid) : launch_multi_state<LcsState<1>>(p, stream, grid);
+    return hipErrorInvalidValue;
 }
 
 // Reduction of many k-entry lists to k entries, in stages: every workgroup takes a slice of <= 4096 keys (4 per

@@ -3,6 +3,7 @@ oracle on the same seeded inputs.  Bit-exact for the integer metrics (u32 scores
 
 Nothing here reads /root/reference: inputs are synthetic (seeded) or the committed golden fixtures.
 """
+import ctypes as C
 import json
 import os
 
@@ -572,3 +573,63 @@ def test_large_scan_properties_and_sample():
     host = rows[:200_000].cpu().numpy()
     exp = _expect_u32(o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=8))
     assert (d[:200_000] == exp).all()
+
+
+# ---------------------------------------------------------------- many queries x one corpus (widening row f1)
+def _equal_rows(got, exp):
+    if got.dtype == np.uint32:
+        return bool((got == exp).all())
+    return bool(((got == exp) | (np.isnan(got) & np.isnan(exp))).all())
+
+
+@pytest.mark.parametrize("metric", ["levenshtein", "indel", "lcs_seq", "osa", "jaro_winkler"])
+@pytest.mark.parametrize("uniform", [False, True])
+def test_many_multi_rows_equal_single_query_rows_and_oracle(metric, uniform):
+    rng = np.random.default_rng(77)
+    # lengths chosen so that neighbours fall in and out of the fused groups: narrow (<= 32), one word, multi-word, empty
+    qlens = [5, 20, 32, 31, 33, 64, 50, 64, 40, 0, 65, 100, 7, 9, 64, 64, 64, 1]
+    queries = [ABCD[rng.integers(0, 4, size=n)].tobytes() if i % 3 else synth.query(n, 1000 + i) for i, n in enumerate(qlens)]
+    if uniform:
+        rows = synth.rows_host(4099, 48, seed=5)
+        corpus = rf.Corpus.from_rows(rows)
+        data, offsets = rows.reshape(-1), np.arange(0, rows.size + 1, 48, dtype=np.uint64)
+    else:
+        data, offsets = synth.ragged_host(4099, 80, seed=6, alphabet=ABCD)
+        corpus = rf.Corpus.from_ragged(data, offsets)
+    bc = GPU[metric].BatchComparator
+    cs = [bc(q) for q in queries]
+    cases = [("distance", {}), ("similarity", {}), ("normalized_distance", {}), ("normalized_similarity", {"score_cutoff": 0.5})]
+    if metric not in ("jaro_winkler",):
+        cases += [("distance", {"score_cutoff": 12}), ("similarity", {"score_cutoff": 10})]
+    if metric == "levenshtein":
+        cases += [("distance", {"weights": (1, 1, 2)}), ("distance", {"weights": (3, 3, 3), "score_cutoff": 40})]
+    for op, kw in cases:
+        got = bc.many_multi(cs, OPS[op], corpus, **kw)
+        assert got.shape == (len(cs), len(corpus))
+        for j, c in enumerate(cs):
+            assert _equal_rows(got[j], c.many(OPS[op], corpus, **kw)), (metric, op, kw, j, qlens[j])
+    # and straight against the oracle for the plain distance
+    got = bc.many_multi(cs, OPS["distance"], corpus)
+    for j in (0, 2, 5, 9, 14):
+        exp = ORA[metric].BatchComparator(queries[j]).many(OPS["distance"], data, offsets, nthreads=8)
+        assert _equal_rows(got[j], _expect_u32(exp) if got.dtype == np.uint32 else exp), (metric, j)
+
+
+def test_many_multi_device_output_and_empty_inputs():
+    import torch
+
+    qs = [synth.query(n, n) for n in (64, 64, 64, 64, 30, 30)]
+    rows = synth.rows_host(100_000, 64, seed=9)
+    corpus = rf.Corpus.from_rows(rows)
+    bc = rf.distance.levenshtein.BatchComparator
+    cs = [bc(q) for q in qs]
+    out = torch.empty((len(cs), len(corpus)), dtype=torch.int32, device="cuda")
+    bc.many_multi(cs, N.OP_DISTANCE, corpus, out=out)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy().view(np.uint32)
+    for j, c in enumerate(cs):
+        assert (host[j] == c.distance_many(corpus)).all()
+    assert bc.many_multi([], N.OP_DISTANCE, corpus).shape == (0, len(corpus))
+    assert bc.many_multi(cs, N.OP_DISTANCE, rf.Corpus.from_list([])).shape == (len(cs), 0)
+    with pytest.raises(rf.RfError):  # u32 entry point, f64-valued op
+        N.check(N.lib().rf_many_multi_u32((C.c_void_p * 1)(cs[0]._h), 1, corpus._h, N.OP_NORMALIZED_DISTANCE, C.byref(rf.Args().to_c(False)), out.data_ptr(), N.MEM_DEVICE, None))
