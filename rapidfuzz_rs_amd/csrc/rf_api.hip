@@ -631,6 +631,27 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
     }
 
+    {
+        // finishing coefficients: dist = dS*S + dM*Mx + dR*raw, maximum = mS*S + mM*Mx (rf_kernels.hip "Finishing")
+        const int32_t f = (int32_t)p->factor;
+        switch (p->finish) {
+        case FIN_LEV: p->fin_dS = 0, p->fin_dM = 0, p->fin_dR = f, p->fin_mS = 0, p->fin_mM = f; break;
+        case FIN_LCS: p->fin_dS = 0, p->fin_dM = 1, p->fin_dR = -1, p->fin_mS = 0, p->fin_mM = 1; break;
+        case FIN_INDEL: p->fin_dS = 1, p->fin_dM = 0, p->fin_dR = -2, p->fin_mS = 1, p->fin_mM = 0; break;
+        case FIN_LEV_INDEL: p->fin_dS = f, p->fin_dM = 0, p->fin_dR = -2 * f, p->fin_mS = f, p->fin_mM = 0; break;
+        default: break;
+        }
+        if (op == RF_OP_DISTANCE || op == RF_OP_NORMALIZED_DISTANCE) {
+            p->fin_vS = p->fin_dS, p->fin_vM = p->fin_dM, p->fin_vR = p->fin_dR;
+            p->fin_flip = 0;
+            p->fin_cflip = (p->has_cutoff && !f64_out) ? p->cutoff_u32 : 0xFFFFFFFFu;
+        } else {  // similarity = maximum - distance (details/distance.rs:209-210)
+            p->fin_vS = p->fin_mS - p->fin_dS, p->fin_vM = p->fin_mM - p->fin_dM, p->fin_vR = -p->fin_dR;
+            p->fin_flip = 0xFFFFFFFFu;
+            p->fin_cflip = ~((p->has_cutoff && !f64_out) ? p->cutoff_u32 : 0u);
+        }
+    }
+
     if (c->words > (size_t)kMaxWords) {
         // beyond 512 symbols: the multi-sweep kernel (8 words per sweep, carries parked in an HBM scratch strip)
         if (c->words > 0x00FFFFFFu) {

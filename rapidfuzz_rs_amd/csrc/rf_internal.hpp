@@ -68,6 +68,9 @@ struct ScanParams {
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
     double cutoff_f64;
     double prefix_weight;
+    // finishing coefficients (see "Finishing" in rf_kernels.hip): value = vS*S + vM*Mx + vR*raw, dist / maximum likewise
+    int32_t fin_vS, fin_vM, fin_vR, fin_dS, fin_dM, fin_dR, fin_mS, fin_mM;
+    uint32_t fin_flip, fin_cflip;
     // many queries x one corpus (scan_multi_kernel): Q single-word tables, out is [Q][n]
     uint32_t multi_q;
     uint32_t multi_len1[kMaxMulti];

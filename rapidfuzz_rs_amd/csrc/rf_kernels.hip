@@ -353,65 +353,58 @@ struct Lcs32State {
 // ---------------------------------------------------------------------------------------------------
 // finishing arithmetic: raw primitive -> the value `<op>_with_args` returns (or None)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lev_maximum(const ScanParams& p, uint32_t len1, uint32_t len2)
-{
-    // levenshtein.rs:263-277 _maximum
-    const uint32_t max_dist = len1 * p.w_del + len2 * p.w_ins;
-    const uint32_t alt = len1 >= len2 ? len2 * p.w_sub + (len1 - len2) * p.w_del : len1 * p.w_sub + (len2 - len1) * p.w_ins;
-    return min(max_dist, alt);
-}
-
 // norm_sim_to_norm_dist, src/details/common.rs:4-7
 __device__ __forceinline__ double norm_sim_to_norm_dist(double c) { return fmin(1.0 - c + 0.00001, 1.0); }
 
-struct UsizeResult {
-    uint32_t dist, maximum;
+// Finishing.  For every (metric, weights) this path serves, distance and maximum are affine in
+//   S = len1 + len2,  Mx = max(len1, len2)  and the raw recurrence result (Levenshtein distance or LCS length):
+//     uniform Levenshtein (f,f,f)      dist = f*raw            maximum = f*Mx   (levenshtein.rs:263-277, :1308-1316)
+//     lcs_seq                          dist = Mx - raw         maximum = Mx     (details/distance.rs:157-179)
+//     indel                            dist = S - 2*raw        maximum = S      (indel.rs:365-367)
+//     Levenshtein (f,f,>=2f)           dist = f*(S - 2*raw)    maximum = f*S    (levenshtein.rs:1321-1327)
+// so the host folds metric, weights and op into a few coefficients (rf_api.hip plan()) and the kernels do one
+// multiply-add per candidate with tile-uniform (scalar) S and Mx -- no per-tile branching on the metric.
+// All arithmetic is mod 2^32 like the reference's usize arithmetic is mod 2^64.
+struct TileFin {
+    uint32_t v0;       // value at raw == 0: fin_vS * S + fin_vM * Mx
+    uint32_t d0, max;  // distance at raw == 0 and the maximum (normalized ops only)
 };
-
-__device__ __forceinline__ UsizeResult usize_result(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t len1)
+__device__ __forceinline__ TileFin tile_fin(const ScanParams& p, uint32_t len1, uint32_t len2)
 {
-    UsizeResult r;
-    if (p.finish == FIN_LEV) {  // uniform weights: distance * factor (levenshtein.rs:1308-1316)
-        r.dist = raw * p.factor;
-        r.maximum = lev_maximum(p, len1, len2);
-    } else if (p.finish == FIN_LCS) {  // details/distance.rs:157-179 over lcs_seq.rs:772-793
-        r.maximum = max(len1, len2);
-        r.dist = r.maximum - raw;
-    } else {  // indel.rs:365-367; FIN_LEV_INDEL = levenshtein weights (f, f, >= 2f), levenshtein.rs:1321-1327
-        r.dist = (len1 + len2 - 2 * raw) * p.factor;
-        r.maximum = p.finish == FIN_LEV_INDEL ? lev_maximum(p, len1, len2) : (len1 + len2);
-    }
-    return r;
+    const uint32_t S = len1 + len2, Mx = max(len1, len2);
+    TileFin f;
+    f.v0 = (uint32_t)p.fin_vS * S + (uint32_t)p.fin_vM * Mx;
+    f.d0 = (uint32_t)p.fin_dS * S + (uint32_t)p.fin_dM * Mx;
+    f.max = (uint32_t)p.fin_mS * S + (uint32_t)p.fin_mM * Mx;
+    return f;
 }
-
 // Which value the op yields and whether `score()` (src/common.rs:43-45 / :83-85) keeps it.  All kernels on
 // this path are exact, so the CPU-side cutoff plumbing (details/distance.rs:157-274) reduces to
 // "compute the value, then compare with the user's cutoff" -- see DESIGN.md "cutoff equivalence".
+// distance keeps v <= cutoff, similarity keeps v >= cutoff: one compare after xor-ing both sides with fin_flip.
+__device__ __forceinline__ uint32_t usize_value(const ScanParams& p, const TileFin& f, uint32_t raw, bool* keep)
+{
+    const uint32_t v = f.v0 + (uint32_t)p.fin_vR * raw;
+    *keep = (v ^ p.fin_flip) <= p.fin_cflip;
+    return v;
+}
 __device__ __forceinline__ uint32_t usize_value(const ScanParams& p, uint32_t raw, uint32_t len2, bool* keep, uint32_t len1)
 {
-    const UsizeResult r = usize_result(p, raw, len2, len1);
-    uint32_t v;
-    if (p.op == RF_OP_DISTANCE) {
-        v = r.dist;
-        *keep = !p.has_cutoff || v <= p.cutoff_u32;
-    } else {  // similarity = maximum - distance (details/distance.rs:209-210)
-        v = r.maximum - r.dist;
-        *keep = !p.has_cutoff || v >= p.cutoff_u32;
-    }
-    return v;
+    return usize_value(p, tile_fin(p, len1, len2), raw, keep);
 }
 
 // `out` / `len1` default to the launch's single query; the multi-query kernel passes its own per query
 __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx, void* out, uint32_t len1)
 {
+    const TileFin f = tile_fin(p, len1, len2);
     if (!p.out_f64) {
         bool keep;
-        const uint32_t v = usize_value(p, raw, len2, &keep, len1);
+        const uint32_t v = usize_value(p, f, raw, &keep);
         reinterpret_cast<uint32_t*>(out)[idx] = keep ? v : RF_NONE_U32;
     } else {
-        const UsizeResult r = usize_result(p, raw, len2, len1);
+        const uint32_t dist = f.d0 + (uint32_t)p.fin_dR * raw;
         // details/distance.rs:246-250: dist / maximum (0.0 when maximum == 0)
-        const double nd = r.maximum == 0 ? 0.0 : (double)r.dist / (double)r.maximum;
+        const double nd = f.max == 0 ? 0.0 : (double)dist / (double)f.max;
         double v;
         bool keep;
         if (p.op == RF_OP_NORMALIZED_DISTANCE) {
@@ -690,6 +683,132 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_
     __shared__ typename State::Word lds_pm[256 * State::kWords];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
     scan_body<State, kUniform>(p, lds_pm, lds_topk);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The no-cutoff scan of the single-word states as a stream: every wavefront sees its tiles as ONE sequence of
+// 16-column chunks and keeps kDepth chunk loads (1 KiB each) in flight ahead of the chunk it is working on, across
+// tile boundaries.  A FETCH cursor runs kDepth chunks ahead of the PROCESS cursor; both walk (tile, chunk) pairs, and
+// a zero-length tile counts as one (unused) chunk so the two stay in lock-step.  Past the wavefront's last tile the
+// fetch cursor parks on its last valid chunk (a cached re-read).  Compared with scan_body (which also carries the
+// cutoff early-out) this loop has about half the scalar/branch instructions per chunk.
+// ---------------------------------------------------------------------------------------------------
+template <class State, bool kUniform, int kDepth>
+__device__ __forceinline__ void stream_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
+{
+    constexpr int W = State::kWords;
+    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock)
+        lds_pm[(uint32_t)p.sigma[i / W] * W + i % W] = (typename State::Word)p.pm[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const bool topk = p.topk_k != 0;
+    WaveTopK best;
+    best.init();
+
+    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
+    if (t < p.n_tiles) {
+        // fetch cursor
+        uint32_t ft = t, fc = 0;
+        TileView fv = load_tile<kUniform>(p, ft);
+        uint32_t fn = max(1u, (fv.len + kChunk - 1) / kChunk);
+        auto fetch = [&]() {
+            const uint4 v = fv.src[(size_t)fc * kWave + lane];
+            if (++fc == fn) {
+                const uint32_t nt = ft + stride;
+                if (nt < p.n_tiles) {
+                    ft = nt;
+                    fv = load_tile<kUniform>(p, ft);
+                    fn = max(1u, (fv.len + kChunk - 1) / kChunk);
+                    fc = 0;
+                } else {
+                    fc = fn - 1;
+                }
+            }
+            return v;
+        };
+        // Ring of kDepth + 1 chunk buffers with STATIC names: the loop below is unrolled over the ring phase, so
+        // no buffer is ever copied (a copy of a register with a load in flight would force a wait for that load)
+        // and the compiler's vmcnt bookkeeping stays exact.
+        uint4 buf[kDepth + 1];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) buf[d] = fetch();
+
+        // process cursor
+        TileView cur_tile = load_tile<kUniform>(p, t);
+        uint32_t c = 0;
+        uint32_t idx = cur_tile.slot0 + lane;
+        if (!kUniform) idx = p.orig[idx];
+        State st;
+        st.init();
+        bool done = false;
+        auto step = [&](const uint4& use, uint4& refill) {
+            refill = fetch();
+            const uint32_t len2 = cur_tile.len;
+            const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+            const uint32_t cols = len2 - c * kChunk;
+            if (cols >= kChunk)
+                process_chunk_full<State>(st, lds_pm, use);
+            else if (nch)
+                process_chunk_tail<State>(st, lds_pm, use, cols);
+            if (++c < max(1u, nch)) return;
+
+            // tile finished
+            const uint32_t slot = cur_tile.slot0 + lane;
+            const bool valid = kUniform ? slot < p.n : idx != kPad;
+            const uint32_t raw = st.result(p.len1, len2);
+            if (p.out && valid) emit_usize(p, raw, len2, idx);
+            if (topk) {
+                bool keep;
+                const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
+                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
+                const uint64_t bound = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t before = best.worst(p.topk_k);
+                best.offer(mine, valid && keep, p.topk_k, lane, bound);
+                const uint64_t after = best.worst(p.topk_k);
+                if (after < before && after < bound && lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)after);
+            }
+            t += stride;
+            if (t >= p.n_tiles) {
+                done = true;
+                return;
+            }
+            cur_tile = load_tile<kUniform>(p, t);
+            c = 0;
+            idx = cur_tile.slot0 + lane;
+            if (!kUniform) idx = p.orig[idx];
+            st.init();
+        };
+        while (!done) {
+#pragma unroll
+            for (int ph = 0; ph <= kDepth; ++ph) {
+                step(buf[ph], buf[(ph + kDepth) % (kDepth + 1)]);
+                if (done) break;
+            }
+        }
+    }
+
+    if (topk) {
+        lds_topk[wave][lane] = best.key;
+        __syncthreads();
+        if (wave == 0) {
+            for (uint32_t w = 1; w < kWavesPerBlock; ++w)
+                for (uint32_t j = 0; j < p.topk_k; ++j) {
+                    const uint64_t x = lds_topk[w][j];
+                    if (x < best.worst(p.topk_k)) best.insert(x, lane);
+                }
+            if (lane < p.topk_k) p.topk_keys[(size_t)blockIdx.x * p.topk_k + lane] = best.key;
+        }
+    }
+}
+template <class State, bool kUniform, int kDepth>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void stream_kernel_occ8(const ScanParams p)
+{
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    stream_body<State, kUniform, kDepth>(p, lds_pm, lds_topk);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1487,6 +1606,16 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
 {
     const dim3 g(grid), b(kWave * kWavesPerBlock);
     if constexpr (State::kWords == 1) {
+        // no cutoff early-out to serve: the leaner stream loop.  Ring depth 1 measured best (2 and 3 were 1-3% slower
+        // on every metric: these kernels are issue-bound, not latency-bound); RF_STREAM=0 selects scan_body for A/B.
+        static const bool use_stream = [] { const char* e = getenv("RF_STREAM"); return !e || atoi(e) != 0; }();
+        if (!p.early && use_stream) {
+            if (p.tiles)
+                hipLaunchKernelGGL((stream_kernel_occ8<State, false, 1>), g, b, 0, stream, p);
+            else
+                hipLaunchKernelGGL((stream_kernel_occ8<State, true, 1>), g, b, 0, stream, p);
+            return hipGetLastError();
+        }
         if (p.tiles)
             hipLaunchKernelGGL((scan_kernel_occ8<State, false>), g, b, 0, stream, p);
         else
