@@ -517,6 +517,8 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->uniform_tile_bytes = (uint32_t)tile_bytes(corpus->uniform_len);
     p->orig = corpus->d_orig;
     p->n_tiles = corpus->n_tiles;
+    p->tile_begin = 0;
+    p->tile_end = corpus->n_tiles;
     p->n = (uint32_t)corpus->n;
 
     const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
@@ -673,6 +675,15 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         if (raw_cutoff < std::max<uint32_t>(p->len1, corpus->max_len)) {
             p->early = 1;
             p->raw_cutoff = raw_cutoff;
+            // distance >= |len1 - len2| (the reference's first test, levenshtein.rs:1389-1391): tiles ascend by length,
+            // so the candidates that can pass are ONE tile range; the rest is never read, only pre-filled with None.
+            const uint64_t lo = p->len1 > raw_cutoff ? p->len1 - raw_cutoff : 0, hi = (uint64_t)p->len1 + raw_cutoff;
+            const auto& L = corpus->lengths;
+            const size_t i_lo = std::lower_bound(L.begin(), L.end(), (uint32_t)lo) - L.begin();
+            const size_t i_hi = hi >= 0xFFFFFFFFull ? L.size() : std::upper_bound(L.begin(), L.end(), (uint32_t)hi) - L.begin();
+            p->tile_begin = i_lo < L.size() ? corpus->length_first_tile[i_lo] : corpus->n_tiles;
+            p->tile_end = i_hi < L.size() ? corpus->length_first_tile[i_hi] : corpus->n_tiles;
+            p->prefill_none = p->tile_begin > 0 || p->tile_end < corpus->n_tiles;
         }
     }
     return RF_OK;
@@ -798,7 +809,8 @@ static rf_status run_many_multi(const rf_comparator* const* cs, uint32_t q, cons
             e = launch_scan(raws[i], p, st, nullptr);
             if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
         } else {
-            p.early = 0;  // the fused kernel always runs every column (values are the same either way)
+            p.early = 0;  // the fused kernel always runs every column of every tile (values are the same either way)
+            p.tile_begin = 0, p.tile_end = p.n_tiles, p.prefill_none = 0;
             p.multi_q = (uint32_t)group.size();
             for (size_t k = 0; k < group.size() && status == RF_OK; ++k) {
                 p.multi_len1[k] = ps[group[k]].len1;

@@ -63,7 +63,8 @@ struct ScanParams {
     uint32_t cutoff_u32;   // usize cutoff clipped to u32 (valid when has_cutoff and !out_f64)
     uint32_t factor;       // common weight factor (levenshtein.rs:1307-1327)
     uint32_t w_ins, w_del, w_sub;  // for _maximum (levenshtein.rs:263-277)
-    uint32_t tile_begin, tile_end;  // tile range of this launch (jaro kernels)
+    uint32_t tile_begin, tile_end;  // tile range of this launch (jaro kernels; the cutoff length window of the scans)
+    uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
     uint32_t jaro_split;   // first tile that needs the multi-word jaro path
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
     double cutoff_f64;

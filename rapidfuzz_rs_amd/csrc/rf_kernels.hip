@@ -58,6 +58,19 @@ __device__ __forceinline__ uint64_t shl1_var(uint64_t x, uint32_t cin)
     return r | cin;
 }
 
+// One 16-byte chunk of this lane.  Candidate bytes are read once per launch: the non-temporal hint (`nt`) keeps the
+// stream from displacing the PM / descriptor lines in L2 (A/B measured; compile with -DRF_NO_NT to drop the hint).
+__device__ __forceinline__ uint4 load_chunk(const uint4* src)
+{
+#ifdef RF_NO_NT
+    return *src;
+#else
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+}
+
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------------------------------------------
@@ -570,14 +583,14 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
     // With a cutoff (`early`) the bet is the opposite: after 16 columns nearly every wavefront of a random
     // corpus is past the cutoff, so the prefetch goes to the NEXT TILE and a surviving wavefront fetches its
     // own next chunk on demand -- a dead tile costs 16 of its 64+ bytes per candidate in HBM traffic.
-    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
-    if (t < p.n_tiles) {
+    uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave;
+    if (t < p.tile_end) {
         TileView cur_tile = load_tile<kUniform>(p, t);
-        uint4 cur = cur_tile.src[lane];  // the packed buffer carries one chunk of tail padding: always readable
+        uint4 cur = load_chunk(cur_tile.src + lane);  // the packed buffer carries one chunk of tail padding: always readable
 
         while (true) {
             const uint32_t t_next = t + stride;
-            const bool has_next = t_next < p.n_tiles;
+            const bool has_next = t_next < p.tile_end;
             const TileView next_tile = load_tile<kUniform>(p, has_next ? t_next : t);
 
             const uint32_t len2 = cur_tile.len;
@@ -590,12 +603,12 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
             const uint32_t nch = (len2 + kChunk - 1) / kChunk;
             bool dead = false;
             uint4 ahead = make_uint4(0, 0, 0, 0);
-            if (early || nch == 0) ahead = next_tile.src[lane];
+            if (early || nch == 0) ahead = load_chunk(next_tile.src + lane);
             for (uint32_t c = 0; c < nch; ++c) {
                 uint4 nxt = ahead;
                 if (!early) {
                     const uint4* nsrc = (c + 1 < nch) ? cur_tile.src + (size_t)(c + 1) * kWave : next_tile.src;
-                    nxt = nsrc[lane];
+                    nxt = load_chunk(nsrc + lane);
                 }
                 const uint32_t cols = len2 - c * kChunk;
                 if (cols >= kChunk) {
@@ -619,7 +632,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                         dead = true;  // the whole wavefront is beyond the cutoff: stop reading this tile
                         break;
                     }
-                    if (c + 1 < nch) nxt = cur_tile.src[(size_t)(c + 1) * kWave + lane];
+                    if (c + 1 < nch) nxt = load_chunk(cur_tile.src + (size_t)(c + 1) * kWave + lane);
                 }
                 cur = nxt;
             }
@@ -708,17 +721,17 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
     WaveTopK best;
     best.init();
 
-    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
-    if (t < p.n_tiles) {
+    uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave;
+    if (t < p.tile_end) {
         // fetch cursor
         uint32_t ft = t, fc = 0;
         TileView fv = load_tile<kUniform>(p, ft);
         uint32_t fn = max(1u, (fv.len + kChunk - 1) / kChunk);
         auto fetch = [&]() {
-            const uint4 v = fv.src[(size_t)fc * kWave + lane];
+            const uint4 v = load_chunk(fv.src + (size_t)fc * kWave + lane);
             if (++fc == fn) {
                 const uint32_t nt = ft + stride;
-                if (nt < p.n_tiles) {
+                if (nt < p.tile_end) {
                     ft = nt;
                     fv = load_tile<kUniform>(p, ft);
                     fn = max(1u, (fv.len + kChunk - 1) / kChunk);
@@ -771,7 +784,7 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
                 if (after < before && after < bound && lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)after);
             }
             t += stride;
-            if (t >= p.n_tiles) {
+            if (t >= p.tile_end) {
                 done = true;
                 return;
             }
@@ -835,7 +848,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_multi_kernel(const
     uint32_t t = blockIdx.x * kWavesPerBlock + wave;
     if (t >= p.n_tiles) return;
     TileView cur_tile = load_tile<kUniform>(p, t);
-    uint4 cur = cur_tile.src[lane];
+    uint4 cur = load_chunk(cur_tile.src + lane);
 
     while (true) {
         const uint32_t t_next = t + stride;
@@ -852,7 +865,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_multi_kernel(const
         const uint32_t nch = (len2 + kChunk - 1) / kChunk;
         for (uint32_t c = 0; c < nch; ++c) {
             const uint4* nsrc = (c + 1 < nch) ? cur_tile.src + (size_t)(c + 1) * kWave : next_tile.src;
-            const uint4 nxt = nsrc[lane];
+            const uint4 nxt = load_chunk(nsrc + lane);
             const uint32_t cols = len2 - c * kChunk;
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
@@ -863,7 +876,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_multi_kernel(const
             }
             cur = nxt;
         }
-        if (nch == 0) cur = next_tile.src[lane];
+        if (nch == 0) cur = load_chunk(next_tile.src + lane);
 
         const bool valid = kUniform ? slot < p.n : idx != kPad;
         if (valid) {
@@ -1655,6 +1668,10 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     if (p.n_tiles == 0) return hipSuccess;
     const int grid = p.long_words_pad ? (int)p.long_grid : scan_grid(p.n_tiles);
     if (grid_used) *grid_used = grid;
+    if (p.prefill_none && p.out) {  // candidates outside the cutoff's length window (plan()): None without being read
+        const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, p.n, stream);
+        if (e != hipSuccess) return e;
+    }
     if (p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS)) {
         const dim3 g(grid), b(kWave * kWavesPerBlock);
         if (raw == RAW_LCS) {

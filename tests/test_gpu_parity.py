@@ -633,3 +633,36 @@ def test_many_multi_device_output_and_empty_inputs():
     assert bc.many_multi(cs, N.OP_DISTANCE, rf.Corpus.from_list([])).shape == (len(cs), 0)
     with pytest.raises(rf.RfError):  # u32 entry point, f64-valued op
         N.check(N.lib().rf_many_multi_u32((C.c_void_p * 1)(cs[0]._h), 1, corpus._h, N.OP_NORMALIZED_DISTANCE, C.byref(rf.Args().to_c(False)), out.data_ptr(), N.MEM_DEVICE, None))
+
+
+# ---------------------------------------------------------------- cutoff length window (only tiles with |len2 - len1| <= cutoff are read)
+@pytest.mark.parametrize("qlen", [0, 7, 40, 64])
+def test_cutoff_length_window_ragged(qlen):
+    q = synth.query(qlen, 4242 + qlen)
+    data, offsets = synth.ragged_host(20_000, 150, seed=777 + qlen)
+    cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+    rng = np.random.default_rng(qlen)
+    for i in range(0, len(cands), 97):  # near-duplicates of the query with a few edits, lengths around qlen
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 5))):
+            r = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, len(b) + 1))
+            if r == 0:
+                b.insert(pos, int(synth.ALNUM[int(rng.integers(0, len(synth.ALNUM)))]))
+            elif r == 1 and len(b):
+                del b[min(pos, len(b) - 1)]
+            elif len(b):
+                b[min(pos, len(b) - 1)] = int(synth.ALNUM[int(rng.integers(0, len(synth.ALNUM)))])
+        cands[i] = bytes(b)
+    data, offsets = rf.ragged(cands)
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    bc = rf.distance.levenshtein.BatchComparator(q)
+    for k in (0, 1, 2, 3, 5, 10, 60, 149, 150, 10_000):
+        got = _check_many("levenshtein", q, data, offsets, "distance", score_cutoff=k)
+        full = bc.distance_many(corpus)
+        assert ((got == NONE32) == (full > k)).all()
+        s, i = bc.topk(corpus, 8, score_cutoff=k)
+        exp = sorted((int(d), j) for j, d in enumerate(full) if d <= k)[:8]
+        assert list(zip(s.tolist(), i.tolist())) == exp, (qlen, k)
+    for w, k in (((2, 2, 2), 7), ((3, 3, 3), 2)):  # factor > 1: the window is cutoff / factor
+        _check_many("levenshtein", q, data, offsets, "distance", weights=w, score_cutoff=k)
