@@ -153,12 +153,19 @@ struct LevState {
     // levenshtein.rs:492-496, so this is value-preserving pruning): adjacent cells of the last row differ by at
     // most 1, hence D[len1][len2] >= D[len1][j] - (len2 - j).  D[len1][j] comes from the same popcount identity
     // as result().  True = this lane can no longer end at or below `raw_cutoff`.
+    // A second bound comes from the diagonal through (len1, len2): values never decrease along a diagonal of the
+    // Levenshtein matrix, so D[len1][len2] >= D[j + len1 - len2][j] -- the same popcount identity with a shorter row
+    // mask.  For equal lengths that is the distance between the two j-prefixes, which for unrelated strings grows by
+    // almost 1 per column: nearly every wavefront of a random corpus is past a small cutoff after 8 columns.
     static constexpr bool kCanPrune = true;
     __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
     {
-        return (int32_t)result(len1, j) - (int32_t)(len2 - j) > (int32_t)raw_cutoff;
+        const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // <= len1 because j <= len2
+        const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
+        return max(last_row, diag) > (int32_t)raw_cutoff;
     }
-    // D[len1][len2] from the final column's vertical deltas
+    // D[len1][len2] from the final column's vertical deltas (any row count <= len1 gives D[rows][len2])
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
         int32_t d = (int32_t)len2;
@@ -339,7 +346,10 @@ struct Lev32State {
     static constexpr bool kCanPrune = true;
     __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
     {
-        return (int32_t)result(len1, j) - (int32_t)(len2 - j) > (int32_t)raw_cutoff;
+        const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // the diagonal bound, see LevState::hopeless
+        const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
+        return max(last_row, diag) > (int32_t)raw_cutoff;
     }
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
