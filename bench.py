@@ -190,7 +190,10 @@ def main():
     gpairs = pairs_per_step / (elapsed / args.steps) / 1e9
     # algorithmic bytes per pair: candidate bytes at bucket length + one u32 result
     # (Q fused queries read each candidate once: ln / Q candidate bytes per pair)
-    bytes_per_pair = ln / nq + (8 if is_f64 else (4 if args.mode == "many" else 0))
+    # With a distance cutoff the early-out is part of the algorithm: on this corpus nearly every candidate is decided
+    # from its first 16-byte chunk, so the bytes the path has to move are that chunk + the result.
+    cand_bytes = min(ln, 16) if (args.cutoff is not None and args.metric in ("levenshtein", "osa") and args.cutoff < max(ln, args.query_len)) else ln
+    bytes_per_pair = cand_bytes / nq + (8 if is_f64 else (4 if args.mode == "many" else 0))
     achieved = n * nq * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
 
     result = {
