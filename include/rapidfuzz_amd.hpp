@@ -124,6 +124,30 @@ public:
         return many<double>(c, RF_OP_NORMALIZED_SIMILARITY, a.to_c());
     }
 
+    // ---- many queries x one corpus: res[j][i] = scorers[j].<op>_with_args(candidate_i, args), one call (rf_many_multi_*)
+    static std::vector<std::vector<std::optional<usize_result>>> distance_many_multi(const std::vector<const BatchComparator*>& scorers,
+                                                                                      const Corpus& c, const Args<usize_result>& a = {})
+    {
+        const rf_args ca = a.to_c();
+        std::vector<const rf_comparator*> hs;
+        for (const BatchComparator* s : scorers) hs.push_back(s->h_);
+        std::vector<std::vector<std::optional<usize_result>>> res(scorers.size(), std::vector<std::optional<usize_result>>(c.size()));
+        if constexpr (FloatMetric) {
+            std::vector<double> out(scorers.size() * c.size());
+            check(rf_many_multi_f64(hs.data(), (uint32_t)hs.size(), c.handle(), RF_OP_DISTANCE, &ca, out.data(), RF_MEM_HOST, nullptr));
+            for (size_t j = 0; j < scorers.size(); ++j)
+                for (size_t i = 0; i < c.size(); ++i)
+                    if (!std::isnan(out[j * c.size() + i])) res[j][i] = out[j * c.size() + i];
+        } else {
+            std::vector<uint32_t> out(scorers.size() * c.size());
+            check(rf_many_multi_u32(hs.data(), (uint32_t)hs.size(), c.handle(), RF_OP_DISTANCE, &ca, out.data(), RF_MEM_HOST, nullptr));
+            for (size_t j = 0; j < scorers.size(); ++j)
+                for (size_t i = 0; i < c.size(); ++i)
+                    if (out[j * c.size() + i] != RF_NONE_U32) res[j][i] = out[j * c.size() + i];
+        }
+        return res;
+    }
+
     // ---- the reference's per-candidate methods (a one-candidate corpus through the same kernels)
     std::optional<usize_result> distance_with_args(std::string_view s2, const Args<usize_result>& a) const
     {

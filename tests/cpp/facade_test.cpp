@@ -43,6 +43,11 @@ int main(int argc, char** argv)
     Corpus corpus({"sitting", "mitten", "kitchen", ""});
     auto d = scorer.distance_many(corpus, distance::levenshtein::Args<size_t>{}.score_cutoff(2));
     EXPECT(!d[0] && *d[1] == 1 && *d[2] == 2 && !d[3]);
+    {
+        distance::levenshtein::BatchComparator a("mitten"), b("kitchen"), c("");
+        auto m = distance::levenshtein::BatchComparator::distance_many_multi({&scorer, &a, &b, &c}, corpus);
+        EXPECT(m.size() == 4 && *m[0][1] == 1 && *m[1][1] == 0 && *m[2][2] == 0 && *m[3][0] == 7 && *m[3][3] == 0);
+    }
     EXPECT(distance::indel::distance("lewenstein", "levenshtein") == 3);
     EXPECT(distance::lcs_seq::similarity("lewenstein", "levenshtein") == 9);
     EXPECT(std::fabs(distance::jaro::similarity("james", "robert") - 0.455556) < 1e-4);
