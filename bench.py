@@ -258,9 +258,14 @@ def main():
                 bad = got != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
             mism += int(bad.sum())
         result["parity"] = {"checked": int(chk) * nq, "mismatches": mism}
-    print(json.dumps(result))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which flushes after Python's buffer when stdout is a pipe:
+    # drain it first so the JSON line is the last line of the output
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(result), flush=True)
 
 
 def measured_traffic(args, n):

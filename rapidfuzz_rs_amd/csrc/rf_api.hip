@@ -75,6 +75,15 @@ struct rf_corpus {
     std::vector<uint32_t> length_first_tile;  // first tile of each distinct length
     uint8_t sigma[256];           // symbol renaming: the packed corpus stores sigma[c] for candidate byte c
     uint8_t* d_sigma = nullptr;   // device copy
+    // top-k scratch, one per stream the corpus has been searched on: [candidate keys | bound | counter].  The kernels
+    // leave bound/counter re-armed, so a top-k call is two launches and no allocation or memset (topk_core()).
+    struct TopkScratch {
+        uint64_t* cand = nullptr;
+        uint64_t* bound = nullptr;
+        uint32_t* count = nullptr;
+    };
+    mutable std::mutex scratch_mu;
+    mutable std::map<hipStream_t, TopkScratch> topk_scratch;
 };
 
 // Symbol renaming.  Every column of every kernel gathers 64 table rows from LDS, one per lane, and LDS bank
@@ -483,6 +492,7 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_orig) (void)hipFree(c->d_orig);
     if (c->d_sigma) (void)hipFree(c->d_sigma);
+    for (auto& kv : c->topk_scratch) (void)hipFree(kv.second.cand);
     delete c;
 }
 
@@ -519,6 +529,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->n_tiles = corpus->n_tiles;
     p->tile_begin = 0;
     p->tile_end = corpus->n_tiles;
+    p->tile_step = 1;
     p->n = (uint32_t)corpus->n;
 
     const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
@@ -879,29 +890,66 @@ static rf_status topk_core(const rf_comparator* c, const rf_corpus* corpus, rf_o
     *desc = op == RF_OP_SIMILARITY;
     s = comparator_device_pm(c, corpus->device, &p.pm);
     if (s != RF_OK) return s;
-    const int grid = scan_grid(corpus->n_tiles);
-    // one stream-ordered allocation: [workgroup lists | merge scratch | shared pruning bound]
-    const size_t n_keys = (size_t)grid * k, n_scratch = topk_merge_scratch_entries((uint32_t)n_keys, k);
-    uint64_t* d_keys = nullptr;
-    RF_HIP(hipMallocAsync((void**)&d_keys, (n_keys + n_scratch + 1) * sizeof(uint64_t), st));
-    p.topk_bound = d_keys + n_keys + n_scratch;
-    RF_HIP(hipMemsetAsync(p.topk_bound, 0xFF, sizeof(uint64_t), st));
+    // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list
+    rf_corpus::TopkScratch sc;
+    {
+        std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+        auto it = corpus->topk_scratch.find(st);
+        if (it == corpus->topk_scratch.end()) {
+            const size_t cap = (size_t)scan_grid(corpus->n_tiles) * kWave;
+            uint8_t* mem = nullptr;
+            RF_HIP(hipMalloc((void**)&mem, cap * sizeof(uint64_t) + 16));
+            sc.cand = reinterpret_cast<uint64_t*>(mem);
+            sc.bound = sc.cand + cap;
+            sc.count = reinterpret_cast<uint32_t*>(sc.bound + 1);
+            hipError_t e0 = hipMemsetAsync(sc.bound, 0xFF, sizeof(uint64_t), st);
+            if (e0 == hipSuccess) e0 = hipMemsetAsync(sc.count, 0, sizeof(uint32_t), st);
+            if (e0 != hipSuccess) {
+                (void)hipFree(mem);
+                set_error(std::string("top-k scratch: ") + hipGetErrorString(e0));
+                return RF_ERR_HIP;
+            }
+            corpus->topk_scratch.emplace(st, sc);
+        } else {
+            sc = it->second;
+        }
+    }
+    p.topk_bound = sc.bound;
+    p.topk_cand = sc.cand;
+    p.topk_count = sc.count;
     p.topk_k = k;
     p.topk_desc = *desc;
-    p.topk_keys = d_keys;
     p.key_index_base = key_index_base;
     // optionally also emit every candidate's score from the same pass (they stay sharded)
     uint32_t* d_all = out_all;
     if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
     p.out = d_all;
-    hipError_t e = launch_scan(raw, p, st, nullptr);
+    hipError_t e = hipSuccess;
+    // Sample pass: the top-k of ~1000 evenly spaced tiles costs 0.1 % of the scan and its k-th best key is a valid
+    // launch-wide bound from the first tile on -- without it every wavefront pays k ln(n_wave / k) list insertions to
+    // warm its own list up (the shared bound alone is only as good as the luckiest wavefront's k-th best).
+    // (RF_TOPK_SAMPLE=<tiles> tunes the sample size, 0 disables the pass: A/B switch)
+    static const uint32_t kSampleTiles = [] { const char* e = getenv("RF_TOPK_SAMPLE"); return e ? (uint32_t)atoi(e) : 1024u; }();
+    if (kSampleTiles && p.tile_end - p.tile_begin >= 8 * kSampleTiles) {
+        ScanParams ps = p;
+        ps.out = nullptr;
+        ps.prefill_none = 0;
+        ps.tile_step = (p.tile_end - p.tile_begin) / kSampleTiles;
+        e = launch_scan(raw, ps, st, nullptr);
+        if (e == hipSuccess) e = launch_topk_final(sc.cand, sc.count, 0, k, d_best, sc.bound, true, st);
+    }
+    if (e == hipSuccess) e = launch_scan(raw, p, st, nullptr);
     if (e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         (void)hipFreeAsync(d_all, st);
     }
-    if (e == hipSuccess) e = launch_topk_merge(d_keys, (uint32_t)n_keys, k, d_keys + n_keys, d_best, st);
-    (void)hipFreeAsync(d_keys, st);
+    if (e == hipSuccess) e = launch_topk_final(sc.cand, sc.count, 0, k, d_best, sc.bound, false, st);
     if (e != hipSuccess) {
+        // the scratch may be left half-armed: drop it so the next call starts from a fresh one
+        std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(sc.cand);
+        corpus->topk_scratch.erase(st);
         set_error(std::string("top-k: ") + hipGetErrorString(e));
         return RF_ERR_HIP;
     }
@@ -983,11 +1031,7 @@ rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t
     DeviceGuard guard(device);
     if (!guard.ok) return RF_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream;
-    const size_t n_scratch = topk_merge_scratch_entries(n, k);
-    uint64_t* d_scratch = nullptr;
-    RF_HIP(hipMallocAsync((void**)&d_scratch, std::max<size_t>(1, n_scratch) * sizeof(uint64_t), st));
-    hipError_t e = launch_topk_merge(d_keys, n, k, d_scratch, d_out, st);
-    (void)hipFreeAsync(d_scratch, st);
+    hipError_t e = launch_topk_final(d_keys, nullptr, n, k, d_out, nullptr, false, st);
     if (e != hipSuccess) {
         set_error(std::string("top-k merge: ") + hipGetErrorString(e));
         return RF_ERR_HIP;

@@ -64,6 +64,7 @@ struct ScanParams {
     uint32_t factor;       // common weight factor (levenshtein.rs:1307-1327)
     uint32_t w_ins, w_del, w_sub;  // for _maximum (levenshtein.rs:263-277)
     uint32_t tile_begin, tile_end;  // tile range of this launch (jaro kernels; the cutoff length window of the scans)
+    uint32_t tile_step;             // >= 1: visit every tile_step-th tile of the range (the top-k bound sample)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
     uint32_t jaro_split;   // first tile that needs the multi-word jaro path
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
@@ -89,19 +90,19 @@ struct ScanParams {
     uint32_t topk_desc;    // 1: larger score is better (similarity)
     uint32_t key_index_base;  // added to the local index inside the key (rf_topk_keys_device)
     uint64_t* topk_bound;  // one u64, initialised to ~0: launch-wide upper bound on the k-th best key
-    uint64_t* topk_keys;   // [grid][k], key = (score or ~score) << 32 | (key_index_base + local index), ~0 = empty
+    uint64_t* topk_cand;   // candidate keys, capacity grid * k; key = (score or ~score) << 32 | (key_index_base + local index)
+    uint32_t* topk_count;  // entries appended to topk_cand so far
 };
 
 // kernels (rf_kernels.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
 hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipStream_t stream);
-hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* scratch, uint64_t* out, hipStream_t stream);
-size_t topk_merge_scratch_entries(uint32_t n, uint32_t k);
+hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t count_imm, uint32_t k, uint64_t* out, uint64_t* bound_ptr,
+                             bool bound_from_result, hipStream_t stream);
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,
                             uint32_t n_tiles, const uint8_t* sigma, hipStream_t stream);
 hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,
                                  hipStream_t stream);
-int scan_max_grid();
 int scan_grid(uint32_t n_tiles);  // the grid launch_scan uses for n_tiles tiles
 
 void set_error(const std::string& msg);

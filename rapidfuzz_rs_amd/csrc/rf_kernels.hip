@@ -72,6 +72,10 @@ __device__ __forceinline__ uint4 load_chunk(const uint4* src)
 }
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Levenshtein: one column of Hyyro's recurrence over W 64-bit words (levenshtein.rs:466-490 for W == 1,
@@ -466,21 +470,65 @@ struct WaveTopK {
         const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
         key = lane > pos ? up : (lane == pos ? x : key);
     }
-    // offer one key per lane (valid lanes only); k is the list length; `bound` is any upper bound on the k-th best
-    // key of the whole launch (keys above it can never be in the answer)
-    __device__ __forceinline__ void offer(uint64_t mine, bool valid, uint32_t k, uint32_t lane, uint64_t bound)
+    // Offer one key per lane (valid lanes only).  `limit` is wavefront-uniform: min(this list's worst key, any upper
+    // bound on the launch's k-th best key) -- keys at or above it can never be in the answer.  The common case (no
+    // lane below the limit) is one compare and one scalar branch; returns true when the list changed.
+    __device__ __forceinline__ bool offer(uint64_t mine, bool valid, uint32_t k, uint32_t lane, uint64_t limit)
     {
-        const uint64_t w0 = worst(k);
-        uint64_t m = __ballot(valid && mine < (w0 < bound ? w0 : bound));
-        while (m) {  // rare: expected k * ln(N / k) insertions over the whole launch thanks to the shared bound
+        uint64_t m = __ballot(valid && mine < limit);
+        if (m == 0) return false;
+        bool changed = false;
+        while (m) {  // rare: a handful per wavefront over a whole launch once the bound is tight
             const uint32_t l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine, l), hi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), l);
             const uint64_t x = ((uint64_t)hi << 32) | lo;
-            if (x < worst(k)) insert(x, lane);
+            if (x < worst(k)) {
+                insert(x, lane);
+                changed = true;
+            }
         }
+        return changed;
     }
 };
+
+// A workgroup's merged list leaves the kernel through ONE launch-wide candidate buffer: only keys at or below the
+// pruning bound can still be in the answer (the bound is some full list's worst key, so the true k-th best is <= it),
+// and those are appended behind an atomic counter.  On a corpus in no particular order a few dozen keys survive per
+// launch, so the final selection (topk_final_kernel) is one small workgroup instead of staged reductions over
+// grid x k keys.  Worst case (scores improving along the corpus) everything is appended: capacity is grid x k.
+__device__ __forceinline__ void topk_publish(const ScanParams& p, const WaveTopK& best, uint32_t lane)
+{
+    const uint64_t bound = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool keep = lane < p.topk_k && best.key != ~0ull && best.key <= bound;
+    const uint64_t m = __ballot(keep);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(p.topk_count, (uint32_t)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (keep) p.topk_cand[base + __popcll(m & ((1ull << lane) - 1))] = best.key;
+}
+
+// Launch-wide pruning bound: once ANY wavefront holds k keys, its worst key bounds the global k-th best from above
+// (and topk_core() seeds it with the k-th best of a sample before the scan starts).  A wavefront whose list just
+// changed publishes its worst key with a 64-bit atomic min.
+__device__ __forceinline__ void topk_list_changed(const ScanParams& p, const WaveTopK& best, uint32_t lane, uint64_t& limit)
+{
+    const uint64_t w = best.worst(p.topk_k);
+    if (w < limit) {  // limit <= the last bound this wavefront saw: only then can the global bound improve
+        if (lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)w);
+        limit = w;
+    }
+}
+// `bound_inflight` is the raw result of a load issued at the end of the previous tile: it is folded into the
+// (scalar) limit here, one tile later, and the next fetch is issued -- stale by a tile (merely conservative), never
+// waited for.
+__device__ __forceinline__ void topk_refresh_bound(const ScanParams& p, uint64_t& bound_inflight, uint64_t& limit)
+{
+    const uint64_t b = uniform64(bound_inflight);
+    limit = b < limit ? b : limit;
+    bound_inflight = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // the scan kernel
@@ -580,11 +628,16 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
-    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t stride = gridDim.x * kWavesPerBlock * p.tile_step;
     const bool topk = p.topk_k != 0;
     const bool early = State::kCanPrune && p.early != 0;
     WaveTopK best;
     best.init();
+    // offers are filtered by `limit` = min(launch-wide pruning bound as last seen, own list's worst key), a scalar.
+    // This body is at its VGPR budget (cutoff state + early-out), so the bound is re-read only every 8th tile and
+    // consumed at once instead of riding in registers across a tile like stream_body's.
+    uint64_t limit = ~0ull;
+    uint32_t tiles_done = 0;
 
     // Each wavefront walks its tiles as one continuous stream of 16-column chunks.  The load of the NEXT
     // chunk (the next 16 columns of this tile, or the first 16 of the wavefront's next tile) is always issued
@@ -593,7 +646,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
     // With a cutoff (`early`) the bet is the opposite: after 16 columns nearly every wavefront of a random
     // corpus is past the cutoff, so the prefetch goes to the NEXT TILE and a surviving wavefront fetches its
     // own next chunk on demand -- a dead tile costs 16 of its 64+ bytes per candidate in HBM traffic.
-    uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave;
+    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
         TileView cur_tile = load_tile<kUniform>(p, t);
         uint4 cur = load_chunk(cur_tile.src + lane);  // the packed buffer carries one chunk of tail padding: always readable
@@ -660,14 +713,11 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                 bool keep;
                 const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
                 const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
-                // Launch-wide pruning bound: once ANY wavefront holds k keys, its worst key bounds the global k-th
-                // best.  Wavefronts publish that with a 64-bit atomic min and read it (possibly stale = merely
-                // conservative) before offering, so freshly started wavefronts skip the k*ln(n) warm-up insertions.
-                const uint64_t bound = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t before = best.worst(p.topk_k);
-                best.offer(mine, valid && keep, p.topk_k, lane, bound);
-                const uint64_t after = best.worst(p.topk_k);
-                if (after < before && after < bound && lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)after);
+                if ((tiles_done++ & 7u) == 0) {
+                    const uint64_t b = uniform64(__hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    limit = b < limit ? b : limit;
+                }
+                if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
             }
 
             if (!has_next) break;
@@ -685,7 +735,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                     const uint64_t x = lds_topk[w][j];  // wavefront-uniform address: a broadcast read
                     if (x < best.worst(p.topk_k)) best.insert(x, lane);
                 }
-            if (lane < p.topk_k) p.topk_keys[(size_t)blockIdx.x * p.topk_k + lane] = best.key;
+            topk_publish(p, best, lane);
         }
     }
 }
@@ -726,12 +776,16 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
-    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t stride = gridDim.x * kWavesPerBlock * p.tile_step;
     const bool topk = p.topk_k != 0;
     WaveTopK best;
     best.init();
+    // offers are filtered by `limit` = min(launch-wide pruning bound as last seen, own list's worst key), a scalar;
+    // `bound` is the bound fetch in flight (topk_refresh_bound)
+    uint64_t bound = topk ? __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+    uint64_t limit = ~0ull;
 
-    uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave;
+    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
         // fetch cursor
         uint32_t ft = t, fc = 0;
@@ -787,11 +841,8 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
                 bool keep;
                 const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
                 const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
-                const uint64_t bound = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t before = best.worst(p.topk_k);
-                best.offer(mine, valid && keep, p.topk_k, lane, bound);
-                const uint64_t after = best.worst(p.topk_k);
-                if (after < before && after < bound && lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)after);
+                if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
+                topk_refresh_bound(p, bound, limit);
             }
             t += stride;
             if (t >= p.tile_end) {
@@ -822,7 +873,7 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
                     const uint64_t x = lds_topk[w][j];
                     if (x < best.worst(p.topk_k)) best.insert(x, lane);
                 }
-            if (lane < p.topk_k) p.topk_keys[(size_t)blockIdx.x * p.topk_k + lane] = best.key;
+            topk_publish(p, best, lane);
         }
     }
 }
@@ -932,76 +983,64 @@ hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipS
     return hipErrorInvalidValue;
 }
 
-// Reduction of many k-entry lists to k entries, in stages: every workgroup takes a slice of <= 4096 keys (4 per
-// thread, in registers) and runs k rounds of "smallest key above the previous pick" (keys are unique), writing k
-// keys; the host repeats until one list is left.  100 M candidates -> 8192 lists -> 32 -> 1: two tiny launches.
-constexpr int kMergeThreads = 1024, kMergePerThread = 4, kMergeSlice = kMergeThreads * kMergePerThread;
-
-__global__ __launch_bounds__(kMergeThreads) void topk_reduce_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t k,
-                                                                    uint64_t* __restrict__ out)
+// Final selection: `count` candidate keys (device counter, or an immediate for the post-all-gather merge) -> the k
+// smallest, ascending, ~0 = empty.  One workgroup of 16 wavefronts: each keeps a sorted k-list over its stripe of
+// the candidates (WaveTopK), the lists meet in LDS and wavefront 0 merges them.  Before it exits the kernel re-arms
+// the launch-wide state (counter = 0, bound = ~0) so the next top-k call on this scratch needs no memset.
+constexpr int kFinalThreads = 256;
+__global__ __launch_bounds__(kFinalThreads) void topk_final_kernel(const uint64_t* __restrict__ keys, uint32_t* count_ptr, uint32_t count_imm,
+                                                                   uint32_t k, uint64_t* __restrict__ out, uint64_t* bound_ptr,
+                                                                   bool bound_from_result)
 {
-    __shared__ uint64_t red[kMergeThreads / 64];
-    __shared__ uint64_t pick;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * kMergeSlice;
-    uint64_t mine[kMergePerThread];
+    constexpr uint32_t kWaves = kFinalThreads / kWave;
+    __shared__ uint64_t lists[kWaves][kWave];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = uniform(threadIdx.x / kWave);
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    const uint32_t used = min(kWaves, (n + kWave - 1) / kWave);  // wavefronts that see any key at all
+    WaveTopK best;
+    best.init();
+    // kRows 64-key rows per trip, all loaded before the first is offered: the loop is bound by load latency, not work
+    constexpr uint32_t kRows = 8;
+    uint64_t limit = ~0ull;  // this list's worst key once it is full
+    for (uint32_t base = wave * kWave; base < n; base += kRows * kFinalThreads) {
+        uint64_t row[kRows];
 #pragma unroll
-    for (int e = 0; e < kMergePerThread; ++e) {
-        const uint32_t i = base + e * kMergeThreads + threadIdx.x;
-        mine[e] = i < n ? keys[i] : ~0ull;
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const uint32_t i = base + r * kFinalThreads + lane;
+            row[r] = i < n ? keys[i] : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r)
+            if (best.offer(row[r], row[r] != ~0ull, k, lane, limit)) limit = best.worst(k);
     }
-    uint64_t last = 0;
-    bool have_last = false;
-    for (uint32_t r = 0; r < k; ++r) {
-        uint64_t m = ~0ull;
-#pragma unroll
-        for (int e = 0; e < kMergePerThread; ++e)
-            if ((!have_last || mine[e] > last) && mine[e] < m) m = mine[e];
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t lo = __shfl_xor((uint32_t)m, off), hi = __shfl_xor((uint32_t)(m >> 32), off);
-            const uint64_t o = ((uint64_t)hi << 32) | lo;
-            m = o < m ? o : m;
-        }
-        if (lane == 0) red[wave] = m;
+    if (used > 1) {
+        lists[wave][lane] = best.key;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t b = ~0ull;
-            for (int w = 0; w < kMergeThreads / 64; ++w) b = red[w] < b ? red[w] : b;
-            pick = b;
-            out[(size_t)blockIdx.x * k + r] = b;
-        }
-        __syncthreads();
-        last = pick;
-        have_last = true;
-        if (last == ~0ull) {  // fewer than k entries in this slice: the rest stay empty
-            for (uint32_t i = r + 1 + threadIdx.x; i < k; i += kMergeThreads) out[(size_t)blockIdx.x * k + i] = ~0ull;
-            break;
+    }
+    if (wave == 0) {
+        for (uint32_t w = 1; w < used; ++w)
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t x = lists[w][j];
+                if (x >= best.worst(k)) break;  // the lists are sorted: nothing further in this one can enter
+                best.insert(x, lane);
+            }
+        if (lane < k) out[lane] = best.key;
+        // re-arm for the next launch on this scratch.  After the SAMPLE pass of a top-k call the bound becomes the
+        // sample's k-th best key: the k-th best of a subset bounds the k-th best of the whole corpus from above.
+        const uint64_t kth = best.worst(k);
+        if (lane == 0) {
+            if (count_ptr) *count_ptr = 0;
+            if (bound_ptr) *bound_ptr = bound_from_result ? kth : ~0ull;
         }
     }
 }
 
-// keys: n entries; scratch: room for ceil(n / 4096) * k entries; the final k keys land in `out`
-hipError_t launch_topk_merge(const uint64_t* keys, uint32_t n, uint32_t k, uint64_t* scratch, uint64_t* out, hipStream_t stream)
+hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t count_imm, uint32_t k, uint64_t* out, uint64_t* bound_ptr,
+                             bool bound_from_result, hipStream_t stream)
 {
-    const uint64_t* src = keys;
-    uint64_t* bufs[2] = {scratch, scratch + (size_t)((n + kMergeSlice - 1) / kMergeSlice) * k};
-    int flip = 0;
-    for (;;) {
-        const uint32_t groups = (n + kMergeSlice - 1) / kMergeSlice;
-        uint64_t* dst = groups == 1 ? out : bufs[flip];
-        hipLaunchKernelGGL(topk_reduce_kernel, dim3(groups), dim3(kMergeThreads), 0, stream, src, n, k, dst);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess || groups == 1) return e;
-        src = dst;
-        n = groups * k;
-        flip ^= 1;
-    }
-}
-
-size_t topk_merge_scratch_entries(uint32_t n, uint32_t k)
-{
-    const size_t g = (n + kMergeSlice - 1) / kMergeSlice;
-    return 2 * g * k;
+    hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(kFinalThreads), 0, stream, keys, count_ptr, count_imm, k, out, bound_ptr,
+                       bound_from_result);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1192,11 +1231,6 @@ constexpr uint32_t T_OR_ANDN_B = TA | (TB & ~TC);     // a | (b & ~c)
 constexpr uint32_t T_ANDN_AND = TA & ~TB & TC;        // a & ~b & c
 constexpr uint32_t T_OR_AND = TA | (TB & TC);         // a | (b & c)
 constexpr uint32_t T_AND_ORN = TA & (TB | ~TC);       // a & (b | ~c)
-
-__device__ __forceinline__ uint64_t uniform64(uint64_t v)
-{
-    return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v);
-}
 
 // Per-lane state of the single-word Jaro passes.  Pass 1 = flag_similar_characters_word (jaro.rs:147-190); pass 2 =
 // count_transpositions_word (:339-368) restated without data-dependent control flow:
@@ -1676,7 +1710,8 @@ int scan_grid(uint32_t n_tiles)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
 {
     if (p.n_tiles == 0) return hipSuccess;
-    const int grid = p.long_words_pad ? (int)p.long_grid : scan_grid(p.n_tiles);
+    const uint32_t launch_tiles = p.tile_end > p.tile_begin ? (p.tile_end - p.tile_begin + p.tile_step - 1) / p.tile_step : 0;
+    const int grid = p.long_words_pad ? (int)p.long_grid : std::max(1, scan_grid(launch_tiles));
     if (grid_used) *grid_used = grid;
     if (p.prefill_none && p.out) {  // candidates outside the cutoff's length window (plan()): None without being read
         const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, p.n, stream);
