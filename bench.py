@@ -133,7 +133,11 @@ def main():
                                     out=out if args.mode == "many" else None, stream=stream.cuda_stream)
             if world > 1 or force_dist:
                 finish_exchange()  # merge the PREVIOUS step's gather: it ran on RCCL's stream under this step's scan
-                pending[0] = (dist.all_gather_into_tensor(all_keys[buf], local_keys[buf], async_op=True), buf)
+                if os.environ.get("RF_BENCH_NOGATHER"):  # diagnostic: the exchange replaced by a local copy
+                    all_keys[buf][: args.topk].copy_(local_keys[buf])
+                    pending[0] = (None, buf)
+                else:
+                    pending[0] = (dist.all_gather_into_tensor(all_keys[buf], local_keys[buf], async_op=True), buf)
             else:
                 last_topk[0] = local_keys[buf][: args.topk]
 
@@ -142,7 +146,8 @@ def main():
             return
         work, buf = pending[0]
         pending[0] = None
-        work.wait()
+        if work is not None:
+            work.wait()
         last_topk[0] = parallel.merge_keys_device(all_keys[buf], args.topk, merged_keys)  # one small kernel
 
     step_no, pending = [0], [None]

@@ -6,7 +6,7 @@ R=${1:-r01}
 tools/profile_c2.sh c2_levenshtein_$R "levenshtein:q64:n100000000:l64:cutNone:many"
 tools/profile_c2.sh c2_levenshtein_cutoff3_$R "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
 tools/profile_c2.sh c4_indel_$R "indel:q64:n100000000:l64:cutNone:many" --metric indel
-mkdir -p gpurun_out/profiles && cp gpurun_out/traffic.json profiles/traffic.json
+sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; mkdir -p gpurun_out/profiles && cp gpurun_out/traffic.json profiles/traffic.json
 b() { name=$1; shift; python bench.py "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
 b c2_levenshtein
 b q32_levenshtein --query-len 32
