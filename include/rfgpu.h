@@ -103,6 +103,12 @@ int rf_device_count(void);
  *   levenshtein.rs:1645-1657, lcs_seq.rs:800-812, indel.rs:375-383, jaro.rs:830-842,
  *   jaro_winkler.rs:413-425, fuzz.rs:102-113 */
 rf_status rf_comparator_new(rf_metric metric, const uint8_t *s1, size_t len1, rf_comparator **out);
+/* The same over `char` / u32 elements (`BatchComparator::new(s.chars())`; the reference keeps non-ASCII symbols in the
+ * hashed half of its table, pattern_match_vector.rs:5-65, :228-260).  Such a comparator is searched in corpora packed
+ * with rf_corpus_pack_u32 (and in byte corpora if every query symbol is <= 255); a byte comparator may equally be
+ * searched in a u32 corpus, its bytes being the code points 0..255.  rf_comparator_pm returns NULL for it: its
+ * table is built per corpus, in that corpus' symbol ids. */
+rf_status rf_comparator_new_u32(rf_metric metric, const uint32_t *s1, size_t len1, rf_comparator **out);
 /* #[derive(Clone)] (levenshtein.rs:1635): deep copy */
 rf_status rf_comparator_clone(const rf_comparator *c, rf_comparator **out);
 void rf_comparator_free(rf_comparator *c);
@@ -146,6 +152,15 @@ size_t rf_corpus_count(const rf_corpus *c);          /* n */
 uint64_t rf_corpus_payload_bytes(const rf_corpus *c); /* sum of candidate lengths */
 uint64_t rf_corpus_device_bytes(const rf_corpus *c);  /* HBM held by the packed form */
 int rf_corpus_device(const rf_corpus *c);
+/* Candidates over `char` / u32 elements: elems[offsets[i] .. offsets[i+1]) is candidate i.  The corpus stores one
+ * byte per element -- the element's id in this corpus' own alphabet (the 254 most frequent symbols; all rarer ones
+ * share one overflow id).  Every metric on this path only asks whether a candidate symbol EQUALS a query symbol, so
+ * results are exact for every query made of alphabet symbols and of symbols the corpus does not contain at all;
+ * a query containing one of the overflow symbols is refused with RF_ERR_UNSUPPORTED (never answered approximately).
+ * rf_corpus_alphabet_size: symbols with an id of their own (256 for a byte corpus), and how many share the
+ * overflow id. */
+rf_status rf_corpus_pack_u32(const uint32_t *elems, const uint64_t *offsets, size_t n, int device, rf_corpus **out);
+size_t rf_corpus_alphabet_size(const rf_corpus *c, size_t *overflow_symbols);
 
 /* ---- one-vs-many ------------------------------------------------------------------------------
  * out[i] = scorer.<op>_with_args(candidate_i, &args) for every candidate, original order.

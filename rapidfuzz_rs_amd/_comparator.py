@@ -15,7 +15,7 @@ from typing import NamedTuple, Optional, Sequence
 import numpy as np
 
 from . import _native as N
-from .corpus import Corpus, _to_bytes
+from .corpus import Corpus, _to_bytes, is_wide, to_u32
 
 
 class WeightTable(NamedTuple):
@@ -109,10 +109,15 @@ class BatchComparator:
     FLOAT = False  # jaro / jaro_winkler / ratio: every method is f64-valued
 
     def __init__(self, s1):
-        self._s1 = _to_bytes(s1)
         h = C.c_void_p()
-        buf = (C.c_uint8 * max(1, len(self._s1))).from_buffer_copy(self._s1 or b"\0")
-        N.check(N.lib().rf_comparator_new(self.METRIC, buf, len(self._s1), C.byref(h)))
+        self._wide = is_wide(s1)
+        if self._wide:  # BatchComparator::new(s1.chars()) with symbols above 255: u32 elements
+            self._s1 = to_u32(s1).copy()
+            N.check(N.lib().rf_comparator_new_u32(self.METRIC, self._s1.ctypes.data, len(self._s1), C.byref(h)))
+        else:
+            self._s1 = _to_bytes(s1)
+            buf = (C.c_uint8 * max(1, len(self._s1))).from_buffer_copy(self._s1 or b"\0")
+            N.check(N.lib().rf_comparator_new(self.METRIC, buf, len(self._s1), C.byref(h)))
         self._h = h.value
 
     def __del__(self):
@@ -233,7 +238,8 @@ class BatchComparator:
 
     # ------------------------------------------------------------------ the reference's per-candidate methods
     def _one(self, op: int, s2, args, kw):
-        corpus = Corpus.from_list([s2], device=default_device())
+        # a u32 query needs the candidate in a u32 corpus even when the candidate itself is plain ASCII
+        corpus = (Corpus.from_u32_list if self._wide else Corpus.from_list)([s2], device=default_device())
         r = self.many(op, corpus, args, **kw)[0]
         if r.dtype == np.uint32:
             return None if int(r) == N.NONE_U32 else int(r)

@@ -11,6 +11,22 @@ import numpy as np
 from . import _native as N
 
 
+def is_wide(s) -> bool:
+    """True when `s` needs u32 elements: a str with a code point above 255, or an integer array wider than a byte."""
+    if isinstance(s, str):
+        return not s.isascii() and any(ord(ch) > 0xFF for ch in s)
+    return isinstance(s, np.ndarray) and s.dtype.itemsize > 1
+
+
+def to_u32(s) -> np.ndarray:
+    """One u32 per element: code points of a str (`s.chars()`), bytes widened, integer arrays as they are."""
+    if isinstance(s, str):
+        return np.frombuffer(s.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
+    if isinstance(s, np.ndarray):
+        return s.astype(np.uint32, copy=False).reshape(-1)
+    return np.frombuffer(bytes(s), dtype=np.uint8).astype(np.uint32)
+
+
 def _to_bytes(s) -> bytes:
     if isinstance(s, str):
         return s.encode("latin-1")  # u8 elements: one byte per element
@@ -66,7 +82,34 @@ class Corpus:
 
     @classmethod
     def from_list(cls, candidates: Sequence, device: int = 0) -> "Corpus":
+        """bytes / str / uint8 arrays; if any candidate needs u32 elements (a `char` above 255) the corpus is packed
+        over u32 elements with its own alphabet (rf_corpus_pack_u32)."""
+        candidates = list(candidates)
+        if any(is_wide(c) for c in candidates):
+            return cls.from_u32_list(candidates, device=device)
         return cls.from_ragged(*ragged(candidates), device=device)
+
+    @classmethod
+    def from_u32_list(cls, candidates: Sequence, device: int = 0) -> "Corpus":
+        parts = [to_u32(c) for c in candidates]
+        offsets = np.zeros(len(parts) + 1, dtype=np.uint64)
+        if parts:
+            offsets[1:] = np.cumsum([len(x) for x in parts], dtype=np.uint64)
+        data = np.concatenate(parts).astype(np.uint32) if parts else np.zeros(0, dtype=np.uint32)
+        return cls.from_ragged_u32(data, offsets, device=device)
+
+    @classmethod
+    def from_ragged_u32(cls, data: np.ndarray, offsets: np.ndarray, device: int = 0) -> "Corpus":
+        data = np.ascontiguousarray(data, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        N.check(N.lib().rf_corpus_pack_u32(data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, device, C.byref(h)))
+        return cls(h.value, device)
+
+    def alphabet_size(self) -> tuple[int, int]:
+        """(symbols with an id of their own, symbols sharing the overflow id); (256, 0) for a byte corpus."""
+        ov = C.c_size_t()
+        return int(N.lib().rf_corpus_alphabet_size(self._h, C.byref(ov))), int(ov.value)
 
     @classmethod
     def from_rows(cls, rows: np.ndarray, device: int = 0) -> "Corpus":

@@ -6,6 +6,9 @@
 // into kernel parameters.  No metric is ever evaluated on the host: a shape without a device kernel is
 // RF_ERR_UNSUPPORTED.  Product code: never includes or links anything from oracle/.
 #include <algorithm>
+#include <atomic>
+#include <unordered_map>
+#include <unordered_set>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -57,6 +60,10 @@ struct rf_comparator {
     size_t words = 1;
     mutable std::mutex mu;
     mutable std::map<int, uint64_t*> d_pm;  // lazily uploaded per device
+    // u32 ("char") queries: the symbols, and one byte-level comparator per wide corpus searched (see resolve())
+    bool wide = false;
+    std::vector<uint32_t> s1w;
+    mutable std::map<uint64_t, rf_comparator*> lowered;
 };
 
 struct rf_corpus {
@@ -84,7 +91,15 @@ struct rf_corpus {
     };
     mutable std::mutex scratch_mu;
     mutable std::map<hipStream_t, TopkScratch> topk_scratch;
+    // u32 ("char") corpora: the stored byte is the symbol's id in THIS corpus' alphabet.  Ids 0..253 are the 254 most
+    // frequent symbols, kOverflowId lumps every rarer symbol together, kAbsentId is never stored (see resolve()).
+    bool wide = false;
+    uint64_t uid = 0;
+    std::unordered_map<uint32_t, uint8_t> alphabet;
+    std::unordered_set<uint32_t> overflow;
 };
+constexpr uint8_t kOverflowId = 254, kAbsentId = 255;
+static std::atomic<uint64_t> g_corpus_uid{1};
 
 // Symbol renaming.  Every column of every kernel gathers 64 table rows from LDS, one per lane, and LDS bank
 // conflicts between DIFFERENT symbols that share a bank (row index mod 32 for 8-byte rows) are the cost of that
@@ -151,15 +166,37 @@ rf_status rf_comparator_new(rf_metric metric, const uint8_t* s1, size_t len1, rf
     return RF_OK;
 }
 
+// BatchComparator::new over `char` (or any u32) elements.  The reference hashes non-ASCII symbols into its
+// pattern-match table (pattern_match_vector.rs:5-65, :228-260); here the table is built per corpus, in terms of that
+// corpus' symbol ids, the first time the comparator meets it (resolve()).
+rf_status rf_comparator_new_u32(rf_metric metric, const uint32_t* s1, size_t len1, rf_comparator** out)
+{
+    if (!out || (len1 && !s1) || (int)metric < 0 || (int)metric > (int)RF_OSA) {
+        set_error("rf_comparator_new_u32: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    rf_comparator* c = new (std::nothrow) rf_comparator();
+    if (!c) return RF_ERR_OOM;
+    c->metric = metric;
+    c->wide = true;
+    c->s1w.assign(s1, s1 + len1);
+    c->block_count = (len1 + 63) / 64;
+    c->words = std::max<size_t>(1, c->block_count);
+    *out = c;
+    return RF_OK;
+}
+
 rf_status rf_comparator_clone(const rf_comparator* c, rf_comparator** out)
 {
     if (!c || !out) return RF_ERR_INVALID_ARG;
+    if (c->wide) return rf_comparator_new_u32(c->metric, c->s1w.data(), c->s1w.size(), out);
     return rf_comparator_new(c->metric, c->s1.data(), c->s1.size(), out);
 }
 
 void rf_comparator_free(rf_comparator* c)
 {
     if (!c) return;
+    for (auto& kv : c->lowered) rf_comparator_free(kv.second);
     for (auto& kv : c->d_pm) {
         DeviceGuard g(kv.first);
         (void)hipFree(kv.second);
@@ -168,11 +205,67 @@ void rf_comparator_free(rf_comparator* c)
 }
 
 rf_metric rf_comparator_metric(const rf_comparator* c) { return c->metric; }
-size_t rf_comparator_query_len(const rf_comparator* c) { return c->s1.size(); }
+size_t rf_comparator_query_len(const rf_comparator* c) { return c->wide ? c->s1w.size() : c->s1.size(); }
 const uint64_t* rf_comparator_pm(const rf_comparator* c, size_t* block_count)
 {
     if (block_count) *block_count = c->block_count;
-    return c->pm.data();
+    return c->wide ? nullptr : c->pm.data();  // a u32 comparator has one table per corpus alphabet, none of its own
+}
+
+// Which byte-level comparator serves (c, corpus).  Byte query x byte corpus: c itself.  Anything involving u32
+// symbols is LOWERED to the corpus' alphabet: query symbol -> its id; a symbol the corpus does not contain at all ->
+// kAbsentId, an id no candidate byte has, so it can never match (which is all any metric on this path asks of it);
+// a symbol the corpus lumped into its overflow class cannot be told apart from the other overflow symbols, so the
+// call is refused rather than answered approximately.  Lowered comparators are cached per corpus.
+static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff)
+{
+    if (!c || !corpus) {
+        set_error("null handle");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (!c->wide && !corpus->wide) {
+        *eff = c;
+        return RF_OK;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->lowered.find(corpus->uid);
+    if (it != c->lowered.end()) {
+        *eff = it->second;
+        return RF_OK;
+    }
+    const size_t len = c->wide ? c->s1w.size() : c->s1.size();
+    std::vector<uint8_t> ids(len);
+    for (size_t i = 0; i < len; ++i) {
+        const uint32_t ch = c->wide ? c->s1w[i] : (uint32_t)c->s1[i];
+        if (!corpus->wide) {  // u32 query on a byte corpus: bytes are the code points 0..255
+            if (ch > 0xFF) {
+                set_error("a query symbol above 255 cannot be searched in a byte corpus: pack the corpus with rf_corpus_pack_u32");
+                return RF_ERR_UNSUPPORTED;
+            }
+            ids[i] = (uint8_t)ch;
+            continue;
+        }
+        auto a = corpus->alphabet.find(ch);
+        if (a != corpus->alphabet.end()) {
+            ids[i] = a->second;
+        } else if (corpus->overflow.count(ch)) {
+            set_error("the query contains a symbol this corpus stores in its overflow class (more than 254 distinct symbols, "
+                      "this one among the rarest): no exact answer on the device");
+            return RF_ERR_UNSUPPORTED;
+        } else {
+            ids[i] = kAbsentId;
+        }
+    }
+    rf_comparator* low = nullptr;
+    const rf_status s = rf_comparator_new(c->metric, ids.data(), ids.size(), &low);
+    if (s != RF_OK) return s;
+    if (c->lowered.size() >= 64) {  // bounded cache: drop the oldest corpus
+        rf_comparator_free(c->lowered.begin()->second);
+        c->lowered.erase(c->lowered.begin());
+    }
+    c->lowered[corpus->uid] = low;
+    *eff = low;
+    return RF_OK;
 }
 
 // row stride (in u64) of the device PM table: the word count, or for patterns beyond the register-resident kernels
@@ -391,6 +484,7 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     }
     rf_corpus* c = new (std::nothrow) rf_corpus();
     if (!c) return RF_ERR_OOM;
+    c->uid = g_corpus_uid.fetch_add(1);
     c->device = device;
     c->n = n;
     c->payload_bytes = L.payload;
@@ -425,6 +519,68 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     return RF_OK;
 }
 
+// Candidates over `char` (or any u32) elements.  The corpus gets its own alphabet: the 254 most frequent symbols
+// become byte ids 0..253 (frequency order, so the LDS rows the kernels touch most sit in distinct banks), every rarer
+// symbol becomes kOverflowId, and the id bytes are packed exactly like a byte corpus.  Results are exact for every
+// query that contains no overflow symbol (resolve()): candidate symbols outside the query only ever need to be
+// "not equal", and the lumped ones still are.
+rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, size_t n, int device, rf_corpus** out)
+{
+    if (!out || (n && !offsets)) {
+        set_error("rf_corpus_pack_u32: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    const uint64_t total = n ? offsets[n] : 0;
+    if (total && !elems) {
+        set_error("rf_corpus_pack_u32: null elements");
+        return RF_ERR_INVALID_ARG;
+    }
+    // histogram: a direct table for the BMP, a hash map above it
+    std::vector<uint64_t> low(0x10000, 0);
+    std::unordered_map<uint32_t, uint64_t> high;
+    for (uint64_t i = 0; i < total; ++i) {
+        const uint32_t ch = elems[i];
+        if (ch < 0x10000)
+            ++low[ch];
+        else
+            ++high[ch];
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> syms;  // (count, symbol)
+    for (uint32_t ch = 0; ch < 0x10000; ++ch)
+        if (low[ch]) syms.emplace_back(low[ch], ch);
+    for (const auto& kv : high) syms.emplace_back(kv.second, kv.first);
+    std::sort(syms.begin(), syms.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    std::unordered_map<uint32_t, uint8_t> alphabet;
+    std::unordered_set<uint32_t> overflow;
+    for (size_t r = 0; r < syms.size(); ++r) {
+        if (r < (size_t)kOverflowId)
+            alphabet.emplace(syms[r].second, (uint8_t)r);
+        else
+            overflow.insert(syms[r].second);
+    }
+    std::vector<uint16_t> low_id(0x10000, 0xFFFF);
+    for (const auto& kv : alphabet)
+        if (kv.first < 0x10000) low_id[kv.first] = kv.second;
+    std::vector<uint8_t> ids(std::max<uint64_t>(1, total));
+    for (uint64_t i = 0; i < total; ++i) {
+        const uint32_t ch = elems[i];
+        if (ch < 0x10000) {
+            ids[i] = low_id[ch] == 0xFFFF ? kOverflowId : (uint8_t)low_id[ch];
+        } else {
+            auto a = alphabet.find(ch);
+            ids[i] = a == alphabet.end() ? kOverflowId : a->second;
+        }
+    }
+    rf_corpus* c = nullptr;
+    const rf_status s = rf_corpus_pack(ids.data(), offsets, n, device, &c);
+    if (s != RF_OK) return s;
+    c->wide = true;
+    c->alphabet = std::move(alphabet);
+    c->overflow = std::move(overflow);
+    *out = c;
+    return RF_OK;
+}
+
 rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, size_t stride, int device, void* stream,
                                      rf_corpus** out)
 {
@@ -439,6 +595,7 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
     }
     rf_corpus* c = new (std::nothrow) rf_corpus();
     if (!c) return RF_ERR_OOM;
+    c->uid = g_corpus_uid.fetch_add(1);
     c->device = device;
     c->n = n;
     c->payload_bytes = (uint64_t)n * len;
@@ -500,6 +657,11 @@ size_t rf_corpus_count(const rf_corpus* c) { return c->n; }
 uint64_t rf_corpus_payload_bytes(const rf_corpus* c) { return c->payload_bytes; }
 uint64_t rf_corpus_device_bytes(const rf_corpus* c) { return c->device_bytes; }
 int rf_corpus_device(const rf_corpus* c) { return c->device; }
+size_t rf_corpus_alphabet_size(const rf_corpus* c, size_t* overflow_symbols)
+{
+    if (overflow_symbols) *overflow_symbols = c->overflow.size();
+    return c->wide ? c->alphabet.size() : 256;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // one-vs-many
@@ -700,9 +862,11 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     return RF_OK;
 }
 
-static rf_status run_many(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, void* out,
+static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus, rf_op op, const rf_args* args, void* out,
                           rf_mem out_mem, void* stream, bool f64_out)
 {
+    const rf_comparator* c = nullptr;
+    if (const rf_status rs = resolve(c_in, corpus, &c); rs != RF_OK) return rs;
     ScanParams p;
     RawKind raw = RAW_LEV;
     rf_status s = plan(c, corpus, op, args, f64_out, &p, &raw);
@@ -761,10 +925,10 @@ rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
 // Queries whose recurrences fit one machine word and agree on the kernel family are fused kMaxMulti (then 2) at a
 // time into scan_multi_kernel launches, which read every candidate byte once per group; the rest go through the
 // single-query launch.  Either way row q of `out` is exactly what rf_many_* gives for cs[q].
-static rf_status run_many_multi(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
                                 void* out, rf_mem out_mem, void* stream, bool f64_out)
 {
-    if (!cs || !corpus || !args) {
+    if (!cs_in || !corpus || !args) {
         set_error("null handle or args");
         return RF_ERR_INVALID_ARG;
     }
@@ -777,10 +941,13 @@ static rf_status run_many_multi(const rf_comparator* const* cs, uint32_t q, cons
     const size_t row_bytes = corpus->n * elem;
     std::vector<ScanParams> ps(q);
     std::vector<RawKind> raws(q, RAW_LEV);
+    std::vector<const rf_comparator*> eff(q, nullptr);
     for (uint32_t i = 0; i < q; ++i) {
-        const rf_status s = plan(cs[i], corpus, op, args, f64_out, &ps[i], &raws[i]);
+        rf_status s = resolve(cs_in[i], corpus, &eff[i]);
+        if (s == RF_OK) s = plan(eff[i], corpus, op, args, f64_out, &ps[i], &raws[i]);
         if (s != RF_OK) return s;
     }
+    const rf_comparator* const* cs = eff.data();
     DeviceGuard guard(corpus->device);
     if (!guard.ok) {
         set_error("cannot select the corpus' device");
@@ -863,10 +1030,12 @@ rf_status rf_many_multi_f64(const rf_comparator* const* cs, uint32_t q, const rf
 // top-k
 // ---------------------------------------------------------------------------------------------------
 // shared by rf_topk_u32 (host results) and rf_topk_keys_device (device keys, fully asynchronous)
-static rf_status topk_core(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
+static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
                            uint32_t key_index_base, uint64_t* d_best /*device, k entries*/, uint32_t* out_all,
                            rf_mem out_all_mem, hipStream_t st, bool* desc)
 {
+    const rf_comparator* c = nullptr;
+    if (const rf_status rs = resolve(c_in, corpus, &c); rs != RF_OK) return rs;
     if (k == 0 || k > (uint32_t)kWave) {
         set_error("top-k: k must be in 1..64 (one list entry per wavefront lane)");
         return k == 0 ? RF_ERR_INVALID_ARG : RF_ERR_UNSUPPORTED;

@@ -666,3 +666,103 @@ def test_cutoff_length_window_ragged(qlen):
         assert list(zip(s.tolist(), i.tolist())) == exp, (qlen, k)
     for w, k in (((2, 2, 2), 7), ((3, 3, 3), 2)):  # factor > 1: the window is cutoff / factor
         _check_many("levenshtein", q, data, offsets, "distance", weights=w, score_cutoff=k)
+
+
+# ---------------------------------------------------------------- u32 ("char") elements (widening row f4)
+GREEK = [chr(c) for c in range(0x391, 0x3CA) if chr(c).isalpha()]
+CYRILLIC = [chr(c) for c in range(0x410, 0x450)]
+CJK = [chr(c) for c in range(0x4E00, 0x4E00 + 600)]
+
+
+def _rand_strings(rng, alphabet, n, max_len, probs=None):
+    out = []
+    for _ in range(n):
+        ln = int(rng.integers(0, max_len + 1))
+        out.append("".join(rng.choice(alphabet, size=ln, p=probs)))
+    return out
+
+
+def _byte_renaming(strings):
+    """an injective char -> byte map over every symbol in `strings` (needs <= 256 distinct symbols)"""
+    syms = sorted({ch for s in strings for ch in s})
+    assert len(syms) <= 256
+    m = {ch: i for i, ch in enumerate(syms)}
+    return lambda s: bytes(m[ch] for ch in s)
+
+
+@pytest.mark.parametrize("metric", ["levenshtein", "indel", "lcs_seq", "osa", "jaro", "jaro_winkler"])
+def test_u32_elements_equal_the_oracle_after_injective_renaming(metric):
+    # the reference's own unicode tests work the same way round: results only depend on which symbols are equal
+    rng = np.random.default_rng(31)
+    alphabet = GREEK + CYRILLIC + list("abcdefghij0123 -")  # ~130 symbols, all with ids of their own
+    cands = _rand_strings(rng, alphabet, 3000, 90)
+    queries = ["", "λόγος"[:3], "".join(rng.choice(alphabet, size=40)), "".join(rng.choice(alphabet, size=100)),
+               "plain ascii", "Ω" * 70, "абв\U0001F600где"]  # the last one has a symbol the corpus does not contain
+    for i in range(0, len(cands), 50):  # near-duplicates of the long queries
+        b = list(queries[2 + (i // 50) % 2])
+        for _ in range(int(rng.integers(0, 6))):
+            if b:
+                b[int(rng.integers(0, len(b)))] = str(rng.choice(alphabet))
+        cands[i] = "".join(b)
+    corpus = rf.Corpus.from_list(cands)
+    assert corpus.alphabet_size()[1] == 0
+    ren = _byte_renaming(cands + queries)
+    data, offsets = rf.ragged([ren(c) for c in cands])
+    is_f = metric in ("jaro", "jaro_winkler")
+    cases = [("distance", {}), ("similarity", {}), ("normalized_distance", {}), ("normalized_similarity", {"score_cutoff": 0.6})]
+    if not is_f:
+        cases += [("distance", {"score_cutoff": 5}), ("similarity", {"score_cutoff": 20})]
+    for q in queries:
+        for op, kw in cases:
+            if metric == "levenshtein" and op == "similarity" and kw:
+                continue  # quirk Q2, covered by the byte tests
+            got = GPU[metric].BatchComparator(q).many(OPS[op], corpus, **kw)
+            exp = ORA[metric].BatchComparator(ren(q)).many(OPS[op], data, offsets, nthreads=8, **kw)
+            exp = _expect_u32(exp) if got.dtype == np.uint32 else exp
+            assert _equal_rows(got, exp), (metric, q[:8], op, kw)
+    # single pairs through the reference-shaped methods, str in / str in
+    bc = GPU[metric].BatchComparator("κόσμος")
+    for s2 in ("κόσμε", "", "kosmos", "κόσμος"):
+        r2 = _byte_renaming(["κόσμος", s2])
+        assert bc.distance(s2) == ORA[metric].BatchComparator(r2("κόσμος")).distance(r2(s2))
+
+
+def test_u32_overflow_class_is_exact_or_refused():
+    import textbook as tb
+
+    rng = np.random.default_rng(5)
+    # 600 CJK symbols with a Zipf-like tail + Latin: more than 254 distinct symbols, the rare ones share the overflow id
+    alphabet = list("abcdefghijklmnopqrstuvwxyz ") + CJK
+    w = 1.0 / np.arange(1, len(alphabet) + 1) ** 1.1
+    cands = _rand_strings(rng, alphabet, 1500, 40, probs=w / w.sum())
+    corpus = rf.Corpus.from_list(cands)
+    own, overflow = corpus.alphabet_size()
+    assert own == 254 and overflow > 0
+    counts = {}
+    for c in cands:
+        for ch in c:
+            counts[ch] = counts.get(ch, 0) + 1
+    ranked = sorted(counts, key=lambda ch: (-counts[ch], ord(ch)))
+    frequent, rare = ranked[:254], ranked[254:]
+    absent = [ch for ch in CJK if ch not in counts][:3] + ["\U0001F642"]
+    q_ok = "".join(rng.choice(frequent, size=30)) + "".join(absent)  # alphabet symbols + symbols the corpus lacks
+    for metric, ref in (("levenshtein", tb.levenshtein_unit), ("indel", tb.indel), ("osa", tb.osa)):
+        got = GPU[metric].BatchComparator(q_ok).distance_many(corpus)
+        for i in range(0, len(cands), 7):
+            assert int(got[i]) == ref(rf.corpus.to_u32(q_ok), rf.corpus.to_u32(cands[i])), (metric, i)
+    got = rf.distance.jaro_winkler.BatchComparator(q_ok).similarity_many(corpus)
+    for i in range(0, len(cands), 29):
+        assert abs(got[i] - tb.jaro_winkler(rf.corpus.to_u32(q_ok), rf.corpus.to_u32(cands[i]))) < 1e-12
+    s, idx = rf.distance.levenshtein.BatchComparator(q_ok).topk(corpus, 5)
+    full = rf.distance.levenshtein.BatchComparator(q_ok).distance_many(corpus)
+    assert list(zip(s.tolist(), idx.tolist())) == sorted((int(d), j) for j, d in enumerate(full))[:5]
+    with pytest.raises(rf.RfError) as e:  # a query with an overflow symbol cannot be answered exactly: refused
+        rf.distance.levenshtein.BatchComparator(q_ok + rare[0]).distance_many(corpus)
+    assert e.value.status == N.RF_ERR_UNSUPPORTED
+    # byte comparator on a u32 corpus (bytes = code points 0..255) and u32 comparator on a byte corpus
+    got = rf.distance.levenshtein.BatchComparator(b"hello world").distance_many(corpus)
+    assert int(got[3]) == tb.levenshtein_unit(rf.corpus.to_u32("hello world"), rf.corpus.to_u32(cands[3]))
+    bcorp = rf.Corpus.from_list([b"hello", b"world", "h\xe9llo".encode("latin-1")])
+    assert rf.distance.levenshtein.BatchComparator(np.array([104, 233, 108, 108, 111], dtype=np.uint32)).distance_many(bcorp).tolist() == [1, 4, 0]
+    with pytest.raises(rf.RfError):
+        rf.distance.levenshtein.BatchComparator("hεllo").distance_many(bcorp)

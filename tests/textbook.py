@@ -10,6 +10,8 @@ import numpy as np
 
 
 def _b(s) -> np.ndarray:
+    if isinstance(s, np.ndarray):  # any integer element type (u32 "chars"): only equality of elements matters
+        return s.reshape(-1)
     if isinstance(s, str):
         s = s.encode("latin-1")
     return np.frombuffer(bytes(s), dtype=np.uint8)
