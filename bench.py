@@ -237,6 +237,13 @@ def main():
             "algorithmic_bytes_per_pair": bytes_per_pair,
         },
     }
+    if args.metric == "levenshtein" and 32 < args.query_len <= 64 and args.cutoff is None and nq == 1 and ln == 64:
+        # The single-word Levenshtein column is 17 VALU + 1 SDWA instructions, three of them half-rate 64-bit forms:
+        # the same column sequence fed from registers, with no memory traffic at all, tops out at 43.1 Gpairs/s on
+        # this chip (tools/microbench.hip k_lev_regs, profiles/microbench_r01.txt) -- that, not HBM, is what binds.
+        per_gpu = gpairs / world
+        result["roofline"]["issue_bound"] = {"achieved": round(per_gpu, 3), "ceiling": 43.14, "unit": "Gpairs/s", "frac": round(per_gpu / 43.14, 4),
+                                             "source": "profiles/microbench_r01.txt: lev col regs, 8 blocks/CU"}
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,
