@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--mode", default="many", choices=["many", "topk"],
                     help="many: one score per candidate (configs[1]); topk: top-k only, no per-candidate output (configs[4])")
     ap.add_argument("--plant-every", type=int, default=1_000_000, help="near-duplicates of the query planted 1-in-N (cutoff/top-k runs)")
+    ap.add_argument("--weights", default=None, help="levenshtein WeightTable as ins,del,sub (e.g. 1,2,3: the generalized Wagner-Fischer kernel)")
+    ap.add_argument("--symbols", type=int, default=62, help="alphabet size of the synthetic corpus (experiment knob, default alphanumeric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -79,7 +81,7 @@ def main():
 
     # synthetic corpus, generated and packed on the device (excluded from the timed region)
     t0 = time.time()
-    rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev)
+    rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev, symbols=args.symbols)
     if args.cutoff is not None or args.mode == "topk":
         # 1 in 10^6 candidates is the query with 0..5 random substitutions
         gen = torch.Generator(device=dev)
@@ -110,6 +112,9 @@ def main():
     call_args = rf.Args()
     if args.cutoff is not None:
         call_args = call_args.score_cutoff(args.cutoff)
+    weights = tuple(int(x) for x in args.weights.split(",")) if args.weights else None
+    if weights:
+        call_args = call_args.weights(rf.WeightTable(*weights))
     stream = torch.cuda.current_stream(dev)
 
     from rapidfuzz_rs_amd import parallel
@@ -216,8 +221,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.metric}::BatchComparator, 1 query len-{args.query_len} x {n} random alphanumeric len-{ln} candidates per GPU, "
-            + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
-            + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64 and args.cutoff is None) else ""),
+            + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}") + (f", weights={weights}" if weights else "")
+            + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64 and args.cutoff is None and not weights) else ""),
             "candidates_per_gpu": n,
             "candidate_len": ln,
             "query_len": args.query_len,
@@ -237,7 +242,7 @@ def main():
             "algorithmic_bytes_per_pair": bytes_per_pair,
         },
     }
-    if args.metric == "levenshtein" and 32 < args.query_len <= 64 and args.cutoff is None and nq == 1 and ln == 64:
+    if args.metric == "levenshtein" and 32 < args.query_len <= 64 and args.cutoff is None and nq == 1 and ln == 64 and not weights:
         # The single-word Levenshtein column is 17 VALU + 1 SDWA instructions, three of them half-rate 64-bit forms:
         # the same column sequence fed from registers, with no memory traffic at all, tops out at 43.1 Gpairs/s on
         # this chip (tools/microbench.hip k_lev_regs, profiles/microbench_r01.txt) -- that, not HBM, is what binds.
@@ -261,7 +266,8 @@ def main():
         op = N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE
         mism = 0
         for j in range(nq):
-            exp = getattr(o, args.metric).BatchComparator(queries[j]).rows(op, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)
+            kw = {"weights": weights} if weights else {}
+            exp = getattr(o, args.metric).BatchComparator(queries[j]).rows(op, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff, **kw)
             if is_f64:
                 got = out[j * n : j * n + chk].cpu().numpy()
                 bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
@@ -303,16 +309,17 @@ def cpu_baseline(args, q, host_sample):
     OP = N.OP_SIMILARITY if args.metric in ("jaro", "jaro_winkler") else N.OP_DISTANCE
     probe = host_sample[:200_000]
     t0 = time.perf_counter()
-    bc.rows(OP, probe, nthreads=1, score_cutoff=args.cutoff)
+    kw = {"weights": tuple(int(x) for x in args.weights.split(","))} if getattr(args, "weights", None) else {}
+    bc.rows(OP, probe, nthreads=1, score_cutoff=args.cutoff, **kw)
     rate = len(probe) / (time.perf_counter() - t0)
     n1 = int(min(len(host_sample), max(200_000, rate * args.cpu_seconds * 0.5)))
     t0 = time.perf_counter()
-    bc.rows(OP, host_sample[:n1], nthreads=1, score_cutoff=args.cutoff)
+    bc.rows(OP, host_sample[:n1], nthreads=1, score_cutoff=args.cutoff, **kw)
     t1 = time.perf_counter() - t0
     cores = os.cpu_count() or 1
     nall = int(min(len(host_sample), max(n1, rate * cores * args.cpu_seconds * 0.3)))
     t0 = time.perf_counter()
-    bc.rows(OP, host_sample[:nall], nthreads=cores, score_cutoff=args.cutoff)
+    bc.rows(OP, host_sample[:nall], nthreads=cores, score_cutoff=args.cutoff, **kw)
     tall = time.perf_counter() - t0
     model = ""
     try:

@@ -738,9 +738,18 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
             p->finish = FIN_LEV_INDEL;
             p->factor = (uint32_t)ins;
         } else {
-            set_error("levenshtein: this weight table needs the generalized Wagner-Fischer path "
-                      "(levenshtein.rs:212-259), which has no device kernel");
-            return RF_ERR_UNSUPPORTED;
+            // every other table: the generalized Wagner-Fischer row DP (levenshtein.rs:212-259) in LDS
+            *raw = RAW_WF;
+            p->finish = FIN_LEV_GENERAL;
+            const uint64_t row_bytes = ((uint64_t)p->len1 + 1) * kWave * sizeof(uint32_t);
+            const uint64_t lds_budget = 150u << 10;  // of the 160 KiB a gfx950 workgroup may hold
+            const uint64_t worst = ((uint64_t)p->len1 + corpus->max_len) * std::max(std::max(ins, del), sub);
+            if (row_bytes + p->len1 + 8 > lds_budget || worst >= (1ull << 31)) {
+                set_error("levenshtein with a general weight table: the query is too long for the LDS-resident Wagner-Fischer "
+                          "kernel (about 590 symbols), or distances would not fit 31 bits");
+                return RF_ERR_UNSUPPORTED;
+            }
+            p->wf_waves = (uint32_t)std::min<uint64_t>(kWavesPerBlock, (lds_budget - p->len1 - 8) / row_bytes);
         }
         break;
     }
@@ -814,6 +823,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         case FIN_LCS: p->fin_dS = 0, p->fin_dM = 1, p->fin_dR = -1, p->fin_mS = 0, p->fin_mM = 1; break;
         case FIN_INDEL: p->fin_dS = 1, p->fin_dM = 0, p->fin_dR = -2, p->fin_mS = 1, p->fin_mM = 0; break;
         case FIN_LEV_INDEL: p->fin_dS = f, p->fin_dM = 0, p->fin_dR = -2 * f, p->fin_mS = f, p->fin_mM = 0; break;
+        case FIN_LEV_GENERAL: p->fin_dS = 0, p->fin_dM = 0, p->fin_dR = 1, p->fin_mS = 0, p->fin_mM = 0; break;  // maximum: wf_kernel
         default: break;
         }
         if (op == RF_OP_DISTANCE || op == RF_OP_NORMALIZED_DISTANCE) {
@@ -827,6 +837,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         }
     }
 
+    if (*raw == RAW_WF) return RF_OK;
     if (c->words > (size_t)kMaxWords) {
         // beyond 512 symbols: the multi-sweep kernel (8 words per sweep, carries parked in an HBM scratch strip)
         if (c->words > 0x00FFFFFFu) {
@@ -1052,8 +1063,8 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, r
         set_error("top-k: usize-valued metrics only");
         return RF_ERR_INVALID_ARG;
     }
-    if (p.long_words_pad) {
-        set_error("top-k: queries longer than 512 symbols are served by rf_many_* only");
+    if (p.long_words_pad || raw == RAW_WF) {
+        set_error("top-k: queries longer than 512 symbols and general Levenshtein weight tables are served by rf_many_* only");
         return RF_ERR_UNSUPPORTED;
     }
     *desc = op == RF_OP_SIMILARITY;

@@ -30,6 +30,7 @@ enum RawKind : uint32_t {
     RAW_LEV = 0,   // uniform Levenshtein distance (Myers/Hyyro)
     RAW_LCS = 1,   // LCS length (Hyyro)
     RAW_JARO = 2,  // Jaro flags + transpositions
+    RAW_WF = 4,    // generalized-weights Levenshtein, Wagner-Fischer rows in LDS
     RAW_OSA = 3    // optimal string alignment distance (Hyyro + transposition term)
 };
 
@@ -40,7 +41,8 @@ enum Finish : uint32_t {
     FIN_INDEL = 2,  // dist = len1+len2 - 2l,         maximum = len1 + len2
     FIN_JARO = 3,
     FIN_JW = 4,
-    FIN_LEV_INDEL = 5  // levenshtein with weights (f, f, >= 2f): dist = (len1+len2-2l)*f, maximum = lev _maximum
+    FIN_LEV_INDEL = 5,  // levenshtein with weights (f, f, >= 2f): dist = (len1+len2-2l)*f, maximum = lev _maximum
+    FIN_LEV_GENERAL = 6 // any other weight table: dist = raw (Wagner-Fischer), maximum = lev _maximum (not affine)
 };
 
 struct ScanParams {
@@ -64,6 +66,7 @@ struct ScanParams {
     uint32_t factor;       // common weight factor (levenshtein.rs:1307-1327)
     uint32_t w_ins, w_del, w_sub;  // for _maximum (levenshtein.rs:263-277)
     uint32_t tile_begin, tile_end;  // tile range of this launch (jaro kernels; the cutoff length window of the scans)
+    uint32_t wf_waves;              // wavefronts per workgroup of wf_kernel (LDS rows per wavefront: (len1 + 1) * 256 B)
     uint32_t tile_step;             // >= 1: visit every tile_step-th tile of the range (the top-k bound sample)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
     uint32_t jaro_split;   // first tile that needs the multi-word jaro path

@@ -420,10 +420,9 @@ __device__ __forceinline__ uint32_t usize_value(const ScanParams& p, uint32_t ra
     return usize_value(p, tile_fin(p, len1, len2), raw, keep);
 }
 
-// `out` / `len1` default to the launch's single query; the multi-query kernel passes its own per query
-__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx, void* out, uint32_t len1)
+// one result from a tile's finishing terms; `out` is the launch's (or, in the multi-query kernel, the query's) row
+__device__ __forceinline__ void emit_fin(const ScanParams& p, const TileFin& f, uint32_t raw, uint32_t idx, void* out)
 {
-    const TileFin f = tile_fin(p, len1, len2);
     if (!p.out_f64) {
         bool keep;
         const uint32_t v = usize_value(p, f, raw, &keep);
@@ -443,6 +442,10 @@ __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, ui
         }
         reinterpret_cast<double*>(out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
     }
+}
+__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx, void* out, uint32_t len1)
+{
+    emit_fin(p, tile_fin(p, len1, len2), raw, idx, out);
 }
 __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx)
 {
@@ -1041,6 +1044,89 @@ hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t
     hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(kFinalThreads), 0, stream, keys, count_ptr, count_imm, k, out, bound_ptr,
                        bound_from_result);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generalized weights (levenshtein.rs:212-259 generalized_wagner_fischer, reached from _distance_with_pm :1328-1330
+// for every weight table that is neither (f,f,f) nor (f,f,>=2f)): the O(len1 * len2) row DP, one candidate per lane.
+//   new[i+1] = s1[i] == ch2 ? old[i] : min(new[i] + del, old[i] + sub, old[i+1] + ins)
+// The row (len1 + 1 u32 per lane) lives in LDS as [i][lane] -- conflict-free, 256 B per row entry and wavefront -- so
+// the workgroup has as many wavefronts as fit (plan(): wf_waves).  The query, renamed like the corpus, is rebuilt
+// from the PM table into LDS and read back 4 symbols at a time with a wavefront-uniform (broadcast) address.
+// A completeness path (~10 VALU + 2.25 LDS operations per cell); the reference's common-affix stripping and minimum-
+// edits test (:286-309) change nothing in the value and are not replayed.
+// ---------------------------------------------------------------------------------------------------
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void wf_kernel(const ScanParams p)
+{
+    extern __shared__ uint32_t lds_wf[];
+    const uint32_t len1 = p.len1;
+    const uint32_t qwords = (len1 + 3) / 4 + 1;  // query bytes, 4 per word, one word of slack
+    uint8_t* lds_q = reinterpret_cast<uint8_t*>(lds_wf);
+    for (uint32_t i = threadIdx.x; i < qwords; i += blockDim.x) lds_wf[i] = 0;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {  // PM row c, bit i  <=>  s1[i] == c
+        const uint8_t stored = p.sigma[c];
+        for (uint32_t w = 0; w * 64 < len1; ++w) {
+            uint64_t bits = p.pm[(size_t)c * p.words + w];
+            while (bits) {
+                lds_q[64 * w + (__ffsll((unsigned long long)bits) - 1)] = stored;
+                bits &= bits - 1;
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t waves = blockDim.x / kWave;
+    uint32_t* row = lds_wf + qwords + (size_t)wave * (len1 + 1) * kWave + lane;  // row[i * kWave] = cache[i] of this lane
+    const uint32_t ins = p.w_ins, del = p.w_del, sub = p.w_sub;
+
+    for (uint32_t t = blockIdx.x * waves + wave; t < p.n_tiles; t += gridDim.x * waves) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2 = tv.len;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+        for (uint32_t i = 0; i <= len1; ++i) row[i * kWave] = i * del;  // :219-221
+        uint32_t top = 0;  // cache[0] = j * ins, the same in every lane
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint4 data = load_chunk(tv.src + (size_t)c * kWave + lane);
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            for (uint32_t j = 0; j < cols; ++j) {
+                const uint32_t word = j < 4 ? data.x : (j < 8 ? data.y : (j < 12 ? data.z : data.w));
+                const uint32_t ch2 = (word >> (8 * (j & 3))) & 0xFFu;
+                uint32_t diag = top;  // old[i]
+                top += ins;           // :226
+                uint32_t left = top;  // new[i]
+                for (uint32_t i = 0; i < len1; i += 4) {
+                    const uint32_t q4 = lds_wf[i / 4];  // wavefront-uniform address: one broadcast read for 4 symbols
+                    const uint32_t lim = min(4u, len1 - i);
+                    for (uint32_t k = 0; k < lim; ++k) {
+                        const uint32_t up = row[(i + k + 1) * kWave];  // old[i+1]
+                        const uint32_t x = ((q4 >> (8 * k)) & 0xFFu) == ch2 ? diag : min(min(left + del, diag + sub), up + ins);
+                        row[(i + k + 1) * kWave] = x;
+                        diag = up;
+                        left = x;
+                    }
+                }
+            }
+        }
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            const uint32_t dist = len1 ? row[len1 * kWave] : top;
+            // _maximum, levenshtein.rs:263-277 (not affine in the lengths for a general table)
+            const uint32_t max_dist = len1 * del + len2 * ins;
+            const uint32_t alt = len1 >= len2 ? len2 * sub + (len1 - len2) * del : len1 * sub + (len2 - len1) * ins;
+            TileFin f;
+            f.max = min(max_dist, alt);
+            f.d0 = 0;
+            f.v0 = p.fin_flip ? f.max : 0;  // similarity = maximum - distance (fin_vR = -1), distance = raw (fin_vR = +1)
+            emit_fin(p, f, dist, idx, p.out);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1730,6 +1816,15 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
             else
                 hipLaunchKernelGGL((long_kernel<false, true>), g, b, 0, stream, p);
         }
+        return hipGetLastError();
+    }
+    if (raw == RAW_WF) {
+        const size_t lds = ((size_t)(p.len1 + 3) / 4 + 1) * 4 + (size_t)p.wf_waves * (p.len1 + 1) * kWave * 4;
+        const dim3 g(std::max(1, scan_grid(p.n_tiles))), b(kWave * p.wf_waves);
+        auto k = p.tiles ? wf_kernel<false> : wf_kernel<true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, g, b, lds, stream, p);
         return hipGetLastError();
     }
     switch (raw) {

@@ -44,8 +44,9 @@ def plant_near_duplicates(rows: np.ndarray, q: bytes, every: int, seed: int, max
     return idx
 
 
-def rows_device(n: int, length: int, seed: int, device=None, chunk: int = 1 << 24):
-    """torch uint8 CUDA tensor [n, length] of alphanumerics, generated on the device in chunks."""
+def rows_device(n: int, length: int, seed: int, device=None, chunk: int = 1 << 24, symbols: int = 62):
+    """torch uint8 CUDA tensor [n, length] of alphanumerics, generated on the device in chunks (`symbols` < 62 draws
+    from the first `symbols` of 0-9A-Za-z: an experiment knob for the LDS gather cost)."""
     import torch
 
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -56,7 +57,7 @@ def rows_device(n: int, length: int, seed: int, device=None, chunk: int = 1 << 2
     total = n * length
     for s in range(0, total, chunk * 16):
         e = min(total, s + chunk * 16)
-        v = torch.randint(0, 62, (e - s,), dtype=torch.uint8, device=dev, generator=g)
+        v = torch.randint(0, symbols, (e - s,), dtype=torch.uint8, device=dev, generator=g)
         # 0-9 -> '0'.., 10-35 -> 'A'.., 36-61 -> 'a'..
         v += 48 + 7 * (v >= 10).to(torch.uint8) + 6 * (v >= 36).to(torch.uint8)
         flat[s:e] = v

@@ -194,12 +194,39 @@ def test_levenshtein_weights(w):
     _check_many("levenshtein", q, data, offsets, "distance", weights=w, score_cutoff=30)
 
 
-@pytest.mark.parametrize("w", [(1, 2, 3), (1, 2, 1), (2, 2, 3), (1, 1, 0)])
-def test_levenshtein_generalized_weights_unsupported(w):
-    corpus = rf.Corpus.from_list([b"abc", b"abcd"])
+@pytest.mark.parametrize("w", [(1, 2, 3), (1, 2, 1), (2, 2, 3), (1, 1, 0), (3, 1, 2), (0, 1, 1), (1, 0, 5), (7, 11, 13)])
+@pytest.mark.parametrize("qlen", [0, 1, 40, 65, 200])
+def test_levenshtein_generalized_weights(w, qlen):
+    # levenshtein.rs:1328-1330 -> generalized_distance :286-309 -> generalized_wagner_fischer :212-259
+    rng = np.random.default_rng(qlen * 31 + w[0])
+    q = ABCD[rng.integers(0, 4, size=qlen)].tobytes() if qlen % 2 else synth.query(qlen, 555 + qlen)
+    data, offsets = synth.ragged_host(1500, 90, seed=qlen + 3, alphabet=ABCD if qlen % 2 else synth.ALNUM)
+    for op in ("distance", "similarity", "normalized_distance", "normalized_similarity"):
+        _check_many("levenshtein", q, data, offsets, op, weights=w)
+    _check_many("levenshtein", q, data, offsets, "distance", weights=w, score_cutoff=25)
+    _check_many("levenshtein", q, data, offsets, "normalized_distance", weights=w, score_cutoff=0.4)
+    _check_many("levenshtein", q, data, offsets, "normalized_similarity", weights=w, score_cutoff=0.5)
+
+
+def test_levenshtein_generalized_weights_limits_and_uniform_corpus():
+    rows = synth.rows_host(5000, 48, seed=8)
+    corpus = rf.Corpus.from_rows(rows)
+    data, offsets = rows.reshape(-1), np.arange(0, rows.size + 1, 48, dtype=np.uint64)
+    q = synth.query(590, 9)  # the longest query whose row fits LDS: one wavefront per workgroup
+    got = rf.distance.levenshtein.BatchComparator(q).distance_many(corpus, weights=(1, 2, 3))
+    exp = o.levenshtein.BatchComparator(q).many(N.OP_DISTANCE, data, offsets, nthreads=8, weights=(1, 2, 3))
+    assert (got == _expect_u32(exp)).all()
     with pytest.raises(rf.RfError) as e:
-        rf.distance.levenshtein.BatchComparator(b"abd").distance_many(corpus, weights=w)
+        rf.distance.levenshtein.BatchComparator(synth.query(700, 9)).distance_many(corpus, weights=(1, 2, 3))
     assert e.value.status == N.RF_ERR_UNSUPPORTED
+    with pytest.raises(rf.RfError):
+        rf.distance.levenshtein.BatchComparator(synth.query(20, 9)).topk(corpus, 4, weights=(1, 2, 3))
+    # a mixed list of queries through rf_many_multi_*: general tables go one launch per query
+    bc = rf.distance.levenshtein.BatchComparator
+    cs = [bc(synth.query(n, n)) for n in (10, 64, 30, 100)]
+    got = bc.many_multi(cs, N.OP_DISTANCE, corpus, weights=(2, 1, 2))
+    for j, c in enumerate(cs):
+        assert (got[j] == c.distance_many(corpus, weights=(2, 1, 2))).all()
 
 
 # ---------------------------------------------------------------- fixed-length rows packed on the device
