@@ -162,6 +162,21 @@ int rf_corpus_device(const rf_corpus *c);
 rf_status rf_corpus_pack_u32(const uint32_t *elems, const uint64_t *offsets, size_t n, int device, rf_corpus **out);
 size_t rf_corpus_alphabet_size(const rf_corpus *c, size_t *overflow_symbols);
 
+/* ---- corpus files, corpora larger than HBM (no reference analogue) -----------------------
+ * rf_corpus_save / rf_corpus_load: the packed form (header, length table, tile descriptors, slot -> original
+ * index, alphabet of a u32 corpus, page-aligned payload) written once and mapped back without re-packing.
+ * rf_stream_many_*: out[i] = scorer.<op>_with_args(candidate_i, &args) over a corpus FILE that need not fit in
+ * HBM: the file is scanned in tile ranges of at most `segment_bytes` of payload (0 = 256 MiB) through two device
+ * buffer sets, the read + upload of one segment overlapping the scan of the previous one.  `out` is HOST memory
+ * of n entries (n from the file; the result vector itself does live on the device during the pass).  Values,
+ * None encoding and errors are those of rf_many_u32 / rf_many_f64. */
+rf_status rf_corpus_save(const rf_corpus *c, const char *path);
+rf_status rf_corpus_load(const char *path, int device, rf_corpus **out);
+rf_status rf_stream_many_u32(const rf_comparator *c, const char *path, rf_op op, const rf_args *args, uint32_t *out,
+                             uint64_t segment_bytes, int device);
+rf_status rf_stream_many_f64(const rf_comparator *c, const char *path, rf_op op, const rf_args *args, double *out,
+                             uint64_t segment_bytes, int device);
+
 /* ---- one-vs-many ------------------------------------------------------------------------------
  * out[i] = scorer.<op>_with_args(candidate_i, &args) for every candidate, original order.
  *

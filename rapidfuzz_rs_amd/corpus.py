@@ -106,6 +106,17 @@ class Corpus:
         N.check(N.lib().rf_corpus_pack_u32(data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, device, C.byref(h)))
         return cls(h.value, device)
 
+    def save(self, path: str) -> None:
+        """Write the packed form to `path` (rf_corpus_save); `Corpus.load` maps it back without re-packing and
+        `BatchComparator.stream_many` scans it segment by segment when it does not fit in HBM."""
+        N.check(N.lib().rf_corpus_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path: str, device: int = 0) -> "Corpus":
+        h = C.c_void_p()
+        N.check(N.lib().rf_corpus_load(str(path).encode(), device, C.byref(h)))
+        return cls(h.value, device)
+
     def alphabet_size(self) -> tuple[int, int]:
         """(symbols with an id of their own, symbols sharing the overflow id); (256, 0) for a byte corpus."""
         ov = C.c_size_t()

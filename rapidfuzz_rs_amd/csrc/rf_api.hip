@@ -6,6 +6,7 @@
 // into kernel parameters.  No metric is ever evaluated on the host: a shape without a device kernel is
 // RF_ERR_UNSUPPORTED.  Product code: never includes or links anything from oracle/.
 #include <algorithm>
+#include <cstdio>
 #include <atomic>
 #include <unordered_map>
 #include <unordered_set>
@@ -71,6 +72,8 @@ struct rf_corpus {
     size_t n = 0;
     uint64_t payload_bytes = 0;
     uint64_t device_bytes = 0;
+    uint64_t data_bytes = 0;     // packed tile payloads + the tail pad chunk row
+    bool borrowed = false;       // a segment view of a streamed corpus file: owns none of its device buffers
     uint8_t* d_data = nullptr;
     TileDesc* d_tiles = nullptr;
     uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
@@ -502,6 +505,7 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     RF_HIP_C(hipMalloc(&c->d_data, L.packed.size()));
     RF_HIP_C(hipMemcpy(c->d_data, L.packed.data(), L.packed.size(), hipMemcpyHostToDevice));
     c->device_bytes = L.packed.size();
+    c->data_bytes = L.packed.size();
     std::memcpy(c->sigma, L.sigma, 256);
     RF_HIP_C(hipMalloc(&c->d_sigma, 256));
     RF_HIP_C(hipMemcpy(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice));
@@ -637,6 +641,7 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
     if (data_bytes) RF_HIP_C(launch_pack_rows((const uint8_t*)d_rows, n, (uint32_t)len, stride, c->d_data, c->n_tiles, c->d_sigma, st));
     RF_HIP_C(hipStreamSynchronize(st));  // the input is only borrowed for the duration of the call
     c->device_bytes = data_bytes + kTailPad;
+    c->data_bytes = data_bytes + kTailPad;
     *out = c;
     return RF_OK;
 }
@@ -644,6 +649,10 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
 void rf_corpus_free(rf_corpus* c)
 {
     if (!c) return;
+    if (c->borrowed) {
+        delete c;
+        return;
+    }
     DeviceGuard guard(c->device);
     if (c->d_data) (void)hipFree(c->d_data);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
@@ -867,7 +876,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
             const size_t i_hi = hi >= 0xFFFFFFFFull ? L.size() : std::upper_bound(L.begin(), L.end(), (uint32_t)hi) - L.begin();
             p->tile_begin = i_lo < L.size() ? corpus->length_first_tile[i_lo] : corpus->n_tiles;
             p->tile_end = i_hi < L.size() ? corpus->length_first_tile[i_hi] : corpus->n_tiles;
-            p->prefill_none = p->tile_begin > 0 || p->tile_end < corpus->n_tiles;
+            p->prefill_none = !corpus->borrowed && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
         }
     }
     return RF_OK;
@@ -1217,6 +1226,371 @@ rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t
         return RF_ERR_HIP;
     }
     return RF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// corpus files, and corpora larger than HBM
+// ---------------------------------------------------------------------------------------------------
+// The packed form is position-independent (tile descriptors hold offsets, tiles ascend by length), so a corpus can
+// be written once and mapped back without re-packing, and ANY tile range [t0, t1) is itself a valid corpus: its
+// payload is one contiguous byte range.  rf_stream_many_* uses that to scan a file segment by segment through two
+// device buffers, the upload of segment k+1 overlapping the scan of segment k.
+namespace {
+struct FileHeader {  // little endian, 512 bytes
+    char magic[8];   // "RFCORPUS"
+    uint32_t version, flags;  // flags: 1 = uniform (no descriptors / orig), 2 = u32 elements (alphabet section)
+    uint64_t n;
+    uint32_t n_tiles, max_len, uniform_len, n_lengths;
+    uint64_t payload_bytes, data_bytes;
+    uint64_t off_lengths, off_tiles, off_orig, off_alphabet, off_data;
+    uint32_t n_alphabet, n_overflow;
+    uint8_t sigma[256];
+    uint8_t reserved[512 - 8 - 8 - 8 - 16 - 16 - 40 - 8 - 256];
+};
+static_assert(sizeof(FileHeader) == 512, "header layout");
+constexpr uint32_t kFileVersion = 1, kFlagUniform = 1, kFlagWide = 2;
+
+struct FileCloser {
+    FILE* f;
+    ~FileCloser()
+    {
+        if (f) std::fclose(f);
+    }
+};
+bool write_all(FILE* f, const void* p, size_t n) { return n == 0 || std::fwrite(p, 1, n, f) == n; }
+bool read_at(FILE* f, uint64_t off, void* p, size_t n)
+{
+    if (n == 0) return true;
+    return fseeko(f, (off_t)off, SEEK_SET) == 0 && std::fread(p, 1, n, f) == n;
+}
+rf_status read_header(FILE* f, FileHeader* h)
+{
+    if (!read_at(f, 0, h, sizeof(*h)) || std::memcmp(h->magic, "RFCORPUS", 8) != 0 || h->version != kFileVersion) {
+        set_error("not a corpus file of this version");
+        return RF_ERR_INVALID_ARG;
+    }
+    return RF_OK;
+}
+}  // namespace
+
+rf_status rf_corpus_save(const rf_corpus* c, const char* path)
+{
+    if (!c || !path || c->borrowed) {
+        set_error("rf_corpus_save: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return RF_ERR_NO_DEVICE;
+    FileCloser fc{std::fopen(path, "wb")};
+    if (!fc.f) {
+        set_error(std::string("rf_corpus_save: cannot open ") + path);
+        return RF_ERR_INVALID_ARG;
+    }
+    FileHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, "RFCORPUS", 8);
+    h.version = kFileVersion;
+    h.flags = (c->uniform ? kFlagUniform : 0) | (c->wide ? kFlagWide : 0);
+    h.n = c->n;
+    h.n_tiles = c->n_tiles;
+    h.max_len = c->max_len;
+    h.uniform_len = c->uniform_len;
+    h.n_lengths = (uint32_t)c->lengths.size();
+    h.payload_bytes = c->payload_bytes;
+    h.data_bytes = c->data_bytes;
+    h.n_alphabet = (uint32_t)c->alphabet.size();
+    h.n_overflow = (uint32_t)c->overflow.size();
+    std::memcpy(h.sigma, c->sigma, 256);
+    const size_t n_slots = c->uniform ? 0 : (size_t)c->n_tiles * kWave;
+    uint64_t off = sizeof(h);
+    h.off_lengths = off, off += (uint64_t)h.n_lengths * 8;
+    h.off_tiles = off, off += c->uniform ? 0 : (uint64_t)c->n_tiles * sizeof(TileDesc);
+    h.off_orig = off, off += (uint64_t)n_slots * 4;
+    h.off_alphabet = off, off += (uint64_t)h.n_alphabet * 8 + (uint64_t)h.n_overflow * 4;
+    h.off_data = (off + 4095) / 4096 * 4096;  // page-aligned payload
+    bool ok = write_all(fc.f, &h, sizeof(h));
+    ok = ok && write_all(fc.f, c->lengths.data(), c->lengths.size() * 4) && write_all(fc.f, c->length_first_tile.data(), c->length_first_tile.size() * 4);
+    if (!c->uniform) {
+        std::vector<TileDesc> tiles(c->n_tiles);
+        std::vector<uint32_t> orig(n_slots);
+        RF_HIP(hipMemcpy(tiles.data(), c->d_tiles, tiles.size() * sizeof(TileDesc), hipMemcpyDeviceToHost));
+        RF_HIP(hipMemcpy(orig.data(), c->d_orig, orig.size() * 4, hipMemcpyDeviceToHost));
+        ok = ok && write_all(fc.f, tiles.data(), tiles.size() * sizeof(TileDesc)) && write_all(fc.f, orig.data(), orig.size() * 4);
+    }
+    {
+        std::vector<uint32_t> a;
+        for (const auto& kv : c->alphabet) a.push_back(kv.first), a.push_back(kv.second);
+        for (uint32_t sym : c->overflow) a.push_back(sym);
+        ok = ok && write_all(fc.f, a.data(), a.size() * 4);
+    }
+    std::vector<uint8_t> buf(std::min<uint64_t>(std::max<uint64_t>(c->data_bytes, 1), 64ull << 20));
+    ok = ok && fseeko(fc.f, (off_t)h.off_data, SEEK_SET) == 0;
+    for (uint64_t done = 0; ok && done < c->data_bytes; done += buf.size()) {
+        const size_t m = (size_t)std::min<uint64_t>(buf.size(), c->data_bytes - done);
+        RF_HIP(hipMemcpy(buf.data(), c->d_data + done, m, hipMemcpyDeviceToHost));
+        ok = write_all(fc.f, buf.data(), m);
+    }
+    if (!ok || std::fflush(fc.f) != 0) {
+        set_error(std::string("rf_corpus_save: write failed: ") + path);
+        return RF_ERR_INVALID_ARG;
+    }
+    return RF_OK;
+}
+
+// host-side metadata shared by rf_corpus_load and the stream driver
+static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vector<TileDesc>* tiles, std::vector<uint32_t>* orig)
+{
+    c->n = h.n;
+    c->payload_bytes = h.payload_bytes;
+    c->data_bytes = h.data_bytes;
+    c->n_tiles = h.n_tiles;
+    c->max_len = h.max_len;
+    c->uniform = (h.flags & kFlagUniform) != 0;
+    c->uniform_len = h.uniform_len;
+    c->wide = (h.flags & kFlagWide) != 0;
+    std::memcpy(c->sigma, h.sigma, 256);
+    c->lengths.resize(h.n_lengths);
+    c->length_first_tile.resize(h.n_lengths);
+    bool ok = read_at(f, h.off_lengths, c->lengths.data(), (size_t)h.n_lengths * 4) &&
+              read_at(f, h.off_lengths + (uint64_t)h.n_lengths * 4, c->length_first_tile.data(), (size_t)h.n_lengths * 4);
+    if (!c->uniform) {
+        tiles->resize(h.n_tiles);
+        orig->resize((size_t)h.n_tiles * kWave);
+        ok = ok && read_at(f, h.off_tiles, tiles->data(), tiles->size() * sizeof(TileDesc)) && read_at(f, h.off_orig, orig->data(), orig->size() * 4);
+    }
+    std::vector<uint32_t> a((size_t)h.n_alphabet * 2 + h.n_overflow);
+    ok = ok && read_at(f, h.off_alphabet, a.data(), a.size() * 4);
+    if (!ok) {
+        set_error("corpus file truncated");
+        return RF_ERR_INVALID_ARG;
+    }
+    for (uint32_t i = 0; i < h.n_alphabet; ++i) c->alphabet.emplace(a[2 * i], (uint8_t)a[2 * i + 1]);
+    for (uint32_t i = 0; i < h.n_overflow; ++i) c->overflow.insert(a[(size_t)h.n_alphabet * 2 + i]);
+    return RF_OK;
+}
+
+rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
+{
+    if (!path || !out) {
+        set_error("rf_corpus_load: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    FileCloser fc{std::fopen(path, "rb")};
+    if (!fc.f) {
+        set_error(std::string("rf_corpus_load: cannot open ") + path);
+        return RF_ERR_INVALID_ARG;
+    }
+    FileHeader h;
+    rf_status s = read_header(fc.f, &h);
+    if (s != RF_OK) return s;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("rf_corpus_load: cannot select device");
+        return RF_ERR_NO_DEVICE;
+    }
+    rf_corpus* c = new (std::nothrow) rf_corpus();
+    if (!c) return RF_ERR_OOM;
+    c->uid = g_corpus_uid.fetch_add(1);
+    c->device = device;
+    std::vector<TileDesc> tiles;
+    std::vector<uint32_t> orig;
+    auto fail = [&](rf_status st) {
+        rf_corpus_free(c);
+        return st;
+    };
+    s = load_meta(fc.f, h, c, &tiles, &orig);
+    if (s != RF_OK) return fail(s);
+    RF_HIP_C(hipMalloc(&c->d_data, std::max<uint64_t>(1, c->data_bytes)));
+    std::vector<uint8_t> buf(std::min<uint64_t>(std::max<uint64_t>(c->data_bytes, 1), 64ull << 20));
+    for (uint64_t done = 0; done < c->data_bytes; done += buf.size()) {
+        const size_t m = (size_t)std::min<uint64_t>(buf.size(), c->data_bytes - done);
+        if (!read_at(fc.f, h.off_data + done, buf.data(), m)) {
+            set_error("corpus file truncated");
+            return fail(RF_ERR_INVALID_ARG);
+        }
+        RF_HIP_C(hipMemcpy(c->d_data + done, buf.data(), m, hipMemcpyHostToDevice));
+    }
+    c->device_bytes = c->data_bytes;
+    RF_HIP_C(hipMalloc(&c->d_sigma, 256));
+    RF_HIP_C(hipMemcpy(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice));
+    if (!c->uniform) {
+        RF_HIP_C(hipMalloc(&c->d_tiles, std::max<size_t>(1, tiles.size()) * sizeof(TileDesc)));
+        RF_HIP_C(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        RF_HIP_C(hipMalloc(&c->d_orig, std::max<size_t>(1, orig.size()) * 4));
+        RF_HIP_C(hipMemcpy(c->d_orig, orig.data(), orig.size() * 4, hipMemcpyHostToDevice));
+        c->device_bytes += tiles.size() * sizeof(TileDesc) + orig.size() * 4;
+    }
+    *out = c;
+    return RF_OK;
+}
+
+// One pass of `scorer.<op>` over a corpus FILE that need not fit in HBM.  Segments are tile ranges of at most
+// `segment_bytes` of payload; two device buffer sets alternate, segment k+1 is read and uploaded (copy stream) while
+// segment k is scanned (compute stream).  The result vector (n x 4 or 8 bytes) does live on the device for the pass.
+static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, void* out_host, bool f64_out,
+                             uint64_t segment_bytes, int device)
+{
+    if (!c || !path || !args || !out_host) {
+        set_error("rf_stream_many: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    FileCloser fc{std::fopen(path, "rb")};
+    if (!fc.f) {
+        set_error(std::string("rf_stream_many: cannot open ") + path);
+        return RF_ERR_INVALID_ARG;
+    }
+    FileHeader h;
+    rf_status s = read_header(fc.f, &h);
+    if (s != RF_OK) return s;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("rf_stream_many: cannot select device");
+        return RF_ERR_NO_DEVICE;
+    }
+    rf_corpus meta;  // whole-file metadata (host side only)
+    meta.uid = g_corpus_uid.fetch_add(1);
+    meta.device = device;
+    std::vector<TileDesc> tiles;
+    std::vector<uint32_t> orig;
+    s = load_meta(fc.f, h, &meta, &tiles, &orig);
+    if (s != RF_OK) return s;
+    if (meta.n == 0) return RF_OK;
+    const uint64_t uniform_tb = tile_bytes(meta.uniform_len);
+    auto tile_off = [&](uint32_t t) { return meta.uniform ? (uint64_t)t * uniform_tb : (t < meta.n_tiles ? tiles[t].data_off : meta.data_bytes - kTailPad); };
+    // segment boundaries
+    if (segment_bytes == 0) segment_bytes = 256ull << 20;
+    std::vector<uint32_t> cuts{0};
+    while (cuts.back() < meta.n_tiles) {
+        uint32_t t0 = cuts.back(), t1 = t0 + 1;
+        while (t1 < meta.n_tiles && tile_off(t1 + 1) - tile_off(t0) <= segment_bytes) ++t1;
+        cuts.push_back(t1);
+    }
+    uint64_t max_seg = 0;
+    uint32_t max_tiles = 0;
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        max_seg = std::max(max_seg, tile_off(cuts[k + 1]) - tile_off(cuts[k]));
+        max_tiles = std::max(max_tiles, cuts[k + 1] - cuts[k]);
+    }
+
+    struct Slot {
+        uint8_t *d_data = nullptr, *h_data = nullptr;
+        TileDesc* d_tiles = nullptr;
+        uint32_t* d_orig = nullptr;
+        hipEvent_t uploaded = nullptr, scanned = nullptr;
+        bool used = false;
+    } slot[2];
+    hipStream_t s_copy = nullptr, s_comp = nullptr;
+    uint8_t* d_sigma = nullptr;
+    void* d_out = nullptr;
+    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
+    rf_status status = RF_OK;
+    hipError_t e = hipSuccess;
+    auto hip_ok = [&](hipError_t err) {
+        if (err != hipSuccess && e == hipSuccess) e = err;
+        return err == hipSuccess;
+    };
+    bool ok = hip_ok(hipStreamCreate(&s_copy)) && hip_ok(hipStreamCreate(&s_comp)) && hip_ok(hipMalloc(&d_sigma, 256)) &&
+              hip_ok(hipMemcpy(d_sigma, meta.sigma, 256, hipMemcpyHostToDevice)) && hip_ok(hipMalloc(&d_out, meta.n * elem));
+    // None everywhere first: a cutoff run skips whole tile ranges (plan()), and segment views never pre-fill
+    if (ok) ok = hip_ok(hipMemsetAsync(d_out, 0xFF, meta.n * elem, s_comp));
+    for (int b = 0; ok && b < 2; ++b) {
+        ok = hip_ok(hipMalloc(&slot[b].d_data, max_seg + kTailPad)) && hip_ok(hipHostMalloc((void**)&slot[b].h_data, max_seg + kTailPad, hipHostMallocDefault)) &&
+             hip_ok(hipEventCreateWithFlags(&slot[b].uploaded, hipEventDisableTiming)) && hip_ok(hipEventCreateWithFlags(&slot[b].scanned, hipEventDisableTiming));
+        if (ok && !meta.uniform)
+            ok = hip_ok(hipMalloc(&slot[b].d_tiles, (size_t)max_tiles * sizeof(TileDesc))) && hip_ok(hipMalloc(&slot[b].d_orig, (size_t)max_tiles * kWave * 4));
+    }
+    std::vector<TileDesc> seg_tiles;
+    for (size_t k = 0; ok && status == RF_OK && k + 1 < cuts.size(); ++k) {
+        Slot& sl = slot[k & 1];
+        const uint32_t t0 = cuts[k], t1 = cuts[k + 1];
+        const uint64_t base = tile_off(t0), bytes = tile_off(t1) - base;
+        if (sl.used) ok = hip_ok(hipEventSynchronize(sl.scanned));  // the scan that last read this buffer set is done
+        if (!ok) break;
+        if (!read_at(fc.f, h.off_data + base, sl.h_data, (size_t)bytes)) {
+            set_error("corpus file truncated");
+            status = RF_ERR_INVALID_ARG;
+            break;
+        }
+        std::memset(sl.h_data + bytes, 0, kTailPad);
+        ok = hip_ok(hipMemcpyAsync(sl.d_data, sl.h_data, bytes + kTailPad, hipMemcpyHostToDevice, s_copy));
+        rf_corpus seg;  // a view: owns nothing
+        seg.borrowed = true;
+        seg.uid = meta.uid;  // one lowered comparator serves every segment of a u32 corpus
+        seg.device = device;
+        seg.wide = meta.wide;
+        seg.alphabet = meta.alphabet;
+        seg.overflow = meta.overflow;
+        std::memcpy(seg.sigma, meta.sigma, 256);
+        seg.d_sigma = d_sigma;
+        seg.d_data = sl.d_data;
+        seg.n_tiles = t1 - t0;
+        seg.data_bytes = bytes + kTailPad;
+        void* seg_out = d_out;
+        if (meta.uniform) {
+            seg.uniform = true;
+            seg.uniform_len = meta.uniform_len;
+            seg.max_len = meta.uniform_len;
+            seg.n = (size_t)std::min<uint64_t>((uint64_t)(t1 - t0) * kWave, meta.n - (uint64_t)t0 * kWave);
+            seg.lengths = {meta.uniform_len};
+            seg.length_first_tile = {0};
+            seg_out = static_cast<char*>(d_out) + (size_t)t0 * kWave * elem;  // slot == original index
+        } else {
+            seg.n = meta.n;  // results are scattered through orig[] into the whole output
+            seg_tiles.assign(tiles.begin() + t0, tiles.begin() + t1);
+            for (uint32_t t = 0; t < t1 - t0; ++t) {
+                seg_tiles[t].data_off -= base;
+                seg_tiles[t].slot0 = t * kWave;
+                if (seg.lengths.empty() || seg.lengths.back() != seg_tiles[t].len) {
+                    seg.lengths.push_back(seg_tiles[t].len);
+                    seg.length_first_tile.push_back(t);
+                }
+                seg.max_len = std::max(seg.max_len, seg_tiles[t].len);
+            }
+            seg.d_tiles = sl.d_tiles;
+            seg.d_orig = sl.d_orig;
+            // pageable sources: both copies are staged before the calls return, so seg_tiles may be reused
+            ok = ok && hip_ok(hipMemcpyAsync(sl.d_tiles, seg_tiles.data(), seg_tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, s_copy)) &&
+                 hip_ok(hipMemcpyAsync(sl.d_orig, orig.data() + (size_t)t0 * kWave, (size_t)(t1 - t0) * kWave * 4, hipMemcpyHostToDevice, s_copy));
+        }
+        ok = ok && hip_ok(hipEventRecord(sl.uploaded, s_copy)) && hip_ok(hipStreamWaitEvent(s_comp, sl.uploaded, 0));
+        if (!ok) break;
+        status = run_many(c, &seg, op, args, seg_out, RF_MEM_DEVICE, s_comp, f64_out);
+        if (status != RF_OK) break;
+        ok = hip_ok(hipEventRecord(sl.scanned, s_comp));
+        sl.used = true;
+    }
+    if (ok && status == RF_OK) ok = hip_ok(hipMemcpyAsync(out_host, d_out, meta.n * elem, hipMemcpyDeviceToHost, s_comp)) && hip_ok(hipStreamSynchronize(s_comp));
+    if (s_copy) (void)hipStreamSynchronize(s_copy);
+    if (s_comp) (void)hipStreamSynchronize(s_comp);
+    for (int b = 0; b < 2; ++b) {
+        if (slot[b].d_data) (void)hipFree(slot[b].d_data);
+        if (slot[b].h_data) (void)hipHostFree(slot[b].h_data);
+        if (slot[b].d_tiles) (void)hipFree(slot[b].d_tiles);
+        if (slot[b].d_orig) (void)hipFree(slot[b].d_orig);
+        if (slot[b].uploaded) (void)hipEventDestroy(slot[b].uploaded);
+        if (slot[b].scanned) (void)hipEventDestroy(slot[b].scanned);
+    }
+    if (d_sigma) (void)hipFree(d_sigma);
+    if (d_out) (void)hipFree(d_out);
+    if (s_copy) (void)hipStreamDestroy(s_copy);
+    if (s_comp) (void)hipStreamDestroy(s_comp);
+    if (status != RF_OK) return status;
+    if (!ok) {
+        set_error(std::string("rf_stream_many: ") + hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;
+    }
+    return RF_OK;
+}
+
+rf_status rf_stream_many_u32(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, uint32_t* out, uint64_t segment_bytes,
+                             int device)
+{
+    return stream_many(c, path, op, args, out, false, segment_bytes, device);
+}
+rf_status rf_stream_many_f64(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, double* out, uint64_t segment_bytes,
+                             int device)
+{
+    return stream_many(c, path, op, args, out, true, segment_bytes, device);
 }
 
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t* scores, const uint64_t* indices, const uint32_t* counts,

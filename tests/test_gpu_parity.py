@@ -793,3 +793,52 @@ def test_u32_overflow_class_is_exact_or_refused():
     assert rf.distance.levenshtein.BatchComparator(np.array([104, 233, 108, 108, 111], dtype=np.uint32)).distance_many(bcorp).tolist() == [1, 4, 0]
     with pytest.raises(rf.RfError):
         rf.distance.levenshtein.BatchComparator("hεllo").distance_many(bcorp)
+
+
+# ---------------------------------------------------------------- corpus files and streamed scans (widening row f4)
+@pytest.mark.parametrize("kind", ["ragged", "uniform", "u32"])
+def test_corpus_file_roundtrip_and_streamed_scan(kind, tmp_path):
+    rng = np.random.default_rng(17)
+    if kind == "ragged":
+        data, offsets = synth.ragged_host(30_000, 150, seed=3)
+        cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+        q, q_long = synth.query(40, 4), synth.query(130, 5)
+        for i in range(0, len(cands), 101):
+            b = bytearray(q)
+            b[int(rng.integers(0, len(b)))] = 48
+            cands[i] = bytes(b)
+        corpus = rf.Corpus.from_list(cands)
+    elif kind == "uniform":
+        rows = synth.rows_host(40_000, 64, seed=6)
+        q, q_long = synth.query(64, 7), synth.query(100, 8)
+        synth.plant_near_duplicates(rows, q, 500, seed=1)
+        corpus = rf.Corpus.from_rows(rows)
+    else:
+        alphabet = GREEK + CYRILLIC + list("abc ")
+        cands = _rand_strings(rng, alphabet, 20_000, 80)
+        q, q_long = "".join(rng.choice(alphabet, size=30)), "".join(rng.choice(alphabet, size=90))
+        corpus = rf.Corpus.from_list(cands)
+    path = str(tmp_path / "corpus.rfc")
+    corpus.save(path)
+    n = len(corpus)
+    loaded = rf.Corpus.load(path)
+    assert len(loaded) == n and loaded.payload_bytes == corpus.payload_bytes and loaded.alphabet_size() == corpus.alphabet_size()
+    cases = [("levenshtein", N.OP_DISTANCE, {}), ("levenshtein", N.OP_DISTANCE, {"score_cutoff": 3}), ("levenshtein", N.OP_NORMALIZED_SIMILARITY, {"score_cutoff": 0.7}),
+             ("indel", N.OP_SIMILARITY, {}), ("osa", N.OP_DISTANCE, {}), ("jaro_winkler", N.OP_SIMILARITY, {}), ("levenshtein", N.OP_DISTANCE, {"weights": (1, 2, 3)})]
+    for metric, op, kw in cases:
+        for query in (q, q_long):
+            bc = GPU[metric].BatchComparator(query)
+            ref = bc.many(op, corpus, **kw)
+            assert _equal_rows(bc.many(op, loaded, **kw), ref), (kind, metric, op, kw, "loaded")
+            for seg in (64 << 10, 1 << 20, 0):  # tens of segments, a few, one
+                got = bc.stream_many(op, path, n, segment_bytes=seg, **kw)
+                assert _equal_rows(got, ref), (kind, metric, op, kw, seg)
+    s0, i0 = GPU["levenshtein"].BatchComparator(q).topk(corpus, 5)
+    s1, i1 = GPU["levenshtein"].BatchComparator(q).topk(loaded, 5)
+    assert (s0 == s1).all() and (i0 == i1).all()
+    with pytest.raises(rf.RfError):
+        rf.Corpus.load(str(tmp_path / "missing.rfc"))
+    bad = tmp_path / "bad.rfc"
+    bad.write_bytes(b"not a corpus file" * 100)
+    with pytest.raises(rf.RfError):
+        rf.Corpus.load(str(bad))
