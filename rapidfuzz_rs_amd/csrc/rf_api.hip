@@ -287,12 +287,16 @@ static rf_status comparator_device_pm(const rf_comparator* c, int device, const 
     const size_t stride = pm_stride(c);
     if (stride == c->words) {
         RF_HIP(hipMalloc(&d, c->pm.size() * sizeof(uint64_t)));
-        RF_HIP(hipMemcpy(d, c->pm.data(), c->pm.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        const hipError_t e = hipMemcpy(d, c->pm.data(), c->pm.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) (void)hipFree(d);
+        RF_HIP(e);
     } else {  // long pattern: rows padded with zero words to a whole number of 8-word groups
         std::vector<uint64_t> padded(256 * stride, 0);
         for (size_t ch = 0; ch < 256; ++ch) std::memcpy(&padded[ch * stride], &c->pm[ch * c->words], c->words * sizeof(uint64_t));
         RF_HIP(hipMalloc(&d, padded.size() * sizeof(uint64_t)));
-        RF_HIP(hipMemcpy(d, padded.data(), padded.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        const hipError_t e = hipMemcpy(d, padded.data(), padded.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) (void)hipFree(d);
+        RF_HIP(e);
     }
     c->d_pm[device] = d;
     *d_out = d;
@@ -911,7 +915,9 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus, rf
     p.out = d_out;
     if (p.long_words_pad) {
         const size_t scratch = (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t);
-        RF_HIP(hipMallocAsync((void**)&p.long_scratch, scratch, st));
+        const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
+        if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+        RF_HIP(ea);
     }
     hipError_t e = launch_scan(raw, p, st, nullptr);
     if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
