@@ -9,6 +9,7 @@ The package is a thin host layer over librfgpu.so (C ABI in include/rfgpu.h, han
 csrc/).  There is no CPU fallback: if the extension cannot be loaded, importing symbols that need it raises.
 """
 from . import _native
+from . import _native as N  # op / metric / status constants: rf.N.OP_DISTANCE, ...
 from ._comparator import Args, BatchComparator, WeightTable
 from ._native import RfError, build
 from .corpus import Corpus, host_layout, ragged

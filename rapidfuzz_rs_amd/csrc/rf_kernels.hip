@@ -785,8 +785,10 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
     best.init();
     // offers are filtered by `limit` = min(launch-wide pruning bound as last seen, own list's worst key), a scalar;
     // `bound` is the bound fetch in flight (topk_refresh_bound)
+    // (the first value is waited for once: it is the sampled bound, and without it the first tile of EVERY wavefront
+    // would insert 64 keys and then hit the one bound word with an atomic -- 32768 serialized device-scope atomics)
     uint64_t bound = topk ? __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-    uint64_t limit = ~0ull;
+    uint64_t limit = uniform64(bound);
 
     uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
