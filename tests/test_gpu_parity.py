@@ -842,3 +842,23 @@ def test_corpus_file_roundtrip_and_streamed_scan(kind, tmp_path):
     bad.write_bytes(b"not a corpus file" * 100)
     with pytest.raises(rf.RfError):
         rf.Corpus.load(str(bad))
+
+
+def test_readme_quick_start(tmp_path):
+    from rapidfuzz_rs_amd.distance import jaro_winkler, levenshtein
+
+    corpus = rf.Corpus.from_list(["sitting", "mitten", "kitchen", "κίτρινο"])
+    scorer = levenshtein.BatchComparator("kitten")
+    assert scorer.distance_many(corpus).tolist() == [3, 1, 2, 7]
+    assert scorer.distance_many(corpus, score_cutoff=2).tolist() == [0xFFFFFFFF, 1, 2, 0xFFFFFFFF]
+    assert abs(scorer.normalized_similarity_many(corpus)[1] - (1 - 1 / 6)) < 1e-15
+    s, i = scorer.topk(corpus, k=2)
+    assert list(zip(s.tolist(), i.tolist())) == [(1, 1), (2, 2)]
+    assert scorer.distance("sitting") == 3
+    m = levenshtein.BatchComparator.many_multi([scorer, levenshtein.BatchComparator("mitten")], rf.N.OP_DISTANCE, corpus)
+    assert m.tolist() == [[3, 1, 2, 7], [3, 0, 3, 7]]
+    jw = jaro_winkler.BatchComparator("kitten").similarity_many(corpus, prefix_weight=0.1)
+    assert abs(jw[0] - o.jaro_winkler.similarity("kitten", "sitting")) < 1e-15
+    path = str(tmp_path / "corpus.rfc")
+    corpus.save(path)
+    assert scorer.stream_many(rf.N.OP_DISTANCE, path, n=len(corpus)).tolist() == [3, 1, 2, 7]
