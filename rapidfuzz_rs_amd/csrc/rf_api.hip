@@ -829,7 +829,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
 
     {
-        // finishing coefficients: dist = dS*S + dM*Mx + dR*raw, maximum = mS*S + mM*Mx (rf_kernels.hip "Finishing")
+        // finishing coefficients: dist = dS*S + dM*Mx + dR*raw, maximum = mS*S + mM*Mx (rf_device.hpp "Finishing")
         const int32_t f = (int32_t)p->factor;
         switch (p->finish) {
         case FIN_LEV: p->fin_dS = 0, p->fin_dM = 0, p->fin_dR = f, p->fin_mS = 0, p->fin_mM = f; break;

@@ -1,0 +1,645 @@
+// rf_device.hpp -- device-side building blocks shared by the gfx950 kernels (rf_scan.hip, rf_long.hip, rf_jaro.hip):
+// boolean LUT / shift helpers, the per-lane recurrence states (Levenshtein, OSA, LCS and their 32-bit forms), the
+// finishing arithmetic, the wavefront-local top-k list, and the tile / chunk access helpers.
+// Everything here is __device__ __forceinline__ or a template: the header is included by several translation units.
+//
+//
+// Execution shape: one candidate per wavefront lane, one 64-candidate tile per wavefront
+// at a time, 4 wavefronts (one per SIMD) per workgroup, grid-stride over tiles.  The query's
+// pattern-match table (256 x W u64, src/details/pattern_match_vector.rs:194-321) is staged once per
+// workgroup into LDS; candidate bytes arrive as one coalesced 1 KiB global_load_dwordx4 per wavefront per
+// 16 columns; the bit-vectors of the recurrence (VP/VN, S, P/T flags) never leave VGPRs.
+// Integer/bitwise work only: no MFMA.  3-input boolean terms use v_bitop3_b32 (new on gfx950).
+//
+// Reference algorithms restated here for the device (cited per function):
+//   hyrroe2003 / hyrroe2003_block      src/distance/levenshtein.rs:435-507, :769-1019 (advance_block :838-875)
+//   lcs_unroll                         src/distance/lcs_seq.rs:199-261
+//   flag_similar_characters_word,
+//   count_transpositions_word          src/distance/jaro.rs:147-190, :339-368
+//   MetricUsize / Metricf64 defaults   src/details/distance.rs:154-385
+#pragma once
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "rf_internal.hpp"
+
+namespace rf {
+
+// ---------------------------------------------------------------------------------------------------
+// v_bitop3_b32: arbitrary 3-input boolean function; the truth table is f(0xF0, 0xCC, 0xAA)
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t TA = 0xF0, TB = 0xCC, TC = 0xAA;
+template <uint32_t TT>
+__device__ __forceinline__ uint64_t lut3(uint64_t a, uint64_t b, uint64_t c)
+{
+    uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, TT & 0xFF);
+    uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), TT & 0xFF);
+    return ((uint64_t)hi << 32) | lo;
+}
+constexpr uint32_t T_XOR_OR = (TA ^ TB) | TC;       // (a ^ b) | c
+constexpr uint32_t T_OR_NOR = TA | (~(TB | TC));    // a | ~(b | c)
+constexpr uint32_t T_OR_ANDN = TA | (TB & ~TC);      // a | (b & ~c)
+
+// (x << 1) | carry_in.  Measured on gfx950 (tools/microbench.hip, profiles/microbench_r01.txt): the 64-bit VALU
+// forms v_lshl_add_u64 / v_lshlrev_b64 issue at the same (half) rate as ONE v_alignbit_b32 / v_lshl_or_b32, so a
+// single 64-bit instruction beats the two-instruction 32-bit pair hipcc otherwise builds from split halves.
+// Plain VALU on VGPR pairs: no memory counters, no hazard padding needed (guide 5.7).
+// (hipcc canonicalises x + x + 1 back into shift-or on split halves, hence the asm; it is plain VALU on VGPR
+// pairs: nothing to count, no hazard padding needed -- guide 5.7.)
+template <int CIN>
+__device__ __forceinline__ uint64_t shl1_const(uint64_t x)
+{
+    uint64_t r;
+    if (CIN)
+        asm("v_lshl_add_u64 %0, %1, 1, 1" : "=v"(r) : "v"(x));
+    else
+        asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint64_t shl1_var(uint64_t x, uint32_t cin)
+{
+    uint64_t r;
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r | cin;
+}
+
+// One 16-byte chunk of this lane.  Candidate bytes are read once per launch: the non-temporal hint (`nt`) keeps the
+// stream from displacing the PM / descriptor lines in L2 (A/B measured; compile with -DRF_NO_NT to drop the hint).
+__device__ __forceinline__ uint4 load_chunk(const uint4* src)
+{
+#ifdef RF_NO_NT
+    return *src;
+#else
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Levenshtein: one column of Hyyro's recurrence over W 64-bit words (levenshtein.rs:466-490 for W == 1,
+// advance_block :838-875 for the carries between words).  The running score of :476-477 is NOT tracked:
+// after the last column VP/VN hold the vertical deltas of column len2, so
+//   D[len1][len2] = len2 + popcount(VP & valid) - popcount(VN & valid)        (D[0][len2] = len2)
+// which removes the per-column mask tests from the hot loop.
+// ---------------------------------------------------------------------------------------------------
+template <int W>
+struct LevState {
+    using Word = uint64_t;
+    static constexpr int kWords = W;
+    uint64_t vp[W], vn[W];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            vp[w] = ~0ull;  // levenshtein.rs:454-455
+            vn[w] = 0;
+        }
+    }
+    __device__ __forceinline__ void step(const uint64_t (&pm_row)[W])
+    {
+        uint32_t hp_c = 1, hn_c = 0;  // levenshtein.rs:824-825
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint64_t x = pm_row[w];
+            if (w > 0) x |= hn_c;                            // :847
+            const uint64_t p = vp[w], n = vn[w];
+            const uint64_t sum = (x & p) + p;
+            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);    // (sum ^ vp) | x
+            const uint64_t d0 = e | n;                       // :848
+            const uint64_t hn = e & p;                       // == d0 & vp because vp & vn == 0   (:852)
+            const uint64_t hp = lut3<T_OR_NOR>(n, d0, p);    // vn | ~(d0 | vp)                  (:851)
+            const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_var(hp, hp_c);  // :865-866
+            const uint64_t hns = w == 0 ? shl1_const<0>(hn) : shl1_var(hn, hn_c);
+            if (w + 1 < W) {                                 // :857-858
+                hp_c = (uint32_t)(hp >> 63);
+                hn_c = (uint32_t)(hn >> 63);
+            }
+            vn[w] = hps & d0;                                // :869
+            vp[w] = lut3<T_OR_NOR>(hns, hps, d0);            // hn | ~(d0 | hp)                  (:868)
+        }
+    }
+    // the same column with the horizontal deltas entering word 0 / leaving word W-1 as variables: one 512-row
+    // group of a longer pattern (long_kernel); levenshtein.rs:838-875 with hp_carry / hn_carry crossing groups
+    __device__ __forceinline__ void step_carry(const uint64_t (&pm_row)[W], uint32_t& hp_c, uint32_t& hn_c)
+    {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t x = pm_row[w] | hn_c;
+            const uint64_t p = vp[w], n = vn[w];
+            const uint64_t sum = (x & p) + p;
+            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
+            const uint64_t d0 = e | n;
+            const uint64_t hn = e & p;
+            const uint64_t hp = lut3<T_OR_NOR>(n, d0, p);
+            const uint64_t hps = shl1_var(hp, hp_c);
+            const uint64_t hns = shl1_var(hn, hn_c);
+            hp_c = (uint32_t)(hp >> 63);
+            hn_c = (uint32_t)(hn >> 63);
+            vn[w] = hps & d0;
+            vp[w] = lut3<T_OR_NOR>(hns, hps, d0);
+        }
+    }
+    // popcount contribution of this group's words to D[len1][j]; word w is absolute word (word0 + w)
+    __device__ __forceinline__ int32_t delta_sum(uint32_t len1, uint32_t word0) const
+    {
+        int32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int32_t bits = (int32_t)len1 - 64 * (int32_t)(word0 + w);
+            const uint64_t valid = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1));
+            d += __popcll(vp[w] & valid) - __popcll(vn[w] & valid);
+        }
+        return d;
+    }
+    // Early-out bound under a distance cutoff (the reference applies its cutoff only after the loop,
+    // levenshtein.rs:492-496, so this is value-preserving pruning): adjacent cells of the last row differ by at
+    // most 1, hence D[len1][len2] >= D[len1][j] - (len2 - j).  D[len1][j] comes from the same popcount identity
+    // as result().  True = this lane can no longer end at or below `raw_cutoff`.
+    // A second bound comes from the diagonal through (len1, len2): values never decrease along a diagonal of the
+    // Levenshtein matrix, so D[len1][len2] >= D[j + len1 - len2][j] -- the same popcount identity with a shorter row
+    // mask.  For equal lengths that is the distance between the two j-prefixes, which for unrelated strings grows by
+    // almost 1 per column: nearly every wavefront of a random corpus is past a small cutoff after 8 columns.
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    {
+        const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // <= len1 because j <= len2
+        const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
+        return max(last_row, diag) > (int32_t)raw_cutoff;
+    }
+    // D[len1][len2] from the final column's vertical deltas (any row count <= len1 gives D[rows][len2])
+    __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
+    {
+        int32_t d = (int32_t)len2;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int32_t bits = (int32_t)len1 - 64 * w;  // valid pattern rows in this word
+            uint64_t valid = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1));
+            d += __popcll(vp[w] & valid) - __popcll(vn[w] & valid);
+        }
+        return (uint32_t)d;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// OSA (optimal string alignment, src/distance/osa.rs:60-226): Hyyro's recurrence plus the transposition term
+//   tr = ((~D0_old & PM) << 1 | carry from the word below) & PM_old          (osa.rs:86, :180)
+// OR-ed into D0, which costs two more bit-vectors of state per word (D0 and the previous column's PM).
+// ---------------------------------------------------------------------------------------------------
+template <int W>
+struct OsaState {
+    using Word = uint64_t;
+    static constexpr int kWords = W;
+    uint64_t vp[W], vn[W], d0[W], pm_old[W];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            vp[w] = ~0ull;  // osa.rs:74-77, :125-135
+            vn[w] = 0;
+            d0[w] = 0;
+            pm_old[w] = 0;
+        }
+    }
+    __device__ __forceinline__ void step(const uint64_t (&pm_row)[W])
+    {
+        uint32_t hp_c = 1, hn_c = 0, tr_c = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t pm_j = pm_row[w];
+            const uint64_t t = ~d0[w] & pm_j;                              // candidates for a transposition
+            const uint64_t tr = (w == 0 ? shl1_const<0>(t) : shl1_var(t, tr_c)) & pm_old[w];  // osa.rs:180
+            if (w + 1 < W) tr_c = (uint32_t)(t >> 63);                      // ((~d0_last) & pm_last) >> 63 for the next word
+            uint64_t x = pm_j;
+            if (w > 0) x |= hn_c;                                           // osa.rs:182
+            const uint64_t p = vp[w], n = vn[w];
+            const uint64_t sum = (x & p) + p;
+            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
+            const uint64_t d = e | n | tr;                                  // osa.rs:183
+            const uint64_t hn = d & p;
+            const uint64_t hp = lut3<T_OR_NOR>(n, d, p);
+            const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_var(hp, hp_c);
+            const uint64_t hns = w == 0 ? shl1_const<0>(hn) : shl1_var(hn, hn_c);
+            if (w + 1 < W) {
+                hp_c = (uint32_t)(hp >> 63);
+                hn_c = (uint32_t)(hn >> 63);
+            }
+            vn[w] = hps & d;
+            vp[w] = lut3<T_OR_NOR>(hns, hps, d);
+            d0[w] = d;
+            pm_old[w] = pm_j;
+        }
+    }
+    // the vertical-delta identity and the last-row bound hold for the OSA matrix as well (unit steps)
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    {
+        return (int32_t)result(len1, j) - (int32_t)(len2 - j) > (int32_t)raw_cutoff;
+    }
+    __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
+    {
+        int32_t d = (int32_t)len2;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int32_t bits = (int32_t)len1 - 64 * w;
+            const uint64_t valid = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1));
+            d += __popcll(vp[w] & valid) - __popcll(vn[w] & valid);
+        }
+        return (uint32_t)d;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// LCS: Hyyro's bit-parallel LCS length (lcs_seq.rs:222-252): S' = (S + (S & M)) | (S - (S & M)) with the
+// add's carry chained across words; similarity = sum popcount(~S).
+// ---------------------------------------------------------------------------------------------------
+template <int W>
+struct LcsState {
+    using Word = uint64_t;
+    static constexpr int kWords = W;
+    uint64_t s[W];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int w = 0; w < W; ++w) s[w] = ~0ull;  // lcs_seq.rs:215
+    }
+    __device__ __forceinline__ void step(const uint64_t (&pm_row)[W])
+    {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t sw = s[w];
+            const uint64_t u = sw & pm_row[w];
+            uint64_t x = sw + u;  // carrying_add, src/details/intrinsics.rs:22-26
+            uint64_t c = x < sw;
+            if (w > 0) {
+                const uint64_t x2 = x + carry;
+                c |= (uint64_t)(x2 < x);
+                x = x2;
+            }
+            carry = c;
+            // lcs_seq.rs:230 `x | (s - u)`: u is a subset of s, so the subtraction never borrows and
+            // s - u == s & ~u -- one v_bitop3 per half instead of a carry-chained 64-bit subtract
+            s[w] = lut3<T_OR_ANDN>(x, sw, u);
+        }
+    }
+    // one group of a longer pattern: the adder carry enters word 0 and leaves word W-1 (lcs_seq.rs:313-318)
+    __device__ __forceinline__ void step_carry(const uint64_t (&pm_row)[W], uint32_t& carry_io)
+    {
+        uint64_t carry = carry_io;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t sw = s[w];
+            const uint64_t u = sw & pm_row[w];
+            uint64_t x = sw + u;
+            uint64_t c = x < sw;
+            const uint64_t x2 = x + carry;
+            c |= (uint64_t)(x2 < x);
+            x = x2;
+            carry = c;
+            s[w] = lut3<T_OR_ANDN>(x, sw, u);
+        }
+        carry_io = (uint32_t)carry;
+    }
+    static constexpr bool kCanPrune = false;
+    __device__ __forceinline__ bool hopeless(uint32_t, uint32_t, uint32_t, uint32_t) const { return false; }
+    __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const
+    {
+        uint32_t sim = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) sim += __popcll(~s[w]);  // lcs_seq.rs:254-257
+        return sim;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// 32-bit specialisations for queries of at most 32 symbols (BASELINE.json configs[0] shape, most real-world
+// names/titles): the same recurrences on ONE VGPR per bit-vector -- 10 instead of 18 VALU instructions per column
+// for Levenshtein -- reading the low half of each PM entry from a 1 KiB LDS table.
+// ---------------------------------------------------------------------------------------------------
+template <uint32_t TT>
+__device__ __forceinline__ uint32_t lut3w(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT & 0xFF);
+}
+
+struct Lev32State {
+    using Word = uint32_t;
+    static constexpr int kWords = 1;
+    uint32_t vp, vn;
+    __device__ __forceinline__ void init()
+    {
+        vp = ~0u;
+        vn = 0;
+    }
+    __device__ __forceinline__ void step(const uint32_t (&pm_row)[1])
+    {
+        const uint32_t x = pm_row[0];
+        const uint32_t sum = (x & vp) + vp;
+        const uint32_t e = lut3w<T_XOR_OR>(sum, vp, x);
+        const uint32_t d0 = e | vn;
+        const uint32_t hn = e & vp;
+        const uint32_t hp = lut3w<T_OR_NOR>(vn, d0, vp);
+        const uint32_t hps = (hp << 1) | 1u;
+        const uint32_t hns = hn << 1;
+        vn = hps & d0;
+        vp = lut3w<T_OR_NOR>(hns, hps, d0);
+    }
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    {
+        const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // the diagonal bound, see LevState::hopeless
+        const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
+        return max(last_row, diag) > (int32_t)raw_cutoff;
+    }
+    __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
+    {
+        const uint32_t valid = len1 >= 32 ? ~0u : ((1u << len1) - 1);
+        return (uint32_t)((int32_t)len2 + __popc(vp & valid) - __popc(vn & valid));
+    }
+};
+
+struct Lcs32State {
+    using Word = uint32_t;
+    static constexpr int kWords = 1;
+    uint32_t s;
+    __device__ __forceinline__ void init() { s = ~0u; }
+    __device__ __forceinline__ void step(const uint32_t (&pm_row)[1])
+    {
+        const uint32_t u = s & pm_row[0];
+        s = lut3w<T_OR_ANDN>(s + u, s, u);  // (s + u) | (s - u) with s - u == s & ~u
+    }
+    static constexpr bool kCanPrune = false;
+    __device__ __forceinline__ bool hopeless(uint32_t, uint32_t, uint32_t, uint32_t) const { return false; }
+    __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const { return __popc(~s); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// finishing arithmetic: raw primitive -> the value `<op>_with_args` returns (or None)
+// ---------------------------------------------------------------------------------------------------
+// norm_sim_to_norm_dist, src/details/common.rs:4-7
+__device__ __forceinline__ double norm_sim_to_norm_dist(double c) { return fmin(1.0 - c + 0.00001, 1.0); }
+
+// Finishing.  For every (metric, weights) this path serves, distance and maximum are affine in
+//   S = len1 + len2,  Mx = max(len1, len2)  and the raw recurrence result (Levenshtein distance or LCS length):
+//     uniform Levenshtein (f,f,f)      dist = f*raw            maximum = f*Mx   (levenshtein.rs:263-277, :1308-1316)
+//     lcs_seq                          dist = Mx - raw         maximum = Mx     (details/distance.rs:157-179)
+//     indel                            dist = S - 2*raw        maximum = S      (indel.rs:365-367)
+//     Levenshtein (f,f,>=2f)           dist = f*(S - 2*raw)    maximum = f*S    (levenshtein.rs:1321-1327)
+// so the host folds metric, weights and op into a few coefficients (rf_api.hip plan()) and the kernels do one
+// multiply-add per candidate with tile-uniform (scalar) S and Mx -- no per-tile branching on the metric.
+// All arithmetic is mod 2^32 like the reference's usize arithmetic is mod 2^64.
+struct TileFin {
+    uint32_t v0;       // value at raw == 0: fin_vS * S + fin_vM * Mx
+    uint32_t d0, max;  // distance at raw == 0 and the maximum (normalized ops only)
+};
+__device__ __forceinline__ TileFin tile_fin(const ScanParams& p, uint32_t len1, uint32_t len2)
+{
+    const uint32_t S = len1 + len2, Mx = max(len1, len2);
+    TileFin f;
+    f.v0 = (uint32_t)p.fin_vS * S + (uint32_t)p.fin_vM * Mx;
+    f.d0 = (uint32_t)p.fin_dS * S + (uint32_t)p.fin_dM * Mx;
+    f.max = (uint32_t)p.fin_mS * S + (uint32_t)p.fin_mM * Mx;
+    return f;
+}
+// Which value the op yields and whether `score()` (src/common.rs:43-45 / :83-85) keeps it.  All kernels on
+// this path are exact, so the CPU-side cutoff plumbing (details/distance.rs:157-274) reduces to
+// "compute the value, then compare with the user's cutoff" -- see DESIGN.md "cutoff equivalence".
+// distance keeps v <= cutoff, similarity keeps v >= cutoff: one compare after xor-ing both sides with fin_flip.
+__device__ __forceinline__ uint32_t usize_value(const ScanParams& p, const TileFin& f, uint32_t raw, bool* keep)
+{
+    const uint32_t v = f.v0 + (uint32_t)p.fin_vR * raw;
+    *keep = (v ^ p.fin_flip) <= p.fin_cflip;
+    return v;
+}
+__device__ __forceinline__ uint32_t usize_value(const ScanParams& p, uint32_t raw, uint32_t len2, bool* keep, uint32_t len1)
+{
+    return usize_value(p, tile_fin(p, len1, len2), raw, keep);
+}
+
+// one result from a tile's finishing terms; `out` is the launch's (or, in the multi-query kernel, the query's) row
+__device__ __forceinline__ void emit_fin(const ScanParams& p, const TileFin& f, uint32_t raw, uint32_t idx, void* out)
+{
+    if (!p.out_f64) {
+        bool keep;
+        const uint32_t v = usize_value(p, f, raw, &keep);
+        reinterpret_cast<uint32_t*>(out)[idx] = keep ? v : RF_NONE_U32;
+    } else {
+        const uint32_t dist = f.d0 + (uint32_t)p.fin_dR * raw;
+        // details/distance.rs:246-250: dist / maximum (0.0 when maximum == 0)
+        const double nd = f.max == 0 ? 0.0 : (double)dist / (double)f.max;
+        double v;
+        bool keep;
+        if (p.op == RF_OP_NORMALIZED_DISTANCE) {
+            v = nd;
+            keep = !p.has_cutoff || v <= p.cutoff_f64;
+        } else {  // details/distance.rs:273: 1.0 - norm_dist
+            v = 1.0 - nd;
+            keep = !p.has_cutoff || v >= p.cutoff_f64;
+        }
+        reinterpret_cast<double*>(out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
+    }
+}
+__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx, void* out, uint32_t len1)
+{
+    emit_fin(p, tile_fin(p, len1, len2), raw, idx, out);
+}
+__device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx)
+{
+    emit_usize(p, raw, len2, idx, p.out, p.len1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wavefront-local top-k (k <= 64): lane l holds the l-th smallest 64-bit key, ~0 = empty.  A key is
+// (score << 32 | local index) for "smaller is better" and (~score << 32 | local index) for similarities, so
+// the order is exactly (score, index) and keys are unique.  Everything stays in two VGPRs per lane.
+// ---------------------------------------------------------------------------------------------------
+struct WaveTopK {
+    uint64_t key;
+    __device__ __forceinline__ void init() { key = ~0ull; }
+    __device__ __forceinline__ uint64_t worst(uint32_t k) const
+    {
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)key, k - 1), hi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), k - 1);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    // x is wavefront-uniform
+    __device__ __forceinline__ void insert(uint64_t x, uint32_t lane)
+    {
+        const uint32_t pos = __popcll(__ballot(key < x));  // sorted ascending: the smaller keys are a lane prefix
+        const uint32_t up_lo = __shfl_up((uint32_t)key, 1), up_hi = __shfl_up((uint32_t)(key >> 32), 1);
+        const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
+        key = lane > pos ? up : (lane == pos ? x : key);
+    }
+    // Offer one key per lane (valid lanes only).  `limit` is wavefront-uniform: min(this list's worst key, any upper
+    // bound on the launch's k-th best key) -- keys at or above it can never be in the answer.  The common case (no
+    // lane below the limit) is one compare and one scalar branch; returns true when the list changed.
+    __device__ __forceinline__ bool offer(uint64_t mine, bool valid, uint32_t k, uint32_t lane, uint64_t limit)
+    {
+        uint64_t m = __ballot(valid && mine < limit);
+        if (m == 0) return false;
+        bool changed = false;
+        while (m) {  // rare: a handful per wavefront over a whole launch once the bound is tight
+            const uint32_t l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mine, l), hi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), l);
+            const uint64_t x = ((uint64_t)hi << 32) | lo;
+            if (x < worst(k)) {
+                insert(x, lane);
+                changed = true;
+            }
+        }
+        return changed;
+    }
+};
+
+// A workgroup's merged list leaves the kernel through ONE launch-wide candidate buffer: only keys at or below the
+// pruning bound can still be in the answer (the bound is some full list's worst key, so the true k-th best is <= it),
+// and those are appended behind an atomic counter.  On a corpus in no particular order a few dozen keys survive per
+// launch, so the final selection (topk_final_kernel) is one small workgroup instead of staged reductions over
+// grid x k keys.  Worst case (scores improving along the corpus) everything is appended: capacity is grid x k.
+__device__ __forceinline__ void topk_publish(const ScanParams& p, const WaveTopK& best, uint32_t lane)
+{
+    const uint64_t bound = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool keep = lane < p.topk_k && best.key != ~0ull && best.key <= bound;
+    const uint64_t m = __ballot(keep);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(p.topk_count, (uint32_t)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (keep) p.topk_cand[base + __popcll(m & ((1ull << lane) - 1))] = best.key;
+}
+
+// end of a scan kernel in top-k mode: the 4 wavefront lists of the workgroup meet in LDS, wavefront 0 merges them
+// (the lists are sorted, so a list is abandoned at its first key that cannot enter) and publishes the survivors
+__device__ __forceinline__ void topk_block_publish(const ScanParams& p, WaveTopK& best, uint64_t (*lds_topk)[kWave], uint32_t wave, uint32_t lane)
+{
+    lds_topk[wave][lane] = best.key;
+    __syncthreads();
+    if (wave != 0) return;
+    for (uint32_t w = 1; w < kWavesPerBlock; ++w)
+        for (uint32_t j = 0; j < p.topk_k; ++j) {
+            const uint64_t x = lds_topk[w][j];  // wavefront-uniform address: a broadcast read
+            if (x >= best.worst(p.topk_k)) break;
+            best.insert(x, lane);
+        }
+    topk_publish(p, best, lane);
+}
+
+// Launch-wide pruning bound: once ANY wavefront holds k keys, its worst key bounds the global k-th best from above
+// (and topk_core() seeds it with the k-th best of a sample before the scan starts).  A wavefront whose list just
+// changed publishes its worst key with a 64-bit atomic min.
+__device__ __forceinline__ void topk_list_changed(const ScanParams& p, const WaveTopK& best, uint32_t lane, uint64_t& limit)
+{
+    const uint64_t w = best.worst(p.topk_k);
+    if (w < limit) {  // limit <= the last bound this wavefront saw: only then can the global bound improve
+        if (lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)w);
+        limit = w;
+    }
+}
+// `bound_inflight` is the raw result of a load issued at the end of the previous tile: it is folded into the
+// (scalar) limit here, one tile later, and the next fetch is issued -- stale by a tile (merely conservative), never
+// waited for.
+__device__ __forceinline__ void topk_refresh_bound(const ScanParams& p, uint64_t& bound_inflight, uint64_t& limit)
+{
+    const uint64_t b = uniform64(bound_inflight);
+    limit = b < limit ? b : limit;
+    bound_inflight = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the scan kernel
+// ---------------------------------------------------------------------------------------------------
+// PM row of one symbol: W consecutive words in LDS (ds_read_b32 / ds_read_b64 / ds_read_b128)
+template <class Word, int W>
+__device__ __forceinline__ void load_pm(Word (&dst)[W], const Word* lds_pm, uint32_t ch)
+{
+    const Word* row = lds_pm + ch * W;
+#pragma unroll
+    for (int w = 0; w < W; ++w) dst[w] = row[w];
+}
+
+// 16 columns in groups of kGroup symbols.  The LDS reads of group g+1 are issued BEFORE the recurrence of group g
+// (pinned with sched_barrier, otherwise the scheduler sinks them back next to their first use), so their latency
+// -- including the 2-4 way bank conflicts of 64 random slots -- hides behind the VALU work of the current group.
+template <class State, int J0 = 0, int J1 = kChunk>
+__device__ __forceinline__ void process_chunk_full(State& st, const typename State::Word* lds_pm, const uint4& c)
+{
+    using Word = typename State::Word;
+    constexpr int W = State::kWords;
+    constexpr int kGroup = W == 1 ? 4 : (W == 2 ? 2 : 1);
+    constexpr int kGroups = (J1 - J0) / kGroup;
+    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    Word cur[kGroup][W], nxt[kGroup][W];
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) load_pm<Word, W>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        if (g + 1 < kGroups) {
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                const int n = J0 + (g + 1) * kGroup + j;
+                load_pm<Word, W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) st.step(cur[j]);
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+#pragma unroll
+            for (int w = 0; w < W; ++w) cur[j][w] = nxt[j][w];
+    }
+}
+
+template <class State>
+__device__ __forceinline__ void process_chunk_tail(State& st, const typename State::Word* lds_pm, uint4 c, uint32_t rem)
+{
+    using Word = typename State::Word;
+    constexpr int W = State::kWords;
+    for (uint32_t j = 0; j < rem; ++j) {  // rem is wavefront-uniform (tile length)
+        Word x[W];
+        load_pm<Word, W>(x, lds_pm, c.x & 0xFFu);
+        st.step(x);
+        c.x = __builtin_amdgcn_alignbit(c.y, c.x, 8);
+        c.y = __builtin_amdgcn_alignbit(c.z, c.y, 8);
+        c.z = __builtin_amdgcn_alignbit(c.w, c.z, 8);
+        c.w >>= 8;
+    }
+}
+
+struct TileView {
+    const uint4* src;  // wavefront-uniform base of the tile payload
+    uint32_t len, slot0;
+};
+template <bool kUniform>
+__device__ __forceinline__ TileView load_tile(const ScanParams& p, uint32_t t)
+{
+    TileView v;
+    if (!kUniform) {
+        // t is wavefront-uniform and the descriptors are read-only for the whole launch: read them through
+        // the constant address space so they become scalar s_load_dwordx4 (no VGPRs, no vmcnt traffic)
+        typedef const __attribute__((address_space(4))) uint32_t* cptr;
+        cptr td = (cptr)(uintptr_t)(p.tiles + t);
+        const uint32_t off_lo = td[0], off_hi = td[1];
+        v.len = td[2];
+        v.slot0 = td[3];
+        v.src = reinterpret_cast<const uint4*>(p.data + (((uint64_t)off_hi << 32) | off_lo));
+    } else {  // single-length corpus: tile t is at t * tile_bytes, no descriptor traffic at all
+        v.len = p.uniform_len;
+        v.slot0 = t * kWave;
+        v.src = reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes);
+    }
+    return v;
+}
+
+
+}  // namespace rf

@@ -1,5 +1,5 @@
 // rf_internal.hpp -- shared between the host side of the C ABI (rf_api.hip) and the gfx950 kernels
-// (rf_kernels.hip).  Product code: never includes or links anything from oracle/.
+// (rf_scan.hip, rf_long.hip, rf_jaro.hip, rf_pack.hip; device helpers in rf_device.hpp).  Product code: never includes or links anything from oracle/.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -73,7 +73,7 @@ struct ScanParams {
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
     double cutoff_f64;
     double prefix_weight;
-    // finishing coefficients (see "Finishing" in rf_kernels.hip): value = vS*S + vM*Mx + vR*raw, dist / maximum likewise
+    // finishing coefficients (see "Finishing" in rf_device.hpp): value = vS*S + vM*Mx + vR*raw, dist / maximum likewise
     int32_t fin_vS, fin_vM, fin_vR, fin_dS, fin_dM, fin_dR, fin_mS, fin_mM;
     uint32_t fin_flip, fin_cflip;
     // many queries x one corpus (scan_multi_kernel): Q single-word tables, out is [Q][n]
@@ -97,8 +97,11 @@ struct ScanParams {
     uint32_t* topk_count;  // entries appended to topk_cand so far
 };
 
-// kernels (rf_kernels.hip)
+// kernel launchers (rf_scan.hip, rf_long.hip, rf_jaro.hip, rf_pack.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
+hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid);
+hipError_t launch_wf(const ScanParams& p, hipStream_t stream);
+hipError_t launch_jaro(const ScanParams& p, hipStream_t stream);
 hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipStream_t stream);
 hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t count_imm, uint32_t k, uint64_t* out, uint64_t* bound_ptr,
                              bool bound_from_result, hipStream_t stream);

@@ -1,0 +1,486 @@
+// rf_jaro.hip -- Jaro / Jaro-Winkler: flagging and transposition passes (jaro.rs:147-190, :192-420, :339-368), the
+// f64 epilogue replaying jaro.rs:516-598 / jaro_winkler.rs:103-141 / details/distance.rs:277-385 bit for bit.
+#include "rf_device.hpp"
+
+namespace rf {
+
+// ---------------------------------------------------------------------------------------------------
+// Jaro / Jaro-Winkler, single-word path (jaro.rs:516-598 with len1, len2 <= 64 after the window truncation
+// of :550-565).  Per lane: P_flag / T_flag in two VGPR pairs; the candidate's <= 64 bytes stay in 16 VGPRs for
+// the second (transposition) pass.  f64 epilogue in the reference's operation order, -ffp-contract=off.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t blsi64(uint64_t v) { return v & (0 - v); }  // intrinsics.rs:35-37
+__device__ __forceinline__ uint64_t mask_lsb64(uint32_t n) { return n < 64 ? (1ull << n) - 1 : ~0ull; }  // :28-34
+
+struct JaroRaw {
+    uint32_t common, transpositions, prefix;
+    bool eq11;  // the two single characters are equal (only meaningful for 1 x 1)
+};
+
+// jaro.rs:106-119
+__device__ __forceinline__ double jaro_calculate_similarity(uint32_t p_len, uint32_t t_len, uint32_t common, uint32_t transposition)
+{
+    transposition /= 2;
+    double sim = 0.0;
+    sim += (double)common / (double)p_len;
+    sim += (double)common / (double)t_len;
+    sim += ((double)common - (double)transposition) / (double)common;
+    return sim / 3.0;
+}
+// jaro.rs:122-131
+__device__ __forceinline__ bool jaro_length_filter(uint32_t p_len, uint32_t t_len, double cutoff)
+{
+    if (t_len == 0 || p_len == 0) return false;
+    const double min_len = (double)min(p_len, t_len);
+    double sim = min_len / (double)p_len + min_len / (double)t_len + 1.0;
+    sim /= 3.0;
+    return sim >= cutoff;
+}
+// jaro.rs:134-145
+__device__ __forceinline__ bool jaro_common_char_filter(uint32_t p_len, uint32_t t_len, uint32_t common, double cutoff)
+{
+    if (common == 0) return false;
+    double sim = 0.0;
+    sim += (double)common / (double)p_len;
+    sim += (double)common / (double)t_len;
+    sim += 1.0;
+    sim /= 3.0;
+    return sim >= cutoff;
+}
+// jaro::similarity_with_pm (jaro.rs:516-598) given the flag counts; every early `return 0.0` of the reference
+// is a select here because the flags were computed unconditionally.
+__device__ __forceinline__ double jaro_similarity(uint32_t len1, uint32_t len2, const JaroRaw& r, double cutoff)
+{
+    if (cutoff > 1.0) return 0.0;                              // :533-535
+    if (len1 == 0 && len2 == 0) return 1.0;                     // :537-539
+    if (!jaro_length_filter(len1, len2, cutoff)) return 0.0;    // :542-544
+    if (len1 == 1 && len2 == 1) return r.eq11 ? 1.0 : 0.0;      // :546-548
+    if (!jaro_common_char_filter(len1, len2, r.common, cutoff)) return 0.0;  // :579-581
+    return jaro_calculate_similarity(len1, len2, r.common, r.transpositions);
+}
+// jaro_winkler::similarity_with_pm (jaro_winkler.rs:103-141)
+__device__ __forceinline__ double jw_similarity(uint32_t len1, uint32_t len2, const JaroRaw& r, double prefix_weight, double cutoff)
+{
+    double jaro_cutoff = cutoff;
+    if (jaro_cutoff > 0.7) {  // :125-133
+        const double prefix_sim = (double)r.prefix * prefix_weight;
+        jaro_cutoff = prefix_sim >= 1.0 ? 0.7 : fmax(0.7, (prefix_sim - jaro_cutoff) / (prefix_sim - 1.0));
+    }
+    double sim = jaro_similarity(len1, len2, r, jaro_cutoff);
+    if (sim > 0.7) sim += (double)r.prefix * prefix_weight * (1.0 - sim);  // :136-138
+    return sim;
+}
+
+// Metricf64 (details/distance.rs:277-385) with maximum == 1.0, then score() (common.rs:43-45 / :83-85)
+__device__ __forceinline__ double f64_metric_value(const ScanParams& p, uint32_t len2, const JaroRaw& r, bool* keep)
+{
+    const bool has = p.has_cutoff != 0;
+    const double c = p.cutoff_f64;
+    auto sim_with = [&](bool has_c, double cc) {  // _similarity: score_cutoff.unwrap_or(0.0)
+        const double cut = has_c ? cc : 0.0;
+        return p.finish == FIN_JW ? jw_similarity(p.len1, len2, r, p.prefix_weight, cut) : jaro_similarity(p.len1, len2, r, cut);
+    };
+    auto dist_with = [&](bool has_c, double cc) {  // _distance, :280-302
+        const double cs = has_c ? (1.0 >= cc ? 1.0 - cc : 0.0) : 0.0;
+        return 1.0 - sim_with(has_c, cs);
+    };
+    auto ndist_with = [&](bool has_c, double cc) {  // _normalized_distance, :336-361 (maximum = 1.0)
+        const double d = dist_with(has_c, 1.0 * cc);
+        return d / 1.0;
+    };
+    double v;
+    switch (p.op) {
+    case RF_OP_SIMILARITY:
+        v = sim_with(has, c);
+        *keep = !has || v >= c;
+        break;
+    case RF_OP_DISTANCE:
+        v = dist_with(has, c);
+        *keep = !has || v <= c;
+        break;
+    case RF_OP_NORMALIZED_DISTANCE:
+        v = ndist_with(has, c);
+        *keep = !has || v <= c;
+        break;
+    default:  // _normalized_similarity, :363-384
+        v = 1.0 - ndist_with(has, has ? norm_sim_to_norm_dist(c) : 0.0);
+        *keep = !has || v >= c;
+        break;
+    }
+    return v;
+}
+
+constexpr uint32_t T_AND_ANDN = TA & TB & ~TC;        // a & b & ~c
+constexpr uint32_t T_OR_ANDN_B = TA | (TB & ~TC);     // a | (b & ~c)
+constexpr uint32_t T_ANDN_AND = TA & ~TB & TC;        // a & ~b & c
+constexpr uint32_t T_OR_AND = TA | (TB & TC);         // a | (b & c)
+constexpr uint32_t T_AND_ORN = TA & (TB | ~TC);       // a & (b | ~c)
+
+// Per-lane state of the single-word Jaro passes.  Pass 1 = flag_similar_characters_word (jaro.rs:147-190); pass 2 =
+// count_transpositions_word (:339-368) restated without data-dependent control flow:
+//   * blsi(x) = x & ~(x - 1): one 64-bit decrement + one v_bitop3 per half instead of a carry-chained negate;
+//   * every flagged text character consumes the lowest remaining pattern flag (P &= P - 1); it is a MATCH when the
+//     PM word of the text character has that bit -- matched bits are OR-ed into `hits`, so
+//     transpositions = common - popcount(hits) with no per-column compare or count.
+struct JaroWordState {
+    uint64_t p_flag, t_flag, hits;
+    uint32_t tacc;  // T bits of the 32 columns currently being processed
+};
+
+// The sliding window mask (jaro.rs:168,176,185) is wavefront-uniform; the asm pins its recurrence
+// bm = (bm << 1) | (j < bound) to the scalar ALU as two 32-bit halves (hipcc otherwise migrates it to VGPRs next to
+// the per-lane flags).  SCC-based: the low bit is free after the shift, so adding the compare's carry sets it.
+__device__ __forceinline__ void window_next(uint32_t& lo, uint32_t& hi, uint32_t j, uint32_t bound)
+{
+    uint32_t tmp;
+    asm("s_lshr_b32 %2, %0, 31\n\t"
+        "s_lshl_b32 %1, %1, 1\n\t"
+        "s_or_b32 %1, %1, %2\n\t"
+        "s_lshl_b32 %0, %0, 1\n\t"
+        "s_cmp_lt_u32 %3, %4\n\t"
+        "s_addc_u32 %0, %0, 0"
+        : "+s"(lo), "+s"(hi), "=&s"(tmp)
+        : "s"(j), "s"(bound)
+        : "scc");
+}
+
+template <bool kFull>
+__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4& c, uint32_t j0, uint32_t cols,
+                                                uint32_t bound, uint32_t& bm_lo_io, uint32_t& bm_hi_io)
+{
+    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    uint32_t bm_lo = uniform(bm_lo_io), bm_hi = uniform(bm_hi_io);  // (re)pin to SGPRs for the asm recurrence
+    bound = uniform(bound);
+    uint64_t cur[4], nxt[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cur[b] = lds_pm0[(dw[0] >> (8 * b)) & 0xFFu];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) nxt[b] = lds_pm0[(dw[g + 1] >> (8 * b)) & 0xFFu];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t j = j0 + g * 4 + b;
+            if (kFull || (uint32_t)(g * 4 + b) < cols) {
+                const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], ((uint64_t)bm_hi << 32) | bm_lo, st.p_flag);  // PM & window & ~P
+                const uint64_t below = pm_j - 1;
+                st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
+                st.tacc |= pm_j != 0 ? (1u << (j & 31)) : 0u;           // jaro.rs:174 / :183
+                window_next(bm_lo, bm_hi, uniform(j), bound);  // :176 / :185
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cur[b] = nxt[b];
+    }
+    bm_lo_io = bm_lo;
+    bm_hi_io = bm_hi;
+}
+
+template <bool kFull>
+__device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4& c, uint32_t j0, uint32_t cols)
+{
+    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    const uint32_t thalf = (j0 & 32) ? (uint32_t)(st.t_flag >> 32) : (uint32_t)st.t_flag;
+    uint64_t cur[4], nxt[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cur[b] = lds_pm0[(dw[0] >> (8 * b)) & 0xFFu];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) nxt[b] = lds_pm0[(dw[g + 1] >> (8 * b)) & 0xFFu];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t j = j0 + g * 4 + b;
+            if (kFull || (uint32_t)(g * 4 + b) < cols) {
+                const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)thalf, j & 31, 1);  // all ones iff T bit j
+                const uint64_t f = ((uint64_t)f32 << 32) | f32;
+                const uint64_t below = st.p_flag - 1;
+                const uint64_t m = lut3<T_ANDN_AND>(st.p_flag, below, f);  // lowest remaining pattern flag, if flagged
+                st.hits = lut3<T_OR_AND>(st.hits, cur[b], m);              // match iff PM[text char] has that bit
+                st.p_flag = lut3<T_AND_ORN>(st.p_flag, below, f);          // consume it, if flagged
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cur[b] = nxt[b];
+    }
+}
+
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
+{
+    const uint32_t W = p.words;  // PM row stride; only block 0 is read on this path (jaro.rs:172, pm.get(0, ..))
+    extern __shared__ uint64_t lds_pm0[];  // 256 entries: block 0 of every row
+    for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm0[p.sigma[i]] = p.pm[(size_t)i * W];  // renamed rows
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t q4 = p.query_head;  // first four query bytes, little endian (Winkler prefix)
+
+    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2_orig = tv.len, len1_orig = p.len1;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+
+        // window truncation, jaro.rs:550-565 (wavefront-uniform)
+        uint32_t len1 = len1_orig, len2 = len2_orig, bound = 0;
+        if (len2 > len1) {
+            bound = len2 / 2 - 1;
+            if (len2 > len1 + bound) len2 = len1 + bound;
+        } else if (len1 >= 2) {
+            bound = len1 / 2 - 1;
+            if (len1 > len2 + bound) len1 = len2 + bound;
+        }
+        // (len1 <= 1 with len2 <= len1 never reaches the flags: the length filter / 1x1 rule decide)
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;  // <= 4 on this path
+
+        // the candidate (<= 64 bytes = 4 chunk rows) is streamed twice: HBM once, the second pass hits L1/L2
+        uint4 cur = tv.src[lane];
+        JaroRaw r;
+        r.eq11 = (cur.x & 0xFFu) == (q4 & 0xFFu);
+        {  // Winkler prefix: equal leading bytes among the first min(4, len1_orig, len2_orig), jaro_winkler.rs:118-123
+            const uint32_t lim = min(4u, min(len1_orig, len2_orig));
+            const uint32_t diff = cur.x ^ q4;
+            const uint32_t first_diff = diff ? (uint32_t)(__ffs(diff) - 1) / 8 : 4u;
+            r.prefix = min(first_diff, lim);
+        }
+
+        JaroWordState st;
+        st.p_flag = st.t_flag = st.hits = 0;
+        st.tacc = 0;
+        const uint64_t bm0 = mask_lsb64(bound + 1);
+        uint32_t bm_lo = uniform((uint32_t)bm0), bm_hi = uniform((uint32_t)(bm0 >> 32));
+        for (uint32_t k = 0; k < nch; ++k) {  // pass 1
+            const uint4 nxt = tv.src[(size_t)(k + 1 < nch ? k + 1 : 0) * kWave + lane];  // next chunk, then chunk 0 again
+            const uint32_t cols = len2 - k * kChunk;
+            if (cols >= (uint32_t)kChunk)
+                jaro_flag_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk, bound, bm_lo, bm_hi);
+            else
+                jaro_flag_chunk<false>(st, lds_pm0, cur, k * kChunk, cols, bound, bm_lo, bm_hi);
+            if ((k & 1) || k + 1 == nch) {  // 32 columns (or the tail) done: bank their T bits
+                st.t_flag |= (uint64_t)st.tacc << ((k & 2) ? 32 : 0);
+                st.tacc = 0;
+            }
+            cur = nxt;
+        }
+        r.common = __popcll(st.p_flag);
+        for (uint32_t k = 0; k < nch; ++k) {  // pass 2
+            uint4 nxt = cur;
+            if (k + 1 < nch) nxt = tv.src[(size_t)(k + 1) * kWave + lane];
+            const uint32_t cols = len2 - k * kChunk;
+            if (cols >= (uint32_t)kChunk)
+                jaro_transpose_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk);
+            else
+                jaro_transpose_chunk<false>(st, lds_pm0, cur, k * kChunk, cols);
+            cur = nxt;
+        }
+        r.transpositions = r.common - __popcll(st.hits);
+
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            bool keep;
+            const double v = f64_metric_value(p, len2_orig, r, &keep);
+            reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Jaro / Jaro-Winkler, multi-word path (jaro.rs:192-337 flag_similar_characters_block / _step, :370-420
+// count_transpositions_block) for strings of up to 512 symbols after the window truncation.  P_flag / T_flag are
+// 8 + 8 VGPR pairs per lane; the sliding search window (SearchBoundMask, jaro.rs:99-104) is wavefront-uniform;
+// the candidate is streamed twice (flags, then transpositions).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kJaroWords = 8;
+
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const ScanParams p)
+{
+    const uint32_t W = p.words;  // PM row stride (<= 8 here)
+    extern __shared__ uint64_t lds_pmw[];  // 256 x W (+ one pad row: an exhausted window may index word W)
+    for (uint32_t i = threadIdx.x; i < 256 * W + W + 1; i += kWave * kWavesPerBlock) {
+        if (i < 256 * W)
+            lds_pmw[(uint32_t)p.sigma[i / W] * W + i % W] = p.pm[i];  // renamed rows
+        else
+            lds_pmw[i] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t q4 = p.query_head;
+
+    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2_orig = tv.len, len1_orig = p.len1;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+
+        uint32_t len1 = len1_orig, len2 = len2_orig, bound = 0;  // jaro.rs:550-565
+        if (len2 > len1) {
+            bound = len2 / 2 - 1;
+            if (len2 > len1 + bound) len2 = len1 + bound;
+        } else if (len1 >= 2) {
+            bound = len1 / 2 - 1;
+            if (len1 > len2 + bound) len1 = len2 + bound;
+        }
+
+        const uint4 head = len2_orig ? tv.src[lane] : make_uint4(0, 0, 0, 0);
+        JaroRaw r;
+        r.eq11 = (head.x & 0xFFu) == (q4 & 0xFFu);
+        {
+            const uint32_t lim = min(4u, min(len1_orig, len2_orig));
+            const uint32_t diff = head.x ^ q4;
+            const uint32_t first_diff = diff ? (uint32_t)(__ffs(diff) - 1) / 8 : 4u;
+            r.prefix = min(first_diff, lim);
+        }
+
+        uint64_t P[kJaroWords], T[kJaroWords];
+#pragma unroll
+        for (int w = 0; w < kJaroWords; ++w) P[w] = T[w] = 0;
+
+        // ---- pass 1: flag_similar_characters_block (jaro.rs:286-337); window state is wavefront-uniform
+        const uint32_t start_range = min(bound + 1, len1);
+        uint32_t win_words = 1 + start_range / 64, empty_words = 0;
+        uint64_t last_mask = (1ull << (start_range % 64)) - 1, first_mask = ~0ull;
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        uint64_t tcur = 0;
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 data = tv.src[(size_t)c * kWave + lane];
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            for (uint32_t b = 0; b < cols; ++b) {
+                const uint32_t j = c * kChunk + b;
+                const uint32_t ch = data.x & 0xFFu;
+                const uint32_t last_word = empty_words + win_words - 1;
+                bool found = false;
+#pragma unroll
+                for (int w = 0; w < kJaroWords; ++w) {  // flag_similar_characters_step, jaro.rs:192-284
+                    if ((uint32_t)w >= empty_words && (uint32_t)w <= last_word) {
+                        uint64_t mask = ~0ull;
+                        if ((uint32_t)w == empty_words) mask &= first_mask;
+                        if ((uint32_t)w == last_word) mask &= last_mask;
+                        const uint64_t pm_j = lds_pmw[ch * W + w] & mask & ~P[w];
+                        const bool hit = !found && pm_j != 0;
+                        P[w] |= hit ? blsi64(pm_j) : 0ull;
+                        found = found || hit;
+                    }
+                }
+                tcur |= (uint64_t)found << (j & 63);
+                if ((j & 63) == 63 || j + 1 == len2) {
+#pragma unroll
+                    for (int k = 0; k < kJaroWords; ++k)
+                        if ((uint32_t)k == (j >> 6)) T[k] = tcur;
+                    tcur = 0;
+                }
+                if (j + bound + 1 < len1) {  // jaro.rs:318-324
+                    last_mask = (last_mask << 1) | 1;
+                    if (j + bound + 2 < len1 && last_mask == ~0ull) {
+                        last_mask = 0;
+                        win_words += 1;
+                    }
+                }
+                if (j >= bound) {  // jaro.rs:326-333
+                    first_mask <<= 1;
+                    if (first_mask == 0) {
+                        first_mask = ~0ull;
+                        win_words -= 1;
+                        empty_words += 1;
+                    }
+                }
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
+            }
+        }
+        uint32_t common = 0;
+#pragma unroll
+        for (int w = 0; w < kJaroWords; ++w) common += __popcll(P[w]);
+        r.common = common;
+
+        // ---- pass 2: count_transpositions_block (jaro.rs:370-420): every flagged text character, in text order,
+        //      consumes the lowest remaining pattern flag
+        uint32_t transpositions = 0;
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 data = tv.src[(size_t)c * kWave + lane];
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            uint64_t tw = 0;
+#pragma unroll
+            for (int k = 0; k < kJaroWords; ++k)
+                if ((uint32_t)k == ((c * kChunk) >> 6)) tw = T[k];
+            for (uint32_t b = 0; b < cols; ++b) {
+                const uint32_t j = c * kChunk + b;
+                const uint32_t ch = data.x & 0xFFu;
+                const bool flagged = (tw >> (j & 63)) & 1;
+                int sel = -1;
+                uint64_t pw = 0;
+#pragma unroll
+                for (int w = kJaroWords - 1; w >= 0; --w)
+                    if (P[w] != 0) {
+                        sel = w;
+                        pw = P[w];
+                    }
+                const uint64_t m = blsi64(pw);
+                const uint64_t pmv = lds_pmw[ch * W + (sel < 0 ? 0 : sel)];
+                transpositions += (flagged && (pmv & m) == 0) ? 1u : 0u;
+#pragma unroll
+                for (int w = 0; w < kJaroWords; ++w)
+                    if (flagged && w == sel) P[w] ^= m;
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
+            }
+        }
+        r.transpositions = transpositions;
+
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            bool keep;
+            const double v = f64_metric_value(p, len2_orig, r, &keep);
+            reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
+        }
+    }
+}
+
+
+hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
+{
+    // tiles [tile_begin, jaro_split) take the single-word path, [jaro_split, tile_end) the multi-word path
+    // (tiles ascend by length, and the single-word condition holds for a length prefix)
+    const dim3 b(kWave * kWavesPerBlock);
+    ScanParams q = p;
+    q.tile_begin = 0;
+    q.tile_end = p.jaro_split;
+    if (q.tile_end > q.tile_begin) {
+        const dim3 g(scan_grid(q.tile_end - q.tile_begin));
+        if (p.tiles)
+            hipLaunchKernelGGL(jaro_word_kernel<false>, g, b, 256 * sizeof(uint64_t), stream, q);
+        else
+            hipLaunchKernelGGL(jaro_word_kernel<true>, g, b, 256 * sizeof(uint64_t), stream, q);
+    }
+    q.tile_begin = p.jaro_split;
+    q.tile_end = p.n_tiles;
+    if (q.tile_end > q.tile_begin) {
+        const dim3 g(scan_grid(q.tile_end - q.tile_begin));
+        const size_t lds = ((size_t)256 * p.words + p.words + 1) * sizeof(uint64_t);
+        if (p.tiles)
+            hipLaunchKernelGGL(jaro_block_kernel<false>, g, b, lds, stream, q);
+        else
+            hipLaunchKernelGGL(jaro_block_kernel<true>, g, b, lds, stream, q);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rf

@@ -1,0 +1,197 @@
+// rf_long.hip -- the two completeness paths of the Levenshtein family that do not fit the register-resident scan:
+//   wf_kernel     generalized weight tables: Wagner-Fischer rows in LDS (levenshtein.rs:212-259)
+//   long_kernel   patterns beyond 512 symbols: 8 words per sweep, carries parked in HBM (levenshtein.rs:769-1019,
+//                 lcs_seq.rs:267-341)
+#include "rf_device.hpp"
+
+namespace rf {
+
+// ---------------------------------------------------------------------------------------------------
+// Generalized weights (levenshtein.rs:212-259 generalized_wagner_fischer, reached from _distance_with_pm :1328-1330
+// for every weight table that is neither (f,f,f) nor (f,f,>=2f)): the O(len1 * len2) row DP, one candidate per lane.
+//   new[i+1] = s1[i] == ch2 ? old[i] : min(new[i] + del, old[i] + sub, old[i+1] + ins)
+// The row (len1 + 1 u32 per lane) lives in LDS as [i][lane] -- conflict-free, 256 B per row entry and wavefront -- so
+// the workgroup has as many wavefronts as fit (plan(): wf_waves).  The query, renamed like the corpus, is rebuilt
+// from the PM table into LDS and read back 4 symbols at a time with a wavefront-uniform (broadcast) address.
+// A completeness path (~10 VALU + 2.25 LDS operations per cell); the reference's common-affix stripping and minimum-
+// edits test (:286-309) change nothing in the value and are not replayed.
+// ---------------------------------------------------------------------------------------------------
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void wf_kernel(const ScanParams p)
+{
+    extern __shared__ uint32_t lds_wf[];
+    const uint32_t len1 = p.len1;
+    const uint32_t qwords = (len1 + 3) / 4 + 1;  // query bytes, 4 per word, one word of slack
+    uint8_t* lds_q = reinterpret_cast<uint8_t*>(lds_wf);
+    for (uint32_t i = threadIdx.x; i < qwords; i += blockDim.x) lds_wf[i] = 0;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {  // PM row c, bit i  <=>  s1[i] == c
+        const uint8_t stored = p.sigma[c];
+        for (uint32_t w = 0; w * 64 < len1; ++w) {
+            uint64_t bits = p.pm[(size_t)c * p.words + w];
+            while (bits) {
+                lds_q[64 * w + (__ffsll((unsigned long long)bits) - 1)] = stored;
+                bits &= bits - 1;
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t waves = blockDim.x / kWave;
+    uint32_t* row = lds_wf + qwords + (size_t)wave * (len1 + 1) * kWave + lane;  // row[i * kWave] = cache[i] of this lane
+    const uint32_t ins = p.w_ins, del = p.w_del, sub = p.w_sub;
+
+    for (uint32_t t = blockIdx.x * waves + wave; t < p.n_tiles; t += gridDim.x * waves) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2 = tv.len;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+        for (uint32_t i = 0; i <= len1; ++i) row[i * kWave] = i * del;  // :219-221
+        uint32_t top = 0;  // cache[0] = j * ins, the same in every lane
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint4 data = load_chunk(tv.src + (size_t)c * kWave + lane);
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            for (uint32_t j = 0; j < cols; ++j) {
+                const uint32_t word = j < 4 ? data.x : (j < 8 ? data.y : (j < 12 ? data.z : data.w));
+                const uint32_t ch2 = (word >> (8 * (j & 3))) & 0xFFu;
+                uint32_t diag = top;  // old[i]
+                top += ins;           // :226
+                uint32_t left = top;  // new[i]
+                for (uint32_t i = 0; i < len1; i += 4) {
+                    const uint32_t q4 = lds_wf[i / 4];  // wavefront-uniform address: one broadcast read for 4 symbols
+                    const uint32_t lim = min(4u, len1 - i);
+                    for (uint32_t k = 0; k < lim; ++k) {
+                        const uint32_t up = row[(i + k + 1) * kWave];  // old[i+1]
+                        const uint32_t x = ((q4 >> (8 * k)) & 0xFFu) == ch2 ? diag : min(min(left + del, diag + sub), up + ins);
+                        row[(i + k + 1) * kWave] = x;
+                        diag = up;
+                        left = x;
+                    }
+                }
+            }
+        }
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            const uint32_t dist = len1 ? row[len1 * kWave] : top;
+            // _maximum, levenshtein.rs:263-277 (not affine in the lengths for a general table)
+            const uint32_t max_dist = len1 * del + len2 * ins;
+            const uint32_t alt = len1 >= len2 ? len2 * sub + (len1 - len2) * del : len1 * sub + (len2 - len1) * ins;
+            TileFin f;
+            f.max = min(max_dist, alt);
+            f.d0 = 0;
+            f.v0 = p.fin_flip ? f.max : 0;  // similarity = maximum - distance (fin_vR = -1), distance = raw (fin_vR = +1)
+            emit_fin(p, f, dist, idx, p.out);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Patterns longer than 512 symbols (the reference's hyrroe2003_block / lcs_blockwise territory,
+// levenshtein.rs:769-1019, lcs_seq.rs:267-341): the pattern is cut into groups of 8 words (512 rows).  A
+// wavefront sweeps the candidate once per group with that group's 16 bit-vectors in registers; the horizontal
+// deltas crossing the group boundary (2 bits per column and lane for Levenshtein, the adder carry for LCS) wait in
+// a chunk-interleaved HBM scratch strip between sweeps.  PM words come straight from global memory (the table of a
+// long pattern does not fit LDS; it is L2-resident).  Throughput path for completeness, not for the roofline.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLongGroup = 8;
+
+template <bool kLcs, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanParams p)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;  // global wavefront id: owns one scratch strip
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t words_pad = p.long_words_pad;
+    const uint32_t groups = words_pad / kLongGroup;
+    uint32_t* strip = p.long_scratch + (size_t)gw * p.long_chunks_max * kWave;
+    __shared__ uint8_t lds_unrename[256];  // stored symbol -> original symbol (the PM table stays in global memory)
+    lds_unrename[p.sigma[threadIdx.x & 255]] = (uint8_t)(threadIdx.x & 255);
+    __syncthreads();
+
+    for (uint32_t t = gw; t < p.n_tiles; t += stride) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2 = tv.len;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        int32_t acc = 0;
+
+        for (uint32_t g = 0; g < groups; ++g) {
+            LevState<kLongGroup> lev;
+            LcsState<kLongGroup> lcs;
+            if (kLcs)
+                lcs.init();
+            else
+                lev.init();
+            for (uint32_t c = 0; c < nch; ++c) {
+                uint4 data = tv.src[(size_t)c * kWave + lane];
+                // carries entering word 0 of this group for the 16 columns of the chunk:
+                // bits 0..15 = hp (or the LCS adder carry), bits 16..31 = hn
+                uint32_t cin = g == 0 ? (kLcs ? 0u : 0x0000FFFFu) : strip[(size_t)c * kWave + lane];
+                uint32_t cout = 0;
+                const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+                for (uint32_t j = 0; j < cols; ++j) {
+                    const uint32_t ch = lds_unrename[data.x & 0xFFu];
+                    const uint64_t* row = p.pm + (size_t)ch * words_pad + (size_t)g * kLongGroup;
+                    uint64_t x[kLongGroup];
+#pragma unroll
+                    for (int w = 0; w < kLongGroup; ++w) x[w] = row[w];
+                    if (kLcs) {
+                        uint32_t carry = (cin >> j) & 1u;
+                        lcs.step_carry(x, carry);
+                        cout |= carry << j;
+                    } else {
+                        uint32_t hp_c = (cin >> j) & 1u, hn_c = (cin >> (16 + j)) & 1u;
+                        lev.step_carry(x, hp_c, hn_c);
+                        cout |= (hp_c << j) | (hn_c << (16 + j));
+                    }
+                    data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                    data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                    data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                    data.w >>= 8;
+                }
+                if (g + 1 < groups) strip[(size_t)c * kWave + lane] = cout;
+            }
+            acc += kLcs ? (int32_t)lcs.result(0, 0) : lev.delta_sum(p.len1, g * kLongGroup);
+        }
+        const uint32_t raw = kLcs ? (uint32_t)acc : (uint32_t)((int32_t)len2 + acc);
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) emit_usize(p, raw, len2, idx);
+    }
+}
+
+hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid)
+{
+    const dim3 g(grid), b(kWave * kWavesPerBlock);
+    if (raw == RAW_LCS) {
+        if (p.tiles)
+            hipLaunchKernelGGL((long_kernel<true, false>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((long_kernel<true, true>), g, b, 0, stream, p);
+    } else {
+        if (p.tiles)
+            hipLaunchKernelGGL((long_kernel<false, false>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((long_kernel<false, true>), g, b, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_wf(const ScanParams& p, hipStream_t stream)
+{
+    const size_t lds = ((size_t)(p.len1 + 3) / 4 + 1) * 4 + (size_t)p.wf_waves * (p.len1 + 1) * kWave * 4;
+    const dim3 g(std::max(1, scan_grid(p.n_tiles))), b(kWave * p.wf_waves);
+    auto k = p.tiles ? wf_kernel<false> : wf_kernel<true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, g, b, lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace rf

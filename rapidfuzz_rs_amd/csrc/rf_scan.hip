@@ -1,0 +1,502 @@
+// rf_scan.hip -- the one-vs-many scan kernels over the packed corpus and their dispatch:
+//   scan_body / scan_kernel*      multi-word states and every cutoff run (early-out)
+//   stream_body / stream_kernel   the lean no-cutoff loop of the single-word states (the headline path)
+//   scan_multi_kernel             Q queries per pass over the corpus
+//   topk_final_kernel             selection of the k best candidate keys
+// Device helpers live in rf_device.hpp; the long-pattern, generalized-weights and Jaro kernels in rf_long.hip / rf_jaro.hip.
+#include "rf_device.hpp"
+
+namespace rf {
+
+template <class State, bool kUniform>
+__device__ __forceinline__ void scan_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
+{
+    constexpr int W = State::kWords;
+    // stage the PM table; the 32-bit states keep the low half of each (single-word) entry
+    // (the corpus stores renamed symbols sigma(c), see rf_corpus: row c of the table goes to row sigma(c))
+    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock)
+        lds_pm[(uint32_t)p.sigma[i / W] * W + i % W] = (typename State::Word)p.pm[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock * p.tile_step;
+    const bool topk = p.topk_k != 0;
+    const bool early = State::kCanPrune && p.early != 0;
+    WaveTopK best;
+    best.init();
+    // offers are filtered by `limit` = min(launch-wide pruning bound as last seen, own list's worst key), a scalar.
+    // This body is at its VGPR budget (cutoff state + early-out), so the bound is re-read only every 8th tile and
+    // consumed at once instead of riding in registers across a tile like stream_body's.
+    uint64_t limit = ~0ull;
+    uint32_t tiles_done = 0;
+
+    // Each wavefront walks its tiles as one continuous stream of 16-column chunks.  The load of the NEXT
+    // chunk (the next 16 columns of this tile, or the first 16 of the wavefront's next tile) is always issued
+    // before the current chunk is processed, so exactly one 1 KiB request per wavefront is in flight and the
+    // wait before each chunk is a counted vmcnt(1), never a drain.
+    // With a cutoff (`early`) the bet is the opposite: after 16 columns nearly every wavefront of a random
+    // corpus is past the cutoff, so the prefetch goes to the NEXT TILE and a surviving wavefront fetches its
+    // own next chunk on demand -- a dead tile costs 16 of its 64+ bytes per candidate in HBM traffic.
+    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
+    if (t < p.tile_end) {
+        TileView cur_tile = load_tile<kUniform>(p, t);
+        uint4 cur = load_chunk(cur_tile.src + lane);  // the packed buffer carries one chunk of tail padding: always readable
+
+        while (true) {
+            const uint32_t t_next = t + stride;
+            const bool has_next = t_next < p.tile_end;
+            const TileView next_tile = load_tile<kUniform>(p, has_next ? t_next : t);
+
+            const uint32_t len2 = cur_tile.len;
+            const uint32_t slot = cur_tile.slot0 + lane;
+            uint32_t idx = slot;
+            if (!kUniform) idx = p.orig[slot];  // issued early; consumed after the columns
+
+            State st;
+            st.init();
+            const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+            bool dead = false;
+            uint4 ahead = make_uint4(0, 0, 0, 0);
+            if (early || nch == 0) ahead = load_chunk(next_tile.src + lane);
+            for (uint32_t c = 0; c < nch; ++c) {
+                uint4 nxt = ahead;
+                if (!early) {
+                    const uint4* nsrc = (c + 1 < nch) ? cur_tile.src + (size_t)(c + 1) * kWave : next_tile.src;
+                    nxt = load_chunk(nsrc + lane);
+                }
+                const uint32_t cols = len2 - c * kChunk;
+                if (cols >= kChunk) {
+                    if (early && c == 0) {
+                        // first chance to stop: after 8 columns a random candidate is already ~6 edits off
+                        process_chunk_full<State, 0, kChunk / 2>(st, lds_pm, cur);
+                        if (__ballot(!st.hopeless(p.len1, kChunk / 2, len2, p.raw_cutoff)) == 0) {
+                            dead = true;
+                            break;
+                        }
+                        process_chunk_full<State, kChunk / 2, kChunk>(st, lds_pm, cur);
+                    } else {
+                        process_chunk_full<State>(st, lds_pm, cur);
+                    }
+                } else {
+                    process_chunk_tail<State>(st, lds_pm, cur, cols);
+                }
+                if (early) {
+                    const uint32_t j = min(len2, (c + 1) * kChunk);
+                    if (__ballot(!st.hopeless(p.len1, j, len2, p.raw_cutoff)) == 0) {
+                        dead = true;  // the whole wavefront is beyond the cutoff: stop reading this tile
+                        break;
+                    }
+                    if (c + 1 < nch) nxt = load_chunk(cur_tile.src + (size_t)(c + 1) * kWave + lane);
+                }
+                cur = nxt;
+            }
+            if (dead || nch == 0) cur = ahead;
+
+            const bool valid = kUniform ? slot < p.n : idx != kPad;
+            const uint32_t raw = st.result(p.len1, len2);
+            if (p.out && valid) {
+                if (dead)
+                    reinterpret_cast<uint32_t*>(p.out)[idx] = RF_NONE_U32;  // early only runs for u32 distance output
+                else
+                    emit_usize(p, raw, len2, idx);
+            }
+            if (topk && !dead) {
+                bool keep;
+                const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
+                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
+                if ((tiles_done++ & 7u) == 0) {
+                    const uint64_t b = uniform64(__hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    limit = b < limit ? b : limit;
+                }
+                if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
+            }
+
+            if (!has_next) break;
+            t = t_next;
+            cur_tile = next_tile;
+        }
+    }
+
+    if (topk) topk_block_publish(p, best, lds_topk, wave, lane);
+}
+
+// Two entry points over the same body: the single-word kernels are pinned to 8 wavefronts per SIMD (otherwise the
+// scalar state of the tile loop pushes them to 96 SGPRs = 7 resident workgroups per CU); W >= 2 keeps the
+// compiler's own register budget (forcing 8 would spill VGPRs).
+template <class State, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanParams p)
+{
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    scan_body<State, kUniform>(p, lds_pm, lds_topk);
+}
+template <class State, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan_kernel_occ8(const ScanParams p)
+{
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    scan_body<State, kUniform>(p, lds_pm, lds_topk);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The no-cutoff scan of the single-word states as a stream: every wavefront sees its tiles as ONE sequence of
+// 16-column chunks and keeps kDepth chunk loads (1 KiB each) in flight ahead of the chunk it is working on, across
+// tile boundaries.  A FETCH cursor runs kDepth chunks ahead of the PROCESS cursor; both walk (tile, chunk) pairs, and
+// a zero-length tile counts as one (unused) chunk so the two stay in lock-step.  Past the wavefront's last tile the
+// fetch cursor parks on its last valid chunk (a cached re-read).  Compared with scan_body (which also carries the
+// cutoff early-out) this loop has about half the scalar/branch instructions per chunk.
+// ---------------------------------------------------------------------------------------------------
+template <class State, bool kUniform, int kDepth>
+__device__ __forceinline__ void stream_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
+{
+    constexpr int W = State::kWords;
+    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock)
+        lds_pm[(uint32_t)p.sigma[i / W] * W + i % W] = (typename State::Word)p.pm[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock * p.tile_step;
+    const bool topk = p.topk_k != 0;
+    WaveTopK best;
+    best.init();
+    // offers are filtered by `limit` = min(launch-wide pruning bound as last seen, own list's worst key), a scalar;
+    // `bound` is the bound fetch in flight (topk_refresh_bound)
+    // (the first value is waited for once: it is the sampled bound, and without it the first tile of EVERY wavefront
+    // would insert 64 keys and then hit the one bound word with an atomic -- 32768 serialized device-scope atomics)
+    uint64_t bound = topk ? __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+    uint64_t limit = uniform64(bound);
+
+    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
+    if (t < p.tile_end) {
+        // fetch cursor
+        uint32_t ft = t, fc = 0;
+        TileView fv = load_tile<kUniform>(p, ft);
+        uint32_t fn = max(1u, (fv.len + kChunk - 1) / kChunk);
+        auto fetch = [&]() {
+            const uint4 v = load_chunk(fv.src + (size_t)fc * kWave + lane);
+            if (++fc == fn) {
+                const uint32_t nt = ft + stride;
+                if (nt < p.tile_end) {
+                    ft = nt;
+                    fv = load_tile<kUniform>(p, ft);
+                    fn = max(1u, (fv.len + kChunk - 1) / kChunk);
+                    fc = 0;
+                } else {
+                    fc = fn - 1;
+                }
+            }
+            return v;
+        };
+        // Ring of kDepth + 1 chunk buffers with STATIC names: the loop below is unrolled over the ring phase, so
+        // no buffer is ever copied (a copy of a register with a load in flight would force a wait for that load)
+        // and the compiler's vmcnt bookkeeping stays exact.
+        uint4 buf[kDepth + 1];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) buf[d] = fetch();
+
+        // process cursor
+        TileView cur_tile = load_tile<kUniform>(p, t);
+        uint32_t c = 0;
+        uint32_t idx = cur_tile.slot0 + lane;
+        if (!kUniform) idx = p.orig[idx];
+        State st;
+        st.init();
+        bool done = false;
+        auto step = [&](const uint4& use, uint4& refill) {
+            refill = fetch();
+            const uint32_t len2 = cur_tile.len;
+            const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+            const uint32_t cols = len2 - c * kChunk;
+            if (cols >= kChunk)
+                process_chunk_full<State>(st, lds_pm, use);
+            else if (nch)
+                process_chunk_tail<State>(st, lds_pm, use, cols);
+            if (++c < max(1u, nch)) return;
+
+            // tile finished
+            const uint32_t slot = cur_tile.slot0 + lane;
+            const bool valid = kUniform ? slot < p.n : idx != kPad;
+            const uint32_t raw = st.result(p.len1, len2);
+            if (p.out && valid) emit_usize(p, raw, len2, idx);
+            if (topk) {
+                bool keep;
+                const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
+                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
+                if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
+                topk_refresh_bound(p, bound, limit);
+            }
+            t += stride;
+            if (t >= p.tile_end) {
+                done = true;
+                return;
+            }
+            cur_tile = load_tile<kUniform>(p, t);
+            c = 0;
+            idx = cur_tile.slot0 + lane;
+            if (!kUniform) idx = p.orig[idx];
+            st.init();
+        };
+        while (!done) {
+#pragma unroll
+            for (int ph = 0; ph <= kDepth; ++ph) {
+                step(buf[ph], buf[(ph + kDepth) % (kDepth + 1)]);
+                if (done) break;
+            }
+        }
+    }
+
+    if (topk) topk_block_publish(p, best, lds_topk, wave, lane);
+}
+template <class State, bool kUniform, int kDepth>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void stream_kernel_occ8(const ScanParams p)
+{
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    stream_body<State, kUniform, kDepth>(p, lds_pm, lds_topk);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Many queries x one corpus: Q pattern-match tables sit side by side in LDS and every 16-column
+// chunk a wavefront loads from HBM is run through Q recurrences before the next chunk is touched, so the candidate
+// bytes are read ONCE for Q queries -- the arithmetic intensity per HBM byte rises Q-fold, which is what the
+// HBM-bound kernels (LCS / Indel / the 32-bit forms) need.  out is [Q][n], original candidate order per query.
+// ---------------------------------------------------------------------------------------------------
+template <class State, int Q, bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_multi_kernel(const ScanParams p)
+{
+    using Word = typename State::Word;
+    static_assert(State::kWords == 1, "multi-query kernels are single-word");
+    __shared__ Word lds_pm[Q][256];
+    for (int i = threadIdx.x; i < Q * 256; i += kWave * kWavesPerBlock) {
+        const int q = i / 256, c = i % 256;
+        lds_pm[q][p.sigma[c]] = (Word)p.multi_pm[q][c];  // single-word tables: row stride 1
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
+    if (t >= p.n_tiles) return;
+    TileView cur_tile = load_tile<kUniform>(p, t);
+    uint4 cur = load_chunk(cur_tile.src + lane);
+
+    while (true) {
+        const uint32_t t_next = t + stride;
+        const bool has_next = t_next < p.n_tiles;
+        const TileView next_tile = load_tile<kUniform>(p, has_next ? t_next : t);
+        const uint32_t len2 = cur_tile.len;
+        const uint32_t slot = cur_tile.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+
+        State st[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) st[q].init();
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint4* nsrc = (c + 1 < nch) ? cur_tile.src + (size_t)(c + 1) * kWave : next_tile.src;
+            const uint4 nxt = load_chunk(nsrc + lane);
+            const uint32_t cols = len2 - c * kChunk;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (cols >= kChunk)
+                    process_chunk_full<State>(st[q], lds_pm[q], cur);
+                else
+                    process_chunk_tail<State>(st[q], lds_pm[q], cur, cols);
+            }
+            cur = nxt;
+        }
+        if (nch == 0) cur = load_chunk(next_tile.src + lane);
+
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t raw = st[q].result(p.multi_len1[q], len2);
+                char* out = reinterpret_cast<char*>(p.out) + (size_t)q * p.n * (p.out_f64 ? sizeof(double) : sizeof(uint32_t));
+                emit_usize(p, raw, len2, idx, out, p.multi_len1[q]);
+            }
+        }
+        if (!has_next) break;
+        t = t_next;
+        cur_tile = next_tile;
+    }
+}
+
+template <class State, int Q>
+static hipError_t launch_multi_q(const ScanParams& p, hipStream_t stream, int grid)
+{
+    const dim3 g(grid), b(kWave * kWavesPerBlock);
+    if (p.tiles)
+        hipLaunchKernelGGL((scan_multi_kernel<State, Q, false>), g, b, 0, stream, p);
+    else
+        hipLaunchKernelGGL((scan_multi_kernel<State, Q, true>), g, b, 0, stream, p);
+    return hipGetLastError();
+}
+template <class State>
+static hipError_t launch_multi_state(const ScanParams& p, hipStream_t stream, int grid)
+{
+    switch (p.multi_q) {
+    case 2: return launch_multi_q<State, 2>(p, stream, grid);
+    case 4: return launch_multi_q<State, 4>(p, stream, grid);
+    default: return hipErrorInvalidValue;
+    }
+}
+// raw: RAW_LEV or RAW_LCS; all queries single-word; `narrow` = every query <= 32 symbols
+hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipStream_t stream)
+{
+    if (p.n_tiles == 0) return hipSuccess;
+    const int grid = scan_grid(p.n_tiles);
+    if (raw == RAW_LEV) return narrow ? launch_multi_state<Lev32State>(p, stream, grid) : launch_multi_state<LevState<1>>(p, stream, grid);
+    if (raw == RAW_LCS) return narrow ? launch_multi_state<Lcs32State>(p, stream, grid) : launch_multi_state<LcsState<1>>(p, stream, grid);
+    return hipErrorInvalidValue;
+}
+
+// Final selection: `count` candidate keys (device counter, or an immediate for the post-all-gather merge) -> the k
+// smallest, ascending, ~0 = empty.  One workgroup of 16 wavefronts: each keeps a sorted k-list over its stripe of
+// the candidates (WaveTopK), the lists meet in LDS and wavefront 0 merges them.  Before it exits the kernel re-arms
+// the launch-wide state (counter = 0, bound = ~0) so the next top-k call on this scratch needs no memset.
+constexpr int kFinalThreads = 256;
+__global__ __launch_bounds__(kFinalThreads) void topk_final_kernel(const uint64_t* __restrict__ keys, uint32_t* count_ptr, uint32_t count_imm,
+                                                                   uint32_t k, uint64_t* __restrict__ out, uint64_t* bound_ptr,
+                                                                   bool bound_from_result)
+{
+    constexpr uint32_t kWaves = kFinalThreads / kWave;
+    __shared__ uint64_t lists[kWaves][kWave];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = uniform(threadIdx.x / kWave);
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    const uint32_t used = min(kWaves, (n + kWave - 1) / kWave);  // wavefronts that see any key at all
+    WaveTopK best;
+    best.init();
+    // kRows 64-key rows per trip, all loaded before the first is offered: the loop is bound by load latency, not work
+    constexpr uint32_t kRows = 8;
+    uint64_t limit = ~0ull;  // this list's worst key once it is full
+    for (uint32_t base = wave * kWave; base < n; base += kRows * kFinalThreads) {
+        uint64_t row[kRows];
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const uint32_t i = base + r * kFinalThreads + lane;
+            row[r] = i < n ? keys[i] : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r)
+            if (best.offer(row[r], row[r] != ~0ull, k, lane, limit)) limit = best.worst(k);
+    }
+    if (used > 1) {
+        lists[wave][lane] = best.key;
+        __syncthreads();
+    }
+    if (wave == 0) {
+        for (uint32_t w = 1; w < used; ++w)
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t x = lists[w][j];
+                if (x >= best.worst(k)) break;  // the lists are sorted: nothing further in this one can enter
+                best.insert(x, lane);
+            }
+        if (lane < k) out[lane] = best.key;
+        // re-arm for the next launch on this scratch.  After the SAMPLE pass of a top-k call the bound becomes the
+        // sample's k-th best key: the k-th best of a subset bounds the k-th best of the whole corpus from above.
+        const uint64_t kth = best.worst(k);
+        if (lane == 0) {
+            if (count_ptr) *count_ptr = 0;
+            if (bound_ptr) *bound_ptr = bound_from_result ? kth : ~0ull;
+        }
+    }
+}
+
+hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t count_imm, uint32_t k, uint64_t* out, uint64_t* bound_ptr,
+                             bool bound_from_result, hipStream_t stream)
+{
+    hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(kFinalThreads), 0, stream, keys, count_ptr, count_imm, k, out, bound_ptr,
+                       bound_from_result);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------------------------
+int scan_max_grid()
+{
+    // 8 workgroups (32 waves) are resident per CU; launching 4x that lets early finishers be replaced and
+    // measured +5% over an exactly-resident grid (profiles/grid_sweep_r01.txt).  RF_SCAN_BLOCKS_PER_CU overrides.
+    static const int per_cu = [] {
+        const char* e = getenv("RF_SCAN_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 32;
+    }();
+    return 256 * per_cu;
+}
+
+template <class State>
+static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid)
+{
+    const dim3 g(grid), b(kWave * kWavesPerBlock);
+    if constexpr (State::kWords == 1) {
+        // no cutoff early-out to serve: the leaner stream loop.  Ring depth 1 measured best (2 and 3 were 1-3% slower
+        // on every metric: these kernels are issue-bound, not latency-bound); RF_STREAM=0 selects scan_body for A/B.
+        static const bool use_stream = [] { const char* e = getenv("RF_STREAM"); return !e || atoi(e) != 0; }();
+        if (!p.early && use_stream) {
+            if (p.tiles)
+                hipLaunchKernelGGL((stream_kernel_occ8<State, false, 1>), g, b, 0, stream, p);
+            else
+                hipLaunchKernelGGL((stream_kernel_occ8<State, true, 1>), g, b, 0, stream, p);
+            return hipGetLastError();
+        }
+        if (p.tiles)
+            hipLaunchKernelGGL((scan_kernel_occ8<State, false>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((scan_kernel_occ8<State, true>), g, b, 0, stream, p);
+    } else {
+        if (p.tiles)
+            hipLaunchKernelGGL((scan_kernel<State, false>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((scan_kernel<State, true>), g, b, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+template <template <int> class StateT>
+static hipError_t launch_words(const ScanParams& p, hipStream_t stream, int grid)
+{
+    switch (p.words) {
+    case 1: return launch_state<StateT<1>>(p, stream, grid);
+    case 2: return launch_state<StateT<2>>(p, stream, grid);
+    case 3: return launch_state<StateT<3>>(p, stream, grid);
+    case 4: return launch_state<StateT<4>>(p, stream, grid);
+    case 5: return launch_state<StateT<5>>(p, stream, grid);
+    case 6: return launch_state<StateT<6>>(p, stream, grid);
+    case 7: return launch_state<StateT<7>>(p, stream, grid);
+    case 8: return launch_state<StateT<8>>(p, stream, grid);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+int scan_grid(uint32_t n_tiles)
+{
+    return (int)std::min<uint32_t>((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)scan_max_grid());
+}
+hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
+{
+    if (p.n_tiles == 0) return hipSuccess;
+    const uint32_t launch_tiles = p.tile_end > p.tile_begin ? (p.tile_end - p.tile_begin + p.tile_step - 1) / p.tile_step : 0;
+    const int grid = p.long_words_pad ? (int)p.long_grid : std::max(1, scan_grid(launch_tiles));
+    if (grid_used) *grid_used = grid;
+    if (p.prefill_none && p.out) {  // candidates outside the cutoff's length window (plan()): None without being read
+        const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, p.n, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS)) return launch_long(raw, p, stream, grid);
+    switch (raw) {
+    case RAW_LEV: return p.len1 <= 32 ? launch_state<Lev32State>(p, stream, grid) : launch_words<LevState>(p, stream, grid);
+    case RAW_LCS: return p.len1 <= 32 ? launch_state<Lcs32State>(p, stream, grid) : launch_words<LcsState>(p, stream, grid);
+    case RAW_OSA: return launch_words<OsaState>(p, stream, grid);
+    case RAW_WF: return launch_wf(p, stream);
+    case RAW_JARO: return launch_jaro(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rf
