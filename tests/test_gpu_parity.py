@@ -862,3 +862,113 @@ def test_readme_quick_start(tmp_path):
     path = str(tmp_path / "corpus.rfc")
     corpus.save(path)
     assert scorer.stream_many(rf.N.OP_DISTANCE, path, n=len(corpus)).tolist() == [3, 1, 2, 7]
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[1] at FULL size: size-independent properties
+def test_full_size_c2_properties():
+    """100 M x len-64 candidates (configs[1]).  The oracle cannot cover this in seconds, so beyond an oracle-checked
+    prefix the test ties together paths that share no kernel code: the no-cutoff stream kernel, the cutoff early-out
+    kernel, the top-k reduction, the 4-query kernel and the Indel kernel must all tell the same story about every one of
+    the 100 M candidates."""
+    import torch
+
+    n, ln = 100_000_000, 64
+    dev = torch.device("cuda", 0)
+    q = synth.query(64, 0xC0FFEE02)
+    rows = synth.rows_device(n, ln, seed=123, device=dev)
+    qrow = torch.tensor(list(q), dtype=torch.uint8, device=dev)
+    planted = torch.arange(777, n, 1_000_003, device=dev)  # near-duplicates so that cutoffs and top-k have something to find
+    rows[planted] = qrow
+    rows[planted[::2], 5] = 33
+    rows[planted[::3], 40] = 35
+    host_prefix = rows[:300_000].cpu().numpy()
+    corpus = rf.Corpus.from_device_rows(rows)
+    del rows
+    bc = rf.distance.levenshtein.BatchComparator(q)
+    full = torch.empty(n, dtype=torch.int32, device=dev)
+    bc.distance_many(corpus, out=full)
+    # (1) oracle on a prefix
+    exp = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host_prefix, nthreads=8)
+    assert (full[:300_000].cpu().numpy().view(np.uint32) == exp.astype(np.uint32)).all()
+    # (2) bounds every exact distance obeys: 0 <= d <= 64, and d == 0 exactly where the row equals the query
+    assert int(full.min()) == 0 and int(full.max()) <= 64
+    # (3) the cutoff kernel (early-out, window, diagonal bound) agrees with the full scan everywhere
+    cut = torch.empty(n, dtype=torch.int32, device=dev)
+    for k in (0, 3, 20):
+        bc.distance_many(corpus, out=cut, score_cutoff=k)
+        want = torch.where(full <= k, full, torch.full_like(full, -1))  # 0xFFFFFFFF as int32
+        assert bool((cut == want).all()), k
+    # (4) top-k == the k smallest (distance, index) pairs of the full result
+    for k, kw in ((16, {}), (5, {"score_cutoff": 2})):
+        s, i = bc.topk(corpus, k, **kw)
+        key = full.to(torch.int64) * (1 << 32) + torch.arange(n, device=dev, dtype=torch.int64)
+        if kw:
+            key = key[full <= kw["score_cutoff"]]
+        best = torch.sort(key).values[:k].cpu().numpy()
+        assert [(int(b) >> 32, int(b) & 0xFFFFFFFF) for b in best] == list(zip(s.tolist(), i.tolist()))
+    # (5) Indel distance bounds Levenshtein from both sides: lev <= indel <= 2 * lev
+    indel = torch.empty(n, dtype=torch.int32, device=dev)
+    rf.distance.indel.BatchComparator(q).distance_many(corpus, out=indel)
+    assert bool((full <= indel).all()) and bool((indel <= 2 * full).all())
+    # (6) the fused 4-query kernel: row 0 is the same query again, and every row obeys the triangle inequality through
+    #     the (oracle-computed) distances between the queries
+    qs = [q, synth.query(64, 1), synth.query(50, 2), synth.query(64, 3)]
+    cs = [rf.distance.levenshtein.BatchComparator(x) for x in qs]
+    multi = torch.empty((4, n), dtype=torch.int32, device=dev)
+    rf.distance.levenshtein.BatchComparator.many_multi(cs, N.OP_DISTANCE, corpus, out=multi)
+    assert bool((multi[0] == full).all())
+    for j in (1, 2, 3):
+        dq = o.levenshtein.distance(q, qs[j])
+        assert bool(((multi[j] - full).abs() <= dq).all())
+
+
+def test_full_size_c3_and_c4_properties():
+    """configs[2] (query 256 x 10 M x len 256, multi-word kernel) and configs[3] (Jaro-Winkler on the 100 M corpus) at full
+    size: an oracle-checked prefix plus properties that hold for every candidate."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    # ---- C3
+    n, ln = 10_000_000, 256
+    q = synth.query(256, 7)
+    rows = synth.rows_device(n, ln, seed=321, device=dev)
+    rows[123_456::1_000_000] = torch.tensor(list(q), dtype=torch.uint8, device=dev)
+    host_prefix = rows[:20_000].cpu().numpy()
+    corpus = rf.Corpus.from_device_rows(rows)
+    del rows
+    bc = rf.distance.levenshtein.BatchComparator(q)
+    full = torch.empty(n, dtype=torch.int32, device=dev)
+    bc.distance_many(corpus, out=full)
+    exp = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host_prefix, nthreads=8)
+    assert (full[:20_000].cpu().numpy().view(np.uint32) == exp.astype(np.uint32)).all()
+    assert int((full == 0).sum()) == 10 and int(full.max()) <= 256
+    cut = torch.empty(n, dtype=torch.int32, device=dev)
+    bc.distance_many(corpus, out=cut, score_cutoff=8)
+    assert bool((cut == torch.where(full <= 8, full, torch.full_like(full, -1))).all())
+    osa = torch.empty(n, dtype=torch.int32, device=dev)
+    rf.distance.osa.BatchComparator(q).distance_many(corpus, out=osa)
+    assert bool((osa <= full).all()) and bool((2 * osa >= full).all())  # a transposition is 1 OSA edit, at most 2 Levenshtein edits
+    del corpus, full, cut, osa
+    torch.cuda.empty_cache()
+    # ---- C4
+    n, ln = 100_000_000, 64
+    q = synth.query(64, 0xC0FFEE02)
+    rows = synth.rows_device(n, ln, seed=124, device=dev)
+    rows[999::10_000_019] = torch.tensor(list(q), dtype=torch.uint8, device=dev)
+    host_prefix = rows[:200_000].cpu().numpy()
+    corpus = rf.Corpus.from_device_rows(rows)
+    del rows
+    jaro = torch.empty(n, dtype=torch.float64, device=dev)
+    jw = torch.empty(n, dtype=torch.float64, device=dev)
+    rf.distance.jaro.BatchComparator(q).similarity_many(corpus, out=jaro)
+    rf.distance.jaro_winkler.BatchComparator(q).similarity_many(corpus, out=jw)
+    exp = o.jaro_winkler.BatchComparator(q).rows(N.OP_SIMILARITY, host_prefix, nthreads=8)
+    assert (jw[:200_000].cpu().numpy() == exp).all()  # bit-equal f64
+    assert float(jaro.min()) >= 0.0 and float(jaro.max()) == 1.0 and int((jaro == 1.0).sum()) == 10
+    assert bool((jw >= jaro).all()) and bool((jw <= 1.0).all())
+    assert bool((jw[jaro <= 0.7] == jaro[jaro <= 0.7]).all())  # the Winkler boost only applies above 0.7
+    lcs = torch.empty(n, dtype=torch.int32, device=dev)
+    rf.distance.lcs_seq.BatchComparator(q).similarity_many(corpus, out=lcs)
+    indel = torch.empty(n, dtype=torch.int32, device=dev)
+    rf.distance.indel.BatchComparator(q).distance_many(corpus, out=indel)
+    assert bool((indel == 128 - 2 * lcs).all())  # indel.rs:365-367 at full size, two different finishing paths
