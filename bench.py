@@ -99,8 +99,10 @@ def main():
             rows[pidx] = planted
     sample_rows = min(n, 32_000_000)
     host_sample = None
+    host_strided = None
     if rank == 0 and not args.no_cpu_baseline:
         host_sample = rows[:sample_rows].cpu().numpy()
+        host_strided = rows[::1009].cpu().numpy()  # every 1009-th candidate of the WHOLE shard
     corpus = rf.Corpus.from_device_rows(rows)
     del rows
     torch.cuda.empty_cache()
@@ -275,7 +277,17 @@ def main():
                 got = out[j * n : j * n + chk].cpu().numpy().view(np.uint32)
                 bad = got != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
             mism += int(bad.sum())
-        result["parity"] = {"checked": int(chk) * nq, "mismatches": mism}
+        # ... and on the strided sample over the whole corpus (first query)
+        kw = {"weights": weights} if weights else {}
+        exp = getattr(o, args.metric).BatchComparator(queries[0]).rows(op, host_strided, nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff, **kw)
+        if is_f64:
+            got = out[:n:1009].cpu().numpy()
+            bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
+        else:
+            got = out[:n:1009].cpu().numpy().view(np.uint32)
+            bad = got != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
+        result["parity"] = {"checked": int(chk) * nq + len(host_strided), "mismatches": mism + int(bad.sum()),
+                            "what": f"first {chk} candidates + every 1009-th of all {n}, vs oracle/"}
     if world > 1 or force_dist:
         dist.destroy_process_group()
     # RCCL prints its version banner through C stdio, which flushes after Python's buffer when stdout is a pipe:
