@@ -445,6 +445,16 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                 hipLaunchKernelGGL((stream_kernel_occ8<State, true, 1>), g, b, 0, stream, p);
             return hipGetLastError();
         }
+        if (p.early) {
+            // cutoff runs: the compiler's own register budget.  Pinned to 8 wavefronts per SIMD this body spills (32 B of
+            // scratch traffic per tile in a loop that only runs 8 columns); 7 resident wavefronts without spills
+            // measured +8 % at cutoff 3 and +3 % at cutoff 10 on the C2 corpus.
+            if (p.tiles)
+                hipLaunchKernelGGL((scan_kernel<State, false>), g, b, 0, stream, p);
+            else
+                hipLaunchKernelGGL((scan_kernel<State, true>), g, b, 0, stream, p);
+            return hipGetLastError();
+        }
         if (p.tiles)
             hipLaunchKernelGGL((scan_kernel_occ8<State, false>), g, b, 0, stream, p);
         else
