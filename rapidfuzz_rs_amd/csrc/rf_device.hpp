@@ -238,11 +238,17 @@ struct OsaState {
             pm_old[w] = pm_j;
         }
     }
-    // the vertical-delta identity and the last-row bound hold for the OSA matrix as well (unit steps)
+    // The vertical-delta identity and both bounds of LevState::hopeless hold for the OSA matrix as well: steps are unit,
+    // and values never decrease along a diagonal (drop the last symbol of both strings from an optimal restricted
+    // alignment: a pair aligned to each other disappears, a transposed pair (a_i a_i+1)/(b_j b_j+1) becomes one
+    // substitution, and in every other case a deletion or insertion of a last symbol is saved for at most one new one).
     static constexpr bool kCanPrune = true;
     __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
     {
-        return (int32_t)result(len1, j) - (int32_t)(len2 - j) > (int32_t)raw_cutoff;
+        const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;
+        const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
+        return max(last_row, diag) > (int32_t)raw_cutoff;
     }
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {

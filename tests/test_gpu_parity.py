@@ -948,6 +948,8 @@ def test_full_size_c3_and_c4_properties():
     osa = torch.empty(n, dtype=torch.int32, device=dev)
     rf.distance.osa.BatchComparator(q).distance_many(corpus, out=osa)
     assert bool((osa <= full).all()) and bool((2 * osa >= full).all())  # a transposition is 1 OSA edit, at most 2 Levenshtein edits
+    rf.distance.osa.BatchComparator(q).distance_many(corpus, out=cut, score_cutoff=8)  # the OSA early-out (both bounds)
+    assert bool((cut == torch.where(osa <= 8, osa, torch.full_like(osa, -1))).all())
     del corpus, full, cut, osa
     torch.cuda.empty_cache()
     # ---- C4
