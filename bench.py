@@ -204,7 +204,12 @@ def main():
     # (Q fused queries read each candidate once: ln / Q candidate bytes per pair)
     # With a distance cutoff the early-out is part of the algorithm: on this corpus nearly every candidate is decided
     # from its first 16-byte chunk, so the bytes the path has to move are that chunk + the result.
-    cand_bytes = min(ln, 16) if (args.cutoff is not None and args.metric in ("levenshtein", "osa") and args.cutoff < max(ln, args.query_len)) else ln
+    # (the library switches the early-out on by how much normalized distance the cutoff allows -- rf_api.hip plan())
+    early = False
+    if args.cutoff is not None and not is_f64 and not weights:
+        maximum = (ln + args.query_len) if args.metric == "indel" else max(ln, args.query_len)
+        early = args.cutoff / max(maximum, 1) < (0.4 if args.metric in ("indel", "lcs_seq") else 0.7)
+    cand_bytes = min(ln, 16) if early else ln
     bytes_per_pair = cand_bytes / nq + (8 if is_f64 else (4 if args.mode == "many" else 0))
     achieved = n * nq * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
 

@@ -865,22 +865,37 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves / kWavesPerBlock, (uint64_t)scan_grid(corpus->n_tiles)));
         return RF_OK;
     }
-    // Value-preserving early-out for a Levenshtein distance cutoff that can actually prune something
-    // (the reference only applies the cutoff after its loop, levenshtein.rs:492-496).
-    if (p->finish == FIN_LEV && op == RF_OP_DISTANCE && !f64_out && p->has_cutoff && p->factor > 0) {
-        const uint32_t raw_cutoff = p->cutoff_u32 / p->factor;
-        if (raw_cutoff < std::max<uint32_t>(p->len1, corpus->max_len)) {
+    // Value-preserving early-out (the reference applies its cutoffs after the loops, e.g. levenshtein.rs:492-496):
+    // the kernels stop reading a tile once no lane can pass the cutoff any more (may_pass() in rf_device.hpp), for
+    // every op and output type.  It pays only when the cutoff is tight enough to kill typical candidates early --
+    // the early-out loop gives up the streaming prefetch -- so it is switched on by how much normalized distance the
+    // cutoff still allows (`slack`; measured on the C2 corpus: Levenshtein wins up to ~0.7, the LCS bound, which only
+    // gains one per remaining column, up to ~0.4).
+    if (p->has_cutoff && (*raw == RAW_LEV || *raw == RAW_OSA || *raw == RAW_LCS) && !(p->finish == FIN_LEV && p->factor == 0)) {
+        const uint64_t S = (uint64_t)p->len1 + corpus->max_len, Mx = std::max<uint64_t>(p->len1, corpus->max_len);
+        const double maximum = (double)((int64_t)p->fin_mS * (int64_t)S + (int64_t)p->fin_mM * (int64_t)Mx);
+        double slack;  // allowed distance / maximum
+        if (f64_out)
+            slack = (op == RF_OP_NORMALIZED_DISTANCE) ? p->cutoff_f64 : 1.0 - p->cutoff_f64;
+        else if (maximum <= 0.0)
+            slack = 1.0;
+        else
+            slack = (op == RF_OP_DISTANCE) ? (double)p->cutoff_u32 / maximum : 1.0 - (double)p->cutoff_u32 / maximum;
+        const double tight = *raw == RAW_LCS ? 0.4 : 0.7;
+        if (slack < tight) {
             p->early = 1;
-            p->raw_cutoff = raw_cutoff;
-            // distance >= |len1 - len2| (the reference's first test, levenshtein.rs:1389-1391): tiles ascend by length,
-            // so the candidates that can pass are ONE tile range; the rest is never read, only pre-filled with None.
-            const uint64_t lo = p->len1 > raw_cutoff ? p->len1 - raw_cutoff : 0, hi = (uint64_t)p->len1 + raw_cutoff;
-            const auto& L = corpus->lengths;
-            const size_t i_lo = std::lower_bound(L.begin(), L.end(), (uint32_t)lo) - L.begin();
-            const size_t i_hi = hi >= 0xFFFFFFFFull ? L.size() : std::upper_bound(L.begin(), L.end(), (uint32_t)hi) - L.begin();
-            p->tile_begin = i_lo < L.size() ? corpus->length_first_tile[i_lo] : corpus->n_tiles;
-            p->tile_end = i_hi < L.size() ? corpus->length_first_tile[i_hi] : corpus->n_tiles;
-            p->prefill_none = !corpus->borrowed && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
+            if (p->finish == FIN_LEV && op == RF_OP_DISTANCE && !f64_out) {
+                // distance >= |len1 - len2| (the reference's first test, levenshtein.rs:1389-1391): tiles ascend by length,
+                // so the candidates that can pass are ONE tile range; the rest is never read, only pre-filled with None.
+                const uint32_t raw_cutoff = p->cutoff_u32 / p->factor;
+                const uint64_t lo = p->len1 > raw_cutoff ? p->len1 - raw_cutoff : 0, hi = (uint64_t)p->len1 + raw_cutoff;
+                const auto& L = corpus->lengths;
+                const size_t i_lo = std::lower_bound(L.begin(), L.end(), (uint32_t)lo) - L.begin();
+                const size_t i_hi = hi >= 0xFFFFFFFFull ? L.size() : std::upper_bound(L.begin(), L.end(), (uint32_t)hi) - L.begin();
+                p->tile_begin = i_lo < L.size() ? corpus->length_first_tile[i_lo] : corpus->n_tiles;
+                p->tile_end = i_hi < L.size() ? corpus->length_first_tile[i_hi] : corpus->n_tiles;
+                p->prefill_none = !corpus->borrowed && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
+            }
         }
     }
     return RF_OK;

@@ -162,18 +162,18 @@ struct LevState {
     // Early-out bound under a distance cutoff (the reference applies its cutoff only after the loop,
     // levenshtein.rs:492-496, so this is value-preserving pruning): adjacent cells of the last row differ by at
     // most 1, hence D[len1][len2] >= D[len1][j] - (len2 - j).  D[len1][j] comes from the same popcount identity
-    // as result().  True = this lane can no longer end at or below `raw_cutoff`.
+    // as result().  The kernels feed the bound to may_pass() (below): no lane may pass -> the tile is abandoned.
     // A second bound comes from the diagonal through (len1, len2): values never decrease along a diagonal of the
     // Levenshtein matrix, so D[len1][len2] >= D[j + len1 - len2][j] -- the same popcount identity with a shorter row
     // mask.  For equal lengths that is the distance between the two j-prefixes, which for unrelated strings grows by
     // almost 1 per column: nearly every wavefront of a random corpus is past a small cutoff after 8 columns.
     static constexpr bool kCanPrune = true;
-    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    __device__ __forceinline__ uint32_t bound(uint32_t len1, uint32_t j, uint32_t len2) const
     {
         const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
         const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // <= len1 because j <= len2
         const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
-        return max(last_row, diag) > (int32_t)raw_cutoff;
+        return (uint32_t)max(max(last_row, diag), 0);  // a LOWER bound on D[len1][len2]
     }
     // D[len1][len2] from the final column's vertical deltas (any row count <= len1 gives D[rows][len2])
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
@@ -238,17 +238,17 @@ struct OsaState {
             pm_old[w] = pm_j;
         }
     }
-    // The vertical-delta identity and both bounds of LevState::hopeless hold for the OSA matrix as well: steps are unit,
+    // The vertical-delta identity and both bounds of LevState::bound hold for the OSA matrix as well: steps are unit,
     // and values never decrease along a diagonal (drop the last symbol of both strings from an optimal restricted
     // alignment: a pair aligned to each other disappears, a transposed pair (a_i a_i+1)/(b_j b_j+1) becomes one
     // substitution, and in every other case a deletion or insertion of a last symbol is saved for at most one new one).
     static constexpr bool kCanPrune = true;
-    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    __device__ __forceinline__ uint32_t bound(uint32_t len1, uint32_t j, uint32_t len2) const
     {
         const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
         const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;
         const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
-        return max(last_row, diag) > (int32_t)raw_cutoff;
+        return (uint32_t)max(max(last_row, diag), 0);
     }
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
@@ -315,8 +315,13 @@ struct LcsState {
         }
         carry_io = (uint32_t)carry;
     }
-    static constexpr bool kCanPrune = false;
-    __device__ __forceinline__ bool hopeless(uint32_t, uint32_t, uint32_t, uint32_t) const { return false; }
+    // After j columns the LCS can still grow by at most one per remaining candidate symbol, and never beyond the shorter
+    // string: an UPPER bound on the final LCS length (the favourable side for every op built on it).
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ uint32_t bound(uint32_t len1, uint32_t j, uint32_t len2) const
+    {
+        return min(result(len1, j) + (len2 - j), min(len1, len2));
+    }
     __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const
     {
         uint32_t sim = 0;
@@ -360,12 +365,12 @@ struct Lev32State {
         vp = lut3w<T_OR_NOR>(hns, hps, d0);
     }
     static constexpr bool kCanPrune = true;
-    __device__ __forceinline__ bool hopeless(uint32_t len1, uint32_t j, uint32_t len2, uint32_t raw_cutoff) const
+    __device__ __forceinline__ uint32_t bound(uint32_t len1, uint32_t j, uint32_t len2) const
     {
         const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
-        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // the diagonal bound, see LevState::hopeless
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // the diagonal bound, see LevState::bound
         const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
-        return max(last_row, diag) > (int32_t)raw_cutoff;
+        return (uint32_t)max(max(last_row, diag), 0);
     }
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
@@ -384,8 +389,13 @@ struct Lcs32State {
         const uint32_t u = s & pm_row[0];
         s = lut3w<T_OR_ANDN>(s + u, s, u);  // (s + u) | (s - u) with s - u == s & ~u
     }
-    static constexpr bool kCanPrune = false;
-    __device__ __forceinline__ bool hopeless(uint32_t, uint32_t, uint32_t, uint32_t) const { return false; }
+    // After j columns the LCS can still grow by at most one per remaining candidate symbol, and never beyond the shorter
+    // string: an UPPER bound on the final LCS length (the favourable side for every op built on it).
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ uint32_t bound(uint32_t len1, uint32_t j, uint32_t len2) const
+    {
+        return min(result(len1, j) + (len2 - j), min(len1, len2));
+    }
     __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const { return __popc(~s); }
 };
 
@@ -458,6 +468,29 @@ __device__ __forceinline__ void emit_fin(const ScanParams& p, const TileFin& f, 
 __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx, void* out, uint32_t len1)
 {
     emit_fin(p, tile_fin(p, len1, len2), raw, idx, out);
+}
+// Could a candidate whose raw result is at best `raw_bound` still pass the cutoff?  `raw_bound` is the favourable
+// bound of State::bound() (a lower bound on a distance, an upper bound on an LCS length); every finishing map here is
+// monotone in raw and runs the very arithmetic of emit_fin, so "the bound fails" implies "every reachable value
+// fails" -- for the u32 and the f64 (normalized_*) outputs alike.  This is what makes the early-out value-preserving.
+__device__ __forceinline__ bool may_pass(const ScanParams& p, const TileFin& f, uint32_t raw_bound)
+{
+    bool keep;
+    if (!p.out_f64) {
+        (void)usize_value(p, f, raw_bound, &keep);
+    } else {
+        const uint32_t dist = f.d0 + (uint32_t)p.fin_dR * raw_bound;
+        const double nd = f.max == 0 ? 0.0 : (double)dist / (double)f.max;
+        keep = p.op == RF_OP_NORMALIZED_DISTANCE ? nd <= p.cutoff_f64 : (1.0 - nd) >= p.cutoff_f64;
+    }
+    return keep;
+}
+__device__ __forceinline__ void emit_none(const ScanParams& p, uint32_t idx)
+{
+    if (!p.out_f64)
+        reinterpret_cast<uint32_t*>(p.out)[idx] = RF_NONE_U32;
+    else
+        reinterpret_cast<double*>(p.out)[idx] = __longlong_as_double(0x7FF8000000000000ll);
 }
 __device__ __forceinline__ void emit_usize(const ScanParams& p, uint32_t raw, uint32_t len2, uint32_t idx)
 {

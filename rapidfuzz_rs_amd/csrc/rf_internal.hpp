@@ -87,7 +87,6 @@ struct ScanParams {
     uint32_t* long_scratch;   // [grid * 4][long_chunks_max][64]
     // value-preserving early-out under a distance cutoff (levenshtein, u32 distance output / top-k)
     uint32_t early;
-    uint32_t raw_cutoff;   // cutoff on the raw kernel distance: floor(cutoff / factor)
     // top-k mode (topk_k != 0): no per-candidate output, one k-entry key list per workgroup
     uint32_t topk_k;       // <= 64
     uint32_t topk_desc;    // 1: larger score is better (similarity)

@@ -56,6 +56,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
             State st;
             st.init();
             const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+            const TileFin fin = tile_fin(p, p.len1, len2);
             bool dead = false;
             uint4 ahead = make_uint4(0, 0, 0, 0);
             if (early || nch == 0) ahead = load_chunk(next_tile.src + lane);
@@ -70,7 +71,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                     if (early && c == 0) {
                         // first chance to stop: after 8 columns a random candidate is already ~6 edits off
                         process_chunk_full<State, 0, kChunk / 2>(st, lds_pm, cur);
-                        if (__ballot(!st.hopeless(p.len1, kChunk / 2, len2, p.raw_cutoff)) == 0) {
+                        if (__ballot(may_pass(p, fin, st.bound(p.len1, kChunk / 2, len2))) == 0) {
                             dead = true;
                             break;
                         }
@@ -83,7 +84,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                 }
                 if (early) {
                     const uint32_t j = min(len2, (c + 1) * kChunk);
-                    if (__ballot(!st.hopeless(p.len1, j, len2, p.raw_cutoff)) == 0) {
+                    if (__ballot(may_pass(p, fin, st.bound(p.len1, j, len2))) == 0) {
                         dead = true;  // the whole wavefront is beyond the cutoff: stop reading this tile
                         break;
                     }
@@ -97,9 +98,9 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
             const uint32_t raw = st.result(p.len1, len2);
             if (p.out && valid) {
                 if (dead)
-                    reinterpret_cast<uint32_t*>(p.out)[idx] = RF_NONE_U32;  // early only runs for u32 distance output
+                    emit_none(p, idx);
                 else
-                    emit_usize(p, raw, len2, idx);
+                    emit_fin(p, fin, raw, idx, p.out);
             }
             if (topk && !dead) {
                 bool keep;

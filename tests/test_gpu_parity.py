@@ -974,3 +974,59 @@ def test_full_size_c3_and_c4_properties():
     indel = torch.empty(n, dtype=torch.int32, device=dev)
     rf.distance.indel.BatchComparator(q).distance_many(corpus, out=indel)
     assert bool((indel == 128 - 2 * lcs).all())  # indel.rs:365-367 at full size, two different finishing paths
+
+
+# ---------------------------------------------------------------- early-out for every op / output type (may_pass on State::bound)
+@pytest.mark.parametrize("metric", ["levenshtein", "osa", "indel", "lcs_seq"])
+@pytest.mark.parametrize("uniform", [False, True])
+def test_cutoff_early_out_every_op(metric, uniform):
+    rng = np.random.default_rng(99)
+    q = synth.query(60, 1234)
+    if uniform:
+        rows = synth.rows_host(6000, 64, seed=77)
+        synth.plant_near_duplicates(rows[:, :60], q, 37, seed=2, max_edits=9)
+        data, offsets = rows.reshape(-1), np.arange(0, rows.size + 1, 64, dtype=np.uint64)
+    else:
+        data, offsets = synth.ragged_host(6000, 130, seed=78)
+        cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+        for i in range(0, len(cands), 31):
+            b = bytearray(q)
+            for _ in range(int(rng.integers(0, 12))):
+                r, pos = int(rng.integers(0, 3)), int(rng.integers(0, len(b) + 1))
+                if r == 0:
+                    b.insert(pos, 65)
+                elif len(b):
+                    if r == 1:
+                        del b[min(pos, len(b) - 1)]
+                    else:
+                        b[min(pos, len(b) - 1)] = 66
+            cands[i] = bytes(b)
+        data, offsets = rf.ragged(cands)
+    for k in (0, 1, 4, 9, 20, 40, 59, 60, 61, 200):
+        _check_many(metric, q, data, offsets, "distance", score_cutoff=k)
+        if metric != "levenshtein":  # quirk Q2 is covered elsewhere
+            _check_many(metric, q, data, offsets, "similarity", score_cutoff=k)
+    for c in (0.0, 0.05, 0.3, 0.35, 0.5, 0.65, 0.8, 0.95, 1.0):
+        _check_many(metric, q, data, offsets, "normalized_distance", score_cutoff=c)
+        _check_many(metric, q, data, offsets, "normalized_similarity", score_cutoff=c)
+    if metric == "levenshtein":
+        for w, k in (((1, 1, 2), 14), ((2, 2, 2), 9), ((1, 1, 5), 30)):
+            _check_many(metric, q, data, offsets, "distance", weights=w, score_cutoff=k)
+            _check_many(metric, q, data, offsets, "normalized_similarity", weights=w, score_cutoff=0.8)
+    # long query (multi-word states) with tight cutoffs
+    ql = synth.query(200, 4321)
+    _check_many(metric, ql, data, offsets, "distance", score_cutoff=30)
+    _check_many(metric, ql, data, offsets, "normalized_similarity", score_cutoff=0.9)
+
+
+def test_fuzz_ratio_cutoff_early_out():
+    q = synth.query(64, 5)
+    rows = synth.rows_host(20_000, 64, seed=6)
+    synth.plant_near_duplicates(rows, q, 97, seed=3, max_edits=8)
+    corpus = rf.Corpus.from_rows(rows)
+    data, offsets = rows.reshape(-1), np.arange(0, rows.size + 1, 64, dtype=np.uint64)
+    for c in (0.5, 0.7, 0.9, 0.95, 1.0):
+        got = rf.fuzz.RatioBatchComparator(q).similarity_many(corpus, score_cutoff=c)
+        exp = o.fuzz.RatioBatchComparator(q).many(N.OP_NORMALIZED_SIMILARITY, data, offsets, nthreads=8, score_cutoff=c)
+        assert _equal_rows(got, exp), c
+        assert np.isfinite(got).sum() > 0
