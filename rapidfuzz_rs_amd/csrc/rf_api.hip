@@ -884,18 +884,39 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         const double tight = *raw == RAW_LCS ? 0.4 : 0.7;
         if (slack < tight) {
             p->early = 1;
-            if (p->finish == FIN_LEV && op == RF_OP_DISTANCE && !f64_out) {
-                // distance >= |len1 - len2| (the reference's first test, levenshtein.rs:1389-1391): tiles ascend by length,
-                // so the candidates that can pass are ONE tile range; the rest is never read, only pre-filled with None.
-                const uint32_t raw_cutoff = p->cutoff_u32 / p->factor;
-                const uint64_t lo = p->len1 > raw_cutoff ? p->len1 - raw_cutoff : 0, hi = (uint64_t)p->len1 + raw_cutoff;
-                const auto& L = corpus->lengths;
-                const size_t i_lo = std::lower_bound(L.begin(), L.end(), (uint32_t)lo) - L.begin();
-                const size_t i_hi = hi >= 0xFFFFFFFFull ? L.size() : std::upper_bound(L.begin(), L.end(), (uint32_t)hi) - L.begin();
-                p->tile_begin = i_lo < L.size() ? corpus->length_first_tile[i_lo] : corpus->n_tiles;
-                p->tile_end = i_hi < L.size() ? corpus->length_first_tile[i_hi] : corpus->n_tiles;
-                p->prefill_none = !corpus->borrowed && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
+            // Length window: before any byte is read a candidate of length L already has a favourable bound -- distance >=
+            // |len1 - L| (the reference's first test, levenshtein.rs:1389-1391), LCS <= min(len1, L).  Lengths whose bound
+            // fails the cutoff (same arithmetic as may_pass() on the device) are never read: tiles ascend by length, so
+            // the survivors lie in ONE tile range [first passing length, last passing length]; the rest of `out` is
+            // pre-filled with None.
+            const auto& L = corpus->lengths;
+            size_t first = L.size(), last = 0;
+            for (size_t i = 0; i < L.size(); ++i) {
+                const uint32_t len2 = L[i];
+                const uint32_t Sv = p->len1 + len2, Mv = std::max(p->len1, len2);
+                const uint32_t raw_b = *raw == RAW_LCS ? std::min(p->len1, len2) : (p->len1 > len2 ? p->len1 - len2 : len2 - p->len1);
+                bool pass;
+                if (!f64_out) {
+                    const uint32_t v = (uint32_t)p->fin_vS * Sv + (uint32_t)p->fin_vM * Mv + (uint32_t)p->fin_vR * raw_b;
+                    pass = (v ^ p->fin_flip) <= p->fin_cflip;
+                } else {
+                    const uint32_t dist = (uint32_t)p->fin_dS * Sv + (uint32_t)p->fin_dM * Mv + (uint32_t)p->fin_dR * raw_b;
+                    const uint32_t mx = (uint32_t)p->fin_mS * Sv + (uint32_t)p->fin_mM * Mv;
+                    const double nd = mx == 0 ? 0.0 : (double)dist / (double)mx;
+                    pass = op == RF_OP_NORMALIZED_DISTANCE ? nd <= p->cutoff_f64 : (1.0 - nd) >= p->cutoff_f64;
+                }
+                if (pass) {
+                    first = std::min(first, i);
+                    last = i;
+                }
             }
+            if (first == L.size()) {
+                p->tile_begin = p->tile_end = corpus->n_tiles;  // nothing can pass
+            } else {
+                p->tile_begin = corpus->length_first_tile[first];
+                p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
+            }
+            p->prefill_none = !corpus->borrowed && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
         }
     }
     return RF_OK;

@@ -496,7 +496,8 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     const int grid = p.long_words_pad ? (int)p.long_grid : std::max(1, scan_grid(launch_tiles));
     if (grid_used) *grid_used = grid;
     if (p.prefill_none && p.out) {  // candidates outside the cutoff's length window (plan()): None without being read
-        const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, p.n, stream);
+        // (for f64 outputs two all-ones words per entry: a NaN, which is all "None" promises)
+        const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, (size_t)p.n * (p.out_f64 ? 2 : 1), stream);
         if (e != hipSuccess) return e;
     }
     if (p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS)) return launch_long(raw, p, stream, grid);
