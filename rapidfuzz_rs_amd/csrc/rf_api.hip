@@ -94,6 +94,10 @@ struct rf_corpus {
     };
     mutable std::mutex scratch_mu;
     mutable std::map<hipStream_t, TopkScratch> topk_scratch;
+    // A top-k call is four launches that hand state to each other through the scratch (sample -> bound -> scan ->
+    // select, which re-arms it).  Host threads sharing a stream must not interleave those sequences: the enqueue
+    // section of topk_core() runs under this lock (kernels of one stream then execute in enqueue order).
+    mutable std::mutex topk_enqueue_mu;
     // u32 ("char") corpora: the stored byte is the symbol's id in THIS corpus' alphabet.  Ids 0..253 are the 254 most
     // frequent symbols, kOverflowId lumps every rarer symbol together, kAbsentId is never stored (see resolve()).
     bool wide = false;
@@ -1155,6 +1159,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, r
     uint32_t* d_all = out_all;
     if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
     p.out = d_all;
+    std::lock_guard<std::mutex> enqueue_lock(corpus->topk_enqueue_mu);
     hipError_t e = hipSuccess;
     // Sample pass: the top-k of ~1000 evenly spaced tiles costs 0.1 % of the scan and its k-th best key is a valid
     // launch-wide bound from the first tile on -- without it every wavefront pays k ln(n_wave / k) list insertions to

@@ -1030,3 +1030,49 @@ def test_fuzz_ratio_cutoff_early_out():
         exp = o.fuzz.RatioBatchComparator(q).many(N.OP_NORMALIZED_SIMILARITY, data, offsets, nthreads=8, score_cutoff=c)
         assert _equal_rows(got, exp), c
         assert np.isfinite(got).sum() > 0
+
+
+def test_concurrent_host_threads_share_corpus_and_comparators():
+    """Handles are immutable after creation and safe to share across host threads (SURVEY 8(b) threading contract):
+    four threads hammer one corpus with shared and private comparators, many / top-k / multi mixed, on private streams."""
+    import threading
+
+    import torch
+
+    rows = synth.rows_host(200_000, 64, seed=21)
+    corpus = rf.Corpus.from_rows(rows)
+    queries = [synth.query(64, 100 + i) for i in range(4)]
+    shared = [rf.distance.levenshtein.BatchComparator(q) for q in queries]
+    expect = [c.distance_many(corpus) for c in shared]
+    expect_topk = [c.topk(corpus, 8) for c in shared]
+    wcorpus = rf.Corpus.from_list(["ναι και όχι", "ίσως", "maybe", "ναι"] * 500)  # u32 elements
+    wide = rf.distance.levenshtein.BatchComparator("ναι" + "x" * 20)
+    expect_wide = wide.distance_many(wcorpus)
+    fresh = [rf.distance.levenshtein.BatchComparator("όχι" + "y" * t) for t in range(4)]  # lowered lazily, inside the threads
+    errors = []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(12):
+                    j = (tid + it) % 4
+                    got = shared[j].distance_many(corpus)
+                    assert (got == expect[j]).all()
+                    s, i = shared[j].topk(corpus, 8)
+                    assert (s == expect_topk[j][0]).all() and (i == expect_topk[j][1]).all()
+                    mine = rf.distance.levenshtein.BatchComparator(queries[j])
+                    assert (mine.distance_many(corpus, score_cutoff=30) == np.where(expect[j] <= 30, expect[j], NONE32)).all()
+                    m = rf.distance.levenshtein.BatchComparator.many_multi(shared, N.OP_DISTANCE, corpus)
+                    assert all((m[q] == expect[q]).all() for q in range(4))
+                    assert (wide.distance_many(wcorpus) == expect_wide).all()
+                    assert fresh[(tid + it) % 4].distance_many(wcorpus)[3] == 2 + (tid + it) % 4
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
