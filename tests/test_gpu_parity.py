@@ -1076,3 +1076,102 @@ def test_concurrent_host_threads_share_corpus_and_comparators():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+# ---------------------------------------------------------------- randomized differential test (the reference's fuzz targets, fuzz/fuzz_targets/*.rs)
+def _random_corpus(rng):
+    kind = int(rng.integers(0, 6))
+    n = int(rng.integers(1, 2500))
+    alpha_kind = int(rng.integers(0, 4))
+    alphabet = [np.array([7], dtype=np.uint8), AB, synth.ALNUM, np.arange(256, dtype=np.uint8)][alpha_kind]
+    if kind == 0:  # everything the same length
+        ln = int(rng.integers(0, 130))
+        lens = np.full(n, ln)
+    elif kind == 1:  # uniform lengths
+        lens = rng.integers(0, int(rng.integers(1, 200)), size=n)
+    elif kind == 2:  # mostly short, a few long
+        lens = np.where(rng.random(n) < 0.02, rng.integers(200, 700, size=n), rng.integers(0, 20, size=n))
+    elif kind == 3:  # many empties
+        lens = np.where(rng.random(n) < 0.5, 0, rng.integers(0, 70, size=n))
+    elif kind == 4:  # exactly the word boundaries
+        lens = rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129], size=n)
+    else:  # two clusters
+        lens = np.where(rng.random(n) < 0.5, rng.integers(28, 36, size=n), rng.integers(60, 68, size=n))
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+    data = alphabet[rng.integers(0, len(alphabet), size=int(offsets[-1]))]
+    return data, offsets, alphabet
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RF_FUZZ_SEEDS", "48"))))
+def test_randomized_differential(seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        data, offsets, alphabet = _random_corpus(rng)
+        n = len(offsets) - 1
+        qlen = int(rng.choice([0, 1, 2, 5, 31, 32, 33, 48, 63, 64, 65, 100, 128, 129, 300, int(rng.integers(0, 400))]))
+        q = alphabet[rng.integers(0, len(alphabet), size=qlen)].tobytes()
+        # make some candidates related to the query so that cutoffs bite on both sides
+        cands = [bytes(data[int(offsets[i]) : int(offsets[i + 1])]) for i in range(n)]
+        for i in range(0, n, max(1, n // 40)):
+            b = bytearray(q)
+            for _e in range(int(rng.integers(0, 8))):
+                r, pos = int(rng.integers(0, 3)), int(rng.integers(0, len(b) + 1))
+                if r == 0:
+                    b.insert(pos, int(alphabet[int(rng.integers(0, len(alphabet)))]))
+                elif len(b):
+                    if r == 1:
+                        del b[min(pos, len(b) - 1)]
+                    else:
+                        b[min(pos, len(b) - 1)] = int(alphabet[int(rng.integers(0, len(alphabet)))])
+            cands[i] = bytes(b)
+        data, offsets = rf.ragged(cands)
+        for _c in range(5):
+            metric = str(rng.choice(["levenshtein", "osa", "indel", "lcs_seq", "jaro", "jaro_winkler"]))
+            if metric == "osa" and qlen > 512:
+                continue
+            op = str(rng.choice(["distance", "similarity", "normalized_distance", "normalized_similarity"]))
+            kw = {}
+            is_f = metric in ("jaro", "jaro_winkler") or op.startswith("normalized")
+            if rng.random() < 0.7:
+                if is_f:
+                    kw["score_cutoff"] = float(rng.choice([0.0, 1.0, float(rng.random()), round(float(rng.random()), 1)]))
+                else:
+                    kw["score_cutoff"] = int(rng.choice([0, 1, 2, 3, 7, qlen // 2, qlen, qlen + 5, 10**6, int(rng.integers(0, 80))]))
+            if metric == "levenshtein" and rng.random() < 0.4:
+                kw["weights"] = tuple(int(x) for x in rng.choice([(1, 1, 1), (1, 1, 2), (2, 2, 2), (1, 2, 3), (3, 1, 1), (2, 2, 5), (0, 0, 1), (1, 1, 0)]))
+                if qlen > 500 and kw["weights"] not in ((1, 1, 1), (2, 2, 2), (1, 1, 2), (2, 2, 5), (0, 0, 1)):
+                    continue  # beyond the LDS-resident Wagner-Fischer kernel: a documented RF_ERR_UNSUPPORTED
+            if metric == "jaro_winkler" and rng.random() < 0.5:
+                kw["prefix_weight"] = float(rng.choice([0.0, 0.1, 0.25]))
+            if metric in ("jaro", "jaro_winkler") and (qlen > 512 or int(np.diff(offsets.astype(np.int64)).max(initial=0)) > 512):
+                continue  # documented limit of the Jaro kernels
+            if metric == "levenshtein" and op == "similarity" and "score_cutoff" in kw:
+                continue  # quirk Q2, see _check_many
+            _check_many(metric, q, data, offsets, op, **kw)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RF_FUZZ_SEEDS", "32"))))
+def test_randomized_topk_and_multi(seed):
+    rng = np.random.default_rng(5000 + seed)
+    data, offsets, alphabet = _random_corpus(rng)
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    n = len(corpus)
+    metric = str(rng.choice(["levenshtein", "osa", "indel", "lcs_seq"]))
+    bc = GPU[metric].BatchComparator
+    queries = [alphabet[rng.integers(0, len(alphabet), size=int(rng.choice([0, 3, 20, 33, 64, 70, 150])))].tobytes() for _ in range(int(rng.integers(1, 7)))]
+    cs = [bc(q) for q in queries]
+    for op_name in ("distance", "similarity"):
+        op = OPS[op_name]
+        kw = {}
+        if rng.random() < 0.5 and not (metric == "levenshtein" and op_name == "similarity"):
+            kw["score_cutoff"] = int(rng.integers(0, 60))
+        rows = bc.many_multi(cs, op, corpus, **kw)
+        for j, c in enumerate(cs):
+            full = c.many(op, corpus, **kw)
+            assert (rows[j] == full).all(), (metric, op_name, kw, j)
+            k = int(rng.integers(1, 65))
+            s, i = c.topk(corpus, k, op=op, **kw)
+            alive = [(int(v), idx) for idx, v in enumerate(full) if v != NONE32]
+            alive.sort(key=(lambda t: (t[0], t[1])) if op_name == "distance" else (lambda t: (-t[0], t[1])))
+            assert list(zip(s.tolist(), i.tolist())) == alive[:k], (metric, op_name, kw, j, k, n)
