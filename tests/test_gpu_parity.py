@@ -1175,3 +1175,37 @@ def test_randomized_topk_and_multi(seed):
             alive = [(int(v), idx) for idx, v in enumerate(full) if v != NONE32]
             alive.sort(key=(lambda t: (t[0], t[1])) if op_name == "distance" else (lambda t: (-t[0], t[1])))
             assert list(zip(s.tolist(), i.tolist())) == alive[:k], (metric, op_name, kw, j, k, n)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RF_FUZZ_SEEDS", "24"))))
+def test_randomized_u32_equals_byte_path(seed, tmp_path):
+    """An injective relabelling of the symbols (byte b -> code point 0x390 + 7 * b) must change nothing -- except that a
+    256-symbol corpus now has an overflow class, where the only acceptable outcomes are the same values or a refusal."""
+    rng = np.random.default_rng(9000 + seed)
+    data, offsets, alphabet = _random_corpus(rng)
+    widen = lambda b: (np.frombuffer(bytes(b), dtype=np.uint8).astype(np.uint32) * 7 + 0x390)
+    bcorpus = rf.Corpus.from_ragged(data, offsets)
+    wcorpus = rf.Corpus.from_ragged_u32(widen(data), offsets)
+    own, overflow = wcorpus.alphabet_size()
+    assert own <= 254 and (overflow == 0) == (len(np.unique(data)) <= 254)
+    path = str(tmp_path / "w.rfc")
+    wcorpus.save(path)
+    wloaded = rf.Corpus.load(path)
+    for _ in range(6):
+        metric = str(rng.choice(["levenshtein", "osa", "indel", "lcs_seq", "jaro_winkler"]))
+        if metric == "jaro_winkler" and int(np.diff(offsets.astype(np.int64)).max(initial=0)) > 512:
+            continue
+        qlen = int(rng.choice([0, 4, 30, 64, 90]))
+        q = alphabet[rng.integers(0, len(alphabet), size=qlen)].tobytes()
+        op = OPS[str(rng.choice(["distance", "normalized_similarity"]))]
+        kw = {"score_cutoff": 0.5} if (op == N.OP_NORMALIZED_SIMILARITY and rng.random() < 0.5) else {}
+        ref = GPU[metric].BatchComparator(q).many(op, bcorpus, **kw)
+        wq = GPU[metric].BatchComparator(widen(q))
+        try:
+            got = wq.many(op, wcorpus, **kw)
+        except rf.RfError as e:
+            assert e.status == N.RF_ERR_UNSUPPORTED and overflow > 0
+            continue
+        assert _equal_rows(got, ref), (metric, op, kw, qlen)
+        assert _equal_rows(wq.many(op, wloaded, **kw), ref)
+        assert _equal_rows(wq.stream_many(op, path, len(wcorpus), segment_bytes=32 << 10, **kw), ref)
