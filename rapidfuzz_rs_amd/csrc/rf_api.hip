@@ -6,6 +6,7 @@
 // into kernel parameters.  No metric is ever evaluated on the host: a shape without a device kernel is
 // RF_ERR_UNSUPPORTED.  Product code: never includes or links anything from oracle/.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <atomic>
 #include <unordered_map>
@@ -14,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -315,7 +317,9 @@ static inline uint64_t tile_bytes(uint32_t len) { return (uint64_t)((len + kChun
 
 // Host-side layout of a ragged candidate set (no device needed): the exact bytes rf_corpus_pack uploads.
 struct HostLayout {
-    std::vector<uint8_t> packed;   // tile payloads + one chunk row of tail padding
+    std::unique_ptr<uint8_t[]> packed_storage;  // (not a vector: no single-threaded zero fill of a multi-GB buffer)
+    uint8_t* packed = nullptr;     // tile payloads + one chunk row of tail padding
+    size_t packed_size = 0;
     std::vector<TileDesc> tiles;   // ascending length, every length padded to whole tiles
     std::vector<uint32_t> orig;    // slot -> original index (kPad = padding lane); empty when identity
     uint64_t payload = 0;
@@ -324,8 +328,21 @@ struct HostLayout {
     uint8_t sigma[256];            // symbol renaming applied to the payload
 };
 
+struct PhaseTimer {  // RF_PACK_TIMING=1 prints where rf_corpus_pack spends its time
+    bool on = getenv("RF_PACK_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rf_corpus_pack] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, size_t n, HostLayout* L)
 {
+    PhaseTimer timer;
     if ((n && !offsets) || n >= 0xFFFFFFFFull) {
         set_error("rf_corpus_pack: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -341,11 +358,18 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
             set_error("rf_corpus_pack: offsets must be non-decreasing and candidates shorter than 4 GiB");
             return RF_ERR_INVALID_ARG;
         }
-        const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
-        max_len = std::max(max_len, len);
-        groups[len].count++;
+        max_len = std::max(max_len, (uint32_t)(offsets[i + 1] - offsets[i]));
+    }
+    if (max_len <= (1u << 20)) {  // the usual case: count in a flat table, then keep the non-empty lengths
+        std::vector<uint64_t> counts((size_t)max_len + 1, 0);
+        for (size_t i = 0; i < n; ++i) counts[offsets[i + 1] - offsets[i]]++;
+        for (uint32_t len = 0; len <= max_len; ++len)
+            if (counts[len]) groups[len].count = counts[len];
+    } else {
+        for (size_t i = 0; i < n; ++i) groups[(uint32_t)(offsets[i + 1] - offsets[i])].count++;
     }
 
+    timer.lap("lengths");
     // 2. one group of tiles per distinct length, ascending; every group is padded to whole tiles
     uint64_t slots = 0, data_bytes = 0;
     for (auto& kv : groups) {
@@ -369,12 +393,17 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
 
     // 2b. symbol renaming from the byte histogram of the whole payload
     {
+        // (any permutation is valid; the frequencies only steer it, so a strided sample of ~256 MiB is enough)
         uint64_t hist[256] = {0};
-        const uint64_t total = n ? offsets[n] : 0;
-        for (uint64_t b = n ? offsets[0] : 0; b < total; ++b) hist[bytes[b]]++;
+        const uint64_t first = n ? offsets[0] : 0, total = n ? offsets[n] : 0;
+        const uint64_t span = total - first, block = 1u << 16;
+        const uint64_t stride = std::max<uint64_t>(1, span / (256ull << 20));
+        for (uint64_t b0 = first; b0 < total; b0 += block * stride)
+            for (uint64_t b = b0, e = std::min(total, b0 + block); b < e; ++b) hist[bytes[b]]++;
         make_sigma(hist, L->sigma);
     }
 
+    timer.lap("tiles + symbol histogram");
     // 3. slot of every candidate (k-th of its length, original order preserved) -- sequential, cheap
     std::vector<uint32_t> slot_of(n);
     {
@@ -392,7 +421,16 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
             L->payload += len;
         }
     }
-    L->packed.assign(data_bytes + kTailPad, 0);  // + one readable chunk row: the scan prefetches one row ahead
+    timer.lap("slots");
+    // + one readable chunk row: the scan prefetches one row ahead.  The buffer is zero-filled by the worker threads
+    // below (first touch in parallel: a single-threaded fill of a multi-GB vector costs as much as the scatter).
+    L->packed_storage.reset(new (std::nothrow) uint8_t[data_bytes + kTailPad]);
+    if (!L->packed_storage) {
+        set_error("rf_corpus_pack: out of host memory");
+        return RF_ERR_OOM;
+    }
+    L->packed = L->packed_storage.get();
+    L->packed_size = data_bytes + kTailPad;
     if (!L->identity) L->orig.assign(slots, kPad);
 
     // 4. scatter the (renamed) bytes into the chunk-interleaved tiles; candidates are independent -> threads
@@ -411,20 +449,29 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
             }
             const uint64_t slot = slot_of[i], k = slot - c_slot0;
             if (!L->identity) L->orig[slot] = (uint32_t)i;
-            uint8_t* dst = L->packed.data() + c_off0 + (k / kWave) * tile_bytes(len) + (k % kWave) * kChunk;
+            uint8_t* dst = L->packed + c_off0 + (k / kWave) * tile_bytes(len) + (k % kWave) * kChunk;
             const uint8_t* src = bytes + offsets[i];
             for (uint32_t b = 0; b < len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = L->sigma[src[b]];
         }
     };
     const size_t hw = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 32));
     const size_t nthreads = L->payload < (8u << 20) ? 1 : hw;
-    if (nthreads == 1) {
-        worker(0, n);
-    } else {
+    auto run = [&](auto&& fn) {  // fn(t, nthreads)
+        if (nthreads == 1) {
+            fn(0, 1);
+            return;
+        }
         std::vector<std::thread> pool;
-        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(worker, n * t / nthreads, n * (t + 1) / nthreads);
+        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(fn, t, nthreads);
         for (auto& th : pool) th.join();
-    }
+    };
+    run([&](size_t t, size_t nt) {
+        const uint64_t lo = L->packed_size * t / nt, hi = L->packed_size * (t + 1) / nt;
+        std::memset(L->packed + lo, 0, hi - lo);
+    });
+    timer.lap("allocate + zero");
+    run([&](size_t t, size_t nt) { worker(n * t / nt, n * (t + 1) / nt); });
+    timer.lap("scatter");
     return RF_OK;
 }
 
@@ -436,10 +483,10 @@ rf_status rf_corpus_layout_host(const uint8_t* bytes, const uint64_t* offsets, s
     rf_status s = build_layout(bytes, offsets, n, &L);
     if (s != RF_OK) return s;
     out->n_tiles = (uint32_t)L.tiles.size();
-    out->packed_bytes = L.packed.size();
+    out->packed_bytes = L.packed_size;
     out->n_slots = L.identity ? 0 : L.orig.size();
     out->identity = L.identity ? 1 : 0;
-    out->packed = (uint8_t*)std::malloc(std::max<size_t>(1, L.packed.size()));
+    out->packed = (uint8_t*)std::malloc(std::max<size_t>(1, L.packed_size));
     out->tile_off = (uint64_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint64_t));
     out->tile_len = (uint32_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint32_t));
     out->tile_slot0 = (uint32_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint32_t));
@@ -448,7 +495,7 @@ rf_status rf_corpus_layout_host(const uint8_t* bytes, const uint64_t* offsets, s
         rf_host_layout_free(out);
         return RF_ERR_OOM;
     }
-    std::memcpy(out->packed, L.packed.data(), L.packed.size());
+    std::memcpy(out->packed, L.packed, L.packed_size);
     for (size_t t = 0; t < L.tiles.size(); ++t) {
         out->tile_off[t] = L.tiles[t].data_off;
         out->tile_len[t] = L.tiles[t].len;
@@ -510,10 +557,12 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
         rf_corpus_free(c);
         return st;
     };
-    RF_HIP_C(hipMalloc(&c->d_data, L.packed.size()));
-    RF_HIP_C(hipMemcpy(c->d_data, L.packed.data(), L.packed.size(), hipMemcpyHostToDevice));
-    c->device_bytes = L.packed.size();
-    c->data_bytes = L.packed.size();
+    PhaseTimer timer;
+    RF_HIP_C(hipMalloc(&c->d_data, L.packed_size));
+    RF_HIP_C(hipMemcpy(c->d_data, L.packed, L.packed_size, hipMemcpyHostToDevice));
+    timer.lap("hipMalloc + upload");
+    c->device_bytes = L.packed_size;
+    c->data_bytes = L.packed_size;
     std::memcpy(c->sigma, L.sigma, 256);
     RF_HIP_C(hipMalloc(&c->d_sigma, 256));
     RF_HIP_C(hipMemcpy(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice));
