@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch  # noqa: F401  (pay the one-off import before anything is timed)
 import rapidfuzz_rs_amd as rf
 from rapidfuzz_rs_amd.utils import synth
 
