@@ -596,15 +596,35 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
         set_error("rf_corpus_pack_u32: null elements");
         return RF_ERR_INVALID_ARG;
     }
-    // histogram: a direct table for the BMP, a hash map above it
-    std::vector<uint64_t> low(0x10000, 0);
-    std::unordered_map<uint32_t, uint64_t> high;
-    for (uint64_t i = 0; i < total; ++i) {
-        const uint32_t ch = elems[i];
-        if (ch < 0x10000)
-            ++low[ch];
-        else
-            ++high[ch];
+    // histogram: a direct table for the BMP, a hash map above it; one pair per worker thread, merged afterwards
+    const size_t nthreads = total < (4u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 32));
+    auto run = [&](auto&& fn) {  // fn(t): elements [total * t / nthreads, total * (t + 1) / nthreads)
+        if (nthreads == 1) {
+            fn((size_t)0);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(fn, t);
+        for (auto& th : pool) th.join();
+    };
+    std::vector<std::vector<uint64_t>> lows(nthreads, std::vector<uint64_t>(0x10000, 0));
+    std::vector<std::unordered_map<uint32_t, uint64_t>> highs(nthreads);
+    run([&](size_t t) {
+        std::vector<uint64_t>& lo = lows[t];
+        std::unordered_map<uint32_t, uint64_t>& hi = highs[t];
+        for (uint64_t i = total * t / nthreads, e = total * (t + 1) / nthreads; i < e; ++i) {
+            const uint32_t ch = elems[i];
+            if (ch < 0x10000)
+                ++lo[ch];
+            else
+                ++hi[ch];
+        }
+    });
+    std::vector<uint64_t>& low = lows[0];
+    std::unordered_map<uint32_t, uint64_t>& high = highs[0];
+    for (size_t t = 1; t < nthreads; ++t) {
+        for (uint32_t ch = 0; ch < 0x10000; ++ch) low[ch] += lows[t][ch];
+        for (const auto& kv : highs[t]) high[kv.first] += kv.second;
     }
     std::vector<std::pair<uint64_t, uint32_t>> syms;  // (count, symbol)
     for (uint32_t ch = 0; ch < 0x10000; ++ch)
@@ -622,18 +642,24 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
     std::vector<uint16_t> low_id(0x10000, 0xFFFF);
     for (const auto& kv : alphabet)
         if (kv.first < 0x10000) low_id[kv.first] = kv.second;
-    std::vector<uint8_t> ids(std::max<uint64_t>(1, total));
-    for (uint64_t i = 0; i < total; ++i) {
-        const uint32_t ch = elems[i];
-        if (ch < 0x10000) {
-            ids[i] = low_id[ch] == 0xFFFF ? kOverflowId : (uint8_t)low_id[ch];
-        } else {
-            auto a = alphabet.find(ch);
-            ids[i] = a == alphabet.end() ? kOverflowId : a->second;
-        }
+    std::unique_ptr<uint8_t[]> ids(new (std::nothrow) uint8_t[std::max<uint64_t>(1, total)]);
+    if (!ids) {
+        set_error("rf_corpus_pack_u32: out of host memory");
+        return RF_ERR_OOM;
     }
+    run([&](size_t t) {
+        for (uint64_t i = total * t / nthreads, e = total * (t + 1) / nthreads; i < e; ++i) {
+            const uint32_t ch = elems[i];
+            if (ch < 0x10000) {
+                ids[i] = low_id[ch] == 0xFFFF ? kOverflowId : (uint8_t)low_id[ch];
+            } else {
+                auto a = alphabet.find(ch);
+                ids[i] = a == alphabet.end() ? kOverflowId : a->second;
+            }
+        }
+    });
     rf_corpus* c = nullptr;
-    const rf_status s = rf_corpus_pack(ids.data(), offsets, n, device, &c);
+    const rf_status s = rf_corpus_pack(ids.get(), offsets, n, device, &c);
     if (s != RF_OK) return s;
     c->wide = true;
     c->alphabet = std::move(alphabet);
