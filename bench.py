@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--metric", default="levenshtein", choices=["levenshtein", "indel", "lcs_seq", "osa", "jaro", "jaro_winkler"])
     ap.add_argument("--queries", type=int, default=1, help="Q > 1: Q queries x the corpus through rf_many_multi_u32 (N=1, many mode)")
     ap.add_argument("--cutoff", type=int, default=None)
+    ap.add_argument("--fcutoff", type=float, default=None, help="similarity cutoff for jaro / jaro_winkler (e.g. 0.9)")
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--mode", default="many", choices=["many", "topk"],
                     help="many: one score per candidate (configs[1]); topk: top-k only, no per-candidate output (configs[4])")
@@ -114,6 +115,9 @@ def main():
     call_args = rf.Args()
     if args.cutoff is not None:
         call_args = call_args.score_cutoff(args.cutoff)
+    if args.fcutoff is not None:
+        args.cutoff = args.fcutoff  # the oracle legs below pass it on unchanged
+        call_args = call_args.score_cutoff(args.fcutoff)
     weights = tuple(int(x) for x in args.weights.split(",")) if args.weights else None
     if weights:
         call_args = call_args.weights(rf.WeightTable(*weights))

@@ -876,6 +876,13 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     case RF_JARO_WINKLER: {
         *raw = RAW_JARO;
         p->finish = c->metric == RF_JARO ? FIN_JARO : FIN_JW;
+        // Early-out under a tight cutoff (the reference's own common_char_filter idea, jaro.rs:134-145, applied while the
+        // flags are still being collected): `jaro_need` is the similarity a candidate has to reach.
+        p->jaro_need = -1.0;
+        if (p->has_cutoff && args->prefix_weight >= 0.0 && 4.0 * args->prefix_weight <= 1.0) {
+            const double need = (op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY) ? args->cutoff_f64 : 1.0 - args->cutoff_f64;
+            if (need >= 0.6 && need <= 1.0) p->jaro_need = need;
+        }
         // Single-word path (jaro.rs:574-583) when both strings are <= 64 symbols AFTER the window truncation of
         // jaro.rs:550-565, multi-word path (up to 512 symbols each) otherwise.  Tiles ascend by length and the
         // single-word condition holds for a length prefix, so the corpus splits at one tile index.

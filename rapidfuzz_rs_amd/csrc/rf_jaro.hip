@@ -259,6 +259,18 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
         st.tacc = 0;
         const uint64_t bm0 = mask_lsb64(bound + 1);
         uint32_t bm_lo = uniform((uint32_t)bm0), bm_hi = uniform((uint32_t)(bm0 >> 32));
+        // Early-out under a tight cutoff: after j text symbols the number of common characters can still grow by at most
+        // one per remaining symbol, the similarity is at most (m/len1 + m/len2 + 1) / 3 (common_char_filter, jaro.rs:134-145)
+        // and the Winkler boost at most prefix * weight * (1 - sim) with the prefix already known.  If no lane can reach
+        // `jaro_need` any more (1e-9 of slack covers the reciprocal arithmetic of this bound), the rest of pass 1 and all
+        // of pass 2 are skipped and the tile is None -- exactly what the replayed filters would say.
+        const bool early = p.jaro_need >= 0.0 && nch > 0;
+        double inv1 = 0.0, inv2 = 0.0;
+        if (early) {
+            inv1 = 1.0 / (double)len1_orig;
+            inv2 = 1.0 / (double)len2_orig;
+        }
+        bool dead = false;
         for (uint32_t k = 0; k < nch; ++k) {  // pass 1
             const uint4 nxt = tv.src[(size_t)(k + 1 < nch ? k + 1 : 0) * kWave + lane];  // next chunk, then chunk 0 again
             const uint32_t cols = len2 - k * kChunk;
@@ -270,7 +282,23 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
                 st.t_flag |= (uint64_t)st.tacc << ((k & 2) ? 32 : 0);
                 st.tacc = 0;
             }
+            if (early) {
+                const uint32_t j = min(len2, (k + 1) * kChunk);
+                const uint32_t m_ub = min((uint32_t)__popcll(st.p_flag) + (len2 - j), min(len1, len2));
+                const double m = (double)m_ub;
+                const double sim_ub = (m * inv1 + m * inv2 + 1.0) / 3.0;
+                const double boosted = p.finish == FIN_JW ? sim_ub + (double)r.prefix * p.prefix_weight * (1.0 - sim_ub) : sim_ub;
+                if (__ballot(m_ub != 0 && boosted + 1e-9 >= p.jaro_need) == 0) {
+                    dead = true;
+                    break;
+                }
+            }
             cur = nxt;
+        }
+        if (dead) {
+            const bool valid_d = kUniform ? slot < p.n : idx != kPad;
+            if (valid_d) reinterpret_cast<double*>(p.out)[idx] = __longlong_as_double(0x7FF8000000000000ll);
+            continue;
         }
         r.common = __popcll(st.p_flag);
         for (uint32_t k = 0; k < nch; ++k) {  // pass 2
