@@ -1106,7 +1106,8 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
     if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc((void**)&d_out, row_bytes * q));
 
     // fusable: single-word Levenshtein / LCS-family recurrences; the group key is what the kernel cannot vary per query
-    auto fusable = [&](uint32_t i) { return (raws[i] == RAW_LEV || raws[i] == RAW_LCS) && cs[i]->words == 1 && !ps[i].long_words_pad; };
+    // (a tight cutoff is better served by one early-out launch per query than by the fused kernel, which runs every column)
+    auto fusable = [&](uint32_t i) { return (raws[i] == RAW_LEV || raws[i] == RAW_LCS) && cs[i]->words == 1 && !ps[i].long_words_pad && !ps[i].early; };
     auto same_group = [&](uint32_t a, uint32_t b) {
         return raws[a] == raws[b] && ps[a].finish == ps[b].finish && ps[a].factor == ps[b].factor && ps[a].op == ps[b].op &&
                (ps[a].len1 <= 32) == (ps[b].len1 <= 32);
