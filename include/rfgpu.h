@@ -152,11 +152,15 @@ size_t rf_corpus_count(const rf_corpus *c);          /* n */
 uint64_t rf_corpus_payload_bytes(const rf_corpus *c); /* sum of candidate lengths */
 uint64_t rf_corpus_device_bytes(const rf_corpus *c);  /* HBM held by the packed form */
 int rf_corpus_device(const rf_corpus *c);
-/* Candidates over `char` / u32 elements: elems[offsets[i] .. offsets[i+1]) is candidate i.  The corpus stores one
- * byte per element -- the element's id in this corpus' own alphabet (the 254 most frequent symbols; all rarer ones
- * share one overflow id).  Every metric on this path only asks whether a candidate symbol EQUALS a query symbol, so
- * results are exact for every query made of alphabet symbols and of symbols the corpus does not contain at all;
- * a query containing one of the overflow symbols is refused with RF_ERR_UNSUPPORTED (never answered approximately).
+/* Candidates over `char` / u32 elements: elems[offsets[i] .. offsets[i+1]) is candidate i (0xFFFFFFFF is reserved).
+ * The corpus stores one byte per element -- the element's id in this corpus' own alphabet (the 254 most frequent
+ * symbols; all rarer ones share one overflow id).  Every metric on this path only asks whether a candidate symbol
+ * EQUALS a query symbol, so that byte image is exact for every query made of alphabet symbols and of symbols the
+ * corpus does not contain at all.  A corpus with overflow symbols also keeps its u32 symbol stream on the device
+ * (4 more bytes per symbol); a query that contains overflow symbols is then served from a per-call byte image
+ * translated from it (query symbol -> query-local id, anything else -> 0): still exact, one extra pass over the
+ * stream per call.  Refused with RF_ERR_UNSUPPORTED only: such a query with more than 255 distinct symbols, and such
+ * a query on the streamed path (rf_stream_many_*, which keeps no raw stream).
  * rf_corpus_alphabet_size: symbols with an id of their own (256 for a byte corpus), and how many share the
  * overflow id. */
 rf_status rf_corpus_pack_u32(const uint32_t *elems, const uint64_t *offsets, size_t n, int device, rf_corpus **out);

@@ -75,7 +75,8 @@ struct rf_corpus {
     uint64_t payload_bytes = 0;
     uint64_t device_bytes = 0;
     uint64_t data_bytes = 0;     // packed tile payloads + the tail pad chunk row
-    bool borrowed = false;       // a segment view of a streamed corpus file: owns none of its device buffers
+    bool borrowed = false;       // a view (stream segment, translated image): owns none of its device buffers
+    bool no_prefill = false;     // stream segments: the driver pre-fills the whole result vector once
     uint8_t* d_data = nullptr;
     TileDesc* d_tiles = nullptr;
     uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
@@ -106,6 +107,12 @@ struct rf_corpus {
     uint64_t uid = 0;
     std::unordered_map<uint32_t, uint8_t> alphabet;
     std::unordered_set<uint32_t> overflow;
+    // Only when `overflow` is not empty: the u32 symbol behind every packed byte (d_raw[x] belongs to d_data[x];
+    // 0xFFFFFFFF in padding).  A query containing overflow symbols is served from a per-call byte image translated from
+    // it (Effective below) -- exact, at the price of one extra pass over 4 bytes per symbol.
+    uint32_t* d_raw = nullptr;
+    mutable uint8_t* d_sigma_identity = nullptr;  // for those images (their bytes are query-local ids, not renamed)
+    const rf_corpus* parent = nullptr;            // set on such an image: scratch and locks live in the real corpus
 };
 constexpr uint8_t kOverflowId = 254, kAbsentId = 255;
 static std::atomic<uint64_t> g_corpus_uid{1};
@@ -226,8 +233,9 @@ const uint64_t* rf_comparator_pm(const rf_comparator* c, size_t* block_count)
 // kAbsentId, an id no candidate byte has, so it can never match (which is all any metric on this path asks of it);
 // a symbol the corpus lumped into its overflow class cannot be told apart from the other overflow symbols, so the
 // call is refused rather than answered approximately.  Lowered comparators are cached per corpus.
-static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff)
+static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff, bool* overflow_hit = nullptr)
 {
+    if (overflow_hit) *overflow_hit = false;
     if (!c || !corpus) {
         set_error("null handle");
         return RF_ERR_INVALID_ARG;
@@ -258,8 +266,9 @@ static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const 
         if (a != corpus->alphabet.end()) {
             ids[i] = a->second;
         } else if (corpus->overflow.count(ch)) {
+            if (overflow_hit) *overflow_hit = true;  // make_effective() serves it from a translated image if it can
             set_error("the query contains a symbol this corpus stores in its overflow class (more than 254 distinct symbols, "
-                      "this one among the rarest): no exact answer on the device");
+                      "this one among the rarest), and the corpus carries no raw symbol stream to translate from");
             return RF_ERR_UNSUPPORTED;
         } else {
             ids[i] = kAbsentId;
@@ -274,6 +283,122 @@ static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const 
     }
     c->lowered[corpus->uid] = low;
     *eff = low;
+    return RF_OK;
+}
+
+// What a call actually runs on: the comparator lowered to the corpus' ids and the corpus itself -- or, for a u32 query
+// that contains overflow-class symbols, a comparator over QUERY-LOCAL ids (1..r in order of first appearance) and a
+// per-call byte image of the corpus translated from its raw symbol stream (translate_kernel: query symbol -> its id,
+// anything else -> 0).  The image is a borrowed view (same tiles / slot map) that lives until the object goes out of
+// scope; its payload is released in stream order.
+struct Effective {
+    const rf_comparator* c = nullptr;
+    const rf_corpus* corpus = nullptr;
+    std::unique_ptr<rf_corpus> image;
+    uint8_t* temp = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<uint32_t> keys;
+    std::vector<uint8_t> vals;
+    ~Effective()
+    {
+        if (temp) (void)hipFreeAsync(temp, stream);
+    }
+};
+
+static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hipStream_t st, Effective* e)
+{
+    bool overflow_hit = false;
+    const rf_status rs = resolve(c_in, corpus, &e->c, &overflow_hit);
+    e->corpus = corpus;
+    e->stream = st;
+    if (rs == RF_OK || !overflow_hit || !corpus->d_raw) return rs;
+
+    // query-local ids
+    const size_t len = c_in->wide ? c_in->s1w.size() : c_in->s1.size();
+    std::unordered_map<uint32_t, uint8_t> local;
+    std::vector<uint8_t> ids(len);
+    for (size_t i = 0; i < len; ++i) {
+        const uint32_t ch = c_in->wide ? c_in->s1w[i] : (uint32_t)c_in->s1[i];
+        auto it = local.find(ch);
+        if (it == local.end()) {
+            if (local.size() >= 255) {
+                set_error("a query with more than 255 distinct symbols cannot be searched in a corpus with an overflow class");
+                return RF_ERR_UNSUPPORTED;
+            }
+            it = local.emplace(ch, (uint8_t)(local.size() + 1)).first;
+        }
+        ids[i] = it->second;
+    }
+    {
+        std::lock_guard<std::mutex> lock(c_in->mu);
+        auto it = c_in->lowered.find(~0ull);  // the query-local lowering does not depend on the corpus
+        if (it == c_in->lowered.end()) {
+            rf_comparator* low = nullptr;
+            const rf_status s = rf_comparator_new(c_in->metric, ids.data(), ids.size(), &low);
+            if (s != RF_OK) return s;
+            it = c_in->lowered.emplace(~0ull, low).first;
+        }
+        e->c = it->second;
+    }
+    // (symbol -> id) as an open-addressing table the kernel stages in LDS
+    uint32_t cap = 8;
+    while (cap < 2 * local.size()) cap *= 2;
+    e->keys.assign(cap, 0xFFFFFFFFu);
+    e->vals.assign(cap, 0);
+    for (const auto& kv : local) {
+        if (kv.first == 0xFFFFFFFFu) continue;  // reserved: the padding value of the raw stream, never a stored symbol
+        uint32_t h = (kv.first * 2654435761u) & (cap - 1);
+        while (e->keys[h] != 0xFFFFFFFFu) h = (h + 1) & (cap - 1);
+        e->keys[h] = kv.first;
+        e->vals[h] = kv.second;
+    }
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    {
+        std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+        if (!corpus->d_sigma_identity) {
+            uint8_t ident[256];
+            for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
+            RF_HIP(hipMalloc((void**)&corpus->d_sigma_identity, 256));
+            RF_HIP(hipMemcpy(corpus->d_sigma_identity, ident, 256, hipMemcpyHostToDevice));
+        }
+    }
+    const size_t table_off = (corpus->data_bytes + 15) / 16 * 16;
+    RF_HIP(hipMallocAsync((void**)&e->temp, table_off + (size_t)cap * 5, st));
+    uint32_t* d_keys = reinterpret_cast<uint32_t*>(e->temp + table_off);
+    uint8_t* d_vals = reinterpret_cast<uint8_t*>(d_keys + cap);
+    RF_HIP(hipMemcpyAsync(d_keys, e->keys.data(), (size_t)cap * 4, hipMemcpyHostToDevice, st));
+    RF_HIP(hipMemcpyAsync(d_vals, e->vals.data(), cap, hipMemcpyHostToDevice, st));
+    const hipError_t le = launch_translate(corpus->d_raw, corpus->data_bytes, d_keys, d_vals, cap, e->temp, st);
+    if (le != hipSuccess) {
+        set_error(std::string("translate: ") + hipGetErrorString(le));
+        return RF_ERR_HIP;
+    }
+    e->image.reset(new (std::nothrow) rf_corpus());
+    if (!e->image) return RF_ERR_OOM;
+    rf_corpus& v = *e->image;
+    v.borrowed = true;
+    v.parent = corpus;
+    v.uid = corpus->uid;
+    v.device = corpus->device;
+    v.n = corpus->n;
+    v.payload_bytes = corpus->payload_bytes;
+    v.data_bytes = corpus->data_bytes;
+    v.d_data = e->temp;
+    v.d_tiles = corpus->d_tiles;
+    v.d_orig = corpus->d_orig;
+    v.n_tiles = corpus->n_tiles;
+    v.max_len = corpus->max_len;
+    v.uniform = corpus->uniform;
+    v.uniform_len = corpus->uniform_len;
+    v.lengths = corpus->lengths;
+    v.length_first_tile = corpus->length_first_tile;
+    for (int i = 0; i < 256; ++i) v.sigma[i] = (uint8_t)i;
+    v.d_sigma = corpus->d_sigma_identity;
+    e->corpus = &v;
     return RF_OK;
 }
 
@@ -526,15 +651,8 @@ void rf_host_layout_free(rf_host_layout* l)
         }                                                                                              \
     } while (0)
 
-rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n, int device, rf_corpus** out)
+static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, rf_corpus** out)
 {
-    if (!out) {
-        set_error("rf_corpus_pack: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    HostLayout L;
-    rf_status s = build_layout(bytes, offsets, n, &L);
-    if (s != RF_OK) return s;
     DeviceGuard guard(device);
     if (!guard.ok) {
         set_error("rf_corpus_pack: cannot select device");
@@ -578,6 +696,18 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     }
     *out = c;
     return RF_OK;
+}
+
+rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n, int device, rf_corpus** out)
+{
+    if (!out) {
+        set_error("rf_corpus_pack: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    HostLayout L;
+    const rf_status s = build_layout(bytes, offsets, n, &L);
+    if (s != RF_OK) return s;
+    return corpus_from_layout(L, n, device, out);
 }
 
 // Candidates over `char` (or any u32) elements.  The corpus gets its own alphabet: the 254 most frequent symbols
@@ -626,6 +756,10 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
         for (uint32_t ch = 0; ch < 0x10000; ++ch) low[ch] += lows[t][ch];
         for (const auto& kv : highs[t]) high[kv.first] += kv.second;
     }
+    if (high.count(0xFFFFFFFFu)) {
+        set_error("rf_corpus_pack_u32: the symbol 0xFFFFFFFF is reserved");
+        return RF_ERR_INVALID_ARG;
+    }
     std::vector<std::pair<uint64_t, uint32_t>> syms;  // (count, symbol)
     for (uint32_t ch = 0; ch < 0x10000; ++ch)
         if (low[ch]) syms.emplace_back(low[ch], ch);
@@ -658,12 +792,57 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
             }
         }
     });
+    HostLayout L;
+    rf_status s = build_layout(ids.get(), offsets, n, &L);
+    if (s != RF_OK) return s;
     rf_corpus* c = nullptr;
-    const rf_status s = rf_corpus_pack(ids.get(), offsets, n, device, &c);
+    s = corpus_from_layout(L, n, device, &c);
     if (s != RF_OK) return s;
     c->wide = true;
     c->alphabet = std::move(alphabet);
     c->overflow = std::move(overflow);
+    if (!c->overflow.empty()) {
+        // the u32 symbol behind every packed byte, same chunk-interleaved positions (one worker per range of tiles)
+        std::unique_ptr<uint32_t[]> raw(new (std::nothrow) uint32_t[L.packed_size]);
+        if (!raw) {
+            rf_corpus_free(c);
+            set_error("rf_corpus_pack_u32: out of host memory");
+            return RF_ERR_OOM;
+        }
+        const size_t n_tiles = L.tiles.size();
+        auto tiles_worker = [&](size_t t0, size_t t1) {
+            for (size_t t = t0; t < t1; ++t) {
+                const TileDesc& td = L.tiles[t];
+                const uint64_t tb = tile_bytes(td.len);
+                std::memset(raw.get() + td.data_off, 0xFF, tb * sizeof(uint32_t));
+                for (uint32_t r = 0; r < (uint32_t)kWave; ++r) {
+                    const uint64_t slot = (uint64_t)td.slot0 + r;
+                    const uint64_t i = L.identity ? slot : (uint64_t)L.orig[slot];
+                    if ((L.identity && i >= n) || (!L.identity && i == kPad)) continue;
+                    const uint32_t* src = elems + offsets[i];
+                    uint32_t* dst = raw.get() + td.data_off + (uint64_t)r * kChunk;
+                    for (uint32_t b = 0; b < td.len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = src[b];
+                }
+            }
+        };
+        std::memset(raw.get() + (L.packed_size - kTailPad), 0xFF, kTailPad * sizeof(uint32_t));
+        if (nthreads == 1) {
+            tiles_worker(0, n_tiles);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(tiles_worker, n_tiles * t / nthreads, n_tiles * (t + 1) / nthreads);
+            for (auto& th : pool) th.join();
+        }
+        DeviceGuard guard(device);
+        hipError_t e = hipMalloc((void**)&c->d_raw, L.packed_size * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(c->d_raw, raw.get(), L.packed_size * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            rf_corpus_free(c);
+            set_error(std::string("rf_corpus_pack_u32: ") + hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;
+        }
+        c->device_bytes += L.packed_size * sizeof(uint32_t);
+    }
     *out = c;
     return RF_OK;
 }
@@ -741,6 +920,8 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_orig) (void)hipFree(c->d_orig);
     if (c->d_sigma) (void)hipFree(c->d_sigma);
+    if (c->d_raw) (void)hipFree(c->d_raw);
+    if (c->d_sigma_identity) (void)hipFree(c->d_sigma_identity);
     for (auto& kv : c->topk_scratch) (void)hipFree(kv.second.cand);
     delete c;
 }
@@ -1002,17 +1183,23 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
                 p->tile_begin = corpus->length_first_tile[first];
                 p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
             }
-            p->prefill_none = !corpus->borrowed && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
+            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
         }
     }
     return RF_OK;
 }
 
-static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus, rf_op op, const rf_args* args, void* out,
+static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out,
                           rf_mem out_mem, void* stream, bool f64_out)
 {
-    const rf_comparator* c = nullptr;
-    if (const rf_status rs = resolve(c_in, corpus, &c); rs != RF_OK) return rs;
+    if (!c_in || !corpus_in || !args) {
+        set_error("null handle or args");
+        return RF_ERR_INVALID_ARG;
+    }
+    Effective eff;
+    if (const rf_status rs = make_effective(c_in, corpus_in, (hipStream_t)stream, &eff); rs != RF_OK) return rs;
+    const rf_comparator* c = eff.c;
+    const rf_corpus* corpus = eff.corpus;
     ScanParams p;
     RawKind raw = RAW_LEV;
     rf_status s = plan(c, corpus, op, args, f64_out, &p, &raw);
@@ -1090,6 +1277,17 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
     std::vector<ScanParams> ps(q);
     std::vector<RawKind> raws(q, RAW_LEV);
     std::vector<const rf_comparator*> eff(q, nullptr);
+    for (uint32_t i = 0; i < q; ++i) {
+        bool overflow_hit = false;
+        if (resolve(cs_in[i], corpus, &eff[i], &overflow_hit) != RF_OK && overflow_hit && corpus->d_raw) {
+            // a query with overflow-class symbols needs its own translated image of the corpus: one launch per query
+            for (uint32_t j = 0; j < q; ++j) {
+                const rf_status sj = run_many(cs_in[j], corpus, op, args, static_cast<char*>(out) + (size_t)j * row_bytes, out_mem, stream, f64_out);
+                if (sj != RF_OK) return sj;
+            }
+            return RF_OK;
+        }
+    }
     for (uint32_t i = 0; i < q; ++i) {
         rf_status s = resolve(cs_in[i], corpus, &eff[i]);
         if (s == RF_OK) s = plan(eff[i], corpus, op, args, f64_out, &ps[i], &raws[i]);
@@ -1179,12 +1377,15 @@ rf_status rf_many_multi_f64(const rf_comparator* const* cs, uint32_t q, const rf
 // top-k
 // ---------------------------------------------------------------------------------------------------
 // shared by rf_topk_u32 (host results) and rf_topk_keys_device (device keys, fully asynchronous)
-static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
+static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, uint32_t k,
                            uint32_t key_index_base, uint64_t* d_best /*device, k entries*/, uint32_t* out_all,
                            rf_mem out_all_mem, hipStream_t st, bool* desc)
 {
-    const rf_comparator* c = nullptr;
-    if (const rf_status rs = resolve(c_in, corpus, &c); rs != RF_OK) return rs;
+    Effective eff;
+    if (const rf_status rs = make_effective(c_in, corpus_in, st, &eff); rs != RF_OK) return rs;
+    const rf_comparator* c = eff.c;
+    const rf_corpus* corpus = eff.corpus;
+    const rf_corpus* owner = corpus->parent ? corpus->parent : corpus;  // scratch and locks live in the real corpus
     if (k == 0 || k > (uint32_t)kWave) {
         set_error("top-k: k must be in 1..64 (one list entry per wavefront lane)");
         return k == 0 ? RF_ERR_INVALID_ARG : RF_ERR_UNSUPPORTED;
@@ -1211,9 +1412,9 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, r
     // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list
     rf_corpus::TopkScratch sc;
     {
-        std::lock_guard<std::mutex> lock(corpus->scratch_mu);
-        auto it = corpus->topk_scratch.find(st);
-        if (it == corpus->topk_scratch.end()) {
+        std::lock_guard<std::mutex> lock(owner->scratch_mu);
+        auto it = owner->topk_scratch.find(st);
+        if (it == owner->topk_scratch.end()) {
             const size_t cap = (size_t)scan_grid(corpus->n_tiles) * kWave;
             uint8_t* mem = nullptr;
             RF_HIP(hipMalloc((void**)&mem, cap * sizeof(uint64_t) + 16));
@@ -1227,7 +1428,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, r
                 set_error(std::string("top-k scratch: ") + hipGetErrorString(e0));
                 return RF_ERR_HIP;
             }
-            corpus->topk_scratch.emplace(st, sc);
+            owner->topk_scratch.emplace(st, sc);
         } else {
             sc = it->second;
         }
@@ -1242,7 +1443,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, r
     uint32_t* d_all = out_all;
     if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
     p.out = d_all;
-    std::lock_guard<std::mutex> enqueue_lock(corpus->topk_enqueue_mu);
+    std::lock_guard<std::mutex> enqueue_lock(owner->topk_enqueue_mu);
     hipError_t e = hipSuccess;
     // Sample pass: the top-k of ~1000 evenly spaced tiles costs 0.1 % of the scan and its k-th best key is a valid
     // launch-wide bound from the first tile on -- without it every wavefront pays k ln(n_wave / k) list insertions to
@@ -1265,10 +1466,10 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus, r
     if (e == hipSuccess) e = launch_topk_final(sc.cand, sc.count, 0, k, d_best, sc.bound, false, st);
     if (e != hipSuccess) {
         // the scratch may be left half-armed: drop it so the next call starts from a fresh one
-        std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+        std::lock_guard<std::mutex> lock(owner->scratch_mu);
         (void)hipStreamSynchronize(st);
         (void)hipFree(sc.cand);
-        corpus->topk_scratch.erase(st);
+        owner->topk_scratch.erase(st);
         set_error(std::string("top-k: ") + hipGetErrorString(e));
         return RF_ERR_HIP;
     }
@@ -1375,10 +1576,11 @@ struct FileHeader {  // little endian, 512 bytes
     uint64_t off_lengths, off_tiles, off_orig, off_alphabet, off_data;
     uint32_t n_alphabet, n_overflow;
     uint8_t sigma[256];
-    uint8_t reserved[512 - 8 - 8 - 8 - 16 - 16 - 40 - 8 - 256];
+    uint64_t off_raw;  // flags & 4: the u32 symbol stream parallel to the payload (data_bytes entries)
+    uint8_t reserved[512 - 8 - 8 - 8 - 16 - 16 - 40 - 8 - 256 - 8];
 };
 static_assert(sizeof(FileHeader) == 512, "header layout");
-constexpr uint32_t kFileVersion = 1, kFlagUniform = 1, kFlagWide = 2;
+constexpr uint32_t kFileVersion = 1, kFlagUniform = 1, kFlagWide = 2, kFlagRaw = 4;
 
 struct FileCloser {
     FILE* f;
@@ -1420,7 +1622,7 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
     std::memset(&h, 0, sizeof(h));
     std::memcpy(h.magic, "RFCORPUS", 8);
     h.version = kFileVersion;
-    h.flags = (c->uniform ? kFlagUniform : 0) | (c->wide ? kFlagWide : 0);
+    h.flags = (c->uniform ? kFlagUniform : 0) | (c->wide ? kFlagWide : 0) | (c->d_raw ? kFlagRaw : 0);
     h.n = c->n;
     h.n_tiles = c->n_tiles;
     h.max_len = c->max_len;
@@ -1438,6 +1640,7 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
     h.off_orig = off, off += (uint64_t)n_slots * 4;
     h.off_alphabet = off, off += (uint64_t)h.n_alphabet * 8 + (uint64_t)h.n_overflow * 4;
     h.off_data = (off + 4095) / 4096 * 4096;  // page-aligned payload
+    h.off_raw = (h.off_data + c->data_bytes + 4095) / 4096 * 4096;
     bool ok = write_all(fc.f, &h, sizeof(h));
     ok = ok && write_all(fc.f, c->lengths.data(), c->lengths.size() * 4) && write_all(fc.f, c->length_first_tile.data(), c->length_first_tile.size() * 4);
     if (!c->uniform) {
@@ -1459,6 +1662,15 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
         const size_t m = (size_t)std::min<uint64_t>(buf.size(), c->data_bytes - done);
         RF_HIP(hipMemcpy(buf.data(), c->d_data + done, m, hipMemcpyDeviceToHost));
         ok = write_all(fc.f, buf.data(), m);
+    }
+    if (c->d_raw) {
+        ok = ok && fseeko(fc.f, (off_t)h.off_raw, SEEK_SET) == 0;
+        const uint64_t raw_bytes = c->data_bytes * sizeof(uint32_t);
+        for (uint64_t done = 0; ok && done < raw_bytes; done += buf.size()) {
+            const size_t m = (size_t)std::min<uint64_t>(buf.size(), raw_bytes - done);
+            RF_HIP(hipMemcpy(buf.data(), reinterpret_cast<const uint8_t*>(c->d_raw) + done, m, hipMemcpyDeviceToHost));
+            ok = write_all(fc.f, buf.data(), m);
+        }
     }
     if (!ok || std::fflush(fc.f) != 0) {
         set_error(std::string("rf_corpus_save: write failed: ") + path);
@@ -1541,6 +1753,19 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
         RF_HIP_C(hipMemcpy(c->d_data + done, buf.data(), m, hipMemcpyHostToDevice));
     }
     c->device_bytes = c->data_bytes;
+    if (h.flags & kFlagRaw) {
+        const uint64_t raw_bytes = c->data_bytes * sizeof(uint32_t);
+        RF_HIP_C(hipMalloc((void**)&c->d_raw, std::max<uint64_t>(1, raw_bytes)));
+        for (uint64_t done = 0; done < raw_bytes; done += buf.size()) {
+            const size_t m = (size_t)std::min<uint64_t>(buf.size(), raw_bytes - done);
+            if (!read_at(fc.f, h.off_raw + done, buf.data(), m)) {
+                set_error("corpus file truncated");
+                return fail(RF_ERR_INVALID_ARG);
+            }
+            RF_HIP_C(hipMemcpy(reinterpret_cast<uint8_t*>(c->d_raw) + done, buf.data(), m, hipMemcpyHostToDevice));
+        }
+        c->device_bytes += raw_bytes;
+    }
     RF_HIP_C(hipMalloc(&c->d_sigma, 256));
     RF_HIP_C(hipMemcpy(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice));
     if (!c->uniform) {
@@ -1645,6 +1870,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         ok = hip_ok(hipMemcpyAsync(sl.d_data, sl.h_data, bytes + kTailPad, hipMemcpyHostToDevice, s_copy));
         rf_corpus seg;  // a view: owns nothing
         seg.borrowed = true;
+        seg.no_prefill = true;
         seg.uid = meta.uid;  // one lowered comparator serves every segment of a u32 corpus
         seg.device = device;
         seg.wide = meta.wide;

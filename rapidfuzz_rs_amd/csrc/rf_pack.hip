@@ -76,4 +76,53 @@ hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// u32 corpora with an overflow class: a query that contains overflow symbols gets its own byte image of the corpus.
+// `raw` is parallel to the packed payload (raw[x] = the u32 symbol behind packed byte x, 0xFFFFFFFF in padding); every
+// symbol of the query maps to its query-local id (1..r), everything else to 0 -- which is all a metric on this path
+// needs to know about a candidate symbol.  The (symbol -> id) pairs arrive as an open-addressing table of `cap` slots
+// (power of two, key 0xFFFFFFFF = empty) and are staged in LDS; 16 symbols in, one 16-byte chunk out per thread.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void translate_kernel(const uint32_t* __restrict__ raw, uint64_t n_chunks, const uint32_t* __restrict__ keys,
+                                                        const uint8_t* __restrict__ vals, uint32_t cap, uint4* __restrict__ out)
+{
+    extern __shared__ uint32_t lds_keys[];  // cap keys, then cap ids (one byte each)
+    uint8_t* lds_vals = reinterpret_cast<uint8_t*>(lds_keys + cap);
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
+        lds_keys[i] = keys[i];
+        lds_vals[i] = vals[i];
+    }
+    __syncthreads();
+    const uint32_t mask = cap - 1;
+    auto map = [&](uint32_t sym) -> uint32_t {
+        uint32_t h = (sym * 2654435761u) & mask;
+        while (true) {
+            const uint32_t k = lds_keys[h];
+            if (k == sym) return lds_vals[h];
+            if (k == 0xFFFFFFFFu) return 0;
+            h = (h + 1) & mask;
+        }
+    };
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_chunks; x += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4* src = reinterpret_cast<const uint4*>(raw) + x * 4;
+        uint32_t o[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint4 s4 = src[w];
+            o[w] = map(s4.x) | (map(s4.y) << 8) | (map(s4.z) << 16) | (map(s4.w) << 24);
+        }
+        out[x] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+hipError_t launch_translate(const uint32_t* raw, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
+                            hipStream_t stream)
+{
+    const uint64_t n_chunks = n_bytes / 16;  // the payload is whole 16-byte chunks by construction
+    if (n_chunks == 0) return hipSuccess;
+    const int grid = (int)std::min<uint64_t>((n_chunks + 255) / 256, (uint64_t)scan_max_grid() * 4);
+    hipLaunchKernelGGL(translate_kernel, dim3(grid), dim3(256), (size_t)cap * 5, stream, raw, n_chunks, keys, vals, cap, reinterpret_cast<uint4*>(out));
+    return hipGetLastError();
+}
+
 }  // namespace rf
