@@ -41,6 +41,25 @@ public:
         }
         check(rf_corpus_pack(bytes.data(), offsets.data(), candidates.size(), device, &h_));
     }
+    /// candidates as code points (`s.chars()` in the reference): one u32 per element, the corpus keeps its own alphabet
+    Corpus(const std::vector<std::u32string_view>& candidates, int device = 0)
+    {
+        std::vector<uint32_t> elems;
+        std::vector<uint64_t> offsets{0};
+        for (auto c : candidates) {
+            elems.insert(elems.end(), c.begin(), c.end());
+            offsets.push_back(elems.size());
+        }
+        check(rf_corpus_pack_u32(elems.data(), offsets.data(), candidates.size(), device, &h_));
+    }
+    /// a packed corpus written by save()
+    static Corpus load(const std::string& path, int device = 0)
+    {
+        Corpus c;
+        check(rf_corpus_load(path.c_str(), device, &c.h_));
+        return c;
+    }
+    void save(const std::string& path) const { check(rf_corpus_save(h_, path.c_str())); }
     /// n rows of `len` bytes already in device memory
     Corpus(const void* d_rows, size_t n, size_t len, size_t stride, int device = 0, void* stream = nullptr)
     {
@@ -54,6 +73,7 @@ public:
     const rf_corpus* handle() const { return h_; }
 
 private:
+    Corpus() = default;
     rf_corpus* h_ = nullptr;
 };
 
@@ -101,6 +121,10 @@ public:
     explicit BatchComparator(std::string_view s1)  // BatchComparator::new
     {
         check(rf_comparator_new(M, reinterpret_cast<const uint8_t*>(s1.data()), s1.size(), &h_));
+    }
+    explicit BatchComparator(std::u32string_view s1)  // BatchComparator::new(s1.chars())
+    {
+        check(rf_comparator_new_u32(M, reinterpret_cast<const uint32_t*>(s1.data()), s1.size(), &h_));
     }
     BatchComparator(const BatchComparator& o) { check(rf_comparator_clone(o.h_, &h_)); }  // #[derive(Clone)]
     BatchComparator& operator=(const BatchComparator&) = delete;

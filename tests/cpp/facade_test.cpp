@@ -48,6 +48,17 @@ int main(int argc, char** argv)
         auto m = distance::levenshtein::BatchComparator::distance_many_multi({&scorer, &a, &b, &c}, corpus);
         EXPECT(m.size() == 4 && *m[0][1] == 1 && *m[1][1] == 0 && *m[2][2] == 0 && *m[3][0] == 7 && *m[3][3] == 0);
     }
+    {   // `char` elements: levenshtein.rs:2163-2169 ("Иванко" / "Петрунко" = 5), then a save / load round trip
+        distance::levenshtein::BatchComparator ivanko(std::u32string_view(U"\u0418\u0432\u0430\u043d\u043a\u043e"));
+        Corpus wide(std::vector<std::u32string_view>{U"\u041f\u0435\u0442\u0440\u0443\u043d\u043a\u043e", U"\u0418\u0432\u0430\u043d", U"plain"});
+        auto d = ivanko.distance_many(wide);
+        EXPECT(*d[0] == 5 && *d[1] == 2 && *d[2] == 6);
+        wide.save("/tmp/rf_facade_test.rfc");
+        Corpus again = Corpus::load("/tmp/rf_facade_test.rfc");
+        auto d2 = ivanko.distance_many(again);
+        EXPECT(*d2[0] == 5 && *d2[1] == 2 && *d2[2] == 6);
+        std::remove("/tmp/rf_facade_test.rfc");
+    }
     EXPECT(distance::indel::distance("lewenstein", "levenshtein") == 3);
     EXPECT(distance::lcs_seq::similarity("lewenstein", "levenshtein") == 9);
     EXPECT(std::fabs(distance::jaro::similarity("james", "robert") - 0.455556) < 1e-4);
