@@ -46,7 +46,11 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
     stale = force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
-        subprocess.run(["make", "-C", _HERE, "librf_oracle.so"], check=True, capture_output=True)
+        import fcntl
+
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # one builder at a time (parallel test workers / ranks)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.run(["make", "-C", _HERE, "librf_oracle.so"], check=True, capture_output=True)
     return _LIB_PATH
 
 

@@ -75,13 +75,21 @@ def build(force: bool = False) -> str:
     src_dir = os.path.join(_HERE, "csrc")
     deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp")) or f == "Makefile"]
     deps.append(os.path.join(_HERE, "..", "include", "rfgpu.h"))
-    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
-    if stale:
+    def is_stale() -> bool:
+        return force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
+
+    if is_stale():
         if not os.path.exists("/opt/rocm/bin/hipcc"):
             raise RuntimeError("librfgpu.so is stale or missing and hipcc is not available to rebuild it")
-        r = subprocess.run(["make", "-C", src_dir, "-j4"], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("building librfgpu.so failed:\n" + r.stdout + r.stderr)
+        # one builder at a time: the ranks of a multi-GPU launch import the package simultaneously
+        import fcntl
+
+        with open(os.path.join(src_dir, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if is_stale():
+                r = subprocess.run(["make", "-C", src_dir, "-j4"], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("building librfgpu.so failed:\n" + r.stdout + r.stderr)
     return LIB_PATH
 
 
