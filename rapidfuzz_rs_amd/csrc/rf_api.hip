@@ -1091,6 +1091,30 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
                 return RF_ERR_UNSUPPORTED;
             }
         }
+        if (p->jaro_need >= 0.0) {
+            // Length window, the reference's length_filter (jaro.rs:122-131) hoisted to the host: with m = min(len1, L)
+            // the similarity of a candidate of length L is at most (m/len1 + m/L + 1)/3 (+ the largest Winkler boost);
+            // lengths that cannot reach `jaro_need` are never read -- pre-filled with None like the usize metrics'.
+            const auto& L = corpus->lengths;
+            size_t first = L.size(), last = 0;
+            const double boost = c->metric == RF_JARO_WINKLER ? 4.0 * args->prefix_weight : 0.0;
+            for (size_t i = 0; i < L.size(); ++i) {
+                const double l1 = (double)len1, l2 = (double)L[i], m = std::min(l1, l2);
+                double ub = (len1 == 0 && L[i] == 0) ? 1.0 : ((len1 == 0 || L[i] == 0) ? 0.0 : (m / l1 + m / l2 + 1.0) / 3.0);
+                ub += boost * (1.0 - ub);
+                if (ub + 1e-9 >= p->jaro_need) {
+                    first = std::min(first, i);
+                    last = i;
+                }
+            }
+            if (first == L.size()) {
+                p->tile_begin = p->tile_end = corpus->n_tiles;
+            } else {
+                p->tile_begin = corpus->length_first_tile[first];
+                p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
+            }
+            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
+        }
         return RF_OK;  // the PM row stride may exceed kMaxWords: only block 0 is read
     }
     }

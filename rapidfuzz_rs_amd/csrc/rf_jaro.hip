@@ -489,8 +489,8 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
     // (tiles ascend by length, and the single-word condition holds for a length prefix)
     const dim3 b(kWave * kWavesPerBlock);
     ScanParams q = p;
-    q.tile_begin = 0;
-    q.tile_end = p.jaro_split;
+    q.tile_begin = p.tile_begin;  // (the cutoff's length window, plan())
+    q.tile_end = std::min(p.jaro_split, p.tile_end);
     if (q.tile_end > q.tile_begin) {
         const dim3 g(scan_grid(q.tile_end - q.tile_begin));
         if (p.tiles)
@@ -498,8 +498,8 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
         else
             hipLaunchKernelGGL(jaro_word_kernel<true>, g, b, 256 * sizeof(uint64_t), stream, q);
     }
-    q.tile_begin = p.jaro_split;
-    q.tile_end = p.n_tiles;
+    q.tile_begin = std::max(p.jaro_split, p.tile_begin);
+    q.tile_end = p.tile_end;
     if (q.tile_end > q.tile_begin) {
         const dim3 g(scan_grid(q.tile_end - q.tile_begin));
         const size_t lds = ((size_t)256 * p.words + p.words + 1) * sizeof(uint64_t);
