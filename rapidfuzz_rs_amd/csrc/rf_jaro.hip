@@ -211,7 +211,7 @@ __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const ui
     }
 }
 
-template <bool kUniform>
+template <bool kUniform, bool kEarly>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
 {
     const uint32_t W = p.words;  // PM row stride; only block 0 is read on this path (jaro.rs:172, pm.get(0, ..))
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
         // and the Winkler boost at most prefix * weight * (1 - sim) with the prefix already known.  If no lane can reach
         // `jaro_need` any more (1e-9 of slack covers the reciprocal arithmetic of this bound), the rest of pass 1 and all
         // of pass 2 are skipped and the tile is None -- exactly what the replayed filters would say.
-        const bool early = p.jaro_need >= 0.0 && nch > 0;
+        const bool early = kEarly && nch > 0;  // (a separate instantiation: the plain kernel keeps its registers and loop shape)
         double inv1 = 0.0, inv2 = 0.0;
         if (early) {
             inv1 = 1.0 / (double)len1_orig;
@@ -493,10 +493,10 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
     q.tile_end = std::min(p.jaro_split, p.tile_end);
     if (q.tile_end > q.tile_begin) {
         const dim3 g(scan_grid(q.tile_end - q.tile_begin));
-        if (p.tiles)
-            hipLaunchKernelGGL(jaro_word_kernel<false>, g, b, 256 * sizeof(uint64_t), stream, q);
-        else
-            hipLaunchKernelGGL(jaro_word_kernel<true>, g, b, 256 * sizeof(uint64_t), stream, q);
+        const bool early = p.jaro_need >= 0.0;
+        auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : jaro_word_kernel<false, false>)
+                         : (early ? jaro_word_kernel<true, true> : jaro_word_kernel<true, false>);
+        hipLaunchKernelGGL(k, g, b, 256 * sizeof(uint64_t), stream, q);
     }
     q.tile_begin = std::max(p.jaro_split, p.tile_begin);
     q.tile_end = p.tile_end;

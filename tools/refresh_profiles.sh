@@ -22,3 +22,9 @@ b multi4_levenshtein --queries 4 --no-cpu-baseline
 b multi4_indel --metric indel --queries 4 --no-cpu-baseline
 cp gpurun_out/c2_* gpurun_out/c4_* gpurun_out/traffic.json gpurun_out/profiles/ 2>/dev/null
 ls -la gpurun_out/profiles
+b wf_weights_1_2_3 --weights 1,2,3 --candidates 20000000 --steps 3 --warmup 1
+b indel_cutoff12 --metric indel --cutoff 12
+b osa_cutoff3 --metric osa --cutoff 3
+b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
+RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/profiles/bench_sharded_path_world1.json
+ls gpurun_out/profiles | wc -l
