@@ -384,7 +384,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const
         uint64_t last_mask = (1ull << (start_range % 64)) - 1, first_mask = ~0ull;
         const uint32_t nch = (len2 + kChunk - 1) / kChunk;
         uint64_t tcur = 0;
-        for (uint32_t c = 0; c < nch; ++c) {
+        // the same early-out as jaro_word_kernel: after every chunk, can any lane still reach `jaro_need`?
+        const bool early = p.jaro_need >= 0.0 && nch > 0;
+        const double inv1 = early ? 1.0 / (double)len1_orig : 0.0, inv2 = early ? 1.0 / (double)len2_orig : 0.0;
+        bool dead = false;
+        for (uint32_t c = 0; c < nch && !dead; ++c) {
             uint4 data = tv.src[(size_t)c * kWave + lane];
             const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
             for (uint32_t b = 0; b < cols; ++b) {
@@ -431,6 +435,22 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const
                 data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
                 data.w >>= 8;
             }
+            if (early) {
+                uint32_t so_far = 0;
+#pragma unroll
+                for (int w = 0; w < kJaroWords; ++w) so_far += __popcll(P[w]);
+                const uint32_t j = min(len2, (c + 1) * kChunk);
+                const uint32_t m_ub = min(so_far + (len2 - j), min(len1, len2));
+                const double m = (double)m_ub;
+                const double sim_ub = (m * inv1 + m * inv2 + 1.0) / 3.0;
+                const double boosted = p.finish == FIN_JW ? sim_ub + (double)r.prefix * p.prefix_weight * (1.0 - sim_ub) : sim_ub;
+                dead = __ballot(m_ub != 0 && boosted + 1e-9 >= p.jaro_need) == 0;
+            }
+        }
+        if (dead) {
+            const bool valid_d = kUniform ? slot < p.n : idx != kPad;
+            if (valid_d) reinterpret_cast<double*>(p.out)[idx] = __longlong_as_double(0x7FF8000000000000ll);
+            continue;
         }
         uint32_t common = 0;
 #pragma unroll
