@@ -1023,6 +1023,8 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
                 return RF_ERR_UNSUPPORTED;
             }
             p->wf_waves = (uint32_t)std::min<uint64_t>(kWavesPerBlock, (lds_budget - p->len1 - 8) / row_bytes);
+            for (size_t i = 0; i < std::min<size_t>(64, c->s1.size()); ++i)  // the register-resident kernel compares against these
+                p->wf_query[i / 4] |= (uint32_t)corpus->sigma[c->s1[i]] << (8 * (i % 4));
         }
         break;
     }

@@ -89,6 +89,66 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void wf_kernel(const ScanPar
     }
 }
 
+// The same recurrence with the row in REGISTERS for queries of at most kMax <= 64 symbols: kMax + 1 VGPRs of row, the
+// (renamed) query bytes arrive in the kernel arguments and so live in SGPRs, both loops over the row are fully
+// unrolled: 6 VALU per cell (compare, three adds, min3, select) and no LDS at all.  Row entries beyond len1 are computed
+// and never read (every entry only depends on lower ones).
+template <bool kUniform, int kMax>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void wf_reg_kernel(const ScanParams p)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t len1 = p.len1;
+    const uint32_t ins = p.w_ins, del = p.w_del, sub = p.w_sub;
+    for (uint32_t t = blockIdx.x * kWavesPerBlock + wave; t < p.n_tiles; t += gridDim.x * kWavesPerBlock) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2 = tv.len;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+        uint32_t row[kMax + 1];
+#pragma unroll
+        for (int i = 0; i <= kMax; ++i) row[i] = (uint32_t)i * del;
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 data = load_chunk(tv.src + (size_t)c * kWave + lane);
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            for (uint32_t j = 0; j < cols; ++j) {
+                const uint32_t ch2 = data.x & 0xFFu;
+                uint32_t diag = row[0];
+                row[0] += ins;
+                uint32_t left = row[0];
+#pragma unroll
+                for (int i = 0; i < kMax; ++i) {
+                    const uint32_t qi = (p.wf_query[i / 4] >> (8 * (i % 4))) & 0xFFu;  // scalar
+                    const uint32_t up = row[i + 1];
+                    const uint32_t x = qi == ch2 ? diag : min(min(left + del, diag + sub), up + ins);
+                    row[i + 1] = x;
+                    diag = up;
+                    left = x;
+                }
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
+            }
+        }
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            uint32_t dist = row[0];
+#pragma unroll
+            for (int i = 1; i <= kMax; ++i) dist = (uint32_t)i == len1 ? row[i] : dist;  // row[len1] without dynamic indexing
+            const uint32_t max_dist = len1 * del + len2 * ins;
+            const uint32_t alt = len1 >= len2 ? len2 * sub + (len1 - len2) * del : len1 * sub + (len2 - len1) * ins;
+            TileFin f;
+            f.max = min(max_dist, alt);
+            f.d0 = 0;
+            f.v0 = p.fin_flip ? f.max : 0;
+            emit_fin(p, f, dist, idx, p.out);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Patterns longer than 512 symbols (the reference's hyrroe2003_block / lcs_blockwise territory,
 // levenshtein.rs:769-1019, lcs_seq.rs:267-341): the pattern is cut into groups of 8 words (512 rows).  A
@@ -183,8 +243,23 @@ hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int
     return hipGetLastError();
 }
 
+template <int kMax>
+static hipError_t launch_wf_reg(const ScanParams& p, hipStream_t stream)
+{
+    const dim3 g(std::max(1, scan_grid(p.n_tiles))), b(kWave * kWavesPerBlock);
+    if (p.tiles)
+        hipLaunchKernelGGL((wf_reg_kernel<false, kMax>), g, b, 0, stream, p);
+    else
+        hipLaunchKernelGGL((wf_reg_kernel<true, kMax>), g, b, 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_wf(const ScanParams& p, hipStream_t stream)
 {
+    static const bool use_reg = [] { const char* e = getenv("RF_WF_REG"); return !e || atoi(e) != 0; }();  // A/B switch
+    if (use_reg && p.len1 <= 16) return launch_wf_reg<16>(p, stream);
+    if (use_reg && p.len1 <= 32) return launch_wf_reg<32>(p, stream);
+    if (use_reg && p.len1 <= 64) return launch_wf_reg<64>(p, stream);
     const size_t lds = ((size_t)(p.len1 + 3) / 4 + 1) * 4 + (size_t)p.wf_waves * (p.len1 + 1) * kWave * 4;
     const dim3 g(std::max(1, scan_grid(p.n_tiles))), b(kWave * p.wf_waves);
     auto k = p.tiles ? wf_kernel<false> : wf_kernel<true>;
