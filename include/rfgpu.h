@@ -198,6 +198,15 @@ rf_status rf_many_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op,
 rf_status rf_many_f64(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args,
                       double *out, rf_mem out_mem, void *stream);
 
+/* The reference's per-candidate methods themselves -- `scorer.<op>_with_args(s2, &args)` for ONE candidate
+ * (levenshtein.rs:1740-1817 and siblings): a one-candidate corpus through the same kernels, result on the host.
+ * Convenience for drop-in call sites; a loop over candidates belongs in rf_many_*.  Returns RF_OK and sets *is_some
+ * to 0 where the reference returns None. */
+rf_status rf_one_u32(const rf_comparator *c, const uint8_t *s2, size_t len2, rf_op op, const rf_args *args, int device,
+                     uint32_t *out, int *is_some);
+rf_status rf_one_f64(const rf_comparator *c, const uint8_t *s2, size_t len2, rf_op op, const rf_args *args, int device,
+                     double *out, int *is_some);
+
 /* ---- many queries x one corpus ------------------------------------------------------------------
  * The reference's user loop one level up: `for q in queries { let scorer = BatchComparator::new(q);
  * for c in corpus { scorer.<op>_with_args(c, &args) } }`.  out is row-major [q][n]: row j is exactly what

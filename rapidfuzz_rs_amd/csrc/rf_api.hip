@@ -1282,6 +1282,42 @@ rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     return run_many(c, corpus, op, args, out, out_mem, stream, true);
 }
 
+static rf_status run_one(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, void* out,
+                         int* is_some, bool f64_out)
+{
+    if (!c || !args || !out || !is_some || (len2 && !s2)) {
+        set_error("rf_one: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    const uint64_t offsets[2] = {0, len2};
+    rf_corpus* corpus = nullptr;
+    rf_status s = rf_corpus_pack(s2, offsets, 1, device, &corpus);
+    if (s != RF_OK) return s;
+    if (f64_out) {
+        double v = 0.0;
+        s = run_many(c, corpus, op, args, &v, RF_MEM_HOST, nullptr, true);
+        *static_cast<double*>(out) = v;
+        *is_some = !std::isnan(v);
+    } else {
+        uint32_t v = 0;
+        s = run_many(c, corpus, op, args, &v, RF_MEM_HOST, nullptr, false);
+        *static_cast<uint32_t*>(out) = v;
+        *is_some = v != RF_NONE_U32;
+    }
+    rf_corpus_free(corpus);
+    return s;
+}
+rf_status rf_one_u32(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, uint32_t* out,
+                     int* is_some)
+{
+    return run_one(c, s2, len2, op, args, device, out, is_some, false);
+}
+rf_status rf_one_f64(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, double* out,
+                     int* is_some)
+{
+    return run_one(c, s2, len2, op, args, device, out, is_some, true);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // many queries x one corpus
 // ---------------------------------------------------------------------------------------------------

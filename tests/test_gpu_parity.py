@@ -1224,3 +1224,23 @@ def test_randomized_u32_equals_byte_path(seed, tmp_path):
             assert _equal_rows(wq.stream_many(op, path, len(wcorpus), segment_bytes=32 << 10, **kw), ref)
         except rf.RfError as e:  # the streamed path keeps no raw symbol stream: overflow queries are refused there
             assert e.status == N.RF_ERR_UNSUPPORTED and overflow > 0
+
+
+def test_rf_one_is_the_per_candidate_method():
+    import ctypes as C
+
+    L = N.lib()
+    bc = rf.distance.levenshtein.BatchComparator(b"kitten")
+    a = rf.Args().score_cutoff(2).to_c(False)
+    out, some = C.c_uint32(), C.c_int()
+    N.check(L.rf_one_u32(bc._h, b"sitting", 7, N.OP_DISTANCE, C.byref(a), 0, C.byref(out), C.byref(some)))
+    assert some.value == 0  # distance 3 > cutoff 2: None
+    a = rf.Args().to_c(False)
+    N.check(L.rf_one_u32(bc._h, b"sitting", 7, N.OP_DISTANCE, C.byref(a), 0, C.byref(out), C.byref(some)))
+    assert (some.value, out.value) == (1, 3)
+    N.check(L.rf_one_u32(bc._h, None, 0, N.OP_DISTANCE, C.byref(a), 0, C.byref(out), C.byref(some)))
+    assert (some.value, out.value) == (1, 6)
+    jw = rf.distance.jaro_winkler.BatchComparator(b"james")
+    f, af = C.c_double(), rf.Args().to_c(True)
+    N.check(L.rf_one_f64(jw._h, b"robert", 6, N.OP_SIMILARITY, C.byref(af), 0, C.byref(f), C.byref(some)))
+    assert some.value == 1 and f.value == o.jaro_winkler.similarity("james", "robert")
