@@ -8,7 +8,8 @@
  * safe wrapper a maintainer would put behind the original signatures.
  *
  * Plain pointers and sizes only; no torch / HIP types (a `hipStream_t` travels as `void*`).
- * Elements are `u8` (the `HashableChar` case `u8 -> Hash::UNSIGNED`, src/details/common.rs:34).
+ * Elements are `u8` (the `HashableChar` case `u8 -> Hash::UNSIGNED`, src/details/common.rs:34) or, through the *_u32
+ * entry points, `char` / u32.
  *
  * Error model: metric evaluation never fails in the reference (no `Result` on this path; "above the
  * cutoff" is `None`, src/common.rs:43-45).  rf_status reports ENGINE failures only (bad argument, HIP
@@ -33,7 +34,7 @@ enum {
     RF_OK = 0,
     RF_ERR_INVALID_ARG = 1,
     RF_ERR_HIP = 2,         /* a HIP runtime call failed; rf_last_error() has the text */
-    RF_ERR_UNSUPPORTED = 3, /* no device kernel for this shape / weight table (never falls back to the CPU) */
+    RF_ERR_UNSUPPORTED = 3, /* no device kernel for this shape (never falls back to the CPU, never approximates) */
     RF_ERR_NO_DEVICE = 4,
     RF_ERR_OOM = 5
 };
