@@ -1244,3 +1244,27 @@ def test_rf_one_is_the_per_candidate_method():
     f, af = C.c_double(), rf.Args().to_c(True)
     N.check(L.rf_one_f64(jw._h, b"robert", 6, N.OP_SIMILARITY, C.byref(af), 0, C.byref(f), C.byref(some)))
     assert some.value == 1 and f.value == o.jaro_winkler.similarity("james", "robert")
+
+
+def test_bench_contract_small():
+    """bench.py's contract on a small corpus: ONE JSON line, last on stdout, with the required keys, a roofline, a
+    cpu_baseline and a clean parity leg; and the sharded path (top-k + all-gather + merge) at world size 1."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--candidates", "300000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5"]
+    r = subprocess.run(base, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Gpairs/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity"]["mismatches"] == 0 and "workload" in d["config"]
+    env = dict(os.environ, RF_BENCH_FORCE_DIST="1", MASTER_PORT="29641")
+    r = subprocess.run(base + ["--no-cpu-baseline"], capture_output=True, text=True, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["config"]["topk_found"] == 16 and d["value"] > 0
