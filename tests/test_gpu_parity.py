@@ -1220,6 +1220,10 @@ def test_randomized_u32_equals_byte_path(seed, tmp_path):
         got = wq.many(op, wcorpus, **kw)  # overflow symbols in the query -> translated image: still exact
         assert _equal_rows(got, ref), (metric, op, kw, qlen)
         assert _equal_rows(wq.many(op, wloaded, **kw), ref)
+        q2 = alphabet[rng.integers(0, len(alphabet), size=max(1, qlen // 2))].tobytes()
+        if len(set(q2)) <= 255:
+            rows = GPU[metric].BatchComparator.many_multi([wq, GPU[metric].BatchComparator(widen(q2))], op, wcorpus, **kw)
+            assert _equal_rows(rows[0], ref) and _equal_rows(rows[1], GPU[metric].BatchComparator(q2).many(op, bcorpus, **kw))
         try:
             assert _equal_rows(wq.stream_many(op, path, len(wcorpus), segment_bytes=32 << 10, **kw), ref)
         except rf.RfError as e:  # the streamed path keeps no raw symbol stream: overflow queries are refused there
