@@ -691,6 +691,9 @@ def test_cutoff_length_window_ragged(qlen):
         s, i = bc.topk(corpus, 8, score_cutoff=k)
         exp = sorted((int(d), j) for j, d in enumerate(full) if d <= k)[:8]
         assert list(zip(s.tolist(), i.tolist())) == exp, (qlen, k)
+        every = np.zeros(len(corpus), dtype=np.uint32)  # the same pass can also hand back every candidate's score
+        s2, i2 = bc.topk(corpus, 8, score_cutoff=k, out=every)
+        assert list(zip(s2.tolist(), i2.tolist())) == exp and (every == got).all(), (qlen, k)
     for w, k in (((2, 2, 2), 7), ((3, 3, 3), 2)):  # factor > 1: the window is cutoff / factor
         _check_many("levenshtein", q, data, offsets, "distance", weights=w, score_cutoff=k)
 
