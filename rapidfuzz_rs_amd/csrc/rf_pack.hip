@@ -115,11 +115,58 @@ __global__ __launch_bounds__(256) void translate_kernel(const uint32_t* __restri
     }
 }
 
+// The same with a DIRECT table for the Basic Multilingual Plane (one id byte per code point, 64 KiB of LDS per
+// workgroup, two workgroups per CU): one LDS byte read per symbol and no probe loop, whose trip count every lane of a
+// wavefront would otherwise share.  Symbols above 0xFFFF (rare) still go through the small hash table, read from global.
+__global__ __launch_bounds__(256) void translate_direct_kernel(const uint32_t* __restrict__ raw, uint64_t n_chunks, const uint32_t* __restrict__ keys,
+                                                               const uint8_t* __restrict__ vals, uint32_t cap, uint4* __restrict__ out)
+{
+    extern __shared__ uint32_t lds_direct[];  // 16384 words = 65536 id bytes
+    uint8_t* table = reinterpret_cast<uint8_t*>(lds_direct);
+    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) lds_direct[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
+        const uint32_t k = keys[i];
+        if (k < 0x10000u) table[k] = vals[i];
+    }
+    __syncthreads();
+    const uint32_t mask = cap - 1;
+    auto map = [&](uint32_t sym) -> uint32_t {
+        if (sym < 0x10000u) return table[sym];
+        if (sym == 0xFFFFFFFFu) return 0;
+        uint32_t h = (sym * 2654435761u) & mask;
+        while (true) {
+            const uint32_t k = keys[h];
+            if (k == sym) return vals[h];
+            if (k == 0xFFFFFFFFu) return 0;
+            h = (h + 1) & mask;
+        }
+    };
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_chunks; x += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4* src = reinterpret_cast<const uint4*>(raw) + x * 4;
+        const uint4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];  // all four loads in flight before the lookups
+        uint4 o;
+        o.x = map(s0.x) | (map(s0.y) << 8) | (map(s0.z) << 16) | (map(s0.w) << 24);
+        o.y = map(s1.x) | (map(s1.y) << 8) | (map(s1.z) << 16) | (map(s1.w) << 24);
+        o.z = map(s2.x) | (map(s2.y) << 8) | (map(s2.z) << 16) | (map(s2.w) << 24);
+        o.w = map(s3.x) | (map(s3.y) << 8) | (map(s3.z) << 16) | (map(s3.w) << 24);
+        out[x] = o;
+    }
+}
+
 hipError_t launch_translate(const uint32_t* raw, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
                             hipStream_t stream)
 {
     const uint64_t n_chunks = n_bytes / 16;  // the payload is whole 16-byte chunks by construction
     if (n_chunks == 0) return hipSuccess;
+    static const bool direct = [] { const char* e = getenv("RF_TRANSLATE_DIRECT"); return !e || atoi(e) != 0; }();  // A/B switch
+    if (direct && n_chunks >= 1024) {  // (below that the table set-up -- 64 KiB per workgroup -- is the larger part)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(translate_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) return e;
+        const int grid = (int)std::min<uint64_t>((n_chunks + 255) / 256, 512);  // two resident workgroups per CU
+        hipLaunchKernelGGL(translate_direct_kernel, dim3(grid), dim3(256), 65536, stream, raw, n_chunks, keys, vals, cap, reinterpret_cast<uint4*>(out));
+        return hipGetLastError();
+    }
     const int grid = (int)std::min<uint64_t>((n_chunks + 255) / 256, (uint64_t)scan_max_grid() * 4);
     hipLaunchKernelGGL(translate_kernel, dim3(grid), dim3(256), (size_t)cap * 5, stream, raw, n_chunks, keys, vals, cap, reinterpret_cast<uint4*>(out));
     return hipGetLastError();
