@@ -157,8 +157,8 @@ int rf_corpus_device(const rf_corpus *c);
  * The corpus stores one byte per element -- the element's id in this corpus' own alphabet (the 254 most frequent
  * symbols; all rarer ones share one overflow id).  Every metric on this path only asks whether a candidate symbol
  * EQUALS a query symbol, so that byte image is exact for every query made of alphabet symbols and of symbols the
- * corpus does not contain at all.  A corpus with overflow symbols also keeps its u32 symbol stream on the device
- * (4 more bytes per symbol); a query that contains overflow symbols is then served from a per-call byte image
+ * corpus does not contain at all.  A corpus with overflow symbols also keeps its raw symbol stream on the device
+ * (2 more bytes per symbol inside the Basic Multilingual Plane, else 4); a query that contains overflow symbols is then served from a per-call byte image
  * translated from it (query symbol -> query-local id, anything else -> 0): still exact, one extra pass over the
  * stream per call.  Refused with RF_ERR_UNSUPPORTED only: such a query with more than 255 distinct symbols, and such
  * a query on the streamed path (rf_stream_many_*, which keeps no raw stream).

@@ -112,7 +112,8 @@ struct rf_corpus {
     // Only when `overflow` is not empty: the u32 symbol behind every packed byte (d_raw[x] belongs to d_data[x];
     // 0xFFFFFFFF in padding).  A query containing overflow symbols is served from a per-call byte image translated from
     // it (Effective below) -- exact, at the price of one extra pass over 4 bytes per symbol.
-    uint32_t* d_raw = nullptr;
+    void* d_raw = nullptr;
+    uint32_t raw_elem = 4;  // bytes per raw symbol: 2 when every symbol of the corpus is <= 0xFFFE (padding 0xFFFF), else 4 (padding 0xFFFFFFFF)
     mutable uint8_t* d_sigma_identity = nullptr;  // for those images (their bytes are query-local ids, not renamed)
     const rf_corpus* parent = nullptr;            // set on such an image: scratch and locks live in the real corpus
 };
@@ -348,7 +349,7 @@ static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corp
     e->keys.assign(cap, 0xFFFFFFFFu);
     e->vals.assign(cap, 0);
     for (const auto& kv : local) {
-        if (kv.first == 0xFFFFFFFFu) continue;  // reserved: the padding value of the raw stream, never a stored symbol
+        if (kv.first == 0xFFFFFFFFu || (corpus->raw_elem == 2 && kv.first >= 0xFFFFu)) continue;  // the raw stream's padding value / not representable in it: never a stored symbol
         uint32_t h = (kv.first * 2654435761u) & (cap - 1);
         while (e->keys[h] != 0xFFFFFFFFu) h = (h + 1) & (cap - 1);
         e->keys[h] = kv.first;
@@ -374,7 +375,7 @@ static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corp
     uint8_t* d_vals = reinterpret_cast<uint8_t*>(d_keys + cap);
     RF_HIP(hipMemcpyAsync(d_keys, e->keys.data(), (size_t)cap * 4, hipMemcpyHostToDevice, st));
     RF_HIP(hipMemcpyAsync(d_vals, e->vals.data(), cap, hipMemcpyHostToDevice, st));
-    const hipError_t le = launch_translate(corpus->d_raw, corpus->data_bytes, d_keys, d_vals, cap, e->temp, st);
+    const hipError_t le = launch_translate(corpus->d_raw, corpus->raw_elem, corpus->data_bytes, d_keys, d_vals, cap, e->temp, st);
     if (le != hipSuccess) {
         set_error(std::string("translate: ") + hipGetErrorString(le));
         return RF_ERR_HIP;
@@ -804,46 +805,57 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
     c->alphabet = std::move(alphabet);
     c->overflow = std::move(overflow);
     if (!c->overflow.empty()) {
-        // the u32 symbol behind every packed byte, same chunk-interleaved positions (one worker per range of tiles)
-        std::unique_ptr<uint32_t[]> raw(new (std::nothrow) uint32_t[L.packed_size]);
+        // the symbol behind every packed byte, same chunk-interleaved positions (one worker per range of tiles); two bytes
+        // per symbol when the whole corpus lies below 0xFFFF (the Basic Multilingual Plane), four otherwise
+        const bool narrow = high.empty() && low[0xFFFF] == 0;
+        c->raw_elem = narrow ? 2 : 4;
+        const size_t raw_bytes = L.packed_size * c->raw_elem;
+        std::unique_ptr<uint8_t[]> raw(new (std::nothrow) uint8_t[raw_bytes]);
         if (!raw) {
             rf_corpus_free(c);
             set_error("rf_corpus_pack_u32: out of host memory");
             return RF_ERR_OOM;
         }
         const size_t n_tiles = L.tiles.size();
-        auto tiles_worker = [&](size_t t0, size_t t1) {
-            for (size_t t = t0; t < t1; ++t) {
-                const TileDesc& td = L.tiles[t];
-                const uint64_t tb = tile_bytes(td.len);
-                std::memset(raw.get() + td.data_off, 0xFF, tb * sizeof(uint32_t));
-                for (uint32_t r = 0; r < (uint32_t)kWave; ++r) {
-                    const uint64_t slot = (uint64_t)td.slot0 + r;
-                    const uint64_t i = L.identity ? slot : (uint64_t)L.orig[slot];
-                    if ((L.identity && i >= n) || (!L.identity && i == kPad)) continue;
-                    const uint32_t* src = elems + offsets[i];
-                    uint32_t* dst = raw.get() + td.data_off + (uint64_t)r * kChunk;
-                    for (uint32_t b = 0; b < td.len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = src[b];
+        auto fill = [&](auto* dst_base) {
+            using Sym = std::remove_pointer_t<decltype(dst_base)>;
+            auto tiles_worker = [&, dst_base](size_t t0, size_t t1) {
+                for (size_t t = t0; t < t1; ++t) {
+                    const TileDesc& td = L.tiles[t];
+                    const uint64_t tb = tile_bytes(td.len);
+                    std::memset(dst_base + td.data_off, 0xFF, tb * sizeof(Sym));
+                    for (uint32_t r = 0; r < (uint32_t)kWave; ++r) {
+                        const uint64_t slot = (uint64_t)td.slot0 + r;
+                        const uint64_t i = L.identity ? slot : (uint64_t)L.orig[slot];
+                        if ((L.identity && i >= n) || (!L.identity && i == kPad)) continue;
+                        const uint32_t* src = elems + offsets[i];
+                        Sym* dst = dst_base + td.data_off + (uint64_t)r * kChunk;
+                        for (uint32_t b = 0; b < td.len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = (Sym)src[b];
+                    }
                 }
+            };
+            std::memset(dst_base + (L.packed_size - kTailPad), 0xFF, kTailPad * sizeof(Sym));
+            if (nthreads == 1) {
+                tiles_worker(0, n_tiles);
+            } else {
+                std::vector<std::thread> pool;
+                for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(tiles_worker, n_tiles * t / nthreads, n_tiles * (t + 1) / nthreads);
+                for (auto& th : pool) th.join();
             }
         };
-        std::memset(raw.get() + (L.packed_size - kTailPad), 0xFF, kTailPad * sizeof(uint32_t));
-        if (nthreads == 1) {
-            tiles_worker(0, n_tiles);
-        } else {
-            std::vector<std::thread> pool;
-            for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(tiles_worker, n_tiles * t / nthreads, n_tiles * (t + 1) / nthreads);
-            for (auto& th : pool) th.join();
-        }
+        if (narrow)
+            fill(reinterpret_cast<uint16_t*>(raw.get()));
+        else
+            fill(reinterpret_cast<uint32_t*>(raw.get()));
         DeviceGuard guard(device);
-        hipError_t e = hipMalloc((void**)&c->d_raw, L.packed_size * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(c->d_raw, raw.get(), L.packed_size * sizeof(uint32_t), hipMemcpyHostToDevice);
+        hipError_t e = hipMalloc(&c->d_raw, raw_bytes);
+        if (e == hipSuccess) e = hipMemcpy(c->d_raw, raw.get(), raw_bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             rf_corpus_free(c);
             set_error(std::string("rf_corpus_pack_u32: ") + hipGetErrorString(e));
             return e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;
         }
-        c->device_bytes += L.packed_size * sizeof(uint32_t);
+        c->device_bytes += raw_bytes;
     }
     *out = c;
     return RF_OK;
@@ -1644,7 +1656,7 @@ struct FileHeader {  // little endian, 512 bytes
     uint8_t reserved[512 - 8 - 8 - 8 - 16 - 16 - 40 - 8 - 256 - 8];
 };
 static_assert(sizeof(FileHeader) == 512, "header layout");
-constexpr uint32_t kFileVersion = 1, kFlagUniform = 1, kFlagWide = 2, kFlagRaw = 4;
+constexpr uint32_t kFileVersion = 1, kFlagUniform = 1, kFlagWide = 2, kFlagRaw = 4, kFlagRaw16 = 8;
 
 struct FileCloser {
     FILE* f;
@@ -1712,7 +1724,7 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
     std::memset(&h, 0, sizeof(h));
     std::memcpy(h.magic, "RFCORPUS", 8);
     h.version = kFileVersion;
-    h.flags = (c->uniform ? kFlagUniform : 0) | (c->wide ? kFlagWide : 0) | (c->d_raw ? kFlagRaw : 0);
+    h.flags = (c->uniform ? kFlagUniform : 0) | (c->wide ? kFlagWide : 0) | (c->d_raw ? kFlagRaw : 0) | (c->d_raw && c->raw_elem == 2 ? kFlagRaw16 : 0);
     h.n = c->n;
     h.n_tiles = c->n_tiles;
     h.max_len = c->max_len;
@@ -1755,7 +1767,7 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
     }
     if (c->d_raw) {
         ok = ok && fseeko(fc.f, (off_t)h.off_raw, SEEK_SET) == 0;
-        const uint64_t raw_bytes = c->data_bytes * sizeof(uint32_t);
+        const uint64_t raw_bytes = c->data_bytes * c->raw_elem;
         for (uint64_t done = 0; ok && done < raw_bytes; done += buf.size()) {
             const size_t m = (size_t)std::min<uint64_t>(buf.size(), raw_bytes - done);
             RF_HIP(hipMemcpy(buf.data(), reinterpret_cast<const uint8_t*>(c->d_raw) + done, m, hipMemcpyDeviceToHost));
@@ -1844,8 +1856,9 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
     }
     c->device_bytes = c->data_bytes;
     if (h.flags & kFlagRaw) {
-        const uint64_t raw_bytes = c->data_bytes * sizeof(uint32_t);
-        RF_HIP_C(hipMalloc((void**)&c->d_raw, std::max<uint64_t>(1, raw_bytes)));
+        c->raw_elem = (h.flags & kFlagRaw16) ? 2 : 4;
+        const uint64_t raw_bytes = c->data_bytes * c->raw_elem;
+        RF_HIP_C(hipMalloc(&c->d_raw, std::max<uint64_t>(1, raw_bytes)));
         for (uint64_t done = 0; done < raw_bytes; done += buf.size()) {
             const size_t m = (size_t)std::min<uint64_t>(buf.size(), raw_bytes - done);
             if (!read_at(fc.f, h.off_raw + done, buf.data(), m)) {

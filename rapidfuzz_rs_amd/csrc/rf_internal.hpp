@@ -108,7 +108,7 @@ hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t
                              bool bound_from_result, hipStream_t stream);
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,
                             uint32_t n_tiles, const uint8_t* sigma, hipStream_t stream);
-hipError_t launch_translate(const uint32_t* raw, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
+hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
                             hipStream_t stream);
 int scan_max_grid();
 hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,

@@ -83,7 +83,30 @@ hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t 
 // needs to know about a candidate symbol.  The (symbol -> id) pairs arrive as an open-addressing table of `cap` slots
 // (power of two, key 0xFFFFFFFF = empty) and are staged in LDS; 16 symbols in, one 16-byte chunk out per thread.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void translate_kernel(const uint32_t* __restrict__ raw, uint64_t n_chunks, const uint32_t* __restrict__ keys,
+// 16 raw symbols of one output chunk (Sym = uint32_t or, for corpora inside the Basic Multilingual Plane, uint16_t)
+template <class Sym>
+__device__ __forceinline__ void load_raw16(const Sym* raw, uint64_t x, uint32_t (&sym)[16])
+{
+    if constexpr (sizeof(Sym) == 4) {
+        const uint4* src = reinterpret_cast<const uint4*>(raw) + x * 4;
+        const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+        const uint32_t v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sym[i] = v[i];
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(raw) + x * 2;
+        const uint4 a = src[0], b = src[1];
+        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sym[2 * i] = v[i] & 0xFFFFu;
+            sym[2 * i + 1] = v[i] >> 16;
+        }
+    }
+}
+
+template <class Sym>
+__global__ __launch_bounds__(256) void translate_kernel(const Sym* __restrict__ raw, uint64_t n_chunks, const uint32_t* __restrict__ keys,
                                                         const uint8_t* __restrict__ vals, uint32_t cap, uint4* __restrict__ out)
 {
     extern __shared__ uint32_t lds_keys[];  // cap keys, then cap ids (one byte each)
@@ -103,14 +126,12 @@ __global__ __launch_bounds__(256) void translate_kernel(const uint32_t* __restri
             h = (h + 1) & mask;
         }
     };
+    constexpr uint32_t kPadSym = sizeof(Sym) == 4 ? 0xFFFFFFFFu : 0xFFFFu;
     for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_chunks; x += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4* src = reinterpret_cast<const uint4*>(raw) + x * 4;
-        uint32_t o[4];
+        uint32_t sym[16], o[4] = {0, 0, 0, 0};
+        load_raw16<Sym>(raw, x, sym);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint4 s4 = src[w];
-            o[w] = map(s4.x) | (map(s4.y) << 8) | (map(s4.z) << 16) | (map(s4.w) << 24);
-        }
+        for (int i = 0; i < 16; ++i) o[i / 4] |= (sym[i] == kPadSym ? 0u : map(sym[i])) << (8 * (i % 4));
         out[x] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -118,7 +139,8 @@ __global__ __launch_bounds__(256) void translate_kernel(const uint32_t* __restri
 // The same with a DIRECT table for the Basic Multilingual Plane (one id byte per code point, 64 KiB of LDS per
 // workgroup, two workgroups per CU): one LDS byte read per symbol and no probe loop, whose trip count every lane of a
 // wavefront would otherwise share.  Symbols above 0xFFFF (rare) still go through the small hash table, read from global.
-__global__ __launch_bounds__(256) void translate_direct_kernel(const uint32_t* __restrict__ raw, uint64_t n_chunks, const uint32_t* __restrict__ keys,
+template <class Sym>
+__global__ __launch_bounds__(256) void translate_direct_kernel(const Sym* __restrict__ raw, uint64_t n_chunks, const uint32_t* __restrict__ keys,
                                                                const uint8_t* __restrict__ vals, uint32_t cap, uint4* __restrict__ out)
 {
     extern __shared__ uint32_t lds_direct[];  // 16384 words = 65536 id bytes
@@ -143,33 +165,38 @@ __global__ __launch_bounds__(256) void translate_direct_kernel(const uint32_t* _
         }
     };
     for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_chunks; x += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4* src = reinterpret_cast<const uint4*>(raw) + x * 4;
-        const uint4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];  // all four loads in flight before the lookups
-        uint4 o;
-        o.x = map(s0.x) | (map(s0.y) << 8) | (map(s0.z) << 16) | (map(s0.w) << 24);
-        o.y = map(s1.x) | (map(s1.y) << 8) | (map(s1.z) << 16) | (map(s1.w) << 24);
-        o.z = map(s2.x) | (map(s2.y) << 8) | (map(s2.z) << 16) | (map(s2.w) << 24);
-        o.w = map(s3.x) | (map(s3.y) << 8) | (map(s3.z) << 16) | (map(s3.w) << 24);
-        out[x] = o;
+        uint32_t sym[16], o[4] = {0, 0, 0, 0};
+        load_raw16<Sym>(raw, x, sym);  // all loads in flight before the lookups
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i / 4] |= map(sym[i]) << (8 * (i % 4));
+        out[x] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
-hipError_t launch_translate(const uint32_t* raw, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
+template <class Sym>
+static hipError_t launch_translate_t(const Sym* raw, uint64_t n_chunks, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint4* out, hipStream_t stream)
+{
+    static const bool direct = [] { const char* e = getenv("RF_TRANSLATE_DIRECT"); return !e || atoi(e) != 0; }();  // A/B switch
+    if (direct && n_chunks >= 1024) {  // (below that the table set-up -- 64 KiB per workgroup -- is the larger part)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(translate_direct_kernel<Sym>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) return e;
+        const int grid = (int)std::min<uint64_t>((n_chunks + 255) / 256, 512);  // two resident workgroups per CU
+        hipLaunchKernelGGL(translate_direct_kernel<Sym>, dim3(grid), dim3(256), 65536, stream, raw, n_chunks, keys, vals, cap, out);
+        return hipGetLastError();
+    }
+    const int grid = (int)std::min<uint64_t>((n_chunks + 255) / 256, (uint64_t)scan_max_grid() * 4);
+    hipLaunchKernelGGL(translate_kernel<Sym>, dim3(grid), dim3(256), (size_t)cap * 5, stream, raw, n_chunks, keys, vals, cap, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
                             hipStream_t stream)
 {
     const uint64_t n_chunks = n_bytes / 16;  // the payload is whole 16-byte chunks by construction
     if (n_chunks == 0) return hipSuccess;
-    static const bool direct = [] { const char* e = getenv("RF_TRANSLATE_DIRECT"); return !e || atoi(e) != 0; }();  // A/B switch
-    if (direct && n_chunks >= 1024) {  // (below that the table set-up -- 64 KiB per workgroup -- is the larger part)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(translate_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        if (e != hipSuccess) return e;
-        const int grid = (int)std::min<uint64_t>((n_chunks + 255) / 256, 512);  // two resident workgroups per CU
-        hipLaunchKernelGGL(translate_direct_kernel, dim3(grid), dim3(256), 65536, stream, raw, n_chunks, keys, vals, cap, reinterpret_cast<uint4*>(out));
-        return hipGetLastError();
-    }
-    const int grid = (int)std::min<uint64_t>((n_chunks + 255) / 256, (uint64_t)scan_max_grid() * 4);
-    hipLaunchKernelGGL(translate_kernel, dim3(grid), dim3(256), (size_t)cap * 5, stream, raw, n_chunks, keys, vals, cap, reinterpret_cast<uint4*>(out));
-    return hipGetLastError();
+    uint4* o = reinterpret_cast<uint4*>(out);
+    if (raw_elem == 2) return launch_translate_t(static_cast<const uint16_t*>(raw), n_chunks, keys, vals, cap, o, stream);
+    return launch_translate_t(static_cast<const uint32_t*>(raw), n_chunks, keys, vals, cap, o, stream);
 }
 
 }  // namespace rf

@@ -1200,7 +1200,8 @@ def test_randomized_u32_equals_byte_path(seed, tmp_path):
     or not (a 256-symbol corpus has one); only the streamed path may refuse a query with overflow symbols."""
     rng = np.random.default_rng(9000 + seed)
     data, offsets, alphabet = _random_corpus(rng)
-    widen = lambda b: (np.frombuffer(bytes(b), dtype=np.uint8).astype(np.uint32) * 7 + 0x390)
+    base = 0x390 if seed % 2 == 0 else 0x1F000  # inside / outside the Basic Multilingual Plane (2- / 4-byte raw stream)
+    widen = lambda b: (np.frombuffer(bytes(b), dtype=np.uint8).astype(np.uint32) * 7 + base)
     bcorpus = rf.Corpus.from_ragged(data, offsets)
     wcorpus = rf.Corpus.from_ragged_u32(widen(data), offsets)
     own, overflow = wcorpus.alphabet_size()
