@@ -66,7 +66,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # RF_BENCH_BACKEND=gloo is a TEST mode: all ranks share GPU 0 and the k-entry exchange goes through host tensors, so the
+    # multi-rank logic (index bases, merge, max-over-ranks timing) can be exercised on a single-GPU box.  Never a result.
+    test_gloo = os.environ.get("RF_BENCH_BACKEND") == "gloo"
+    if test_gloo:
+        local_rank = 0
+    if world > 1 or force_dist:
+        if test_gloo:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if N.lib().rf_device_count() < 1:
@@ -148,7 +157,13 @@ def main():
                     all_keys[buf][: args.topk].copy_(local_keys[buf])
                     pending[0] = (None, buf)
                 else:
-                    pending[0] = (dist.all_gather_into_tensor(all_keys[buf], local_keys[buf], async_op=True), buf)
+                    if test_gloo:
+                        host = [torch.empty(args.topk, dtype=torch.int64) for _ in range(world)]
+                        dist.all_gather(host, local_keys[buf].cpu())
+                        all_keys[buf].copy_(torch.cat(host))
+                        pending[0] = (None, buf)
+                    else:
+                        pending[0] = (dist.all_gather_into_tensor(all_keys[buf], local_keys[buf], async_op=True), buf)
             else:
                 last_topk[0] = local_keys[buf][: args.topk]
 
@@ -189,10 +204,10 @@ def main():
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
     if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        km = torch.tensor([kernel_ms], dtype=torch.float64, device="cpu" if test_gloo else dev)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
         kernel_ms = float(km.item())
 
@@ -241,6 +256,7 @@ def main():
             "output": ("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else f"top-{args.topk} only",
             "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if world > 1 else "1 GPU",
             "setup_s": round(t_setup, 2),
+            **({"test_backend": "gloo: ranks share one GPU, NOT a measurement"} if test_gloo else {}),
         },
         "roofline": {
             "bound": "hbm",

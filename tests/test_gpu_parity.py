@@ -1276,3 +1276,33 @@ def test_bench_contract_small():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["config"]["topk_found"] == 16 and d["value"] > 0
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """The multi-rank logic of bench.py (per-rank shards, global index bases, k-entry exchange, merge, max-over-ranks
+    timing, rank 0 prints) with two processes sharing this box's one GPU and the exchange over gloo -- a test mode, not a
+    measurement.  The merged top-k must be the top-k of the two shards put together."""
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 200_000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29647",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--candidates", str(n), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=dict(os.environ, RF_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # only rank 0 prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["topk_found"] == 16
+    # the same two shards, scored in this process
+    q = synth.query(64, 0xC0FFEE02)
+    keys = []
+    for rank in range(2):
+        rows = synth.rows_device(n, 64, seed=0xC0FFEE02 + 7919 * rank, device=torch.device("cuda", 0))
+        dist_r = rf.distance.levenshtein.BatchComparator(q).distance_many(rf.Corpus.from_device_rows(rows))
+        keys += [(int(v), rank * n + i) for i, v in enumerate(dist_r.tolist())]
+    keys.sort()
+    assert [tuple(k) for k in d["config"]["topk_best"]] == keys[:4]
