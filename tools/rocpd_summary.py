@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--match", default="scan_kernel")
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--skip", type=int, default=3, help="warm-up dispatches left out of the steady-state average")
     ap.add_argument("--traffic-key", default=None, help="also record the HBM traffic under this key in --traffic-json")
     ap.add_argument("--traffic-json", default="profiles/traffic.json")
     a = ap.parse_args()
@@ -32,6 +33,11 @@ def main():
         if rows:
             d = [r[1] for r in rows]
             lines.append(f"== {a.match}: {len(d)} dispatches, duration ns min/avg/max = {min(d)}/{sum(d)/len(d):.0f}/{max(d)}; grid_x={rows[0][2]} wg_x={rows[0][3]} vgpr={rows[0][4]} sgpr={rows[0][5]} lds={rows[0][6]}")
+            # bench.py times only the steps after its warm-up: the same window here (the first dispatches run on cold clocks / caches)
+            main = [r[1] for r in rows if r[0] == rows[-1][0]]
+            steady = main[a.skip:] if len(main) > a.skip else main
+            lines.append(f"== steady state (dispatches after the first {a.skip} of {rows[-1][0][:60]}): n={len(steady)} avg {sum(steady)/len(steady):.0f} ns  median {sorted(steady)[len(steady)//2]} ns")
+            summary["steady_avg_us"] = sum(steady) / len(steady) / 1e3
     counters = {}
     for f in a.pmc:
         cur = sqlite3.connect(f).cursor()
