@@ -4,9 +4,11 @@
 A "step" is ONE pass of the hot path over the whole device-resident corpus: 1 query x n candidates
 through `levenshtein::BatchComparator` semantics (rf_many_u32, RF_OP_DISTANCE), one u32 per candidate.
 Workload at N=1 = BASELINE.json configs[1]: query len 64 vs 100 M random alphanumeric len-64 candidates.
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own 100 M-candidate
-shard (weak scaling), there is no data-path collective, and each step ends with the top-k all-gather the
-north star names (k entries per rank over RCCL).
+With N > 1 (one rank per GPU; `python bench.py --gpus N` spawns the ranks itself through torch.distributed.run when
+it is not already running under it) every rank owns its own 100 M-candidate shard (weak scaling), there is no data-path
+collective, and each step ends with the top-k all-gather the north star names (k entries per rank over RCCL).
+`--config c5` is BASELINE.json configs[4]: ONE logical corpus of 1 B len-64 candidates split over the ranks (strong
+scaling), score_cutoff = 3, top-16 only, the RCCL all-gather + merge every step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -44,22 +46,50 @@ def parse():
     ap.add_argument("--plant-every", type=int, default=1_000_000, help="near-duplicates of the query planted 1-in-N (cutoff/top-k runs)")
     ap.add_argument("--weights", default=None, help="levenshtein WeightTable as ins,del,sub (e.g. 1,2,3: the generalized Wagner-Fischer kernel)")
     ap.add_argument("--symbols", type=int, default=62, help="alphabet size of the synthetic corpus (experiment knob, default alphanumeric)")
+    ap.add_argument("--config", default=None, choices=["c2", "c5"],
+                    help="c2 = BASELINE.json configs[1] (the default workload); c5 = configs[4]: 1 B candidates split over the ranks, "
+                         "score_cutoff 3, top-16, all-gather every step")
+    ap.add_argument("--total-candidates", type=int, default=1_000_000_000, help="size of the logical corpus of --config c5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: launch N ranks of this very command (one per GPU,
+    rendezvous on 127.0.0.1) and pass their output through.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
     import rapidfuzz_rs_amd as rf
     from rapidfuzz_rs_amd import _native as N
+    from rapidfuzz_rs_amd import parallel
     from rapidfuzz_rs_amd.utils import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    force_dist = os.environ.get("RF_BENCH_FORCE_DIST") == "1"  # exercise the collective path at world size 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): refusing to report a number for a job "
+                         "that is not the one asked for")
+    c5 = args.config == "c5"
+    # exercise the collective path at world size 1 as well: always for c5 (its step IS scan + gather + merge)
+    force_dist = os.environ.get("RF_BENCH_FORCE_DIST") == "1" or c5
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or force_dist:
@@ -80,9 +110,24 @@ def main():
     dev = torch.device("cuda", local_rank)
     if N.lib().rf_device_count() < 1:
         raise RuntimeError("no HIP device visible to librfgpu.so")
+    # the ranks that actually joined, and the distinct GPUs they sit on: what n_gpus reports
+    joined, gpus_used = 1, 1
+    if world > 1 or force_dist:
+        mine = torch.tensor([1, local_rank], dtype=torch.int64, device="cpu" if test_gloo else dev)
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        joined = int(sum(int(t[0]) for t in everyone))
+        gpus_used = len({int(t[1]) for t in everyone})
+        if joined != world or (gpus_used != world and not test_gloo):
+            raise SystemExit(f"bench.py: {joined} of {world} ranks joined on {gpus_used} distinct GPUs")
 
+    if c5:  # BASELINE.json configs[4]
+        args.metric, args.mode, args.cutoff, args.topk, args.queries = "levenshtein", "topk", 3, 16, 1
+        args.cand_len, args.query_len, args.weights, args.fcutoff = 64, 64, None, None
+        shard_lo, shard_hi = parallel.shard_range(args.total_candidates, rank, world)
+        args.candidates = shard_hi - shard_lo
     n, ln = args.candidates, args.cand_len
-    q = synth.query(args.query_len, 0xC0FFEE02)
+    q = synth.query(args.query_len, 0xC0FFEE05 if c5 else 0xC0FFEE02)
     mod = getattr(rf.distance, args.metric)
     scorer = mod.BatchComparator(q)
     nq = args.queries if (world == 1 and not force_dist and args.mode == "many") else 1
@@ -91,8 +136,13 @@ def main():
 
     # synthetic corpus, generated and packed on the device (excluded from the timed region)
     t0 = time.time()
-    rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev, symbols=args.symbols)
-    if args.cutoff is not None or args.mode == "topk":
+    index_base = rank * n
+    if c5:  # this rank's slice of the ONE logical corpus (the same rows whatever the world size)
+        rows = synth.rows_device_range(shard_lo, shard_hi, ln, seed=0xC0FFEE05, device=dev, symbols=args.symbols, q=q, plant_every=args.plant_every)
+        index_base = shard_lo
+    else:
+        rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev, symbols=args.symbols)
+    if not c5 and (args.cutoff is not None or args.mode == "topk"):
         # 1 in 10^6 candidates is the query with 0..5 random substitutions
         gen = torch.Generator(device=dev)
         gen.manual_seed(99 + rank)
@@ -132,8 +182,6 @@ def main():
         call_args = call_args.weights(rf.WeightTable(*weights))
     stream = torch.cuda.current_stream(dev)
 
-    from rapidfuzz_rs_amd import parallel
-
     last_topk = [None]
 
     def step():
@@ -149,7 +197,7 @@ def main():
             # Everything is stream-ordered on the device -- no host round trip inside a step.
             buf = step_no[0] & 1
             step_no[0] += 1
-            scorer.topk_keys_device(corpus, args.topk, local_keys[buf], N.OP_DISTANCE, call_args, index_base=rank * n,
+            scorer.topk_keys_device(corpus, args.topk, local_keys[buf], N.OP_DISTANCE, call_args, index_base=index_base,
                                     out=out if args.mode == "many" else None, stream=stream.cuda_stream)
             if world > 1 or force_dist:
                 finish_exchange()  # merge the PREVIOUS step's gather: it ran on RCCL's stream under this step's scan
@@ -216,45 +264,60 @@ def main():
             dist.destroy_process_group()
         return
 
-    pairs_per_step = n * world * nq
+    pairs_per_step = args.total_candidates if c5 else n * world * nq
     ms_per_step = elapsed * 1e3 / args.steps
     gpairs = pairs_per_step / (elapsed / args.steps) / 1e9
-    # algorithmic bytes per pair: candidate bytes at bucket length + one u32 result
-    # (Q fused queries read each candidate once: ln / Q candidate bytes per pair)
-    # With a distance cutoff the early-out is part of the algorithm: on this corpus nearly every candidate is decided
-    # from its first 16-byte chunk, so the bytes the path has to move are that chunk + the result.
+    # Algorithmic bytes per pair, SURVEY.md 8(d): candidate bytes at bucket length + the result (u32 / f64 per candidate,
+    # nothing in top-k-only mode); Q fused queries read each candidate once: ln / Q candidate bytes per pair.
+    out_bytes = (8 if is_f64 else 4) if args.mode == "many" else 0
+    survey_bpp = ln / nq + out_bytes
+    # With a tight cutoff the early-out is part of the algorithm: on this corpus nearly every candidate is decided from
+    # its first 16-byte chunk, so the bytes the path HAS to move are that chunk + the result -- which is also what the
+    # PMC counters see (profiles/traffic.json).  Both accountings are reported: `roofline` prices what is moved,
+    # `roofline.survey_8d` the survey's full-candidate figure (its frac can exceed 1: the bytes are legitimately not read).
     # (the library switches the early-out on by how much normalized distance the cutoff allows -- rf_api.hip plan())
     early = False
     if args.cutoff is not None and not is_f64 and not weights:
         maximum = (ln + args.query_len) if args.metric == "indel" else max(ln, args.query_len)
         early = args.cutoff / max(maximum, 1) < (0.4 if args.metric in ("indel", "lcs_seq") else 0.7)
-    cand_bytes = min(ln, 16) if early else ln
-    bytes_per_pair = cand_bytes / nq + (8 if is_f64 else (4 if args.mode == "many" else 0))
-    achieved = n * nq * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
+    bytes_per_pair = (min(ln, 16) if early else ln) / nq + out_bytes
+    pairs_per_gpu = pairs_per_step / world
+    achieved = pairs_per_gpu * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
+    survey_achieved = pairs_per_gpu * survey_bpp / (kernel_ms * 1e-3) / 1e9
 
+    what = f"{args.metric}::BatchComparator, 1 query len-{args.query_len} x "
+    if c5:
+        what += (f"{args.total_candidates} random alphanumeric len-{ln} candidates in ONE logical corpus split over {world} GPU(s), score_cutoff=3, "
+                 f"top-{args.topk} + all-gather + merge every step" + (", BASELINE.json configs[4]" if args.total_candidates == 1_000_000_000 else ""))
+    else:
+        what += (f"{n} random alphanumeric len-{ln} candidates per GPU, " + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
+                 + (f", weights={weights}" if weights else "")
+                 + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64
+                                                     and args.cutoff is None and not weights) else ""))
     result = {
         "metric": "Gpairs/s (1 query x N candidates, Levenshtein BatchComparator semantics)" if args.metric == "levenshtein" else f"Gpairs/s ({args.metric})",
         "value": round(gpairs, 3),
         "unit": "Gpairs/s",
-        "n_gpus": world,
+        "n_gpus": gpus_used if not test_gloo else joined,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if c5 else "weak",
         "vs_baseline": None,
         "dtype": "u64 bit-vectors (u32 results)",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.metric}::BatchComparator, 1 query len-{args.query_len} x {n} random alphanumeric len-{ln} candidates per GPU, "
-            + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}") + (f", weights={weights}" if weights else "")
-            + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64 and args.cutoff is None and not weights) else ""),
+            "workload": what,
             "candidates_per_gpu": n,
             "candidate_len": ln,
             "query_len": args.query_len,
             "queries": nq,
             "output": ("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else f"top-{args.topk} only",
-            "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if world > 1 else "1 GPU",
+            "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if (world > 1 or force_dist) else "1 GPU",
+            "ranks_joined": joined,
+            **({"rccl_ranks": dist.get_world_size(), "collective": "ncclAllGather via torch.distributed (backend nccl = RCCL)"}
+               if (world > 1 or force_dist) and not test_gloo else {}),
             "setup_s": round(t_setup, 2),
             **({"test_backend": "gloo: ranks share one GPU, NOT a measurement"} if test_gloo else {}),
         },
@@ -264,18 +327,27 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(args, n),
+            "traffic": measured_traffic(args, n, kernel_ms),
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_pair": bytes_per_pair,
+            "survey_8d": {"bytes_per_pair": survey_bpp, "achieved": round(survey_achieved, 1), "frac": round(survey_achieved / HBM_PEAK_GBS, 4)},
         },
     }
-    if args.metric == "levenshtein" and 32 < args.query_len <= 64 and args.cutoff is None and nq == 1 and ln == 64 and not weights:
-        # The single-word Levenshtein column is 17 VALU + 1 SDWA instructions, three of them half-rate 64-bit forms:
-        # the same column sequence fed from registers, with no memory traffic at all, tops out at 43.1 Gpairs/s on
-        # this chip (tools/microbench.hip k_lev_regs, profiles/microbench_r01.txt) -- that, not HBM, is what binds.
-        per_gpu = gpairs / world
-        result["roofline"]["issue_bound"] = {"achieved": round(per_gpu, 3), "ceiling": 43.14, "unit": "Gpairs/s", "frac": round(per_gpu / 43.14, 4),
-                                             "source": "profiles/microbench_r01.txt: lev col regs, 8 blocks/CU"}
+    if args.metric in ("levenshtein", "indel", "lcs_seq", "osa") and args.query_len <= (256 if args.metric == "levenshtein" else 64) and not weights and not early:
+        # The bit-parallel scans of this family are bound by VALU issue before they are bound by HBM.  The
+        # ceiling is MEASURED here, in this process: the library's own recurrence column on register-resident pattern
+        # words, no HBM / LDS / tile loop (rf_probe_issue_rate, rapidfuzz_rs_amd/csrc/rf_probe.hip).
+        import ctypes
+
+        torch.cuda.synchronize()
+        rate = ctypes.c_double(0.0)
+        metric_id = {"levenshtein": N.LEVENSHTEIN, "indel": N.INDEL, "lcs_seq": N.LCS_SEQ, "osa": N.OSA}[args.metric]
+        if N.lib().rf_probe_issue_rate(metric_id, args.query_len, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
+            ceiling = rate.value * 64.0 / max(ln, 1) * nq  # wave-columns/ns -> Gpairs/s at this candidate length
+            per_gpu = gpairs / world
+            result["roofline"]["issue_bound"] = {"achieved": round(per_gpu, 3), "ceiling": round(ceiling, 3), "unit": "Gpairs/s",
+                                                 "frac": round(per_gpu / ceiling, 4),
+                                                 "source": "rf_probe_issue_rate in this run: the product's State::step on register-resident PM words, 8 workgroups/CU"}
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,
@@ -283,8 +355,25 @@ def main():
         keys = [int(x) for x in last_topk[0].cpu().tolist() if x not in (-1, 2**63 - 1)]
         result["config"]["topk_found"] = len(keys)
         result["config"]["topk_best"] = [[k >> 32, k & 0xFFFFFFFF] for k in sorted(keys)[:4]]
-    if host_sample is not None and args.mode == "many":
+        import zlib
+
+        # the same for every world size when the corpus is ONE logical corpus (c5): the scaling runs must agree on it
+        result["config"]["topk_checksum"] = zlib.crc32(np.array(sorted(keys), dtype=np.uint64).tobytes())
+        if c5 and not args.no_cpu_baseline:
+            # parity of the merged top-k: the only candidates within the cutoff are planted near-duplicates (a random
+            # len-64 alphanumeric string is ~55 edits from the query), and a planted row depends only on its global
+            # index, so rank 0 re-creates ALL of them on the host and lets the oracle rank them
+            from oracle import oracle as o
+
+            pidx = synth.planted_indices(0, args.total_candidates, args.plant_every)
+            prow = np.stack([synth.planted_row(q, ln, int(i)) for i in pidx]) if len(pidx) else np.zeros((0, ln), np.uint8)
+            d = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, prow, nthreads=1, score_cutoff=args.cutoff)
+            exp = sorted((int(dv) << 32) | int(i) for dv, i in zip(d, pidx) if dv != np.uint64(2**64 - 1))[: args.topk]
+            result["parity"] = {"checked": int(len(pidx)), "mismatches": int(sorted(keys) != exp),
+                                "what": f"merged top-{args.topk} keys vs the oracle's (distance, global index) ranking of all {len(pidx)} planted near-duplicates"}
+    if host_sample is not None:
         result["cpu_baseline"] = cpu_baseline(args, q, host_sample)
+    if host_sample is not None and args.mode == "many":
         # parity on the sample, in the same run
         from oracle import oracle as o
 
@@ -323,17 +412,25 @@ def main():
     print(json.dumps(result), flush=True)
 
 
-def measured_traffic(args, n):
+def measured_traffic(args, n, kernel_ms):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload
     (profiles/traffic.json, written by tools/rocpd_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs with the
-    gfx950 2x FETCH_SIZE correction of MI355X_MICROARCH.md).  None when no profile matches the workload."""
+    gfx950 2x FETCH_SIZE correction of MI355X_MICROARCH.md).  None when no profile matches the workload -- or when the
+    kernel has changed since the counters were collected (its steady-state time then differs from this run's by more
+    than 15 %): a stale counter is not evidence."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except OSError:
         return None
     key = f"{args.metric}:q{args.query_len}:n{n}:l{args.cand_len}:cut{args.cutoff}:{args.mode}"
     e = table.get(key)
-    return None if e is None else {"bytes_per_launch": e["total"], "read": e["read"], "write": e["write"], "source": e.get("source", "")}
+    if e is None:
+        return None
+    at = e.get("kernel_us_at_collection")
+    if at and abs(at / 1e3 - kernel_ms) > 0.15 * kernel_ms:
+        return None
+    return {"bytes_per_launch": e["total"], "read": e["read"], "write": e["write"], "source": e.get("source", ""),
+            **({"kernel_us_at_collection": at} if at else {})}
 
 
 def cpu_baseline(args, q, host_sample):

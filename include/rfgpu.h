@@ -173,14 +173,18 @@ size_t rf_corpus_alphabet_size(const rf_corpus *c, size_t *overflow_symbols);
  * rf_stream_many_*: out[i] = scorer.<op>_with_args(candidate_i, &args) over a corpus FILE that need not fit in
  * HBM: the file is scanned in tile ranges of at most `segment_bytes` of payload (0 = 256 MiB) through two device
  * buffer sets, the read + upload of one segment overlapping the scan of the previous one.  `out` is HOST memory
- * of n entries (n from the file; the result vector itself does live on the device during the pass).  Values,
- * None encoding and errors are those of rf_many_u32 / rf_many_f64. */
+ * with room for `out_capacity` entries; the file's own candidate count n (rf_corpus_file_count) decides how many are
+ * written, and a file holding more than out_capacity is refused with RF_ERR_INVALID_ARG before anything is written
+ * (the result vector itself does live on the device during the pass).  Values, None encoding and errors are those of
+ * rf_many_u32 / rf_many_f64.  Files are validated on load (section bounds, tile offsets, slot map): an inconsistent
+ * file is RF_ERR_INVALID_ARG, never an out-of-bounds access. */
 rf_status rf_corpus_save(const rf_corpus *c, const char *path);
 rf_status rf_corpus_load(const char *path, int device, rf_corpus **out);
+rf_status rf_corpus_file_count(const char *path, size_t *n);
 rf_status rf_stream_many_u32(const rf_comparator *c, const char *path, rf_op op, const rf_args *args, uint32_t *out,
-                             uint64_t segment_bytes, int device);
+                             size_t out_capacity, uint64_t segment_bytes, int device);
 rf_status rf_stream_many_f64(const rf_comparator *c, const char *path, rf_op op, const rf_args *args, double *out,
-                             uint64_t segment_bytes, int device);
+                             size_t out_capacity, uint64_t segment_bytes, int device);
 
 /* ---- one-vs-many ------------------------------------------------------------------------------
  * out[i] = scorer.<op>_with_args(candidate_i, &args) for every candidate, original order.
@@ -249,6 +253,15 @@ rf_status rf_topk_merge_keys_device(const uint64_t *d_keys, uint32_t n, uint32_t
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t *scores, const uint64_t *indices, const uint32_t *counts,
                             uint32_t lists, uint32_t k, uint32_t *out_score, uint64_t *out_index,
                             uint32_t *out_count);
+
+/* ---- measurement aid (not part of the drop-in surface) ----------------------------------------------------------
+ * The single-word scans are bound by VALU issue, not HBM.  rf_probe_issue_rate runs the library's own
+ * recurrence column for (metric, query_len) on register-resident pattern words -- no HBM, no LDS, no tile loop -- with
+ * blocks_per_cu (0 = 8) 256-thread workgroups per CU and reports wavefront-columns per nanosecond, which for
+ * 64-symbol candidates is the Gpairs/s no scan of that recurrence can exceed on this device.  bench.py reports it as
+ * roofline.issue_bound, measured in the same process as the scan.  Synchronous; uses the default stream. */
+rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, int device, uint32_t blocks_per_cu,
+                              double *wave_columns_per_ns);
 
 #ifdef __cplusplus
 }

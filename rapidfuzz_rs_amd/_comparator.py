@@ -184,16 +184,22 @@ class BatchComparator:
         N.check(fn(hs, q, corpus._h, op, C.byref(ca), res.ctypes.data, N.MEM_HOST, stream))
         return res
 
-    def stream_many(self, op: int, path: str, n: int, args: Optional[Args] = None, segment_bytes: int = 0, device: Optional[int] = None, *,
+    def stream_many(self, op: int, path: str, n: Optional[int] = None, args: Optional[Args] = None, segment_bytes: int = 0, device: Optional[int] = None, *,
                     score_cutoff=None, score_hint=None, weights=None, prefix_weight=None) -> np.ndarray:
         """`many` over a corpus FILE written by `Corpus.save` that need not fit in HBM (rf_stream_many_*): scanned in
-        segments of `segment_bytes` of payload, uploads overlapped with scans.  `n` = number of candidates in the file."""
+        segments of `segment_bytes` of payload, uploads overlapped with scans.  The number of candidates comes from the
+        file itself (`n`, if given, must agree with it)."""
         a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
         is_f = self.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
         ca = a.to_c(is_f)
-        res = np.empty(n, dtype=np.float64 if is_f else np.uint32)
+        cnt = C.c_size_t()
+        N.check(N.lib().rf_corpus_file_count(str(path).encode(), C.byref(cnt)))
+        if n is not None and n != cnt.value:
+            raise ValueError(f"{path} holds {cnt.value} candidates, not {n}")
+        res = np.empty(cnt.value, dtype=np.float64 if is_f else np.uint32)
         fn = N.lib().rf_stream_many_f64 if is_f else N.lib().rf_stream_many_u32
-        N.check(fn(self._h, str(path).encode(), op, C.byref(ca), res.ctypes.data, int(segment_bytes), default_device() if device is None else device))
+        N.check(fn(self._h, str(path).encode(), op, C.byref(ca), res.ctypes.data, res.size, int(segment_bytes),
+                   default_device() if device is None else device))
         return res
 
     def distance_many(self, corpus, args=None, **kw):

@@ -63,10 +63,11 @@ class RfHostLayout(C.Structure):
 SYMBOLS = [
     "rf_args_default", "rf_last_error", "rf_device_count",
     "rf_comparator_new", "rf_comparator_clone", "rf_comparator_free", "rf_comparator_metric",
-    "rf_comparator_query_len", "rf_comparator_pm", "rf_comparator_new_u32", "rf_corpus_pack_u32", "rf_corpus_alphabet_size", "rf_corpus_save", "rf_corpus_load", "rf_stream_many_u32", "rf_stream_many_f64",
+    "rf_comparator_query_len", "rf_comparator_pm", "rf_comparator_new_u32", "rf_corpus_pack_u32", "rf_corpus_alphabet_size", "rf_corpus_save", "rf_corpus_load", "rf_stream_many_u32", "rf_stream_many_f64", "rf_corpus_file_count",
     "rf_corpus_pack", "rf_corpus_pack_rows_device", "rf_corpus_free", "rf_corpus_layout_host",
     "rf_host_layout_free", "rf_corpus_count", "rf_corpus_payload_bytes", "rf_corpus_device_bytes",
     "rf_corpus_device", "rf_many_u32", "rf_many_f64", "rf_one_u32", "rf_one_f64", "rf_many_multi_u32", "rf_many_multi_f64", "rf_topk_u32", "rf_topk_keys_device", "rf_topk_merge_keys_device", "rf_topk_merge_u32",
+    "rf_probe_issue_rate",
 ]
 
 
@@ -127,8 +128,9 @@ def lib() -> C.CDLL:
     L.rf_corpus_alphabet_size.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.rf_corpus_save.argtypes = [vp, C.c_char_p]
     L.rf_corpus_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
-    L.rf_stream_many_u32.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(RfArgs), vp, C.c_uint64, C.c_int]
-    L.rf_stream_many_f64.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(RfArgs), vp, C.c_uint64, C.c_int]
+    L.rf_stream_many_u32.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(RfArgs), vp, C.c_size_t, C.c_uint64, C.c_int]
+    L.rf_stream_many_f64.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(RfArgs), vp, C.c_size_t, C.c_uint64, C.c_int]
+    L.rf_corpus_file_count.argtypes = [C.c_char_p, C.POINTER(C.c_size_t)]
     L.rf_corpus_pack_rows_device.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp, C.POINTER(vp)]
     L.rf_corpus_free.argtypes = [vp]
     L.rf_corpus_layout_host.argtypes = [vp, vp, C.c_size_t, C.POINTER(RfHostLayout)]
@@ -149,6 +151,7 @@ def lib() -> C.CDLL:
     L.rf_topk_u32.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint64, vp, vp, u32p, vp, C.c_int, vp]
     L.rf_topk_keys_device.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint32, vp, vp, C.c_int, vp]
     L.rf_topk_merge_keys_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_int, vp]
+    L.rf_probe_issue_rate.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.rf_topk_merge_u32.argtypes = [C.c_int, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, u32p]
     _lib = L
     return L

@@ -44,6 +44,7 @@ struct DeviceGuard {
     bool ok = false;
     explicit DeviceGuard(int dev)
     {
+        if (dev < 0) return;  // nothing to select (e.g. an empty corpus: the call never touches a device)
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         ok = hipSetDevice(dev) == hipSuccess;
     }
@@ -68,7 +69,9 @@ struct rf_comparator {
     // u32 ("char") queries: the symbols, and one byte-level comparator per wide corpus searched (see resolve())
     bool wide = false;
     std::vector<uint32_t> s1w;
-    mutable std::map<uint64_t, rf_comparator*> lowered;
+    // (shared_ptr: a call keeps the lowered comparator it runs on alive even if another host thread's call evicts it from
+    // this bounded cache meanwhile -- handles may be shared between threads)
+    mutable std::map<uint64_t, std::shared_ptr<rf_comparator>> lowered;
 };
 
 struct rf_corpus {
@@ -215,7 +218,7 @@ rf_status rf_comparator_clone(const rf_comparator* c, rf_comparator** out)
 void rf_comparator_free(rf_comparator* c)
 {
     if (!c) return;
-    for (auto& kv : c->lowered) rf_comparator_free(kv.second);
+    c->lowered.clear();
     for (auto& kv : c->d_pm) {
         DeviceGuard g(kv.first);
         (void)hipFree(kv.second);
@@ -236,7 +239,10 @@ const uint64_t* rf_comparator_pm(const rf_comparator* c, size_t* block_count)
 // kAbsentId, an id no candidate byte has, so it can never match (which is all any metric on this path asks of it);
 // a symbol the corpus lumped into its overflow class cannot be told apart from the other overflow symbols, so the
 // call is refused rather than answered approximately.  Lowered comparators are cached per corpus.
-static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff, bool* overflow_hit = nullptr)
+using ComparatorRef = std::shared_ptr<rf_comparator>;
+static ComparatorRef own_comparator(rf_comparator* c) { return ComparatorRef(c, [](rf_comparator* p) { rf_comparator_free(p); }); }
+
+static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff, ComparatorRef* hold, bool* overflow_hit = nullptr)
 {
     if (overflow_hit) *overflow_hit = false;
     if (!c || !corpus) {
@@ -250,7 +256,8 @@ static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const 
     std::lock_guard<std::mutex> lock(c->mu);
     auto it = c->lowered.find(corpus->uid);
     if (it != c->lowered.end()) {
-        *eff = it->second;
+        *hold = it->second;
+        *eff = hold->get();
         return RF_OK;
     }
     const size_t len = c->wide ? c->s1w.size() : c->s1.size();
@@ -280,11 +287,9 @@ static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const 
     rf_comparator* low = nullptr;
     const rf_status s = rf_comparator_new(c->metric, ids.data(), ids.size(), &low);
     if (s != RF_OK) return s;
-    if (c->lowered.size() >= 64) {  // bounded cache: drop the oldest corpus
-        rf_comparator_free(c->lowered.begin()->second);
-        c->lowered.erase(c->lowered.begin());
-    }
-    c->lowered[corpus->uid] = low;
+    if (c->lowered.size() >= 64) c->lowered.erase(c->lowered.begin());  // bounded cache: drop the oldest corpus (calls in flight hold their own reference)
+    *hold = own_comparator(low);
+    c->lowered[corpus->uid] = *hold;
     *eff = low;
     return RF_OK;
 }
@@ -296,6 +301,7 @@ static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const 
 // scope; its payload is released in stream order.
 struct Effective {
     const rf_comparator* c = nullptr;
+    ComparatorRef hold;  // keeps a lowered comparator alive for the duration of the call
     const rf_corpus* corpus = nullptr;
     std::unique_ptr<rf_corpus> image;
     uint8_t* temp = nullptr;
@@ -311,7 +317,7 @@ struct Effective {
 static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hipStream_t st, Effective* e)
 {
     bool overflow_hit = false;
-    const rf_status rs = resolve(c_in, corpus, &e->c, &overflow_hit);
+    const rf_status rs = resolve(c_in, corpus, &e->c, &e->hold, &overflow_hit);
     e->corpus = corpus;
     e->stream = st;
     if (rs == RF_OK || !overflow_hit || !corpus->d_raw) return rs;
@@ -339,9 +345,10 @@ static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corp
             rf_comparator* low = nullptr;
             const rf_status s = rf_comparator_new(c_in->metric, ids.data(), ids.size(), &low);
             if (s != RF_OK) return s;
-            it = c_in->lowered.emplace(~0ull, low).first;
+            it = c_in->lowered.emplace(~0ull, own_comparator(low)).first;
         }
-        e->c = it->second;
+        e->hold = it->second;
+        e->c = e->hold.get();
     }
     // (symbol -> id) as an open-addressing table the kernel stages in LDS
     uint32_t cap = 8;
@@ -1135,6 +1142,12 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
     }
 
+    // The device finishes in u32 (results are u32): with a common weight factor f every intermediate is bounded by
+    // f * (len1 + max_len) -- refuse what would wrap instead of returning it mod 2^32 (the reference computes in usize).
+    if ((uint64_t)std::max<uint32_t>(p->factor, 1) * ((uint64_t)p->len1 + corpus->max_len) > 0xFFFFFFFEull) {
+        set_error("weights x string lengths exceed the u32 range of the device results");
+        return RF_ERR_UNSUPPORTED;
+    }
     {
         // finishing coefficients: dist = dS*S + dM*Mx + dR*raw, maximum = mS*S + mM*Mx (rf_device.hpp "Finishing")
         const int32_t f = (int32_t)p->factor;
@@ -1240,6 +1253,11 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     if (const rf_status rs = make_effective(c_in, corpus_in, (hipStream_t)stream, &eff); rs != RF_OK) return rs;
     const rf_comparator* c = eff.c;
     const rf_corpus* corpus = eff.corpus;
+    DeviceGuard guard(corpus->n ? corpus->device : -1);  // (before plan(): grids are sized from the current device's CU count)
+    if (corpus->n && !guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
     ScanParams p;
     RawKind raw = RAW_LEV;
     rf_status s = plan(c, corpus, op, args, f64_out, &p, &raw);
@@ -1248,11 +1266,6 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     if (!out) {
         set_error("null output");
         return RF_ERR_INVALID_ARG;
-    }
-    DeviceGuard guard(corpus->device);
-    if (!guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
     }
     s = comparator_device_pm(c, corpus->device, &p.pm);
     if (s != RF_OK) return s;
@@ -1353,9 +1366,10 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
     std::vector<ScanParams> ps(q);
     std::vector<RawKind> raws(q, RAW_LEV);
     std::vector<const rf_comparator*> eff(q, nullptr);
+    std::vector<ComparatorRef> holds(q);
     for (uint32_t i = 0; i < q; ++i) {
         bool overflow_hit = false;
-        if (resolve(cs_in[i], corpus, &eff[i], &overflow_hit) != RF_OK && overflow_hit && corpus->d_raw) {
+        if (resolve(cs_in[i], corpus, &eff[i], &holds[i], &overflow_hit) != RF_OK && overflow_hit && corpus->d_raw) {
             // a query with overflow-class symbols needs its own translated image of the corpus: one launch per query
             for (uint32_t j = 0; j < q; ++j) {
                 const rf_status sj = run_many(cs_in[j], corpus, op, args, static_cast<char*>(out) + (size_t)j * row_bytes, out_mem, stream, f64_out);
@@ -1365,7 +1379,7 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
         }
     }
     for (uint32_t i = 0; i < q; ++i) {
-        rf_status s = resolve(cs_in[i], corpus, &eff[i]);
+        rf_status s = resolve(cs_in[i], corpus, &eff[i], &holds[i]);
         if (s == RF_OK) s = plan(eff[i], corpus, op, args, f64_out, &ps[i], &raws[i]);
         if (s != RF_OK) return s;
     }
@@ -1703,6 +1717,20 @@ rf_status read_header(FILE* f, FileHeader* h)
         set_error("not a corpus file of this version");
         return RF_ERR_INVALID_ARG;
     }
+    // every section must lie inside the file (sizes in 128-bit-safe steps: the counts are attacker-sized)
+    uint64_t fsize = 0;
+    if (fseeko(f, 0, SEEK_END) == 0) fsize = (uint64_t)ftello(f);
+    auto inside = [&](uint64_t off, uint64_t count, uint64_t elem) { return off <= fsize && count <= (fsize - off) / std::max<uint64_t>(elem, 1); };
+    const bool uniform = (h->flags & kFlagUniform) != 0;
+    const uint64_t raw_elem = (h->flags & kFlagRaw) ? ((h->flags & kFlagRaw16) ? 2 : 4) : 0;
+    const bool ok = h->n < 0xFFFFFFFFull && inside(h->off_lengths, (uint64_t)h->n_lengths * 2, 4) &&
+                    (uniform || (inside(h->off_tiles, h->n_tiles, sizeof(TileDesc)) && inside(h->off_orig, (uint64_t)h->n_tiles * kWave, 4))) &&
+                    inside(h->off_alphabet, (uint64_t)h->n_alphabet * 2 + h->n_overflow, 4) && inside(h->off_data, h->data_bytes, 1) &&
+                    (!raw_elem || inside(h->off_raw, h->data_bytes, raw_elem)) && h->n_alphabet <= 256 && h->off_data >= sizeof(FileHeader);
+    if (!ok) {
+        set_error("corpus file is inconsistent: a section lies outside the file (truncated?)");
+        return RF_ERR_INVALID_ARG;
+    }
     return RF_OK;
 }
 }  // namespace
@@ -1810,6 +1838,55 @@ static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vect
     }
     for (uint32_t i = 0; i < h.n_alphabet; ++i) c->alphabet.emplace(a[2 * i], (uint8_t)a[2 * i + 1]);
     for (uint32_t i = 0; i < h.n_overflow; ++i) c->overflow.insert(a[(size_t)h.n_alphabet * 2 + i]);
+    // Nothing in the file is trusted: every index the kernels will follow is checked against what it indexes, so a
+    // truncated, stale or crafted file is refused here instead of becoming an out-of-bounds device access.
+    auto bad = [](const char* what) {
+        set_error(std::string("corpus file is inconsistent: ") + what);
+        return RF_ERR_INVALID_ARG;
+    };
+    if (c->data_bytes < kTailPad) return bad("payload smaller than its tail padding");
+    const uint64_t body = c->data_bytes - kTailPad;
+    if (c->n > (uint64_t)c->n_tiles * kWave) return bad("more candidates than tile slots");
+    if ((c->n == 0) != (c->n_tiles == 0) && c->n_tiles == 0) return bad("candidates without tiles");
+    if (c->lengths.size() != c->length_first_tile.size()) return bad("length table");
+    for (size_t i = 0; i < c->lengths.size(); ++i) {
+        if (i && (c->lengths[i] <= c->lengths[i - 1] || c->length_first_tile[i] <= c->length_first_tile[i - 1])) return bad("length table not ascending");
+        if (c->length_first_tile[i] >= c->n_tiles || c->lengths[i] > c->max_len) return bad("length table out of range");
+    }
+    if (!c->lengths.empty() && (c->length_first_tile[0] != 0 || c->lengths.back() != c->max_len)) return bad("length table does not cover the tiles");
+    if (c->uniform) {
+        if (c->lengths.size() > 1 || c->uniform_len != c->max_len || (c->n_tiles && c->lengths.empty())) return bad("uniform flag vs length table");
+        if (tile_bytes(c->uniform_len) > 0xFFFFFFFFull || (uint64_t)c->n_tiles * tile_bytes(c->uniform_len) != body) return bad("uniform payload size");
+        if (c->n_tiles && c->n <= (uint64_t)(c->n_tiles - 1) * kWave) return bad("empty trailing tile");
+    } else {
+        if (c->n_tiles && c->lengths.empty()) return bad("tiles without a length table");
+        size_t li = 0;
+        uint64_t expect_off = 0, real = 0;
+        for (uint32_t t = 0; t < c->n_tiles; ++t) {
+            const TileDesc& td = (*tiles)[t];
+            while (li + 1 < c->lengths.size() && c->length_first_tile[li + 1] <= t) ++li;
+            if (td.len != c->lengths[li]) return bad("tile length vs length table");
+            if (td.slot0 != t * (uint32_t)kWave) return bad("tile slot base");
+            if (td.data_off != expect_off) return bad("tile payload offset");
+            expect_off += tile_bytes(td.len);
+            if (expect_off > body) return bad("tile payload beyond the data section");
+        }
+        if (expect_off != body) return bad("data section size");
+        std::vector<uint8_t> seen;  // every original index exactly once
+        if (c->n <= (64u << 20)) seen.assign((size_t)c->n, 0);
+        for (uint32_t v : *orig) {
+            if (v == kPad) continue;
+            if (v >= c->n) return bad("slot map entry beyond the candidate count");
+            if (!seen.empty()) {
+                if (seen[v]) return bad("slot map maps two slots to one candidate");
+                seen[v] = 1;
+            }
+            ++real;
+        }
+        if (real != c->n) return bad("slot map does not cover every candidate");
+    }
+    for (const auto& kv : c->alphabet)
+        if (kv.second >= kOverflowId) return bad("alphabet id");
     return RF_OK;
 }
 
@@ -1885,8 +1962,8 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
 // One pass of `scorer.<op>` over a corpus FILE that need not fit in HBM.  Segments are tile ranges of at most
 // `segment_bytes` of payload; two device buffer sets alternate, segment k+1 is read and uploaded (copy stream) while
 // segment k is scanned (compute stream).  The result vector (n x 4 or 8 bytes) does live on the device for the pass.
-static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, void* out_host, bool f64_out,
-                             uint64_t segment_bytes, int device)
+static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, void* out_host, size_t out_capacity,
+                             bool f64_out, uint64_t segment_bytes, int device)
 {
     if (!c || !path || !args || !out_host) {
         set_error("rf_stream_many: invalid argument");
@@ -1913,6 +1990,11 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     std::vector<uint32_t> orig;
     s = load_meta(fc.f, h, &meta, &tiles, &orig);
     if (s != RF_OK) return s;
+    if (out_capacity < meta.n) {
+        set_error("rf_stream_many: the file holds " + std::to_string(meta.n) + " candidates but `out` has room for " + std::to_string(out_capacity) +
+                  " (ask rf_corpus_file_count)");
+        return RF_ERR_INVALID_ARG;
+    }
     if (meta.n == 0) return RF_OK;
     const uint64_t uniform_tb = tile_bytes(meta.uniform_len);
     auto tile_off = [&](uint32_t t) { return meta.uniform ? (uint64_t)t * uniform_tb : (t < meta.n_tiles ? tiles[t].data_off : meta.data_bytes - kTailPad); };
@@ -2030,6 +2112,11 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         if (slot[b].uploaded) (void)hipEventDestroy(slot[b].uploaded);
         if (slot[b].scanned) (void)hipEventDestroy(slot[b].scanned);
     }
+    {   // this pass' identity dies with it: drop the comparator lowered for it (a long-lived u32 comparator would
+        // otherwise accumulate one cache entry per streamed pass)
+        std::lock_guard<std::mutex> lock(c->mu);
+        c->lowered.erase(meta.uid);
+    }
     if (d_sigma) (void)hipFree(d_sigma);
     if (d_out) (void)hipFree(d_out);
     if (s_copy) (void)hipStreamDestroy(s_copy);
@@ -2042,15 +2129,59 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     return RF_OK;
 }
 
-rf_status rf_stream_many_u32(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, uint32_t* out, uint64_t segment_bytes,
-                             int device)
+rf_status rf_stream_many_u32(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, uint32_t* out, size_t out_capacity,
+                             uint64_t segment_bytes, int device)
 {
-    return stream_many(c, path, op, args, out, false, segment_bytes, device);
+    return stream_many(c, path, op, args, out, out_capacity, false, segment_bytes, device);
 }
-rf_status rf_stream_many_f64(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, double* out, uint64_t segment_bytes,
-                             int device)
+rf_status rf_stream_many_f64(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, double* out, size_t out_capacity,
+                             uint64_t segment_bytes, int device)
 {
-    return stream_many(c, path, op, args, out, true, segment_bytes, device);
+    return stream_many(c, path, op, args, out, out_capacity, true, segment_bytes, device);
+}
+rf_status rf_corpus_file_count(const char* path, size_t* n)
+{
+    if (!path || !n) {
+        set_error("rf_corpus_file_count: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    FileCloser fc{std::fopen(path, "rb")};
+    if (!fc.f) {
+        set_error(std::string("rf_corpus_file_count: cannot open ") + path);
+        return RF_ERR_INVALID_ARG;
+    }
+    FileHeader h;
+    const rf_status s = read_header(fc.f, &h);
+    if (s == RF_OK) *n = (size_t)h.n;
+    return s;
+}
+
+// Issue-rate probe (rf_probe.hip): the product's own column code on register-resident PM words.
+rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, int device, uint32_t blocks_per_cu, double* wave_columns_per_ns)
+{
+    if (!wave_columns_per_ns) return RF_ERR_INVALID_ARG;
+    *wave_columns_per_ns = 0.0;
+    RawKind raw;
+    switch (metric) {
+    case RF_LEVENSHTEIN: raw = RAW_LEV; break;
+    case RF_INDEL:
+    case RF_LCS_SEQ:
+    case RF_FUZZ_RATIO: raw = RAW_LCS; break;
+    case RF_OSA: raw = RAW_OSA; break;
+    default: set_error("rf_probe_issue_rate: no register-only probe for this metric"); return RF_ERR_UNSUPPORTED;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("rf_probe_issue_rate: cannot select device");
+        return RF_ERR_NO_DEVICE;
+    }
+    const hipError_t e = launch_probe(raw, query_len, blocks_per_cu ? (int)blocks_per_cu : 8, 40000, wave_columns_per_ns);
+    if (e == hipErrorInvalidValue) {
+        set_error("rf_probe_issue_rate: no probe for this query length");
+        return RF_ERR_UNSUPPORTED;
+    }
+    RF_HIP(e);
+    return RF_OK;
 }
 
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t* scores, const uint64_t* indices, const uint32_t* counts,

@@ -40,6 +40,8 @@ __device__ __forceinline__ uint64_t lut3(uint64_t a, uint64_t b, uint64_t c)
 constexpr uint32_t T_XOR_OR = (TA ^ TB) | TC;       // (a ^ b) | c
 constexpr uint32_t T_OR_NOR = TA | (~(TB | TC));    // a | ~(b | c)
 constexpr uint32_t T_OR_ANDN = TA | (TB & ~TC);      // a | (b & ~c)
+constexpr uint32_t T_AND_OR = TA & (TB | TC);        // a & (b | c)
+constexpr uint32_t T_NOR3 = ~(TA | TB | TC);         // ~(a | b | c)
 
 // (x << 1) | carry_in.  Measured on gfx950 (tools/microbench.hip, profiles/microbench_r01.txt): the 64-bit VALU
 // forms v_lshl_add_u64 / v_lshlrev_b64 issue at the same (half) rate as ONE v_alignbit_b32 / v_lshl_or_b32, so a
@@ -55,6 +57,15 @@ __device__ __forceinline__ uint64_t shl1_const(uint64_t x)
         asm("v_lshl_add_u64 %0, %1, 1, 1" : "=v"(r) : "v"(x));
     else
         asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// (x << 1) + y in one v_lshl_add_u64 (callers guarantee the terms are disjoint where an OR is meant)
+__device__ __forceinline__ uint64_t shl1_add(uint64_t x, uint64_t y)
+{
+    // (asm: written as (x << 1) + y hipcc sometimes splits the add into {lo, 0} + {0, hi} partial sums -- two
+    // v_lshl_add_u64 and two v_mov; the price of the asm is one s_nop of hazard padding after it)
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
 __device__ __forceinline__ uint64_t shl1_var(uint64_t x, uint32_t cin)
@@ -103,6 +114,18 @@ struct LevState {
             vn[w] = 0;
         }
     }
+    // One column, after algebra on levenshtein.rs:467-484 (D0 is never materialised):
+    //   e   = (((x & VP) + VP) ^ VP) | x           D0 = e | VN
+    //   HN  = e & VP                               (== D0 & VP because VP & VN == 0)
+    //   HP  = VN | ~(e | VP)                       (== VN | ~(D0 | VP))
+    //   HP' = (HP << 1) + carry-in                 one v_lshl_add_u64
+    //   VN' = HP' & (e | VN)                       one 3-input LUT per half
+    //   T   = ~(e | VN | HP')                      one 3-input LUT per half
+    //   VP' = (HN << 1) + T (+ carry-in)           one v_lshl_add_u64: the two terms are disjoint -- a set bit i of HN << 1
+    //         says the cell above-left..above lost one, D[i-1][j] = D[i-1][j-1] - 1, which forces D[i][j] = D[i-1][j-1],
+    //         i.e. bit i of D0 is set and bit i of T is clear -- so the add never carries and equals the reference's OR.
+    // 12 full-rate + 3 half-rate VALU instructions per word (the textbook order costs 14 + 3: D0 and the separate shift
+    // of HN are gone).
     __device__ __forceinline__ void step(const uint64_t (&pm_row)[W])
     {
         uint32_t hp_c = 1, hn_c = 0;  // levenshtein.rs:824-825
@@ -112,18 +135,17 @@ struct LevState {
             if (w > 0) x |= hn_c;                            // :847
             const uint64_t p = vp[w], n = vn[w];
             const uint64_t sum = (x & p) + p;
-            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);    // (sum ^ vp) | x
-            const uint64_t d0 = e | n;                       // :848
-            const uint64_t hn = e & p;                       // == d0 & vp because vp & vn == 0   (:852)
-            const uint64_t hp = lut3<T_OR_NOR>(n, d0, p);    // vn | ~(d0 | vp)                  (:851)
-            const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_var(hp, hp_c);  // :865-866
-            const uint64_t hns = w == 0 ? shl1_const<0>(hn) : shl1_var(hn, hn_c);
-            if (w + 1 < W) {                                 // :857-858
-                hp_c = (uint32_t)(hp >> 63);
-                hn_c = (uint32_t)(hn >> 63);
-            }
-            vn[w] = hps & d0;                                // :869
-            vp[w] = lut3<T_OR_NOR>(hns, hps, d0);            // hn | ~(d0 | hp)                  (:868)
+            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);    // (sum ^ vp) | x;  d0 = e | vn (:848)
+            const uint64_t hn = e & p;                       // :852
+            const uint64_t hp = lut3<T_OR_NOR>(n, e, p);     // vn | ~(d0 | vp) == vn | ~(e | vp)   (:851)
+            const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_add(hp, (uint64_t)hp_c);  // :865-866
+            if (w + 1 < W) hp_c = (uint32_t)(hp >> 63);      // :857-858
+            vn[w] = lut3<T_AND_OR>(hps, e, n);               // hp & d0                            (:869)
+            const uint64_t t = lut3<T_NOR3>(e, n, hps);      // ~(d0 | hp)
+            uint64_t v = shl1_add(hn, t);                    // hn | ~(d0 | hp), hn shifted          (:868)
+            if (w > 0) v |= hn_c;                            // bit 0 of T is clear when hn_c is set (x |= hn_c above)
+            if (w + 1 < W) hn_c = (uint32_t)(hn >> 63);
+            vp[w] = v;
         }
     }
     // the same column with the horizontal deltas entering word 0 / leaving word W-1 as variables: one 512-row
@@ -136,15 +158,14 @@ struct LevState {
             const uint64_t p = vp[w], n = vn[w];
             const uint64_t sum = (x & p) + p;
             const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
-            const uint64_t d0 = e | n;
             const uint64_t hn = e & p;
-            const uint64_t hp = lut3<T_OR_NOR>(n, d0, p);
-            const uint64_t hps = shl1_var(hp, hp_c);
-            const uint64_t hns = shl1_var(hn, hn_c);
+            const uint64_t hp = lut3<T_OR_NOR>(n, e, p);
+            const uint64_t hps = shl1_add(hp, (uint64_t)hp_c);
             hp_c = (uint32_t)(hp >> 63);
+            vn[w] = lut3<T_AND_OR>(hps, e, n);
+            const uint64_t t = lut3<T_NOR3>(e, n, hps);
+            vp[w] = shl1_add(hn, t) | hn_c;
             hn_c = (uint32_t)(hn >> 63);
-            vn[w] = hps & d0;
-            vp[w] = lut3<T_OR_NOR>(hns, hps, d0);
         }
     }
     // popcount contribution of this group's words to D[len1][j]; word w is absolute word (word0 + w)

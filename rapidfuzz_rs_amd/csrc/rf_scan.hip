@@ -4,6 +4,8 @@
 //   scan_multi_kernel             Q queries per pass over the corpus
 //   topk_final_kernel             selection of the k best candidate keys
 // Device helpers live in rf_device.hpp; the long-pattern, generalized-weights and Jaro kernels in rf_long.hip / rf_jaro.hip.
+#include <atomic>
+
 #include "rf_device.hpp"
 
 namespace rf {
@@ -400,10 +402,13 @@ __global__ __launch_bounds__(kFinalThreads) void topk_final_kernel(const uint64_
         if (lane < k) out[lane] = best.key;
         // re-arm for the next launch on this scratch.  After the SAMPLE pass of a top-k call the bound becomes the
         // sample's k-th best key: the k-th best of a subset bounds the k-th best of the whole corpus from above.
+        // The scans admit keys strictly below their limit (WaveTopK::offer) and the sample's lists are discarded, so the
+        // bound handed over is kth + 1: the sample's k-th best candidate itself may BE the corpus' k-th best and has to
+        // be found again by the main scan (keys are unique, so `key < kth + 1` is `key <= kth`).
         const uint64_t kth = best.worst(k);
         if (lane == 0) {
             if (count_ptr) *count_ptr = 0;
-            if (bound_ptr) *bound_ptr = bound_from_result ? kth : ~0ull;
+            if (bound_ptr) *bound_ptr = (bound_from_result && kth != ~0ull) ? kth + 1 : ~0ull;
         }
     }
 }
@@ -422,13 +427,22 @@ hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t
 int scan_max_grid()
 {
     // 8 workgroups (32 waves) are resident per CU; launching 4x that lets early finishers be replaced and
-    // measured +5% over an exactly-resident grid (profiles/grid_sweep_r01.txt).  RF_SCAN_BLOCKS_PER_CU overrides.
+    // measured +5% over an exactly-resident grid.  RF_SCAN_BLOCKS_PER_CU overrides.  The CU count is the current
+    // device's (256 on a whole MI355X, 32 on a CPX partition), cached per device.
     static const int per_cu = [] {
         const char* e = getenv("RF_SCAN_BLOCKS_PER_CU");
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 32;
     }();
-    return 256 * per_cu;
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256 * per_cu;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n * per_cu;
 }
 
 template <class State>

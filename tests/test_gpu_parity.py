@@ -1306,3 +1306,79 @@ def test_bench_two_ranks_share_one_gpu():
         keys += [(int(v), rank * n + i) for i, v in enumerate(dist_r.tolist())]
     keys.sort()
     assert [tuple(k) for k in d["config"]["topk_best"]] == keys[:4]
+
+
+def _bench_json(cmd, env=None):
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # only rank 0 prints
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (it used to ignore the
+    flag and report one).  Two ranks share this box's one GPU over gloo (test mode); n_gpus must be what actually joined."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["RF_BENCH_BACKEND"] = "gloo"
+    d = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--candidates", "200000", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline"], env)
+    assert d["n_gpus"] == 2 and d["config"]["ranks_joined"] == 2 and d["config"]["topk_found"] == 16
+    # and a launcher that starts a different number of ranks than --gpus says is refused, not mis-reported
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--candidates", "1000"], capture_output=True, text=True, cwd=root,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_bench_c5_preset_same_answer_for_every_world_size():
+    """--config c5 (BASELINE.json configs[4] scaled down): ONE logical corpus split over the ranks, cutoff 3, top-16,
+    gather + merge every step.  World sizes 1 and 2 must return the same merged top-k (checksum), equal to the oracle's
+    ranking of the planted near-duplicates; the N=1 line goes through the RCCL collective."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--config", "c5", "--total-candidates", "3000000", "--plant-every", "50000", "--steps", "3",
+            "--warmup", "1", "--cpu-seconds", "0.3"]
+    d1 = _bench_json(base, env)
+    assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["config"]["rccl_ranks"] == 1
+    assert d1["parity"]["mismatches"] == 0 and d1["parity"]["checked"] == 60 and "cpu_baseline" in d1
+    assert d1["roofline"]["survey_8d"]["bytes_per_pair"] == 64 and d1["roofline"]["algorithmic_bytes_per_pair"] == 16
+    d2 = _bench_json(base + ["--gpus", "2"], dict(env, RF_BENCH_BACKEND="gloo"))
+    assert d2["n_gpus"] == 2 and d2["parity"]["mismatches"] == 0
+    assert d2["config"]["topk_checksum"] == d1["config"]["topk_checksum"] and d2["config"]["topk_best"] == d1["config"]["topk_best"]
+
+
+@pytest.mark.parametrize("k", [1, 2, 16])
+def test_topk_best_match_inside_the_bound_sample(k):
+    """the sampled bound used to be the sample's exact k-th best key while offers were filtered with a
+    strict `<`, so when the corpus' k best candidates all sat in sampled tiles the k-th of them was lost (k = 1: an empty
+    result).  The sample visits tiles tile_begin + m * tile_step with tile_step = n_tiles / 1024; plant the k best there."""
+    import torch
+
+    n_tiles = 8192 + 640  # >= 8 * 1024 tiles: the sample pass runs, tile_step = 8
+    n = n_tiles * 64
+    step = n_tiles // 1024
+    q = synth.query(64, 77)
+    rows = synth.rows_device(n, 64, seed=78, device=torch.device("cuda", 0))
+    qrow = torch.tensor(list(q), dtype=torch.uint8, device=rows.device)
+    planted = []
+    for j in range(k):
+        idx = (step * (37 + 101 * j)) * 64 + (5 * j) % 64  # a lane of a sampled tile
+        r = qrow.clone()
+        r[:j % 3] = 33  # 0..2 substitutions by '!': distances 0, 1, 2, 0, ...
+        rows[idx] = r
+        planted.append((j % 3, idx))
+    corpus = rf.Corpus.from_device_rows(rows)
+    bc = rf.distance.levenshtein.BatchComparator(q)
+    for kw in ({}, {"score_cutoff": 3}):
+        s, i = bc.topk(corpus, k, **kw)
+        assert sorted(zip(s.tolist(), i.tolist())) == sorted(planted), (k, kw)
