@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librfgpu.so")
+LIB_PATH = os.environ.get("RF_LIB") or os.path.join(_HERE, "librfgpu.so")  # RF_LIB: an A/B build of the library (tools/ab.sh)
 
 RF_OK, RF_ERR_INVALID_ARG, RF_ERR_HIP, RF_ERR_UNSUPPORTED, RF_ERR_NO_DEVICE, RF_ERR_OOM = range(6)
 STATUS_NAMES = ["RF_OK", "RF_ERR_INVALID_ARG", "RF_ERR_HIP", "RF_ERR_UNSUPPORTED", "RF_ERR_NO_DEVICE", "RF_ERR_OOM"]

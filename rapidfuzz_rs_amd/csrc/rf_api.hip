@@ -93,17 +93,20 @@ struct rf_corpus {
     std::vector<uint32_t> length_first_tile;  // first tile of each distinct length
     uint8_t sigma[256];           // symbol renaming: the packed corpus stores sigma[c] for candidate byte c
     uint8_t* d_sigma = nullptr;   // device copy
-    // top-k scratch, one per stream the corpus has been searched on: [candidate keys | bound | counter].  The kernels
-    // leave bound/counter re-armed, so a top-k call is two launches and no allocation or memset (topk_core()).
+    // top-k scratch, one per stream the corpus has been searched on: [candidate keys by way | root table | bound | counters].  The
+    // kernels leave bound/counters re-armed, so a top-k call is two launches (one under a tight cutoff) and no
+    // allocation or memset (topk_core()).
     struct TopkScratch {
-        uint64_t* cand = nullptr;
+        uint64_t* cand = nullptr;  // (also the base of the allocation)
+        uint64_t* root = nullptr;
         uint64_t* bound = nullptr;
-        uint32_t* count = nullptr;
+        uint32_t* ctl = nullptr;
+        uint32_t seg_cap = 0;
     };
     mutable std::mutex scratch_mu;
     mutable std::map<hipStream_t, TopkScratch> topk_scratch;
-    // A top-k call is four launches that hand state to each other through the scratch (sample -> bound -> scan ->
-    // select, which re-arms it).  Host threads sharing a stream must not interleave those sequences: the enqueue
+    // A top-k call is two launches that hand state to each other through the scratch (sample scan -> bound -> scan, each
+    // selecting in its last workgroup and re-arming it).  Host threads sharing a stream must not interleave those sequences: the enqueue
     // section of topk_core() runs under this lock (kernels of one stream then execute in enqueue order).
     mutable std::mutex topk_enqueue_mu;
     // u32 ("char") corpora: the stored byte is the symbol's id in THIS corpus' alphabet.  Ids 0..253 are the 254 most
@@ -1505,14 +1508,18 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         std::lock_guard<std::mutex> lock(owner->scratch_mu);
         auto it = owner->topk_scratch.find(st);
         if (it == owner->topk_scratch.end()) {
-            const size_t cap = (size_t)scan_grid(corpus->n_tiles) * kWave;
+            // [64 way segments of candidate keys | root table 64 x 64 keys | bound (u64, own line) | control block 65 x 128 B]
+            const size_t ways = 64, per_way = ((size_t)scan_grid(corpus->n_tiles) + ways - 1) / ways;
+            sc.seg_cap = (uint32_t)(per_way * kWave);
+            const size_t cand_bytes = ways * sc.seg_cap * sizeof(uint64_t), root_bytes = ways * kWave * sizeof(uint64_t), ctl_bytes = 65 * 128;
             uint8_t* mem = nullptr;
-            RF_HIP(hipMalloc((void**)&mem, cap * sizeof(uint64_t) + 16));
+            RF_HIP(hipMalloc((void**)&mem, cand_bytes + root_bytes + 128 + ctl_bytes));
             sc.cand = reinterpret_cast<uint64_t*>(mem);
-            sc.bound = sc.cand + cap;
-            sc.count = reinterpret_cast<uint32_t*>(sc.bound + 1);
+            sc.root = reinterpret_cast<uint64_t*>(mem + cand_bytes);
+            sc.bound = reinterpret_cast<uint64_t*>(mem + cand_bytes + root_bytes);
+            sc.ctl = reinterpret_cast<uint32_t*>(mem + cand_bytes + root_bytes + 128);
             hipError_t e0 = hipMemsetAsync(sc.bound, 0xFF, sizeof(uint64_t), st);
-            if (e0 == hipSuccess) e0 = hipMemsetAsync(sc.count, 0, sizeof(uint32_t), st);
+            if (e0 == hipSuccess) e0 = hipMemsetAsync(sc.ctl, 0, ctl_bytes, st);
             if (e0 != hipSuccess) {
                 (void)hipFree(mem);
                 set_error(std::string("top-k scratch: ") + hipGetErrorString(e0));
@@ -1525,7 +1532,10 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     }
     p.topk_bound = sc.bound;
     p.topk_cand = sc.cand;
-    p.topk_count = sc.count;
+    p.topk_seg_cap = sc.seg_cap;
+    p.topk_ctl = sc.ctl;
+    p.topk_root = sc.root;
+    p.topk_out = d_best;
     p.topk_k = k;
     p.topk_desc = *desc;
     p.key_index_base = key_index_base;
@@ -1537,23 +1547,24 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     hipError_t e = hipSuccess;
     // Sample pass: the top-k of ~1000 evenly spaced tiles costs 0.1 % of the scan and its k-th best key is a valid
     // launch-wide bound from the first tile on -- without it every wavefront pays k ln(n_wave / k) list insertions to
-    // warm its own list up (the shared bound alone is only as good as the luckiest wavefront's k-th best).
+    // warm its own list up (the shared bound alone is only as good as the luckiest wavefront's k-th best).  Under a
+    // tight cutoff (p.early) the cutoff itself keeps nearly everything out of the lists and the pass is skipped.
+    // Each launch selects its own k best in its last workgroup (topk_block_publish): 2 launches, or 1.
     // (RF_TOPK_SAMPLE=<tiles> tunes the sample size, 0 disables the pass: A/B switch)
     static const uint32_t kSampleTiles = [] { const char* e = getenv("RF_TOPK_SAMPLE"); return e ? (uint32_t)atoi(e) : 1024u; }();
-    if (kSampleTiles && p.tile_end - p.tile_begin >= 8 * kSampleTiles) {
+    if (kSampleTiles && !p.early && p.tile_end - p.tile_begin >= 8 * kSampleTiles) {
         ScanParams ps = p;
         ps.out = nullptr;
         ps.prefill_none = 0;
         ps.tile_step = (p.tile_end - p.tile_begin) / kSampleTiles;
+        ps.topk_bound_from_result = 1;
         e = launch_scan(raw, ps, st, nullptr);
-        if (e == hipSuccess) e = launch_topk_final(sc.cand, sc.count, 0, k, d_best, sc.bound, true, st);
     }
     if (e == hipSuccess) e = launch_scan(raw, p, st, nullptr);
     if (e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         (void)hipFreeAsync(d_all, st);
     }
-    if (e == hipSuccess) e = launch_topk_final(sc.cand, sc.count, 0, k, d_best, sc.bound, false, st);
     if (e != hipSuccess) {
         // the scratch may be left half-armed: drop it so the next call starts from a fresh one
         std::lock_guard<std::mutex> lock(owner->scratch_mu);
@@ -1641,7 +1652,7 @@ rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t
     DeviceGuard guard(device);
     if (!guard.ok) return RF_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_topk_final(d_keys, nullptr, n, k, d_out, nullptr, false, st);
+    hipError_t e = launch_topk_final(d_keys, n, k, d_out, st);
     if (e != hipSuccess) {
         set_error(std::string("top-k merge: ") + hipGetErrorString(e));
         return RF_ERR_HIP;

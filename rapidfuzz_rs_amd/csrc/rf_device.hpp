@@ -561,37 +561,148 @@ struct WaveTopK {
     }
 };
 
-// A workgroup's merged list leaves the kernel through ONE launch-wide candidate buffer: only keys at or below the
-// pruning bound can still be in the answer (the bound is some full list's worst key, so the true k-th best is <= it),
-// and those are appended behind an atomic counter.  On a corpus in no particular order a few dozen keys survive per
-// launch, so the final selection (topk_final_kernel) is one small workgroup instead of staged reductions over
-// grid x k keys.  Worst case (scores improving along the corpus) everything is appended: capacity is grid x k.
-__device__ __forceinline__ void topk_publish(const ScanParams& p, const WaveTopK& best, uint32_t lane)
+// ---------------------------------------------------------------------------------------------------
+// End of a scan kernel in top-k mode: from per-wavefront lists to the launch's k best keys, inside the scan launch
+// (the selection used to be launches of its own).  Workgroups are dealt into kTopkWays "ways" (way = blockIdx % 64):
+//   * every workgroup merges its 4 wavefront lists (LDS) and appends the keys that can still be in the answer (at or
+//     below the pruning bound as it last saw it) to its WAY's segment of the candidate buffer, behind that way's counter;
+//   * it then ARRIVES at its way with one fire-and-forget atomic increment (no return value: nobody waits for it);
+//   * the workgroup with the highest blockIdx of each way is that way's SUB-COLLECTOR: it polls the way's arrival counter
+//     (s_sleep between polls) until every other member has arrived, selects the k best of the way's segment, writes them
+//     to the root table, re-arms the way's counters and arrives at the root;
+//   * the sub-collector with the highest blockIdx is the ROOT: it waits for the other sub-collectors, selects the k best
+//     of the root table into p.topk_out and re-arms the root counter and the bound (so the next launch on this scratch
+//     needs no memset).
+// 64 small selections run in parallel where one workgroup used to chew through every published key (~24 k keys after a
+// sampled bound: a 60 us serial tail on a 2.5 ms scan).  Only collectors ever wait, and only for workgroups that never
+// wait themselves (or, the root, for sub-collectors), so whatever order the dispatcher picks this cannot deadlock: at
+// worst 64 of the 2048 workgroup slots idle while the rest drain.
+// Counters live one per 128-byte line (same-address atomics retire one at a time at the memory side).  Keys are written
+// with agent-scope stores (sc1: through to the memory side, where a collector on another XCD -- whose L2 is not coherent
+// with this one -- will read them) and the writer only waits for their completion (vmcnt) before it arrives: an
+// agent-scope release FENCE would write back the whole L2, which is full of the scan's own result stores (measured
+// +0.16 ms per launch with ~13 k publishing workgroups; acq_rel tickets on every workgroup: +0.7 ms).  A collector does
+// one agent-scope acquire (L2 invalidate) after its last arrival.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kTopkWays = 64, kTopkLine = 32;  // ways; u32 units per 128-byte control line
+// control block (u32 units): line w < 64: {arrivals, candidate count} of way w; line 64: {arrivals at the root}
+__device__ __forceinline__ uint32_t* topk_way_arrivals(const ScanParams& p, uint32_t way) { return p.topk_ctl + way * kTopkLine; }
+__device__ __forceinline__ uint32_t* topk_way_count(const ScanParams& p, uint32_t way) { return p.topk_ctl + way * kTopkLine + 1; }
+
+__device__ __forceinline__ void topk_arrive(uint32_t* counter)
 {
-    const uint64_t bound = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool keep = lane < p.topk_k && best.key != ~0ull && best.key <= bound;
-    const uint64_t m = __ballot(keep);
-    if (m == 0) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(p.topk_count, (uint32_t)__popcll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (keep) p.topk_cand[base + __popcll(m & ((1ull << lane) - 1))] = best.key;
+    (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wavefront-uniform wait until *counter == expect, then acquire.  Bounded by wall time (100 MHz constant clock): a lost
+// arrival -- a bug -- must not hang the device for good; no scan that fits in HBM runs anywhere near two minutes.
+__device__ __forceinline__ void topk_await(const uint32_t* counter, uint32_t expect)
+{
+    const uint64_t t0 = wall_clock64();
+    while (uniform(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != expect) {
+        if (wall_clock64() - t0 > 120ull * 100000000ull) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-// end of a scan kernel in top-k mode: the 4 wavefront lists of the workgroup meet in LDS, wavefront 0 merges them
-// (the lists are sorted, so a list is abandoned at its first key that cannot enter) and publishes the survivors
-__device__ __forceinline__ void topk_block_publish(const ScanParams& p, WaveTopK& best, uint64_t (*lds_topk)[kWave], uint32_t wave, uint32_t lane)
+// Final selection over `n` candidate keys by ONE workgroup of kWavesPerBlock wavefronts: each keeps a sorted k-list over its
+// stripe of the candidates (WaveTopK), the lists meet in LDS and wavefront 0 merges them; returns (in wavefront 0) the
+// merged list.  kRows 64-key rows per trip are loaded before the first is offered: the loop is bound by load latency.
+__device__ __forceinline__ void topk_select(const uint64_t* __restrict__ keys, uint32_t n, uint32_t k, uint64_t (*lists)[kWave], uint32_t wave,
+                                            uint32_t lane, WaveTopK& best)
 {
-    lds_topk[wave][lane] = best.key;
-    __syncthreads();
-    if (wave != 0) return;
-    for (uint32_t w = 1; w < kWavesPerBlock; ++w)
-        for (uint32_t j = 0; j < p.topk_k; ++j) {
-            const uint64_t x = lds_topk[w][j];  // wavefront-uniform address: a broadcast read
-            if (x >= best.worst(p.topk_k)) break;
-            best.insert(x, lane);
+    constexpr uint32_t kThreads = kWave * kWavesPerBlock;
+    const uint32_t used = min((uint32_t)kWavesPerBlock, (n + kWave - 1) / kWave);  // wavefronts that see any key at all
+    best.init();
+    constexpr uint32_t kRows = 8;
+    uint64_t limit = ~0ull;  // this list's worst key once it is full
+    for (uint32_t base = wave * kWave; base < n; base += kRows * kThreads) {
+        uint64_t row[kRows];
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const uint32_t i = base + r * kThreads + lane;
+            row[r] = i < n ? keys[i] : ~0ull;
         }
-    topk_publish(p, best, lane);
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r)
+            if (best.offer(row[r], row[r] != ~0ull, k, lane, limit)) limit = best.worst(k);
+    }
+    if (used > 1) {  // (workgroup-uniform)
+        __syncthreads();  // (the lists array may still be read by wavefront 0 from an earlier use)
+        lists[wave][lane] = best.key;
+        __syncthreads();
+    }
+    if (wave == 0)
+        for (uint32_t w = 1; w < used; ++w)
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t x = lists[w][j];
+                if (x >= best.worst(k)) break;  // the lists are sorted: nothing further in this one can enter
+                best.insert(x, lane);
+            }
+}
+
+// `bound_seen` = the launch-wide pruning bound as this workgroup last saw it: stale is merely conservative, and
+// re-reading it here would put one more memory round trip at the end of every workgroup.
+__device__ __forceinline__ void topk_block_publish(const ScanParams& p, WaveTopK& best, uint64_t (*lds_topk)[kWave], uint32_t wave, uint32_t lane,
+                                                   uint64_t bound_seen)
+{
+    const uint32_t grid = gridDim.x, way = blockIdx.x % kTopkWays;
+    const uint32_t n_ways = min(kTopkWays, grid);
+    const bool is_sub = blockIdx.x + n_ways >= grid, is_root = blockIdx.x + 1 == grid;  // workgroup-uniform
+    // most workgroups of a launch with a tight bound end with four empty lists: one barrier and they are gone
+    if (__syncthreads_or(__ballot(best.key != ~0ull) != 0)) {
+        lds_topk[wave][lane] = best.key;
+        __syncthreads();
+        if (wave == 0) {
+            for (uint32_t w = 1; w < kWavesPerBlock; ++w)
+                for (uint32_t j = 0; j < p.topk_k; ++j) {
+                    const uint64_t x = lds_topk[w][j];  // wavefront-uniform address: a broadcast read
+                    if (x >= best.worst(p.topk_k)) break;
+                    best.insert(x, lane);
+                }
+            const bool keep = lane < p.topk_k && best.key != ~0ull && best.key <= bound_seen;
+            const uint64_t m = __ballot(keep);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(topk_way_count(p, way), (uint32_t)__popcll(m));
+                base = uniform(base);
+                uint64_t* seg = p.topk_cand + (size_t)way * p.topk_seg_cap;
+                if (keep) __hip_atomic_store(seg + base + __popcll(m & ((1ull << lane) - 1)), best.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the key stores have reached the memory side
+            }
+        }
+    }
+    if (!is_sub) {
+        if (wave == 0 && lane == 0) topk_arrive(topk_way_arrivals(p, way));
+        return;
+    }
+    // ---- sub-collector of `way` ----
+    if (wave == 0) topk_await(topk_way_arrivals(p, way), grid / kTopkWays + (way < grid % kTopkWays ? 1u : 0u) - 1u);
+    __syncthreads();
+    const uint32_t n = __hip_atomic_load(topk_way_count(p, way), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    topk_select(p.topk_cand + (size_t)way * p.topk_seg_cap, n, p.topk_k, lds_topk, wave, lane, best);
+    if (wave == 0) {
+        __hip_atomic_store(p.topk_root + way * kWave + lane, lane < p.topk_k ? best.key : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 2) topk_way_arrivals(p, way)[lane] = 0;  // re-arm {arrivals, count}: every member of the way has arrived
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!is_root && lane == 0) topk_arrive(p.topk_ctl + kTopkWays * kTopkLine);
+    }
+    if (!is_root) return;
+    // ---- root ----
+    if (wave == 0) topk_await(p.topk_ctl + kTopkWays * kTopkLine, n_ways - 1);
+    __syncthreads();
+    topk_select(p.topk_root, n_ways * kWave, p.topk_k, lds_topk, wave, lane, best);
+    if (wave == 0) {
+        if (lane < p.topk_k) p.topk_out[lane] = best.key;
+        // The scans admit keys strictly below their limit and the sample's lists are discarded, so the bound handed to
+        // the main scan after the SAMPLE pass of a top-k call (topk_core()) is kth + 1: the sample's k-th best candidate
+        // may BE the corpus' k-th best and has to be found again (keys are unique: `key < kth + 1` is `key <= kth`).
+        const uint64_t kth = best.worst(p.topk_k);
+        if (lane == 0) {
+            p.topk_ctl[kTopkWays * kTopkLine] = 0;
+            *p.topk_bound = (p.topk_bound_from_result && kth != ~0ull) ? kth + 1 : ~0ull;
+        }
+    }
 }
 
 // Launch-wide pruning bound: once ANY wavefront holds k keys, its worst key bounds the global k-th best from above
@@ -601,18 +712,26 @@ __device__ __forceinline__ void topk_list_changed(const ScanParams& p, const Wav
 {
     const uint64_t w = best.worst(p.topk_k);
     if (w < limit) {  // limit <= the last bound this wavefront saw: only then can the global bound improve
-        if (lane == 0) atomicMin((unsigned long long*)p.topk_bound, (unsigned long long)w);
+        // fire-and-forget, and invisible to the compiler's vmcnt bookkeeping for the same reason as topk_refresh_bound: a
+        // conditionally issued vector-memory op inside the tile loop makes every chunk wait pessimistic (an extra op in
+        // flight can only make a counted wait longer, never shorter: loads still return in order among themselves)
+        if (lane == 0) asm volatile("global_atomic_umin_x2 %0, %1, off" ::"v"(p.topk_bound), "v"(w) : "memory");
         limit = w;
     }
 }
-// `bound_inflight` is the raw result of a load issued at the end of the previous tile: it is folded into the
-// (scalar) limit here, one tile later, and the next fetch is issued -- stale by a tile (merely conservative), never
-// waited for.
-__device__ __forceinline__ void topk_refresh_bound(const ScanParams& p, uint64_t& bound_inflight, uint64_t& limit)
+// Re-read the launch-wide bound (every few tiles) and fold it into the scalar limit.  The load is issued AND waited for
+// inside one asm statement, deliberately: as a compiler-visible load riding across tiles it sat in the middle of the chunk
+// prefetch stream, and because it is issued conditionally the compiler's vmcnt bookkeeping had to assume the worst at
+// every loop merge point -- its waits for "my chunk" degenerated into drains and the one-chunk-ahead prefetch was lost
+// (rocprofv3 PMC, Indel scan in top-k mode: same instruction counts as the plain scan, +30 % SQ_WAIT_INST_ANY,
+// 1.32 -> 1.50 ms).  A synchronous read costs one memory round trip per 8 tiles instead.  sc1: read at the memory side
+// (the bound is updated by atomics from every XCD and the XCDs' L2s are not coherent with each other).
+__device__ __forceinline__ void topk_refresh_bound(const ScanParams& p, uint64_t& limit)
 {
-    const uint64_t b = uniform64(bound_inflight);
+    uint64_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p.topk_bound) : "memory");
+    const uint64_t b = uniform64(v);
     limit = b < limit ? b : limit;
-    bound_inflight = __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------------

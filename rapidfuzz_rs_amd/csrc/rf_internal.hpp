@@ -94,8 +94,12 @@ struct ScanParams {
     uint32_t topk_desc;    // 1: larger score is better (similarity)
     uint32_t key_index_base;  // added to the local index inside the key (rf_topk_keys_device)
     uint64_t* topk_bound;  // one u64, initialised to ~0: launch-wide upper bound on the k-th best key
-    uint64_t* topk_cand;   // candidate keys, capacity grid * k; key = (score or ~score) << 32 | (key_index_base + local index)
-    uint32_t* topk_count;  // entries appended to topk_cand so far
+    uint64_t* topk_cand;   // candidate keys: 64 way segments of topk_seg_cap keys; key = (score or ~score) << 32 | (key_index_base + local index)
+    uint32_t topk_seg_cap; // keys per way segment (>= workgroups per way x 64)
+    uint32_t* topk_ctl;    // control block: 65 lines of 128 bytes (per-way {arrivals, candidate count}, root arrivals) -- rf_device.hpp
+    uint64_t* topk_root;   // 64 x 64 keys: the sub-collectors' selections
+    uint64_t* topk_out;    // k keys, best first, ~0 = empty: the launch's result
+    uint32_t topk_bound_from_result;  // sample pass: leave (k-th best key + 1) in *topk_bound for the main scan
 };
 
 // kernel launchers (rf_scan.hip, rf_long.hip, rf_jaro.hip, rf_pack.hip)
@@ -104,8 +108,7 @@ hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int
 hipError_t launch_wf(const ScanParams& p, hipStream_t stream);
 hipError_t launch_jaro(const ScanParams& p, hipStream_t stream);
 hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipStream_t stream);
-hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t count_imm, uint32_t k, uint64_t* out, uint64_t* bound_ptr,
-                             bool bound_from_result, hipStream_t stream);
+hipError_t launch_topk_final(const uint64_t* keys, uint32_t count, uint32_t k, uint64_t* out, hipStream_t stream);
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed,
                             uint32_t n_tiles, const uint8_t* sigma, hipStream_t stream);
 hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,

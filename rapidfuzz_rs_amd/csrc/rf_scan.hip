@@ -108,10 +108,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                 bool keep;
                 const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
                 const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
-                if ((tiles_done++ & 7u) == 0) {
-                    const uint64_t b = uniform64(__hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    limit = b < limit ? b : limit;
-                }
+                if ((tiles_done++ & 7u) == 0) topk_refresh_bound(p, limit);
                 if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
             }
 
@@ -121,7 +118,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
         }
     }
 
-    if (topk) topk_block_publish(p, best, lds_topk, wave, lane);
+    if (topk) topk_block_publish(p, best, lds_topk, wave, lane, limit);
 }
 
 // Two entry points over the same body: the single-word kernels are pinned to 8 wavefronts per SIMD (otherwise the
@@ -168,8 +165,9 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
     // `bound` is the bound fetch in flight (topk_refresh_bound)
     // (the first value is waited for once: it is the sampled bound, and without it the first tile of EVERY wavefront
     // would insert 64 keys and then hit the one bound word with an atomic -- 32768 serialized device-scope atomics)
-    uint64_t bound = topk ? __hip_atomic_load(p.topk_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-    uint64_t limit = uniform64(bound);
+    uint64_t limit = ~0ull;
+    if (topk) topk_refresh_bound(p, limit);
+    uint32_t tiles_done = 0;
 
     uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
@@ -228,7 +226,11 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
                 const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
                 const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
                 if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
-                topk_refresh_bound(p, bound, limit);
+                // every 8th tile: the bound word is ONE line that every wavefront of the chip reads at agent scope, i.e.
+                // from the memory side (the XCDs' L2s are not coherent) -- per tile that was 1.5 M requests per launch
+                // on one channel and cost the Indel scan +27 % (rocprofv3: 1.32 -> 1.68 ms); the sampled bound is tight
+                // from the start, so a staler copy loses nothing measurable
+                if ((++tiles_done & 7u) == 0) topk_refresh_bound(p, limit);
             }
             t += stride;
             if (t >= p.tile_end) {
@@ -250,7 +252,7 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
         }
     }
 
-    if (topk) topk_block_publish(p, best, lds_topk, wave, lane);
+    if (topk) topk_block_publish(p, best, lds_topk, wave, lane, limit);
 }
 template <class State, bool kUniform, int kDepth>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void stream_kernel_occ8(const ScanParams p)
@@ -358,66 +360,21 @@ hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipS
     return hipErrorInvalidValue;
 }
 
-// Final selection: `count` candidate keys (device counter, or an immediate for the post-all-gather merge) -> the k
-// smallest, ascending, ~0 = empty.  One workgroup of 16 wavefronts: each keeps a sorted k-list over its stripe of
-// the candidates (WaveTopK), the lists meet in LDS and wavefront 0 merges them.  Before it exits the kernel re-arms
-// the launch-wide state (counter = 0, bound = ~0) so the next top-k call on this scratch needs no memset.
-constexpr int kFinalThreads = 256;
-__global__ __launch_bounds__(kFinalThreads) void topk_final_kernel(const uint64_t* __restrict__ keys, uint32_t* count_ptr, uint32_t count_imm,
-                                                                   uint32_t k, uint64_t* __restrict__ out, uint64_t* bound_ptr,
-                                                                   bool bound_from_result)
+// Stand-alone selection (the post-all-gather merge, rf_topk_merge_keys_device): `count` keys -> the k smallest, ascending,
+// ~0 = empty.  The scans select inside their last workgroup (topk_block_publish) with the same topk_select().
+constexpr int kFinalThreads = kWave * kWavesPerBlock;
+__global__ __launch_bounds__(kFinalThreads) void topk_final_kernel(const uint64_t* __restrict__ keys, uint32_t count, uint32_t k, uint64_t* __restrict__ out)
 {
-    constexpr uint32_t kWaves = kFinalThreads / kWave;
-    __shared__ uint64_t lists[kWaves][kWave];
+    __shared__ uint64_t lists[kWavesPerBlock][kWave];
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = uniform(threadIdx.x / kWave);
-    const uint32_t n = count_ptr ? *count_ptr : count_imm;
-    const uint32_t used = min(kWaves, (n + kWave - 1) / kWave);  // wavefronts that see any key at all
     WaveTopK best;
-    best.init();
-    // kRows 64-key rows per trip, all loaded before the first is offered: the loop is bound by load latency, not work
-    constexpr uint32_t kRows = 8;
-    uint64_t limit = ~0ull;  // this list's worst key once it is full
-    for (uint32_t base = wave * kWave; base < n; base += kRows * kFinalThreads) {
-        uint64_t row[kRows];
-#pragma unroll
-        for (uint32_t r = 0; r < kRows; ++r) {
-            const uint32_t i = base + r * kFinalThreads + lane;
-            row[r] = i < n ? keys[i] : ~0ull;
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < kRows; ++r)
-            if (best.offer(row[r], row[r] != ~0ull, k, lane, limit)) limit = best.worst(k);
-    }
-    if (used > 1) {
-        lists[wave][lane] = best.key;
-        __syncthreads();
-    }
-    if (wave == 0) {
-        for (uint32_t w = 1; w < used; ++w)
-            for (uint32_t j = 0; j < k; ++j) {
-                const uint64_t x = lists[w][j];
-                if (x >= best.worst(k)) break;  // the lists are sorted: nothing further in this one can enter
-                best.insert(x, lane);
-            }
-        if (lane < k) out[lane] = best.key;
-        // re-arm for the next launch on this scratch.  After the SAMPLE pass of a top-k call the bound becomes the
-        // sample's k-th best key: the k-th best of a subset bounds the k-th best of the whole corpus from above.
-        // The scans admit keys strictly below their limit (WaveTopK::offer) and the sample's lists are discarded, so the
-        // bound handed over is kth + 1: the sample's k-th best candidate itself may BE the corpus' k-th best and has to
-        // be found again by the main scan (keys are unique, so `key < kth + 1` is `key <= kth`).
-        const uint64_t kth = best.worst(k);
-        if (lane == 0) {
-            if (count_ptr) *count_ptr = 0;
-            if (bound_ptr) *bound_ptr = (bound_from_result && kth != ~0ull) ? kth + 1 : ~0ull;
-        }
-    }
+    topk_select(keys, count, k, lists, wave, lane, best);
+    if (wave == 0 && lane < k) out[lane] = best.key;
 }
 
-hipError_t launch_topk_final(const uint64_t* keys, uint32_t* count_ptr, uint32_t count_imm, uint32_t k, uint64_t* out, uint64_t* bound_ptr,
-                             bool bound_from_result, hipStream_t stream)
+hipError_t launch_topk_final(const uint64_t* keys, uint32_t count, uint32_t k, uint64_t* out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(kFinalThreads), 0, stream, keys, count_ptr, count_imm, k, out, bound_ptr,
-                       bound_from_result);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(kFinalThreads), 0, stream, keys, count, k, out);
     return hipGetLastError();
 }
 

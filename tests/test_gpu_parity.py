@@ -1364,7 +1364,7 @@ def test_topk_best_match_inside_the_bound_sample(k):
     result).  The sample visits tiles tile_begin + m * tile_step with tile_step = n_tiles / 1024; plant the k best there."""
     import torch
 
-    n_tiles = 8192 + 640  # >= 8 * 1024 tiles: the sample pass runs, tile_step = 8
+    n_tiles = 8192 * 3 + 640  # >= 8 * 1024 tiles: the sample pass runs, tile_step = 24
     n = n_tiles * 64
     step = n_tiles // 1024
     q = synth.query(64, 77)
@@ -1372,7 +1372,7 @@ def test_topk_best_match_inside_the_bound_sample(k):
     qrow = torch.tensor(list(q), dtype=torch.uint8, device=rows.device)
     planted = []
     for j in range(k):
-        idx = (step * (37 + 101 * j)) * 64 + (5 * j) % 64  # a lane of a sampled tile
+        idx = (step * (37 + 13 * j)) * 64 + (5 * j) % 64  # a lane of a sampled tile
         r = qrow.clone()
         r[:j % 3] = 33  # 0..2 substitutions by '!': distances 0, 1, 2, 0, ...
         rows[idx] = r

@@ -1,0 +1,43 @@
+"""A/B timing of one scan variant with the library named by RF_LIB (tools/ab.sh runs it alternately for two builds on the
+same box: boxes differ by several percent, so only same-session pairs are comparable).  Not part of the product."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rapidfuzz_rs_amd as rf
+from rapidfuzz_rs_amd import _native as N
+from rapidfuzz_rs_amd.utils import synth
+
+what = sys.argv[1] if len(sys.argv) > 1 else "lev64"
+n = int(os.environ.get("AB_N", 100_000_000))
+cfg = {
+    "lev64": ("levenshtein", 64, 64, {}), "lev32": ("levenshtein", 32, 64, {}), "indel": ("indel", 64, 64, {}), "osa": ("osa", 64, 64, {}),
+    "lev256": ("levenshtein", 256, 256, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
+    "jaro": ("jaro", 64, 64, {}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
+}[what.split("+")[0]]
+metric, qlen, clen, kw = cfg
+if clen == 256:
+    n //= 10
+q = synth.query(qlen, 0xC0FFEE02)
+rows = synth.rows_device(n, clen, seed=1)
+corpus = rf.Corpus.from_device_rows(rows)
+del rows
+bc = getattr(rf.distance, metric).BatchComparator(q)
+is_f = metric in ("jaro", "jaro_winkler")
+out = torch.empty(n, dtype=torch.float64 if is_f else torch.int32, device="cuda")
+keys = torch.empty(64, dtype=torch.int64, device="cuda")
+if "+topk" in what:
+    fn = lambda: bc.topk_keys_device(corpus, 16, keys, out=out if "+out" in what else None, **kw)
+else:
+    fn = lambda: bc.many(N.OP_SIMILARITY if is_f else N.OP_DISTANCE, corpus, out=out, **kw)
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+reps = int(os.environ.get("AB_REPS", 20))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+print(f"{os.path.basename(os.environ.get('RF_LIB', 'librfgpu.so')):18s} {what:18s} {ms:8.3f} ms  {n / ms / 1e6:8.2f} Gpairs/s")
