@@ -197,34 +197,40 @@ def main():
             # Everything is stream-ordered on the device -- no host round trip inside a step.
             buf = step_no[0] & 1
             step_no[0] += 1
+            if buf_free[buf] is not None:
+                stream.wait_event(buf_free[buf])  # the exchange that last read this buffer pair (two steps ago) is done
             scorer.topk_keys_device(corpus, args.topk, local_keys[buf], N.OP_DISTANCE, call_args, index_base=index_base,
                                     out=out if args.mode == "many" else None, stream=stream.cuda_stream)
             if world > 1 or force_dist:
-                finish_exchange()  # merge the PREVIOUS step's gather: it ran on RCCL's stream under this step's scan
-                if os.environ.get("RF_BENCH_NOGATHER"):  # diagnostic: the exchange replaced by a local copy
-                    all_keys[buf][: args.topk].copy_(local_keys[buf])
-                    pending[0] = (None, buf)
+                if test_gloo:
+                    host = [torch.empty(args.topk, dtype=torch.int64) for _ in range(world)]
+                    dist.all_gather(host, local_keys[buf].cpu())
+                    all_keys[buf].copy_(torch.cat(host))
+                    last_topk[0] = parallel.merge_keys_device(all_keys[buf], args.topk, merged_keys)
                 else:
-                    if test_gloo:
-                        host = [torch.empty(args.topk, dtype=torch.int64) for _ in range(world)]
-                        dist.all_gather(host, local_keys[buf].cpu())
-                        all_keys[buf].copy_(torch.cat(host))
-                        pending[0] = (None, buf)
-                    else:
-                        pending[0] = (dist.all_gather_into_tensor(all_keys[buf], local_keys[buf], async_op=True), buf)
+                    # The exchange runs on its own stream, beside the next step's scan: the scan stream never waits for a
+                    # collective (only, trivially, for the one of two steps ago before it reuses a key buffer).
+                    keys_ready = torch.cuda.Event()
+                    keys_ready.record(stream)
+                    with torch.cuda.stream(xchg):
+                        xchg.wait_event(keys_ready)
+                        if os.environ.get("RF_BENCH_NOGATHER"):  # diagnostic: the exchange replaced by a local copy
+                            all_keys[buf][: args.topk].copy_(local_keys[buf])
+                        else:
+                            dist.all_gather_into_tensor(all_keys[buf], local_keys[buf])  # RCCL; the CPU does not block
+                        last_topk[0] = parallel.merge_keys_device(all_keys[buf], args.topk, merged_keys, stream=xchg.cuda_stream)  # one small kernel
+                        buf_free[buf] = torch.cuda.Event()
+                        buf_free[buf].record(xchg)
             else:
                 last_topk[0] = local_keys[buf][: args.topk]
 
     def finish_exchange():
-        if pending[0] is None:
-            return
-        work, buf = pending[0]
-        pending[0] = None
-        if work is not None:
-            work.wait()
-        last_topk[0] = parallel.merge_keys_device(all_keys[buf], args.topk, merged_keys)  # one small kernel
+        if xchg is not None:
+            stream.wait_stream(xchg)  # the last step's gather + merge belongs to the timed region
 
-    step_no, pending = [0], [None]
+    xchg = torch.cuda.Stream(device=dev) if ((world > 1 or force_dist) and not test_gloo) else None
+    buf_free = [None, None]
+    step_no = [0]
     merged_keys = torch.empty(args.topk, dtype=torch.int64, device=dev)
     local_keys = [torch.empty(args.topk, dtype=torch.int64, device=dev) for _ in range(2)]
     all_keys = [torch.empty(args.topk * max(world, 1), dtype=torch.int64, device=dev) for _ in range(2)]
@@ -342,12 +348,14 @@ def main():
         torch.cuda.synchronize()
         rate = ctypes.c_double(0.0)
         metric_id = {"levenshtein": N.LEVENSHTEIN, "indel": N.INDEL, "lcs_seq": N.LCS_SEQ, "osa": N.OSA}[args.metric]
-        if N.lib().rf_probe_issue_rate(metric_id, args.query_len, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
+        if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 0, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
             ceiling = rate.value * 64.0 / max(ln, 1) * nq  # wave-columns/ns -> Gpairs/s at this candidate length
             per_gpu = gpairs / world
             result["roofline"]["issue_bound"] = {"achieved": round(per_gpu, 3), "ceiling": round(ceiling, 3), "unit": "Gpairs/s",
                                                  "frac": round(per_gpu / ceiling, 4),
                                                  "source": "rf_probe_issue_rate in this run: the product's State::step on register-resident PM words, 8 workgroups/CU"}
+            if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 1, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
+                result["roofline"]["issue_bound"]["ceiling_with_lds_gather"] = round(rate.value * 64.0 / max(ln, 1) * nq, 3)
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,

@@ -151,7 +151,7 @@ def lib() -> C.CDLL:
     L.rf_topk_u32.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint64, vp, vp, u32p, vp, C.c_int, vp]
     L.rf_topk_keys_device.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint32, vp, vp, C.c_int, vp]
     L.rf_topk_merge_keys_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_int, vp]
-    L.rf_probe_issue_rate.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    L.rf_probe_issue_rate.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.rf_topk_merge_u32.argtypes = [C.c_int, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, u32p]
     _lib = L
     return L

@@ -415,6 +415,30 @@ static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corp
     return RF_OK;
 }
 
+// (c - h) / c for c = 0..64 common characters and h = 0..32 half-transpositions: the third term of jaro.rs:106-119,
+// divided HERE with the host's IEEE divide (the values the reference computes) and looked up by the Jaro kernels'
+// no-cutoff epilogue.  One 17 KiB table per device, uploaded on first use and kept for the life of the process.
+static const double* jaro_device_table(int device)
+{
+    static std::mutex mu;
+    static std::map<int, double*> tabs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = tabs.find(device);
+    if (it != tabs.end()) return it->second;
+    std::vector<double> h(65 * 33);
+    for (int c = 0; c <= 64; ++c)
+        for (int t = 0; t <= 32; ++t) h[(size_t)c * 33 + t] = c == 0 ? 0.0 : ((double)c - (double)t) / (double)c;
+    DeviceGuard guard(device);
+    double* d = nullptr;
+    if (!guard.ok || hipMalloc((void**)&d, h.size() * sizeof(double)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    tabs[device] = d;
+    return d;
+}
+
 // row stride (in u64) of the device PM table: the word count, or for patterns beyond the register-resident kernels
 // the word count rounded up to whole groups of 8
 static size_t pm_stride(const rf_comparator* c) { return c->words <= (size_t)kMaxWords ? c->words : (c->words + 7) / 8 * 8; }
@@ -1086,6 +1110,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         // Early-out under a tight cutoff (the reference's own common_char_filter idea, jaro.rs:134-145, applied while the
         // flags are still being collected): `jaro_need` is the similarity a candidate has to reach.
         p->jaro_need = -1.0;
+        if (!p->has_cutoff) p->jaro_tab = jaro_device_table(corpus->device);  // (nullptr on failure: the kernels then divide)
         if (p->has_cutoff && args->prefix_weight >= 0.0 && 4.0 * args->prefix_weight <= 1.0) {
             const double need = (op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY) ? args->cutoff_f64 : 1.0 - args->cutoff_f64;
             if (need >= 0.6 && need <= 1.0) p->jaro_need = need;
@@ -2168,7 +2193,7 @@ rf_status rf_corpus_file_count(const char* path, size_t* n)
 }
 
 // Issue-rate probe (rf_probe.hip): the product's own column code on register-resident PM words.
-rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, int device, uint32_t blocks_per_cu, double* wave_columns_per_ns)
+rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, uint32_t mode, int device, uint32_t blocks_per_cu, double* wave_columns_per_ns)
 {
     if (!wave_columns_per_ns) return RF_ERR_INVALID_ARG;
     *wave_columns_per_ns = 0.0;
@@ -2186,9 +2211,9 @@ rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, int device, 
         set_error("rf_probe_issue_rate: cannot select device");
         return RF_ERR_NO_DEVICE;
     }
-    const hipError_t e = launch_probe(raw, query_len, blocks_per_cu ? (int)blocks_per_cu : 8, 40000, wave_columns_per_ns);
+    const hipError_t e = launch_probe(raw, query_len, mode, blocks_per_cu ? (int)blocks_per_cu : 8, 40000, wave_columns_per_ns);
     if (e == hipErrorInvalidValue) {
-        set_error("rf_probe_issue_rate: no probe for this query length");
+        set_error("rf_probe_issue_rate: no probe for this query length / mode");
         return RF_ERR_UNSUPPORTED;
     }
     RF_HIP(e);

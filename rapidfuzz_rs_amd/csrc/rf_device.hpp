@@ -136,6 +136,8 @@ struct LevState {
             const uint64_t p = vp[w], n = vn[w];
             const uint64_t sum = (x & p) + p;
             const uint64_t e = lut3<T_XOR_OR>(sum, p, x);    // (sum ^ vp) | x;  d0 = e | vn (:848)
+            // (source order matters to the schedule: with hn computed AFTER the asm shift the s_nop of hazard padding
+            // behind the asm disappears, and the kernel gets 1.5 % slower -- measured A/B, twice)
             const uint64_t hn = e & p;                       // :852
             const uint64_t hp = lut3<T_OR_NOR>(n, e, p);     // vn | ~(d0 | vp) == vn | ~(e | vp)   (:851)
             const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_add(hp, (uint64_t)hp_c);  // :865-866
@@ -535,7 +537,11 @@ struct WaveTopK {
     __device__ __forceinline__ void insert(uint64_t x, uint32_t lane)
     {
         const uint32_t pos = __popcll(__ballot(key < x));  // sorted ascending: the smaller keys are a lane prefix
-        const uint32_t up_lo = __shfl_up((uint32_t)key, 1), up_hi = __shfl_up((uint32_t)(key >> 32), 1);
+        // the key of lane - 1: DPP wave_shr:1 (one v_mov_b32_dpp per half, whole-wavefront shift on gfx9-family parts).
+        // __shfl_up goes through ds_bpermute_b32 -- two LDS round trips per insertion, which made every selection phase
+        // (a wavefront's first tile, the workgroup merge, the collectors) latency-bound at ~0.2 us per inserted key.
+        const uint32_t up_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)key, 0x138, 0xF, 0xF, false);
+        const uint32_t up_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(key >> 32), 0x138, 0xF, 0xF, false);
         const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
         key = lane > pos ? up : (lane == pos ? x : key);
     }

@@ -66,6 +66,7 @@ struct ScanParams {
     uint32_t factor;       // common weight factor (levenshtein.rs:1307-1327)
     uint32_t w_ins, w_del, w_sub;  // for _maximum (levenshtein.rs:263-277)
     uint32_t tile_begin, tile_end;  // tile range of this launch (jaro kernels; the cutoff length window of the scans)
+    const double* jaro_tab;         // jaro kernels: device table [65][33] of (c - h) / c (rf_api.hip jaro_device_table); nullptr = compute
     double jaro_need;               // jaro kernels: the similarity a candidate must reach to pass the cutoff; < 0 = no early-out
     uint32_t wf_query[16];          // wf_reg_kernel: the (renamed) query bytes, 4 per word, for queries of <= 64 symbols
     uint32_t wf_waves;              // wavefronts per workgroup of wf_kernel (LDS rows per wavefront: (len1 + 1) * 256 B)
@@ -114,7 +115,7 @@ hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t 
 hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
                             hipStream_t stream);
 int scan_max_grid();
-hipError_t launch_probe(RawKind raw, uint32_t len1, int blocks_per_cu, int iters, double* wave_columns_per_ns);  // rf_probe.hip
+hipError_t launch_probe(RawKind raw, uint32_t len1, uint32_t mode, int blocks_per_cu, int iters, double* wave_columns_per_ns);  // rf_probe.hip
 hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,
                                  hipStream_t stream);
 int scan_grid(uint32_t n_tiles);  // the grid launch_scan uses for n_tiles tiles

@@ -144,27 +144,36 @@ __device__ __forceinline__ void window_next(uint32_t& lo, uint32_t& hi, uint32_t
         : "scc");
 }
 
+// (PM rows are fetched kJaroGroup symbols ahead of their use; 2 rather than the scans' 4 keeps the kernel inside the
+// 64-VGPR budget of 8 wavefronts per SIMD, and with 8 wavefronts the LDS latency is covered either way)
+constexpr int kJaroGroup = 2;
+__device__ __forceinline__ uint32_t chunk_byte(const uint4& c, int n)
+{
+    const uint32_t dw = n < 4 ? c.x : (n < 8 ? c.y : (n < 12 ? c.z : c.w));
+    return (dw >> (8 * (n % 4))) & 0xFFu;
+}
+
 template <bool kFull>
-__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4& c, uint32_t j0, uint32_t cols,
+__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4 c, uint32_t j0, uint32_t cols,
                                                 uint32_t bound, uint32_t& bm_lo_io, uint32_t& bm_hi_io)
 {
-    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    constexpr int G = kJaroGroup, NG = kChunk / G;
     uint32_t bm_lo = uniform(bm_lo_io), bm_hi = uniform(bm_hi_io);  // (re)pin to SGPRs for the asm recurrence
     bound = uniform(bound);
-    uint64_t cur[4], nxt[4];
+    uint64_t cur[G], nxt[G];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) cur[b] = lds_pm0[(dw[0] >> (8 * b)) & 0xFFu];
+    for (int b = 0; b < G; ++b) cur[b] = lds_pm0[chunk_byte(c, b)];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (g + 1 < 4) {
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) nxt[b] = lds_pm0[(dw[g + 1] >> (8 * b)) & 0xFFu];
+            for (int b = 0; b < G; ++b) nxt[b] = lds_pm0[chunk_byte(c, (g + 1) * G + b)];
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t j = j0 + g * 4 + b;
-            if (kFull || (uint32_t)(g * 4 + b) < cols) {
+        for (int b = 0; b < G; ++b) {
+            const uint32_t j = j0 + g * G + b;
+            if (kFull || (uint32_t)(g * G + b) < cols) {
                 const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], ((uint64_t)bm_hi << 32) | bm_lo, st.p_flag);  // PM & window & ~P
                 const uint64_t below = pm_j - 1;
                 st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
@@ -173,31 +182,31 @@ __device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_
             }
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) cur[b] = nxt[b];
+        for (int b = 0; b < G; ++b) cur[b] = nxt[b];
     }
     bm_lo_io = bm_lo;
     bm_hi_io = bm_hi;
 }
 
 template <bool kFull>
-__device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4& c, uint32_t j0, uint32_t cols)
+__device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4 c, uint32_t j0, uint32_t cols)
 {
-    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+    constexpr int G = kJaroGroup, NG = kChunk / G;
     const uint32_t thalf = (j0 & 32) ? (uint32_t)(st.t_flag >> 32) : (uint32_t)st.t_flag;
-    uint64_t cur[4], nxt[4];
+    uint64_t cur[G], nxt[G];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) cur[b] = lds_pm0[(dw[0] >> (8 * b)) & 0xFFu];
+    for (int b = 0; b < G; ++b) cur[b] = lds_pm0[chunk_byte(c, b)];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (g + 1 < 4) {
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) nxt[b] = lds_pm0[(dw[g + 1] >> (8 * b)) & 0xFFu];
+            for (int b = 0; b < G; ++b) nxt[b] = lds_pm0[chunk_byte(c, (g + 1) * G + b)];
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t j = j0 + g * 4 + b;
-            if (kFull || (uint32_t)(g * 4 + b) < cols) {
+        for (int b = 0; b < G; ++b) {
+            const uint32_t j = j0 + g * G + b;
+            if (kFull || (uint32_t)(g * G + b) < cols) {
                 const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)thalf, j & 31, 1);  // all ones iff T bit j
                 const uint64_t f = ((uint64_t)f32 << 32) | f32;
                 const uint64_t below = st.p_flag - 1;
@@ -207,17 +216,30 @@ __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const ui
             }
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) cur[b] = nxt[b];
+        for (int b = 0; b < G; ++b) cur[b] = nxt[b];
     }
 }
 
-template <bool kUniform, bool kEarly>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
+// The f64 epilogue without a cutoff (kFast), bit for bit the reference's arithmetic but without its divisions: every
+// quotient of jaro.rs:106-119 has a small integer numerator and denominator, so it is LOOKED UP instead of computed --
+//   common / len1            tab1[common]      LDS, filled once per workgroup (len1 is the query's length)
+//   common / len2            tab2[common]      LDS, per wavefront, refilled when the tile length changes (one division per lane)
+//   (common - t/2) / common  p.jaro_tab[common * 33 + t/2]   global, 65 x 33 doubles built once per device on the host
+// with the same IEEE divide, so the looked-up values ARE the reference's; only `sim / 3.0` is still divided per candidate.
+// The general epilogue (f64_metric_value: filters, cutoff back-translation) costs ~8 f64 divisions per candidate, a
+// quarter of this kernel's VALU time (rocprofv3: 24.8 VALU per column, ~21 of them the two passes).
+constexpr int kJaroTabStride = 66;  // doubles per table (65 used)
+template <bool kUniform, bool kEarly, bool kFast>
+__device__ __forceinline__ void jaro_word_body(const ScanParams& p)
 {
     const uint32_t W = p.words;  // PM row stride; only block 0 is read on this path (jaro.rs:172, pm.get(0, ..))
-    extern __shared__ uint64_t lds_pm0[];  // 256 entries: block 0 of every row
+    extern __shared__ uint64_t lds_pm0[];  // 256 entries: block 0 of every row [+ tab1 + 4 x tab2 when kFast]
+    double* tab1 = reinterpret_cast<double*>(lds_pm0 + 256);
     for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm0[p.sigma[i]] = p.pm[(size_t)i * W];  // renamed rows
+    if (kFast && threadIdx.x < 65) tab1[threadIdx.x] = (double)threadIdx.x / (double)p.len1;
     __syncthreads();
+    double* tab2 = tab1 + kJaroTabStride * (1 + uniform(threadIdx.x / kWave));
+    uint32_t tab2_len = 0xFFFFFFFFu;
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
@@ -314,12 +336,51 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const 
         r.transpositions = r.common - __popcll(st.hits);
 
         const bool valid = kUniform ? slot < p.n : idx != kPad;
-        if (valid) {
+        if (kFast) {
+            // jaro::similarity_with_pm with score_cutoff = 0.0 (jaro.rs:533-598): the filters reduce to the empty-string
+            // and common == 0 cases; calculate_similarity (:106-119) from the tables, in the reference's order
+            if (len2_orig != tab2_len) {  // wavefront-uniform; this wavefront's own table: no barrier
+                tab2[lane] = (double)lane / (double)len2_orig;
+                if (lane == 0) tab2[64] = 64.0 / (double)len2_orig;
+                tab2_len = len2_orig;
+            }
+            double sim;
+            if (len1_orig == 0 || len2_orig == 0) {
+                sim = (len1_orig == 0 && len2_orig == 0) ? 1.0 : 0.0;       // :537-544
+            } else if (len1_orig == 1 && len2_orig == 1) {
+                sim = r.eq11 ? 1.0 : 0.0;                                   // :546-548
+            } else {
+                double acc = 0.0;
+                acc += tab1[r.common];
+                acc += tab2[r.common];
+                acc += p.jaro_tab[r.common * 33u + r.transpositions / 2u];
+                acc = acc / 3.0;
+                sim = r.common == 0 ? 0.0 : acc;                            // :579-581
+            }
+            if (p.finish == FIN_JW && sim > 0.7) sim += (double)r.prefix * p.prefix_weight * (1.0 - sim);  // jaro_winkler.rs:136-138
+            double v = sim;                                                 // Metricf64 defaults, details/distance.rs:277-385
+            if (p.op == RF_OP_DISTANCE || p.op == RF_OP_NORMALIZED_DISTANCE) v = 1.0 - sim;
+            if (p.op == RF_OP_NORMALIZED_SIMILARITY) v = 1.0 - (1.0 - sim);
+            if (valid) reinterpret_cast<double*>(p.out)[idx] = v;
+        } else if (valid) {
             bool keep;
             const double v = f64_metric_value(p, len2_orig, r, &keep);
             reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
         }
     }
+}
+
+// Two entry points over the same body: the table-epilogue kernel fits the 64-VGPR budget of 8 wavefronts per SIMD and is
+// pinned there; the general one (cutoff replay, early-out) keeps the compiler's own budget (pinned it would spill).
+template <bool kUniform, bool kEarly>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
+{
+    jaro_word_body<kUniform, kEarly, false>(p);
+}
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void jaro_word_fast_kernel(const ScanParams p)
+{
+    jaro_word_body<kUniform, false, true>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -514,9 +575,11 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
     if (q.tile_end > q.tile_begin) {
         const dim3 g(scan_grid(q.tile_end - q.tile_begin));
         const bool early = p.jaro_need >= 0.0;
-        auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : jaro_word_kernel<false, false>)
-                         : (early ? jaro_word_kernel<true, true> : jaro_word_kernel<true, false>);
-        hipLaunchKernelGGL(k, g, b, 256 * sizeof(uint64_t), stream, q);
+        const bool fast = !p.has_cutoff && p.jaro_tab != nullptr;  // the table epilogue (no cutoff to replay)
+        auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : (fast ? jaro_word_fast_kernel<false> : jaro_word_kernel<false, false>))
+                         : (early ? jaro_word_kernel<true, true> : (fast ? jaro_word_fast_kernel<true> : jaro_word_kernel<true, false>));
+        const size_t lds = 256 * sizeof(uint64_t) + (fast ? (size_t)kJaroTabStride * (1 + kWavesPerBlock) * sizeof(double) : 0);
+        hipLaunchKernelGGL(k, g, b, lds, stream, q);
     }
     q.tile_begin = std::max(p.jaro_split, p.tile_begin);
     q.tile_end = p.tile_end;

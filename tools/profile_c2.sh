@@ -13,6 +13,6 @@ rocprofv3 --pmc FETCH_SIZE -d $W/p3 -o p3 -- python $R/bench.py --steps 3 --warm
 rocprofv3 --pmc WRITE_SIZE -d $W/p4 -o p4 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $W/p4.log 2>&1
 cd $R
 python tools/rocpd_summary.py --kernel-trace $W/kt/kt_results.db --pmc $W/p1/p1_results.db $W/p2/p2_results.db $W/p3/p3_results.db $W/p4/p4_results.db \
-   --match "rf::s" --out gpurun_out/$TAG --traffic-key "$KEY" --traffic-json gpurun_out/traffic.json \
+   --match "${MATCH:-rf::s}" --out gpurun_out/$TAG --traffic-key "$KEY" --traffic-json gpurun_out/traffic.json \
    --note "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline $* ; PMC passes with --steps 3" > gpurun_out/$TAG.stdout 2>&1
 rm -rf $W

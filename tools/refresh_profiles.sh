@@ -1,12 +1,23 @@
 #!/bin/bash
 # Regenerates everything under profiles/ that comes from the GPU box (run through gpurun from the repo root):
-#   rocprofv3 kernel-trace + PMC summaries of the three dominant workloads, and one bench.py JSON line per config.
+#   rocprofv3 kernel-trace + PMC summaries of every BASELINE.json config's dominant kernel, and one bench.py JSON line per config.
+# Results land in gpurun_out/profiles/; copy them into profiles/ afterwards.
 set -u
-R=${1:-r01}
-tools/profile_c2.sh c2_levenshtein_$R "levenshtein:q64:n100000000:l64:cutNone:many"
-tools/profile_c2.sh c2_levenshtein_cutoff3_$R "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
-tools/profile_c2.sh c4_indel_$R "indel:q64:n100000000:l64:cutNone:many" --metric indel
-sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; mkdir -p gpurun_out/profiles && cp gpurun_out/traffic.json profiles/traffic.json
+R=${1:-r02}
+mkdir -p gpurun_out/profiles
+cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
+P() { tag=$1; key=$2; shift 2; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
+P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
+P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
+P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
+P c4_indel "indel:q64:n100000000:l64:cutNone:many" --metric indel
+MATCH="rf::jaro" P c4_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many" --metric jaro_winkler
+P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
+P q32_levenshtein "levenshtein:q32:n100000000:l64:cutNone:many" --query-len 32
+P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" --cutoff 3 --mode topk
+P topk16_nocutoff "levenshtein:q64:n100000000:l64:cutNone:topk" --mode topk
+MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
+sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
 b() { name=$1; shift; python bench.py "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
 b c2_levenshtein
 b q32_levenshtein --query-len 32
@@ -18,13 +29,15 @@ b c4_jaro_winkler --metric jaro_winkler
 b osa --metric osa
 b c5_cutoff3_many --cutoff 3
 b c5_cutoff3_topk --cutoff 3 --mode topk --no-cpu-baseline
+b topk16_nocutoff --mode topk --no-cpu-baseline
 b multi4_levenshtein --queries 4 --no-cpu-baseline
 b multi4_indel --metric indel --queries 4 --no-cpu-baseline
-cp gpurun_out/c2_* gpurun_out/c4_* gpurun_out/traffic.json gpurun_out/profiles/ 2>/dev/null
-ls -la gpurun_out/profiles
 b wf_weights_1_2_3 --weights 1,2,3 --candidates 20000000 --steps 3 --warmup 1
 b indel_cutoff12 --metric indel --cutoff 12
 b osa_cutoff3 --metric osa --cutoff 3
 b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
+b c3_cutoff8 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
 RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/profiles/bench_sharded_path_world1.json
+python bench.py --config c5 2>/dev/null | tail -1 > gpurun_out/profiles/bench_c5_1B_world1.json
+cp gpurun_out/*_$R.txt gpurun_out/*_$R.json gpurun_out/profiles/ 2>/dev/null
 ls gpurun_out/profiles | wc -l

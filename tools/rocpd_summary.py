@@ -27,9 +27,13 @@ def main():
         lines.append("== rocprofv3 --kernel-trace --stats : top kernels (name, calls, total_us, avg_us, pct)")
         for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
             lines.append(f"{name[:110]:110s} {calls:6d} {total:14.3f} {avg:12.3f} {pct:7.2f}")
-            if a.match in name and "kernel" not in summary:
-                summary["kernel"] = {"name": name, "calls": calls, "avg_us": avg}
-        rows = list(cur.execute("select name, duration, grid_x, workgroup_x, vgpr_count, sgpr_count, lds_size from kernels where name like ? order by start", (f"%{a.match}%",)))
+            if a.match in name and ("kernel" not in summary or total > summary["kernel"]["total_us"]):
+                summary["kernel"] = {"name": name, "calls": calls, "avg_us": avg, "total_us": total}
+        dominant = summary.get("kernel", {}).get("name", "")
+        rows = list(cur.execute("select name, duration, grid_x, workgroup_x, vgpr_count, sgpr_count, lds_size from kernels where name = ? order by start", (dominant,)))
+        if rows:  # the sample pass of a top-k call is the same kernel on a small grid: keep the full-size dispatches
+            gmax = max(r[2] for r in rows)
+            rows = [r for r in rows if r[2] == gmax]
         if rows:
             d = [r[1] for r in rows]
             lines.append(f"== {a.match}: {len(d)} dispatches, duration ns min/avg/max = {min(d)}/{sum(d)/len(d):.0f}/{max(d)}; grid_x={rows[0][2]} wg_x={rows[0][3]} vgpr={rows[0][4]} sgpr={rows[0][5]} lds={rows[0][6]}")
@@ -41,7 +45,11 @@ def main():
     counters = {}
     for f in a.pmc:
         cur = sqlite3.connect(f).cursor()
-        for name, cname, val, n in cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by kernel_name, counter_name", (f"%{a.match}%",)):
+        best = {}
+        for name, grid, cname, val, n in cur.execute("select kernel_name, grid_size, counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by kernel_name, grid_size, counter_name", (f"%{a.match}%",)):
+            if cname not in best or grid * n > best[cname][0]:  # the dominant (largest-grid, most-dispatched) instance
+                best[cname] = (grid * n, val)
+        for cname, (_, val) in best.items():
             counters[cname] = val
     if counters:
         lines.append("== PMC (average per dispatch of the matched kernel; one rocprofv3 --pmc pass per group)")
@@ -60,6 +68,8 @@ def main():
             table = {}
         e = dict(summary["hbm_traffic_bytes_per_launch"])
         e["source"] = a.out + ".json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        if "steady_avg_us" in summary:
+            e["kernel_us_at_collection"] = summary["steady_avg_us"]  # bench.py drops the entry when the kernel has changed since
         table[a.traffic_key] = e
         json.dump(table, open(a.traffic_json, "w"), indent=1, sort_keys=True)
     open(a.out + ".txt", "w").write("\n".join(lines) + "\n")
