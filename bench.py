@@ -349,13 +349,13 @@ def main():
         rate = ctypes.c_double(0.0)
         metric_id = {"levenshtein": N.LEVENSHTEIN, "indel": N.INDEL, "lcs_seq": N.LCS_SEQ, "osa": N.OSA}[args.metric]
         if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 0, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
-            ceiling = rate.value * 64.0 / max(ln, 1) * nq  # wave-columns/ns -> Gpairs/s at this candidate length
+            ceiling = rate.value * 64.0 / max(ln, 1)  # wave-columns/ns -> Gpairs/s at this candidate length (every pair runs its own columns)
             per_gpu = gpairs / world
             result["roofline"]["issue_bound"] = {"achieved": round(per_gpu, 3), "ceiling": round(ceiling, 3), "unit": "Gpairs/s",
                                                  "frac": round(per_gpu / ceiling, 4),
                                                  "source": "rf_probe_issue_rate in this run: the product's State::step on register-resident PM words, 8 workgroups/CU"}
             if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 1, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
-                result["roofline"]["issue_bound"]["ceiling_with_lds_gather"] = round(rate.value * 64.0 / max(ln, 1) * nq, 3)
+                result["roofline"]["issue_bound"]["ceiling_with_lds_gather"] = round(rate.value * 64.0 / max(ln, 1), 3)
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,

@@ -250,6 +250,14 @@ rf_status rf_topk_keys_device(const rf_comparator *c, const rf_corpus *corpus, r
  * asynchronous on `stream`.  d_out may not alias d_keys. */
 rf_status rf_topk_merge_keys_device(const uint64_t *d_keys, uint32_t n, uint32_t k, uint64_t *d_out, int device,
                                     void *stream);
+/* The whole exchange for a host that drives RCCL itself (C, C++, Rust): ncclAllGather of every rank's k keys
+ * (d_local_keys, as written by rf_topk_keys_device) into d_all_keys (world * k entries, rank order) over the caller's
+ * communicator, then the device-side merge into d_merged (k entries) -- both enqueued on `stream`, nothing synchronizes.
+ * `nccl_comm` is the caller's ncclComm_t; RCCL is not a link dependency of this library: ncclAllGather is resolved at
+ * run time in the RCCL instance already loaded in the process (the one that created the communicator).
+ * RF_ERR_UNSUPPORTED when no RCCL can be found.  The per-candidate outputs never move: only k * 8 bytes per rank do. */
+rf_status rf_topk_allgather_merge(const uint64_t *d_local_keys, uint32_t k, void *nccl_comm, uint32_t world,
+                                  uint64_t *d_all_keys, uint64_t *d_merged, int device, void *stream);
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t *scores, const uint64_t *indices, const uint32_t *counts,
                             uint32_t lists, uint32_t k, uint32_t *out_score, uint64_t *out_index,
                             uint32_t *out_count);

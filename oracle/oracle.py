@@ -61,7 +61,8 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        # RF_ORACLE_LIB: a differently built oracle (tests/test_oracle_sanitize.py runs the known answers on the ASan/UBSan build)
+        L = C.CDLL(os.environ.get("RF_ORACLE_LIB") or _LIB_PATH)
         u8p = C.POINTER(C.c_uint8)
         L.rfo_batch_new.restype = C.c_void_p
         L.rfo_batch_new.argtypes = [C.c_int, u8p, C.c_size_t]

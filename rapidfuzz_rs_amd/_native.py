@@ -67,7 +67,7 @@ SYMBOLS = [
     "rf_corpus_pack", "rf_corpus_pack_rows_device", "rf_corpus_free", "rf_corpus_layout_host",
     "rf_host_layout_free", "rf_corpus_count", "rf_corpus_payload_bytes", "rf_corpus_device_bytes",
     "rf_corpus_device", "rf_many_u32", "rf_many_f64", "rf_one_u32", "rf_one_f64", "rf_many_multi_u32", "rf_many_multi_f64", "rf_topk_u32", "rf_topk_keys_device", "rf_topk_merge_keys_device", "rf_topk_merge_u32",
-    "rf_probe_issue_rate",
+    "rf_probe_issue_rate", "rf_topk_allgather_merge",
 ]
 
 
@@ -152,6 +152,7 @@ def lib() -> C.CDLL:
     L.rf_topk_keys_device.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint32, vp, vp, C.c_int, vp]
     L.rf_topk_merge_keys_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_int, vp]
     L.rf_probe_issue_rate.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    L.rf_topk_allgather_merge.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_int, vp]
     L.rf_topk_merge_u32.argtypes = [C.c_int, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, u32p]
     _lib = L
     return L

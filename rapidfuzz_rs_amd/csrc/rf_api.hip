@@ -5,6 +5,7 @@
 // length and lay them out for the wavefronts, translate `Args` (levenshtein.rs:1285-1331 weight dispatch)
 // into kernel parameters.  No metric is ever evaluated on the host: a shape without a device kernel is
 // RF_ERR_UNSUPPORTED.  Product code: never includes or links anything from oracle/.
+#include <dlfcn.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -1683,6 +1684,52 @@ rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t
         return RF_ERR_HIP;
     }
     return RF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The exchange step below the host language: all-gather of the per-shard key lists over RCCL + merge.  RCCL is not a
+// link-time dependency of this library: the caller owns the communicator, so the RCCL that created it is already in the
+// process, and ncclAllGather is looked up in THAT instance (RTLD_NOLOAD), falling back to the system librccl.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+using nccl_all_gather_fn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
+nccl_all_gather_fn find_nccl_all_gather()
+{
+    static nccl_all_gather_fn fn = [] {
+        if (void* f = dlsym(RTLD_DEFAULT, "ncclAllGather")) return (nccl_all_gather_fn)f;
+        for (const char* name : {"librccl.so", "librccl.so.1"})
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))
+                if (void* f = dlsym(h, "ncclAllGather")) return (nccl_all_gather_fn)f;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL))
+                if (void* f = dlsym(h, "ncclAllGather")) return (nccl_all_gather_fn)f;
+        return (nccl_all_gather_fn) nullptr;
+    }();
+    return fn;
+}
+}  // namespace
+
+rf_status rf_topk_allgather_merge(const uint64_t* d_local_keys, uint32_t k, void* nccl_comm, uint32_t world, uint64_t* d_all_keys,
+                                  uint64_t* d_merged, int device, void* stream)
+{
+    if (!d_local_keys || !d_all_keys || !d_merged || !nccl_comm || k == 0 || k > (uint32_t)kWave || world == 0) {
+        set_error("rf_topk_allgather_merge: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    const nccl_all_gather_fn all_gather = find_nccl_all_gather();
+    if (!all_gather) {
+        set_error("rf_topk_allgather_merge: no RCCL (ncclAllGather) found in this process or on the library path");
+        return RF_ERR_UNSUPPORTED;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return RF_ERR_NO_DEVICE;
+    constexpr int kNcclUint64 = 5;  // ncclDataType_t::ncclUint64 (nccl.h)
+    const int rc = all_gather(d_local_keys, d_all_keys, k, kNcclUint64, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) {
+        set_error("rf_topk_allgather_merge: ncclAllGather failed with ncclResult_t " + std::to_string(rc));
+        return RF_ERR_HIP;
+    }
+    return rf_topk_merge_keys_device(d_all_keys, world * k, k, d_merged, device, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

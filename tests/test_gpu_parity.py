@@ -1382,3 +1382,53 @@ def test_topk_best_match_inside_the_bound_sample(k):
     for kw in ({}, {"score_cutoff": 3}):
         s, i = bc.topk(corpus, k, **kw)
         assert sorted(zip(s.tolist(), i.tolist())) == sorted(planted), (k, kw)
+
+
+def test_gpu_selfcheck_fixture():
+    """The oracle-free check smoke() runs: the committed fixture (tests/golden/gpu_selfcheck.json) through the device."""
+    from rapidfuzz_rs_amd.utils import selfcheck
+
+    assert selfcheck.run(0) == 8 * 256
+
+
+def test_topk_allgather_merge_over_a_raw_nccl_communicator():
+    """rf_topk_allgather_merge: the exchange for hosts below Python.  A one-rank ncclComm_t is created by hand through
+    ctypes on the RCCL that ships with torch (ncclGetUniqueId + ncclCommInitRank), handed to the library as void*, and the
+    gathered + merged keys must be the shard's own top-k."""
+    import ctypes as C
+    import glob
+
+    import torch
+
+    libs = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+    if not libs:
+        pytest.skip("no librccl next to torch")
+    rccl = C.CDLL(libs[0], mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        n, k = 300_000, 16
+        q = synth.query(64, 5)
+        rows = synth.rows_device(n, 64, seed=6, device=torch.device("cuda", 0))
+        corpus = rf.Corpus.from_device_rows(rows)
+        bc = rf.distance.levenshtein.BatchComparator(q)
+        local = torch.empty(k, dtype=torch.int64, device="cuda")
+        gathered = torch.empty(k, dtype=torch.int64, device="cuda")
+        merged = torch.empty(k, dtype=torch.int64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        bc.topk_keys_device(corpus, k, local, index_base=1000, stream=st)
+        N.check(N.lib().rf_topk_allgather_merge(local.data_ptr(), k, comm, 1, gathered.data_ptr(), merged.data_ptr(), 0, st))
+        torch.cuda.synchronize()
+        dist_all = bc.distance_many(corpus)
+        exp = sorted((int(v) << 32) | (1000 + i) for i, v in enumerate(dist_all.tolist()))[:k]
+        assert merged.cpu().tolist() == exp and gathered.cpu().tolist() == exp
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -379,3 +379,30 @@ def test_pm_layout():
     for i, c in enumerate(q):
         exp[c, i // 64] |= np.uint64(1) << np.uint64(i % 64)
     assert (pm == exp).all()
+
+
+def test_gpu_selfcheck_fixture_is_what_the_oracle_says():
+    """tests/golden/gpu_selfcheck.json (the oracle-free GPU check of smoke()) must equal the oracle's output today."""
+    import json
+    import os
+
+    import numpy as np
+
+    from rapidfuzz_rs_amd import _native as N
+
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpu_selfcheck.json")))
+    q = fx["query"].encode("latin-1")
+    cands = [c.encode("latin-1") for c in fx["candidates"]]
+    data = np.frombuffer(b"".join(cands), dtype=np.uint8)
+    offsets = np.zeros(len(cands) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(c) for c in cands])
+    ops = {"distance": N.OP_DISTANCE, "similarity": N.OP_SIMILARITY, "normalized_similarity": N.OP_NORMALIZED_SIMILARITY}
+    for key, exp in fx["expected"].items():
+        metric, op, cutoff = key.split(":")
+        cut = None if cutoff == "None" else (float(cutoff) if "." in cutoff else int(cutoff))
+        got = getattr(o, metric).BatchComparator(q).many(ops[op], data, offsets, score_cutoff=cut)
+        for g, e in zip(got.tolist(), exp):
+            if got.dtype == np.float64:
+                assert (e is None and np.isnan(g)) or (e is not None and g == float.fromhex(e)), key
+            else:
+                assert (e is None and g == 2**64 - 1) or (e is not None and g == e), key

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Regenerates the measurement table of DESIGN.md section 6 from the committed bench lines (profiles/bench_*.json), between the
+markers `<!-- bench-table:begin -->` and `<!-- bench-table:end -->`, so the prose cannot drift from the evidence
+(tests/test_docs.py checks the table is current).   python tools/design_table.py [--check]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROWS = [  # (file stem, label)
+    ("c2_levenshtein", "C2 Levenshtein, query 64 x 100 M len 64, no cutoff (the default `bench.py` line)"),
+    ("q32_levenshtein", "same corpus, query 32 (32-bit kernel)"),
+    ("c3_levenshtein_256", "C3 Levenshtein, query 256 x 10 M len 256"),
+    ("c3_cutoff8", "C3 corpus, `score_cutoff = 8`"),
+    ("c4_indel", "C4 Indel"),
+    ("c4_lcs_seq", "C4 LCS"),
+    ("c4_jaro", "C4 Jaro (f64 out)"),
+    ("c4_jaro_winkler", "C4 Jaro-Winkler (f64 out)"),
+    ("osa", "OSA"),
+    ("c5_cutoff3_many", "C5 shape, 100 M: `score_cutoff = 3`, one u32 per candidate"),
+    ("c5_cutoff3_topk", "C5 shape, 100 M: `score_cutoff = 3`, top-16 only"),
+    ("c5_1B_world1", "C5 = BASELINE configs[4] at N = 1: 1 B candidates, cutoff 3, top-16 + RCCL gather + merge per step (`--config c5`)"),
+    ("topk16_nocutoff", "top-16, no cutoff, no per-candidate output"),
+    ("sharded_path_world1", "the sharded step at world size 1 (top-16 + per-candidate distances + all-gather + merge)"),
+    ("multi4_levenshtein", "4 queries x C2 corpus, Levenshtein (`--queries 4`)"),
+    ("multi4_indel", "4 queries x C2 corpus, Indel"),
+    ("indel_cutoff12", "Indel, `score_cutoff = 12` (a 0.9 `fuzz::ratio` threshold)"),
+    ("osa_cutoff3", "OSA, `score_cutoff = 3`"),
+    ("jw_cutoff0.9", "Jaro-Winkler, `score_cutoff = 0.9`"),
+    ("wf_weights_1_2_3", "Levenshtein weights (1,2,3), 20 M candidates (`wf_reg_kernel<64>`)"),
+]
+
+
+def table():
+    out = ["| workload (1 x MI355X, 100 M candidates unless noted) | Gpairs/s | moved GB/s (frac of 8 TB/s) | SURVEY 8(d) GB/s (frac) | issue ceiling Gpairs/s (kernel / ceiling) | CPU oracle, 1 thread | parity |",
+           "|---|---|---|---|---|---|---|"]
+    for stem, label in ROWS:
+        p = os.path.join(ROOT, "profiles", f"bench_{stem}.json")
+        try:
+            d = json.load(open(p))
+        except (OSError, ValueError):
+            continue
+        r = d["roofline"]
+        s8 = r.get("survey_8d", {"achieved": r["achieved"], "frac": r["frac"]})
+        ib = r.get("issue_bound")
+        ceil = f'{ib["ceiling"]:.1f} ({ib["frac"]:.2f})' if ib and ib["ceiling"] < 1e4 else "-"
+        cpu = d.get("cpu_baseline")
+        par = d.get("parity")
+        out.append(f'| {label} | {d["value"]:.2f} | {r["achieved"]:.0f} ({r["frac"]:.3f}) | {s8["achieved"]:.0f} ({s8["frac"]:.3f}) | {ceil} | '
+                   f'{cpu["value"]:.4f} Gpairs/s' + (f' ({d["value"] / cpu["value"]:.0f}x)' if cpu else "") if cpu else
+                   f'| {label} | {d["value"]:.2f} | {r["achieved"]:.0f} ({r["frac"]:.3f}) | {s8["achieved"]:.0f} ({s8["frac"]:.3f}) | {ceil} | -')
+        out[-1] += f' | {par["mismatches"]} / {par["checked"]} |' if par else " | tests |"
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    path = os.path.join(ROOT, "DESIGN.md")
+    s = open(path).read()
+    b, e = "<!-- bench-table:begin -->", "<!-- bench-table:end -->"
+    new = s[: s.index(b) + len(b)] + "\n" + table() + "\n" + s[s.index(e):] if b in s and e in s else None
+    if "--check" in sys.argv:
+        sys.exit(0 if new is not None and new == s else 1)
+    if new is None:
+        print(table())
+    else:
+        open(path, "w").write(new)
+        print("DESIGN.md table refreshed")
