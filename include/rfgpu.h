@@ -230,7 +230,8 @@ rf_status rf_many_multi_f64(const rf_comparator *const *cs, uint32_t q, const rf
  * defined as: evaluate every candidate with `op`/`args`, drop None, order by
  *   (score ascending for RF_OP_DISTANCE / descending for RF_OP_SIMILARITY, index ascending)
  * and keep the first k.  index = index_base + original candidate index, so shards of one logical
- * corpus produce globally comparable entries.  Outputs are HOST arrays of k entries (k <= 64);
+ * corpus produce globally comparable entries.  Outputs are HOST arrays of k entries (any k >= 1; up to 64 the lists are
+ * kept inside the scan, beyond that the selection path of rf_topk_f64 is used);
  * *out_count <= k.  If out_all is not NULL the same pass also writes every candidate's score there (as
  * rf_many_u32 would; it stays on this GPU).  With a Levenshtein distance cutoff a wavefront stops reading a tile
  * as soon as all of its 64 candidates are provably beyond the cutoff.
@@ -238,6 +239,14 @@ rf_status rf_many_multi_f64(const rf_comparator *const *cs, uint32_t q, const rf
 rf_status rf_topk_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint32_t k,
                       uint64_t index_base, uint32_t *out_score, uint64_t *out_index, uint32_t *out_count,
                       uint32_t *out_all, rf_mem out_all_mem, void *stream);
+/* The same for f64-valued scores -- jaro / jaro_winkler / fuzz ratio, and normalized_* of the usize metrics -- and for
+ * any k: every candidate is scored into a device vector (out_all if given) and the k best are SELECTED from it exactly
+ * (radix selection on order-preserving keys; ties broken by index; None never selected).  Ascending for RF_OP_DISTANCE /
+ * RF_OP_NORMALIZED_DISTANCE, descending for the similarity ops.  rf_topk_u32 takes the same path when k > 64 (one list
+ * entry per wavefront lane is the limit of the in-scan lists), so k is bounded by the candidate count only. */
+rf_status rf_topk_f64(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint64_t k,
+                      uint64_t index_base, double *out_score, uint64_t *out_index, uint64_t *out_count,
+                      double *out_all, rf_mem out_all_mem, void *stream);
 /* Fully asynchronous variant for pipelines that stay on the device (e.g. an RCCL all-gather right after):
  * writes k 64-bit keys to DEVICE memory, best first, empty entries = UINT64_MAX.
  *   key = (score << 32) | (index_base + index)             for RF_OP_DISTANCE   (ascending = best first)

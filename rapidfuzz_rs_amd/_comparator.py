@@ -214,30 +214,34 @@ class BatchComparator:
     def normalized_similarity_many(self, corpus, args=None, **kw):
         return self.many(N.OP_NORMALIZED_SIMILARITY, corpus, args, **kw)
 
-    def topk(self, corpus: Corpus, k: int, op: int = N.OP_DISTANCE, args: Optional[Args] = None, index_base: int = 0,
+    def topk(self, corpus: Corpus, k: int, op: Optional[int] = None, args: Optional[Args] = None, index_base: int = 0,
              out=None, stream=None, *, score_cutoff=None, score_hint=None, weights=None, prefix_weight=None):
-        """(scores uint32[m], indices uint64[m]), m <= k <= 64, ordered by (score, index) -- best first; see
-        rf_topk_u32.  `out` (a CUDA int32/uint32 tensor or a numpy uint32 array of len(corpus)) additionally
-        receives every candidate's score from the same pass."""
+        """(scores[m], indices uint64[m]), m <= k, ordered by (score, index) -- best first (ascending for the distance ops,
+        descending for the similarity ops); see rf_topk_u32 / rf_topk_f64.  Scores are uint32 for distance / similarity of
+        the usize metrics and float64 for everything else (jaro, jaro_winkler, ratio, normalized_*).  Any k >= 1.  `out` (a
+        CUDA tensor or numpy array of len(corpus) scores) additionally receives every candidate's score from the same pass."""
+        if op is None:
+            op = N.OP_SIMILARITY if self.FLOAT else N.OP_DISTANCE
         a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
-        ca = a.to_c(False)
-        scores = np.empty(k, dtype=np.uint32)
+        is_f = self.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
+        ca = a.to_c(is_f)
+        scores = np.empty(k, dtype=np.float64 if is_f else np.uint32)
         idx = np.empty(k, dtype=np.uint64)
-        cnt = C.c_uint32()
+        cnt = C.c_uint64() if is_f else C.c_uint32()
         out_ptr, out_mem = None, N.MEM_HOST
         if out is not None:
             if hasattr(out, "is_cuda") and out.is_cuda:
                 import torch
 
-                assert out.numel() >= len(corpus) and out.is_contiguous() and out.element_size() == 4
+                assert out.numel() >= len(corpus) and out.is_contiguous() and out.element_size() == (8 if is_f else 4)
                 out_ptr, out_mem = out.data_ptr(), N.MEM_DEVICE
                 if stream is None:
                     stream = torch.cuda.current_stream(out.device).cuda_stream
             else:
-                assert out.dtype == np.uint32 and out.size >= len(corpus)
+                assert out.dtype == (np.float64 if is_f else np.uint32) and out.size >= len(corpus)
                 out_ptr = out.ctypes.data
-        N.check(N.lib().rf_topk_u32(self._h, corpus._h, op, C.byref(ca), k, index_base, scores.ctypes.data, idx.ctypes.data,
-                                    C.byref(cnt), out_ptr, out_mem, stream))
+        fn = N.lib().rf_topk_f64 if is_f else N.lib().rf_topk_u32
+        N.check(fn(self._h, corpus._h, op, C.byref(ca), k, index_base, scores.ctypes.data, idx.ctypes.data, C.byref(cnt), out_ptr, out_mem, stream))
         return scores[: cnt.value], idx[: cnt.value]
 
     def topk_keys_device(self, corpus: Corpus, k: int, keys_out, op: int = N.OP_DISTANCE, args: Optional[Args] = None,

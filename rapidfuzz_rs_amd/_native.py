@@ -66,7 +66,7 @@ SYMBOLS = [
     "rf_comparator_query_len", "rf_comparator_pm", "rf_comparator_new_u32", "rf_corpus_pack_u32", "rf_corpus_alphabet_size", "rf_corpus_save", "rf_corpus_load", "rf_stream_many_u32", "rf_stream_many_f64", "rf_corpus_file_count",
     "rf_corpus_pack", "rf_corpus_pack_rows_device", "rf_corpus_free", "rf_corpus_layout_host",
     "rf_host_layout_free", "rf_corpus_count", "rf_corpus_payload_bytes", "rf_corpus_device_bytes",
-    "rf_corpus_device", "rf_many_u32", "rf_many_f64", "rf_one_u32", "rf_one_f64", "rf_many_multi_u32", "rf_many_multi_f64", "rf_topk_u32", "rf_topk_keys_device", "rf_topk_merge_keys_device", "rf_topk_merge_u32",
+    "rf_corpus_device", "rf_many_u32", "rf_many_f64", "rf_one_u32", "rf_one_f64", "rf_many_multi_u32", "rf_many_multi_f64", "rf_topk_u32", "rf_topk_f64", "rf_topk_keys_device", "rf_topk_merge_keys_device", "rf_topk_merge_u32",
     "rf_probe_issue_rate", "rf_topk_allgather_merge",
 ]
 
@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
     L.rf_many_multi_u32.argtypes = [vp, C.c_uint32, vp, C.c_int, C.POINTER(RfArgs), vp, C.c_int, vp]
     L.rf_many_multi_f64.argtypes = [vp, C.c_uint32, vp, C.c_int, C.POINTER(RfArgs), vp, C.c_int, vp]
     L.rf_topk_u32.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint64, vp, vp, u32p, vp, C.c_int, vp]
+    L.rf_topk_f64.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint64, C.c_uint64, vp, vp, u64p, vp, C.c_int, vp]
     L.rf_topk_keys_device.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint32, C.c_uint32, vp, vp, C.c_int, vp]
     L.rf_topk_merge_keys_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_int, vp]
     L.rf_probe_issue_rate.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]

@@ -1603,6 +1603,147 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     return RF_OK;
 }
 
+// ---- the general top-k path: scan to a score vector, then exact selection over it (rf_select.hip) ------------------
+// Any k, u32 or f64 scores.  Returns the kk = min(k, #not-None) best (key, index) pairs sorted by (key, index).
+static rf_status select_topk(const void* d_scores, bool f64, bool desc, uint32_t n, uint64_t k, hipStream_t st, std::vector<uint64_t>* keys,
+                             std::vector<uint32_t>* idx)
+{
+    keys->clear();
+    idx->clear();
+    const uint32_t nb = select_blocks(n);
+    uint8_t* mem = nullptr;
+    const size_t hist_bytes = 2048 * sizeof(unsigned long long), cnt_bytes = (size_t)nb * sizeof(uint32_t);
+    RF_HIP(hipMallocAsync((void**)&mem, 64 + hist_bytes + 2 * cnt_bytes, st));
+    struct Free {
+        uint8_t* p;
+        hipStream_t st;
+        ~Free() { (void)hipFreeAsync(p, st); }
+    } free_mem{mem, st};
+    unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(mem + 64);
+    uint32_t* d_less = reinterpret_cast<uint32_t*>(mem + 64 + hist_bytes);
+    uint32_t* d_eq = d_less + nb;
+    unsigned long long ctl[3] = {~0ull, 0ull, 0ull};  // min key, max key, valid
+    RF_HIP(hipMemcpyAsync(mem, ctl, sizeof(ctl), hipMemcpyHostToDevice, st));
+    RF_HIP(launch_select_minmax(d_scores, f64, n, desc, mem, st));
+    RF_HIP(hipMemcpyAsync(ctl, mem, sizeof(ctl), hipMemcpyDeviceToHost, st));
+    RF_HIP(hipStreamSynchronize(st));
+    const uint64_t valid = ctl[2];
+    if (valid == 0 || k == 0) return RF_OK;
+    const uint64_t kk = std::min<uint64_t>(k, valid);
+    // the k-th smallest key value T, 11 bits at a time from the first bit in which the keys differ
+    uint64_t prefix = 0, prefix_mask = 0, n_less = 0, rank = kk;  // rank: 1-based among the keys matching the prefix
+    const uint64_t diff = ctl[0] ^ ctl[1];
+    int hb = diff ? 63 - __builtin_clzll(diff) : -1;  // highest differing bit
+    if (hb < 63) {
+        prefix_mask = hb < 0 ? ~0ull : ~((2ull << hb) - 1);
+        prefix = ctl[0] & prefix_mask;
+    }
+    if (!f64) prefix_mask &= 0xFFFFFFFFull, prefix &= 0xFFFFFFFFull;
+    std::vector<unsigned long long> hist(2048);
+    while (hb >= 0) {
+        const uint32_t shift = hb + 1 > 11 ? (uint32_t)(hb + 1 - 11) : 0u;
+        const uint32_t bits = (uint32_t)(hb + 1) - shift;
+        RF_HIP(hipMemsetAsync(d_hist, 0, hist_bytes, st));
+        RF_HIP(launch_select_hist(d_scores, f64, n, desc, prefix_mask, prefix, shift, bits, d_hist, st));
+        RF_HIP(hipMemcpyAsync(hist.data(), d_hist, hist_bytes, hipMemcpyDeviceToHost, st));
+        RF_HIP(hipStreamSynchronize(st));
+        uint64_t cum = 0;
+        uint32_t d = 0;
+        for (; d < (1u << bits); ++d) {
+            if (cum + hist[d] >= rank) break;
+            cum += hist[d];
+        }
+        if (d == (1u << bits)) {
+            if (getenv("RF_SELECT_DEBUG")) {
+                unsigned long long tot = 0;
+                for (auto h : hist) tot += h;
+                std::fprintf(stderr, "[select] min %llx max %llx valid %llu kk %llu hb %d shift %u bits %u prefix %llx mask %llx rank %llu cum %llu total-in-hist %llu\n",
+                             ctl[0], ctl[1], (unsigned long long)valid, (unsigned long long)kk, hb, shift, bits, (unsigned long long)prefix,
+                             (unsigned long long)prefix_mask, (unsigned long long)rank, (unsigned long long)cum, tot);
+            }
+            set_error("top-k selection: inconsistent histogram");
+            return RF_ERR_HIP;
+        }
+        n_less += cum;
+        rank -= cum;
+        prefix |= (uint64_t)d << shift;
+        prefix_mask |= (((1ull << bits) - 1) << shift);
+        hb = (int)shift - 1;
+    }
+    const uint64_t T = prefix;
+    const uint32_t need_eq = (uint32_t)(kk - n_less);
+    uint8_t* out = nullptr;
+    const size_t key_bytes = f64 ? 8 : 4;
+    RF_HIP(hipMallocAsync((void**)&out, kk * (key_bytes + 4), st));
+    Free free_out{out, st};
+    uint32_t* d_idx = reinterpret_cast<uint32_t*>(out + kk * key_bytes);
+    RF_HIP(launch_select_count(d_scores, f64, n, desc, T, d_less, d_eq, st));
+    RF_HIP(launch_select_emit(d_scores, f64, n, desc, T, d_less, d_eq, (uint32_t)n_less, need_eq, out, d_idx, st));
+    std::vector<uint8_t> hk(kk * key_bytes);
+    std::vector<uint32_t> hi(kk);
+    RF_HIP(hipMemcpyAsync(hk.data(), out, hk.size(), hipMemcpyDeviceToHost, st));
+    RF_HIP(hipMemcpyAsync(hi.data(), d_idx, kk * 4, hipMemcpyDeviceToHost, st));
+    RF_HIP(hipStreamSynchronize(st));
+    std::vector<std::pair<uint64_t, uint32_t>> pairs(kk);
+    for (uint64_t i = 0; i < kk; ++i)
+        pairs[i] = {f64 ? reinterpret_cast<const uint64_t*>(hk.data())[i] : (uint64_t) reinterpret_cast<const uint32_t*>(hk.data())[i], hi[i]};
+    std::sort(pairs.begin(), pairs.end());
+    keys->resize(kk);
+    idx->resize(kk);
+    for (uint64_t i = 0; i < kk; ++i) (*keys)[i] = pairs[i].first, (*idx)[i] = pairs[i].second;
+    return RF_OK;
+}
+
+// scan every candidate into a device score vector (the caller's out_all if it is device memory, a temporary otherwise),
+// select, and hand the scores to a host out_all if one was asked for
+static rf_status topk_by_selection(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, bool f64, void* out_all,
+                                   rf_mem out_all_mem, hipStream_t st, std::vector<uint64_t>* keys, std::vector<uint32_t>* idx, bool* desc)
+{
+    const size_t elem = f64 ? sizeof(double) : sizeof(uint32_t);
+    *desc = op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY;
+    void* d_scores = out_all;
+    const bool temp = !(out_all && out_all_mem == RF_MEM_DEVICE);
+    if (temp) RF_HIP(hipMallocAsync(&d_scores, corpus->n * elem, st));
+    rf_status s = run_many(c, corpus, op, args, d_scores, RF_MEM_DEVICE, st, f64);
+    if (s == RF_OK) s = select_topk(d_scores, f64, *desc, (uint32_t)corpus->n, k, st, keys, idx);
+    if (s == RF_OK && out_all && out_all_mem == RF_MEM_HOST) {
+        hipError_t e = hipMemcpyAsync(out_all, d_scores, corpus->n * elem, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) s = RF_ERR_HIP;
+    }
+    if (temp) (void)hipFreeAsync(d_scores, st);
+    return s;
+}
+
+rf_status rf_topk_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, uint64_t index_base, double* out_score,
+                      uint64_t* out_index, uint64_t* out_count, double* out_all, rf_mem out_all_mem, void* stream)
+{
+    if (!out_score || !out_index || !out_count || !c || !corpus || !args) {
+        set_error("rf_topk_f64: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    *out_count = 0;
+    if (corpus->n == 0 || k == 0) return RF_OK;
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> idx;
+    bool desc = false;
+    const rf_status s = topk_by_selection(c, corpus, op, args, k, true, out_all, out_all_mem, (hipStream_t)stream, &keys, &idx, &desc);
+    if (s != RF_OK) return s;
+    for (size_t i = 0; i < keys.size(); ++i) {
+        uint64_t b = desc ? ~keys[i] : keys[i];
+        b ^= (b >> 63) ? 0x8000000000000000ull : ~0ull;  // undo the order-preserving map of rf_select.hip
+        std::memcpy(&out_score[i], &b, sizeof(double));
+        out_index[i] = index_base + idx[i];
+    }
+    *out_count = keys.size();
+    return RF_OK;
+}
+
 rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
                       uint64_t index_base, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count,
                       uint32_t* out_all, rf_mem out_all_mem, void* stream)
@@ -1612,7 +1753,34 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         return RF_ERR_INVALID_ARG;
     }
     *out_count = 0;
-    if (corpus->n == 0) return k >= 1 && k <= (uint32_t)kWave ? RF_OK : RF_ERR_INVALID_ARG;
+    if (k == 0) {
+        set_error("top-k: k must be at least 1");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (corpus->n == 0) return RF_OK;
+    if (k > (uint32_t)kWave) {
+        // more than one list entry per wavefront lane: the selection path (any k; also general weight tables, long queries)
+        if (op != RF_OP_DISTANCE && op != RF_OP_SIMILARITY) {
+            set_error("top-k: op must be RF_OP_DISTANCE or RF_OP_SIMILARITY (normalized_*: rf_topk_f64)");
+            return RF_ERR_INVALID_ARG;
+        }
+        DeviceGuard guard(corpus->device);
+        if (!guard.ok) {
+            set_error("cannot select the corpus' device");
+            return RF_ERR_NO_DEVICE;
+        }
+        std::vector<uint64_t> keys;
+        std::vector<uint32_t> idx;
+        bool desc = false;
+        const rf_status s = topk_by_selection(c, corpus, op, args, k, false, out_all, out_all_mem, (hipStream_t)stream, &keys, &idx, &desc);
+        if (s != RF_OK) return s;
+        for (size_t i = 0; i < keys.size(); ++i) {
+            out_score[i] = desc ? ~(uint32_t)keys[i] : (uint32_t)keys[i];
+            out_index[i] = index_base + idx[i];
+        }
+        *out_count = (uint32_t)keys.size();
+        return RF_OK;
+    }
     DeviceGuard guard(corpus->device);
     if (!guard.ok) {
         set_error("cannot select the corpus' device");
@@ -1628,6 +1796,19 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     if (s == RF_OK) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
     (void)hipFreeAsync(d_best, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (s == RF_ERR_UNSUPPORTED && (op == RF_OP_DISTANCE || op == RF_OP_SIMILARITY)) {
+        // shapes the in-scan lists do not cover (queries beyond 512 symbols, general weight tables): score everything, select
+        std::vector<uint64_t> keys;
+        std::vector<uint32_t> idx;
+        s = topk_by_selection(c, corpus, op, args, k, false, out_all, out_all_mem, st, &keys, &idx, &desc);
+        if (s != RF_OK) return s;
+        for (size_t i = 0; i < keys.size(); ++i) {
+            out_score[i] = desc ? ~(uint32_t)keys[i] : (uint32_t)keys[i];
+            out_index[i] = index_base + idx[i];
+        }
+        *out_count = (uint32_t)keys.size();
+        return RF_OK;
+    }
     if (s != RF_OK) return s;
     if (e != hipSuccess) {
         set_error(std::string("top-k: ") + hipGetErrorString(e));

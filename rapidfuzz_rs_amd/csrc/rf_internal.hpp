@@ -115,6 +115,14 @@ hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t 
 hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
                             hipStream_t stream);
 int scan_max_grid();
+// exact selection over a device score vector (rf_select.hip)
+hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, void* ctl, hipStream_t st);
+hipError_t launch_select_hist(const void* s, bool f64, uint32_t n, bool desc, uint64_t prefix_mask, uint64_t prefix, uint32_t shift, uint32_t bits,
+                              unsigned long long* hist, hipStream_t st);
+uint32_t select_blocks(uint32_t n);
+hipError_t launch_select_count(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, uint32_t* cnt_less, uint32_t* cnt_eq, hipStream_t st);
+hipError_t launch_select_emit(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, const uint32_t* off_less, const uint32_t* off_eq, uint32_t n_less,
+                              uint32_t need_eq, void* out_key, uint32_t* out_idx, hipStream_t st);
 hipError_t launch_probe(RawKind raw, uint32_t len1, uint32_t mode, int blocks_per_cu, int iters, double* wave_columns_per_ns);  // rf_probe.hip
 hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,
                                  hipStream_t stream);

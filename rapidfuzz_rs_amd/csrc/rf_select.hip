@@ -1,0 +1,266 @@
+// rf_select.hip -- exact top-k SELECTION over a device-resident score vector: the general top-k path
+// (any k, u32 or f64 scores), next to the in-scan wavefront lists of rf_scan.hip (k <= 64, u32 scores).
+//
+// Definition (rfgpu.h "top-k"): drop None, order by (score ascending for distances / descending for similarities, index
+// ascending), keep the first k.  The reference has no extract API; the oracle is "sort the full result".
+//
+// A score becomes an order-preserving unsigned key (u32: the score or its complement; f64: the sign-flipped IEEE bits or
+// their complement), None becomes the maximum key and is never selected.  Then
+//   1. minmax pass            the key range; the radix passes below start at its first differing bit
+//   2. digit passes (11 bits) histogram of the next digit among keys matching the prefix found so far -> the k-th smallest
+//                             KEY value T exactly, and how many keys are below it
+//   3. block-count pass       per block of 2048 scores: #keys < T and #keys == T
+//   4. block scan             exclusive prefix sums (one workgroup)
+//   5. emit pass              every key < T, and the first (k - #below) keys == T in INDEX order (scores are stored in
+//                             original candidate order, so index order is position order) -> exactly min(k, #valid) pairs
+// The k pairs are sorted by (key, index) on the host (they are going to host arrays anyway).  Every pass streams the
+// score vector once: 4 + ceil(significant bits / 11) reads of 4 or 8 bytes per candidate.
+#include "rf_device.hpp"
+
+namespace rf {
+
+constexpr int kSelThreads = 256;
+constexpr int kSelPerThread = 8;
+constexpr int kSelBlock = kSelThreads * kSelPerThread;  // scores per block
+constexpr int kSelBins = 2048;                          // 11-bit digits
+
+// order-preserving keys; the all-ones key is None
+template <class Key>
+struct KeyOf;
+template <>
+struct KeyOf<uint32_t> {
+    using Score = uint32_t;
+    static __device__ __forceinline__ uint32_t get(uint32_t s, bool desc) { return s == RF_NONE_U32 ? ~0u : (desc ? ~s : s); }
+};
+template <>
+struct KeyOf<uint64_t> {
+    using Score = double;
+    static __device__ __forceinline__ uint64_t get(double d, bool desc)
+    {
+        if (d != d) return ~0ull;  // NaN = None
+        uint64_t b = (uint64_t)__double_as_longlong(d);
+        if (b == 0x8000000000000000ull) b = 0;                      // -0.0 == +0.0
+        b ^= (b >> 63) ? ~0ull : 0x8000000000000000ull;             // ascending in the value
+        return desc ? ~b : b;                                       // (never all ones for a number: that pattern is a NaN)
+    }
+};
+
+struct SelectCtl {  // device-resident, 64-bit fields
+    unsigned long long min_key, max_key;  // over valid keys
+    unsigned long long valid;             // number of valid (not None) scores
+};
+
+template <class Key>
+__global__ __launch_bounds__(kSelThreads) void sel_minmax_kernel(const typename KeyOf<Key>::Score* __restrict__ s, uint32_t n, bool desc, SelectCtl* ctl)
+{
+    Key lo = ~(Key)0, hi = 0;
+    uint32_t valid = 0;
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n; i += gridDim.x * kSelThreads) {
+        const Key k = KeyOf<Key>::get(s[i], desc);
+        if (k != ~(Key)0) {
+            lo = k < lo ? k : lo;
+            hi = k > hi ? k : hi;
+            ++valid;
+        }
+    }
+    __shared__ unsigned long long s_lo, s_hi, s_valid;
+    if (threadIdx.x == 0) s_lo = ~0ull, s_hi = 0, s_valid = 0;
+    __syncthreads();
+    if (valid) {
+        atomicMin(&s_lo, (unsigned long long)lo);
+        atomicMax(&s_hi, (unsigned long long)hi);
+        atomicAdd(&s_valid, (unsigned long long)valid);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) {
+        atomicMin(&ctl->min_key, s_lo);
+        atomicMax(&ctl->max_key, s_hi);
+        atomicAdd(&ctl->valid, s_valid);
+    }
+}
+
+// histogram of digit (key >> shift) & 2047 among keys with (key & prefix_mask) == prefix; per-workgroup LDS histogram,
+// wavefront-aggregated (integer scores concentrate on a handful of bins: one LDS atomic per DISTINCT bin per wavefront)
+template <class Key>
+__global__ __launch_bounds__(kSelThreads) void sel_hist_kernel(const typename KeyOf<Key>::Score* __restrict__ s, uint32_t n, bool desc, Key prefix_mask,
+                                                               Key prefix, uint32_t shift, uint32_t digit_mask, unsigned long long* __restrict__ hist)
+{
+    __shared__ uint32_t lh[kSelBins];
+    for (int i = threadIdx.x; i < kSelBins; i += kSelThreads) lh[i] = 0;
+    __syncthreads();
+    for (uint32_t base = blockIdx.x * kSelThreads; base < n; base += gridDim.x * kSelThreads) {
+        const uint32_t i = base + threadIdx.x;
+        Key k = ~(Key)0;
+        if (i < n) k = KeyOf<Key>::get(s[i], desc);
+        bool active = k != ~(Key)0 && (k & prefix_mask) == prefix;
+        const uint32_t bin = (uint32_t)(k >> shift) & digit_mask;  // (the last digit may be narrower than 11 bits)
+        uint64_t todo = __ballot(active);
+        while (todo) {
+            const uint32_t leader = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t b = __builtin_amdgcn_readlane(bin, leader);
+            const uint64_t same = __ballot(active && bin == b);
+            if ((threadIdx.x & 63) == leader) atomicAdd(&lh[b], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSelBins; i += kSelThreads)
+        if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
+// per block of kSelBlock scores: how many keys are below T, how many equal T
+template <class Key>
+__global__ __launch_bounds__(kSelThreads) void sel_count_kernel(const typename KeyOf<Key>::Score* __restrict__ s, uint32_t n, bool desc, Key T,
+                                                                uint32_t* __restrict__ cnt_less, uint32_t* __restrict__ cnt_eq)
+{
+    uint32_t less = 0, eq = 0;
+    const uint32_t b0 = blockIdx.x * kSelBlock;
+#pragma unroll
+    for (int r = 0; r < kSelPerThread; ++r) {
+        const uint32_t i = b0 + r * kSelThreads + threadIdx.x;
+        if (i < n) {
+            const Key k = KeyOf<Key>::get(s[i], desc);
+            less += k < T;
+            eq += k == T && k != ~(Key)0;
+        }
+    }
+    __shared__ uint32_t s_less, s_eq;
+    if (threadIdx.x == 0) s_less = s_eq = 0;
+    __syncthreads();
+    if (less) atomicAdd(&s_less, less);
+    if (eq) atomicAdd(&s_eq, eq);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt_less[blockIdx.x] = s_less;
+        cnt_eq[blockIdx.x] = s_eq;
+    }
+}
+
+// exclusive scan of both count arrays, in place (one workgroup; nb is n / 2048: tens of thousands at most)
+__global__ __launch_bounds__(kSelThreads) void sel_scan_kernel(uint32_t* cnt_less, uint32_t* cnt_eq, uint32_t nb)
+{
+    __shared__ unsigned long long part[2][kSelThreads];
+    const uint32_t per = (nb + kSelThreads - 1) / kSelThreads;
+    const uint32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
+    unsigned long long a = 0, b = 0;
+    for (uint32_t i = lo; i < hi; ++i) a += cnt_less[i], b += cnt_eq[i];
+    part[0][threadIdx.x] = a;
+    part[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ra = 0, rb = 0;
+        for (int t = 0; t < kSelThreads; ++t) {
+            const unsigned long long xa = part[0][t], xb = part[1][t];
+            part[0][t] = ra;
+            part[1][t] = rb;
+            ra += xa;
+            rb += xb;
+        }
+    }
+    __syncthreads();
+    unsigned long long ra = part[0][threadIdx.x], rb = part[1][threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t xa = cnt_less[i], xb = cnt_eq[i];
+        cnt_less[i] = (uint32_t)ra;  // (both totals fit 32 bits: they are bounded by n)
+        cnt_eq[i] = (uint32_t)std::min<unsigned long long>(rb, 0xFFFFFFFFull);
+        ra += xa;
+        rb += xb;
+    }
+}
+
+// emit: keys below T go to out[off_less[block] + rank], keys equal to T with global equal-rank < need_eq go to
+// out[n_less + rank]; ranks inside a block follow index order (row by row, lane prefix inside a row)
+template <class Key>
+__global__ __launch_bounds__(kSelThreads) void sel_emit_kernel(const typename KeyOf<Key>::Score* __restrict__ s, uint32_t n, bool desc, Key T,
+                                                               const uint32_t* __restrict__ off_less, const uint32_t* __restrict__ off_eq, uint32_t n_less,
+                                                               uint32_t need_eq, Key* __restrict__ out_key, uint32_t* __restrict__ out_idx)
+{
+    __shared__ uint32_t w_less[kSelThreads / kWave], w_eq[kSelThreads / kWave];
+    const uint32_t b0 = blockIdx.x * kSelBlock;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t run_less = off_less[blockIdx.x], run_eq = off_eq[blockIdx.x];
+    if (run_eq >= need_eq && off_less[blockIdx.x] == (blockIdx.x + 1 < gridDim.x ? off_less[blockIdx.x + 1] : 0xFFFFFFFFu)) {
+        // nothing below T in this block and the equal quota is already used up: nothing to emit
+        // (cheap early exit for the common case of a tight T; correctness does not depend on it)
+        return;
+    }
+    for (int r = 0; r < kSelPerThread; ++r) {  // index order: row r covers indices b0 + r*256 .. +255
+        const uint32_t i = b0 + r * kSelThreads + threadIdx.x;
+        Key k = ~(Key)0;
+        if (i < n) k = KeyOf<Key>::get(s[i], desc);
+        const bool is_less = k < T, is_eq = k == T && k != ~(Key)0;
+        const uint64_t ml = __ballot(is_less), me = __ballot(is_eq);
+        if (lane == 0) w_less[wave] = (uint32_t)__popcll(ml), w_eq[wave] = (uint32_t)__popcll(me);
+        __syncthreads();
+        uint32_t pl = 0, pe = 0, tl = 0, te = 0;
+        for (uint32_t w = 0; w < (uint32_t)(kSelThreads / kWave); ++w) {
+            if (w < wave) pl += w_less[w], pe += w_eq[w];
+            tl += w_less[w], te += w_eq[w];
+        }
+        const uint64_t below = (1ull << lane) - 1;
+        if (is_less) {
+            const uint32_t pos = run_less + pl + (uint32_t)__popcll(ml & below);
+            out_key[pos] = k;
+            out_idx[pos] = i;
+        }
+        if (is_eq) {
+            const uint32_t rank = run_eq + pe + (uint32_t)__popcll(me & below);
+            if (rank < need_eq) {
+                out_key[n_less + rank] = k;
+                out_idx[n_less + rank] = i;
+            }
+        }
+        run_less += tl;
+        run_eq += te;
+        __syncthreads();
+    }
+}
+
+// ---- host-callable launchers ----------------------------------------------------------------------------------------
+static int sel_grid(uint32_t n) { return (int)std::min<uint32_t>((n + kSelThreads - 1) / kSelThreads, (uint32_t)scan_max_grid()); }
+
+template <class Key>
+static hipError_t launch_minmax_t(const void* s, uint32_t n, bool desc, void* ctl, hipStream_t st)
+{
+    hipLaunchKernelGGL((sel_minmax_kernel<Key>), dim3(sel_grid(n)), dim3(kSelThreads), 0, st, (const typename KeyOf<Key>::Score*)s, n, desc, (SelectCtl*)ctl);
+    return hipGetLastError();
+}
+hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, void* ctl, hipStream_t st)
+{
+    return f64 ? launch_minmax_t<uint64_t>(s, n, desc, ctl, st) : launch_minmax_t<uint32_t>(s, n, desc, ctl, st);
+}
+hipError_t launch_select_hist(const void* s, bool f64, uint32_t n, bool desc, uint64_t prefix_mask, uint64_t prefix, uint32_t shift, uint32_t bits,
+                              unsigned long long* hist, hipStream_t st)
+{
+    const uint32_t digit_mask = (1u << bits) - 1;
+    if (f64)
+        hipLaunchKernelGGL((sel_hist_kernel<uint64_t>), dim3(sel_grid(n)), dim3(kSelThreads), 0, st, (const double*)s, n, desc, prefix_mask, prefix, shift, digit_mask, hist);
+    else
+        hipLaunchKernelGGL((sel_hist_kernel<uint32_t>), dim3(sel_grid(n)), dim3(kSelThreads), 0, st, (const uint32_t*)s, n, desc, (uint32_t)prefix_mask,
+                           (uint32_t)prefix, shift, digit_mask, hist);
+    return hipGetLastError();
+}
+uint32_t select_blocks(uint32_t n) { return (n + kSelBlock - 1) / kSelBlock; }
+hipError_t launch_select_count(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, uint32_t* cnt_less, uint32_t* cnt_eq, hipStream_t st)
+{
+    const dim3 g(select_blocks(n)), b(kSelThreads);
+    if (f64)
+        hipLaunchKernelGGL((sel_count_kernel<uint64_t>), g, b, 0, st, (const double*)s, n, desc, T, cnt_less, cnt_eq);
+    else
+        hipLaunchKernelGGL((sel_count_kernel<uint32_t>), g, b, 0, st, (const uint32_t*)s, n, desc, (uint32_t)T, cnt_less, cnt_eq);
+    hipLaunchKernelGGL(sel_scan_kernel, dim3(1), b, 0, st, cnt_less, cnt_eq, select_blocks(n));
+    return hipGetLastError();
+}
+hipError_t launch_select_emit(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, const uint32_t* off_less, const uint32_t* off_eq, uint32_t n_less,
+                              uint32_t need_eq, void* out_key, uint32_t* out_idx, hipStream_t st)
+{
+    const dim3 g(select_blocks(n)), b(kSelThreads);
+    if (f64)
+        hipLaunchKernelGGL((sel_emit_kernel<uint64_t>), g, b, 0, st, (const double*)s, n, desc, T, off_less, off_eq, n_less, need_eq, (uint64_t*)out_key, out_idx);
+    else
+        hipLaunchKernelGGL((sel_emit_kernel<uint32_t>), g, b, 0, st, (const uint32_t*)s, n, desc, (uint32_t)T, off_less, off_eq, n_less, need_eq,
+                           (uint32_t*)out_key, out_idx);
+    return hipGetLastError();
+}
+
+}  // namespace rf
