@@ -121,8 +121,10 @@ const uint64_t *rf_comparator_pm(const rf_comparator *c, size_t *block_count);
 /* ---- corpus -----------------------------------------------------------------------------------
  * The candidates a user would feed one by one to `scorer.distance(candidate)` (the loop in
  * rapidfuzz-benches/benches/bench_levenshtein.rs:51-60), packed once and kept in HBM.
- * Layout: candidates are grouped by exact length into tiles of 64 (one candidate per wavefront lane);
- * inside a tile the 16-byte chunk k of lane r sits at tile_base + (k*64 + r)*16, so a wavefront's
+ * Layout: candidates are grouped by exact length into tiles of 64 (one candidate per wavefront lane); what is left
+ * over of each length (fewer than 64) is pooled, sorted by length, into mixed tiles whose lanes carry their own lengths,
+ * so a corpus of few, long, all-different-length candidates packs to its payload instead of 64 lanes per length.
+ * Inside a tile the 16-byte chunk k of lane r sits at tile_base + (k*64 + r)*16, so a wavefront's
  * `global_load_dwordx4` of "my chunk k" is one contiguous 1 KiB read.  Symbols are stored renamed by a
  * per-corpus permutation (frequency rank), which the kernels undo when they stage the PM table; results always
  * come back in the ORIGINAL candidate order and never depend on the renaming.
@@ -146,6 +148,10 @@ typedef struct rf_host_layout {
     uint32_t n_tiles, identity;
     uint8_t sigma[256];    /* symbol renaming: the payload stores sigma[c] for candidate byte c (a permutation that
                               spreads this corpus' frequent symbols over distinct LDS banks) */
+    uint32_t n_exact;      /* tiles [0, n_exact) hold 64 candidates of one length each (whole multiples of 64 per length) */
+    uint32_t n_mixed;      /* the leftovers of every length, sorted by length, share n_mixed MIXED payload blocks of 64 lanes;
+                              tiles [n_exact, n_tiles) are the one-length views of those blocks (one per distinct length in a
+                              block, same tile_off, orig = 0xFFFFFFFF for the lanes of other lengths) */
 } rf_host_layout;
 rf_status rf_corpus_layout_host(const uint8_t *bytes, const uint64_t *offsets, size_t n, rf_host_layout *out);
 void rf_host_layout_free(rf_host_layout *l);

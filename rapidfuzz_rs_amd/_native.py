@@ -56,6 +56,8 @@ class RfHostLayout(C.Structure):
         ("n_tiles", C.c_uint32),
         ("identity", C.c_uint32),
         ("sigma", C.c_uint8 * 256),
+        ("n_exact", C.c_uint32),
+        ("n_mixed", C.c_uint32),
     ]
 
 

@@ -159,6 +159,8 @@ def host_layout(data: np.ndarray, offsets: np.ndarray) -> dict:
             "orig": np.ctypeslib.as_array(lay.orig, shape=(max(lay.n_slots, 1),))[: lay.n_slots].copy(),
             "identity": bool(lay.identity),
             "sigma": np.frombuffer(bytes(lay.sigma), dtype=np.uint8).copy(),
+            "n_exact": int(lay.n_exact),
+            "n_mixed": int(lay.n_mixed),
         }
     finally:
         N.lib().rf_host_layout_free(C.byref(lay))

@@ -86,7 +86,14 @@ struct rf_corpus {
     uint8_t* d_data = nullptr;
     TileDesc* d_tiles = nullptr;
     uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
-    uint32_t n_tiles = 0;
+    uint32_t n_tiles = 0;        // exact tiles, then the virtual (one-length) views of the mixed section
+    uint32_t n_exact = 0;        // tiles [0, n_exact) are exact-length tiles; [n_exact, n_tiles) virtual views (HostLayout)
+    // the mixed section as the Levenshtein / LCS / OSA scans see it: one tile of 64 leftovers with per-lane lengths
+    uint32_t n_mixed = 0;
+    MixedDesc* d_mixed = nullptr;
+    uint32_t* d_mixed_len = nullptr;   // 64 per mixed tile
+    uint32_t* d_mixed_orig = nullptr;  // 64 per mixed tile, kPad = no candidate
+    std::vector<MixedDesc> mixed;      // host copy (length windows of cutoff runs)
     uint32_t max_len = 0;
     bool uniform = false;        // single length bucket: no descriptors, tile t at t * tile_bytes(uniform_len)
     uint32_t uniform_len = 0;
@@ -405,6 +412,12 @@ static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corp
     v.d_tiles = corpus->d_tiles;
     v.d_orig = corpus->d_orig;
     v.n_tiles = corpus->n_tiles;
+    v.n_exact = corpus->n_exact;
+    v.n_mixed = corpus->n_mixed;
+    v.d_mixed = corpus->d_mixed;
+    v.d_mixed_len = corpus->d_mixed_len;
+    v.d_mixed_orig = corpus->d_mixed_orig;
+    v.mixed = corpus->mixed;
     v.max_len = corpus->max_len;
     v.uniform = corpus->uniform;
     v.uniform_len = corpus->uniform_len;
@@ -479,12 +492,28 @@ constexpr size_t kTailPad = (size_t)kWave * kChunk;  // one readable chunk row p
 static inline uint64_t tile_bytes(uint32_t len) { return (uint64_t)((len + kChunk - 1) / kChunk) * kWave * kChunk; }
 
 // Host-side layout of a ragged candidate set (no device needed): the exact bytes rf_corpus_pack uploads.
+//
+// Candidates are grouped by exact length.  Every whole multiple of 64 candidates of one length becomes EXACT tiles (64
+// lanes, one length, no masks anywhere -- the fast shape).  What is left over of each length (< 64 candidates) goes into a
+// pool, sorted by length, and the pool is cut into MIXED tiles: 64 consecutive leftovers with neighbouring lengths share
+// one payload block sized for the longest of them.  A mixed tile is visible in two ways:
+//   * to the Levenshtein / LCS / OSA scans as ONE tile with a per-lane length (MixedDesc + mixed_len / mixed_orig): the
+//     column loop runs to the longest lane and a lane steps only while it still has symbols (scan_kernel_mixed);
+//   * to every other kernel (Jaro, generalized weights, long patterns, multi-query, top-k) as one ordinary exact-length
+//     TileDesc PER DISTINCT LENGTH in it, all pointing at the shared payload, with an orig[] slice that is kPad for the
+//     lanes of other lengths ("virtual tiles": those kernels need no change and pay one pass per distinct length, which
+//     is what exact-length tiles cost them before -- but the payload is no longer padded to 64 lanes per length).
+// Round 1 padded every length to whole tiles: a corpus of few, long, all-different-length candidates used one lane per
+// tile -- 64x the HBM bytes and 64x the scan time of a dense corpus.  Now such a corpus packs to its payload (+ < 2 %).
 struct HostLayout {
     std::unique_ptr<uint8_t[]> packed_storage;  // (not a vector: no single-threaded zero fill of a multi-GB buffer)
     uint8_t* packed = nullptr;     // tile payloads + one chunk row of tail padding
     size_t packed_size = 0;
-    std::vector<TileDesc> tiles;   // ascending length, every length padded to whole tiles
+    std::vector<TileDesc> tiles;   // [exact tiles, ascending length | virtual tiles of the mixed section, ascending length]
+    uint32_t n_exact = 0;          // tiles [0, n_exact) are exact, [n_exact, size) virtual
     std::vector<uint32_t> orig;    // slot -> original index (kPad = padding lane); empty when identity
+    std::vector<MixedDesc> mixed;  // the mixed section as the scans see it
+    std::vector<uint32_t> mixed_len, mixed_orig;  // 64 per mixed tile: lane -> length / original index (kPad = no candidate)
     uint64_t payload = 0;
     uint32_t max_len = 0;
     bool identity = true;          // a single length bucket: slot i is candidate i
@@ -512,7 +541,9 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
     }
     // 1. distinct lengths and their counts (a sorted map: one 4 GiB candidate must not cost a 32 GiB table)
     struct Group {
-        uint64_t count = 0, slot0 = 0, off0 = 0, next = 0;
+        uint64_t count = 0, next = 0;
+        uint64_t slot0 = 0, off0 = 0, in_exact = 0;  // exact part: first slot, payload offset, candidates in it
+        uint64_t pool0 = 0;                           // leftovers: first position in the pool
     };
     std::map<uint32_t, Group> groups;
     uint32_t max_len = 0;
@@ -531,30 +562,64 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
     } else {
         for (size_t i = 0; i < n; ++i) groups[(uint32_t)(offsets[i + 1] - offsets[i])].count++;
     }
-
     timer.lap("lengths");
-    // 2. one group of tiles per distinct length, ascending; every group is padded to whole tiles
-    uint64_t slots = 0, data_bytes = 0;
+
+    // a single length bucket in original order is addressed arithmetically (tile t at t * tile_bytes), last tile partial
+    L->identity = groups.size() <= 1 && tile_bytes(max_len) <= 0xFFFFFFFFull;
+    L->max_len = max_len;
+    static const bool no_mixed = getenv("RF_NO_MIXED_TILES") != nullptr;  // A/B switch: round-1 layout (every length padded to whole tiles)
+
+    // 2. exact tiles: whole multiples of 64 per length, ascending (everything, for the identity layout)
+    uint64_t slots = 0, data_bytes = 0, pool_n = 0;
     for (auto& kv : groups) {
         Group& g = kv.second;
+        const bool all = L->identity || no_mixed;
+        const uint64_t nt = all ? (g.count + kWave - 1) / kWave : g.count / kWave;
+        g.in_exact = all ? g.count : nt * kWave;
         g.slot0 = slots;
         g.off0 = data_bytes;
-        const uint64_t nt = (g.count + kWave - 1) / kWave;
         for (uint64_t t = 0; t < nt; ++t) {
             L->tiles.push_back(TileDesc{data_bytes, kv.first, (uint32_t)slots});
             slots += kWave;
             data_bytes += tile_bytes(kv.first);
         }
+        g.pool0 = pool_n;
+        pool_n += g.count - g.in_exact;
+    }
+    L->n_exact = (uint32_t)L->tiles.size();
+    // 3. mixed tiles over the pool (sorted by length because the groups are), and their virtual exact views
+    const uint64_t n_mixed = (pool_n + kWave - 1) / kWave;
+    std::vector<uint32_t> pool_len(pool_n);
+    for (auto& kv : groups)
+        for (uint64_t k = 0; k < kv.second.count - kv.second.in_exact; ++k) pool_len[kv.second.pool0 + k] = kv.first;
+    std::vector<uint64_t> mixed_off(n_mixed);
+    L->mixed_len.assign(n_mixed * kWave, 0);
+    L->mixed_orig.assign(n_mixed * kWave, kPad);
+    std::vector<std::pair<uint32_t, uint32_t>> vtile_of_len;  // per mixed tile: (length -> virtual tile) as a flat sorted run
+    std::vector<uint64_t> vrun0(n_mixed + 1, 0);
+    for (uint64_t m = 0; m < n_mixed; ++m) {
+        const uint64_t p0 = m * kWave, p1 = std::min<uint64_t>(pool_n, p0 + kWave);
+        const uint32_t lo = pool_len[p0], hi = pool_len[p1 - 1];
+        mixed_off[m] = data_bytes;
+        L->mixed.push_back(MixedDesc{data_bytes, hi, lo, (uint32_t)(m * kWave), 0});
+        for (uint64_t q = p0; q < p1; ++q) L->mixed_len[q] = pool_len[q];
+        uint32_t prev = 0xFFFFFFFFu;
+        for (uint64_t q = p0; q < p1; ++q)
+            if (pool_len[q] != prev) {  // one virtual exact tile per distinct length, sharing the payload block
+                prev = pool_len[q];
+                vtile_of_len.emplace_back(prev, (uint32_t)L->tiles.size());
+                L->tiles.push_back(TileDesc{data_bytes, prev, (uint32_t)slots});
+                slots += kWave;
+            }
+        vrun0[m + 1] = vtile_of_len.size();
+        data_bytes += tile_bytes(hi);
     }
     if (slots >= 0xFFFFFFFFull) {
         set_error("rf_corpus_pack: too many candidates for one corpus");
         return RF_ERR_INVALID_ARG;
     }
-    // a single length bucket is addressed arithmetically (tile t at t * tile_bytes) as long as that fits 32 bits
-    L->identity = groups.size() <= 1 && tile_bytes(max_len) <= 0xFFFFFFFFull;
-    L->max_len = max_len;
 
-    // 2b. symbol renaming from the byte histogram of the whole payload
+    // 3b. symbol renaming from the byte histogram of the whole payload
     {
         // (any permutation is valid; the frequencies only steer it, so a strided sample of ~256 MiB is enough)
         uint64_t hist[256] = {0};
@@ -565,22 +630,27 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
             for (uint64_t b = b0, e = std::min(total, b0 + block); b < e; ++b) hist[bytes[b]]++;
         make_sigma(hist, L->sigma);
     }
-
     timer.lap("tiles + symbol histogram");
-    // 3. slot of every candidate (k-th of its length, original order preserved) -- sequential, cheap
-    std::vector<uint32_t> slot_of(n);
+
+    // 4. where every candidate goes (k-th of its length, original order preserved) -- sequential, cheap:
+    //    place[i] = exact slot, or 0x80000000 | pool position for a leftover
+    std::vector<uint32_t> place(n);
     {
-        // a direct table when lengths are small, the map otherwise
         const bool direct = max_len <= (1u << 20);
         std::vector<Group*> by_len;
         if (direct) {
             by_len.assign((size_t)max_len + 1, nullptr);
             for (auto& kv : groups) by_len[kv.first] = &kv.second;
         }
+        if (pool_n >= 0x80000000ull) {
+            set_error("rf_corpus_pack: too many candidates for one corpus");
+            return RF_ERR_INVALID_ARG;
+        }
         for (size_t i = 0; i < n; ++i) {
             const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
             Group& g = direct ? *by_len[len] : groups[len];
-            slot_of[i] = (uint32_t)(g.slot0 + g.next++);
+            const uint64_t k = g.next++;
+            place[i] = k < g.in_exact ? (uint32_t)(g.slot0 + k) : (0x80000000u | (uint32_t)(g.pool0 + (k - g.in_exact)));
             L->payload += len;
         }
     }
@@ -596,23 +666,34 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
     L->packed_size = data_bytes + kTailPad;
     if (!L->identity) L->orig.assign(slots, kPad);
 
-    // 4. scatter the (renamed) bytes into the chunk-interleaved tiles; candidates are independent -> threads
-    std::map<uint32_t, std::pair<uint64_t, uint64_t>> base;  // len -> (slot0, off0)
+    // 5. scatter the (renamed) bytes into the chunk-interleaved tiles; candidates are independent -> threads
+    std::map<uint32_t, std::pair<uint64_t, uint64_t>> base;  // len -> (slot0, off0) of the exact part
     for (auto& kv : groups) base[kv.first] = {kv.second.slot0, kv.second.off0};
     auto worker = [&](size_t lo, size_t hi) {
         uint32_t cached_len = 0xFFFFFFFFu;
         uint64_t c_slot0 = 0, c_off0 = 0;
         for (size_t i = lo; i < hi; ++i) {
             const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
-            if (len != cached_len) {
-                const auto& b = base.find(len)->second;
-                cached_len = len;
-                c_slot0 = b.first;
-                c_off0 = b.second;
+            uint8_t* dst;
+            if (!(place[i] & 0x80000000u)) {
+                if (len != cached_len) {
+                    const auto& b = base.find(len)->second;
+                    cached_len = len;
+                    c_slot0 = b.first;
+                    c_off0 = b.second;
+                }
+                const uint64_t slot = place[i], k = slot - c_slot0;
+                if (!L->identity) L->orig[slot] = (uint32_t)i;
+                dst = L->packed + c_off0 + (k / kWave) * tile_bytes(len) + (k % kWave) * kChunk;
+            } else {
+                const uint64_t q = place[i] & 0x7FFFFFFFu, m = q / kWave, lane = q % kWave;
+                L->mixed_orig[q] = (uint32_t)i;
+                // its virtual tile: the one of this mixed tile with this length
+                auto first = vtile_of_len.begin() + vrun0[m], last = vtile_of_len.begin() + vrun0[m + 1];
+                auto it = std::lower_bound(first, last, std::make_pair(len, 0u));
+                L->orig[(uint64_t)L->tiles[it->second].slot0 + lane] = (uint32_t)i;
+                dst = L->packed + mixed_off[m] + lane * kChunk;
             }
-            const uint64_t slot = slot_of[i], k = slot - c_slot0;
-            if (!L->identity) L->orig[slot] = (uint32_t)i;
-            uint8_t* dst = L->packed + c_off0 + (k / kWave) * tile_bytes(len) + (k % kWave) * kChunk;
             const uint8_t* src = bytes + offsets[i];
             for (uint32_t b = 0; b < len; ++b) dst[(uint64_t)(b / kChunk) * kWave * kChunk + b % kChunk] = L->sigma[src[b]];
         }
@@ -649,6 +730,8 @@ rf_status rf_corpus_layout_host(const uint8_t* bytes, const uint64_t* offsets, s
     out->packed_bytes = L.packed_size;
     out->n_slots = L.identity ? 0 : L.orig.size();
     out->identity = L.identity ? 1 : 0;
+    out->n_exact = L.n_exact;
+    out->n_mixed = (uint32_t)L.mixed.size();
     out->packed = (uint8_t*)std::malloc(std::max<size_t>(1, L.packed_size));
     out->tile_off = (uint64_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint64_t));
     out->tile_len = (uint32_t*)std::malloc(std::max<size_t>(1, L.tiles.size()) * sizeof(uint32_t));
@@ -703,6 +786,9 @@ static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, r
     c->n = n;
     c->payload_bytes = L.payload;
     c->n_tiles = (uint32_t)L.tiles.size();
+    c->n_exact = L.n_exact;
+    c->n_mixed = (uint32_t)L.mixed.size();
+    c->mixed = L.mixed;
     c->max_len = L.max_len;
     for (size_t t = 0; t < L.tiles.size(); ++t)
         if (c->lengths.empty() || c->lengths.back() != L.tiles[t].len) {
@@ -731,6 +817,15 @@ static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, r
         RF_HIP_C(hipMalloc(&c->d_orig, L.orig.size() * sizeof(uint32_t)));
         RF_HIP_C(hipMemcpy(c->d_orig, L.orig.data(), L.orig.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->device_bytes += L.tiles.size() * sizeof(TileDesc) + L.orig.size() * sizeof(uint32_t);
+    }
+    if (c->n_mixed) {
+        RF_HIP_C(hipMalloc(&c->d_mixed, L.mixed.size() * sizeof(MixedDesc)));
+        RF_HIP_C(hipMemcpy(c->d_mixed, L.mixed.data(), L.mixed.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
+        RF_HIP_C(hipMalloc(&c->d_mixed_len, L.mixed_len.size() * sizeof(uint32_t)));
+        RF_HIP_C(hipMemcpy(c->d_mixed_len, L.mixed_len.data(), L.mixed_len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        RF_HIP_C(hipMalloc(&c->d_mixed_orig, L.mixed_orig.size() * sizeof(uint32_t)));
+        RF_HIP_C(hipMemcpy(c->d_mixed_orig, L.mixed_orig.data(), L.mixed_orig.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->device_bytes += L.mixed.size() * sizeof(MixedDesc) + 2 * L.mixed_len.size() * sizeof(uint32_t);
     }
     *out = c;
     return RF_OK;
@@ -857,8 +952,6 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
             auto tiles_worker = [&, dst_base](size_t t0, size_t t1) {
                 for (size_t t = t0; t < t1; ++t) {
                     const TileDesc& td = L.tiles[t];
-                    const uint64_t tb = tile_bytes(td.len);
-                    std::memset(dst_base + td.data_off, 0xFF, tb * sizeof(Sym));
                     for (uint32_t r = 0; r < (uint32_t)kWave; ++r) {
                         const uint64_t slot = (uint64_t)td.slot0 + r;
                         const uint64_t i = L.identity ? slot : (uint64_t)L.orig[slot];
@@ -869,7 +962,12 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
                     }
                 }
             };
-            std::memset(dst_base + (L.packed_size - kTailPad), 0xFF, kTailPad * sizeof(Sym));
+            // padding value everywhere first (in parallel): the virtual tiles of a mixed tile share one payload block, so no
+            // worker may blank "its" tile after another one has written its own lanes into the same block
+            run([&](size_t t) {
+                const uint64_t lo = (uint64_t)L.packed_size * t / nthreads, hi = (uint64_t)L.packed_size * (t + 1) / nthreads;
+                std::memset(dst_base + lo, 0xFF, (hi - lo) * sizeof(Sym));
+            });
             if (nthreads == 1) {
                 tiles_worker(0, n_tiles);
             } else {
@@ -916,6 +1014,7 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
     c->payload_bytes = (uint64_t)n * len;
     c->max_len = (uint32_t)len;
     c->n_tiles = (uint32_t)((n + kWave - 1) / kWave);
+    c->n_exact = c->n_tiles;
     if (n) {
         c->lengths.push_back((uint32_t)len);
         c->length_first_tile.push_back(0);
@@ -968,6 +1067,9 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_data) (void)hipFree(c->d_data);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_orig) (void)hipFree(c->d_orig);
+    if (c->d_mixed) (void)hipFree(c->d_mixed);
+    if (c->d_mixed_len) (void)hipFree(c->d_mixed_len);
+    if (c->d_mixed_orig) (void)hipFree(c->d_mixed_orig);
     if (c->d_sigma) (void)hipFree(c->d_sigma);
     if (c->d_raw) (void)hipFree(c->d_raw);
     if (c->d_sigma_identity) (void)hipFree(c->d_sigma_identity);
@@ -1013,6 +1115,12 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->n_tiles = corpus->n_tiles;
     p->tile_begin = 0;
     p->tile_end = corpus->n_tiles;
+    p->n_exact = corpus->n_exact;
+    p->mixed = corpus->d_mixed;  // (nullptr when the corpus has no mixed section, and on views without one)
+    p->mixed_len = corpus->d_mixed_len;
+    p->mixed_orig = corpus->d_mixed_orig;
+    p->mixed_begin = 0;
+    p->mixed_end = corpus->d_mixed ? corpus->n_mixed : 0;
     p->tile_step = 1;
     p->n = (uint32_t)corpus->n;
 
@@ -1240,6 +1348,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
             // pre-filled with None.
             const auto& L = corpus->lengths;
             size_t first = L.size(), last = 0;
+            uint32_t pass_lo = 0xFFFFFFFFu, pass_hi = 0;  // the shortest and the longest candidate length that can pass
             for (size_t i = 0; i < L.size(); ++i) {
                 const uint32_t len2 = L[i];
                 const uint32_t Sv = p->len1 + len2, Mv = std::max(p->len1, len2);
@@ -1257,15 +1366,27 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
                 if (pass) {
                     first = std::min(first, i);
                     last = i;
+                    pass_lo = std::min(pass_lo, len2);
+                    pass_hi = std::max(pass_hi, len2);
                 }
             }
+            // (the length table follows the tile order -- exact tiles ascending, then the one-length views of the mixed
+            // section ascending -- so [first, last] may enclose lengths that cannot pass: those tiles are merely read)
             if (first == L.size()) {
                 p->tile_begin = p->tile_end = corpus->n_tiles;  // nothing can pass
+                p->mixed_begin = p->mixed_end = 0;
             } else {
                 p->tile_begin = corpus->length_first_tile[first];
                 p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
+                // mixed tiles ascend by length as well: the ones whose length span meets [pass_lo, pass_hi]
+                uint32_t mb = 0, me = p->mixed_end;
+                while (mb < me && corpus->mixed[mb].max_len < pass_lo) ++mb;
+                while (me > mb && corpus->mixed[me - 1].min_len > pass_hi) --me;
+                p->mixed_begin = mb;
+                p->mixed_end = me;
             }
-            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
+            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles ||
+                                                      (corpus->d_mixed && (p->mixed_begin > 0 || p->mixed_end < corpus->n_mixed)));
         }
     }
     return RF_OK;
@@ -1931,10 +2052,12 @@ struct FileHeader {  // little endian, 512 bytes
     uint32_t n_alphabet, n_overflow;
     uint8_t sigma[256];
     uint64_t off_raw;  // flags & 4: the u32 symbol stream parallel to the payload (data_bytes entries)
-    uint8_t reserved[512 - 8 - 8 - 8 - 16 - 16 - 40 - 8 - 256 - 8];
+    uint64_t off_mixed;  // n_mixed MixedDesc, then 64 * n_mixed lengths, then 64 * n_mixed original indices
+    uint32_t n_exact, n_mixed;  // tiles [0, n_exact) exact, the rest one-length views of the n_mixed mixed tiles
+    uint8_t reserved[512 - 8 - 8 - 8 - 16 - 16 - 40 - 8 - 256 - 8 - 16];
 };
 static_assert(sizeof(FileHeader) == 512, "header layout");
-constexpr uint32_t kFileVersion = 1, kFlagUniform = 1, kFlagWide = 2, kFlagRaw = 4, kFlagRaw16 = 8;
+constexpr uint32_t kFileVersion = 2, kFlagUniform = 1, kFlagWide = 2, kFlagRaw = 4, kFlagRaw16 = 8;
 
 struct FileCloser {
     FILE* f;
@@ -1990,7 +2113,8 @@ rf_status read_header(FILE* f, FileHeader* h)
     const bool ok = h->n < 0xFFFFFFFFull && inside(h->off_lengths, (uint64_t)h->n_lengths * 2, 4) &&
                     (uniform || (inside(h->off_tiles, h->n_tiles, sizeof(TileDesc)) && inside(h->off_orig, (uint64_t)h->n_tiles * kWave, 4))) &&
                     inside(h->off_alphabet, (uint64_t)h->n_alphabet * 2 + h->n_overflow, 4) && inside(h->off_data, h->data_bytes, 1) &&
-                    (!raw_elem || inside(h->off_raw, h->data_bytes, raw_elem)) && h->n_alphabet <= 256 && h->off_data >= sizeof(FileHeader);
+                    (!raw_elem || inside(h->off_raw, h->data_bytes, raw_elem)) && h->n_alphabet <= 256 && h->off_data >= sizeof(FileHeader) &&
+                    h->n_exact <= h->n_tiles && (h->n_mixed == 0 || (!uniform && inside(h->off_mixed, (uint64_t)h->n_mixed * (sizeof(MixedDesc) + 2 * kWave * 4), 1)));
     if (!ok) {
         set_error("corpus file is inconsistent: a section lies outside the file (truncated?)");
         return RF_ERR_INVALID_ARG;
@@ -2033,6 +2157,9 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
     h.off_tiles = off, off += c->uniform ? 0 : (uint64_t)c->n_tiles * sizeof(TileDesc);
     h.off_orig = off, off += (uint64_t)n_slots * 4;
     h.off_alphabet = off, off += (uint64_t)h.n_alphabet * 8 + (uint64_t)h.n_overflow * 4;
+    h.n_exact = c->n_exact;
+    h.n_mixed = c->d_mixed ? c->n_mixed : 0;
+    h.off_mixed = off, off += (uint64_t)h.n_mixed * (sizeof(MixedDesc) + 2 * kWave * 4);
     h.off_data = (off + 4095) / 4096 * 4096;  // page-aligned payload
     h.off_raw = (h.off_data + c->data_bytes + 4095) / 4096 * 4096;
     bool ok = write_all(fc.f, &h, sizeof(h));
@@ -2049,6 +2176,13 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
         for (const auto& kv : c->alphabet) a.push_back(kv.first), a.push_back(kv.second);
         for (uint32_t sym : c->overflow) a.push_back(sym);
         ok = ok && write_all(fc.f, a.data(), a.size() * 4);
+    }
+    if (h.n_mixed) {
+        std::vector<uint32_t> lens((size_t)h.n_mixed * kWave), origs((size_t)h.n_mixed * kWave);
+        RF_HIP(hipMemcpy(lens.data(), c->d_mixed_len, lens.size() * 4, hipMemcpyDeviceToHost));
+        RF_HIP(hipMemcpy(origs.data(), c->d_mixed_orig, origs.size() * 4, hipMemcpyDeviceToHost));
+        ok = ok && write_all(fc.f, c->mixed.data(), c->mixed.size() * sizeof(MixedDesc)) && write_all(fc.f, lens.data(), lens.size() * 4) &&
+             write_all(fc.f, origs.data(), origs.size() * 4);
     }
     std::vector<uint8_t> buf(std::min<uint64_t>(std::max<uint64_t>(c->data_bytes, 1), 64ull << 20));
     ok = ok && fseeko(fc.f, (off_t)h.off_data, SEEK_SET) == 0;
@@ -2074,12 +2208,17 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
 }
 
 // host-side metadata shared by rf_corpus_load and the stream driver
-static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vector<TileDesc>* tiles, std::vector<uint32_t>* orig)
+struct MixedArrays {
+    std::vector<uint32_t> len, orig;  // 64 per mixed tile (the descriptors go to rf_corpus::mixed)
+};
+static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vector<TileDesc>* tiles, std::vector<uint32_t>* orig, MixedArrays* mx = nullptr)
 {
     c->n = h.n;
     c->payload_bytes = h.payload_bytes;
     c->data_bytes = h.data_bytes;
     c->n_tiles = h.n_tiles;
+    c->n_exact = h.n_exact;
+    c->n_mixed = h.n_mixed;
     c->max_len = h.max_len;
     c->uniform = (h.flags & kFlagUniform) != 0;
     c->uniform_len = h.uniform_len;
@@ -2096,6 +2235,16 @@ static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vect
     }
     std::vector<uint32_t> a((size_t)h.n_alphabet * 2 + h.n_overflow);
     ok = ok && read_at(f, h.off_alphabet, a.data(), a.size() * 4);
+    MixedArrays local;
+    if (!mx) mx = &local;
+    if (h.n_mixed) {
+        c->mixed.resize(h.n_mixed);
+        mx->len.resize((size_t)h.n_mixed * kWave);
+        mx->orig.resize((size_t)h.n_mixed * kWave);
+        const uint64_t o1 = h.off_mixed + (uint64_t)h.n_mixed * sizeof(MixedDesc), o2 = o1 + mx->len.size() * 4;
+        ok = ok && read_at(f, h.off_mixed, c->mixed.data(), c->mixed.size() * sizeof(MixedDesc)) && read_at(f, o1, mx->len.data(), mx->len.size() * 4) &&
+             read_at(f, o2, mx->orig.data(), mx->orig.size() * 4);
+    }
     if (!ok) {
         set_error("corpus file truncated");
         return RF_ERR_INVALID_ARG;
@@ -2113,17 +2262,21 @@ static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vect
     if (c->n > (uint64_t)c->n_tiles * kWave) return bad("more candidates than tile slots");
     if ((c->n == 0) != (c->n_tiles == 0) && c->n_tiles == 0) return bad("candidates without tiles");
     if (c->lengths.size() != c->length_first_tile.size()) return bad("length table");
+    if (c->n_exact > c->n_tiles) return bad("exact tile count");
     for (size_t i = 0; i < c->lengths.size(); ++i) {
-        if (i && (c->lengths[i] <= c->lengths[i - 1] || c->length_first_tile[i] <= c->length_first_tile[i - 1])) return bad("length table not ascending");
+        if (i && c->length_first_tile[i] <= c->length_first_tile[i - 1]) return bad("length table not in tile order");
         if (c->length_first_tile[i] >= c->n_tiles || c->lengths[i] > c->max_len) return bad("length table out of range");
     }
-    if (!c->lengths.empty() && (c->length_first_tile[0] != 0 || c->lengths.back() != c->max_len)) return bad("length table does not cover the tiles");
+    if (!c->lengths.empty() && c->length_first_tile[0] != 0) return bad("length table does not start at tile 0");
     if (c->uniform) {
-        if (c->lengths.size() > 1 || c->uniform_len != c->max_len || (c->n_tiles && c->lengths.empty())) return bad("uniform flag vs length table");
+        if (c->lengths.size() > 1 || c->uniform_len != c->max_len || (c->n_tiles && c->lengths.empty()) || c->n_mixed || c->n_exact != c->n_tiles)
+            return bad("uniform flag vs length table");
         if (tile_bytes(c->uniform_len) > 0xFFFFFFFFull || (uint64_t)c->n_tiles * tile_bytes(c->uniform_len) != body) return bad("uniform payload size");
         if (c->n_tiles && c->n <= (uint64_t)(c->n_tiles - 1) * kWave) return bad("empty trailing tile");
     } else {
         if (c->n_tiles && c->lengths.empty()) return bad("tiles without a length table");
+        // exact tiles: ascending lengths, payload blocks back to back; then the mixed blocks, back to back as well; every
+        // virtual tile (a one-length view of a mixed tile) must lie inside ONE mixed block and be no longer than it
         size_t li = 0;
         uint64_t expect_off = 0, real = 0;
         for (uint32_t t = 0; t < c->n_tiles; ++t) {
@@ -2131,10 +2284,36 @@ static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vect
             while (li + 1 < c->lengths.size() && c->length_first_tile[li + 1] <= t) ++li;
             if (td.len != c->lengths[li]) return bad("tile length vs length table");
             if (td.slot0 != t * (uint32_t)kWave) return bad("tile slot base");
-            if (td.data_off != expect_off) return bad("tile payload offset");
-            expect_off += tile_bytes(td.len);
-            if (expect_off > body) return bad("tile payload beyond the data section");
+            if (t < c->n_exact) {
+                if (t && td.len < (*tiles)[t - 1].len) return bad("exact tiles not ascending");
+                if (td.data_off != expect_off) return bad("tile payload offset");
+                expect_off += tile_bytes(td.len);
+                if (expect_off > body) return bad("tile payload beyond the data section");
+            }
         }
+        uint32_t vt = c->n_exact;  // virtual tiles follow their mixed tiles in order
+        for (uint32_t m = 0; m < c->n_mixed; ++m) {
+            const MixedDesc& md = c->mixed[m];
+            if (md.data_off != expect_off || md.min_len > md.max_len || md.max_len > c->max_len || md.slot0 != m * (uint32_t)kWave) return bad("mixed tile descriptor");
+            if (m && md.min_len < c->mixed[m - 1].max_len) return bad("mixed tiles not ascending");
+            expect_off += tile_bytes(md.max_len);
+            if (expect_off > body) return bad("mixed payload beyond the data section");
+            uint32_t prev_len = 0;
+            bool any = false;
+            for (; vt < c->n_tiles && (*tiles)[vt].data_off == md.data_off; ++vt) {
+                const TileDesc& td = (*tiles)[vt];
+                if (td.len < md.min_len || td.len > md.max_len || (any && td.len <= prev_len)) return bad("view of a mixed tile");
+                prev_len = td.len;
+                any = true;
+            }
+            if (!any) return bad("mixed tile without views");
+            for (uint32_t r = 0; r < (uint32_t)kWave; ++r) {
+                const uint32_t o = mx->orig[(size_t)m * kWave + r], l = mx->len[(size_t)m * kWave + r];
+                if (o == kPad) continue;
+                if (o >= c->n || l < md.min_len || l > md.max_len) return bad("mixed lane");
+            }
+        }
+        if (vt != c->n_tiles) return bad("views without a mixed tile");
         if (expect_off != body) return bad("data section size");
         std::vector<uint8_t> seen;  // every original index exactly once
         if (c->n <= (64u << 20)) seen.assign((size_t)c->n, 0);
@@ -2183,7 +2362,8 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
         rf_corpus_free(c);
         return st;
     };
-    s = load_meta(fc.f, h, c, &tiles, &orig);
+    MixedArrays mx;
+    s = load_meta(fc.f, h, c, &tiles, &orig, &mx);
     if (s != RF_OK) return fail(s);
     RF_HIP_C(hipMalloc(&c->d_data, std::max<uint64_t>(1, c->data_bytes)));
     std::vector<uint8_t> buf(std::min<uint64_t>(std::max<uint64_t>(c->data_bytes, 1), 64ull << 20));
@@ -2218,6 +2398,15 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
         RF_HIP_C(hipMalloc(&c->d_orig, std::max<size_t>(1, orig.size()) * 4));
         RF_HIP_C(hipMemcpy(c->d_orig, orig.data(), orig.size() * 4, hipMemcpyHostToDevice));
         c->device_bytes += tiles.size() * sizeof(TileDesc) + orig.size() * 4;
+    }
+    if (c->n_mixed) {
+        RF_HIP_C(hipMalloc(&c->d_mixed, c->mixed.size() * sizeof(MixedDesc)));
+        RF_HIP_C(hipMemcpy(c->d_mixed, c->mixed.data(), c->mixed.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
+        RF_HIP_C(hipMalloc(&c->d_mixed_len, mx.len.size() * 4));
+        RF_HIP_C(hipMemcpy(c->d_mixed_len, mx.len.data(), mx.len.size() * 4, hipMemcpyHostToDevice));
+        RF_HIP_C(hipMalloc(&c->d_mixed_orig, mx.orig.size() * 4));
+        RF_HIP_C(hipMemcpy(c->d_mixed_orig, mx.orig.data(), mx.orig.size() * 4, hipMemcpyHostToDevice));
+        c->device_bytes += c->mixed.size() * sizeof(MixedDesc) + 2 * mx.len.size() * 4;
     }
     *out = c;
     return RF_OK;
@@ -2265,9 +2454,17 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     // segment boundaries
     if (segment_bytes == 0) segment_bytes = 256ull << 20;
     std::vector<uint32_t> cuts{0};
+    // (the one-length views of a mixed tile share one payload block: a cut may only fall where the payload offset changes)
+    auto block_start = [&](uint32_t t) { return t >= meta.n_tiles || t == 0 || tile_off(t) != tile_off(t - 1); };
     while (cuts.back() < meta.n_tiles) {
         uint32_t t0 = cuts.back(), t1 = t0 + 1;
-        while (t1 < meta.n_tiles && tile_off(t1 + 1) - tile_off(t0) <= segment_bytes) ++t1;
+        while (t1 < meta.n_tiles && !block_start(t1)) ++t1;  // at least one whole block
+        while (t1 < meta.n_tiles) {
+            uint32_t t2 = t1 + 1;
+            while (t2 < meta.n_tiles && !block_start(t2)) ++t2;
+            if (tile_off(t2) - tile_off(t0) > segment_bytes) break;
+            t1 = t2;
+        }
         cuts.push_back(t1);
     }
     uint64_t max_seg = 0;
@@ -2330,6 +2527,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         seg.d_sigma = d_sigma;
         seg.d_data = sl.d_data;
         seg.n_tiles = t1 - t0;
+        seg.n_exact = seg.n_tiles;  // (a segment view has no mixed section of its own: mixed tiles are scanned through their views)
         seg.data_bytes = bytes + kTailPad;
         void* seg_out = d_out;
         if (meta.uniform) {

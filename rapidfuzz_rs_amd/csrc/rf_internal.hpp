@@ -26,6 +26,16 @@ struct TileDesc {
     uint32_t slot0;     // index of lane 0 in the slot arrays (orig[])
 };
 
+// One MIXED tile: 64 leftover candidates of neighbouring lengths sharing one payload block sized for the longest
+// (rf_api.hip HostLayout).  Seen by scan_kernel_mixed with a per-lane length; every other kernel sees it through
+// ordinary one-length TileDesc views.
+struct MixedDesc {
+    uint64_t data_off;          // the shared payload block
+    uint32_t max_len, min_len;  // over the real lanes
+    uint32_t slot0;             // first entry of this tile in mixed_len / mixed_orig (64 per tile)
+    uint32_t pad;
+};
+
 enum RawKind : uint32_t {
     RAW_LEV = 0,   // uniform Levenshtein distance (Myers/Hyyro)
     RAW_LCS = 1,   // LCS length (Hyyro)
@@ -49,6 +59,9 @@ struct ScanParams {
     const uint8_t* data;
     const TileDesc* tiles;  // nullptr: every tile has length uniform_len and sits at t * uniform_tile_bytes
     const uint32_t* orig;  // slot -> original index (kPad for padding lanes); nullptr = identity
+    const MixedDesc* mixed;        // scan_kernel_mixed: the mixed section, tiles [tile_begin, tile_end) of it
+    const uint32_t* mixed_len;     // per lane: candidate length
+    const uint32_t* mixed_orig;    // per lane: original index, kPad = no candidate
     const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w], indexed by ORIGINAL symbol
     const uint8_t* sigma;  // device uint8[256]: original symbol -> the symbol stored in the packed corpus
     void* out;             // uint32_t* or double*
@@ -66,6 +79,8 @@ struct ScanParams {
     uint32_t factor;       // common weight factor (levenshtein.rs:1307-1327)
     uint32_t w_ins, w_del, w_sub;  // for _maximum (levenshtein.rs:263-277)
     uint32_t tile_begin, tile_end;  // tile range of this launch (jaro kernels; the cutoff length window of the scans)
+    uint32_t n_exact;               // tiles below this index are exact-length tiles; above: one-length views of mixed tiles
+    uint32_t mixed_begin, mixed_end;  // the mixed tiles (indices into `mixed`) a Levenshtein / LCS / OSA scan has to visit
     const double* jaro_tab;         // jaro kernels: device table [65][33] of (c - h) / c (rf_api.hip jaro_device_table); nullptr = compute
     double jaro_need;               // jaro kernels: the similarity a candidate must reach to pass the cutoff; < 0 = no early-out
     uint32_t wf_query[16];          // wf_reg_kernel: the (renamed) query bytes, 4 per word, for queries of <= 64 symbols
@@ -105,6 +120,7 @@ struct ScanParams {
 
 // kernel launchers (rf_scan.hip, rf_long.hip, rf_jaro.hip, rf_pack.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
+hipError_t launch_scan_mixed(RawKind raw, const ScanParams& p, hipStream_t stream);  // p.mixed / tile_begin / tile_end: the mixed section
 hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid);
 hipError_t launch_wf(const ScanParams& p, hipStream_t stream);
 hipError_t launch_jaro(const ScanParams& p, hipStream_t stream);

@@ -463,6 +463,24 @@ int scan_grid(uint32_t n_tiles)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
 {
     if (p.n_tiles == 0) return hipSuccess;
+    // A corpus with a mixed section (leftovers of every length pooled into tiles with per-lane lengths) is scanned in two
+    // launches by the register-resident Levenshtein / LCS / OSA kernels: the exact tiles as always, the mixed tiles by
+    // scan_kernel_mixed.  Top-k, multi-query and the other kernel families walk the one-length views instead (p stays as is).
+    if (p.mixed && p.mixed_end > p.mixed_begin && !p.topk_k && !p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA) &&
+        p.tile_step == 1) {
+        ScanParams q = p;
+        q.mixed = nullptr;
+        q.tile_end = std::min(p.tile_end, p.n_exact);
+        q.tile_begin = std::min(p.tile_begin, q.tile_end);
+        hipError_t e = hipSuccess;
+        if (q.tile_end > q.tile_begin || p.prefill_none) e = launch_scan(raw, q, stream, grid_used);  // (also does the None pre-fill)
+        if (e != hipSuccess) return e;
+        ScanParams m = p;
+        m.tile_begin = p.mixed_begin;
+        m.tile_end = p.mixed_end;
+        m.prefill_none = 0;
+        return launch_scan_mixed(raw, m, stream);
+    }
     const uint32_t launch_tiles = p.tile_end > p.tile_begin ? (p.tile_end - p.tile_begin + p.tile_step - 1) / p.tile_step : 0;
     const int grid = p.long_words_pad ? (int)p.long_grid : std::max(1, scan_grid(launch_tiles));
     if (grid_used) *grid_used = grid;

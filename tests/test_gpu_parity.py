@@ -226,8 +226,11 @@ def test_levenshtein_generalized_weights_limits_and_uniform_corpus():
     with pytest.raises(rf.RfError) as e:
         rf.distance.levenshtein.BatchComparator(synth.query(700, 9)).distance_many(corpus, weights=(1, 2, 3))
     assert e.value.status == N.RF_ERR_UNSUPPORTED
-    with pytest.raises(rf.RfError):
-        rf.distance.levenshtein.BatchComparator(synth.query(20, 9)).topk(corpus, 4, weights=(1, 2, 3))
+    # top-k under a general weight table: no in-scan lists for it, so the selection path (round 1 refused)
+    q20 = synth.query(20, 9)
+    s4, i4 = rf.distance.levenshtein.BatchComparator(q20).topk(corpus, 4, weights=(1, 2, 3))
+    full = rf.distance.levenshtein.BatchComparator(q20).distance_many(corpus, weights=(1, 2, 3))
+    assert list(zip(s4.tolist(), i4.tolist())) == sorted((int(v), j) for j, v in enumerate(full.tolist()))[:4]
     # a mixed list of queries through rf_many_multi_*: general tables go one launch per query
     bc = rf.distance.levenshtein.BatchComparator
     cs = [bc(synth.query(n, n)) for n in (10, 64, 30, 100)]
@@ -1508,3 +1511,46 @@ def test_topk_selection_edge_cases():
     same = rf.Corpus.from_list([b"abc"] * 3000)
     s, i = rf.distance.levenshtein.BatchComparator(b"abd").topk(same, 200)
     assert s.tolist() == [1] * 200 and i.tolist() == list(range(200))
+
+
+def test_distinct_lengths_scan_within_2x_of_a_dense_corpus():
+    """10 000 candidates with 10 000 distinct lengths scan within 2x of a dense corpus of the same bytes (round 1:
+    one lane per 64-lane tile = 64x), with results equal to the oracle's."""
+    import time
+
+    import torch
+
+    n = 10_000
+    lens = np.arange(1, n + 1, dtype=np.uint64)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    rng = np.random.default_rng(3)
+    data = synth.ALNUM[rng.integers(0, 62, size=int(offsets[-1]))]
+    q = synth.query(64, 9)
+    ragged = rf.Corpus.from_ragged(data, offsets)
+    assert ragged.device_bytes <= 1.15 * int(offsets[-1])  # payload + views + slot maps (round 1: 64x the payload)
+    dense_rows = int(offsets[-1]) // 5000
+    dense = rf.Corpus.from_device_rows(torch.from_numpy(data[: dense_rows * 5000].reshape(dense_rows, 5000).copy()).cuda())
+    bc = GPU["levenshtein"].BatchComparator(q)
+    out_r = torch.empty(n, dtype=torch.int32, device="cuda")
+    out_d = torch.empty(dense_rows, dtype=torch.int32, device="cuda")
+
+    def timed(corpus, out):
+        for _ in range(2):
+            bc.distance_many(corpus, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            bc.distance_many(corpus, out=out)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 5
+
+    t_ragged, t_dense = timed(ragged, out_r), timed(dense, out_d)
+    assert t_ragged <= 2.0 * t_dense, (t_ragged, t_dense)
+    got = out_r.cpu().numpy().view(np.uint32)
+    sample = np.arange(0, n, 37)
+    sub_off = np.zeros(len(sample) + 1, dtype=np.uint64)
+    sub_off[1:] = np.cumsum(lens[sample])
+    sub = np.concatenate([data[int(offsets[i]) : int(offsets[i + 1])] for i in sample])
+    exp = o.levenshtein.BatchComparator(q).many(N.OP_DISTANCE, sub, sub_off)
+    assert (got[sample] == exp.astype(np.uint32)).all()

@@ -2,4 +2,4 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q -k "topk or allgather or selfcheck" > gpurun_out/pytest_gpu_sel.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu_sel.log
+timeout 2400 python -m pytest tests -m gpu -x -q -k "distinct_lengths or file or stream or u32 or relabel" > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.log
