@@ -1308,7 +1308,16 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
 
     if (*raw == RAW_WF) return RF_OK;
-    if (c->words > (size_t)kMaxWords) {
+    // Long query + small distance cutoff (the reference's hyrroe2003_small_band_with_pm, levenshtein.rs:509-617, taken when
+    // len1 > 64 and 2k + 1 <= 64, :1059-1062): one 64-bit word sliding down the diagonal instead of ceil(len1 / 64) words
+    // per column.  k is the cutoff on the RAW distance (the common weight factor divided out).
+    static const bool no_band = getenv("RF_NO_BAND") != nullptr;  // A/B switch
+    if (!no_band && *raw == RAW_LEV && p->finish == FIN_LEV && p->factor >= 1 && op == RF_OP_DISTANCE && !f64_out && p->has_cutoff && c->words >= 2 &&
+        c->words <= 64 && p->cutoff_u32 / p->factor <= 31) {
+        p->band = 1;
+        p->band_k = p->cutoff_u32 / p->factor;
+    }
+    if (c->words > (size_t)kMaxWords && !p->band) {
         // beyond 512 symbols: the multi-sweep kernel (8 words per sweep, carries parked in an HBM scratch strip)
         if (c->words > 0x00FFFFFFu) {
             set_error("query too long");

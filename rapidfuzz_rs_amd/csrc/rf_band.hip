@@ -1,0 +1,129 @@
+// rf_band.hip -- Levenshtein with a long query and a small distance cutoff: one 64-bit word sliding down the diagonal.
+//
+// The reference's hyrroe2003_small_band_with_pm (src/distance/levenshtein.rs:509-617; Hyyro's band variant, after Ukkonen):
+// if the distance is to be at most k, only the cells within k of the main diagonal matter, and 2k + 1 <= 64 of them per
+// column fit ONE machine word whatever the query length.  The word covers pattern rows [j + k - 63, j + k] at column j and
+// moves down one row per column: where the full-matrix recurrence shifts the horizontal deltas up by one (HP << 1,
+// HN << 1), the band recurrence shifts the diagonal term down instead (D0 >> 1).  The multi-word scan kernel spends
+// ceil(len1 / 64) words of VALU per column on such a query (4 for BASELINE.json configs[2], 8 at 512 symbols); this one
+// spends one, plus fetching the pattern bits at a bit offset:
+//   * the PM table is staged in LDS as 32-bit words with 64 zero bits below row 0 and above the last row of every symbol's
+//     bit-vector, row stride odd (bank spread), so the 64 pattern bits at ANY window position v = start_pos + 64 are three
+//     consecutive dwords d0 d1 d2 at index v / 32 funnel-shifted by v % 32: two v_alignbit_b32 with a scalar shift amount
+//     (the window position depends on the column only: wavefront-uniform);
+//   * the running score follows the reference: down the diagonal while the window's top row is above the last pattern row
+//     (score += the diagonal delta, bit 63 of D0 clear), then along the last row (+HP, -HN at a bit that moves down).
+// Exact whenever the distance is <= k; any value > k otherwise, which the finishing compare turns into None -- the same
+// contract the reference relies on (levenshtein.rs:1059-1066).  A wavefront abandons a tile as soon as every lane is past
+// break_score (levenshtein.rs:519-523, :568-570), and candidates whose length differs from the query's by more than k are
+// None without being read.
+#include "rf_device.hpp"
+
+namespace rf {
+
+constexpr uint32_t band_row_dwords(uint32_t words) { return 2 * words + 5; }  // 2 zero dwords + 2W + 2 zero dwords + 1 (odd stride)
+
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void band_kernel(const ScanParams p)
+{
+    extern __shared__ uint32_t lds_band[];  // 256 rows x band_row_dwords(words)
+    const uint32_t W = p.words, stride = band_row_dwords(W);
+    for (uint32_t i = threadIdx.x; i < 256 * stride; i += kWave * kWavesPerBlock) {
+        const uint32_t c = i / stride, d = i % stride;
+        uint32_t v = 0;
+        if (d >= 2 && d < 2 + 2 * W) {
+            const uint64_t word = p.pm[(size_t)c * W + (d - 2) / 2];
+            v = (d & 1) ? (uint32_t)(word >> 32) : (uint32_t)word;  // d - 2 even -> low half
+        }
+        lds_band[(uint32_t)p.sigma[c] * stride + d] = v;  // the corpus stores renamed symbols
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t len1 = p.len1, k = p.band_k;
+    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += gridDim.x * kWavesPerBlock) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2 = tv.len;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        const uint32_t diff = len1 > len2 ? len1 - len2 : len2 - len1;
+        if (diff > k) {  // levenshtein.rs:1389-1391: the distance is at least the length difference
+            if (valid) emit_none(p, idx);
+            continue;
+        }
+        // levenshtein.rs:515-531
+        uint64_t vp = ~0ull << (63 - k), vn = 0;
+        const uint32_t break_score = 2 * k + len2 - len1;  // (diff <= k: never negative)
+        const uint32_t first = min(len1 - k, len2);        // columns walked down the diagonal (len1 > 64 > k)
+        uint32_t diag_hits = 0;                            // set diagonal deltas seen in phase 1: score = k + columns - hits
+        uint32_t score = k;                                // phase 2 continues from the phase-1 total
+        uint32_t v = k + 1;                                // window position + 64: bit v - 64 + b of the pattern is window bit b
+        bool dead = false;
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        uint4 cur = nch ? load_chunk(tv.src + lane) : make_uint4(0, 0, 0, 0);
+        for (uint32_t c = 0; c < nch && !dead; ++c) {
+            uint4 nxt = cur;
+            if (c + 1 < nch) nxt = load_chunk(tv.src + (size_t)(c + 1) * kWave + lane);
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            uint4 data = cur;
+            for (uint32_t b = 0; b < cols; ++b, ++v) {
+                const uint32_t j = c * kChunk + b;
+                const uint32_t* row = lds_band + (data.x & 0xFFu) * stride + (v >> 5);
+                const uint32_t d0w = row[0], d1w = row[1], d2w = row[2];
+                const uint32_t sh = v & 31;
+                const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2w, d1w, sh) << 32) | __builtin_amdgcn_alignbit(d1w, d0w, sh);
+                const uint64_t sum = (x & vp) + vp;
+                const uint64_t e = lut3<T_XOR_OR>(sum, vp, x);
+                const uint64_t d0 = e | vn;                     // levenshtein.rs:556 / :593
+                const uint64_t hp = lut3<T_OR_NOR>(vn, e, vp);  // vn | ~(d0 | vp)
+                const uint64_t hn = e & vp;                     // d0 & vp (vp & vn == 0)
+                if (j < first) {                                // :560-562 (wavefront-uniform)
+                    diag_hits += (uint32_t)(d0 >> 63);
+                    score = k + (j + 1) - diag_hits;
+                } else {                                        // :597-600: the last row, at a bit that moves down
+                    const uint64_t hmask = 1ull << (62 - (j - first));
+                    score += (hp & hmask) != 0;
+                    score -= (hn & hmask) != 0;
+                }
+                const uint64_t d0s = d0 >> 1;
+                vp = lut3<T_OR_NOR>(hn, d0s, hp);               // :571 / :611
+                vn = d0s & hp;
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
+                if ((b & 7) == 7 || b + 1 == cols)  // :568-570 / :607-609, checked per wavefront every 8 columns
+                    if (__ballot(valid && score <= break_score) == 0) {
+                        dead = true;
+                        break;
+                    }
+            }
+            cur = nxt;
+        }
+        if (valid) {
+            if (dead || score > k)
+                emit_none(p, idx);
+            else
+                emit_usize(p, score, len2, idx);
+        }
+    }
+}
+
+hipError_t launch_band(const ScanParams& p, hipStream_t stream)
+{
+    if (p.tile_end <= p.tile_begin) return hipSuccess;
+    const size_t lds = (size_t)256 * band_row_dwords(p.words) * sizeof(uint32_t);
+    const dim3 g(std::max(1, scan_grid(p.tile_end - p.tile_begin))), b(kWave * kWavesPerBlock);
+    auto kern = p.tiles ? band_kernel<false> : band_kernel<true>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, g, b, lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace rf

@@ -105,6 +105,8 @@ struct ScanParams {
     uint32_t* long_scratch;   // [grid * 4][long_chunks_max][64]
     // value-preserving early-out under a distance cutoff (levenshtein, u32 distance output / top-k)
     uint32_t early;
+    // band_kernel (rf_band.hip): long query, raw distance cutoff band_k with 2 * band_k + 1 <= 64; band = 1 selects it
+    uint32_t band, band_k;
     // top-k mode (topk_k != 0): no per-candidate output, one k-entry key list per workgroup
     uint32_t topk_k;       // <= 64
     uint32_t topk_desc;    // 1: larger score is better (similarity)
@@ -120,6 +122,7 @@ struct ScanParams {
 
 // kernel launchers (rf_scan.hip, rf_long.hip, rf_jaro.hip, rf_pack.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
+hipError_t launch_band(const ScanParams& p, hipStream_t stream);  // rf_band.hip: exact tiles [tile_begin, tile_end)
 hipError_t launch_scan_mixed(RawKind raw, const ScanParams& p, hipStream_t stream);  // p.mixed / tile_begin / tile_end: the mixed section
 hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid);
 hipError_t launch_wf(const ScanParams& p, hipStream_t stream);

@@ -466,8 +466,8 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     // A corpus with a mixed section (leftovers of every length pooled into tiles with per-lane lengths) is scanned in two
     // launches by the register-resident Levenshtein / LCS / OSA kernels: the exact tiles as always, the mixed tiles by
     // scan_kernel_mixed.  Top-k, multi-query and the other kernel families walk the one-length views instead (p stays as is).
-    if (p.mixed && p.mixed_end > p.mixed_begin && !p.topk_k && !p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA) &&
-        p.tile_step == 1) {
+    if (p.mixed && p.mixed_end > p.mixed_begin && !p.topk_k && !p.long_words_pad && p.words <= (uint32_t)kMaxWords &&
+        (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA) && p.tile_step == 1) {
         ScanParams q = p;
         q.mixed = nullptr;
         q.tile_end = std::min(p.tile_end, p.n_exact);
@@ -489,6 +489,8 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
         const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, (size_t)p.n * (p.out_f64 ? 2 : 1), stream);
         if (e != hipSuccess) return e;
     }
+    // long query, small distance cutoff: one word down the diagonal (rf_band.hip); exact tiles and one-length views alike
+    if (p.band && raw == RAW_LEV && !p.topk_k) return launch_band(p, stream);
     if (p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS)) return launch_long(raw, p, stream, grid);
     switch (raw) {
     case RAW_LEV: return p.len1 <= 32 ? launch_state<Lev32State>(p, stream, grid) : launch_words<LevState>(p, stream, grid);

@@ -1554,3 +1554,39 @@ def test_distinct_lengths_scan_within_2x_of_a_dense_corpus():
     sub = np.concatenate([data[int(offsets[i]) : int(offsets[i + 1])] for i in sample])
     exp = o.levenshtein.BatchComparator(q).many(N.OP_DISTANCE, sub, sub_off)
     assert (got[sample] == exp.astype(np.uint32)).all()
+
+
+@pytest.mark.parametrize("qlen", [65, 100, 128, 129, 256, 300, 512, 700, 1000])
+def test_band_kernel_long_query_small_cutoff(qlen):
+    """The diagonal band kernel (rf_band.hip = the reference's hyrroe2003_small_band_with_pm, levenshtein.rs:509-617): every
+    cutoff k with 2k + 1 <= 64 on queries beyond 64 symbols, candidates within and just outside the band, ragged lengths
+    around the query's, weights (f,f,f) -- against the oracle, which takes the same reference path."""
+    rng = np.random.default_rng(qlen)
+    alpha = ABCD if qlen % 2 else synth.ALNUM
+    q = alpha[rng.integers(0, len(alpha), size=qlen)].tobytes()
+    cands = []
+    for i in range(1500):
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 45))):  # 0..44 random edits: distances on both sides of every k <= 31
+            r = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, len(b) + 1))
+            if r == 0 and len(b):
+                del b[min(pos, len(b) - 1)]
+            elif r == 1:
+                b.insert(pos, int(alpha[int(rng.integers(0, len(alpha)))]))
+            elif len(b):
+                b[min(pos, len(b) - 1)] = int(alpha[int(rng.integers(0, len(alpha)))])
+        cands.append(bytes(b))
+    cands += [alpha[rng.integers(0, len(alpha), size=int(n))].tobytes() for n in rng.integers(max(0, qlen - 40), qlen + 40, size=300)]
+    from rapidfuzz_rs_amd.corpus import ragged as _ragged
+
+    data, offsets = _ragged(cands)
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    bc, obc = GPU["levenshtein"].BatchComparator(q), o.levenshtein.BatchComparator(q)
+    for k in (0, 1, 4, 5, 8, 17, 30, 31, 32):  # 32: just outside the band kernel's range (the multi-word kernel again)
+        got = bc.distance_many(corpus, score_cutoff=k)
+        exp = obc.many(N.OP_DISTANCE, data, offsets, nthreads=8, score_cutoff=k)
+        assert (got == _expect_u32(exp)).all(), (qlen, k)
+    got = bc.distance_many(corpus, score_cutoff=40, weights=(2, 2, 2))  # raw cutoff 20 after the common factor
+    exp = obc.many(N.OP_DISTANCE, data, offsets, nthreads=8, score_cutoff=40, weights=(2, 2, 2))
+    assert (got == _expect_u32(exp)).all()
