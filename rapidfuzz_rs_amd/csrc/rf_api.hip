@@ -1174,12 +1174,19 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
             const uint64_t row_bytes = ((uint64_t)p->len1 + 1) * kWave * sizeof(uint32_t);
             const uint64_t lds_budget = 150u << 10;  // of the 160 KiB a gfx950 workgroup may hold
             const uint64_t worst = ((uint64_t)p->len1 + corpus->max_len) * std::max(std::max(ins, del), sub);
-            if (row_bytes + p->len1 + 8 > lds_budget || worst >= (1ull << 31)) {
-                set_error("levenshtein with a general weight table: the query is too long for the LDS-resident Wagner-Fischer "
-                          "kernel (about 590 symbols), or distances would not fit 31 bits");
+            if (worst >= (1ull << 31) || p->len1 > 150000) {
+                set_error("levenshtein with a general weight table: distances would not fit 31 bits (or the query is beyond 150 000 symbols)");
                 return RF_ERR_UNSUPPORTED;
             }
-            p->wf_waves = (uint32_t)std::min<uint64_t>(kWavesPerBlock, (lds_budget - p->len1 - 8) / row_bytes);
+            if (row_bytes + p->len1 + 8 > lds_budget) {
+                // the row does not fit LDS (queries beyond ~590 symbols): one global scratch strip per wavefront instead
+                p->wf_global = 1;
+                p->wf_waves = kWavesPerBlock;
+                const uint64_t per_block = row_bytes * kWavesPerBlock, budget = 1ull << 30;
+                p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / per_block, (uint64_t)scan_grid(corpus->n_tiles)));
+            } else {
+                p->wf_waves = (uint32_t)std::min<uint64_t>(kWavesPerBlock, (lds_budget - p->len1 - 8) / row_bytes);
+            }
             for (size_t i = 0; i < std::min<size_t>(64, c->s1.size()); ++i)  // the register-resident kernel compares against these
                 p->wf_query[i / 4] |= (uint32_t)corpus->sigma[c->s1[i]] << (8 * (i % 4));
         }
@@ -1187,11 +1194,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
     case RF_OSA:  // osa.rs:431-461; maximum = max(len1, len2) = levenshtein's at unit weights
         *raw = RAW_OSA;
-        p->finish = FIN_LEV;
-        if (c->words > (size_t)kMaxWords) {
-            set_error("osa: queries longer than 512 symbols have no device kernel");
-            return RF_ERR_UNSUPPORTED;
-        }
+        p->finish = FIN_LEV;  // (beyond 512 symbols: long_kernel, with the transposition bit carried between word groups)
         break;
     case RF_INDEL:
         *raw = RAW_LCS;
@@ -1325,7 +1328,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         }
         p->long_words_pad = (uint32_t)pm_stride(c);
         p->long_chunks_max = (corpus->max_len + kChunk - 1) / kChunk;
-        const uint64_t strip_bytes = std::max<uint64_t>(1, (uint64_t)p->long_chunks_max * kWave * sizeof(uint32_t));
+        const uint64_t strip_bytes = std::max<uint64_t>(1, (uint64_t)p->long_chunks_max * kWave * sizeof(uint32_t)) * (*raw == RAW_OSA ? 2 : 1);
         const uint64_t budget = 256ull << 20;
         const uint64_t waves = std::max<uint64_t>(kWavesPerBlock, budget / strip_bytes);
         p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves / kWavesPerBlock, (uint64_t)scan_grid(corpus->n_tiles)));
@@ -1434,8 +1437,9 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     void* d_out = out;
     if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
     p.out = d_out;
-    if (p.long_words_pad) {
-        const size_t scratch = (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t);
+    if (p.long_words_pad || p.wf_global) {
+        const size_t scratch = p.wf_global ? (size_t)p.long_grid * kWavesPerBlock * ((size_t)p.len1 + 1) * kWave * sizeof(uint32_t)
+                                           : (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t) * (raw == RAW_OSA ? 2 : 1);
         const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
         if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
         RF_HIP(ea);
@@ -1575,8 +1579,9 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
         if (group.size() == 1) {
             status = comparator_device_pm(cs[i], corpus->device, &p.pm);
             if (status != RF_OK) break;
-            if (p.long_words_pad) {
-                const size_t scratch = (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t);
+            if (p.long_words_pad || p.wf_global) {
+                const size_t scratch = p.wf_global ? (size_t)p.long_grid * kWavesPerBlock * ((size_t)p.len1 + 1) * kWave * sizeof(uint32_t)
+                                                   : (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t) * (raws[i] == RAW_OSA ? 2 : 1);
                 e = hipMallocAsync((void**)&p.long_scratch, scratch, st);
                 if (e != hipSuccess) break;
             }

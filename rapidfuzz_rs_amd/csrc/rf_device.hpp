@@ -261,6 +261,44 @@ struct OsaState {
             pm_old[w] = pm_j;
         }
     }
+    // one 512-row group of a longer pattern (long_kernel): the horizontal deltas and the transposition candidate bit enter
+    // word 0 from the group below and leave word W-1 for the group above (osa.rs:156-226 across block boundaries)
+    __device__ __forceinline__ void step_carry(const uint64_t (&pm_row)[W], uint32_t& hp_c, uint32_t& hn_c, uint32_t& tr_c)
+    {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t pm_j = pm_row[w];
+            const uint64_t t = ~d0[w] & pm_j;
+            const uint64_t tr = shl1_var(t, tr_c) & pm_old[w];  // osa.rs:180
+            tr_c = (uint32_t)(t >> 63);
+            const uint64_t x = pm_j | hn_c;                       // osa.rs:182
+            const uint64_t p = vp[w], n = vn[w];
+            const uint64_t sum = (x & p) + p;
+            const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
+            const uint64_t d = e | n | tr;                        // osa.rs:183
+            const uint64_t hn = d & p;
+            const uint64_t hp = lut3<T_OR_NOR>(n, d, p);
+            const uint64_t hps = shl1_var(hp, hp_c);
+            const uint64_t hns = shl1_var(hn, hn_c);
+            hp_c = (uint32_t)(hp >> 63);
+            hn_c = (uint32_t)(hn >> 63);
+            vn[w] = hps & d;
+            vp[w] = lut3<T_OR_NOR>(hns, hps, d);
+            d0[w] = d;
+            pm_old[w] = pm_j;
+        }
+    }
+    __device__ __forceinline__ int32_t delta_sum(uint32_t len1, uint32_t word0) const
+    {
+        int32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int32_t bits = (int32_t)len1 - 64 * (int32_t)(word0 + w);
+            const uint64_t valid = bits >= 64 ? ~0ull : (bits <= 0 ? 0ull : ((1ull << bits) - 1));
+            d += __popcll(vp[w] & valid) - __popcll(vn[w] & valid);
+        }
+        return d;
+    }
     // The vertical-delta identity and both bounds of LevState::bound hold for the OSA matrix as well: steps are unit,
     // and values never decrease along a diagonal (drop the last symbol of both strings from an optimal restricted
     // alignment: a pair aligned to each other disappears, a transposed pair (a_i a_i+1)/(b_j b_j+1) becomes one

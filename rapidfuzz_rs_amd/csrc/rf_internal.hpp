@@ -84,6 +84,7 @@ struct ScanParams {
     const double* jaro_tab;         // jaro kernels: device table [65][33] of (c - h) / c (rf_api.hip jaro_device_table); nullptr = compute
     double jaro_need;               // jaro kernels: the similarity a candidate must reach to pass the cutoff; < 0 = no early-out
     uint32_t wf_query[16];          // wf_reg_kernel: the (renamed) query bytes, 4 per word, for queries of <= 64 symbols
+    uint32_t wf_global;             // wf_kernel: the DP row lives in long_scratch (global) instead of LDS: queries beyond ~590 symbols
     uint32_t wf_waves;              // wavefronts per workgroup of wf_kernel (LDS rows per wavefront: (len1 + 1) * 256 B)
     uint32_t tile_step;             // >= 1: visit every tile_step-th tile of the range (the top-k bound sample)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32

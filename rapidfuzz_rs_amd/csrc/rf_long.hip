@@ -40,7 +40,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void wf_kernel(const ScanPar
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t waves = blockDim.x / kWave;
-    uint32_t* row = lds_wf + qwords + (size_t)wave * (len1 + 1) * kWave + lane;  // row[i * kWave] = cache[i] of this lane
+    // row[i * kWave] = cache[i] of this lane: in LDS, or -- for queries whose row does not fit (beyond ~590 symbols) -- in a
+    // global scratch strip per wavefront (same [i][lane] layout, coalesced, L2-resident): slower, but no length limit
+    uint32_t* row = p.wf_global ? p.long_scratch + ((size_t)blockIdx.x * waves + wave) * (len1 + 1) * kWave + lane
+                                : lds_wf + qwords + (size_t)wave * (len1 + 1) * kWave + lane;
     const uint32_t ins = p.w_ins, del = p.w_del, sub = p.w_sub;
 
     for (uint32_t t = blockIdx.x * waves + wave; t < p.n_tiles; t += gridDim.x * waves) {
@@ -158,17 +161,22 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void wf_reg_kernel(const Sca
 // long pattern does not fit LDS; it is L2-resident).  Throughput path for completeness, not for the roofline.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kLongGroup = 8;
+enum LongKind : int { LONG_LEV = 0, LONG_LCS = 1, LONG_OSA = 2 };
 
-template <bool kLcs, bool kUniform>
+template <int kKind, bool kUniform>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanParams p)
 {
+    constexpr bool kLcs = kKind == LONG_LCS, kOsa = kKind == LONG_OSA;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;  // global wavefront id: owns one scratch strip
     const uint32_t stride = gridDim.x * kWavesPerBlock;
     const uint32_t words_pad = p.long_words_pad;
     const uint32_t groups = words_pad / kLongGroup;
-    uint32_t* strip = p.long_scratch + (size_t)gw * p.long_chunks_max * kWave;
+    // one strip of carries per wavefront (OSA: two, the second for the transposition bit: osa.rs:180 across word groups)
+    const size_t strip_words = (size_t)p.long_chunks_max * kWave;
+    uint32_t* strip = p.long_scratch + (size_t)gw * strip_words * (kOsa ? 2 : 1);
+    uint32_t* strip_tr = strip + strip_words;
     __shared__ uint8_t lds_unrename[256];  // stored symbol -> original symbol (the PM table stays in global memory)
     lds_unrename[p.sigma[threadIdx.x & 255]] = (uint8_t)(threadIdx.x & 255);
     __syncthreads();
@@ -185,16 +193,20 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanP
         for (uint32_t g = 0; g < groups; ++g) {
             LevState<kLongGroup> lev;
             LcsState<kLongGroup> lcs;
+            OsaState<kLongGroup> osa;
             if (kLcs)
                 lcs.init();
+            else if (kOsa)
+                osa.init();
             else
                 lev.init();
             for (uint32_t c = 0; c < nch; ++c) {
                 uint4 data = tv.src[(size_t)c * kWave + lane];
                 // carries entering word 0 of this group for the 16 columns of the chunk:
-                // bits 0..15 = hp (or the LCS adder carry), bits 16..31 = hn
+                // bits 0..15 = hp (or the LCS adder carry), bits 16..31 = hn; OSA: the transposition bits in a strip of their own
                 uint32_t cin = g == 0 ? (kLcs ? 0u : 0x0000FFFFu) : strip[(size_t)c * kWave + lane];
-                uint32_t cout = 0;
+                uint32_t tin = (kOsa && g != 0) ? strip_tr[(size_t)c * kWave + lane] : 0u;
+                uint32_t cout = 0, tout = 0;
                 const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
                 for (uint32_t j = 0; j < cols; ++j) {
                     const uint32_t ch = lds_unrename[data.x & 0xFFu];
@@ -206,6 +218,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanP
                         uint32_t carry = (cin >> j) & 1u;
                         lcs.step_carry(x, carry);
                         cout |= carry << j;
+                    } else if (kOsa) {
+                        uint32_t hp_c = (cin >> j) & 1u, hn_c = (cin >> (16 + j)) & 1u, tr_c = (tin >> j) & 1u;
+                        osa.step_carry(x, hp_c, hn_c, tr_c);
+                        cout |= (hp_c << j) | (hn_c << (16 + j));
+                        tout |= tr_c << j;
                     } else {
                         uint32_t hp_c = (cin >> j) & 1u, hn_c = (cin >> (16 + j)) & 1u;
                         lev.step_carry(x, hp_c, hn_c);
@@ -216,9 +233,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanP
                     data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
                     data.w >>= 8;
                 }
-                if (g + 1 < groups) strip[(size_t)c * kWave + lane] = cout;
+                if (g + 1 < groups) {
+                    strip[(size_t)c * kWave + lane] = cout;
+                    if (kOsa) strip_tr[(size_t)c * kWave + lane] = tout;
+                }
             }
-            acc += kLcs ? (int32_t)lcs.result(0, 0) : lev.delta_sum(p.len1, g * kLongGroup);
+            acc += kLcs ? (int32_t)lcs.result(0, 0) : (kOsa ? osa.delta_sum(p.len1, g * kLongGroup) : lev.delta_sum(p.len1, g * kLongGroup));
         }
         const uint32_t raw = kLcs ? (uint32_t)acc : (uint32_t)((int32_t)len2 + acc);
         const bool valid = kUniform ? slot < p.n : idx != kPad;
@@ -226,21 +246,21 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void long_kernel(const ScanP
     }
 }
 
-hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid)
+template <int kKind>
+static hipError_t launch_long_kind(const ScanParams& p, hipStream_t stream, int grid)
 {
     const dim3 g(grid), b(kWave * kWavesPerBlock);
-    if (raw == RAW_LCS) {
-        if (p.tiles)
-            hipLaunchKernelGGL((long_kernel<true, false>), g, b, 0, stream, p);
-        else
-            hipLaunchKernelGGL((long_kernel<true, true>), g, b, 0, stream, p);
-    } else {
-        if (p.tiles)
-            hipLaunchKernelGGL((long_kernel<false, false>), g, b, 0, stream, p);
-        else
-            hipLaunchKernelGGL((long_kernel<false, true>), g, b, 0, stream, p);
-    }
+    if (p.tiles)
+        hipLaunchKernelGGL((long_kernel<kKind, false>), g, b, 0, stream, p);
+    else
+        hipLaunchKernelGGL((long_kernel<kKind, true>), g, b, 0, stream, p);
     return hipGetLastError();
+}
+hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid)
+{
+    if (raw == RAW_LCS) return launch_long_kind<LONG_LCS>(p, stream, grid);
+    if (raw == RAW_OSA) return launch_long_kind<LONG_OSA>(p, stream, grid);
+    return launch_long_kind<LONG_LEV>(p, stream, grid);
 }
 
 template <int kMax>
@@ -260,8 +280,8 @@ hipError_t launch_wf(const ScanParams& p, hipStream_t stream)
     if (use_reg && p.len1 <= 16) return launch_wf_reg<16>(p, stream);
     if (use_reg && p.len1 <= 32) return launch_wf_reg<32>(p, stream);
     if (use_reg && p.len1 <= 64) return launch_wf_reg<64>(p, stream);
-    const size_t lds = ((size_t)(p.len1 + 3) / 4 + 1) * 4 + (size_t)p.wf_waves * (p.len1 + 1) * kWave * 4;
-    const dim3 g(std::max(1, scan_grid(p.n_tiles))), b(kWave * p.wf_waves);
+    const size_t lds = ((size_t)(p.len1 + 3) / 4 + 1) * 4 + (p.wf_global ? 0 : (size_t)p.wf_waves * (p.len1 + 1) * kWave * 4);
+    const dim3 g(p.wf_global ? std::max(1u, p.long_grid) : (uint32_t)std::max(1, scan_grid(p.n_tiles))), b(kWave * p.wf_waves);
     auto k = p.tiles ? wf_kernel<false> : wf_kernel<true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -491,7 +491,7 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     }
     // long query, small distance cutoff: one word down the diagonal (rf_band.hip); exact tiles and one-length views alike
     if (p.band && raw == RAW_LEV && !p.topk_k) return launch_band(p, stream);
-    if (p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS)) return launch_long(raw, p, stream, grid);
+    if (p.long_words_pad && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA)) return launch_long(raw, p, stream, grid);
     switch (raw) {
     case RAW_LEV: return p.len1 <= 32 ? launch_state<Lev32State>(p, stream, grid) : launch_words<LevState>(p, stream, grid);
     case RAW_LCS: return p.len1 <= 32 ? launch_state<Lcs32State>(p, stream, grid) : launch_words<LcsState>(p, stream, grid);

@@ -148,7 +148,7 @@ def test_topk_long_query_takes_the_selection_path():
 
 
 # ---------------------------------------------------------------- OSA (widening row f3)
-@pytest.mark.parametrize("qlen", [0, 1, 2, 17, 63, 64, 65, 128, 200, 512])
+@pytest.mark.parametrize("qlen", [0, 1, 2, 17, 63, 64, 65, 128, 200, 512, 513, 700, 1100])  # beyond 512: long_kernel, transposition bit carried between groups
 def test_osa_ragged(qlen):
     rng = np.random.default_rng(qlen + 900)
     alpha = ABCD if qlen % 2 else synth.ALNUM
@@ -186,8 +186,9 @@ def test_osa_known_answers_and_topk_on_gpu():
     cands = [b"AC", b"CA", b"ABC", b"", b"CAA", b"ACA"]
     s, i = bc("CA").topk(rf.Corpus.from_list(cands), 3)
     assert list(zip(s.tolist(), i.tolist())) == sorted((o.osa.distance("CA", c), j) for j, c in enumerate(cands))[:3]
-    with pytest.raises(rf.RfError):
-        bc(b"a" * 600).distance_many(rf.Corpus.from_list([b"abc"]))
+    # beyond 512 symbols (round 1 refused): long_kernel with the transposition bit carried between word groups
+    long_q = b"ab" * 300
+    assert bc(long_q).distance_many(rf.Corpus.from_list([b"abc", long_q, b"ba" * 300])).tolist() == [o.osa.distance(long_q, b"abc"), 0, o.osa.distance(long_q, b"ba" * 300)]
 
 
 # ---------------------------------------------------------------- weights (levenshtein.rs:1285-1331)
@@ -223,9 +224,11 @@ def test_levenshtein_generalized_weights_limits_and_uniform_corpus():
     got = rf.distance.levenshtein.BatchComparator(q).distance_many(corpus, weights=(1, 2, 3))
     exp = o.levenshtein.BatchComparator(q).many(N.OP_DISTANCE, data, offsets, nthreads=8, weights=(1, 2, 3))
     assert (got == _expect_u32(exp)).all()
-    with pytest.raises(rf.RfError) as e:
-        rf.distance.levenshtein.BatchComparator(synth.query(700, 9)).distance_many(corpus, weights=(1, 2, 3))
-    assert e.value.status == N.RF_ERR_UNSUPPORTED
+    # beyond ~590 symbols the DP row no longer fits LDS: it moves to a global scratch strip per wavefront (round 1 refused)
+    q700 = synth.query(700, 9)
+    got = rf.distance.levenshtein.BatchComparator(q700).distance_many(corpus, weights=(1, 2, 3))
+    exp = o.levenshtein.BatchComparator(q700).many(N.OP_DISTANCE, data, offsets, nthreads=8, weights=(1, 2, 3))
+    assert (got == _expect_u32(exp)).all()
     # top-k under a general weight table: no in-scan lists for it, so the selection path (round 1 refused)
     q20 = synth.query(20, 9)
     s4, i4 = rf.distance.levenshtein.BatchComparator(q20).topk(corpus, 4, weights=(1, 2, 3))
@@ -1157,8 +1160,6 @@ def test_randomized_differential(seed):
         data, offsets = rf.ragged(cands)
         for _c in range(5):
             metric = str(rng.choice(["levenshtein", "osa", "indel", "lcs_seq", "jaro", "jaro_winkler"]))
-            if metric == "osa" and qlen > 512:
-                continue
             op = str(rng.choice(["distance", "similarity", "normalized_distance", "normalized_similarity"]))
             kw = {}
             is_f = metric in ("jaro", "jaro_winkler") or op.startswith("normalized")
