@@ -1248,11 +1248,15 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
                 in_block = true;
                 p->jaro_split = corpus->length_first_tile[i];
             }
-            if (in_block && needs_flags && (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords)) {
-                set_error("jaro / jaro_winkler: strings longer than 512 symbols after the window truncation have no "
-                          "device kernel");
-                return RF_ERR_UNSUPPORTED;
-            }
+            if (in_block && needs_flags && (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords))
+                p->jaro_long = 1;  // beyond 512 symbols: the flag words move from registers to global scratch strips
+        }
+        if (p->jaro_long) {
+            // per wavefront: P words (len1 / 64 + 1) and T words (max candidate length / 64) for 64 lanes
+            p->long_chunks_max = (corpus->max_len + 63) / 64 + 1;
+            const uint64_t strip_bytes = ((uint64_t)(p->len1 + 63) / 64 + 1 + p->long_chunks_max) * kWave * sizeof(uint64_t);
+            const uint64_t budget = 1ull << 30;
+            p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / (strip_bytes * kWavesPerBlock), (uint64_t)scan_grid(corpus->n_tiles)));
         }
         if (p->jaro_need >= 0.0) {
             // Length window, the reference's length_filter (jaro.rs:122-131) hoisted to the host: with m = min(len1, L)
@@ -1404,6 +1408,17 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     return RF_OK;
 }
 
+// bytes of per-launch scratch the planned kernels need (0 = none): carry strips of long_kernel, the global DP rows of
+// wf_kernel, the flag strips of jaro_long_kernel -- all handed to the kernels through ScanParams::long_scratch
+static size_t launch_scratch_bytes(const ScanParams& p, RawKind raw)
+{
+    const size_t waves = (size_t)p.long_grid * kWavesPerBlock;
+    if (p.jaro_long) return waves * (((size_t)p.len1 + 63) / 64 + 1 + p.long_chunks_max) * kWave * sizeof(uint64_t);
+    if (p.wf_global) return waves * ((size_t)p.len1 + 1) * kWave * sizeof(uint32_t);
+    if (p.long_words_pad) return waves * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t) * (raw == RAW_OSA ? 2 : 1);
+    return 0;
+}
+
 static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out,
                           rf_mem out_mem, void* stream, bool f64_out)
 {
@@ -1437,9 +1452,7 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     void* d_out = out;
     if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
     p.out = d_out;
-    if (p.long_words_pad || p.wf_global) {
-        const size_t scratch = p.wf_global ? (size_t)p.long_grid * kWavesPerBlock * ((size_t)p.len1 + 1) * kWave * sizeof(uint32_t)
-                                           : (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t) * (raw == RAW_OSA ? 2 : 1);
+    if (const size_t scratch = launch_scratch_bytes(p, raw)) {
         const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
         if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
         RF_HIP(ea);
@@ -1579,9 +1592,7 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
         if (group.size() == 1) {
             status = comparator_device_pm(cs[i], corpus->device, &p.pm);
             if (status != RF_OK) break;
-            if (p.long_words_pad || p.wf_global) {
-                const size_t scratch = p.wf_global ? (size_t)p.long_grid * kWavesPerBlock * ((size_t)p.len1 + 1) * kWave * sizeof(uint32_t)
-                                                   : (size_t)p.long_grid * kWavesPerBlock * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t) * (raws[i] == RAW_OSA ? 2 : 1);
+            if (const size_t scratch = launch_scratch_bytes(p, raws[i])) {
                 e = hipMallocAsync((void**)&p.long_scratch, scratch, st);
                 if (e != hipSuccess) break;
             }

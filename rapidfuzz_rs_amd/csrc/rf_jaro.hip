@@ -564,6 +564,142 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Jaro / Jaro-Winkler beyond 512 symbols (after the window truncation): the same two passes (jaro.rs:192-337, :370-420) with
+// the flag words in a global scratch strip per wavefront instead of registers -- P_flag [word][lane], then T_flag [word][lane],
+// coalesced across the lanes -- and PM words fetched from the L2-resident global table.  Only the words inside the sliding
+// search window are touched per text symbol (the window bounds are wavefront-uniform).  A completeness path: no length
+// limit, no attempt at the roofline.
+// ---------------------------------------------------------------------------------------------------
+template <bool kUniform>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_long_kernel(const ScanParams p)
+{
+    const uint32_t W = p.words;  // PM row stride
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t q4 = p.query_head;
+    __shared__ uint8_t lds_unrename[256];  // stored symbol -> original symbol (the PM table is indexed by original symbols)
+    lds_unrename[p.sigma[threadIdx.x & 255]] = (uint8_t)(threadIdx.x & 255);
+    __syncthreads();
+    const uint32_t wp_max = (p.len1 + 63) / 64 + 1, wt_max = p.long_chunks_max;  // words of P / T per lane (T: ceil(max len2 / 64))
+    uint64_t* P = reinterpret_cast<uint64_t*>(p.long_scratch) + (size_t)gw * (wp_max + wt_max) * kWave + lane;  // P[w * kWave]
+    uint64_t* T = P + (size_t)wp_max * kWave;
+
+    for (uint32_t t = p.tile_begin + gw; t < p.tile_end; t += stride) {
+        const TileView tv = load_tile<kUniform>(p, t);
+        const uint32_t len2_orig = tv.len, len1_orig = p.len1;
+        const uint32_t slot = tv.slot0 + lane;
+        uint32_t idx = slot;
+        if (!kUniform) idx = p.orig[slot];
+        uint32_t len1 = len1_orig, len2 = len2_orig, bound = 0;  // jaro.rs:550-565
+        if (len2 > len1) {
+            bound = len2 / 2 - 1;
+            if (len2 > len1 + bound) len2 = len1 + bound;
+        } else if (len1 >= 2) {
+            bound = len1 / 2 - 1;
+            if (len1 > len2 + bound) len1 = len2 + bound;
+        }
+        const uint4 head = len2_orig ? tv.src[lane] : make_uint4(0, 0, 0, 0);
+        JaroRaw r;
+        r.eq11 = (head.x & 0xFFu) == (q4 & 0xFFu);
+        {
+            const uint32_t lim = min(4u, min(len1_orig, len2_orig));
+            const uint32_t diff = head.x ^ q4;
+            const uint32_t first_diff = diff ? (uint32_t)(__ffs(diff) - 1) / 8 : 4u;
+            r.prefix = min(first_diff, lim);
+        }
+        const uint32_t wp = (len1 + 63) / 64, wt = (len2 + 63) / 64;
+        for (uint32_t w = 0; w < wp; ++w) P[(size_t)w * kWave] = 0;
+        for (uint32_t w = 0; w < wt; ++w) T[(size_t)w * kWave] = 0;
+
+        // ---- pass 1 (jaro.rs:286-337); the window state is wavefront-uniform
+        const uint32_t start_range = min(bound + 1, len1);
+        uint32_t win_words = 1 + start_range / 64, empty_words = 0;
+        uint64_t last_mask = (1ull << (start_range % 64)) - 1, first_mask = ~0ull;
+        const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+        uint64_t tcur = 0;
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 data = tv.src[(size_t)c * kWave + lane];
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            for (uint32_t b = 0; b < cols; ++b) {
+                const uint32_t j = c * kChunk + b;
+                const uint64_t* row = p.pm + (size_t)lds_unrename[data.x & 0xFFu] * W;
+                const uint32_t last_word = empty_words + win_words - 1;
+                bool found = false;
+                for (uint32_t w = empty_words; w <= last_word && w < wp; ++w) {  // flag_similar_characters_step, jaro.rs:192-284
+                    uint64_t mask = ~0ull;
+                    if (w == empty_words) mask &= first_mask;
+                    if (w == last_word) mask &= last_mask;
+                    const uint64_t pw = P[(size_t)w * kWave];
+                    const uint64_t pm_j = row[w] & mask & ~pw;
+                    const bool hit = !found && pm_j != 0;
+                    if (hit) P[(size_t)w * kWave] = pw | blsi64(pm_j);
+                    found = found || hit;
+                }
+                tcur |= (uint64_t)found << (j & 63);
+                if ((j & 63) == 63 || j + 1 == len2) {
+                    T[(size_t)(j >> 6) * kWave] = tcur;
+                    tcur = 0;
+                }
+                if (j + bound + 1 < len1) {  // jaro.rs:318-324
+                    last_mask = (last_mask << 1) | 1;
+                    if (j + bound + 2 < len1 && last_mask == ~0ull) {
+                        last_mask = 0;
+                        win_words += 1;
+                    }
+                }
+                if (j >= bound) {  // jaro.rs:326-333
+                    first_mask <<= 1;
+                    if (first_mask == 0) {
+                        first_mask = ~0ull;
+                        win_words -= 1;
+                        empty_words += 1;
+                    }
+                }
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
+            }
+        }
+        uint32_t common = 0;
+        for (uint32_t w = 0; w < wp; ++w) common += __popcll(P[(size_t)w * kWave]);
+        r.common = common;
+
+        // ---- pass 2 (jaro.rs:370-420): every flagged text character, in text order, consumes the lowest remaining pattern flag
+        uint32_t transpositions = 0, wsel = 0;  // wsel: this lane's first word that may still hold a flag (only ever grows)
+        uint64_t pcur = wp ? P[0] : 0;
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 data = tv.src[(size_t)c * kWave + lane];
+            const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
+            const uint64_t tw = T[(size_t)((c * kChunk) >> 6) * kWave];
+            for (uint32_t b = 0; b < cols; ++b) {
+                const uint32_t j = c * kChunk + b;
+                if ((tw >> (j & 63)) & 1) {  // (per lane)
+                    while (pcur == 0 && wsel + 1 < wp) pcur = P[(size_t)(++wsel) * kWave];
+                    const uint64_t m = blsi64(pcur);
+                    const uint64_t pmv = p.pm[(size_t)lds_unrename[data.x & 0xFFu] * W + wsel];
+                    transpositions += (pmv & m) == 0;
+                    pcur ^= m;
+                }
+                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
+                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
+                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
+                data.w >>= 8;
+            }
+        }
+        r.transpositions = transpositions;
+        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (valid) {
+            bool keep;
+            const double v = f64_metric_value(p, len2_orig, r, &keep);
+            reinterpret_cast<double*>(p.out)[idx] = keep ? v : __longlong_as_double(0x7FF8000000000000ll);
+        }
+    }
+}
+
 hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
 {
     // tiles [tile_begin, jaro_split) take the single-word path, [jaro_split, tile_end) the multi-word path
@@ -583,7 +719,13 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
     }
     q.tile_begin = std::max(p.jaro_split, p.tile_begin);
     q.tile_end = p.tile_end;
-    if (q.tile_end > q.tile_begin) {
+    if (q.tile_end > q.tile_begin && p.jaro_long) {  // some string is beyond 512 symbols: flags in the global scratch strips
+        const dim3 g(std::max(1u, std::min<uint32_t>(p.long_grid, (uint32_t)scan_grid(q.tile_end - q.tile_begin))));
+        if (p.tiles)
+            hipLaunchKernelGGL(jaro_long_kernel<false>, g, b, 0, stream, q);
+        else
+            hipLaunchKernelGGL(jaro_long_kernel<true>, g, b, 0, stream, q);
+    } else if (q.tile_end > q.tile_begin) {
         const dim3 g(scan_grid(q.tile_end - q.tile_begin));
         const size_t lds = ((size_t)256 * p.words + p.words + 1) * sizeof(uint64_t);
         if (p.tiles)

@@ -430,11 +430,27 @@ def test_jaro_reference_fuzz_regression_on_gpu():
     assert abs(got - 0.1) <= 0.32144
 
 
-def test_jaro_beyond_512_is_refused_loudly():
-    corpus = rf.Corpus.from_list([b"a" * 600, b"abc"])
-    with pytest.raises(rf.RfError) as e:
-        GPU["jaro"].BatchComparator(b"a" * 600).similarity_many(corpus)
-    assert e.value.status == N.RF_ERR_UNSUPPORTED
+@pytest.mark.parametrize("qlen,clen", [(600, 700), (513, 40), (40, 1200), (2000, 2000), (1025, 1024)])
+def test_jaro_beyond_512_symbols(qlen, clen):
+    """Strings beyond 512 symbols (after the window truncation) take jaro_long_kernel: flag words in global strips instead of
+    registers (round 1 refused).  Bit-equal f64 like the register kernels, with and without cutoffs, mixed with short
+    candidates that stay on the single-word / multi-word kernels."""
+    rng = np.random.default_rng(qlen * 7 + clen)
+    alpha = ABCD if qlen % 2 else synth.ALNUM
+    q = alpha[rng.integers(0, len(alpha), size=qlen)].tobytes()
+    cands = [alpha[rng.integers(0, len(alpha), size=int(n))].tobytes() for n in rng.integers(max(1, clen - 30), clen + 30, size=150)]
+    cands += [q, q[: qlen // 2], q[::-1], b"", q + q[:17]] + [alpha[rng.integers(0, len(alpha), size=int(n))].tobytes() for n in (1, 5, 64, 65, 300, 511, 512, 513)]
+    for i in range(0, 60, 3):  # near-duplicates of the query: many common characters, real transpositions
+        b = bytearray(q)
+        for _ in range(20):
+            k = int(rng.integers(0, len(b) - 1))
+            b[k], b[k + 1] = b[k + 1], b[k]
+        cands[i] = bytes(b)
+    data, offsets = rf.ragged(cands)
+    for metric in ("jaro", "jaro_winkler"):
+        for op, kw in (("similarity", {}), ("distance", {}), ("similarity", {"score_cutoff": 0.7}), ("normalized_similarity", {"score_cutoff": 0.85})):
+            _check_many(metric, q, data, offsets, op, **kw)
+
 
 
 def test_jaro_fixed_rows_c4():
@@ -1170,12 +1186,8 @@ def test_randomized_differential(seed):
                     kw["score_cutoff"] = int(rng.choice([0, 1, 2, 3, 7, qlen // 2, qlen, qlen + 5, 10**6, int(rng.integers(0, 80))]))
             if metric == "levenshtein" and rng.random() < 0.4:
                 kw["weights"] = tuple(int(x) for x in rng.choice([(1, 1, 1), (1, 1, 2), (2, 2, 2), (1, 2, 3), (3, 1, 1), (2, 2, 5), (0, 0, 1), (1, 1, 0)]))
-                if qlen > 500 and kw["weights"] not in ((1, 1, 1), (2, 2, 2), (1, 1, 2), (2, 2, 5), (0, 0, 1)):
-                    continue  # beyond the LDS-resident Wagner-Fischer kernel: a documented RF_ERR_UNSUPPORTED
             if metric == "jaro_winkler" and rng.random() < 0.5:
                 kw["prefix_weight"] = float(rng.choice([0.0, 0.1, 0.25]))
-            if metric in ("jaro", "jaro_winkler") and (qlen > 512 or int(np.diff(offsets.astype(np.int64)).max(initial=0)) > 512):
-                continue  # documented limit of the Jaro kernels
             if metric == "levenshtein" and op == "similarity" and "score_cutoff" in kw:
                 continue  # quirk Q2, see _check_many
             _check_many(metric, q, data, offsets, op, **kw)
@@ -1224,8 +1236,6 @@ def test_randomized_u32_equals_byte_path(seed, tmp_path):
     wloaded = rf.Corpus.load(path)
     for _ in range(6):
         metric = str(rng.choice(["levenshtein", "osa", "indel", "lcs_seq", "jaro_winkler"]))
-        if metric == "jaro_winkler" and int(np.diff(offsets.astype(np.int64)).max(initial=0)) > 512:
-            continue
         qlen = int(rng.choice([0, 4, 30, 64, 90]))
         q = alphabet[rng.integers(0, len(alphabet), size=qlen)].tobytes()
         op = OPS[str(rng.choice(["distance", "normalized_similarity"]))]

@@ -2,4 +2,4 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -x -q -k "osa or weights or long or ocr" > gpurun_out/pytest_gpu_sel.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu_sel.log
+timeout 2400 python -m pytest tests -m gpu -x -q -k "jaro or random" > gpurun_out/pytest_gpu_sel.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu_sel.log
