@@ -180,7 +180,11 @@ def main():
     weights = tuple(int(x) for x in args.weights.split(",")) if args.weights else None
     if weights:
         call_args = call_args.weights(rf.WeightTable(*weights))
-    stream = torch.cuda.current_stream(dev)
+    # The scans run on a stream of their own and the exchange on a HIGH-PRIORITY side stream: the runtime multiplexes streams
+    # onto a few hardware queues, and with the null stream + a default-priority side stream both landed on ONE queue
+    # (rocprofv3: same queue id), which put the exchange kernels and their barrier packets between every two scans.
+    stream = torch.cuda.Stream(device=dev) if (world > 1 or force_dist) else torch.cuda.current_stream(dev)
+    torch.cuda.set_stream(stream)
 
     last_topk = [None]
 
@@ -197,8 +201,9 @@ def main():
             # Everything is stream-ordered on the device -- no host round trip inside a step.
             buf = step_no[0] & 1
             step_no[0] += 1
-            if buf_free[buf] is not None:
-                stream.wait_event(buf_free[buf])  # the exchange that last read this buffer pair (two steps ago) is done
+            if buf_free[buf] is not None and not buf_free[buf].query():
+                buf_free[buf].synchronize()  # the exchange that last read this buffer pair (two steps ago): long done -- checked
+                # on the host, because a cross-queue wait enqueued on the scan stream costs a barrier packet every step
             scorer.topk_keys_device(corpus, args.topk, local_keys[buf], N.OP_DISTANCE, call_args, index_base=index_base,
                                     out=out if args.mode == "many" else None, stream=stream.cuda_stream)
             if world > 1 or force_dist:
@@ -228,7 +233,7 @@ def main():
         if xchg is not None:
             stream.wait_stream(xchg)  # the last step's gather + merge belongs to the timed region
 
-    xchg = torch.cuda.Stream(device=dev) if ((world > 1 or force_dist) and not test_gloo) else None
+    xchg = torch.cuda.Stream(device=dev, priority=-1) if ((world > 1 or force_dist) and not test_gloo) else None
     buf_free = [None, None]
     step_no = [0]
     merged_keys = torch.empty(args.topk, dtype=torch.int64, device=dev)
@@ -243,12 +248,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream bracket the K steps (one pair, not one per step: every event record is a marker packet
+    # the queue has to process between two back-to-back kernels, ~7 us each on this runtime)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(stream)
     for s in range(args.steps):
-        ev[s][0].record(stream)
         step()
-        ev[s][1].record(stream)
+    ev1.record(stream)
     finish_exchange()  # the last step's gather + merge is inside the timed region
     torch.cuda.synchronize()
     if world > 1 or force_dist:
@@ -256,7 +263,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration: HIP events on the launch stream over the timed region
     if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -16,6 +16,7 @@ P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
 P q32_levenshtein "levenshtein:q32:n100000000:l64:cutNone:many" --query-len 32
 P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" --cutoff 3 --mode topk
 P topk16_nocutoff "levenshtein:q64:n100000000:l64:cutNone:topk" --mode topk
+MATCH="rf::band" P c3_cutoff8_band "levenshtein:q256:n10000000:l256:cut8:many" --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
 MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
 b() { name=$1; shift; python bench.py "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
@@ -39,5 +40,8 @@ b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
 b c3_cutoff8 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
 RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/profiles/bench_sharded_path_world1.json
 python bench.py --config c5 2>/dev/null | tail -1 > gpurun_out/profiles/bench_c5_1B_world1.json
+python tools/time_mixed.py > gpurun_out/profiles/mixed_tiles_$R.txt 2>/dev/null; RF_NO_MIXED_TILES=1 python tools/time_mixed.py >> gpurun_out/profiles/mixed_tiles_$R.txt 2>/dev/null
+for v in lev256c8; do RF_NO_BAND=1 python tools/ab_time.py $v 2>/dev/null | tail -1 | sed 's/librfgpu.so/RF_NO_BAND=1/'; python tools/ab_time.py $v 2>/dev/null | tail -1; done > gpurun_out/profiles/band_ab_$R.txt
+for v in lev64 lev64+topk lev64+topk+out indel indel+topk jw; do python tools/ab_time.py $v 2>/dev/null | tail -1; done > gpurun_out/profiles/variants_$R.txt
 cp gpurun_out/*_$R.txt gpurun_out/*_$R.json gpurun_out/profiles/ 2>/dev/null
 ls gpurun_out/profiles | wc -l
