@@ -127,25 +127,8 @@ struct JaroWordState {
     uint32_t tacc;  // T bits of the 32 columns currently being processed
 };
 
-// The sliding window mask (jaro.rs:168,176,185) is wavefront-uniform; the asm pins its recurrence
-// bm = (bm << 1) | (j < bound) to the scalar ALU as two 32-bit halves (hipcc otherwise migrates it to VGPRs next to
-// the per-lane flags).  SCC-based: the low bit is free after the shift, so adding the compare's carry sets it.
-__device__ __forceinline__ void window_next(uint32_t& lo, uint32_t& hi, uint32_t j, uint32_t bound)
-{
-    uint32_t tmp;
-    asm("s_lshr_b32 %2, %0, 31\n\t"
-        "s_lshl_b32 %1, %1, 1\n\t"
-        "s_or_b32 %1, %1, %2\n\t"
-        "s_lshl_b32 %0, %0, 1\n\t"
-        "s_cmp_lt_u32 %3, %4\n\t"
-        "s_addc_u32 %0, %0, 0"
-        : "+s"(lo), "+s"(hi), "=&s"(tmp)
-        : "s"(j), "s"(bound)
-        : "scc");
-}
-
-// (PM rows are fetched kJaroGroup symbols ahead of their use; 2 rather than the scans' 4 keeps the kernel inside the
-// 64-VGPR budget of 8 wavefronts per SIMD, and with 8 wavefronts the LDS latency is covered either way)
+// (PM rows are fetched kJaroGroup symbols ahead of their use; 2 rather than the scans' 4 saves 8 VGPRs, and with 7-8
+// wavefronts per SIMD the LDS latency is covered either way)
 constexpr int kJaroGroup = 2;
 __device__ __forceinline__ uint32_t chunk_byte(const uint4& c, int n)
 {
@@ -153,13 +136,18 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4& c, int n)
     return (dw >> (8 * (n % 4))) & 0xFFu;
 }
 
+// Pass 1 over one 16-column chunk.  The sliding window mask of column j (jaro.rs:168,176,185) depends on j and the
+// tile's bound only, so it comes from a 64-entry table this wavefront keeps in LDS (jaro_window_table, rebuilt when the
+// bound changes): one broadcast ds_read per column.  Round 1 advanced the mask with 6 scalar instructions per column and
+// built the T bit with 3 more; the CU's one scalar unit serves four SIMDs, and at 9 SALU per column x 4 wavefronts it --
+// not the vector unit (10 VALU per column) -- was what bounded this pass (ISA tally of the r01 kernel: 144 SALU next to
+// 160 VALU per chunk).  T bits are gathered at compile-time positions 0..15 and shifted into place once per chunk.
 template <bool kFull>
-__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4 c, uint32_t j0, uint32_t cols,
-                                                uint32_t bound, uint32_t& bm_lo_io, uint32_t& bm_hi_io)
+__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint64_t* wtab, const uint4 c, uint32_t j0, uint32_t cols)
 {
     constexpr int G = kJaroGroup, NG = kChunk / G;
-    uint32_t bm_lo = uniform(bm_lo_io), bm_hi = uniform(bm_hi_io);  // (re)pin to SGPRs for the asm recurrence
-    bound = uniform(bound);
+    const uint64_t* wrow = wtab + j0;
+    uint32_t t16 = 0;
     uint64_t cur[G], nxt[G];
 #pragma unroll
     for (int b = 0; b < G; ++b) cur[b] = lds_pm0[chunk_byte(c, b)];
@@ -172,20 +160,25 @@ __device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) {
-            const uint32_t j = j0 + g * G + b;
             if (kFull || (uint32_t)(g * G + b) < cols) {
-                const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], ((uint64_t)bm_hi << 32) | bm_lo, st.p_flag);  // PM & window & ~P
+                const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], wrow[g * G + b], st.p_flag);  // PM & window & ~P
                 const uint64_t below = pm_j - 1;
                 st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
-                st.tacc |= pm_j != 0 ? (1u << (j & 31)) : 0u;           // jaro.rs:174 / :183
-                window_next(bm_lo, bm_hi, uniform(j), bound);  // :176 / :185
+                t16 |= pm_j != 0 ? (1u << (g * G + b)) : 0u;           // jaro.rs:174 / :183
             }
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) cur[b] = nxt[b];
     }
-    bm_lo_io = bm_lo;
-    bm_hi_io = bm_hi;
+    st.tacc |= t16 << (j0 & 16);  // columns j0 .. j0 + 15 of the current 32-column half
+}
+
+// the window mask of every column for this bound (closed form of the recurrence bm' = (bm << 1) | (j < bound) started
+// at the low bound + 1 bits): bits [max(j - bound, 0), min(j + bound + 1, 64))
+__device__ __forceinline__ void jaro_window_table(uint64_t* wtab, uint32_t lane, uint32_t bound)
+{
+    const uint32_t lo = lane > bound ? lane - bound : 0, hi = min(lane + bound + 1, 64u);
+    wtab[lane] = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & (~0ull << lo);
 }
 
 template <bool kFull>
@@ -193,6 +186,7 @@ __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const ui
 {
     constexpr int G = kJaroGroup, NG = kChunk / G;
     const uint32_t thalf = (j0 & 32) ? (uint32_t)(st.t_flag >> 32) : (uint32_t)st.t_flag;
+    const uint32_t t16 = thalf >> (j0 & 16);  // this chunk's T bits at positions 0..15 (no scalar address arithmetic per column)
     uint64_t cur[G], nxt[G];
 #pragma unroll
     for (int b = 0; b < G; ++b) cur[b] = lds_pm0[chunk_byte(c, b)];
@@ -205,9 +199,8 @@ __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const ui
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) {
-            const uint32_t j = j0 + g * G + b;
             if (kFull || (uint32_t)(g * G + b) < cols) {
-                const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)thalf, j & 31, 1);  // all ones iff T bit j
+                const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)t16, g * G + b, 1);  // all ones iff T bit j
                 const uint64_t f = ((uint64_t)f32 << 32) | f32;
                 const uint64_t below = st.p_flag - 1;
                 const uint64_t m = lut3<T_ANDN_AND>(st.p_flag, below, f);  // lowest remaining pattern flag, if flagged
@@ -240,6 +233,9 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p)
     __syncthreads();
     double* tab2 = tab1 + kJaroTabStride * (1 + uniform(threadIdx.x / kWave));
     uint32_t tab2_len = 0xFFFFFFFFu;
+    // this wavefront's window-mask table (64 x u64), behind the f64 tables
+    uint64_t* wtab = reinterpret_cast<uint64_t*>(tab1 + kJaroTabStride * (1 + kWavesPerBlock)) + kWave * uniform(threadIdx.x / kWave);
+    uint32_t wtab_bound = 0xFFFFFFFFu;
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
@@ -279,8 +275,10 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p)
         JaroWordState st;
         st.p_flag = st.t_flag = st.hits = 0;
         st.tacc = 0;
-        const uint64_t bm0 = mask_lsb64(bound + 1);
-        uint32_t bm_lo = uniform((uint32_t)bm0), bm_hi = uniform((uint32_t)(bm0 >> 32));
+        if (bound != wtab_bound) {  // wavefront-uniform; this wavefront's own table: no barrier
+            jaro_window_table(wtab, lane, bound);
+            wtab_bound = bound;
+        }
         // Early-out under a tight cutoff: after j text symbols the number of common characters can still grow by at most
         // one per remaining symbol, the similarity is at most (m/len1 + m/len2 + 1) / 3 (common_char_filter, jaro.rs:134-145)
         // and the Winkler boost at most prefix * weight * (1 - sim) with the prefix already known.  If no lane can reach
@@ -297,9 +295,9 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p)
             const uint4 nxt = tv.src[(size_t)(k + 1 < nch ? k + 1 : 0) * kWave + lane];  // next chunk, then chunk 0 again
             const uint32_t cols = len2 - k * kChunk;
             if (cols >= (uint32_t)kChunk)
-                jaro_flag_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk, bound, bm_lo, bm_hi);
+                jaro_flag_chunk<true>(st, lds_pm0, wtab, cur, k * kChunk, kChunk);
             else
-                jaro_flag_chunk<false>(st, lds_pm0, cur, k * kChunk, cols, bound, bm_lo, bm_hi);
+                jaro_flag_chunk<false>(st, lds_pm0, wtab, cur, k * kChunk, cols);
             if ((k & 1) || k + 1 == nch) {  // 32 columns (or the tail) done: bank their T bits
                 st.t_flag |= (uint64_t)st.tacc << ((k & 2) ? 32 : 0);
                 st.tacc = 0;
@@ -370,15 +368,15 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p)
     }
 }
 
-// Two entry points over the same body: the table-epilogue kernel fits the 64-VGPR budget of 8 wavefronts per SIMD and is
-// pinned there; the general one (cutoff replay, early-out) keeps the compiler's own budget (pinned it would spill).
+// Two entry points over the same body (the table epilogue is a different instantiation).  Both keep the compiler's own
+// register budget: pinned to 8 wavefronts per SIMD the fast kernel spills 20 bytes and measures 1.5 % slower than at 7.
 template <bool kUniform, bool kEarly>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
 {
     jaro_word_body<kUniform, kEarly, false>(p);
 }
 template <bool kUniform>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void jaro_word_fast_kernel(const ScanParams p)
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_fast_kernel(const ScanParams p)
 {
     jaro_word_body<kUniform, false, true>(p);
 }
@@ -714,7 +712,7 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
         const bool fast = !p.has_cutoff && p.jaro_tab != nullptr;  // the table epilogue (no cutoff to replay)
         auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : (fast ? jaro_word_fast_kernel<false> : jaro_word_kernel<false, false>))
                          : (early ? jaro_word_kernel<true, true> : (fast ? jaro_word_fast_kernel<true> : jaro_word_kernel<true, false>));
-        const size_t lds = 256 * sizeof(uint64_t) + (fast ? (size_t)kJaroTabStride * (1 + kWavesPerBlock) * sizeof(double) : 0);
+        const size_t lds = 256 * sizeof(uint64_t) + (size_t)kJaroTabStride * (1 + kWavesPerBlock) * sizeof(double) + (size_t)kWavesPerBlock * kWave * sizeof(uint64_t);
         hipLaunchKernelGGL(k, g, b, lds, stream, q);
     }
     q.tile_begin = std::max(p.jaro_split, p.tile_begin);
