@@ -1681,7 +1681,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         auto it = owner->topk_scratch.find(st);
         if (it == owner->topk_scratch.end()) {
             // [64 way segments of candidate keys | root table 64 x 64 keys | bound (u64, own line) | control block 65 x 128 B]
-            const size_t ways = 64, per_way = ((size_t)scan_grid(corpus->n_tiles) + ways - 1) / ways;
+            const size_t ways = 64, per_way = ((size_t)scan_grid_full(corpus->n_tiles) + ways - 1) / ways;  // (the largest grid any top-k launch uses)
             sc.seg_cap = (uint32_t)(per_way * kWave);
             const size_t cand_bytes = ways * sc.seg_cap * sizeof(uint64_t), root_bytes = ways * kWave * sizeof(uint64_t), ctl_bytes = 65 * 128;
             uint8_t* mem = nullptr;

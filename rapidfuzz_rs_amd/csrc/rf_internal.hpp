@@ -147,7 +147,8 @@ hipError_t launch_select_emit(const void* s, bool f64, uint32_t n, bool desc, ui
 hipError_t launch_probe(RawKind raw, uint32_t len1, uint32_t mode, int blocks_per_cu, int iters, double* wave_columns_per_ns);  // rf_probe.hip
 hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,
                                  hipStream_t stream);
-int scan_grid(uint32_t n_tiles);  // the grid launch_scan uses for n_tiles tiles
+int scan_grid(uint32_t n_tiles);       // the grid of short-running launches over n_tiles tiles
+int scan_grid_full(uint32_t n_tiles);  // the grid of full (no-cutoff) scans; >= scan_grid
 
 void set_error(const std::string& msg);
 

@@ -707,8 +707,8 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
     q.tile_begin = p.tile_begin;  // (the cutoff's length window, plan())
     q.tile_end = std::min(p.jaro_split, p.tile_end);
     if (q.tile_end > q.tile_begin) {
-        const dim3 g(scan_grid(q.tile_end - q.tile_begin));
         const bool early = p.jaro_need >= 0.0;
+        const dim3 g(early ? scan_grid(q.tile_end - q.tile_begin) : scan_grid_full(q.tile_end - q.tile_begin));
         const bool fast = !p.has_cutoff && p.jaro_tab != nullptr;  // the table epilogue (no cutoff to replay)
         auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : (fast ? jaro_word_fast_kernel<false> : jaro_word_kernel<false, false>))
                          : (early ? jaro_word_kernel<true, true> : (fast ? jaro_word_fast_kernel<true> : jaro_word_kernel<true, false>));

@@ -354,7 +354,7 @@ static hipError_t launch_multi_state(const ScanParams& p, hipStream_t stream, in
 hipError_t launch_scan_multi(RawKind raw, bool narrow, const ScanParams& p, hipStream_t stream)
 {
     if (p.n_tiles == 0) return hipSuccess;
-    const int grid = scan_grid(p.n_tiles);
+    const int grid = scan_grid_full(p.n_tiles);
     if (raw == RAW_LEV) return narrow ? launch_multi_state<Lev32State>(p, stream, grid) : launch_multi_state<LevState<1>>(p, stream, grid);
     if (raw == RAW_LCS) return narrow ? launch_multi_state<Lcs32State>(p, stream, grid) : launch_multi_state<LcsState<1>>(p, stream, grid);
     return hipErrorInvalidValue;
@@ -381,25 +381,42 @@ hipError_t launch_topk_final(const uint64_t* keys, uint32_t count, uint32_t k, u
 // ---------------------------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------------------------
-int scan_max_grid()
+// Workgroups per launch: 8 (32 wavefronts) are resident per CU; launching a multiple of that lets early finishers be
+// replaced.  Two factors, measured on the C2 / C3 corpora (same-session sweeps):
+//   * full scans (no cutoff): the more the better up to ~256-512 per CU -- Levenshtein +1.2 %, Indel +4 % over 32 -- the
+//     static grid-stride deal leaves a tail when wavefronts own dozens of tiles each;
+//   * short-running launches (cutoff early-out, the band kernel, the completeness paths): 32 per CU -- every workgroup
+//     stages the pattern table before its first tile, and with 6 tiles per wavefront that prologue shows (the band kernel
+//     lost 37 % at 256 per CU).
+// RF_SCAN_BLOCKS_PER_CU / RF_SCAN_BLOCKS_PER_CU_FULL override.  The CU count is the current device's (256 on a whole
+// MI355X, 32 on a CPX partition), cached per device.
+static int device_cus()
 {
-    // 8 workgroups (32 waves) are resident per CU; launching 4x that lets early finishers be replaced and
-    // measured +5% over an exactly-resident grid.  RF_SCAN_BLOCKS_PER_CU overrides.  The CU count is the current
-    // device's (256 on a whole MI355X, 32 on a CPX partition), cached per device.
-    static const int per_cu = [] {
-        const char* e = getenv("RF_SCAN_BLOCKS_PER_CU");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 32;
-    }();
     static std::atomic<int> cus[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256 * per_cu;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
     int n = cus[dev].load(std::memory_order_relaxed);
     if (n == 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus[dev].store(n, std::memory_order_relaxed);
     }
-    return n * per_cu;
+    return n;
+}
+static int env_or(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
+int scan_max_grid()
+{
+    static const int per_cu = env_or("RF_SCAN_BLOCKS_PER_CU", 32);
+    return device_cus() * per_cu;
+}
+int scan_max_grid_full()
+{
+    static const int per_cu = env_or("RF_SCAN_BLOCKS_PER_CU_FULL", 256);
+    return device_cus() * per_cu;
 }
 
 template <class State>
@@ -460,6 +477,10 @@ int scan_grid(uint32_t n_tiles)
 {
     return (int)std::min<uint32_t>((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)scan_max_grid());
 }
+int scan_grid_full(uint32_t n_tiles)  // full (no-cutoff) scans of the register-resident kernels; also the capacity of the top-k scratch
+{
+    return (int)std::min<uint32_t>((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)scan_max_grid_full());
+}
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
 {
     if (p.n_tiles == 0) return hipSuccess;
@@ -482,7 +503,8 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
         return launch_scan_mixed(raw, m, stream);
     }
     const uint32_t launch_tiles = p.tile_end > p.tile_begin ? (p.tile_end - p.tile_begin + p.tile_step - 1) / p.tile_step : 0;
-    const int grid = p.long_words_pad ? (int)p.long_grid : std::max(1, scan_grid(launch_tiles));
+    const bool full_scan = !p.early && !p.band && !p.long_words_pad && p.tile_step == 1 && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA);
+    const int grid = p.long_words_pad ? (int)p.long_grid : std::max(1, full_scan ? scan_grid_full(launch_tiles) : scan_grid(launch_tiles));
     if (grid_used) *grid_used = grid;
     if (p.prefill_none && p.out) {  // candidates outside the cutoff's length window (plan()): None without being read
         // (for f64 outputs two all-ones words per entry: a NaN, which is all "None" promises)
