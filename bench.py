@@ -160,7 +160,7 @@ def main():
     sample_rows = min(n, 32_000_000)
     host_sample = None
     host_strided = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and world == 1:  # the CPU baseline and the oracle parity leg run at N = 1 only
         host_sample = rows[:sample_rows].cpu().numpy()
         host_strided = rows[::1009].cpu().numpy()  # every 1009-th candidate of the WHOLE shard
     corpus = rf.Corpus.from_device_rows(rows)
@@ -374,7 +374,7 @@ def main():
 
         # the same for every world size when the corpus is ONE logical corpus (c5): the scaling runs must agree on it
         result["config"]["topk_checksum"] = zlib.crc32(np.array(sorted(keys), dtype=np.uint64).tobytes())
-        if c5 and not args.no_cpu_baseline:
+        if c5 and not args.no_cpu_baseline:  # (cheap: the oracle on ~1000 rows; kept at every world size -- it is the check that the shards add up)
             # parity of the merged top-k: the only candidates within the cutoff are planted near-duplicates (a random
             # len-64 alphanumeric string is ~55 edits from the query), and a planted row depends only on its global
             # index, so rank 0 re-creates ALL of them on the host and lets the oracle rank them
