@@ -374,6 +374,18 @@ def main():
 
         # the same for every world size when the corpus is ONE logical corpus (c5): the scaling runs must agree on it
         result["config"]["topk_checksum"] = zlib.crc32(np.array(sorted(keys), dtype=np.uint64).tobytes())
+        if args.mode == "many" and not is_f64:
+            # oracle-free consistency of the exchange at any world size: rank 0 ranks its OWN shard from the per-candidate
+            # distances the same pass wrote (torch on the device) -- each of its k best must be in the merged list or lose to
+            # the merged list's worst entry, and every merged entry that points into this shard must carry that candidate's distance
+            d0 = out[:n].to(torch.int64) & 0xFFFFFFFF
+            mine = (d0 << 32) | (index_base + torch.arange(n, device=dev, dtype=torch.int64))
+            mine = mine[d0 != 0xFFFFFFFF]
+            local_best = torch.topk(mine, min(args.topk, mine.numel()), largest=False).values.cpu().tolist()
+            worst = max(keys) if len(keys) == args.topk else 2**63 - 1
+            bad = sum(1 for x in local_best if x not in keys and x < worst)
+            bad += sum(1 for x in keys if index_base <= (x & 0xFFFFFFFF) < index_base + n and x not in local_best)
+            result["config"]["exchange_selfcheck"] = {"rank0_shard_entries_checked": len(local_best), "inconsistent": bad}
         if c5 and not args.no_cpu_baseline:  # (cheap: the oracle on ~1000 rows; kept at every world size -- it is the check that the shards add up)
             # parity of the merged top-k: the only candidates within the cutoff are planted near-duplicates (a random
             # len-64 alphanumeric string is ~55 edits from the query), and a planted row depends only on its global

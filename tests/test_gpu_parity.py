@@ -1299,6 +1299,7 @@ def test_bench_contract_small():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["config"]["topk_found"] == 16 and d["value"] > 0
+    assert d["config"]["exchange_selfcheck"]["inconsistent"] == 0 and d["config"]["exchange_selfcheck"]["rank0_shard_entries_checked"] == 16
 
 
 def test_bench_two_ranks_share_one_gpu():
@@ -1353,6 +1354,7 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     d = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--candidates", "200000", "--steps", "3", "--warmup", "1",
                      "--no-cpu-baseline"], env)
     assert d["n_gpus"] == 2 and d["config"]["ranks_joined"] == 2 and d["config"]["topk_found"] == 16
+    assert d["config"]["exchange_selfcheck"]["inconsistent"] == 0
     # and a launcher that starts a different number of ranks than --gpus says is refused, not mis-reported
     import subprocess
 

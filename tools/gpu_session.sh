@@ -2,4 +2,4 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-RF_FUZZ_SEEDS=3000 timeout 2700 python -m pytest tests -m gpu -x -q -k "randomized" -n 4 > gpurun_out/pytest_fuzz.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_fuzz.log
+timeout 2400 python -m pytest tests -m gpu -x -q -k "bench" > gpurun_out/pytest_gpu_sel.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu_sel.log
