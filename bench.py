@@ -50,6 +50,9 @@ def parse():
                     help="c2 = BASELINE.json configs[1] (the default workload); c5 = configs[4]: 1 B candidates split over the ranks, "
                          "score_cutoff 3, top-16, all-gather every step")
     ap.add_argument("--total-candidates", type=int, default=1_000_000_000, help="size of the logical corpus of --config c5")
+    ap.add_argument("--settle-ms", type=float, default=200.0,
+                    help="untimed steps run for this long BEFORE the W warm-up steps: after the idle set-up phase the GPU's clock takes "
+                         "~15 back-to-back launches to ramp (profiles/clock_ramp_r02.txt); 0 = off.  Reported as config.settle_steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -117,6 +120,7 @@ def main():
         everyone = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
         joined = int(sum(int(t[0]) for t in everyone))
+        dist.barrier()  # the first barrier of a process group initialises lazily (~0.6 s here); pay that now, not between warm-up and the timed steps
         gpus_used = len({int(t[1]) for t in everyone})
         if joined != world or (gpus_used != world and not test_gloo):
             raise SystemExit(f"bench.py: {joined} of {world} ranks joined on {gpus_used} distinct GPUs")
@@ -240,6 +244,24 @@ def main():
     local_keys = [torch.empty(args.topk, dtype=torch.int64, device=dev) for _ in range(2)]
     all_keys = [torch.empty(args.topk * max(world, 1), dtype=torch.int64, device=dev) for _ in range(2)]
 
+    # clock settle (disclosed in config.settle_steps): the set-up phase above leaves the GPU mostly idle and its clock low
+    settle_steps = 0
+    if args.settle_ms > 0:
+        t_settle = time.perf_counter()
+        for _ in range(4):
+            step()
+        finish_exchange()
+        torch.cuda.synchronize()
+        more = int(min(2000, max(0.0, args.settle_ms * 1e-3 / max((time.perf_counter() - t_settle) / 4, 1e-5) - 4)))
+        if world > 1 or force_dist:  # every rank must issue the same number of exchanges
+            t = torch.tensor([more], dtype=torch.int64, device="cpu" if test_gloo else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            more = int(t.item())
+        for _ in range(more):
+            step()
+        finish_exchange()
+        torch.cuda.synchronize()
+        settle_steps = 4 + more
     for _ in range(args.warmup):
         step()
     finish_exchange()
@@ -332,6 +354,7 @@ def main():
             **({"rccl_ranks": dist.get_world_size(), "collective": "ncclAllGather via torch.distributed (backend nccl = RCCL)"}
                if (world > 1 or force_dist) and not test_gloo else {}),
             "setup_s": round(t_setup, 2),
+            "settle_steps": settle_steps,
             **({"test_backend": "gloo: ranks share one GPU, NOT a measurement"} if test_gloo else {}),
         },
         "roofline": {

@@ -44,19 +44,17 @@ python tools/time_mixed.py > gpurun_out/profiles/mixed_tiles_$R.txt 2>/dev/null;
 for v in lev256c8; do RF_NO_BAND=1 python tools/ab_time.py $v 2>/dev/null | tail -1 | sed 's/librfgpu.so/RF_NO_BAND=1/'; python tools/ab_time.py $v 2>/dev/null | tail -1; done > gpurun_out/profiles/band_ab_$R.txt
 for v in lev64 lev64+topk lev64+topk+out indel indel+topk jw; do python tools/ab_time.py $v 2>/dev/null | tail -1; done > gpurun_out/profiles/variants_$R.txt
 # kernel timeline of the sharded step (top-16 + every distance + exchange), world size 1
-( cd /tmp && RF_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --stats -d /tmp/kt_sh_$R -o kt -- python $OLDPWD/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /tmp/kt_sh_$R.log 2>&1 )
-python - > gpurun_out/profiles/sharded_step_$R.txt <<PY
+( cd /tmp && RF_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace -d /tmp/kt_sh_$R -o kt -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/kt_sh_$R.log 2>&1 )
+( echo "sharded step at world size 1 (RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5): rocprofv3 --kernel-trace, last two steps"; python tools/timeline.py /tmp/kt_sh_$R/kt_results.db 3 ) > gpurun_out/profiles/sharded_step_$R.txt
+# the clock ramp after an idle phase: per-launch duration of back-to-back plain scans with the settle phase off
+( cd /tmp && rocprofv3 --kernel-trace -d /tmp/kt_ramp_$R -o kt -- python $OLDPWD/bench.py --steps 40 --warmup 0 --settle-ms 0 --no-cpu-baseline > /tmp/kt_ramp_$R.log 2>&1 )
+python - > gpurun_out/profiles/clock_ramp_$R.txt <<PY
 import sqlite3
-cur = sqlite3.connect("/tmp/kt_sh_$R/kt_results.db").cursor()
-rows = list(cur.execute("select name, start, end, grid_x, stream_id, queue_id from kernels order by start"))
-scans = [(s, e) for n, s, e, g, st, q in rows if "stream_kernel_occ8" in n and g > 1000000]
-steps = [scans[i + 1][0] - scans[i][0] for i in range(3, len(scans) - 1)]
-print("sharded step at world size 1 (RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 3): rocprofv3 --kernel-trace")
-print(f"main scan: n={len(scans)} avg {sum(e - s for s, e in scans[3:]) / len(scans[3:]) / 1e3:.1f} us; step period (scan start to scan start) avg {sum(steps) / len(steps) / 1e3:.1f} us")
-print("last two steps (start us, duration us, grid, stream, queue, kernel):")
-t0 = rows[0][1]
-for n, s, e, g, st, q in [r for r in rows if r[1] >= scans[-3][1] and r[1] <= scans[-1][2]]:
-    print(f"{(s - t0) / 1e3:12.1f} {(e - s) / 1e3:9.1f} {g:9d} {st:3d} {q:3d}  {n[:70]}")
+cur = sqlite3.connect("/tmp/kt_ramp_$R/kt_results.db").cursor()
+d = [(e - s) / 1e3 for n, s, e in cur.execute("select name, start, end from kernels order by start") if "stream_kernel" in n and e - s > 1_000_000]
+print("python bench.py --steps 40 --warmup 0 --settle-ms 0 under rocprofv3 --kernel-trace: duration (us) of each back-to-back scan launch after the idle set-up phase")
+print(" ".join(f"{x:.0f}" for x in d))
+print(f"first 5 avg {sum(d[:5]) / 5:.0f} us; launches 20+ avg {sum(d[20:]) / max(1, len(d[20:])):.0f} us -> bench.py runs --settle-ms (default 200) of untimed steps before the W warm-up steps and reports config.settle_steps")
 PY
 cp gpurun_out/*_$R.txt gpurun_out/*_$R.json gpurun_out/profiles/ 2>/dev/null
 ls gpurun_out/profiles | wc -l
