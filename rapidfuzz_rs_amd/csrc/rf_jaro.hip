@@ -129,11 +129,47 @@ struct JaroWordState {
 
 // (PM rows are fetched kJaroGroup symbols ahead of their use; 2 rather than the scans' 4 saves 8 VGPRs, and with 7-8
 // wavefronts per SIMD the LDS latency is covered either way)
-constexpr int kJaroGroup = 2;
+#ifndef RF_JARO_GROUP
+#define RF_JARO_GROUP 2
+#endif
+constexpr int kJaroGroup = RF_JARO_GROUP;
 __device__ __forceinline__ uint32_t chunk_byte(const uint4& c, int n)
 {
     const uint32_t dw = n < 4 ? c.x : (n < 8 ? c.y : (n < 12 ? c.z : c.w));
     return (dw >> (8 * (n % 4))) & 0xFFu;
+}
+
+// Row of the (single-block) pattern table for column n of a chunk.  The byte offset sym * 8 is ONE v_lshlrev_b32_sdwa (the
+// byte select and the shift in one half-rate instruction); written as `(dw >> 8k) & 0xFF` and indexed, hipcc emits
+// v_bfe_u32 + v_lshl_add_u32 here -- two half-rate instructions (tools/microbench_issue: 1.85 ns each per wavefront and SIMD).
+__device__ __forceinline__ uint64_t jaro_pm_row(const uint64_t* lds_pm0, const uint4& c, int n)
+{
+#ifdef RF_JARO_OLD_GATHER
+    return lds_pm0[chunk_byte(c, n)];
+#else
+    const uint32_t dw = n < 4 ? c.x : (n < 8 ? c.y : (n < 12 ? c.z : c.w));
+    uint32_t off;
+    switch (n % 4) {
+    case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(3u), "v"(dw)); break;
+    case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(3u), "v"(dw)); break;
+    case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(3u), "v"(dw)); break;
+    default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(3u), "v"(dw)); break;
+    }
+    return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(lds_pm0) + off);
+#endif
+}
+
+// x - 1 on an aligned register pair (hipcc otherwise feeds v_lshl_add_u64 a pair with a stale high half and repairs the
+// result with an extra v_add_u32 per column)
+__device__ __forceinline__ uint64_t dec64(uint64_t x)
+{
+#ifdef RF_JARO_NO_DEC_ASM
+    return x - 1;
+#else
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 0, -1" : "=v"(r) : "v"(x));
+    return r;
+#endif
 }
 
 // Pass 1 over one 16-column chunk.  The sliding window mask of column j (jaro.rs:168,176,185) depends on j and the
@@ -150,21 +186,31 @@ __device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_
     uint32_t t16 = 0;
     uint64_t cur[G], nxt[G];
 #pragma unroll
-    for (int b = 0; b < G; ++b) cur[b] = lds_pm0[chunk_byte(c, b)];
+    for (int b = 0; b < G; ++b) cur[b] = jaro_pm_row(lds_pm0, c, b);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) {
 #pragma unroll
-            for (int b = 0; b < G; ++b) nxt[b] = lds_pm0[chunk_byte(c, (g + 1) * G + b)];
+            for (int b = 0; b < G; ++b) nxt[b] = jaro_pm_row(lds_pm0, c, (g + 1) * G + b);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) {
             if (kFull || (uint32_t)(g * G + b) < cols) {
                 const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], wrow[g * G + b], st.p_flag);  // PM & window & ~P
-                const uint64_t below = pm_j - 1;
+                const uint64_t below = dec64(pm_j);
                 st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
-                t16 |= pm_j != 0 ? (1u << (g * G + b)) : 0u;           // jaro.rs:174 / :183
+#ifdef RF_JARO_OLD_TBIT
+                t16 |= pm_j != 0 ? (1u << (15 - (g * G + b))) : 0u;    // jaro.rs:174 / :183
+#else
+                // T bit of this column = (pm_j != 0) = the sign of pm_j | -pm_j, and -pm_j == ~below: one LUT on the high
+                // halves and one funnel shift that pushes the sign into t16 -- a 64-bit compare + select + or costs 4.7 ns
+                // per wavefront and SIMD on this chip, this 3.0 (tools/microbench_issue).  Column j lands on bit 15 - j.
+                const uint32_t y = (uint32_t)(pm_j >> 32) | ~(uint32_t)(below >> 32);
+                t16 = __builtin_amdgcn_alignbit(t16, y, 31);           // (t16 << 1) | (y >> 31)      jaro.rs:174 / :183
+#endif
+            } else {
+                t16 <<= 1;
             }
         }
 #pragma unroll
@@ -186,23 +232,23 @@ __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const ui
 {
     constexpr int G = kJaroGroup, NG = kChunk / G;
     const uint32_t thalf = (j0 & 32) ? (uint32_t)(st.t_flag >> 32) : (uint32_t)st.t_flag;
-    const uint32_t t16 = thalf >> (j0 & 16);  // this chunk's T bits at positions 0..15 (no scalar address arithmetic per column)
+    const uint32_t t16 = thalf >> (j0 & 16);  // this chunk's T bits, column j at position 15 - j (no scalar address arithmetic per column)
     uint64_t cur[G], nxt[G];
 #pragma unroll
-    for (int b = 0; b < G; ++b) cur[b] = lds_pm0[chunk_byte(c, b)];
+    for (int b = 0; b < G; ++b) cur[b] = jaro_pm_row(lds_pm0, c, b);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) {
 #pragma unroll
-            for (int b = 0; b < G; ++b) nxt[b] = lds_pm0[chunk_byte(c, (g + 1) * G + b)];
+            for (int b = 0; b < G; ++b) nxt[b] = jaro_pm_row(lds_pm0, c, (g + 1) * G + b);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) {
             if (kFull || (uint32_t)(g * G + b) < cols) {
-                const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)t16, g * G + b, 1);  // all ones iff T bit j
+                const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)t16, 15 - (g * G + b), 1);  // all ones iff T bit j
                 const uint64_t f = ((uint64_t)f32 << 32) | f32;
-                const uint64_t below = st.p_flag - 1;
+                const uint64_t below = dec64(st.p_flag);
                 const uint64_t m = lut3<T_ANDN_AND>(st.p_flag, below, f);  // lowest remaining pattern flag, if flagged
                 st.hits = lut3<T_OR_AND>(st.hits, cur[b], m);              // match iff PM[text char] has that bit
                 st.p_flag = lut3<T_AND_ORN>(st.p_flag, below, f);          // consume it, if flagged
@@ -222,19 +268,27 @@ __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const ui
 // The general epilogue (f64_metric_value: filters, cutoff back-translation) costs ~8 f64 divisions per candidate, a
 // quarter of this kernel's VALU time (rocprofv3: 24.8 VALU per column, ~21 of them the two passes).
 constexpr int kJaroTabStride = 66;  // doubles per table (65 used)
+// One STATIC LDS object per kernel: its address is a compile-time constant, so the pattern-table reads take their base in
+// the instruction's offset field (as dynamic `extern __shared__` memory the base was a relocation the compiler added to every
+// gather address with a v_add_u32 -- one VALU instruction per column and pass).
+struct JaroWordLds {
+    uint64_t pm0[256];                                   // block 0 of every row
+    double tabs[kJaroTabStride * (1 + kWavesPerBlock)];  // tab1 + one tab2 per wavefront (kFast)
+    uint64_t wtab[kWavesPerBlock * kWave];               // one window-mask table per wavefront
+};
 template <bool kUniform, bool kEarly, bool kFast>
-__device__ __forceinline__ void jaro_word_body(const ScanParams& p)
+__device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds& lds)
 {
     const uint32_t W = p.words;  // PM row stride; only block 0 is read on this path (jaro.rs:172, pm.get(0, ..))
-    extern __shared__ uint64_t lds_pm0[];  // 256 entries: block 0 of every row [+ tab1 + 4 x tab2 when kFast]
-    double* tab1 = reinterpret_cast<double*>(lds_pm0 + 256);
+    uint64_t* lds_pm0 = lds.pm0;
+    double* tab1 = lds.tabs;
     for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm0[p.sigma[i]] = p.pm[(size_t)i * W];  // renamed rows
     if (kFast && threadIdx.x < 65) tab1[threadIdx.x] = (double)threadIdx.x / (double)p.len1;
     __syncthreads();
     double* tab2 = tab1 + kJaroTabStride * (1 + uniform(threadIdx.x / kWave));
     uint32_t tab2_len = 0xFFFFFFFFu;
     // this wavefront's window-mask table (64 x u64), behind the f64 tables
-    uint64_t* wtab = reinterpret_cast<uint64_t*>(tab1 + kJaroTabStride * (1 + kWavesPerBlock)) + kWave * uniform(threadIdx.x / kWave);
+    uint64_t* wtab = lds.wtab + kWave * uniform(threadIdx.x / kWave);
     uint32_t wtab_bound = 0xFFFFFFFFu;
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -294,10 +348,14 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p)
         for (uint32_t k = 0; k < nch; ++k) {  // pass 1
             const uint4 nxt = tv.src[(size_t)(k + 1 < nch ? k + 1 : 0) * kWave + lane];  // next chunk, then chunk 0 again
             const uint32_t cols = len2 - k * kChunk;
+#ifndef RF_JX_NOPASS1
             if (cols >= (uint32_t)kChunk)
                 jaro_flag_chunk<true>(st, lds_pm0, wtab, cur, k * kChunk, kChunk);
             else
                 jaro_flag_chunk<false>(st, lds_pm0, wtab, cur, k * kChunk, cols);
+#else
+            st.p_flag |= cur.x;
+#endif
             if ((k & 1) || k + 1 == nch) {  // 32 columns (or the tail) done: bank their T bits
                 st.t_flag |= (uint64_t)st.tacc << ((k & 2) ? 32 : 0);
                 st.tacc = 0;
@@ -325,10 +383,14 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p)
             uint4 nxt = cur;
             if (k + 1 < nch) nxt = tv.src[(size_t)(k + 1) * kWave + lane];
             const uint32_t cols = len2 - k * kChunk;
+#ifndef RF_JX_NOPASS2
             if (cols >= (uint32_t)kChunk)
                 jaro_transpose_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk);
             else
                 jaro_transpose_chunk<false>(st, lds_pm0, cur, k * kChunk, cols);
+#else
+            st.hits |= cur.x;
+#endif
             cur = nxt;
         }
         r.transpositions = r.common - __popcll(st.hits);
@@ -373,12 +435,14 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p)
 template <bool kUniform, bool kEarly>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_kernel(const ScanParams p)
 {
-    jaro_word_body<kUniform, kEarly, false>(p);
+    __shared__ JaroWordLds lds;
+    jaro_word_body<kUniform, kEarly, false>(p, lds);
 }
 template <bool kUniform>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_fast_kernel(const ScanParams p)
 {
-    jaro_word_body<kUniform, false, true>(p);
+    __shared__ JaroWordLds lds;
+    jaro_word_body<kUniform, false, true>(p, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -712,8 +776,7 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
         const bool fast = !p.has_cutoff && p.jaro_tab != nullptr;  // the table epilogue (no cutoff to replay)
         auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : (fast ? jaro_word_fast_kernel<false> : jaro_word_kernel<false, false>))
                          : (early ? jaro_word_kernel<true, true> : (fast ? jaro_word_fast_kernel<true> : jaro_word_kernel<true, false>));
-        const size_t lds = 256 * sizeof(uint64_t) + (size_t)kJaroTabStride * (1 + kWavesPerBlock) * sizeof(double) + (size_t)kWavesPerBlock * kWave * sizeof(uint64_t);
-        hipLaunchKernelGGL(k, g, b, lds, stream, q);
+        hipLaunchKernelGGL(k, g, b, 0, stream, q);
     }
     q.tile_begin = std::max(p.jaro_split, p.tile_begin);
     q.tile_end = p.tile_end;

@@ -29,7 +29,7 @@ if "+topk" in what:
     fn = lambda: bc.topk_keys_device(corpus, 16, keys, out=out if "+out" in what else None, **kw)
 else:
     fn = lambda: bc.many(N.OP_SIMILARITY if is_f else N.OP_DISTANCE, corpus, out=out, **kw)
-for _ in range(3):
+for _ in range(int(os.environ.get("AB_WARMUP", 30))):
     fn()
 torch.cuda.synchronize()
 reps = int(os.environ.get("AB_REPS", 20))
