@@ -49,27 +49,19 @@ constexpr uint32_t T_NOR3 = ~(TA | TB | TC);         // ~(a | b | c)
 // Plain VALU on VGPR pairs: no memory counters, no hazard padding needed (guide 5.7).
 // (hipcc canonicalises x + x + 1 back into shift-or on split halves, hence the asm; it is plain VALU on VGPR
 // pairs: nothing to count, no hazard padding needed -- guide 5.7.)
-template <int CIN, int kNop = 0>
+template <int CIN>
 __device__ __forceinline__ uint64_t shl1_const(uint64_t x)
 {
     uint64_t r;
-    if (CIN && kNop)
-        asm("s_nop 0\n\tv_lshl_add_u64 %0, %1, 1, 1" : "=v"(r) : "v"(x));
-    else if (CIN)
+    if (CIN)
         asm("v_lshl_add_u64 %0, %1, 1, 1" : "=v"(r) : "v"(x));
     else
         asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
     return r;
 }
 // (x << 1) + y in one v_lshl_add_u64 (callers guarantee the terms are disjoint where an OR is meant)
-template <int kNop = 0>
 __device__ __forceinline__ uint64_t shl1_add(uint64_t x, uint64_t y)
 {
-    if (kNop) {
-        uint64_t r;
-        asm("s_nop 0\n\tv_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(x), "v"(y));
-        return r;
-    }
     // (asm: written as (x << 1) + y hipcc sometimes splits the add into {lo, 0} + {0, hi} partial sums -- two
     // v_lshl_add_u64 and two v_mov; the price of the asm is one s_nop of hazard padding after it)
     uint64_t r;
@@ -109,10 +101,6 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 //   D[len1][len2] = len2 + popcount(VP & valid) - popcount(VN & valid)        (D[0][len2] = len2)
 // which removes the per-column mask tests from the hot loop.
 // ---------------------------------------------------------------------------------------------------
-#ifndef RF_NOPMASK
-#define RF_NOPMASK 0
-#endif
-__device__ __forceinline__ void nop_tie(uint64_t& a, uint64_t& b) { asm volatile("s_nop 0" : "+v"(a), "+v"(b)); }
 template <int W>
 struct LevState {
     using Word = uint64_t;
@@ -146,38 +134,17 @@ struct LevState {
             uint64_t x = pm_row[w];
             if (w > 0) x |= hn_c;                            // :847
             const uint64_t p = vp[w], n = vn[w];
-#if RF_NOPMASK & 1
-            uint64_t sum;
-            asm("s_nop 0\n\tv_lshl_add_u64 %0, %1, 0, %2" : "=v"(sum) : "v"(x & p), "v"(p));
-#else
             const uint64_t sum = (x & p) + p;
-#endif
             const uint64_t e = lut3<T_XOR_OR>(sum, p, x);    // (sum ^ vp) | x;  d0 = e | vn (:848)
             // (source order matters to the schedule: with hn computed AFTER the asm shift the s_nop of hazard padding
             // behind the asm disappears, and the kernel gets 1.5 % slower -- measured A/B, twice)
-#if RF_NOPMASK & 2
-            uint64_t e_ = e;
-            uint64_t hp = lut3<T_OR_NOR>(n, e, p);
-            nop_tie(hp, e_);
-            const uint64_t hn = e_ & p;
-#else
             const uint64_t hn = e & p;                       // :852
-            uint64_t hp = lut3<T_OR_NOR>(n, e, p);     // vn | ~(d0 | vp) == vn | ~(e | vp)   (:851)
-#endif
-            uint64_t hps = w == 0 ? shl1_const<1, (RF_NOPMASK >> 2) & 1>(hp) : shl1_add(hp, (uint64_t)hp_c);  // :865-866
+            const uint64_t hp = lut3<T_OR_NOR>(n, e, p);     // vn | ~(d0 | vp) == vn | ~(e | vp)   (:851)
+            const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_add(hp, (uint64_t)hp_c);  // :865-866
             if (w + 1 < W) hp_c = (uint32_t)(hp >> 63);      // :857-858
-#if RF_NOPMASK & 8
-            uint64_t t = lut3<T_NOR3>(e, n, hps);      // ~(d0 | hp)
-            nop_tie(t, hps);
-            vn[w] = lut3<T_AND_OR>(hps, e, n);               // hp & d0                            (:869)
-#else
             vn[w] = lut3<T_AND_OR>(hps, e, n);               // hp & d0                            (:869)
             const uint64_t t = lut3<T_NOR3>(e, n, hps);      // ~(d0 | hp)
-#endif
-            uint64_t v = shl1_add<(RF_NOPMASK >> 4) & 1>(hn, t);                    // hn | ~(d0 | hp), hn shifted          (:868)
-#if RF_NOPMASK & 32
-            nop_tie(v, vn[w]);
-#endif
+            uint64_t v = shl1_add(hn, t);                    // hn | ~(d0 | hp), hn shifted          (:868)
             if (w > 0) v |= hn_c;                            // bit 0 of T is clear when hn_c is set (x |= hn_c above)
             if (w + 1 < W) hn_c = (uint32_t)(hn >> 63);
             vp[w] = v;
@@ -854,46 +821,6 @@ __device__ __forceinline__ void process_chunk_full(State& st, const typename Sta
 #pragma unroll
             for (int w = 0; w < W; ++w) cur[j][w] = nxt[j][w];
     }
-}
-
-// The same 16 columns with the look-ahead carried ACROSS chunks: `first` holds the table rows of this chunk's first group
-// (read while the previous chunk was still being computed) and leaves holding those of `next`'s first group, so a chunk
-// never starts by waiting for an LDS round trip.
-template <class State>
-__device__ __forceinline__ void process_chunk_xpipe(State& st, const typename State::Word* lds_pm, const uint4& c,
-                                                    typename State::Word (&first)[State::kWords == 1 ? 4 : (State::kWords == 2 ? 2 : 1)][State::kWords],
-                                                    const uint4& next)
-{
-    using Word = typename State::Word;
-    constexpr int W = State::kWords;
-    constexpr int kGroup = W == 1 ? 4 : (W == 2 ? 2 : 1);
-    constexpr int kGroups = kChunk / kGroup;
-    const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
-    Word nxt[kGroup][W];
-#pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-            const int n = (g + 1) * kGroup + j;
-            const uint32_t src = g + 1 < kGroups ? dw[n / 4] : (j / 4 == 0 ? next.x : next.y);  // kGroup <= 4: the next chunk's first dword
-            load_pm<Word, W>(nxt[j], lds_pm, (src >> (8 * (n % 4))) & 0xFFu);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) st.step(first[j]);
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j)
-#pragma unroll
-            for (int w = 0; w < W; ++w) first[j][w] = nxt[j][w];
-    }
-}
-template <class State>
-__device__ __forceinline__ void load_first_group(typename State::Word (&first)[State::kWords == 1 ? 4 : (State::kWords == 2 ? 2 : 1)][State::kWords],
-                                                 const typename State::Word* lds_pm, const uint4& c)
-{
-    constexpr int kGroup = State::kWords == 1 ? 4 : (State::kWords == 2 ? 2 : 1);
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) load_pm<typename State::Word, State::kWords>(first[j], lds_pm, (c.x >> (8 * j)) & 0xFFu);
 }
 
 template <class State>

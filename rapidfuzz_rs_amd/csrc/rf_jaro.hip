@@ -129,24 +129,12 @@ struct JaroWordState {
 
 // (PM rows are fetched kJaroGroup symbols ahead of their use; 2 rather than the scans' 4 saves 8 VGPRs, and with 7-8
 // wavefronts per SIMD the LDS latency is covered either way)
-#ifndef RF_JARO_GROUP
-#define RF_JARO_GROUP 2
-#endif
-constexpr int kJaroGroup = RF_JARO_GROUP;
-__device__ __forceinline__ uint32_t chunk_byte(const uint4& c, int n)
-{
-    const uint32_t dw = n < 4 ? c.x : (n < 8 ? c.y : (n < 12 ? c.z : c.w));
-    return (dw >> (8 * (n % 4))) & 0xFFu;
-}
-
+constexpr int kJaroGroup = 2;
 // Row of the (single-block) pattern table for column n of a chunk.  The byte offset sym * 8 is ONE v_lshlrev_b32_sdwa (the
 // byte select and the shift in one half-rate instruction); written as `(dw >> 8k) & 0xFF` and indexed, hipcc emits
 // v_bfe_u32 + v_lshl_add_u32 here -- two half-rate instructions (tools/microbench_issue: 1.85 ns each per wavefront and SIMD).
 __device__ __forceinline__ uint64_t jaro_pm_row(const uint64_t* lds_pm0, const uint4& c, int n)
 {
-#ifdef RF_JARO_OLD_GATHER
-    return lds_pm0[chunk_byte(c, n)];
-#else
     const uint32_t dw = n < 4 ? c.x : (n < 8 ? c.y : (n < 12 ? c.z : c.w));
     uint32_t off;
     switch (n % 4) {
@@ -156,20 +144,15 @@ __device__ __forceinline__ uint64_t jaro_pm_row(const uint64_t* lds_pm0, const u
     default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(3u), "v"(dw)); break;
     }
     return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(lds_pm0) + off);
-#endif
 }
 
 // x - 1 on an aligned register pair (hipcc otherwise feeds v_lshl_add_u64 a pair with a stale high half and repairs the
 // result with an extra v_add_u32 per column)
 __device__ __forceinline__ uint64_t dec64(uint64_t x)
 {
-#ifdef RF_JARO_NO_DEC_ASM
-    return x - 1;
-#else
     uint64_t r;
     asm("v_lshl_add_u64 %0, %1, 0, -1" : "=v"(r) : "v"(x));
     return r;
-#endif
 }
 
 // Pass 1 over one 16-column chunk.  The sliding window mask of column j (jaro.rs:168,176,185) depends on j and the
@@ -200,15 +183,11 @@ __device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_
                 const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], wrow[g * G + b], st.p_flag);  // PM & window & ~P
                 const uint64_t below = dec64(pm_j);
                 st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
-#ifdef RF_JARO_OLD_TBIT
-                t16 |= pm_j != 0 ? (1u << (15 - (g * G + b))) : 0u;    // jaro.rs:174 / :183
-#else
                 // T bit of this column = (pm_j != 0) = the sign of pm_j | -pm_j, and -pm_j == ~below: one LUT on the high
                 // halves and one funnel shift that pushes the sign into t16 -- a 64-bit compare + select + or costs 4.7 ns
                 // per wavefront and SIMD on this chip, this 3.0 (tools/microbench_issue).  Column j lands on bit 15 - j.
                 const uint32_t y = (uint32_t)(pm_j >> 32) | ~(uint32_t)(below >> 32);
                 t16 = __builtin_amdgcn_alignbit(t16, y, 31);           // (t16 << 1) | (y >> 31)      jaro.rs:174 / :183
-#endif
             } else {
                 t16 <<= 1;
             }
@@ -348,14 +327,10 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
         for (uint32_t k = 0; k < nch; ++k) {  // pass 1
             const uint4 nxt = tv.src[(size_t)(k + 1 < nch ? k + 1 : 0) * kWave + lane];  // next chunk, then chunk 0 again
             const uint32_t cols = len2 - k * kChunk;
-#ifndef RF_JX_NOPASS1
             if (cols >= (uint32_t)kChunk)
                 jaro_flag_chunk<true>(st, lds_pm0, wtab, cur, k * kChunk, kChunk);
             else
                 jaro_flag_chunk<false>(st, lds_pm0, wtab, cur, k * kChunk, cols);
-#else
-            st.p_flag |= cur.x;
-#endif
             if ((k & 1) || k + 1 == nch) {  // 32 columns (or the tail) done: bank their T bits
                 st.t_flag |= (uint64_t)st.tacc << ((k & 2) ? 32 : 0);
                 st.tacc = 0;
@@ -383,14 +358,10 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
             uint4 nxt = cur;
             if (k + 1 < nch) nxt = tv.src[(size_t)(k + 1) * kWave + lane];
             const uint32_t cols = len2 - k * kChunk;
-#ifndef RF_JX_NOPASS2
             if (cols >= (uint32_t)kChunk)
                 jaro_transpose_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk);
             else
                 jaro_transpose_chunk<false>(st, lds_pm0, cur, k * kChunk, cols);
-#else
-            st.hits |= cur.x;
-#endif
             cur = nxt;
         }
         r.transpositions = r.common - __popcll(st.hits);

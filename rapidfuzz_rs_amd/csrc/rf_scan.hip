@@ -10,10 +10,6 @@
 
 namespace rf {
 
-#ifndef RF_STREAM_DEPTH
-#define RF_STREAM_DEPTH 1
-#endif
-
 template <class State, bool kUniform>
 __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
 {
@@ -180,11 +176,7 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
         TileView fv = load_tile<kUniform>(p, ft);
         uint32_t fn = max(1u, (fv.len + kChunk - 1) / kChunk);
         auto fetch = [&]() {
-#ifdef RF_EXP_NOHBM  // experiment: every fetch re-reads the wavefront's first chunk (cache hit) -- results are wrong
-            const uint4 v = load_chunk((const uint4*)p.data + lane + (size_t)(blockIdx.x & 1023) * kWave);
-#else
             const uint4 v = load_chunk(fv.src + (size_t)fc * kWave + lane);
-#endif
             if (++fc == fn) {
                 const uint32_t nt = ft + stride;
                 if (nt < p.tile_end) {
@@ -213,41 +205,22 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
         State st;
         st.init();
         bool done = false;
-#ifdef RF_XCHUNK
-        typename State::Word first[W == 1 ? 4 : (W == 2 ? 2 : 1)][W];
-        load_first_group<State>(first, lds_pm, buf[0]);
-        auto step = [&](const uint4& use, uint4& refill, const uint4& next_use) {
-#else
         auto step = [&](const uint4& use, uint4& refill) {
-#endif
             refill = fetch();
             const uint32_t len2 = cur_tile.len;
             const uint32_t nch = (len2 + kChunk - 1) / kChunk;
             const uint32_t cols = len2 - c * kChunk;
-#ifdef RF_XCHUNK
-            if (cols >= kChunk) {
-                process_chunk_xpipe<State>(st, lds_pm, use, first, next_use);
-            } else {
-                if (nch) process_chunk_tail<State>(st, lds_pm, use, cols);
-                load_first_group<State>(first, lds_pm, next_use);
-            }
-#else
             if (cols >= kChunk)
                 process_chunk_full<State>(st, lds_pm, use);
             else if (nch)
                 process_chunk_tail<State>(st, lds_pm, use, cols);
-#endif
             if (++c < max(1u, nch)) return;
 
             // tile finished
             const uint32_t slot = cur_tile.slot0 + lane;
             const bool valid = kUniform ? slot < p.n : idx != kPad;
             const uint32_t raw = st.result(p.len1, len2);
-#ifdef RF_EXP_NOSTORE  // experiment: one store per wavefront instead of 64 per tile
-            if (p.out && valid && raw == 0x12345u) emit_usize(p, raw, len2, idx);
-#else
             if (p.out && valid) emit_usize(p, raw, len2, idx);
-#endif
             if (topk) {
                 bool keep;
                 const uint32_t v = usize_value(p, raw, len2, &keep, p.len1);
@@ -273,11 +246,7 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
         while (!done) {
 #pragma unroll
             for (int ph = 0; ph <= kDepth; ++ph) {
-#ifdef RF_XCHUNK
-                step(buf[ph], buf[(ph + kDepth) % (kDepth + 1)], buf[(ph + 1) % (kDepth + 1)]);
-#else
                 step(buf[ph], buf[(ph + kDepth) % (kDepth + 1)]);
-#endif
                 if (done) break;
             }
         }
@@ -460,9 +429,9 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
         static const bool use_stream = [] { const char* e = getenv("RF_STREAM"); return !e || atoi(e) != 0; }();
         if (!p.early && use_stream) {
             if (p.tiles)
-                hipLaunchKernelGGL((stream_kernel_occ8<State, false, RF_STREAM_DEPTH>), g, b, 0, stream, p);
+                hipLaunchKernelGGL((stream_kernel_occ8<State, false, 1>), g, b, 0, stream, p);
             else
-                hipLaunchKernelGGL((stream_kernel_occ8<State, true, RF_STREAM_DEPTH>), g, b, 0, stream, p);
+                hipLaunchKernelGGL((stream_kernel_occ8<State, true, 1>), g, b, 0, stream, p);
             return hipGetLastError();
         }
         if (p.early) {

@@ -68,7 +68,6 @@ K["addc_chain_vcc"] = rep(["v_addc_co_u32 v16, vcc, v1, v6, vcc"], 32)
 K["bfe_i32"] = rep([f"v_bfe_i32 v{16 + i}, v1, 3, 1" for i in range(8)])
 K["sub_and_mask_trick"] = rep([x for i in range(4) for x in (f"v_and_b32 v{16 + i}, 1, v6", f"v_sub_u32 v{16 + i}, 0, v{16 + i}")])
 for nm, fmt in MORE.items(): K2[nm] = ind(fmt)
-K2 = {k: v for k, v in K2.items() if k.startswith('v_cndmask')}
 
 def mix(nv, ns, sop):
     v = [f"v_and_b32 v{16 + i % 8}, v1, v6" for i in range(nv)]
