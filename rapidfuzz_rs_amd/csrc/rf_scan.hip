@@ -5,6 +5,7 @@
 //   topk_final_kernel             selection of the k best candidate keys
 // Device helpers live in rf_device.hpp; the long-pattern, generalized-weights and Jaro kernels in rf_long.hip / rf_jaro.hip.
 #include <atomic>
+#include <type_traits>
 
 #include "rf_device.hpp"
 
@@ -428,6 +429,10 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
         // on every metric: these kernels are issue-bound, not latency-bound); RF_STREAM=0 selects scan_body for A/B.
         static const bool use_stream = [] { const char* e = getenv("RF_STREAM"); return !e || atoi(e) != 0; }();
         if (!p.early && use_stream) {
+            // the headline case has its chunk in hand-scheduled asm (rf_lev_asm.hip); RF_ASM_CHUNK=0 selects the compiled loop
+            static const bool use_asm = [] { const char* e = getenv("RF_ASM_CHUNK"); return !e || atoi(e) != 0; }();
+            if (std::is_same<State, LevState<1>>::value && !p.tiles && use_asm && p.uniform_len >= (uint32_t)kChunk && p.uniform_len % kChunk == 0)
+                return launch_lev1_asm(p, stream, grid);
             if (p.tiles)
                 hipLaunchKernelGGL((stream_kernel_occ8<State, false, 1>), g, b, 0, stream, p);
             else

@@ -1,0 +1,41 @@
+"""rf_lev_asm.hip keeps its recurrence state and look-ahead table rows in PHYSICAL registers (v34..v49, v60..v63) between asm
+blocks (register-asm variables that are in/out operands of every block, so the compiler knows they are live) and uses
+v30..v33 / v50..v59 as scratch inside the blocks.  Checked here on the compiler's own output (no GPU needed): nothing outside
+the asm statements of that kernel reads or writes the pinned registers -- in particular no copies in and out around the blocks,
+which is what any C++ use of those variables produces -- and the resource limits the launch relies on hold."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+_P = r"(3[4-9]|4[0-9]|6[0-3])"
+PINNED = re.compile(rf"\bv{_P}\b|\bv\[{_P}:|\bv\[\d+:{_P}\]")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_compiler_never_touches_the_pinned_registers(tmp_path):
+    src = os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc")
+    out = tmp_path / "rf_lev_asm.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function", "-S", "--cuda-device-only",
+                    "-o", str(out), os.path.join(src, "rf_lev_asm.hip")], check=True, stderr=subprocess.DEVNULL)
+    lines = out.read_text().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN2rf15lev1_asm_kernelENS_10ScanParamsE:"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    in_asm, blocks, offenders = False, 0, []
+    for l in lines[start:end]:
+        if "ASMSTART" in l:
+            in_asm, blocks = True, blocks + 1
+        elif "ASMEND" in l:
+            in_asm = False
+        elif not in_asm and not l.strip().startswith(";") and PINNED.search(l):
+            offenders.append(l.strip())
+    assert blocks >= 4  # prologue, chunk blocks, state init, result
+    assert offenders == [], offenders[:5]
+    meta = "\n".join(lines[end : end + 80])
+    assert re.search(r"; ScratchSize: 0\b", meta), "the asm kernel must not spill"
+    assert re.search(r"; Occupancy: 8\b", meta), "the asm kernel is budgeted for 8 wavefronts per SIMD"
+    assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= 64

@@ -1659,3 +1659,37 @@ def test_results_beyond_u32_are_refused_not_wrapped():
     with pytest.raises(rf.RfError) as e:
         bc.distance_many(corpus, weights=(60000, 60000, 60000))  # 60000 x 80000 symbols does not fit u32
     assert e.value.status == N.RF_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("len2", [16, 32, 48, 64, 96, 160])
+def test_asm_chunk_kernel_single_length_corpora(len2):
+    """rf_lev_asm.hip (the 16-column chunk of the single-word Levenshtein scan in hand-scheduled asm) serves every single-length
+    corpus whose length is a multiple of 16 when there is no cutoff: every op, query lengths 1..64, candidates that share long
+    runs with the query, odd candidate counts (a partial last tile), and the in-scan top-k -- against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(len2)
+    n = 20_011
+    for len1 in (1, 5, 31, 32, 33, 63, 64):
+        lo, hi = (97, 105) if len1 % 2 else (33, 127)  # a small and a large alphabet (table rows all over the 2 KiB table)
+        q = bytes(rng.integers(lo, hi, size=len1, dtype=np.uint8))
+        host = rng.integers(lo, hi, size=(n, len2), dtype=np.uint8)
+        qa = np.frombuffer(q, dtype=np.uint8)
+        for r in range(0, n, 97):  # plant the query (cyclically repeated / cut) with a few edits
+            row = np.resize(qa, len2).copy()
+            row[rng.integers(0, len2, size=r % 5)] = 122
+            if r % 2: row = np.roll(row, 1)  # and shifted by one: insertions / deletions, not only substitutions
+            host[r] = row
+        corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
+        bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
+        for opname, op in OPS.items():
+            got = bc.many(op, corpus)
+            exp = ob.rows(op, host, nthreads=8)
+            if got.dtype == np.uint32:
+                assert (got == _expect_u32(exp)).all(), (len1, len2, opname)
+            else:
+                assert (got == exp).all(), (len1, len2, opname)
+        dist = ob.rows(N.OP_DISTANCE, host, nthreads=8)
+        order = np.lexsort((np.arange(n), dist))[:16]
+        s, i = bc.topk(corpus, 16)
+        assert list(zip(s.tolist(), i.tolist())) == [(int(dist[j]), int(j)) for j in order], (len1, len2)

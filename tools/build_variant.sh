@@ -4,7 +4,7 @@
 set -e
 NAME=$1; FLAGS=${2:-}
 SRC=rapidfuzz_rs_amd/csrc; OBJ=/tmp/rf_variant_$NAME; mkdir -p $OBJ
-for f in rf_api rf_scan rf_long rf_jaro rf_pack rf_probe rf_select rf_mixed rf_band; do
+for f in rf_api rf_scan rf_long rf_jaro rf_pack rf_probe rf_select rf_mixed rf_band rf_lev_asm; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o &
 done
 wait
