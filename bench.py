@@ -386,6 +386,9 @@ def main():
                                                  "source": "rf_probe_issue_rate in this run: the product's State::step on register-resident PM words, 8 workgroups/CU"}
             if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 1, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
                 result["roofline"]["issue_bound"]["ceiling_with_lds_gather"] = round(rate.value * 64.0 / max(ln, 1), 3)
+            if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 2, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
+                # the kernel's own hand-scheduled chunk (rf_lev_asm.hip) with LDS gathers but no HBM traffic and no tile loop
+                result["roofline"]["issue_bound"]["ceiling_asm_chunk"] = round(rate.value * 64.0 / max(ln, 1), 3)
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,

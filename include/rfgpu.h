@@ -284,7 +284,8 @@ rf_status rf_topk_merge_u32(rf_op op, const uint32_t *scores, const uint64_t *in
  * 64-symbol candidates is the Gpairs/s no scan of that recurrence can exceed on this device.  bench.py reports it as
  * roofline.issue_bound, measured in the same process as the scan.  mode 0: pattern words from registers (the pure
  * recurrence); mode 1: the scans' own chunk code -- byte extraction and the pattern-table gather from LDS over 62 random
- * symbols -- still without HBM traffic or a tile loop.  Synchronous; uses the default stream. */
+ * symbols -- still without HBM traffic or a tile loop; mode 2 (Levenshtein, 33..64 query symbols): the hand-scheduled asm
+ * chunk of the headline kernel (rf_lev_asm.hip) alone, the same way.  Synchronous; uses the default stream. */
 rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, uint32_t mode, int device, uint32_t blocks_per_cu,
                               double *wave_columns_per_ns);
 

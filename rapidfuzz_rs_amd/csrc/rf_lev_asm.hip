@@ -150,4 +150,49 @@ hipError_t launch_lev1_asm(const ScanParams& p, hipStream_t stream, int grid)
     return hipGetLastError();
 }
 
+// Measurement probe (rf_probe_issue_rate mode 2): the very asm block of the kernel above in a loop -- table rows gathered from
+// LDS, look-ahead carried from iteration to iteration -- with the chunk's dwords constant: no HBM traffic, no tile loop.
+__global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void lev1_asm_probe_kernel(uint32_t* out, int iters, uint32_t seed)
+{
+    __shared__ LevAsmLds lds;
+    for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds.pm[i] = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    __syncthreads();
+    uint32_t h = (threadIdx.x + 1) * 2654435761u + seed, dw[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            h = h * 1664525u + 1013904223u;
+            v |= ((h >> 16) % 62u) << (8 * b);
+        }
+        dw[d] = v;
+    }
+    const uint32_t three = 3u;
+    register uint32_t vpl asm("v60"), vph asm("v61"), vnl asm("v62"), vnh asm("v63");
+    register uint32_t r34 asm("v34"), r35 asm("v35"), r36 asm("v36"), r37 asm("v37"), r38 asm("v38"), r39 asm("v39"), r40 asm("v40"), r41 asm("v41");
+    register uint32_t r42 asm("v42"), r43 asm("v43"), r44 asm("v44"), r45 asm("v45"), r46 asm("v46"), r47 asm("v47"), r48 asm("v48"), r49 asm("v49");
+#define RF_ROWS(c) c(r34), c(r35), c(r36), c(r37), c(r38), c(r39), c(r40), c(r41), c(r42), c(r43), c(r44), c(r45), c(r46), c(r47), c(r48), c(r49)
+#define RF_OUT(r) "=v"(r)
+#define RF_INOUT(r) "+v"(r)
+    asm volatile("v_mov_b32 %0, -1\n\tv_mov_b32 %1, -1\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(vpl), "=v"(vph), "=v"(vnl), "=v"(vnh));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_LEV_PROLOGUE_ASM : RF_ROWS(RF_OUT) : [c0] "v"(dw[0]), [c1] "v"(dw[1]), [k3] "v"(three) : "v30", "v31", "v32", "v33");
+    for (int i = 0; i < iters; ++i)
+        asm volatile(RF_LEV_CHUNK_VARIANT
+                     : "+v"(vpl), "+v"(vph), "+v"(vnl), "+v"(vnh), RF_ROWS(RF_INOUT)
+                     : [c2] "v"(dw[2]), [c3] "v"(dw[3]), [n0] "v"(dw[0]), [n1] "v"(dw[1]), [k3] "v"(three)
+                     : RF_LEV_CHUNK_CLOBBERS);
+    uint32_t sink;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(sink) : "v"(vpl), "v"(vnh));
+    if ((int)threadIdx.x == iters) out[0] = sink;  // never true, keeps the state live
+#undef RF_INOUT
+#undef RF_OUT
+#undef RF_ROWS
+}
+
+void launch_lev1_asm_probe(dim3 g, dim3 b, uint32_t* out, int iters, uint32_t seed)
+{
+    hipLaunchKernelGGL(lev1_asm_probe_kernel, g, b, 0, 0, out, iters, seed);
+}
+
 }  // namespace rf

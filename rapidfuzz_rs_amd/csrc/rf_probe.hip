@@ -6,6 +6,7 @@
 // come from registers: no HBM traffic, no LDS gather, no byte extraction, no tile bookkeeping.  bench.py calls the probe
 // in the same process and reports `roofline.issue_bound` from it, so the ceiling can never go stale against the kernel.
 #include "rf_device.hpp"
+#include "rf_internal.hpp"
 
 namespace rf {
 
@@ -80,6 +81,8 @@ static hipError_t probe_run(uint32_t mode, int blocks_per_cu, int iters, double*
     auto launch = [&](int n, uint32_t seed) {
         if (mode == 0)
             hipLaunchKernelGGL((probe_regs_kernel<State>), g, b, 0, 0, d_out, n, seed);
+        else if (mode == 2)
+            launch_lev1_asm_probe(g, b, d_out, n, seed);
         else
             hipLaunchKernelGGL((probe_lds_kernel<State>), g, b, 0, 0, d_out, n, seed, 62u);
     };
@@ -108,7 +111,8 @@ static hipError_t probe_run(uint32_t mode, int blocks_per_cu, int iters, double*
 
 hipError_t launch_probe(RawKind raw, uint32_t len1, uint32_t mode, int blocks_per_cu, int iters, double* wave_columns_per_ns)
 {
-    if (mode > 1) return hipErrorInvalidValue;
+    if (mode > 2) return hipErrorInvalidValue;
+    if (mode == 2 && !(raw == RAW_LEV && len1 > 32 && len1 <= 64)) return hipErrorInvalidValue;  // the asm chunk exists for LevState<1> only
     switch (raw) {
     case RAW_LEV:
         if (len1 <= 32) return probe_run<Lev32State>(mode, blocks_per_cu, iters, wave_columns_per_ns);
