@@ -51,7 +51,7 @@ for v in lev64 lev64+topk lev64+topk+out indel indel+topk jw; do python tools/ab
 python - > gpurun_out/profiles/clock_ramp_$R.txt <<PY
 import sqlite3
 cur = sqlite3.connect("/tmp/kt_ramp_$R/kt_results.db").cursor()
-d = [(e - s) / 1e3 for n, s, e in cur.execute("select name, start, end from kernels order by start") if ("stream_kernel" in n or "lev1_asm" in n) and e - s > 1_000_000]
+d = [(e - s) / 1e3 for n, s, e in cur.execute("select name, start, end from kernels order by start") if ("stream_kernel" in n or "lev1_asm_kernel" in n) and e - s > 1_000_000]
 print("python bench.py --steps 40 --warmup 0 --settle-ms 0 under rocprofv3 --kernel-trace: duration (us) of each back-to-back scan launch after the idle set-up phase")
 print(" ".join(f"{x:.0f}" for x in d))
 print(f"first 5 avg {sum(d[:5]) / 5:.0f} us; launches 20+ avg {sum(d[20:]) / max(1, len(d[20:])):.0f} us -> bench.py runs --settle-ms (default 200) of untimed steps before the W warm-up steps and reports config.settle_steps")
