@@ -580,8 +580,16 @@ struct WaveTopK {
         // (a wavefront's first tile, the workgroup merge, the collectors) latency-bound at ~0.2 us per inserted key.
         const uint32_t up_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)key, 0x138, 0xF, 0xF, false);
         const uint32_t up_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(key >> 32), 0x138, 0xF, 0xF, false);
-        const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
-        key = lane > pos ? up : (lane == pos ? x : key);
+        // key = lane > pos ? up : (lane == pos ? x : key), with the two lane masks built on the scalar unit (pos is uniform) and
+        // selected through SGPR pairs: written as `?:` on 64-bit values hipcc emits pairs of VOP2 v_cndmask_b32 ..., vcc, and two
+        // of those back to back cost ~10 ns each on this chip (profiles/issue_rates_r02.txt)
+        const uint64_t at = pos < 64 ? 1ull << pos : 0ull, above = pos < 63 ? ~0ull << (pos + 1) : 0ull;
+        uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        asm("v_cndmask_b32 %0, %0, %2, %6\n\tv_cndmask_b32 %1, %1, %3, %6\n\tv_cndmask_b32 %0, %0, %4, %7\n\tv_cndmask_b32 %1, %1, %5, %7"
+            : "+v"(lo), "+v"(hi)
+            : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(up_lo), "v"(up_hi), "s"(at), "s"(above));  // (one SGPR operand per VALU instruction: x travels in VGPRs)
+        key = ((uint64_t)hi << 32) | lo;
+        (void)lane;
     }
     // Offer one key per lane (valid lanes only).  `limit` is wavefront-uniform: min(this list's worst key, any upper
     // bound on the launch's k-th best key) -- keys at or above it can never be in the answer.  The common case (no

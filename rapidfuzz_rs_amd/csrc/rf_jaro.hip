@@ -123,8 +123,10 @@ constexpr uint32_t T_AND_ORN = TA & (TB | ~TC);       // a & (b | ~c)
 //     PM word of the text character has that bit -- matched bits are OR-ed into `hits`, so
 //     transpositions = common - popcount(hits) with no per-column compare or count.
 struct JaroWordState {
-    uint64_t p_flag, t_flag, hits;
-    uint32_t tacc;  // T bits of the 32 columns currently being processed
+    uint64_t p_flag, hits;
+    uint32_t t_lo, t_hi;  // T bits of columns 0..31 / 32..63; chunk k's sixteen sit at bits (k & 1) * 16 .., column j on bit 15 - j
+                          // (two words steered by a scalar mask: a 64-bit conditional update compiles to a PAIR of VOP2
+                          // v_cndmask_b32, and two of those back to back cost ~10 ns each on this chip, profiles/issue_rates_r02.txt)
 };
 
 // (PM rows are fetched kJaroGroup symbols ahead of their use; 2 rather than the scans' 4 saves 8 VGPRs, and with 7-8
@@ -144,6 +146,19 @@ __device__ __forceinline__ uint64_t jaro_pm_row(const uint64_t* lds_pm0, const u
     default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(3u), "v"(dw)); break;
     }
     return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(lds_pm0) + off);
+}
+
+// c ? a : b for doubles through an SGPR-pair lane mask: as `c ? a : b` hipcc emits two VOP2 v_cndmask_b32 ..., vcc back to back,
+// which cost ~10 ns each on this chip (profiles/issue_rates_r02.txt); the e64 form with the mask in SGPRs is 1.9 ns
+__device__ __forceinline__ double select_f64(bool c, double a, double b)
+{
+    const uint64_t m = __ballot(c);
+    const uint64_t ua = (uint64_t)__double_as_longlong(a), ub = (uint64_t)__double_as_longlong(b);
+    uint32_t lo, hi;
+    asm("v_cndmask_b32 %0, %2, %3, %6\n\tv_cndmask_b32 %1, %4, %5, %6"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"((uint32_t)ub), "v"((uint32_t)ua), "v"((uint32_t)(ub >> 32)), "v"((uint32_t)(ua >> 32)), "s"(m));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 // x - 1 on an aligned register pair (hipcc otherwise feeds v_lshl_add_u64 a pair with a stale high half and repairs the
@@ -195,7 +210,9 @@ __device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_
 #pragma unroll
         for (int b = 0; b < G; ++b) cur[b] = nxt[b];
     }
-    st.tacc |= t16 << (j0 & 16);  // columns j0 .. j0 + 15 of the current 32-column half
+    const uint32_t v = t16 << (j0 & 16), in_lo = (j0 & 32) ? 0u : ~0u;  // j0 is wavefront-uniform: the mask is scalar
+    st.t_lo |= v & in_lo;
+    st.t_hi |= v & ~in_lo;
 }
 
 // the window mask of every column for this bound (closed form of the recurrence bm' = (bm << 1) | (j < bound) started
@@ -210,7 +227,8 @@ template <bool kFull>
 __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4 c, uint32_t j0, uint32_t cols)
 {
     constexpr int G = kJaroGroup, NG = kChunk / G;
-    const uint32_t thalf = (j0 & 32) ? (uint32_t)(st.t_flag >> 32) : (uint32_t)st.t_flag;
+    const uint32_t in_lo = (j0 & 32) ? 0u : ~0u;
+    const uint32_t thalf = (st.t_lo & in_lo) | (st.t_hi & ~in_lo);
     const uint32_t t16 = thalf >> (j0 & 16);  // this chunk's T bits, column j at position 15 - j (no scalar address arithmetic per column)
     uint64_t cur[G], nxt[G];
 #pragma unroll
@@ -306,8 +324,8 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
         }
 
         JaroWordState st;
-        st.p_flag = st.t_flag = st.hits = 0;
-        st.tacc = 0;
+        st.p_flag = st.hits = 0;
+        st.t_lo = st.t_hi = 0;
         if (bound != wtab_bound) {  // wavefront-uniform; this wavefront's own table: no barrier
             jaro_window_table(wtab, lane, bound);
             wtab_bound = bound;
@@ -331,10 +349,6 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
                 jaro_flag_chunk<true>(st, lds_pm0, wtab, cur, k * kChunk, kChunk);
             else
                 jaro_flag_chunk<false>(st, lds_pm0, wtab, cur, k * kChunk, cols);
-            if ((k & 1) || k + 1 == nch) {  // 32 columns (or the tail) done: bank their T bits
-                st.t_flag |= (uint64_t)st.tacc << ((k & 2) ? 32 : 0);
-                st.tacc = 0;
-            }
             if (early) {
                 const uint32_t j = min(len2, (k + 1) * kChunk);
                 const uint32_t m_ub = min((uint32_t)__popcll(st.p_flag) + (len2 - j), min(len1, len2));
@@ -386,9 +400,9 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
                 acc += tab2[r.common];
                 acc += p.jaro_tab[r.common * 33u + r.transpositions / 2u];
                 acc = acc / 3.0;
-                sim = r.common == 0 ? 0.0 : acc;                            // :579-581
+                sim = select_f64(r.common == 0, 0.0, acc);                  // :579-581
             }
-            if (p.finish == FIN_JW && sim > 0.7) sim += (double)r.prefix * p.prefix_weight * (1.0 - sim);  // jaro_winkler.rs:136-138
+            if (p.finish == FIN_JW) sim = select_f64(sim > 0.7, sim + (double)r.prefix * p.prefix_weight * (1.0 - sim), sim);  // jaro_winkler.rs:136-138
             double v = sim;                                                 // Metricf64 defaults, details/distance.rs:277-385
             if (p.op == RF_OP_DISTANCE || p.op == RF_OP_NORMALIZED_DISTANCE) v = 1.0 - sim;
             if (p.op == RF_OP_NORMALIZED_SIMILARITY) v = 1.0 - (1.0 - sim);
