@@ -1357,6 +1357,17 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         const double tight = *raw == RAW_LCS ? 0.4 : 0.7;
         if (slack < tight) {
             p->early = 1;
+            // where a tile's first chunk takes its first look (scan_body): unrelated strings gain almost one edit per column
+            {
+                static const int forced = [] { const char* e = getenv("RF_FIRST_CHECK"); return e ? atoi(e) : 0; }();  // A/B switch
+                const double raw_allowed = slack * maximum / (double)std::max<uint32_t>(1u, (uint32_t)std::abs(p->fin_dR));
+                // measured on the C2 corpus (cutoffs 0..12, looks at 4..16): the best look is the first even column >= cutoff + 3
+                // (cutoff 3: 195 -> 213 Gpairs/s, cutoff 0: 197 -> 233, cutoff 8: 125 -> 159)
+                const double need = raw_allowed + 3.0;
+                p->first_check = need <= 4.0 ? 4u : (need >= 15.0 ? 16u : 2u * (uint32_t)((need + 1.999) / 2.0));
+                if (*raw == RAW_LCS) p->first_check = 8;  // the LCS bound gains one per REMAINING column: a different curve, left as it was
+                if (forced >= 4 && forced <= 16 && forced % 2 == 0) p->first_check = (uint32_t)forced;
+            }
             // Length window: before any byte is read a candidate of length L already has a favourable bound -- distance >=
             // |len1 - L| (the reference's first test, levenshtein.rs:1389-1391), LCS <= min(len1, L).  Lengths whose bound
             // fails the cutoff (same arithmetic as may_pass() on the device) are never read: tiles ascend by length, so

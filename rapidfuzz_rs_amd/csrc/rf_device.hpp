@@ -807,23 +807,25 @@ __device__ __forceinline__ void process_chunk_full(State& st, const typename Sta
     using Word = typename State::Word;
     constexpr int W = State::kWords;
     constexpr int kGroup = W == 1 ? 4 : (W == 2 ? 2 : 1);
-    constexpr int kGroups = (J1 - J0) / kGroup;
+    constexpr int kGroups = (J1 - J0 + kGroup - 1) / kGroup;  // the last group may be partial (cutoff scans stop a chunk at column 4 or 6)
     const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
     Word cur[kGroup][W], nxt[kGroup][W];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) load_pm<Word, W>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
+    for (int j = 0; j < kGroup; ++j)
+        if (J0 + j < J1) load_pm<Word, W>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
         if (g + 1 < kGroups) {
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
                 const int n = J0 + (g + 1) * kGroup + j;
-                load_pm<Word, W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
+                if (n < J1) load_pm<Word, W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = 0; j < kGroup; ++j) st.step(cur[j]);
+        for (int j = 0; j < kGroup; ++j)
+            if (J0 + g * kGroup + j < J1) st.step(cur[j]);
 #pragma unroll
         for (int j = 0; j < kGroup; ++j)
 #pragma unroll

@@ -107,6 +107,7 @@ struct ScanParams {
     uint32_t* long_scratch;   // [grid * 4][long_chunks_max][64]
     // value-preserving early-out under a distance cutoff (levenshtein, u32 distance output / top-k)
     uint32_t early;
+    uint32_t first_check;           // column of the first early-out look inside a tile's first chunk: 4, 6 or 8 (plan())
     // band_kernel (rf_band.hip): long query, raw distance cutoff band_k with 2 * band_k + 1 <= 64; band = 1 selects it
     uint32_t band, band_k;
     // top-k mode (topk_k != 0): no per-candidate output, one k-entry key list per workgroup

@@ -72,13 +72,26 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                 const uint32_t cols = len2 - c * kChunk;
                 if (cols >= kChunk) {
                     if (early && c == 0) {
-                        // first chance to stop: after 8 columns a random candidate is already ~6 edits off
-                        process_chunk_full<State, 0, kChunk / 2>(st, lds_pm, cur);
-                        if (__ballot(may_pass(p, fin, st.bound(p.len1, kChunk / 2, len2))) == 0) {
-                            dead = true;
-                            break;
-                        }
-                        process_chunk_full<State, kChunk / 2, kChunk>(st, lds_pm, cur);
+                        // first chance to stop: an unrelated candidate gains almost one edit per column, so the first look is
+                        // taken a few columns past the cutoff (p.first_check = 4 ... 16, chosen by plan() from the raw
+                        // distance the cutoff still allows -- a choice of speed only, every look is value-preserving)
+#define RF_FIRST_LOOK(J)                                                                  \
+    {                                                                                     \
+        process_chunk_full<State, 0, J>(st, lds_pm, cur);                                 \
+        if (__ballot(may_pass(p, fin, st.bound(p.len1, J, len2))) == 0) {                 \
+            dead = true;                                                                  \
+            break;                                                                        \
+        }                                                                                 \
+        process_chunk_full<State, J, kChunk>(st, lds_pm, cur);                            \
+    }
+                        if (p.first_check == 4) RF_FIRST_LOOK(4)
+                        else if (p.first_check == 6) RF_FIRST_LOOK(6)
+                        else if (p.first_check == 10) RF_FIRST_LOOK(10)
+                        else if (p.first_check == 12) RF_FIRST_LOOK(12)
+                        else if (p.first_check == 14) RF_FIRST_LOOK(14)
+                        else if (p.first_check == 16) process_chunk_full<State>(st, lds_pm, cur);  // loose cutoff: the look at the chunk's end is the first
+                        else RF_FIRST_LOOK(8)
+#undef RF_FIRST_LOOK
                     } else {
                         process_chunk_full<State>(st, lds_pm, cur);
                     }

@@ -13,7 +13,10 @@ cfg = {
     "lev64": ("levenshtein", 64, 64, {}), "lev32": ("levenshtein", 32, 64, {}), "indel": ("indel", 64, 64, {}), "osa": ("osa", 64, 64, {}),
     "lev256": ("levenshtein", 256, 256, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
     "jaro": ("jaro", 64, 64, {}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
-}[what.split("+")[0]]
+}
+import re as _re
+_m = _re.fullmatch(r"lev64c(\d+)", what.split("+")[0])
+cfg = ("levenshtein", 64, 64, {"score_cutoff": int(_m.group(1))}) if _m else cfg[what.split("+")[0]]
 metric, qlen, clen, kw = cfg
 if clen == 256:
     n //= 10
