@@ -1365,7 +1365,12 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
                 // (cutoff 3: 195 -> 213 Gpairs/s, cutoff 0: 197 -> 233, cutoff 8: 125 -> 159)
                 const double need = raw_allowed + 3.0;
                 p->first_check = need <= 4.0 ? 4u : (need >= 15.0 ? 16u : 2u * (uint32_t)((need + 1.999) / 2.0));
-                if (*raw == RAW_LCS) p->first_check = 8;  // the LCS bound gains one per REMAINING column: a different curve, left as it was
+                if (*raw == RAW_LCS) {
+                    // the LCS bound loses one per column WITHOUT a match, and random strings still match every third column or so:
+                    // Indel cutoff 4 is best looked at in column 10-12 (221 -> 233 Gpairs/s), cutoff 12 not before the chunk's end
+                    const double misses = (p->finish == FIN_LCS ? slack * maximum : slack * maximum / 2.0), lcs_need = (misses + 3.0) / 0.55;
+                    p->first_check = lcs_need >= 15.0 ? 16u : std::max(4u, 2u * (uint32_t)((lcs_need + 1.999) / 2.0));
+                }
                 if (forced >= 4 && forced <= 16 && forced % 2 == 0) p->first_check = (uint32_t)forced;
             }
             // Length window: before any byte is read a candidate of length L already has a favourable bound -- distance >=

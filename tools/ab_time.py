@@ -16,7 +16,8 @@ cfg = {
 }
 import re as _re
 _m = _re.fullmatch(r"lev64c(\d+)", what.split("+")[0])
-cfg = ("levenshtein", 64, 64, {"score_cutoff": int(_m.group(1))}) if _m else cfg[what.split("+")[0]]
+_i = _re.fullmatch(r"indelc(\d+)", what.split("+")[0])
+cfg = ("levenshtein", 64, 64, {"score_cutoff": int(_m.group(1))}) if _m else (("indel", 64, 64, {"score_cutoff": int(_i.group(1))}) if _i else cfg[what.split("+")[0]])
 metric, qlen, clen, kw = cfg
 if clen == 256:
     n //= 10
