@@ -198,6 +198,14 @@ struct LevState {
         const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
         return (uint32_t)max(max(last_row, diag), 0);  // a LOWER bound on D[len1][len2]
     }
+    // the bound for the look taken in the MIDDLE of a tile's first chunk (scan_body): the diagonal term alone -- early in the
+    // tile the last-row term is just the length difference, which the host's length window has already applied -- at half the
+    // popcounts.  Weaker than bound() at worst, never wrong.
+    __device__ __forceinline__ uint32_t bound_first(uint32_t len1, uint32_t j, uint32_t len2) const
+    {
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;
+        return i > 0 ? result((uint32_t)i, j) : bound(len1, j, len2);
+    }
     // D[len1][len2] from the final column's vertical deltas (any row count <= len1 gives D[rows][len2])
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
@@ -311,6 +319,14 @@ struct OsaState {
         const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
         return (uint32_t)max(max(last_row, diag), 0);
     }
+    // the bound for the look taken in the MIDDLE of a tile's first chunk (scan_body): the diagonal term alone -- early in the
+    // tile the last-row term is just the length difference, which the host's length window has already applied -- at half the
+    // popcounts.  Weaker than bound() at worst, never wrong.
+    __device__ __forceinline__ uint32_t bound_first(uint32_t len1, uint32_t j, uint32_t len2) const
+    {
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;
+        return i > 0 ? result((uint32_t)i, j) : bound(len1, j, len2);
+    }
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
         int32_t d = (int32_t)len2;
@@ -383,6 +399,7 @@ struct LcsState {
     {
         return min(result(len1, j) + (len2 - j), min(len1, len2));
     }
+    __device__ __forceinline__ uint32_t bound_first(uint32_t len1, uint32_t j, uint32_t len2) const { return bound(len1, j, len2); }
     __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const
     {
         uint32_t sim = 0;
@@ -433,6 +450,14 @@ struct Lev32State {
         const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
         return (uint32_t)max(max(last_row, diag), 0);
     }
+    // the bound for the look taken in the MIDDLE of a tile's first chunk (scan_body): the diagonal term alone -- early in the
+    // tile the last-row term is just the length difference, which the host's length window has already applied -- at half the
+    // popcounts.  Weaker than bound() at worst, never wrong.
+    __device__ __forceinline__ uint32_t bound_first(uint32_t len1, uint32_t j, uint32_t len2) const
+    {
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;
+        return i > 0 ? result((uint32_t)i, j) : bound(len1, j, len2);
+    }
     __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
     {
         const uint32_t valid = len1 >= 32 ? ~0u : ((1u << len1) - 1);
@@ -457,6 +482,7 @@ struct Lcs32State {
     {
         return min(result(len1, j) + (len2 - j), min(len1, len2));
     }
+    __device__ __forceinline__ uint32_t bound_first(uint32_t len1, uint32_t j, uint32_t len2) const { return bound(len1, j, len2); }
     __device__ __forceinline__ uint32_t result(uint32_t, uint32_t) const { return __popc(~s); }
 };
 

@@ -78,7 +78,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
 #define RF_FIRST_LOOK(J)                                                                  \
     {                                                                                     \
         process_chunk_full<State, 0, J>(st, lds_pm, cur);                                 \
-        if (__ballot(may_pass(p, fin, st.bound(p.len1, J, len2))) == 0) {                 \
+        if (__ballot(may_pass(p, fin, st.bound_first(p.len1, J, len2))) == 0) {           \
             dead = true;                                                                  \
             break;                                                                        \
         }                                                                                 \
