@@ -384,6 +384,9 @@ def main():
             result["roofline"]["issue_bound"] = {"achieved": round(per_gpu, 3), "ceiling": round(ceiling, 3), "unit": "Gpairs/s",
                                                  "frac": round(per_gpu / ceiling, 4),
                                                  "source": "rf_probe_issue_rate in this run: the product's State::step on register-resident PM words, 8 workgroups/CU"}
+            if per_gpu > ceiling:
+                # (multi-word states: the probe holds W x the state at a lower occupancy than the scan kernel; 32-bit states: within noise)
+                result["roofline"]["issue_bound"]["note"] = "the register probe ran SLOWER than the kernel here: a reference point, not an upper bound"
             if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 1, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
                 result["roofline"]["issue_bound"]["ceiling_with_lds_gather"] = round(rate.value * 64.0 / max(ln, 1), 3)
             if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 2, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:

@@ -66,7 +66,12 @@ def v_bench(b):
         parallel.merge_keys_device(ak[b], 16, mk, stream=xchg.cuda_stream)
         bf[b] = torch.cuda.Event(); bf[b].record(xchg)
 run("  bench step verbatim", v_bench)
+run("  bench step verbatim, again", v_bench)
 dist.barrier(); torch.cuda.synchronize()
 run("  bench step verbatim, after a barrier", v_bench)
+run("  bench step verbatim, again (no barrier)", v_bench)
+time.sleep(0.001); run("  bench step verbatim, after 1 ms host sleep", v_bench)
+time.sleep(0.02); run("  bench step verbatim, after 20 ms host sleep", v_bench)
+run("  bench step verbatim, again", v_bench)
 run("plain distance_many again", lambda b: bc.distance_many(corpus, out=out, stream=cs))
 dist.destroy_process_group()
