@@ -1,5 +1,6 @@
 // rf_jaro.hip -- Jaro / Jaro-Winkler: flagging and transposition passes (jaro.rs:147-190, :192-420, :339-368), the
 // f64 epilogue replaying jaro.rs:516-598 / jaro_winkler.rs:103-141 / details/distance.rs:277-385 bit for bit.
+#include <cstddef>
 #include "rf_device.hpp"
 
 namespace rf {
@@ -747,6 +748,140 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_long_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The single-word Jaro kernel for the headline shape -- single-length corpus, no cutoff, candidate length (after the window
+// truncation) a multiple of 16 -- with both passes over a 16-column chunk as hand-scheduled asm blocks
+// (tools/gen_jaro_chunk_asm.py -> rf_jaro_chunk_asm.inc; same reasons and technique as rf_lev_asm.hip: dependent chains of
+// full- and half-rate instructions whose issue stalls eight wavefronts do not hide, s_nop placement the compiler cannot be told).
+// P, hits and the T flags live in physical VGPRs (v58..v63) as register-asm variables that only asm statements touch; the
+// pattern table is the first member of the kernel's only LDS object, so table rows are at symbol * 8 and the window rows at
+// offsetof(wtab).  Everything else -- tile loop, Winkler prefix, table epilogue -- is jaro_word_body<true, false, true> again.
+// ---------------------------------------------------------------------------------------------------
+#include "rf_jaro_chunk_asm.inc"
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_asm_kernel(const ScanParams p)
+{
+    __shared__ JaroWordLds lds;
+    const uint32_t W = p.words;
+    double* tab1 = lds.tabs;
+    for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds.pm0[p.sigma[i]] = p.pm[(size_t)i * W];  // renamed rows
+    if (threadIdx.x < 65) tab1[threadIdx.x] = (double)threadIdx.x / (double)p.len1;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    double* tab2 = tab1 + kJaroTabStride * (1 + wave);
+    uint64_t* wtab = lds.wtab + kWave * wave;
+    const uint32_t wtab_addr = (uint32_t)offsetof(JaroWordLds, wtab) + kWave * wave * 8u;  // LDS byte address (the struct is at 0)
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    const uint32_t q4 = p.query_head;
+    const uint32_t three = 3u;
+
+    // single-length corpus: lengths, window and tables are the same for every tile
+    const uint32_t len2_orig = p.uniform_len, len1_orig = p.len1;
+    uint32_t len1 = len1_orig, len2 = len2_orig, bound = 0;  // window truncation, jaro.rs:550-565
+    if (len2 > len1) {
+        bound = len2 / 2 - 1;
+        if (len2 > len1 + bound) len2 = len1 + bound;
+    } else if (len1 >= 2) {
+        bound = len1 / 2 - 1;
+        if (len1 > len2 + bound) len1 = len2 + bound;
+    }
+    const uint32_t nch = len2 / kChunk;  // the launcher sends only whole-chunk lengths here
+    jaro_window_table(wtab, lane, bound);
+    tab2[lane] = (double)lane / (double)len2_orig;
+    if (lane == 0) tab2[64] = 64.0 / (double)len2_orig;
+
+    register uint32_t pl asm("v60"), ph asm("v61"), hl asm("v62"), hh asm("v63"), tlo asm("v58"), thi asm("v59");
+    // The candidate's chunk rows (<= 4) stay in registers for BOTH passes, and the next tile's rows are fetched into them one
+    // by one as pass 2 finishes with each: every load has the rest of pass 2, the epilogue and the earlier chunks of pass 1
+    // (>= 3 us) to arrive.  (Fetching chunk k + 1 while chunk k is processed, as the compiled kernel does, gives a load ~1.2 us
+    // -- a pass-1 chunk is short -- which is less than the loaded HBM latency: every chunk started with a stall.)
+    uint4 b0, b1, b2, b3;
+    uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave;
+    if (t >= p.tile_end) return;
+    const uint4* src = reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes);
+    b0 = src[lane];
+    b1 = b2 = b3 = b0;
+    if (nch > 1) b1 = src[kWave + lane];
+    if (nch > 2) b2 = src[2 * kWave + lane];
+    if (nch > 3) b3 = src[3 * kWave + lane];
+#define RF_P1(buf, j0)                                                                                                          \
+    asm volatile(RF_JARO_PASS1_ASM                                                                                              \
+                 : "+v"(pl), "+v"(ph), "+v"(tlo), "+v"(thi)                                                                     \
+                 : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [k3] "v"(three), [wa] "v"(wtab_addr + (j0) * 8u), \
+                   [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u)                                                      \
+                 : RF_JARO_CHUNK_CLOBBERS)
+#define RF_P2(buf, j0)                                                                                                          \
+    asm volatile(RF_JARO_PASS2_ASM                                                                                              \
+                 : "+v"(pl), "+v"(ph), "+v"(hl), "+v"(hh)                                                                       \
+                 : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [k3] "v"(three), "v"(tlo), "v"(thi),     \
+                   [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u)                                                      \
+                 : RF_JARO_CHUNK_CLOBBERS)
+    while (true) {
+        const uint32_t idx = t * kWave + lane;
+        JaroRaw r;
+        r.eq11 = (b0.x & 0xFFu) == (q4 & 0xFFu);
+        {  // Winkler prefix, jaro_winkler.rs:118-123
+            const uint32_t lim = min(4u, min(len1_orig, len2_orig));
+            const uint32_t diff = b0.x ^ q4;
+            const uint32_t first_diff = diff ? (uint32_t)(__ffs(diff) - 1) / 8 : 4u;
+            r.prefix = min(first_diff, lim);
+        }
+        asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0\n\tv_mov_b32 %4, 0\n\tv_mov_b32 %5, 0"
+                     : "=v"(pl), "=v"(ph), "=v"(hl), "=v"(hh), "=v"(tlo), "=v"(thi));
+        RF_P1(b0, 0u);  // pass 1
+        if (nch > 1) RF_P1(b1, 16u);
+        if (nch > 2) RF_P1(b2, 32u);
+        if (nch > 3) RF_P1(b3, 48u);
+        uint32_t common;
+        asm volatile("v_bcnt_u32_b32 %0, %1, 0\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(common) : "v"(pl), "v"(ph));
+        const uint32_t t_next = t + stride;
+        const bool more = t_next < p.tile_end;
+        const uint4* nsrc = reinterpret_cast<const uint4*>(p.data + (uint64_t)(more ? t_next : t) * p.uniform_tile_bytes);
+        RF_P2(b0, 0u);  // pass 2, and the next tile's rows behind it
+        b0 = nsrc[lane];
+        if (nch > 1) {
+            RF_P2(b1, 16u);
+            b1 = nsrc[kWave + lane];
+        }
+        if (nch > 2) {
+            RF_P2(b2, 32u);
+            b2 = nsrc[2 * kWave + lane];
+        }
+        if (nch > 3) {
+            RF_P2(b3, 48u);
+            b3 = nsrc[3 * kWave + lane];
+        }
+        uint32_t nhits;
+        asm volatile("v_bcnt_u32_b32 %0, %1, 0\n\tv_bcnt_u32_b32 %0, %2, %0" : "=&v"(nhits) : "v"(hl), "v"(hh));
+        r.common = common;
+        r.transpositions = common - nhits;
+
+        // jaro::similarity_with_pm with score_cutoff = 0.0, from the tables (see jaro_word_body)
+        double sim;
+        if (len1_orig == 0 || len2_orig == 0) {
+            sim = (len1_orig == 0 && len2_orig == 0) ? 1.0 : 0.0;
+        } else if (len1_orig == 1 && len2_orig == 1) {
+            sim = r.eq11 ? 1.0 : 0.0;
+        } else {
+            double acc = 0.0;
+            acc += tab1[r.common];
+            acc += tab2[r.common];
+            acc += p.jaro_tab[r.common * 33u + r.transpositions / 2u];
+            acc = acc / 3.0;
+            sim = select_f64(r.common == 0, 0.0, acc);
+        }
+        if (p.finish == FIN_JW) sim = select_f64(sim > 0.7, sim + (double)r.prefix * p.prefix_weight * (1.0 - sim), sim);
+        double v = sim;
+        if (p.op == RF_OP_DISTANCE || p.op == RF_OP_NORMALIZED_DISTANCE) v = 1.0 - sim;
+        if (p.op == RF_OP_NORMALIZED_SIMILARITY) v = 1.0 - (1.0 - sim);
+        if (idx < p.n) reinterpret_cast<double*>(p.out)[idx] = v;
+        if (!more) break;
+        t = t_next;
+    }
+#undef RF_P1
+#undef RF_P2
+}
+
 hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
 {
     // tiles [tile_begin, jaro_split) take the single-word path, [jaro_split, tile_end) the multi-word path
@@ -761,7 +896,21 @@ hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
         const bool fast = !p.has_cutoff && p.jaro_tab != nullptr;  // the table epilogue (no cutoff to replay)
         auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : (fast ? jaro_word_fast_kernel<false> : jaro_word_kernel<false, false>))
                          : (early ? jaro_word_kernel<true, true> : (fast ? jaro_word_fast_kernel<true> : jaro_word_kernel<true, false>));
-        hipLaunchKernelGGL(k, g, b, 0, stream, q);
+        // the hand-scheduled kernel: single-length corpus, table epilogue, truncated candidate length a multiple of 16
+        static const bool use_asm = [] { const char* e = getenv("RF_ASM_CHUNK"); return !e || atoi(e) != 0; }();
+        bool asm_ok = use_asm && fast && !early && !p.tiles && p.len1 >= 2;
+        if (asm_ok) {
+            uint32_t len1 = p.len1, len2 = p.uniform_len, bound = 0;  // jaro.rs:550-565, as in the kernel
+            if (len2 > len1) {
+                bound = len2 / 2 - 1;
+                if (len2 > len1 + bound) len2 = len1 + bound;
+            }
+            asm_ok = len2 >= (uint32_t)kChunk && len2 % kChunk == 0 && len2 <= 64;
+        }
+        if (asm_ok)
+            hipLaunchKernelGGL(jaro_word_asm_kernel, g, b, 0, stream, q);
+        else
+            hipLaunchKernelGGL(k, g, b, 0, stream, q);
     }
     q.tile_begin = std::max(p.jaro_split, p.tile_begin);
     q.tile_end = p.tile_end;

@@ -27,3 +27,10 @@ def test_asm_chunk_include_is_the_generators_output(tmp_path):
     env = {k: v for k, v in os.environ.items() if k != "RF_GEN_MASKS"}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_lev_chunk_asm.py"), str(out)], check=True, env=env)
     assert out.read_text() == open(os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc", "rf_lev_chunk_asm.inc")).read()
+
+
+def test_jaro_asm_include_is_the_generators_output(tmp_path):
+    out = tmp_path / "jaro.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RF_GEN_")}
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_jaro_chunk_asm.py"), str(out)], check=True, env=env)
+    assert out.read_text() == open(os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc", "rf_jaro_chunk_asm.inc")).read()

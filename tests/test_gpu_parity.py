@@ -1693,3 +1693,35 @@ def test_asm_chunk_kernel_single_length_corpora(len2):
         order = np.lexsort((np.arange(n), dist))[:16]
         s, i = bc.topk(corpus, 16)
         assert list(zip(s.tolist(), i.tolist())) == [(int(dist[j]), int(j)) for j in order], (len1, len2)
+
+
+@pytest.mark.parametrize("metric", ["jaro", "jaro_winkler"])
+@pytest.mark.parametrize("len2", [16, 32, 48, 64])
+def test_asm_jaro_kernel_single_length_corpora(metric, len2):
+    """jaro_word_asm_kernel (both passes of the single-word Jaro kernel as hand-scheduled asm, the candidate's chunk rows held in
+    registers) serves single-length corpora whose length -- after the reference's window truncation -- is a multiple of 16, when
+    there is no cutoff: every op, bit-equal f64, query lengths that do and do not truncate the candidate, a small and a large
+    alphabet, shifted near-duplicates (transpositions), a partial last tile."""
+    import torch
+
+    rng = np.random.default_rng(1000 + len2)
+    n = 20_011
+    for len1 in (2, 7, 16, 31, 33, 50, 64):
+        lo, hi = (97, 103) if len1 % 2 else (33, 127)
+        q = bytes(rng.integers(lo, hi, size=len1, dtype=np.uint8))
+        host = rng.integers(lo, hi, size=(n, len2), dtype=np.uint8)
+        qa = np.frombuffer(q, dtype=np.uint8)
+        for r in range(0, n, 53):
+            row = np.resize(qa, len2).copy()
+            row[rng.integers(0, len2, size=r % 4)] = 122
+            if r % 2:
+                row = np.roll(row, 1 + r % 3)
+            if r % 5 == 0 and len2 >= 4:
+                row[[1, 2]] = row[[2, 1]]  # an adjacent transposition
+            host[r] = row
+        corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
+        bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+        for opname, op in OPS.items():
+            got = bc.many(op, corpus)
+            exp = ob.rows(op, host, nthreads=8)
+            assert (got == exp).all(), (metric, len1, len2, opname, np.nonzero(got != exp)[0][:5])
