@@ -438,8 +438,10 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
 {
     const dim3 g(grid), b(kWave * kWavesPerBlock);
     if constexpr (State::kWords == 1) {
-        // no cutoff early-out to serve: the leaner stream loop.  Ring depth 1 measured best (2 and 3 were 1-3% slower
-        // on every metric: these kernels are issue-bound, not latency-bound); RF_STREAM=0 selects scan_body for A/B.
+        // no cutoff early-out to serve: the leaner stream loop.  Ring depth: 1 for the issue-bound recurrences (2 and 3 measured
+        // 1-3 % slower), 2 for the LCS states, whose 5-instruction column makes a chunk short enough for a second load in flight to
+        // pay (Indel 80.8 -> 81.6 Gpairs/s, depth 3: 79.6); RF_STREAM=0 selects scan_body for A/B.
+        constexpr int kDepth = (std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value) ? 2 : 1;
         static const bool use_stream = [] { const char* e = getenv("RF_STREAM"); return !e || atoi(e) != 0; }();
         if (!p.early && use_stream) {
             // the headline case has its chunk in hand-scheduled asm (rf_lev_asm.hip); RF_ASM_CHUNK=0 selects the compiled loop
@@ -447,9 +449,9 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             if (std::is_same<State, LevState<1>>::value && !p.tiles && use_asm && p.uniform_len >= (uint32_t)kChunk && p.uniform_len % kChunk == 0)
                 return launch_lev1_asm(p, stream, grid);
             if (p.tiles)
-                hipLaunchKernelGGL((stream_kernel_occ8<State, false, 1>), g, b, 0, stream, p);
+                hipLaunchKernelGGL((stream_kernel_occ8<State, false, kDepth>), g, b, 0, stream, p);
             else
-                hipLaunchKernelGGL((stream_kernel_occ8<State, true, 1>), g, b, 0, stream, p);
+                hipLaunchKernelGGL((stream_kernel_occ8<State, true, kDepth>), g, b, 0, stream, p);
             return hipGetLastError();
         }
         if (p.early) {
