@@ -1725,3 +1725,46 @@ def test_asm_jaro_kernel_single_length_corpora(metric, len2):
             got = bc.many(op, corpus)
             exp = ob.rows(op, host, nthreads=8)
             assert (got == exp).all(), (metric, len1, len2, opname, np.nonzero(got != exp)[0][:5])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RF_FUZZ_SEEDS", "32"))))
+def test_randomized_single_length_corpora(seed):
+    """Single-length corpora pick different kernels than ragged ones (arithmetic tile addressing, the hand-scheduled asm kernels
+    when the length is a multiple of 16 and there is no cutoff, the cutoff scans' first look at column 4..16): random metric, op,
+    lengths, alphabet, cutoff and candidate count against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(77_000 + seed)
+    metric = ["levenshtein", "levenshtein", "jaro", "jaro_winkler", "indel", "osa"][int(rng.integers(0, 6))]
+    len2 = int(rng.choice([16, 32, 48, 64, 64, 80, 96, int(rng.integers(1, 130))]))
+    len1 = int(rng.integers(1, 65)) if rng.random() < 0.8 else int(rng.integers(65, 200))
+    n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 20_011]))
+    lo, hi = [(97, 100), (97, 123), (33, 127), (0, 256)][int(rng.integers(0, 4))]
+    q = bytes(rng.integers(lo, hi, size=len1, dtype=np.uint8))
+    host = rng.integers(lo, hi, size=(n, len2), dtype=np.uint8)
+    qa = np.frombuffer(q, dtype=np.uint8)
+    for r in range(0, n, 7):
+        row = np.resize(qa, len2).copy()
+        k = int(rng.integers(0, 6))
+        if k:
+            row[rng.integers(0, len2, size=k)] = rng.integers(lo, hi, size=k, dtype=np.uint8)
+        host[r] = np.roll(row, int(rng.integers(0, 3)))
+    corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
+    bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+    is_f = metric in ("jaro", "jaro_winkler")
+    for opname, op in OPS.items():
+        kws = [{}]
+        if is_f or opname.startswith("normalized"):
+            kws.append({"score_cutoff": float(rng.choice([0.0, 0.3, 0.7, 0.9, 1.0]))})
+        else:
+            kws.append({"score_cutoff": int(rng.choice([0, 1, 2, 3, 4, 5, 7, 9, 12, 20, max(len1, len2)]))})
+        for kw in kws:
+            if metric == "levenshtein" and opname == "similarity" and kw:
+                continue  # reference quirk Q2 (see _check_many)
+            got = bc.many(op, corpus, **kw)
+            exp = ob.rows(op, host, nthreads=8, **kw)
+            if got.dtype == np.uint32:
+                bad = np.nonzero(got != _expect_u32(exp))[0]
+            else:
+                bad = np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
+            assert len(bad) == 0, (metric, opname, kw, len1, len2, n, (lo, hi), bad[:5], got[bad[:5]], exp[bad[:5]])
