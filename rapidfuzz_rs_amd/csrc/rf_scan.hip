@@ -84,13 +84,15 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
         }                                                                                 \
         process_chunk_full<State, J, kChunk>(st, lds_pm, cur);                            \
     }
-                        if (p.first_check == 4) RF_FIRST_LOOK(4)
-                        else if (p.first_check == 6) RF_FIRST_LOOK(6)
-                        else if (p.first_check == 10) RF_FIRST_LOOK(10)
-                        else if (p.first_check == 12) RF_FIRST_LOOK(12)
-                        else if (p.first_check == 14) RF_FIRST_LOOK(14)
-                        else if (p.first_check == 16) process_chunk_full<State>(st, lds_pm, cur);  // loose cutoff: the look at the chunk's end is the first
-                        else RF_FIRST_LOOK(8)
+                        if constexpr (W == 1) {  // (the multi-word kernels keep the one look at column 8: six copies of their chunk code would not pay)
+                            if (p.first_check == 4) RF_FIRST_LOOK(4)
+                            else if (p.first_check == 6) RF_FIRST_LOOK(6)
+                            else if (p.first_check == 10) RF_FIRST_LOOK(10)
+                            else if (p.first_check == 12) RF_FIRST_LOOK(12)
+                            else if (p.first_check == 14) RF_FIRST_LOOK(14)
+                            else if (p.first_check == 16) process_chunk_full<State>(st, lds_pm, cur);  // loose cutoff: the look at the chunk's end is the first
+                            else RF_FIRST_LOOK(8)
+                        } else RF_FIRST_LOOK(8)
 #undef RF_FIRST_LOOK
                     } else {
                         process_chunk_full<State>(st, lds_pm, cur);
