@@ -42,6 +42,9 @@ constexpr uint32_t T_OR_NOR = TA | (~(TB | TC));    // a | ~(b | c)
 constexpr uint32_t T_OR_ANDN = TA | (TB & ~TC);      // a | (b & ~c)
 constexpr uint32_t T_AND_OR = TA & (TB | TC);        // a & (b | c)
 constexpr uint32_t T_NOR3 = ~(TA | TB | TC);         // ~(a | b | c)
+constexpr uint32_t T_OR3 = TA | TB | TC;             // a | b | c   (as a LUT: hipcc picks v_or3_b32 for `a | b | c`, a half-rate
+                                                     //  instruction on gfx950; v_bitop3_b32 is full rate, profiles/issue_rates_r02.txt)
+constexpr uint32_t T_ANDN_BA = TB & ~TA;             // ~a & b      (likewise instead of v_bfi_b32)
 
 // (x << 1) | carry_in.  Measured on gfx950 (tools/microbench.hip, profiles/microbench_r01.txt): the 64-bit VALU
 // forms v_lshl_add_u64 / v_lshlrev_b64 issue at the same (half) rate as ONE v_alignbit_b32 / v_lshl_or_b32, so a
@@ -246,7 +249,7 @@ struct OsaState {
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const uint64_t pm_j = pm_row[w];
-            const uint64_t t = ~d0[w] & pm_j;                              // candidates for a transposition
+            const uint64_t t = lut3<T_ANDN_BA>(d0[w], pm_j, pm_j);         // ~d0 & pm_j: candidates for a transposition
             const uint64_t tr = (w == 0 ? shl1_const<0>(t) : shl1_var(t, tr_c)) & pm_old[w];  // osa.rs:180
             if (w + 1 < W) tr_c = (uint32_t)(t >> 63);                      // ((~d0_last) & pm_last) >> 63 for the next word
             uint64_t x = pm_j;
@@ -254,7 +257,7 @@ struct OsaState {
             const uint64_t p = vp[w], n = vn[w];
             const uint64_t sum = (x & p) + p;
             const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
-            const uint64_t d = e | n | tr;                                  // osa.rs:183
+            const uint64_t d = lut3<T_OR3>(e, n, tr);                       // osa.rs:183
             const uint64_t hn = d & p;
             const uint64_t hp = lut3<T_OR_NOR>(n, d, p);
             const uint64_t hps = w == 0 ? shl1_const<1>(hp) : shl1_var(hp, hp_c);
@@ -276,14 +279,14 @@ struct OsaState {
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const uint64_t pm_j = pm_row[w];
-            const uint64_t t = ~d0[w] & pm_j;
+            const uint64_t t = lut3<T_ANDN_BA>(d0[w], pm_j, pm_j);
             const uint64_t tr = shl1_var(t, tr_c) & pm_old[w];  // osa.rs:180
             tr_c = (uint32_t)(t >> 63);
             const uint64_t x = pm_j | hn_c;                       // osa.rs:182
             const uint64_t p = vp[w], n = vn[w];
             const uint64_t sum = (x & p) + p;
             const uint64_t e = lut3<T_XOR_OR>(sum, p, x);
-            const uint64_t d = e | n | tr;                        // osa.rs:183
+            const uint64_t d = lut3<T_OR3>(e, n, tr);             // osa.rs:183
             const uint64_t hn = d & p;
             const uint64_t hp = lut3<T_OR_NOR>(n, d, p);
             const uint64_t hps = shl1_var(hp, hp_c);
