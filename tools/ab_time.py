@@ -11,7 +11,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "lev64"
 n = int(os.environ.get("AB_N", 100_000_000))
 cfg = {
     "lev64": ("levenshtein", 64, 64, {}), "lev32": ("levenshtein", 32, 64, {}), "indel": ("indel", 64, 64, {}), "osa": ("osa", 64, 64, {}),
-    "lev256": ("levenshtein", 256, 256, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
+    "lev256": ("levenshtein", 256, 256, {}), "indel256": ("indel", 256, 256, {}), "indel128": ("indel", 128, 64, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
     "jaro": ("jaro", 64, 64, {}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
 }
 import re as _re
@@ -19,7 +19,7 @@ _m = _re.fullmatch(r"lev64c(\d+)", what.split("+")[0])
 _i = _re.fullmatch(r"indelc(\d+)", what.split("+")[0])
 cfg = ("levenshtein", 64, 64, {"score_cutoff": int(_m.group(1))}) if _m else (("indel", 64, 64, {"score_cutoff": int(_i.group(1))}) if _i else cfg[what.split("+")[0]])
 metric, qlen, clen, kw = cfg
-if clen == 256:
+if clen == 256 and qlen == 256:
     n //= 10
 q = synth.query(qlen, 0xC0FFEE02)
 rows = synth.rows_device(n, clen, seed=1)
