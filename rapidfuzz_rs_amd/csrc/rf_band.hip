@@ -68,38 +68,44 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void band_kernel(const ScanP
             uint4 nxt = cur;
             if (c + 1 < nch) nxt = load_chunk(tv.src + (size_t)(c + 1) * kWave + lane);
             const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
-            uint4 data = cur;
-            for (uint32_t b = 0; b < cols; ++b, ++v) {
-                const uint32_t j = c * kChunk + b;
-                const uint32_t* row = lds_band + (data.x & 0xFFu) * stride + (v >> 5);
-                const uint32_t d0w = row[0], d1w = row[1], d2w = row[2];
-                const uint32_t sh = v & 31;
-                const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2w, d1w, sh) << 32) | __builtin_amdgcn_alignbit(d1w, d0w, sh);
-                const uint64_t sum = (x & vp) + vp;
-                const uint64_t e = lut3<T_XOR_OR>(sum, vp, x);
-                const uint64_t d0 = e | vn;                     // levenshtein.rs:556 / :593
-                const uint64_t hp = lut3<T_OR_NOR>(vn, e, vp);  // vn | ~(d0 | vp)
-                const uint64_t hn = e & vp;                     // d0 & vp (vp & vn == 0)
-                if (j < first) {                                // :560-562 (wavefront-uniform)
-                    diag_hits += (uint32_t)(d0 >> 63);
-                    score = k + (j + 1) - diag_hits;
-                } else {                                        // :597-600: the last row, at a bit that moves down
-                    const uint64_t hmask = 1ull << (62 - (j - first));
-                    score += (hp & hmask) != 0;
-                    score -= (hn & hmask) != 0;
-                }
-                const uint64_t d0s = d0 >> 1;
-                vp = lut3<T_OR_NOR>(hn, d0s, hp);               // :571 / :611
-                vn = d0s & hp;
-                data.x = __builtin_amdgcn_alignbit(data.y, data.x, 8);
-                data.y = __builtin_amdgcn_alignbit(data.z, data.y, 8);
-                data.z = __builtin_amdgcn_alignbit(data.w, data.z, 8);
-                data.w >>= 8;
-                if ((b & 7) == 7 || b + 1 == cols)  // :568-570 / :607-609, checked per wavefront every 8 columns
-                    if (__ballot(valid && score <= break_score) == 0) {
-                        dead = true;
-                        break;
+            // 16 columns = 4 dwords x 4 bytes with COMPILE-TIME byte positions: `((dw >> 8k) & 0xFF) * stride` is one
+            // v_mul_u32_u24_sdwa; walking the chunk with a running byte shift cost three v_alignbit_b32 + a shift + an and + a
+            // v_mul_lo_u32 per column -- six instructions, five of them half-rate on gfx950 (profiles/issue_rates_r02.txt)
+            const uint32_t dws[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int dq = 0; dq < 4 && !dead; ++dq) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const uint32_t bcol = (uint32_t)(dq * 4 + kb);
+                    if (bcol >= cols) break;  // wavefront-uniform
+                    const uint32_t j = c * kChunk + bcol;
+                    const uint32_t* row = lds_band + ((dws[dq] >> (8 * kb)) & 0xFFu) * stride + (v >> 5);
+                    const uint32_t d0w = row[0], d1w = row[1], d2w = row[2];
+                    const uint32_t sh = v & 31;
+                    const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2w, d1w, sh) << 32) | __builtin_amdgcn_alignbit(d1w, d0w, sh);
+                    const uint64_t sum = (x & vp) + vp;
+                    const uint64_t e = lut3<T_XOR_OR>(sum, vp, x);
+                    const uint64_t d0 = e | vn;                     // levenshtein.rs:556 / :593
+                    const uint64_t hp = lut3<T_OR_NOR>(vn, e, vp);  // vn | ~(d0 | vp)
+                    const uint64_t hn = e & vp;                     // d0 & vp (vp & vn == 0)
+                    if (j < first) {                                // :560-562 (wavefront-uniform)
+                        diag_hits += (uint32_t)(d0 >> 63);
+                        score = k + (j + 1) - diag_hits;
+                    } else {                                        // :597-600: the last row, at a bit that moves down
+                        const uint64_t hmask = 1ull << (62 - (j - first));
+                        score += (hp & hmask) != 0;
+                        score -= (hn & hmask) != 0;
                     }
+                    const uint64_t d0s = d0 >> 1;
+                    vp = lut3<T_OR_NOR>(hn, d0s, hp);               // :571 / :611
+                    vn = d0s & hp;
+                    ++v;
+                    if ((bcol & 7) == 7 || bcol + 1 == cols)  // :568-570 / :607-609, checked per wavefront every 8 columns
+                        if (__ballot(valid && score <= break_score) == 0) {
+                            dead = true;
+                            break;
+                        }
+                }
             }
             cur = nxt;
         }
