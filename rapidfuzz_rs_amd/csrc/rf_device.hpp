@@ -865,19 +865,48 @@ __device__ __forceinline__ void process_chunk_full(State& st, const typename Sta
     }
 }
 
+// A tile's last, partial chunk: `rem` (< 16, wavefront-uniform) columns.  Single-word states run the full chunk's code shape --
+// table rows gathered a group of 4 symbols ahead at COMPILE-TIME byte positions (the bytes behind a candidate's end are zero
+// padding, i.e. valid rows) -- and only the recurrence step is guarded by the column count.  (The first version walked the chunk
+// with a running byte shift and one exposed LDS round trip per column: three v_alignbit_b32 + a shift per column, all half-rate
+// on gfx950.)  Multi-word states keep the compact loop: sixteen more copies of their column would not pay.
 template <class State>
 __device__ __forceinline__ void process_chunk_tail(State& st, const typename State::Word* lds_pm, uint4 c, uint32_t rem)
 {
     using Word = typename State::Word;
     constexpr int W = State::kWords;
-    for (uint32_t j = 0; j < rem; ++j) {  // rem is wavefront-uniform (tile length)
-        Word x[W];
-        load_pm<Word, W>(x, lds_pm, c.x & 0xFFu);
-        st.step(x);
-        c.x = __builtin_amdgcn_alignbit(c.y, c.x, 8);
-        c.y = __builtin_amdgcn_alignbit(c.z, c.y, 8);
-        c.z = __builtin_amdgcn_alignbit(c.w, c.z, 8);
-        c.w >>= 8;
+    if constexpr (W == 1) {
+        constexpr int kGroup = 4, kGroups = kChunk / kGroup;
+        const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+        Word cur[kGroup][W], nxt[kGroup][W];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) load_pm<Word, W>(cur[j], lds_pm, (dw[0] >> (8 * j)) & 0xFFu);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            if ((uint32_t)(g * kGroup) >= rem) break;  // wavefront-uniform
+            if (g + 1 < kGroups) {
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) load_pm<Word, W>(nxt[j], lds_pm, (dw[g + 1] >> (8 * j)) & 0xFFu);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j)
+                if ((uint32_t)(g * kGroup + j) < rem) st.step(cur[j]);
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j)
+#pragma unroll
+                for (int w = 0; w < W; ++w) cur[j][w] = nxt[j][w];
+        }
+    } else {
+        for (uint32_t j = 0; j < rem; ++j) {  // rem is wavefront-uniform (tile length)
+            Word x[W];
+            load_pm<Word, W>(x, lds_pm, c.x & 0xFFu);
+            st.step(x);
+            c.x = __builtin_amdgcn_alignbit(c.y, c.x, 8);
+            c.y = __builtin_amdgcn_alignbit(c.z, c.y, 8);
+            c.z = __builtin_amdgcn_alignbit(c.w, c.z, 8);
+            c.w >>= 8;
+        }
     }
 }
 
