@@ -1768,3 +1768,13 @@ def test_randomized_single_length_corpora(seed):
             else:
                 bad = np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
             assert len(bad) == 0, (metric, opname, kw, len1, len2, n, (lo, hi), bad[:5], got[bad[:5]], exp[bad[:5]])
+
+
+def test_integration_md_python_example():
+    """The Python snippet of INTEGRATION.md section 4, values included."""
+    scorer = rf.distance.levenshtein.BatchComparator(b"kitten")
+    corpus = rf.Corpus.from_list([b"sitting", b"mitten", b"kitchen"])
+    assert scorer.distance_many(corpus, score_cutoff=3).tolist() == [3, 1, 2]
+    assert scorer.distance(b"sitting", score_cutoff=2) is None
+    s, i = scorer.topk(corpus, k=2)
+    assert (s.tolist(), i.tolist()) == ([1, 2], [1, 2])
