@@ -11,7 +11,9 @@
 
 namespace rf {
 
-template <class State, bool kUniform>
+// kFirst >= 0: a cutoff scan (`early` is a compile-time fact) whose first look inside a tile's first chunk sits at column kFirst
+// (16 = at the chunk's end); kFirst < 0: `early` and the look are read from ScanParams at run time.
+template <class State, bool kUniform, int kFirst = -1>
 __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
 {
     constexpr int W = State::kWords;
@@ -25,7 +27,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t stride = gridDim.x * kWavesPerBlock * p.tile_step;
     const bool topk = p.topk_k != 0;
-    const bool early = State::kCanPrune && p.early != 0;
+    const bool early = kFirst >= 0 ? true : (State::kCanPrune && p.early != 0);
     WaveTopK best;
     best.init();
     // offers are filtered by `limit` = min(launch-wide pruning bound as last seen, own list's worst key), a scalar.
@@ -84,7 +86,11 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
         }                                                                                 \
         process_chunk_full<State, J, kChunk>(st, lds_pm, cur);                            \
     }
-                        if constexpr (W == 1) {  // (the multi-word kernels keep the one look at column 8: six copies of their chunk code would not pay)
+                        if constexpr (kFirst == 16) {
+                            process_chunk_full<State>(st, lds_pm, cur);
+                        } else if constexpr (kFirst >= 0) {
+                            RF_FIRST_LOOK(kFirst)
+                        } else if constexpr (W == 1) {  // (the multi-word kernels keep the one look at column 8: six copies of their chunk code would not pay)
                             if (p.first_check == 4) RF_FIRST_LOOK(4)
                             else if (p.first_check == 6) RF_FIRST_LOOK(6)
                             else if (p.first_check == 10) RF_FIRST_LOOK(10)
@@ -146,6 +152,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
     __shared__ typename State::Word lds_pm[256 * State::kWords];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
     scan_body<State, kUniform>(p, lds_pm, lds_topk);
+}
+template <class State, bool kUniform, int kFirst>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void early_kernel(const ScanParams p)
+{
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    scan_body<State, kUniform, kFirst>(p, lds_pm, lds_topk);
 }
 template <class State, bool kUniform>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan_kernel_occ8(const ScanParams p)
@@ -460,6 +473,33 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             // cutoff runs: the compiler's own register budget.  Pinned to 8 wavefronts per SIMD this body spills (32 B of
             // scratch traffic per tile in a loop that only runs 8 columns); 7 resident wavefronts without spills
             // measured +8 % at cutoff 3 and +3 % at cutoff 10 on the C2 corpus.
+            // The Levenshtein family gets the look's column (and `early` itself) as compile-time facts: the run-time dispatch
+            // and flags cost the short per-tile loop of a cutoff scan 83 scalar instructions and 34 branches per tile -- with
+            // four SIMDs sharing one scalar unit about as much time as its 139 vector instructions (cutoff 3: 217 -> 237
+            // Gpairs/s, top-16 237 -> 263).  RF_EARLY_STATIC=0 selects the run-time form for A/B.
+            static const bool early_static = [] { const char* e = getenv("RF_EARLY_STATIC"); return !e || atoi(e) != 0; }();
+            if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value) {
+                if (early_static) {
+#define RF_EARLY_CASE(J)                                                                   \
+    case J:                                                                                \
+        if (p.tiles)                                                                       \
+            hipLaunchKernelGGL((early_kernel<State, false, J>), g, b, 0, stream, p);       \
+        else                                                                               \
+            hipLaunchKernelGGL((early_kernel<State, true, J>), g, b, 0, stream, p);        \
+        return hipGetLastError();
+                    switch (p.first_check) {
+                        RF_EARLY_CASE(4)
+                        RF_EARLY_CASE(6)
+                        RF_EARLY_CASE(8)
+                        RF_EARLY_CASE(10)
+                        RF_EARLY_CASE(12)
+                        RF_EARLY_CASE(14)
+                        RF_EARLY_CASE(16)
+                    default: break;
+                    }
+#undef RF_EARLY_CASE
+                }
+            }
             if (p.tiles)
                 hipLaunchKernelGGL((scan_kernel<State, false>), g, b, 0, stream, p);
             else
