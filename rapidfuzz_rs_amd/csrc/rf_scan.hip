@@ -153,6 +153,103 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
     scan_body<State, kUniform>(p, lds_pm, lds_topk);
 }
+// The cutoff scan of a SINGLE-LENGTH corpus, written around its common case: a tile whose every lane is past the cutoff at the
+// first look.  That case is a straight line here -- state, kFirst columns, the diagonal bound, one ballot, the None results, the
+// next tile -- with the length-dependent values (chunk count, finishing coefficients, row masks) computed once per wavefront;
+// everything a surviving tile needs (the rest of its first chunk, later chunks fetched on demand, looks at every chunk end,
+// finishing, top-k) sits behind one branch.  scan_body spends 50 scalar instructions and 21 branches on a dead tile even with
+// the look compiled in; four SIMDs share one scalar unit, so that is time the 136 vector instructions cannot overlap.
+template <class State, int kFirst>
+__device__ __forceinline__ void early_lean_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
+{
+    constexpr int W = State::kWords;
+    static_assert(W == 1 && kFirst >= 4 && kFirst <= 16, "single-word states, first look inside the first chunk");
+    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock)
+        lds_pm[(uint32_t)p.sigma[i / W] * W + i % W] = (typename State::Word)p.pm[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t stride = gridDim.x * kWavesPerBlock * p.tile_step;
+    const bool topk = p.topk_k != 0;
+    WaveTopK best;
+    best.init();
+    uint64_t limit = ~0ull;
+    uint32_t tiles_done = 0;
+
+    const uint32_t len2 = p.uniform_len, len1 = p.len1;
+    const uint32_t nch = (len2 + kChunk - 1) / kChunk;  // >= 1: the launcher sends lengths >= 16 here
+    const TileFin fin = tile_fin(p, len1, len2);
+    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
+    if (t < p.tile_end) {
+        const uint8_t* base = p.data + (size_t)lane * sizeof(uint4);
+        uint4 cur = load_chunk(reinterpret_cast<const uint4*>(base + (uint64_t)t * p.uniform_tile_bytes));
+        while (true) {
+            const uint32_t t_next = t + stride;
+            const bool has_next = t_next < p.tile_end;
+            // the first chunk row of the next tile (past the last tile: a cached re-read of this one)
+            const uint4 ahead = load_chunk(reinterpret_cast<const uint4*>(base + (uint64_t)(has_next ? t_next : t) * p.uniform_tile_bytes));
+            const uint32_t idx = t * kWave + lane;
+            const bool valid = idx < p.n;
+            State st;
+            st.init();
+            bool dead;
+            if constexpr (kFirst < 16) {
+                process_chunk_full<State, 0, kFirst>(st, lds_pm, cur);
+                dead = __ballot(may_pass(p, fin, st.bound_first(len1, kFirst, len2))) == 0;
+            } else {
+                process_chunk_full<State>(st, lds_pm, cur);
+                dead = __ballot(may_pass(p, fin, st.bound(len1, kChunk, len2))) == 0;
+            }
+            if (dead) {
+                if (p.out && valid) emit_none(p, idx);
+            } else {
+                // a tile with a lane still in the race: the general walk (looks at every chunk end, chunks fetched on demand)
+                if constexpr (kFirst < 16) {
+                    process_chunk_full<State, kFirst, kChunk>(st, lds_pm, cur);
+                    dead = __ballot(may_pass(p, fin, st.bound(len1, kChunk, len2))) == 0;
+                }
+                const uint4* src = reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes);
+                for (uint32_t c = 1; c < nch && !dead; ++c) {
+                    const uint4 more = load_chunk(src + (size_t)c * kWave + lane);
+                    const uint32_t cols = len2 - c * kChunk;
+                    if (cols >= (uint32_t)kChunk)
+                        process_chunk_full<State>(st, lds_pm, more);
+                    else
+                        process_chunk_tail<State>(st, lds_pm, more, cols);
+                    const uint32_t j = min(len2, (c + 1) * kChunk);
+                    dead = __ballot(may_pass(p, fin, st.bound(len1, j, len2))) == 0;
+                }
+                const uint32_t raw = st.result(len1, len2);
+                if (p.out && valid) {
+                    if (dead)
+                        emit_none(p, idx);
+                    else
+                        emit_fin(p, fin, raw, idx, p.out);
+                }
+                if (topk && !dead) {
+                    bool keep;
+                    const uint32_t v = usize_value(p, raw, len2, &keep, len1);
+                    const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
+                    if ((tiles_done++ & 7u) == 0) topk_refresh_bound(p, limit);
+                    if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
+                }
+            }
+            if (!has_next) break;
+            t = t_next;
+            cur = ahead;
+        }
+    }
+    if (topk) topk_block_publish(p, best, lds_topk, wave, lane, limit);
+}
+template <class State, int kFirst>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void early_lean_kernel(const ScanParams p)
+{
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    early_lean_body<State, kFirst>(p, lds_pm, lds_topk);
+}
+
 template <class State, bool kUniform, int kFirst>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void early_kernel(const ScanParams p)
 {
@@ -478,12 +575,15 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             // four SIMDs sharing one scalar unit about as much time as its 139 vector instructions (cutoff 3: 217 -> 237
             // Gpairs/s, top-16 237 -> 263).  RF_EARLY_STATIC=0 selects the run-time form for A/B.
             static const bool early_static = [] { const char* e = getenv("RF_EARLY_STATIC"); return !e || atoi(e) != 0; }();
+            static const bool lean = [] { const char* e = getenv("RF_EARLY_LEAN"); return !e || atoi(e) != 0; }();  // A/B: early_lean_kernel
             if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value) {
                 if (early_static) {
 #define RF_EARLY_CASE(J)                                                                   \
     case J:                                                                                \
         if (p.tiles)                                                                       \
             hipLaunchKernelGGL((early_kernel<State, false, J>), g, b, 0, stream, p);       \
+        else if (lean && p.uniform_len >= (uint32_t)kChunk)                                \
+            hipLaunchKernelGGL((early_lean_kernel<State, J>), g, b, 0, stream, p);         \
         else                                                                               \
             hipLaunchKernelGGL((early_kernel<State, true, J>), g, b, 0, stream, p);        \
         return hipGetLastError();
