@@ -70,42 +70,54 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void band_kernel(const ScanP
             const uint32_t cols = min((uint32_t)kChunk, len2 - c * kChunk);
             // 16 columns = 4 dwords x 4 bytes with COMPILE-TIME byte positions: `((dw >> 8k) & 0xFF) * stride` is one
             // v_mul_u32_u24_sdwa; walking the chunk with a running byte shift cost three v_alignbit_b32 + a shift + an and + a
-            // v_mul_lo_u32 per column -- six instructions, five of them half-rate on gfx950 (profiles/issue_rates_r02.txt)
+            // v_mul_lo_u32 per column -- six instructions, five of them half-rate on gfx950 (profiles/issue_rates_r02.txt).
+            // Columns go in runs of 8 (the reference's break test, :568-570 / :607-609, is evaluated per wavefront after each run);
+            // a run that lies entirely on the diagonal walk and inside the chunk -- the common case -- is a straight line with no
+            // per-column scalar tests: the first version spent 340 scalar instructions per tile next to 550 vector ones, and four
+            // SIMDs share one scalar unit.
             const uint32_t dws[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-            for (int dq = 0; dq < 4 && !dead; ++dq) {
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const uint32_t bcol = (uint32_t)(dq * 4 + kb);
-                    if (bcol >= cols) break;  // wavefront-uniform
-                    const uint32_t j = c * kChunk + bcol;
-                    const uint32_t* row = lds_band + ((dws[dq] >> (8 * kb)) & 0xFFu) * stride + (v >> 5);
-                    const uint32_t d0w = row[0], d1w = row[1], d2w = row[2];
-                    const uint32_t sh = v & 31;
-                    const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2w, d1w, sh) << 32) | __builtin_amdgcn_alignbit(d1w, d0w, sh);
-                    const uint64_t sum = (x & vp) + vp;
-                    const uint64_t e = lut3<T_XOR_OR>(sum, vp, x);
-                    const uint64_t d0 = e | vn;                     // levenshtein.rs:556 / :593
-                    const uint64_t hp = lut3<T_OR_NOR>(vn, e, vp);  // vn | ~(d0 | vp)
-                    const uint64_t hn = e & vp;                     // d0 & vp (vp & vn == 0)
-                    if (j < first) {                                // :560-562 (wavefront-uniform)
-                        diag_hits += (uint32_t)(d0 >> 63);
-                        score = k + (j + 1) - diag_hits;
-                    } else {                                        // :597-600: the last row, at a bit that moves down
-                        const uint64_t hmask = 1ull << (62 - (j - first));
-                        score += (hp & hmask) != 0;
-                        score -= (hn & hmask) != 0;
-                    }
-                    const uint64_t d0s = d0 >> 1;
-                    vp = lut3<T_OR_NOR>(hn, d0s, hp);               // :571 / :611
-                    vn = d0s & hp;
-                    ++v;
-                    if ((bcol & 7) == 7 || bcol + 1 == cols)  // :568-570 / :607-609, checked per wavefront every 8 columns
-                        if (__ballot(valid && score <= break_score) == 0) {
-                            dead = true;
-                            break;
-                        }
+            auto column = [&](uint32_t sym, uint32_t j, bool diagonal) {
+                const uint32_t* row = lds_band + sym * stride + (v >> 5);
+                const uint32_t d0w = row[0], d1w = row[1], d2w = row[2];
+                const uint32_t sh = v & 31;
+                const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2w, d1w, sh) << 32) | __builtin_amdgcn_alignbit(d1w, d0w, sh);
+                const uint64_t sum = (x & vp) + vp;
+                const uint64_t e = lut3<T_XOR_OR>(sum, vp, x);
+                const uint64_t d0 = e | vn;                     // levenshtein.rs:556 / :593
+                const uint64_t hp = lut3<T_OR_NOR>(vn, e, vp);  // vn | ~(d0 | vp)
+                const uint64_t hn = e & vp;                     // d0 & vp (vp & vn == 0)
+                if (diagonal) {                                 // :560-562
+                    diag_hits += (uint32_t)(d0 >> 63);
+                } else {                                        // :597-600: the last row, at a bit that moves down
+                    const uint64_t hmask = 1ull << (62 - (j - first));
+                    score += (hp & hmask) != 0;
+                    score -= (hn & hmask) != 0;
                 }
+                const uint64_t d0s = d0 >> 1;
+                vp = lut3<T_OR_NOR>(hn, d0s, hp);               // :571 / :611
+                vn = d0s & hp;
+                ++v;
+            };
+#pragma unroll
+            for (int run = 0; run < 2; ++run) {
+                const uint32_t b0 = (uint32_t)run * 8, j0 = c * kChunk + b0;
+                if (b0 >= cols || dead) break;  // wavefront-uniform
+                if (b0 + 8 <= cols && j0 + 8 <= first) {
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) column((dws[run * 2 + kb / 4] >> (8 * (kb % 4))) & 0xFFu, j0 + kb, true);
+                    score = k + (j0 + 8) - diag_hits;           // :561: the running total of the diagonal walk
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) {
+                        if (b0 + kb < cols) {
+                            const uint32_t j = j0 + kb;
+                            const bool diagonal = j < first;
+                            column((dws[run * 2 + kb / 4] >> (8 * (kb % 4))) & 0xFFu, j, diagonal);
+                            if (diagonal) score = k + (j + 1) - diag_hits;
+                        }
+                    }
+                }
+                if (__ballot(valid && score <= break_score) == 0) dead = true;
             }
             cur = nxt;
         }
@@ -122,7 +134,11 @@ hipError_t launch_band(const ScanParams& p, hipStream_t stream)
 {
     if (p.tile_end <= p.tile_begin) return hipSuccess;
     const size_t lds = (size_t)256 * band_row_dwords(p.words) * sizeof(uint32_t);
-    const dim3 g(std::max(1, scan_grid(p.tile_end - p.tile_begin))), b(kWave * kWavesPerBlock);
+    // every workgroup stages the 32-bit band table (256 x (2W + 5) dwords: 13 KiB at 256 symbols) before its first tile, and a
+    // tile dies after 8-16 columns: half the general launches' workgroups per CU measured best (configs[2] corpus, cutoff 8:
+    // 8 or 16 per CU 76.7 Gpairs/s, 24: 72.7, 32: 67.8, 64: 55.5)
+    const int band_grid = std::max(1, std::min(scan_grid(p.tile_end - p.tile_begin), (scan_max_grid() + 1) / 2));
+    const dim3 g(band_grid), b(kWave * kWavesPerBlock);
     auto kern = p.tiles ? band_kernel<false> : band_kernel<true>;
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
