@@ -1681,14 +1681,16 @@ def test_asm_chunk_kernel_single_length_corpora(len2):
             if r % 2: row = np.roll(row, 1)  # and shifted by one: insertions / deletions, not only substitutions
             host[r] = row
         corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
+        for metric in ("levenshtein", "indel", "lcs_seq"):  # lev1_asm / lev32_asm / lcs1_asm kernels (and the compiled Lcs32State)
+            bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+            for opname, op in OPS.items():
+                got = bc.many(op, corpus)
+                exp = ob.rows(op, host, nthreads=8)
+                if got.dtype == np.uint32:
+                    assert (got == _expect_u32(exp)).all(), (metric, len1, len2, opname)
+                else:
+                    assert (got == exp).all(), (metric, len1, len2, opname)
         bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
-        for opname, op in OPS.items():
-            got = bc.many(op, corpus)
-            exp = ob.rows(op, host, nthreads=8)
-            if got.dtype == np.uint32:
-                assert (got == _expect_u32(exp)).all(), (len1, len2, opname)
-            else:
-                assert (got == exp).all(), (len1, len2, opname)
         dist = ob.rows(N.OP_DISTANCE, host, nthreads=8)
         order = np.lexsort((np.arange(n), dist))[:16]
         s, i = bc.topk(corpus, 16)
