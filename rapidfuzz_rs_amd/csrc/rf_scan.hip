@@ -572,13 +572,14 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             // cutoff runs: the compiler's own register budget.  Pinned to 8 wavefronts per SIMD this body spills (32 B of
             // scratch traffic per tile in a loop that only runs 8 columns); 7 resident wavefronts without spills
             // measured +8 % at cutoff 3 and +3 % at cutoff 10 on the C2 corpus.
-            // The Levenshtein family gets the look's column (and `early` itself) as compile-time facts: the run-time dispatch
+            // The single-word states get the look's column (and `early` itself) as compile-time facts: the run-time dispatch
             // and flags cost the short per-tile loop of a cutoff scan 83 scalar instructions and 34 branches per tile -- with
             // four SIMDs sharing one scalar unit about as much time as its 139 vector instructions (cutoff 3: 217 -> 237
             // Gpairs/s, top-16 237 -> 263).  RF_EARLY_STATIC=0 selects the run-time form for A/B.
             static const bool early_static = [] { const char* e = getenv("RF_EARLY_STATIC"); return !e || atoi(e) != 0; }();
             static const bool lean = [] { const char* e = getenv("RF_EARLY_LEAN"); return !e || atoi(e) != 0; }();  // A/B: early_lean_kernel
-            if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value) {
+            if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value ||
+                          std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value) {
                 if (early_static) {
 #define RF_EARLY_CASE(J)                                                                   \
     case J:                                                                                \
