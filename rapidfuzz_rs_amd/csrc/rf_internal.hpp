@@ -125,6 +125,7 @@ struct ScanParams {
 
 // kernel launchers (rf_scan.hip, rf_long.hip, rf_jaro.hip, rf_pack.hip)
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
+hipError_t launch_osa1_asm(const ScanParams& p, hipStream_t stream, int grid);   // the same around the OSA column (OsaState<1>)
 hipError_t launch_lev32_asm(const ScanParams& p, hipStream_t stream, int grid);  // the same for queries of <= 32 symbols (Lev32State)
 hipError_t launch_lev1_asm(const ScanParams& p, hipStream_t stream, int grid);  // rf_lev_asm.hip: single-word Levenshtein, single-length corpus, no early-out
 void launch_lev1_asm_probe(dim3 g, dim3 b, uint32_t* out, int iters, uint32_t seed);  // rf_lev_asm.hip: the asm chunk alone (rf_probe_issue_rate mode 2)

@@ -562,6 +562,8 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                 return launch_lev1_asm(p, stream, grid);
             if (std::is_same<State, Lev32State>::value && !p.tiles && use_asm && p.uniform_len >= (uint32_t)kChunk && p.uniform_len % kChunk == 0)
                 return launch_lev32_asm(p, stream, grid);
+            if (std::is_same<State, OsaState<1>>::value && !p.tiles && use_asm && p.uniform_len >= (uint32_t)kChunk && p.uniform_len % kChunk == 0)
+                return launch_osa1_asm(p, stream, grid);
             if (p.tiles)
                 hipLaunchKernelGGL((stream_kernel_occ8<State, false, kDepth>), g, b, 0, stream, p);
             else

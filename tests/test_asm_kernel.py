@@ -17,6 +17,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CASES = [  # source file, mangled kernel, pinned registers, wavefronts per SIMD the launch is budgeted for, VGPR limit
     ("rf_lev_asm.hip", "_ZN2rf15lev1_asm_kernelENS_10ScanParamsE", r"(3[4-9]|4[0-9]|6[0-3])", 8, 64),
     ("rf_lev_asm.hip", "_ZN2rf16lev32_asm_kernelENS_10ScanParamsE", r"(3[4-9]|4[01]|6[01])", 8, 64),
+    ("rf_lev_asm.hip", "_ZN2rf15osa1_asm_kernelENS_10ScanParamsE", r"(3[4-9]|4[0-9]|5[89]|6[0-3])", 8, 64),
     ("rf_jaro.hip", "_ZN2rf20jaro_word_asm_kernelENS_10ScanParamsE", r"(5[89]|6[0-3])", 7, 72),
 ]
 

@@ -1681,7 +1681,7 @@ def test_asm_chunk_kernel_single_length_corpora(len2):
             if r % 2: row = np.roll(row, 1)  # and shifted by one: insertions / deletions, not only substitutions
             host[r] = row
         corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
-        for metric in ("levenshtein", "indel", "lcs_seq"):  # lev1_asm / lev32_asm / lcs1_asm kernels (and the compiled Lcs32State)
+        for metric in ("levenshtein", "osa", "indel", "lcs_seq"):  # lev1_asm / lev32_asm / osa1_asm kernels and the compiled LCS states
             bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
             for opname, op in OPS.items():
                 got = bc.many(op, corpus)

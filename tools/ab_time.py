@@ -11,7 +11,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "lev64"
 n = int(os.environ.get("AB_N", 100_000_000))
 cfg = {
     "lev64": ("levenshtein", 64, 64, {}), "lev32": ("levenshtein", 32, 64, {}), "indel": ("indel", 64, 64, {}), "osa": ("osa", 64, 64, {}),
-    "lev256": ("levenshtein", 256, 256, {}), "indel256": ("indel", 256, 256, {}), "levrag": ("levenshtein", 64, 64, {}), "indelrag": ("indel", 64, 64, {}), "osarag": ("osa", 64, 64, {}), "lev32rag": ("levenshtein", 32, 64, {}), "indel128": ("indel", 128, 64, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
+    "lev256": ("levenshtein", 256, 256, {}), "indel256": ("indel", 256, 256, {}), "levrag": ("levenshtein", 64, 64, {}), "levragc3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "indelragc12": ("indel", 64, 64, {"score_cutoff": 12}), "indelrag": ("indel", 64, 64, {}), "osarag": ("osa", 64, 64, {}), "lev32rag": ("levenshtein", 32, 64, {}), "indel128": ("indel", 128, 64, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
     "jaro": ("jaro", 64, 64, {}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
 }
 import re as _re
@@ -22,7 +22,7 @@ metric, qlen, clen, kw = cfg
 if clen == 256 and qlen == 256:
     n //= 10
 q = synth.query(qlen, 0xC0FFEE02)
-if what.split("+")[0].endswith("rag"):  # ragged corpus: lengths uniform in [20, 64] -> exact tiles of 45 lengths, most with a partial last chunk
+if "rag" in what.split("+")[0]:  # ragged corpus: lengths uniform in [20, 64] -> exact tiles of 45 lengths, most with a partial last chunk
     import numpy as np
     n = int(os.environ.get("AB_N", 20_000_000))
     rng = np.random.default_rng(5)

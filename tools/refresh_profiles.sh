@@ -12,7 +12,7 @@ P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
 P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
 P c4_indel "indel:q64:n100000000:l64:cutNone:many" --metric indel
 MATCH="rf::jaro" P c4_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many" --metric jaro_winkler
-P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
+MATCH="rf::osa1_asm" P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
 MATCH="rf::lev32_asm" P q32_levenshtein "levenshtein:q32:n100000000:l64:cutNone:many" --query-len 32
 P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" --cutoff 3 --mode topk
 MATCH="rf::lev1_asm" P topk16_nocutoff "levenshtein:q64:n100000000:l64:cutNone:topk" --mode topk
