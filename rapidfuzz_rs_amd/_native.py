@@ -76,7 +76,7 @@ SYMBOLS = [
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of librfgpu.so (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp")) or f == "Makefile"]
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".hpp", ".inc")) or f == "Makefile"]
     deps.append(os.path.join(_HERE, "..", "include", "rfgpu.h"))
     def is_stale() -> bool:
         return force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
