@@ -72,6 +72,15 @@ typedef enum rf_mem { RF_MEM_HOST = 0, RF_MEM_DEVICE = 1 } rf_mem;
  *   cutoff_f64   : NaN = NoScoreCutoff, else WithScoreCutoff(v) for the f64-valued ops
  *   score_hint_* : accepted and ignored -- in the reference a hint only steers the CPU band search
  *                  (levenshtein.rs:1069-1088); results never depend on it (levenshtein.rs:2153-2160)
+ *
+ * Two places where the device deliberately does NOT reproduce what release-mode rapidfuzz 0.5.0 returns (both tested,
+ * tests/test_gpu_parity.py, both also in DESIGN.md section 3):
+ *   Q7  For len1 > 64 and an explicit score_hint with 2 * max(hint, 31) < len1 - len2, the reference's hint-doubling loop
+ *       (levenshtein.rs:1069-1088) calls the small-band kernel without the |len1 - len2| guard hyrroe2003_block has, and
+ *       its result then DEPENDS on the hint (an upstream defect, reproduced by the oracle).  The device ignores hints and
+ *       returns the exact distance -- what the reference returns for every other hint.
+ *   Q2  levenshtein similarity_with_args above its cutoff evaluates `maximum - usize::MAX` (details/distance.rs:209-210:
+ *       a panic in debug builds, a wrapped value in release builds).  The device returns None.
  */
 typedef struct rf_args {
     uint64_t cutoff_usize;

@@ -1228,12 +1228,17 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
             if (need >= 0.6 && need <= 1.0) p->jaro_need = need;
         }
         // Single-word path (jaro.rs:574-583) when both strings are <= 64 symbols AFTER the window truncation of
-        // jaro.rs:550-565, multi-word path (up to 512 symbols each) otherwise.  Tiles ascend by length and the
-        // single-word condition holds for a length prefix, so the corpus splits at one tile index.
+        // jaro.rs:550-565, multi-word path (up to 512 symbols each) otherwise.  Tiles ascend by length TWICE -- the exact
+        // tiles, then the one-length views of the mixed section -- and the single-word condition holds for a length prefix
+        // of each run, so each section splits at one tile index (jaro_split, jaro_split2): a short leftover behind a long
+        // exact tile still takes the single-word kernel.
         const uint64_t len1 = c->s1.size();
-        p->jaro_split = corpus->n_tiles;
+        p->jaro_split = corpus->n_exact;
+        p->jaro_split2 = corpus->n_tiles;
         bool in_block = false;
         for (size_t i = 0; i < corpus->lengths.size(); ++i) {
+            const bool virt = corpus->length_first_tile[i] >= corpus->n_exact;
+            if (virt && (i == 0 || corpus->length_first_tile[i - 1] < corpus->n_exact)) in_block = false;  // the second run starts over
             uint64_t a = len1, b = corpus->lengths[i];
             if (b > a) {
                 const uint64_t bound = b / 2 - 1;
@@ -1246,7 +1251,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
             const bool word_ok = !needs_flags || (a <= 64 && b <= 64);
             if (!word_ok && !in_block) {
                 in_block = true;
-                p->jaro_split = corpus->length_first_tile[i];
+                (virt ? p->jaro_split2 : p->jaro_split) = corpus->length_first_tile[i];
             }
             if (in_block && needs_flags && (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords))
                 p->jaro_long = 1;  // beyond 512 symbols: the flag words move from registers to global scratch strips
@@ -1683,7 +1688,9 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         set_error("top-k: usize-valued metrics only");
         return RF_ERR_INVALID_ARG;
     }
-    if (p.long_words_pad || raw == RAW_WF) {
+    // (a long query under a small cutoff is planned onto the band kernel, which has no top-k epilogue, and the register-resident
+    // scans stop at 8 words: beyond 512 symbols that shape goes the selection way like every other long query -- ADVICE r2)
+    if (p.long_words_pad || raw == RAW_WF || (p.band && c->words > (size_t)kMaxWords)) {
         set_error("top-k: queries longer than 512 symbols and general Levenshtein weight tables are served by rf_many_* only");
         return RF_ERR_UNSUPPORTED;
     }
@@ -1937,7 +1944,7 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         const rf_status s = topk_by_selection(c, corpus, op, args, k, false, out_all, out_all_mem, (hipStream_t)stream, &keys, &idx, &desc);
         if (s != RF_OK) return s;
         for (size_t i = 0; i < keys.size(); ++i) {
-            out_score[i] = desc ? ~(uint32_t)keys[i] : (uint32_t)keys[i];
+            out_score[i] = desc ? 0xFFFFFFFEu - (uint32_t)keys[i] : (uint32_t)keys[i];  // KeyOf<uint32_t>::get, rf_select.hip
             out_index[i] = index_base + idx[i];
         }
         *out_count = (uint32_t)keys.size();
@@ -1965,7 +1972,7 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         s = topk_by_selection(c, corpus, op, args, k, false, out_all, out_all_mem, st, &keys, &idx, &desc);
         if (s != RF_OK) return s;
         for (size_t i = 0; i < keys.size(); ++i) {
-            out_score[i] = desc ? ~(uint32_t)keys[i] : (uint32_t)keys[i];
+            out_score[i] = desc ? 0xFFFFFFFEu - (uint32_t)keys[i] : (uint32_t)keys[i];  // KeyOf<uint32_t>::get, rf_select.hip
             out_index[i] = index_base + idx[i];
         }
         *out_count = (uint32_t)keys.size();

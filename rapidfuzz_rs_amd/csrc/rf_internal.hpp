@@ -88,7 +88,8 @@ struct ScanParams {
     uint32_t wf_waves;              // wavefronts per workgroup of wf_kernel (LDS rows per wavefront: (len1 + 1) * 256 B)
     uint32_t tile_step;             // >= 1: visit every tile_step-th tile of the range (the top-k bound sample)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
-    uint32_t jaro_split;   // first tile that needs the multi-word jaro path
+    uint32_t jaro_split;   // first EXACT tile that needs the multi-word jaro path (n_exact = none)
+    uint32_t jaro_split2;  // the same for the one-length views of the mixed section, tiles [n_exact, n_tiles)
     uint32_t jaro_long;    // 1: some string exceeds 512 symbols: the multi-word tiles run jaro_long_kernel (flags in long_scratch)
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
     double cutoff_f64;

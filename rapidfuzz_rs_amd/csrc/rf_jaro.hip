@@ -882,51 +882,67 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_asm_kernel(co
 #undef RF_P2
 }
 
-hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
+static hipError_t launch_jaro_word(const ScanParams& p, ScanParams q, hipStream_t stream)
 {
-    // tiles [tile_begin, jaro_split) take the single-word path, [jaro_split, tile_end) the multi-word path
-    // (tiles ascend by length, and the single-word condition holds for a length prefix)
     const dim3 b(kWave * kWavesPerBlock);
-    ScanParams q = p;
-    q.tile_begin = p.tile_begin;  // (the cutoff's length window, plan())
-    q.tile_end = std::min(p.jaro_split, p.tile_end);
-    if (q.tile_end > q.tile_begin) {
-        const bool early = p.jaro_need >= 0.0;
-        const dim3 g(early ? scan_grid(q.tile_end - q.tile_begin) : scan_grid_full(q.tile_end - q.tile_begin));
-        const bool fast = !p.has_cutoff && p.jaro_tab != nullptr;  // the table epilogue (no cutoff to replay)
-        auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : (fast ? jaro_word_fast_kernel<false> : jaro_word_kernel<false, false>))
-                         : (early ? jaro_word_kernel<true, true> : (fast ? jaro_word_fast_kernel<true> : jaro_word_kernel<true, false>));
-        // the hand-scheduled kernel: single-length corpus, table epilogue, truncated candidate length a multiple of 16
-        static const bool use_asm = [] { const char* e = getenv("RF_ASM_CHUNK"); return !e || atoi(e) != 0; }();
-        bool asm_ok = use_asm && fast && !early && !p.tiles && p.len1 >= 2;
-        if (asm_ok) {
-            uint32_t len1 = p.len1, len2 = p.uniform_len, bound = 0;  // jaro.rs:550-565, as in the kernel
-            if (len2 > len1) {
-                bound = len2 / 2 - 1;
-                if (len2 > len1 + bound) len2 = len1 + bound;
-            }
-            asm_ok = len2 >= (uint32_t)kChunk && len2 % kChunk == 0 && len2 <= 64;
+    const bool early = p.jaro_need >= 0.0;
+    const dim3 g(early ? scan_grid(q.tile_end - q.tile_begin) : scan_grid_full(q.tile_end - q.tile_begin));
+    const bool fast = !p.has_cutoff && p.jaro_tab != nullptr;  // the table epilogue (no cutoff to replay)
+    auto k = p.tiles ? (early ? jaro_word_kernel<false, true> : (fast ? jaro_word_fast_kernel<false> : jaro_word_kernel<false, false>))
+                     : (early ? jaro_word_kernel<true, true> : (fast ? jaro_word_fast_kernel<true> : jaro_word_kernel<true, false>));
+    // the hand-scheduled kernel: single-length corpus, table epilogue, truncated candidate length a multiple of 16
+    static const bool use_asm = [] { const char* e = getenv("RF_ASM_CHUNK"); return !e || atoi(e) != 0; }();
+    bool asm_ok = use_asm && fast && !early && !p.tiles && p.len1 >= 2;
+    if (asm_ok) {
+        uint32_t len1 = p.len1, len2 = p.uniform_len, bound = 0;  // jaro.rs:550-565, as in the kernel
+        if (len2 > len1) {
+            bound = len2 / 2 - 1;
+            if (len2 > len1 + bound) len2 = len1 + bound;
         }
-        if (asm_ok)
-            hipLaunchKernelGGL(jaro_word_asm_kernel, g, b, 0, stream, q);
-        else
-            hipLaunchKernelGGL(k, g, b, 0, stream, q);
+        asm_ok = len2 >= (uint32_t)kChunk && len2 % kChunk == 0 && len2 <= 64;
     }
-    q.tile_begin = std::max(p.jaro_split, p.tile_begin);
-    q.tile_end = p.tile_end;
-    if (q.tile_end > q.tile_begin && p.jaro_long) {  // some string is beyond 512 symbols: flags in the global scratch strips
+    if (asm_ok)
+        hipLaunchKernelGGL(jaro_word_asm_kernel, g, b, 0, stream, q);
+    else
+        hipLaunchKernelGGL(k, g, b, 0, stream, q);
+    return hipGetLastError();
+}
+static hipError_t launch_jaro_block(const ScanParams& p, ScanParams q, hipStream_t stream)
+{
+    const dim3 b(kWave * kWavesPerBlock);
+    if (p.jaro_long) {  // some string is beyond 512 symbols: flags in the global scratch strips
         const dim3 g(std::max(1u, std::min<uint32_t>(p.long_grid, (uint32_t)scan_grid(q.tile_end - q.tile_begin))));
         if (p.tiles)
             hipLaunchKernelGGL(jaro_long_kernel<false>, g, b, 0, stream, q);
         else
             hipLaunchKernelGGL(jaro_long_kernel<true>, g, b, 0, stream, q);
-    } else if (q.tile_end > q.tile_begin) {
+    } else {
         const dim3 g(scan_grid(q.tile_end - q.tile_begin));
         const size_t lds = ((size_t)256 * p.words + p.words + 1) * sizeof(uint64_t);
         if (p.tiles)
             hipLaunchKernelGGL(jaro_block_kernel<false>, g, b, lds, stream, q);
         else
             hipLaunchKernelGGL(jaro_block_kernel<true>, g, b, lds, stream, q);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_jaro(const ScanParams& p, hipStream_t stream)
+{
+    // Two runs of tiles, each ascending by length: the exact tiles [0, n_exact) and the one-length views of the mixed section
+    // [n_exact, n_tiles).  In each run the tiles below the split (jaro_split / jaro_split2, plan()) take the single-word path and
+    // the rest the multi-word path -- so the short leftovers behind a long exact tile are not dragged into the block kernel.
+    // All of it clipped to [tile_begin, tile_end), the cutoff's length window.
+    const uint32_t n_exact = std::min(p.n_exact, p.n_tiles);
+    const uint32_t lo[4] = {0, std::min(p.jaro_split, n_exact), n_exact, std::max(n_exact, std::min(p.jaro_split2, p.n_tiles))};
+    const uint32_t hi[4] = {lo[1], n_exact, lo[3], p.n_tiles};
+    for (int r = 0; r < 4; ++r) {
+        ScanParams q = p;
+        q.tile_begin = std::max(lo[r], p.tile_begin);
+        q.tile_end = std::min(hi[r], p.tile_end);
+        if (q.tile_end <= q.tile_begin) continue;
+        const hipError_t e = (r % 2 == 0) ? launch_jaro_word(p, q, stream) : launch_jaro_block(p, q, stream);
+        if (e != hipSuccess) return e;
     }
     return hipGetLastError();
 }

@@ -654,7 +654,8 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
     // A corpus with a mixed section (leftovers of every length pooled into tiles with per-lane lengths) is scanned in two
     // launches by the register-resident Levenshtein / LCS / OSA kernels: the exact tiles as always, the mixed tiles by
     // scan_kernel_mixed.  Top-k, multi-query and the other kernel families walk the one-length views instead (p stays as is).
-    if (p.mixed && p.mixed_end > p.mixed_begin && !p.topk_k && !p.long_words_pad && p.words <= (uint32_t)kMaxWords &&
+    // (band launches walk the one-length views instead: band_kernel has no per-lane-length form)
+    if (p.mixed && p.mixed_end > p.mixed_begin && !p.topk_k && !p.long_words_pad && !p.band && p.words <= (uint32_t)kMaxWords &&
         (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA) && p.tile_step == 1) {
         ScanParams q = p;
         q.mixed = nullptr;

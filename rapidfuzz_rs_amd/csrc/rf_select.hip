@@ -4,7 +4,7 @@
 // Definition (rfgpu.h "top-k"): drop None, order by (score ascending for distances / descending for similarities, index
 // ascending), keep the first k.  The reference has no extract API; the oracle is "sort the full result".
 //
-// A score becomes an order-preserving unsigned key (u32: the score or its complement; f64: the sign-flipped IEEE bits or
+// A score becomes an order-preserving unsigned key (u32: the score, or 0xFFFFFFFE minus it; f64: the sign-flipped IEEE bits or
 // their complement), None becomes the maximum key and is never selected.  Then
 //   1. minmax pass            the key range; the radix passes below start at its first differing bit
 //   2. digit passes (11 bits) histogram of the next digit among keys matching the prefix found so far -> the k-th smallest
@@ -30,7 +30,9 @@ struct KeyOf;
 template <>
 struct KeyOf<uint32_t> {
     using Score = uint32_t;
-    static __device__ __forceinline__ uint32_t get(uint32_t s, bool desc) { return s == RF_NONE_U32 ? ~0u : (desc ? ~s : s); }
+    // valid scores are 0 .. 0xFFFFFFFE (0xFFFFFFFF is None), so the descending key is 0xFFFFFFFE - s: a similarity of 0 must
+    // not land on the None key (`~s` did, and the selection path lost every zero-similarity candidate)
+    static __device__ __forceinline__ uint32_t get(uint32_t s, bool desc) { return s == RF_NONE_U32 ? ~0u : (desc ? 0xFFFFFFFEu - s : s); }
 };
 template <>
 struct KeyOf<uint64_t> {

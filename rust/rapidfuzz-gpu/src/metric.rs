@@ -77,7 +77,9 @@ macro_rules! comparator_core {
         impl Clone for BatchComparator {
             fn clone(&self) -> Self {
                 let mut h = std::ptr::null_mut();
-                unsafe { rf_comparator_clone(self.0, &mut h) };
+                // (the reference's constructors cannot fail; an allocation failure here panics with the library's message
+                // instead of handing out a null handle)
+                check(unsafe { rf_comparator_clone(self.0, &mut h) }).expect("rf_comparator_clone");
                 Self(h)
             }
         }
@@ -91,14 +93,14 @@ macro_rules! comparator_core {
             pub fn new<I: IntoIterator<Item = u8>>(s1: I) -> Self {
                 let s1: Vec<u8> = s1.into_iter().collect();
                 let mut h = std::ptr::null_mut();
-                unsafe { rf_comparator_new($metric, s1.as_ptr(), s1.len(), &mut h) };
+                check(unsafe { rf_comparator_new($metric, s1.as_ptr(), s1.len(), &mut h) }).expect("rf_comparator_new");
                 Self(h)
             }
             /// `BatchComparator::new(s1.chars())`: searched in corpora built by `Corpus::from_chars`.
             pub fn from_chars<I: IntoIterator<Item = char>>(s1: I) -> Self {
                 let s1: Vec<u32> = s1.into_iter().map(|c| c as u32).collect();
                 let mut h = std::ptr::null_mut();
-                unsafe { rf_comparator_new_u32($metric, s1.as_ptr(), s1.len(), &mut h) };
+                check(unsafe { rf_comparator_new_u32($metric, s1.as_ptr(), s1.len(), &mut h) }).expect("rf_comparator_new_u32");
                 Self(h)
             }
         }

@@ -1380,6 +1380,11 @@ def test_bench_c5_preset_same_answer_for_every_world_size():
     d2 = _bench_json(base + ["--gpus", "2"], dict(env, RF_BENCH_BACKEND="gloo"))
     assert d2["n_gpus"] == 2 and d2["parity"]["mismatches"] == 0
     assert d2["config"]["topk_checksum"] == d1["config"]["topk_checksum"] and d2["config"]["topk_best"] == d1["config"]["topk_best"]
+    # the real rank count of configs[4]: 8 ranks (sharing this box's one GPU, exchange over gloo) cut the same logical corpus
+    # into 8 shards with 8 index bases and must merge to the same keys
+    d8 = _bench_json(base + ["--gpus", "8"], dict(env, RF_BENCH_BACKEND="gloo"))
+    assert d8["n_gpus"] == 8 and d8["config"]["ranks_joined"] == 8 and d8["parity"]["mismatches"] == 0
+    assert d8["config"]["topk_checksum"] == d1["config"]["topk_checksum"] and d8["config"]["topk_best"] == d1["config"]["topk_best"]
 
 
 @pytest.mark.parametrize("k", [1, 2, 16])
@@ -1770,6 +1775,135 @@ def test_randomized_single_length_corpora(seed):
             else:
                 bad = np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
             assert len(bad) == 0, (metric, opname, kw, len1, len2, n, (lo, hi), bad[:5], got[bad[:5]], exp[bad[:5]])
+
+
+@pytest.mark.parametrize("mode", ["rows", "ragged"])
+def test_asm_kernels_many_tiles_per_wavefront(mode):
+    """with the default grid a wavefront owns a second tile only beyond 16.8 M candidates, so the tests
+    above never exercise the hand-scheduled kernels' cross-tile fetch ring, state re-arm, parked fetch cursor and mid-block tail
+    entries.  tests/multitile_check.py runs in a subprocess with RF_SCAN_BLOCKS_PER_CU_FULL=1 (1024 wavefronts) over ~300 k
+    candidates: >= 4 tiles per wavefront, all asm kernels (Levenshtein 64-/32-bit, OSA, Jaro / JW) and the compiled Indel scan,
+    lengths 16..160 ("rows") and every length 0..70 ("ragged"), all four ops and the in-scan top-16, full-array oracle compare."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "multitile_check.py"), mode], capture_output=True, text=True, cwd=root,
+                       env=dict(os.environ, RF_SCAN_BLOCKS_PER_CU_FULL="1"))
+    assert r.returncode == 0, (r.stdout[-4000:], r.stderr[-2000:])
+    assert "FAILURES 0" in r.stdout
+
+
+def test_full_size_osa_and_query32_properties():
+    """VERDICT r2 item 1a, second half: osa1_asm_kernel and lev32_asm_kernel at BASELINE's full 100 M x 64 size (6 tiles per
+    wavefront with the product grid), like test_full_size_c2_properties does for lev1_asm_kernel: an oracle-checked prefix plus
+    properties that tie them to kernels sharing no code with them."""
+    import torch
+
+    n, ln = 100_000_000, 64
+    dev = torch.device("cuda", 0)
+    q64, q32 = synth.query(64, 0xC0FFEE02), synth.query(32, 0xC0FFEE05)
+    rows = synth.rows_device(n, ln, seed=125, device=dev)
+    planted = torch.arange(4321, n, 1_000_003, device=dev)
+    rows[planted] = torch.tensor(list(q64), dtype=torch.uint8, device=dev)
+    rows[planted[::2], 7] = 33
+    rows[planted[1::2], :32] = torch.tensor(list(q32), dtype=torch.uint8, device=dev)
+    host_prefix = rows[:300_000].cpu().numpy()
+    host_tail = rows[n - 100_000:].cpu().numpy()  # the last tiles: the parked fetch cursor
+    corpus = rf.Corpus.from_device_rows(rows)
+    del rows
+    lev = torch.empty(n, dtype=torch.int32, device=dev)
+    osa = torch.empty(n, dtype=torch.int32, device=dev)
+    cut = torch.empty(n, dtype=torch.int32, device=dev)
+    for q, qname in ((q64, "q64"), (q32, "q32")):
+        rf.distance.levenshtein.BatchComparator(q).distance_many(corpus, out=lev)  # lev1_asm / lev32_asm
+        rf.distance.osa.BatchComparator(q).distance_many(corpus, out=osa)          # osa1_asm
+        for name, t, ora in (("levenshtein", lev, o.levenshtein), ("osa", osa, o.osa)):
+            exp = ora.BatchComparator(q).rows(N.OP_DISTANCE, host_prefix, nthreads=8)
+            assert (t[:300_000].cpu().numpy().view(np.uint32) == exp.astype(np.uint32)).all(), (name, qname)
+            exp = ora.BatchComparator(q).rows(N.OP_DISTANCE, host_tail, nthreads=8)
+            assert (t[n - 100_000:].cpu().numpy().view(np.uint32) == exp.astype(np.uint32)).all(), (name, qname, "tail")
+        assert bool((osa <= lev).all()) and bool((2 * osa >= lev).all())
+        assert int(lev.min()) >= 0 and int(lev.max()) <= 64
+        # the cutoff kernels (early_lean_kernel: different code, different launch shape) agree everywhere
+        for k in (2, 9):
+            rf.distance.levenshtein.BatchComparator(q).distance_many(corpus, out=cut, score_cutoff=k)
+            assert bool((cut == torch.where(lev <= k, lev, torch.full_like(lev, -1))).all()), (qname, k)
+            rf.distance.osa.BatchComparator(q).distance_many(corpus, out=cut, score_cutoff=k)
+            assert bool((cut == torch.where(osa <= k, osa, torch.full_like(osa, -1))).all()), (qname, k)
+        # similarity through the same kernels: max(len1, 64) - distance
+        rf.distance.levenshtein.BatchComparator(q).similarity_many(corpus, out=cut)
+        assert bool((cut == max(len(q), 64) - lev).all())
+        # top-16 of the asm kernels == the 16 smallest (distance, index) pairs
+        for bc, t in ((rf.distance.levenshtein.BatchComparator(q), lev), (rf.distance.osa.BatchComparator(q), osa)):
+            s, i = bc.topk(corpus, 16)
+            key = t.to(torch.int64) * (1 << 32) + torch.arange(n, device=dev, dtype=torch.int64)
+            best = torch.sort(key).values[:16].cpu().numpy()
+            assert [(int(b) >> 32, int(b) & 0xFFFFFFFF) for b in best] == list(zip(s.tolist(), i.tolist()))
+
+
+def test_topk_long_query_with_a_small_cutoff():
+    """a 513..4096-symbol query with a raw cutoff <= 31 is planned onto the band kernel, which has no
+    top-k epilogue; k <= 64 used to fall into launch_words with 10 words -> RF_ERR_HIP.  Now the selection path serves it."""
+    rng = np.random.default_rng(600)
+    q = bytes(rng.integers(97, 123, size=600, dtype=np.uint8))
+    cands = []
+    for i in range(3000):
+        b = bytearray(q)
+        for _ in range(int(rng.integers(0, 40))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(97, 123))
+        cands.append(bytes(b[: int(rng.integers(560, 601))]))
+    data, offsets = rf.ragged(cands)
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    bc = rf.distance.levenshtein.BatchComparator(q)
+    for k, cutoff in ((16, 31), (64, 10), (5, 0)):
+        s, i = bc.topk(corpus, k, score_cutoff=cutoff)
+        full = o.levenshtein.BatchComparator(q).many(N.OP_DISTANCE, data, offsets, score_cutoff=cutoff).tolist()
+        assert list(zip(s.tolist(), i.tolist())) == _topk_oracle(full, k, False, lambda v: v == 2**64 - 1), (k, cutoff)
+    import torch
+
+    with pytest.raises(rf.RfError) as e:  # the device-key variant has no selection path: refused, not a HIP error
+        bc.topk_keys_device(corpus, 16, torch.empty(16, dtype=torch.int64, device="cuda"), score_cutoff=31)
+    assert e.value.status == N.RF_ERR_UNSUPPORTED
+
+
+def test_topk_selection_keeps_zero_similarity():
+    """on the selection path (k > 64, long queries, general weights) a similarity of 0 mapped to the None key
+    and was dropped.  The definition is 'drop None, keep the first k' whatever k is."""
+    corpus = rf.Corpus.from_list([b"xyz"])
+    s, i = rf.distance.levenshtein.BatchComparator(b"abc").topk(corpus, 100, N.OP_SIMILARITY)
+    assert list(zip(s.tolist(), i.tolist())) == [(0, 0)]
+    s5, i5 = rf.distance.levenshtein.BatchComparator(b"abc").topk(corpus, 5, N.OP_SIMILARITY)
+    assert list(zip(s5.tolist(), i5.tolist())) == [(0, 0)]
+    # fewer than k non-zero similarities: the zero ones fill the list in index order, for every k
+    rng = np.random.default_rng(5)
+    cands = [bytes(rng.integers(48, 58, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(500)]  # digits: share nothing with the query
+    for j in (3, 77, 200, 450):
+        cands[j] = b"abcdefgh"[: 2 + j % 5]
+    data, offsets = rf.ragged(cands)
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    for metric in ("lcs_seq", "indel", "levenshtein"):
+        full = getattr(o, metric).BatchComparator(b"abcdefgh").many(N.OP_SIMILARITY, data, offsets).tolist()
+        for k in (10, 64, 65, 300, 1000):
+            s, i = GPU[metric].BatchComparator(b"abcdefgh").topk(corpus, k, N.OP_SIMILARITY)
+            assert list(zip(s.tolist(), i.tolist())) == _topk_oracle(full, k, True, lambda v: v == 2**64 - 1), (metric, k)
+
+
+def test_jaro_short_leftovers_behind_long_exact_tiles():
+    """the tile order is exact tiles ascending, then the views of the mixed section ascending again; the Jaro
+    plan now splits each run on its own, so short leftovers behind a long exact tile keep the single-word kernel.  Values are what
+    is asserted here (they were right before too); the split itself is visible in the kernel trace."""
+    rng = np.random.default_rng(9)
+    cands = [bytes(rng.integers(97, 105, size=700, dtype=np.uint8)) for _ in range(128)]   # two exact tiles far beyond 512 symbols
+    cands += [bytes(rng.integers(97, 105, size=int(L), dtype=np.uint8)) for L in rng.integers(0, 40, size=50)]  # leftovers: views
+    cands += [bytes(rng.integers(97, 105, size=90, dtype=np.uint8)) for _ in range(64)]    # an exact multi-word tile
+    cands += [bytes(rng.integers(97, 105, size=int(L), dtype=np.uint8)) for L in rng.integers(100, 600, size=20)]  # multi-word leftovers
+    data, offsets = rf.ragged(cands)
+    for q in (b"abcdefgh" * 3, bytes(rng.integers(97, 105, size=80, dtype=np.uint8))):
+        for metric in ("jaro", "jaro_winkler"):
+            for op in ("similarity", "distance"):
+                _check_many(metric, q, data, offsets, op)
+            _check_many(metric, q, data, offsets, "similarity", score_cutoff=0.7)
 
 
 def test_integration_md_python_example():
