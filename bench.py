@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=200.0,
                     help="untimed steps run for this long BEFORE the W warm-up steps: after the idle set-up phase the GPU's clock takes "
                          "~15 back-to-back launches to ramp (profiles/clock_ramp_r02.txt); 0 = off.  Reported as config.settle_steps")
+    ap.add_argument("--ragged", action="store_true",
+                    help="candidate lengths uniform in [1, --cand-len] instead of one fixed length (BASELINE.json configs[0]'s 'len <= 64' "
+                         "distribution at scale): the corpus is packed from host arrays into exact-length tiles + mixed tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -164,11 +167,42 @@ def main():
     sample_rows = min(n, 32_000_000)
     host_sample = None
     host_strided = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:  # the CPU baseline and the oracle parity leg run at N = 1 only
-        host_sample = rows[:sample_rows].cpu().numpy()
-        host_strided = rows[::1009].cpu().numpy()  # every 1009-th candidate of the WHOLE shard
-    corpus = rf.Corpus.from_device_rows(rows)
-    del rows
+    ragged_sample = None  # (data, offsets) of the first candidates / of every 1009-th candidate
+    ragged_strided = None
+    mean_len = float(ln)
+    if args.ragged:
+        if c5 or world > 1 or force_dist:
+            raise SystemExit("bench.py: --ragged is a single-GPU 'many' workload")
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xC0FFEE07)
+        lens = torch.randint(1, ln + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
+        offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(lens, 0)
+        flat = torch.empty(int(offsets[-1].item()), dtype=torch.uint8, device=dev)
+        col = torch.arange(ln, device=dev)[None, :]
+        for a in range(0, n, 1 << 23):  # (boolean indexing in slabs: one mask over all n x ln symbols overflows torch's index arithmetic)
+            b = min(n, a + (1 << 23))
+            flat[int(offsets[a].item()) : int(offsets[b].item())] = rows[a:b][col < lens[a:b, None]]  # row-major: candidate a's symbols, then a + 1's, ...
+        del rows, col
+        mean_len = float(offsets[-1].item()) / n
+        h_data, h_off = flat.cpu().numpy(), offsets.cpu().numpy().astype(np.uint64)
+        del flat, offsets, lens
+        if rank == 0 and not args.no_cpu_baseline:
+            m = min(n, 8_000_000)
+            ragged_sample = (h_data[: int(h_off[m])], h_off[: m + 1].copy())
+            pick = np.arange(0, n, 1009)
+            parts = [h_data[int(h_off[i]) : int(h_off[i + 1])] for i in pick]
+            so = np.zeros(len(pick) + 1, dtype=np.uint64)
+            so[1:] = np.cumsum([len(x) for x in parts])
+            ragged_strided = (np.concatenate(parts), so)
+        corpus = rf.Corpus.from_ragged(h_data, h_off, device=local_rank)
+        del h_data, h_off
+    else:
+        if rank == 0 and not args.no_cpu_baseline and world == 1:  # the CPU baseline and the oracle parity leg run at N = 1 only
+            host_sample = rows[:sample_rows].cpu().numpy()
+            host_strided = rows[::1009].cpu().numpy()  # every 1009-th candidate of the WHOLE shard
+        corpus = rf.Corpus.from_device_rows(rows)
+        del rows
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
     t_setup = time.time() - t0
@@ -312,6 +346,8 @@ def main():
     # Algorithmic bytes per pair, SURVEY.md 8(d): candidate bytes at bucket length + the result (u32 / f64 per candidate,
     # nothing in top-k-only mode); Q fused queries read each candidate once: ln / Q candidate bytes per pair.
     out_bytes = (8 if is_f64 else 4) if args.mode == "many" else 0
+    if args.ragged:
+        ln = mean_len  # algorithmic candidate bytes per pair: the mean candidate length (no padding byte is read or computed)
     survey_bpp = ln / nq + out_bytes
     # With a tight cutoff the early-out is part of the algorithm: on this corpus nearly every candidate is decided from
     # its first 16-byte chunk, so the bytes the path HAS to move are that chunk + the result -- which is also what the
@@ -332,10 +368,11 @@ def main():
         what += (f"{args.total_candidates} random alphanumeric len-{ln} candidates in ONE logical corpus split over {world} GPU(s), score_cutoff=3, "
                  f"top-{args.topk} + all-gather + merge every step" + (", BASELINE.json configs[4]" if args.total_candidates == 1_000_000_000 else ""))
     else:
-        what += (f"{n} random alphanumeric len-{ln} candidates per GPU, " + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
+        what += ((f"{n} random alphanumeric candidates with lengths uniform in [1, {args.cand_len}] (mean {mean_len:.2f}) per GPU, " if args.ragged
+                  else f"{n} random alphanumeric len-{ln} candidates per GPU, ") + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
                  + (f", weights={weights}" if weights else "")
                  + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64
-                                                     and args.cutoff is None and not weights) else ""))
+                                                     and args.cutoff is None and not weights and not args.ragged) else ""))
     result = {
         "metric": "Gpairs/s (1 query x N candidates, Levenshtein BatchComparator semantics)" if args.metric == "levenshtein" else f"Gpairs/s ({args.metric})",
         "value": round(gpairs, 3),
@@ -352,7 +389,7 @@ def main():
         "config": {
             "workload": what,
             "candidates_per_gpu": n,
-            "candidate_len": ln,
+            "candidate_len": args.cand_len if not args.ragged else f"uniform in [1, {args.cand_len}], mean {mean_len:.3f}",
             "query_len": args.query_len,
             "queries": nq,
             "output": ("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else f"top-{args.topk} only",
@@ -437,6 +474,25 @@ def main():
                                 "what": f"merged top-{args.topk} keys vs the oracle's (distance, global index) ranking of all {len(pidx)} planted near-duplicates"}
     if host_sample is not None:
         result["cpu_baseline"] = cpu_baseline(args, q, host_sample)
+    if ragged_sample is not None:
+        result["cpu_baseline"] = cpu_baseline(args, q, None, ragged=ragged_sample)
+        from oracle import oracle as o
+
+        torch.cuda.synchronize()
+        op = N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE
+        got_all = out[:n].cpu().numpy()
+        mism, checked = 0, 0
+        for (d_, o_), sel in ((ragged_sample, slice(0, len(ragged_sample[1]) - 1)), (ragged_strided, slice(0, n, 1009))):
+            m = min(len(o_) - 1, 2_000_000)
+            exp = getattr(o, args.metric).BatchComparator(q).many(op, d_[: int(o_[m])], o_[: m + 1], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff)
+            got = got_all[sel][:m]
+            if is_f64:
+                bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
+            else:
+                bad = got.view(np.uint32) != np.where(exp == np.uint64(2**64 - 1), np.uint32(0xFFFFFFFF), exp.astype(np.uint32))
+            mism += int(bad.sum())
+            checked += m
+        result["parity"] = {"checked": checked, "mismatches": mism, "what": f"first candidates + every 1009-th of all {n}, vs oracle/"}
     if host_sample is not None and args.mode == "many":
         # parity on the sample, in the same run
         from oracle import oracle as o
@@ -486,7 +542,7 @@ def measured_traffic(args, n, kernel_ms):
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except OSError:
         return None
-    key = f"{args.metric}:q{args.query_len}:n{n}:l{args.cand_len}:cut{args.cutoff}:{args.mode}"
+    key = f"{args.metric}:q{args.query_len}:n{n}:l{args.cand_len}:cut{args.cutoff}:{args.mode}" + (":ragged" if getattr(args, "ragged", False) else "")
     e = table.get(key)
     if e is None:
         return None
@@ -497,22 +553,35 @@ def measured_traffic(args, n, kernel_ms):
             **({"kernel_us_at_collection": at} if at else {})}
 
 
-def cpu_baseline(args, q, host_sample):
+def cpu_baseline(args, q, host_sample, ragged=None):
     """The oracle (kind = "port": the C restatement of the reference's BatchComparator loop) timed on the
-    GPU box's host cores over a bounded prefix of the SAME corpus."""
+    GPU box's host cores over a bounded prefix of the SAME corpus (fixed-length rows, or ragged (data, offsets))."""
     from oracle import oracle as o
     from rapidfuzz_rs_amd import _native as N
 
     bc = getattr(o, args.metric).BatchComparator(q)
     OP = N.OP_SIMILARITY if args.metric in ("jaro", "jaro_winkler") else N.OP_DISTANCE
+    kw = {"weights": tuple(int(x) for x in args.weights.split(","))} if getattr(args, "weights", None) else {}
+    if ragged is not None:
+        class _Prefix:  # host_sample[:m] of a ragged sample
+            def __init__(self, data, offsets):
+                self.data, self.offsets = data, offsets
+            def __len__(self):
+                return len(self.offsets) - 1
+            def __getitem__(self, sl):
+                m = min(sl.stop, len(self))
+                return _Prefix(self.data[: int(self.offsets[m])], self.offsets[: m + 1])
+        host_sample = _Prefix(*ragged)
+        run = lambda part, nthreads: bc.many(OP, part.data, part.offsets, nthreads=nthreads, score_cutoff=args.cutoff, **kw)
+    else:
+        run = lambda part, nthreads: bc.rows(OP, part, nthreads=nthreads, score_cutoff=args.cutoff, **kw)
     probe = host_sample[:200_000]
     t0 = time.perf_counter()
-    kw = {"weights": tuple(int(x) for x in args.weights.split(","))} if getattr(args, "weights", None) else {}
-    bc.rows(OP, probe, nthreads=1, score_cutoff=args.cutoff, **kw)
+    run(probe, 1)
     rate = len(probe) / (time.perf_counter() - t0)
     n1 = int(min(len(host_sample), max(200_000, rate * args.cpu_seconds * 0.5)))
     t0 = time.perf_counter()
-    bc.rows(OP, host_sample[:n1], nthreads=1, score_cutoff=args.cutoff, **kw)
+    run(host_sample[:n1], 1)
     t1 = time.perf_counter() - t0
     try:
         cores = len(os.sched_getaffinity(0))  # the hardware threads this process may actually run on
@@ -521,11 +590,11 @@ def cpu_baseline(args, q, host_sample):
     # all hardware threads: the whole host sample per call, repeated until >= 2 s of wall time have been measured (a
     # single 0.4 s call is mostly thread start-up and first-touch page faults; the first call is a warm-up and not counted)
     nall = len(host_sample)
-    bc.rows(OP, host_sample[:nall], nthreads=cores, score_cutoff=args.cutoff, **kw)
+    run(host_sample[:nall], cores)
     tall, reps = 0.0, 0
     while reps < 2 or (tall < min(2.0, args.cpu_seconds) and reps < 64):
         t0 = time.perf_counter()
-        bc.rows(OP, host_sample[:nall], nthreads=cores, score_cutoff=args.cutoff, **kw)
+        run(host_sample[:nall], cores)
         tall += time.perf_counter() - t0
         reps += 1
     model = ""

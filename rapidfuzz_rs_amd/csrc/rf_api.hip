@@ -86,6 +86,10 @@ struct rf_corpus {
     uint8_t* d_data = nullptr;
     TileDesc* d_tiles = nullptr;
     uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
+    size_t n_slots = 0;          // entries of d_orig: 64 per tile (exact tiles, then the views)
+    // large ragged corpora return their results through a slot-ordered temporary + one gather (rf_pack.hip): built on first use
+    mutable uint32_t* d_slot_of = nullptr;     // candidate -> its slot
+    mutable uint32_t* d_slot_ident = nullptr;  // slot -> slot, kPad on padding lanes (stands in for d_orig in such a launch)
     uint32_t n_tiles = 0;        // exact tiles, then the virtual (one-length) views of the mixed section
     uint32_t n_exact = 0;        // tiles [0, n_exact) are exact-length tiles; [n_exact, n_tiles) virtual views (HostLayout)
     // the mixed section as the Levenshtein / LCS / OSA scans see it: one tile of 64 leftovers with per-lane lengths
@@ -816,6 +820,7 @@ static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, r
         RF_HIP_C(hipMemcpy(c->d_tiles, L.tiles.data(), L.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
         RF_HIP_C(hipMalloc(&c->d_orig, L.orig.size() * sizeof(uint32_t)));
         RF_HIP_C(hipMemcpy(c->d_orig, L.orig.data(), L.orig.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->n_slots = L.orig.size();
         c->device_bytes += L.tiles.size() * sizeof(TileDesc) + L.orig.size() * sizeof(uint32_t);
     }
     if (c->n_mixed) {
@@ -1067,6 +1072,8 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_data) (void)hipFree(c->d_data);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_orig) (void)hipFree(c->d_orig);
+    if (c->d_slot_of) (void)hipFree(c->d_slot_of);
+    if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
     if (c->d_mixed) (void)hipFree(c->d_mixed);
     if (c->d_mixed_len) (void)hipFree(c->d_mixed_len);
     if (c->d_mixed_orig) (void)hipFree(c->d_mixed_orig);
@@ -1123,6 +1130,15 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->mixed_end = corpus->d_mixed ? corpus->n_mixed : 0;
     p->tile_step = 1;
     p->n = (uint32_t)corpus->n;
+    {   // zero-length tiles (the asm stream kernels are not given them): at most one run per ascending section of the tile order
+        int runs = 0;
+        for (size_t i = 0; i < corpus->lengths.size() && runs < 2; ++i)
+            if (corpus->lengths[i] == 0) {
+                p->zero_begin[runs] = corpus->length_first_tile[i];
+                p->zero_end[runs] = i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles;
+                ++runs;
+            }
+    }
 
     const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
     const bool norm_op = op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY;
@@ -1235,10 +1251,7 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         const uint64_t len1 = c->s1.size();
         p->jaro_split = corpus->n_exact;
         p->jaro_split2 = corpus->n_tiles;
-        bool in_block = false;
         for (size_t i = 0; i < corpus->lengths.size(); ++i) {
-            const bool virt = corpus->length_first_tile[i] >= corpus->n_exact;
-            if (virt && (i == 0 || corpus->length_first_tile[i - 1] < corpus->n_exact)) in_block = false;  // the second run starts over
             uint64_t a = len1, b = corpus->lengths[i];
             if (b > a) {
                 const uint64_t bound = b / 2 - 1;
@@ -1249,11 +1262,14 @@ static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
             }
             const bool needs_flags = a != 0 && b != 0;  // otherwise decided by the length filter alone
             const bool word_ok = !needs_flags || (a <= 64 && b <= 64);
-            if (!word_ok && !in_block) {
-                in_block = true;
-                (virt ? p->jaro_split2 : p->jaro_split) = corpus->length_first_tile[i];
-            }
-            if (in_block && needs_flags && (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords))
+            if (word_ok) continue;
+            // this run of equal-length tiles [first, end) needs the multi-word path.  (A run may straddle the two sections: the last
+            // exact length and the first view can be the same length, and the length table merges them.)
+            const uint32_t first = corpus->length_first_tile[i];
+            const uint32_t end = i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles;
+            if (first < corpus->n_exact) p->jaro_split = std::min(p->jaro_split, first);
+            if (end > corpus->n_exact) p->jaro_split2 = std::min(p->jaro_split2, std::max(first, corpus->n_exact));
+            if (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords)
                 p->jaro_long = 1;  // beyond 512 symbols: the flag words move from registers to global scratch strips
         }
         if (p->jaro_long) {
@@ -1469,10 +1485,46 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     if (s != RF_OK) return s;
 
     hipStream_t st = (hipStream_t)stream;
-    const size_t out_bytes = corpus->n * (f64_out ? sizeof(double) : sizeof(uint32_t));
+    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
+    const size_t out_bytes = corpus->n * elem;
     void* d_out = out;
     if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
     p.out = d_out;
+    // Large ragged corpora: results in slot order into a temporary, then ONE gather into original order (rf_pack.hip
+    // "gather_results_kernel" has the why: the scattered out[orig[slot]] stores of a length-bucketed corpus cost more than the scan).
+    // Every tile writes (no cutoff window with pre-filled entries), the mixed section is walked through its one-length views so that
+    // every candidate has exactly one slot.  RF_UNSCATTER_MIN=<candidates> moves the threshold (0 = never).
+    static const size_t unscatter_min = [] { const char* e = getenv("RF_UNSCATTER_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
+    void* d_tmp = nullptr;
+    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && !p.early && !p.prefill_none) {
+        {
+            std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+            if (!corpus->d_slot_of) {
+                uint32_t *so = nullptr, *si = nullptr;
+                RF_HIP(hipMalloc((void**)&so, corpus->n * sizeof(uint32_t)));
+                hipError_t e1 = hipMalloc((void**)&si, corpus->n_slots * sizeof(uint32_t));
+                if (e1 == hipSuccess) e1 = hipMemsetAsync(so, 0xFF, corpus->n * sizeof(uint32_t), st);
+                if (e1 == hipSuccess) e1 = launch_slot_maps(corpus->d_orig, (uint32_t)corpus->n_slots, so, si, st);
+                if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);  // (other streams may use the maps as soon as the lock is released)
+                if (e1 != hipSuccess) {
+                    (void)hipFree(so);
+                    if (si) (void)hipFree(si);
+                    if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+                    RF_HIP(e1);
+                }
+                corpus->d_slot_of = so;
+                corpus->d_slot_ident = si;
+            }
+        }
+        const hipError_t ea = hipMallocAsync(&d_tmp, corpus->n_slots * elem, st);
+        if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+        RF_HIP(ea);
+        p.out = d_tmp;
+        p.orig = corpus->d_slot_ident;
+        p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
+        p.mixed_end = 0;
+        p.n = (uint32_t)corpus->n_slots;
+    }
     if (const size_t scratch = launch_scratch_bytes(p, raw)) {
         const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
         if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
@@ -1480,6 +1532,10 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     }
     hipError_t e = launch_scan(raw, p, st, nullptr);
     if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
+    if (d_tmp) {
+        if (e == hipSuccess) e = launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
+        (void)hipFreeAsync(d_tmp, st);
+    }
     if (e == hipSuccess && out_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -2445,6 +2501,7 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
         RF_HIP_C(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
         RF_HIP_C(hipMalloc(&c->d_orig, std::max<size_t>(1, orig.size()) * 4));
         RF_HIP_C(hipMemcpy(c->d_orig, orig.data(), orig.size() * 4, hipMemcpyHostToDevice));
+        c->n_slots = orig.size();
         c->device_bytes += tiles.size() * sizeof(TileDesc) + orig.size() * 4;
     }
     if (c->n_mixed) {

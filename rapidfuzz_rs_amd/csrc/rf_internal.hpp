@@ -80,6 +80,7 @@ struct ScanParams {
     uint32_t w_ins, w_del, w_sub;  // for _maximum (levenshtein.rs:263-277)
     uint32_t tile_begin, tile_end;  // tile range of this launch (jaro kernels; the cutoff length window of the scans)
     uint32_t n_exact;               // tiles below this index are exact-length tiles; above: one-length views of mixed tiles
+    uint32_t zero_begin[2], zero_end[2];  // the (at most two) runs of zero-length tiles in tile order: one per ascending section (plan())
     uint32_t mixed_begin, mixed_end;  // the mixed tiles (indices into `mixed`) a Levenshtein / LCS / OSA scan has to visit
     const double* jaro_tab;         // jaro kernels: device table [65][33] of (c - h) / c (rf_api.hip jaro_device_table); nullptr = compute
     double jaro_need;               // jaro kernels: the similarity a candidate must reach to pass the cutoff; < 0 = no early-out
@@ -128,6 +129,8 @@ struct ScanParams {
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used);
 hipError_t launch_osa1_asm(const ScanParams& p, hipStream_t stream, int grid);   // the same around the OSA column (OsaState<1>)
 hipError_t launch_lev32_asm(const ScanParams& p, hipStream_t stream, int grid);  // the same for queries of <= 32 symbols (Lev32State)
+bool stream_asm_serves(const ScanParams& p);  // rf_stream_asm.hip: whole-kernel asm scans (u32 results, single word, no early-out / top-k)
+hipError_t launch_stream_asm(int kind, const ScanParams& p, hipStream_t stream, int grid);  // kind: 0 Lev64, 1 Lev32, 2 OSA; no zero-length tile in [tile_begin, tile_end)
 hipError_t launch_lev1_asm(const ScanParams& p, hipStream_t stream, int grid);  // rf_lev_asm.hip: single-word Levenshtein, single-length corpus, no early-out
 void launch_lev1_asm_probe(dim3 g, dim3 b, uint32_t* out, int iters, uint32_t seed);  // rf_lev_asm.hip: the asm chunk alone (rf_probe_issue_rate mode 2)
 hipError_t launch_band(const ScanParams& p, hipStream_t stream);  // rf_band.hip: exact tiles [tile_begin, tile_end)
@@ -142,6 +145,9 @@ hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t 
 hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
                             hipStream_t stream);
 int scan_max_grid();
+// results of a ragged corpus in original order without scattered stores (rf_pack.hip): slot -> slot / candidate -> slot maps, and the gather
+hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream);
+hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void* out, uint32_t n, bool f64, hipStream_t stream);
 // exact selection over a device score vector (rf_select.hip)
 hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, void* ctl, hipStream_t st);
 hipError_t launch_select_hist(const void* s, bool f64, uint32_t n, bool desc, uint64_t prefix_mask, uint64_t prefix, uint32_t shift, uint32_t bits,

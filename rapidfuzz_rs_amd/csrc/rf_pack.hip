@@ -199,4 +199,67 @@ hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes
     return launch_translate_t(static_cast<const uint32_t*>(raw), n_chunks, keys, vals, cap, o, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Results of a length-bucketed corpus in ORIGINAL candidate order without scattered stores.
+// A tile holds 64 candidates of one length, i.e. 64 original indices spread over the whole corpus: writing out[orig[slot]]
+// from the scan puts one 4-byte store into 64 different cache lines per tile, and the other 15..31 results of each line arrive
+// from tiles of other lengths, much later -- every line goes to HBM as many partial writes (100 M ragged candidates: 1.5 ms of
+// a 2.6 ms launch, measured; bench.py --ragged).  Seen from the OUTPUT side the same permutation is friendly: consecutive
+// candidates read from as many sequential streams as there are lengths, and each stream's cache line is used up by neighbouring
+// threads.  So for large ragged corpora the scans write tmp[slot] (coalesced: p.orig is replaced by a slot -> slot map that
+// keeps the padding lanes' kPad) and one gather pass writes out[i] = tmp[slot_of[i]]: 12 bytes of streaming traffic per candidate.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slot_maps_kernel(const uint32_t* __restrict__ orig, uint32_t n_slots, uint32_t* __restrict__ slot_of,
+                                                        uint32_t* __restrict__ ident)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
+        const uint32_t o = orig[s];
+        ident[s] = o == kPad ? kPad : s;
+        if (o != kPad) slot_of[o] = s;  // (one-time scattered pass, per corpus)
+    }
+}
+hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream)
+{
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(slot_maps_kernel, dim3(std::min<uint32_t>((n_slots + 255) / 256, 65536u)), dim3(256), 0, stream, orig, n_slots, slot_of, ident);
+    return hipGetLastError();
+}
+
+// One workgroup walks kGatherSpan CONSECUTIVE candidates per trip: their slots advance along one sequential stream per candidate
+// length, so with a span of 16 K candidates every 128-byte line of tmp (32 results of one length) is used up by this workgroup
+// within a few iterations -- out of its own L1 / L2 -- instead of being fetched by whichever workgroups (on whichever XCDs)
+// happen to hold the neighbouring candidates (first version: 4 consecutive candidates per thread, grid-stride: 0.65 ms for
+// 100 M results = 1.9 TB/s of the 1.2 GB it has to move).
+constexpr uint32_t kGatherSpan = 16384, kGatherUnroll = 8;
+template <class T>
+__global__ __launch_bounds__(256) void gather_results_kernel(const T* __restrict__ tmp, const uint32_t* __restrict__ slot_of, T* __restrict__ out, uint32_t n)
+{
+    const uint32_t spans = (n + kGatherSpan - 1) / kGatherSpan;
+    for (uint32_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
+        const uint32_t base = sp * kGatherSpan, end = min(n, base + kGatherSpan);
+        for (uint32_t i0 = base + threadIdx.x; i0 < end; i0 += 256 * kGatherUnroll) {
+            uint32_t s[kGatherUnroll];
+            T v[kGatherUnroll];
+#pragma unroll
+            for (uint32_t j = 0; j < kGatherUnroll; ++j) s[j] = i0 + j * 256 < end ? __builtin_nontemporal_load(slot_of + i0 + j * 256) : kPad;
+#pragma unroll
+            for (uint32_t j = 0; j < kGatherUnroll; ++j)
+                if (s[j] != kPad) v[j] = tmp[s[j]];
+#pragma unroll
+            for (uint32_t j = 0; j < kGatherUnroll; ++j)
+                if (s[j] != kPad) __builtin_nontemporal_store(v[j], out + i0 + j * 256);
+        }
+    }
+}
+hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void* out, uint32_t n, bool f64, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const dim3 g(std::min<uint32_t>((n + kGatherSpan - 1) / kGatherSpan, (uint32_t)scan_max_grid())), b(256);
+    if (f64)
+        hipLaunchKernelGGL(gather_results_kernel<double>, g, b, 0, stream, static_cast<const double*>(tmp), slot_of, static_cast<double*>(out), n);
+    else
+        hipLaunchKernelGGL(gather_results_kernel<uint32_t>, g, b, 0, stream, static_cast<const uint32_t*>(tmp), slot_of, static_cast<uint32_t*>(out), n);
+    return hipGetLastError();
+}
+
 }  // namespace rf

@@ -558,6 +558,32 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
         if (!p.early && use_stream) {
             // the headline case has its chunk in hand-scheduled asm (rf_lev_asm.hip); RF_ASM_CHUNK=0 selects the compiled loop
             static const bool use_asm = [] { const char* e = getenv("RF_ASM_CHUNK"); return !e || atoi(e) != 0; }();
+            // per-candidate u32 results of the Levenshtein / OSA states: the whole-kernel asm scans (rf_stream_asm.hip), whatever the
+            // corpus looks like.  Zero-length tiles have no column to run: the compiled loop fills those runs in.  RF_ASM_STREAM=0
+            // keeps round 2's fixed-shape asm kernels + the compiled loop for A/B.
+            static const bool use_stream_asm = [] { const char* e = getenv("RF_ASM_STREAM"); return !e || atoi(e) != 0; }();
+            constexpr int kAsmKind = std::is_same<State, LevState<1>>::value ? 0 : (std::is_same<State, Lev32State>::value ? 1 : (std::is_same<State, OsaState<1>>::value ? 2 : -1));
+            if (kAsmKind >= 0 && use_asm && use_stream_asm && stream_asm_serves(p)) {
+                uint32_t at = p.tile_begin;
+                for (int r = 0; r <= 2 && at < p.tile_end; ++r) {
+                    const uint32_t zb = r < 2 ? std::min(std::max(p.zero_begin[r], at), p.tile_end) : p.tile_end;
+                    const uint32_t ze = r < 2 ? std::min(std::max(p.zero_end[r], zb), p.tile_end) : p.tile_end;
+                    if (r < 2 && p.zero_end[r] <= p.zero_begin[r]) continue;  // no such run
+                    if (zb > at) {
+                        ScanParams q = p;
+                        q.tile_begin = at, q.tile_end = zb;
+                        const hipError_t e = launch_stream_asm(kAsmKind, q, stream, std::max(1, scan_grid_full(zb - at)));
+                        if (e != hipSuccess) return e;
+                    }
+                    if (ze > zb) {
+                        ScanParams q = p;
+                        q.tile_begin = zb, q.tile_end = ze;
+                        hipLaunchKernelGGL((stream_kernel_occ8<State, false, kDepth>), dim3(std::max(1, scan_grid(ze - zb))), b, 0, stream, q);
+                    }
+                    at = ze;
+                }
+                return hipGetLastError();
+            }
             if (std::is_same<State, LevState<1>>::value && !p.tiles && use_asm && p.uniform_len >= (uint32_t)kChunk && p.uniform_len % kChunk == 0)
                 return launch_lev1_asm(p, stream, grid);
             if (std::is_same<State, Lev32State>::value && !p.tiles && use_asm && p.uniform_len >= (uint32_t)kChunk && p.uniform_len % kChunk == 0)

@@ -1777,7 +1777,25 @@ def test_randomized_single_length_corpora(seed):
             assert len(bad) == 0, (metric, opname, kw, len1, len2, n, (lo, hi), bad[:5], got[bad[:5]], exp[bad[:5]])
 
 
-@pytest.mark.parametrize("mode", ["rows", "ragged"])
+def test_ragged_results_through_the_gather_path():
+    """Large ragged corpora (>= 2^20 candidates) return their results through a slot-ordered temporary and one gather instead of
+    scattered out[orig[slot]] stores (rf_pack.hip gather_results_kernel).  RF_UNSCATTER_MIN=1 sends every corpus that way: the
+    ragged parity tests of every kernel family (register-resident scans, long patterns, general weights, Jaro word / block / long,
+    OSA, u32 elements, randomized differential) must not notice."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = ("test_c1_levenshtein or test_query_lengths_ragged or test_long_queries_multi_sweep_kernel or test_osa_ragged or test_levenshtein_generalized_weights or "
+           "test_jaro_ragged_bit_exact or test_jaro_multi_word_path_bit_exact or test_jaro_beyond_512 or test_jaro_short_leftovers or test_fuzz_ratio_batch or "
+           "test_u32_elements_equal or test_randomized_differential or test_band_kernel_long_query")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", sel],
+                       capture_output=True, text=True, cwd=root, env=dict(os.environ, RF_UNSCATTER_MIN="1"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["rows", "ragged", "ragged-gather"])
 def test_asm_kernels_many_tiles_per_wavefront(mode):
     """with the default grid a wavefront owns a second tile only beyond 16.8 M candidates, so the tests
     above never exercise the hand-scheduled kernels' cross-tile fetch ring, state re-arm, parked fetch cursor and mid-block tail
@@ -1788,8 +1806,10 @@ def test_asm_kernels_many_tiles_per_wavefront(mode):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "multitile_check.py"), mode], capture_output=True, text=True, cwd=root,
-                       env=dict(os.environ, RF_SCAN_BLOCKS_PER_CU_FULL="1"))
+    env = dict(os.environ, RF_SCAN_BLOCKS_PER_CU_FULL="1")
+    if mode == "ragged-gather":  # the same ragged corpora with their results going through the slot-ordered temporary + gather
+        env["RF_UNSCATTER_MIN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "multitile_check.py"), mode.split("-")[0]], capture_output=True, text=True, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout[-4000:], r.stderr[-2000:])
     assert "FAILURES 0" in r.stdout
 

@@ -1,0 +1,350 @@
+"""Generates rapidfuzz_rs_amd/csrc/rf_stream_asm.inc: the no-cutoff scans of the single-word bit-parallel states (Levenshtein
+64-bit, Levenshtein 32-bit, OSA) as WHOLE KERNELS in gfx950 assembly -- one asm body per (kind, corpus addressing) pair, wrapped
+by rf_stream_asm.hip in a __global__ function whose only job is to hand over the kernarg pointer and the workgroup / thread ids.
+
+Why whole kernels: round 2 pinned the recurrence state and the look-ahead table rows in physical registers and left the loop
+around the 16-column blocks to hipcc.  Giving that kernel tile descriptors, partial last chunks and a rolled loop needs the chunk
+ring pinned too, and with 46 + 14 of 64 VGPRs spoken for the register allocator starts splitting the pinned live ranges (copies
+and scratch traffic around every block).  Here nothing is left to it: registers, waits and the schedule are all explicit.
+
+One wavefront = one stream of 16-column chunks over its tiles (tile t, t + stride, ...):
+  * STEP (x RING phases, the ring rotates by renaming): fetch the chunk RING-1 steps ahead into the ring (global_load_dwordx4, 1 KiB
+    per wavefront), then the 16 recurrence columns of the current chunk (rf_device.hpp LevState<1>::step / Lev32State::step /
+    OsaState<1>::step; levenshtein.rs:466-490, osa.rs:156-226) with the LDS gather of table rows running LA columns ahead, across
+    chunk and tile boundaries, behind counted lgkmcnt waits.  The ring is waited for with counted vmcnt: this chunk at the top of
+    the block, the next chunk's first dwords only at column 8.  s_nop 0 placement: the best of the placements measured in round 2
+    (profiles/lev_schedule_experiments_r02.txt).
+  * a tile's last, partial chunk (rem < 16 symbols) is shifted up by k = 16 - rem byte positions in place (wavefront-uniform) and
+    the block is ENTERED AT COLUMN k: exactly rem columns run and the block still ends at column 15, where the look-ahead reads
+    of the next tile's first columns have been issued the usual way.  Stub k waits for what is in flight (the rows the previous
+    block gathered for this chunk's first columns came from the unshifted bytes), gathers the rows of columns k .. k+LA-1 in
+    issue order -- positions >= 16 are the next chunk's first columns -- and jumps to column k.
+  * tile epilogue (shared by the phases): D[len1][len2] = len2 + popcount(VP & valid) - popcount(VN & valid), the affine finishing
+    map of rf_device.hpp ("Finishing": value = v0(tile) + vR * raw, None unless (value ^ flip) <= cflip), one u32 per candidate to
+    out[orig[slot]] (general corpora) or out[slot] (single-length corpora), then the next tile's descriptor and state.
+Zero-length tiles never reach these kernels (the launcher splits them off), nor do top-k / f64 / early-out launches.
+
+Register map (all kinds):  SGPRs s8.. are loaded from the kernarg block (StreamAsmArgs, offsets below), s33.. are cursors;
+VGPRs: v1 lane, v2 lane*16, v3 lane*4, v4 candidate index of the current tile, v5 zero, v6..v9 epilogue temporaries, v10 log2(row
+size), ring buffers / ADDR v30..v33 / table rows v34.. / scratch v50..v59 / state v58..v63 per KINDS.
+
+  python tools/gen_stream_asm.py [output path]        tests/test_docs.py checks the committed .inc is this script's output
+"""
+import os
+import sys
+
+ADDR = [30, 31, 32, 33]
+# kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
+ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
+        ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
+        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("pad", 4)]
+# SGPR map
+S_DATA, S_TILES, S_ORIG, S_PM, S_SIGMA, S_OUT = "s[8:9]", "s[10:11]", "s[12:13]", "s[14:15]", "s[16:17]", "s[18:19]"
+(S_TBEGIN, S_TEND, S_N, S_ULEN, S_UBYTES, S_LEN1, S_VS, S_VM, S_VR, S_FLIP, S_CFLIP, S_VLO) = [f"s{i}" for i in range(20, 32)]
+S_VHI = "s68"  # (s32 is the ABI's stack pointer: the compiler refuses it on a clobber list)
+S_STRIDE, S_T, S_C, S_NCH, S_LEN2, S_SLOT0, S_V0 = "s33", "s34", "s35", "s36", "s37", "s38", "s39"
+S_FT, S_FC, S_FN = "s40", "s41", "s42"
+S_FBASE, S_FBASE_LO, S_FBASE_HI = "s[44:45]", "s44", "s45"
+S_SRC, S_SRC_LO, S_SRC_HI = "s[46:47]", "s46", "s47"
+S_K, S_Q, S_R8, S_SH = "s48", "s49", "s50", "s51"
+T0, T1, T2, T3 = "s52", "s53", "s54", "s55"
+S_DESC = "s[60:63]"  # TileDesc {u64 data_off, u32 len, u32 slot0}
+S_NEXT, S_AFTER, S_EXEC = "s64", "s65", "s[66:67]"  # S_AFTER: this step follows a tile epilogue whose store (and index load) are still younger than the ring
+V_LANE, V_OFF16, V_OFF4, V_IDX, V_ZERO, V_KS = "v1", "v2", "v3", "v4", "v5", "v10"
+
+
+def pr(r):
+    return f"v[{r[0]}:{r[1]}]"
+
+
+VP, VN, A, E, HN, HP, T = (60, 61), (62, 63), (58, 59), (56, 57), (54, 55), (52, 53), (50, 51)
+LEV_BASE = "a S e hp hn hq t vn vp".split()
+VP32, VN32, A32, E32, HN32, HP32, T32 = 60, 61, 58, 56, 54, 52, 50
+# OSA (osa.rs:156-226): the Levenshtein column with the transposition term; D0 is state, the previous column's table row is
+# still in the ring (7 columns of look-ahead instead of 8, so slot (i - 1) % 8 has not been overwritten yet)
+D0_, R1_, R2_ = (58, 59), (56, 57), (54, 55)
+OSA_BASE = "t ts tr a S e d hn hp hq hs vn vp".split()
+
+
+class Kind:
+    def __init__(self, name, bits, la, bufs, state, nop_mask):
+        self.name, self.bits, self.la, self.bufs, self.state, self.nop_mask = name, bits, la, bufs, list(state), nop_mask
+        self.ring = len(bufs)
+        self.rows = [(34 + 2 * k, 35 + 2 * k) for k in range(8)] if bits == 64 else [(34 + k,) for k in range(8)]
+        self.ks = 3 if bits == 64 else 2
+
+    # LDS gather of the table row of window position j (0..15: this chunk, 16..23: the next chunk's first columns)
+    def gather(self, j, use, nxt):
+        src = use + (j // 4) if j < 16 else nxt + ((j - 16) // 4)
+        a = ADDR[j % 4]
+        x = f"v_lshlrev_b32_sdwa v{a}, {V_KS}, v{src} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{j % 4}"
+        slot = self.rows[j % 8]
+        return [x, f"ds_read_b64 {pr(slot)}, v{a}" if self.bits == 64 else f"ds_read_b32 v{slot[0]}, v{a}"]
+
+    def op(self, tok, i):
+        if self.name == "lev64":
+            PM = self.rows[i % 8]
+            return {"a": [f"v_and_b32 v{A[h]}, v{PM[h]}, v{VP[h]}" for h in (0, 1)],                               # x & VP
+                    "S": [f"v_lshl_add_u64 {pr(A)}, {pr(A)}, 0, {pr(VP)}"],                                        # + VP
+                    "e": [f"v_bitop3_b32 v{E[h]}, v{A[h]}, v{VP[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],       # e = (sum ^ VP) | x
+                    "hp": [f"v_bitop3_b32 v{HP[h]}, v{VN[h]}, v{E[h]}, v{VP[h]} bitop3:0xf1" for h in (0, 1)],     # HP = VN | ~(e | VP)
+                    "hn": [f"v_and_b32 v{HN[h]}, v{E[h]}, v{VP[h]}" for h in (0, 1)],                              # HN = e & VP
+                    "hq": [f"v_lshl_add_u64 {pr(HP)}, {pr(HP)}, 1, 1"],                                            # HP' = (HP << 1) + 1
+                    "t": [f"v_bitop3_b32 v{T[h]}, v{E[h]}, v{VN[h]}, v{HP[h]} bitop3:0x01" for h in (0, 1)],       # T = ~(e | VN | HP')
+                    "vn": [f"v_bitop3_b32 v{VN[h]}, v{HP[h]}, v{E[h]}, v{VN[h]} bitop3:0xe0" for h in (0, 1)],     # VN' = HP' & (e | VN)
+                    "vp": [f"v_lshl_add_u64 {pr(VP)}, {pr(HN)}, 1, {pr(T)}"]}[tok]                                 # VP' = (HN << 1) + T
+        if self.name == "lev32":
+            PM = self.rows[i % 8][0]
+            return {"a": [f"v_and_b32 v{A32}, v{PM}, v{VP32}"], "S": [f"v_add_u32 v{A32}, v{A32}, v{VP32}"],
+                    "e": [f"v_bitop3_b32 v{E32}, v{A32}, v{VP32}, v{PM} bitop3:0xbe"], "hp": [f"v_bitop3_b32 v{HP32}, v{VN32}, v{E32}, v{VP32} bitop3:0xf1"],
+                    "hn": [f"v_and_b32 v{HN32}, v{E32}, v{VP32}"], "hq": [f"v_lshl_or_b32 v{HP32}, v{HP32}, 1, 1"],
+                    "t": [f"v_bitop3_b32 v{T32}, v{E32}, v{VN32}, v{HP32} bitop3:0x01"], "vn": [f"v_bitop3_b32 v{VN32}, v{HP32}, v{E32}, v{VN32} bitop3:0xe0"],
+                    "vp": [f"v_lshl_add_u32 v{VP32}, v{HN32}, 1, v{T32}"]}[tok]
+        PM, PMO = self.rows[i % 8], self.rows[(i - 1) % 8]
+        return {"t": [f"v_bitop3_b32 v{R1_[h]}, v{D0_[h]}, v{PM[h]}, v{PM[h]} bitop3:0x0c" for h in (0, 1)],       # ~D0 & PM
+                "ts": [f"v_lshlrev_b64 {pr(R1_)}, 1, {pr(R1_)}"],
+                "tr": [f"v_and_b32 v{R1_[h]}, v{R1_[h]}, v{PMO[h]}" for h in (0, 1)],                              # & PM_old
+                "a": [f"v_and_b32 v{R2_[h]}, v{PM[h]}, v{VP[h]}" for h in (0, 1)],
+                "S": [f"v_lshl_add_u64 {pr(R2_)}, {pr(R2_)}, 0, {pr(VP)}"],
+                "e": [f"v_bitop3_b32 v{R2_[h]}, v{R2_[h]}, v{VP[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],
+                "d": [f"v_bitop3_b32 v{D0_[h]}, v{R2_[h]}, v{VN[h]}, v{R1_[h]} bitop3:0xfe" for h in (0, 1)],      # D0 = e | VN | tr
+                "hn": [f"v_and_b32 v{R1_[h]}, v{D0_[h]}, v{VP[h]}" for h in (0, 1)],
+                "hp": [f"v_bitop3_b32 v{R2_[h]}, v{VN[h]}, v{D0_[h]}, v{VP[h]} bitop3:0xf1" for h in (0, 1)],
+                "hq": [f"v_lshl_add_u64 {pr(R2_)}, {pr(R2_)}, 1, 1"],
+                "hs": [f"v_lshlrev_b64 {pr(R1_)}, 1, {pr(R1_)}"],
+                "vn": [f"v_and_b32 v{VN[h]}, v{R2_[h]}, v{D0_[h]}" for h in (0, 1)],
+                "vp": [f"v_bitop3_b32 v{VP[h]}, v{R1_[h]}, v{R2_[h]}, v{D0_[h]} bitop3:0xf1" for h in (0, 1)]}[tok]  # hns | ~(hps | D0)
+
+    def column(self, i):  # one recurrence column on row slot i % 8
+        L = [f"s_waitcnt lgkmcnt({self.la - 1})"]  # `la` reads in flight, in order: column i's row has arrived
+        for j, tok in enumerate(OSA_BASE if self.name == "osa" else LEV_BASE):
+            L += self.op(tok, i)
+            if self.nop_mask >> j & 1:
+                L.append("s_nop 0")
+        return L
+
+    def state_init(self):
+        if self.name == "lev64":  # levenshtein.rs:454-455
+            return ["v_mov_b32 v60, -1", "v_mov_b32 v61, -1", "v_mov_b32 v62, 0", "v_mov_b32 v63, 0"]
+        if self.name == "lev32":
+            return ["v_mov_b32 v60, -1", "v_mov_b32 v61, 0"]
+        # osa.rs:74-77, :125-135: D0 = 0 and no previous column: its table row (slot 7) is zero
+        return ["v_mov_b32 v60, -1", "v_mov_b32 v61, -1", "v_mov_b32 v62, 0", "v_mov_b32 v63, 0", "v_mov_b32 v58, 0", "v_mov_b32 v59, 0",
+                "v_mov_b32 v48, 0", "v_mov_b32 v49, 0"]
+
+
+def dispatch(lo, hi, L, sfx):  # binary tree of scalar compares over k in [lo, hi]
+    if lo == hi:
+        L.append(f"s_branch Ls{lo}_{sfx}")
+        return
+    mid = (lo + hi + 1) // 2
+    L += [f"s_cmp_lt_u32 {S_K}, {mid}", f"s_cbranch_scc0 Ld{mid}_{hi}_{sfx}"]
+    dispatch(lo, mid - 1, L, sfx)
+    L.append(f"Ld{mid}_{hi}_{sfx}:")
+    dispatch(mid, hi, L, sfx)
+
+
+def wait_vm(n, extra, tag, sfx):
+    """s_waitcnt vmcnt(n) -- or vmcnt(n + extra) in the first step after a tile epilogue: the epilogue's result store and (general
+    corpora) the next tile's index load were issued BEHIND the ring loads this wait is about, and memory operations return in
+    issue order, so they may stay outstanding.  (Counting them in is exact only because the store is issued with every lane
+    enabled, see the epilogue; waiting for them instead would put a store round trip at the top of every tile.)"""
+    if not extra:
+        return [f"s_waitcnt vmcnt({n})"]
+    return [f"s_cmp_eq_u32 {S_AFTER}, 0", f"s_cbranch_scc1 Lw{tag}a_{sfx}", f"s_waitcnt vmcnt({n + extra})", f"s_branch Lw{tag}b_{sfx}",
+            f"Lw{tag}a_{sfx}:", f"s_waitcnt vmcnt({n})", f"Lw{tag}b_{sfx}:"]
+
+
+def step(K, P, extra):
+    """fetch + the 16 columns of ring phase P; labels carry the phase and the statement's unique id"""
+    R, sfx = K.ring, f"p{P}_%="
+    use, nxt, refill = K.bufs[P], K.bufs[(P + 1) % R], K.bufs[(P + R - 1) % R]
+    L = [f"global_load_dwordx4 v[{refill}:{refill + 3}], {V_OFF16}, {S_SRC} nt",  # the chunk RING-1 steps ahead
+         f"s_cmp_eq_u32 {S_K}, 0", f"s_cbranch_scc1 Lfull_{sfx}"]
+    # ---- a tile's last, partial chunk: shift its bytes up by k positions in place, gather its rows, enter at column k
+    L += wait_vm(R - 2, extra, "t", sfx)  # this chunk and the next one have arrived (only younger operations may still be out)
+    L.append(f"s_mov_b32 {S_AFTER}, 0")
+    u = [use + i for i in range(4)]
+    L += [f"s_cmp_eq_u32 {S_R8}, 0", f"s_cbranch_scc1 Lq_{sfx}",
+          f"v_alignbit_b32 v{u[3]}, v{u[3]}, v{u[2]}, {S_SH}", f"v_alignbit_b32 v{u[2]}, v{u[2]}, v{u[1]}, {S_SH}",
+          f"v_alignbit_b32 v{u[1]}, v{u[1]}, v{u[0]}, {S_SH}", f"v_lshlrev_b32 v{u[0]}, {S_R8}, v{u[0]}", f"Lq_{sfx}:",
+          f"s_cmp_eq_u32 {S_Q}, 0", f"s_cbranch_scc1 Lsh_{sfx}", f"s_cmp_eq_u32 {S_Q}, 1", f"s_cbranch_scc0 Lq2_{sfx}",
+          f"v_mov_b32 v{u[3]}, v{u[2]}", f"v_mov_b32 v{u[2]}, v{u[1]}", f"v_mov_b32 v{u[1]}, v{u[0]}", f"v_mov_b32 v{u[0]}, 0", f"s_branch Lsh_{sfx}",
+          f"Lq2_{sfx}:", f"s_cmp_eq_u32 {S_Q}, 2", f"s_cbranch_scc0 Lq3_{sfx}",
+          f"v_mov_b32 v{u[3]}, v{u[1]}", f"v_mov_b32 v{u[2]}, v{u[0]}", f"v_mov_b32 v{u[1]}, 0", f"v_mov_b32 v{u[0]}, 0", f"s_branch Lsh_{sfx}",
+          f"Lq3_{sfx}:", f"v_mov_b32 v{u[3]}, v{u[0]}", f"v_mov_b32 v{u[2]}, 0", f"v_mov_b32 v{u[1]}, 0", f"v_mov_b32 v{u[0]}, 0", f"Lsh_{sfx}:"]
+    dispatch(1, 15, L, sfx)
+    for k in range(1, 16):
+        L += [f"Ls{k}_{sfx}:", "s_waitcnt lgkmcnt(0)"]
+        if K.name == "osa" and (k - 1) % 8 != 7:  # the previous column's row (zero at a tile's start) sits in slot 7: move it to where column k looks
+            L += [f"v_mov_b32 v{K.rows[(k - 1) % 8][h]}, v{K.rows[7][h]}" for h in (0, 1)]
+        for j in range(k, k + K.la):
+            L += K.gather(j, use, nxt)
+        L.append(f"s_branch Lc{k}_{sfx}")
+    # ---- a whole chunk
+    L.append(f"Lfull_{sfx}:")
+    L += wait_vm(R - 1, extra, "f", sfx)  # this chunk's dwords 2, 3 are about to be read
+    for i in range(16):
+        if i == 8:
+            L += wait_vm(R - 2, extra, "h", sfx)  # from here on the look-ahead reads the NEXT chunk's dwords 0, 1
+            L.append(f"s_mov_b32 {S_AFTER}, 0")
+        L.append(f"Lc{i}_{sfx}:")
+        L += K.column(i)
+        L += K.gather(i + K.la, use, nxt)
+    return L
+
+
+def tile_desc(tile_reg, uniform, fetch):
+    """descriptor of tile `tile_reg` into the fetch cursor (fbase, fn) or the process cursor (len2, nch, slot0)"""
+    L = []
+    if not uniform:
+        L += [f"s_lshl_b32 {T1}, {tile_reg}, 4", "s_nop 0", f"s_load_dwordx4 {S_DESC}, {S_TILES}, {T1}", "s_waitcnt lgkmcnt(0)"]
+        if fetch:
+            L += [f"s_add_u32 {S_FBASE_LO}, s8, s60", f"s_addc_u32 {S_FBASE_HI}, s9, s61", f"s_add_u32 {S_FN}, s62, 15", f"s_lshr_b32 {S_FN}, {S_FN}, 4"]
+        else:
+            L += [f"s_mov_b32 {S_LEN2}, s62", f"s_mov_b32 {S_SLOT0}, s63", f"s_add_u32 {S_NCH}, s62, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4"]
+    elif fetch:  # tile t at t * tile_bytes (64-bit product); chunk count fixed
+        L += [f"s_mul_i32 {T1}, {tile_reg}, {S_UBYTES}", f"s_mul_hi_u32 {T2}, {tile_reg}, {S_UBYTES}",
+              f"s_add_u32 {S_FBASE_LO}, s8, {T1}", f"s_addc_u32 {S_FBASE_HI}, s9, {T2}"]
+    return L
+
+
+def tile_start(K, uniform, sfx):
+    """per tile: the finishing map's constant term, the candidate index of every lane, the recurrence state"""
+    L = [f"s_add_u32 {T0}, {S_LEN1}, {S_LEN2}", f"s_max_u32 {T1}, {S_LEN1}, {S_LEN2}", f"s_mul_i32 {T0}, {T0}, {S_VS}", f"s_mul_i32 {T1}, {T1}, {S_VM}",
+         f"s_add_u32 {S_V0}, {T0}, {T1}"]
+    if uniform:
+        L.append(f"v_lshl_add_u32 {V_IDX}, {S_T}, 6, {V_LANE}")  # slot = index
+    else:  # idx = orig[slot0 + lane]: lands long before the tile's epilogue (the next step's counted vmcnt wait is younger)
+        L += [f"s_lshl_b32 {T0}, {S_SLOT0}, 2", f"s_lshr_b32 {T1}, {S_SLOT0}, 30", f"s_add_u32 {T2}, s12, {T0}", f"s_addc_u32 {T3}, s13, {T1}",
+              f"global_load_dword {V_IDX}, {V_OFF4}, s[54:55]"]
+    return L + K.state_init()
+
+
+def kernel(K, uniform):
+    R = K.ring
+    extra = 1 if uniform else 2  # memory operations a tile epilogue leaves younger than the ring: the result store (+ the index load)
+    off, o = {}, 0
+    for name, size in ARGS:
+        off[name] = o
+        o += size
+    L = []
+    # ---- kernarg block -> s8..s32
+    L += [f"s_load_dwordx8 s[8:15], %[kp], {off['data']}", f"s_load_dwordx4 s[16:19], %[kp], {off['sigma']}",
+          f"s_load_dwordx8 s[20:27], %[kp], {off['tile_begin']}", f"s_load_dwordx4 s[28:31], %[kp], {off['fin_vR']}",
+          f"s_load_dword {S_VHI}, %[kp], {off['valid_hi']}", f"s_mov_b32 {S_STRIDE}, %[stride]",
+          # ---- stage the pattern table: thread i puts row i at row sigma(i) (the corpus stores renamed symbols)
+          "v_and_b32 v1, 0x3ff, %[tid]", "s_waitcnt lgkmcnt(0)",
+          f"global_load_ubyte v6, v1, {S_SIGMA}", "v_lshlrev_b32 v7, 3, v1",
+          f"global_load_dwordx2 v[8:9], v7, {S_PM}" if K.bits == 64 else f"global_load_dword v8, v7, {S_PM}",
+          "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6",
+          "ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8",
+          "s_waitcnt lgkmcnt(0)", "s_barrier",
+          # ---- lane constants, first tile of this wavefront
+          f"v_readfirstlane_b32 {T0}, v1", f"s_lshr_b32 {T0}, {T0}, 6",  # wavefront within the workgroup
+          "v_and_b32 v1, 63, v1", "v_lshlrev_b32 v2, 4, v1", "v_lshlrev_b32 v3, 2, v1", "v_mov_b32 v5, 0", f"v_mov_b32 {V_KS}, {K.ks}",
+          f"s_lshl_b32 {T1}, %[wg], 2", f"s_add_u32 {T1}, {T1}, {T0}", f"s_add_u32 {S_T}, {S_TBEGIN}, {T1}",
+          f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lexit_%=",
+          f"s_mov_b32 {S_FT}, {S_T}", f"s_mov_b32 {S_FC}, 0", f"s_mov_b32 {S_C}, 0", f"s_mov_b32 {S_AFTER}, 0"]
+    if uniform:
+        L += [f"s_mov_b32 {S_LEN2}, {S_ULEN}", f"s_add_u32 {S_NCH}, {S_ULEN}, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4", f"s_mov_b32 {S_FN}, {S_NCH}"]
+    L += tile_desc(S_T, uniform, fetch=True)
+    if not uniform:
+        L += [f"s_mov_b32 {S_LEN2}, s62", f"s_mov_b32 {S_SLOT0}, s63", f"s_mov_b32 {S_NCH}, {S_FN}"]
+    L += tile_start(K, uniform, "%=")
+
+    def fetch_glue(tag):  # src = address of the chunk under the fetch cursor; advance the cursor (parks on the last valid chunk)
+        G = [f"s_lshl_b32 {T0}, {S_FC}, 10", f"s_add_u32 {S_SRC_LO}, {S_FBASE_LO}, {T0}", f"s_addc_u32 {S_SRC_HI}, {S_FBASE_HI}, 0",
+             f"s_add_u32 {S_FC}, {S_FC}, 1", f"s_cmp_lt_u32 {S_FC}, {S_FN}", f"s_cbranch_scc1 Lfok_{tag}_%=",
+             f"s_add_u32 {T0}, {S_FT}, {S_STRIDE}", f"s_cmp_lt_u32 {T0}, {S_TEND}", f"s_cbranch_scc0 Lfpark_{tag}_%=",
+             f"s_mov_b32 {S_FT}, {T0}"]
+        G += tile_desc(S_FT, uniform, fetch=True)
+        G += [f"s_mov_b32 {S_FC}, 0", f"s_branch Lfok_{tag}_%=", f"Lfpark_{tag}_%=:", f"s_sub_u32 {S_FC}, {S_FN}, 1", f"Lfok_{tag}_%=:"]
+        return G
+
+    # ---- the first RING-1 chunks of the stream, then the rows of the first chunk's first columns
+    for b in range(R - 1):
+        L += fetch_glue(f"pre{b}")
+        L.append(f"global_load_dwordx4 v[{K.bufs[b]}:{K.bufs[b] + 3}], {V_OFF16}, {S_SRC} nt")
+    L.append(f"s_waitcnt vmcnt({R - 2})")  # buffer 0 has arrived (a partial first chunk gathers its own rows again: harmless)
+    for j in range(K.la):
+        L += K.gather(j, K.bufs[0], K.bufs[1])
+    # ---- the phases
+    for P in range(R):
+        L.append(f"Lphase{P}_%=:")
+        L += fetch_glue(f"ph{P}")
+        L += [f"s_lshl_b32 {T0}, {S_C}, 4", f"s_sub_u32 {T0}, {S_LEN2}, {T0}", f"s_mov_b32 {S_K}, 0",  # columns left in this tile
+              f"s_cmp_ge_u32 {T0}, 16", f"s_cbranch_scc1 Lkok_{P}_%=",
+              f"s_sub_u32 {S_K}, 16, {T0}", f"s_lshr_b32 {S_Q}, {S_K}, 2", f"s_and_b32 {S_R8}, {S_K}, 3", f"s_lshl_b32 {S_R8}, {S_R8}, 3",
+              f"s_sub_u32 {S_SH}, 32, {S_R8}", f"Lkok_{P}_%=:"]
+        L += step(K, P, extra)
+        L += [f"s_add_u32 {S_C}, {S_C}, 1", f"s_cmp_lt_u32 {S_C}, {S_NCH}"]
+        if P + 1 < R:
+            L += [f"s_cbranch_scc1 Lphase{P + 1}_%=", f"s_mov_b32 {S_NEXT}, {P + 1}", "s_branch Lepi_%="]
+        else:
+            L += [f"s_cbranch_scc1 Lphase0_%=", f"s_mov_b32 {S_NEXT}, 0"]  # falls into the epilogue
+    # ---- tile epilogue
+    L.append("Lepi_%=:")
+    if K.bits == 64:
+        L += [f"v_and_b32 v6, {S_VLO}, v60", "v_bcnt_u32_b32 v6, v6, 0", f"v_and_b32 v7, {S_VHI}, v61", "v_bcnt_u32_b32 v6, v7, v6",
+              f"v_and_b32 v7, {S_VLO}, v62", "v_bcnt_u32_b32 v7, v7, 0", f"v_and_b32 v8, {S_VHI}, v63", "v_bcnt_u32_b32 v7, v8, v7"]
+    else:
+        L += [f"v_and_b32 v6, {S_VLO}, v60", "v_bcnt_u32_b32 v6, v6, 0", f"v_and_b32 v7, {S_VLO}, v61", "v_bcnt_u32_b32 v7, v7, 0"]
+    L += ["v_sub_u32 v6, v6, v7", f"v_add_u32 v6, {S_LEN2}, v6",                       # raw = len2 + pp - pn
+          f"v_mul_lo_u32 v6, v6, {S_VR}", f"v_add_u32 v6, {S_V0}, v6",                  # value = v0 + vR * raw
+          f"v_xor_b32 v7, {S_FLIP}, v6", f"v_cmp_ge_u32 vcc, {S_CFLIP}, v7", "v_cndmask_b32 v6, -1, v6, vcc"]  # None unless (value ^ flip) <= cflip
+    if not uniform:
+        # the index load was issued at the tile's start, BEHIND the ring loads then in flight: all but the newest operation done
+        # means it has landed (the over-wait is the chunk fetched one step ago, which the next block needs at its column 8 anyway)
+        L.append("s_waitcnt vmcnt(1)")
+    L += [f"v_cmp_gt_u32 vcc, {S_N}, {V_IDX}" if uniform else f"v_cmp_ne_u32 vcc, -1, {V_IDX}",                 # real candidates only
+          f"v_lshl_add_u64 v[8:9], v[4:5], 2, {S_OUT}",
+          "s_cmp_eq_u64 vcc, -1", "s_cbranch_scc0 Lpart_%=",
+          "global_store_dword v[8:9], v6, off", f"s_mov_b32 {S_AFTER}, 1", "s_branch Lstored_%=",
+          # a tile with padding lanes (the last of its length): store under the mask and drain, so that the next step's counted waits
+          # see no operation of unknown presence
+          "Lpart_%=:", f"s_and_saveexec_b64 {S_EXEC}, vcc", "global_store_dword v[8:9], v6, off", f"s_mov_b64 exec, {S_EXEC}",
+          "s_waitcnt vmcnt(0)", f"s_mov_b32 {S_AFTER}, 0", "Lstored_%=:",
+          f"s_add_u32 {S_T}, {S_T}, {S_STRIDE}", f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lexit_%=", f"s_mov_b32 {S_C}, 0"]
+    L += tile_desc(S_T, uniform, fetch=False)
+    L += tile_start(K, uniform, "%=")
+    for P in range(1, R):
+        L += [f"s_cmp_eq_u32 {S_NEXT}, {P}", f"s_cbranch_scc1 Lphase{P}_%="]
+    L += ["s_branch Lphase0_%=", "Lexit_%=:"]
+    return L
+
+
+def macro(name, lines):
+    return [f"#define {name} \\"] + [f'    "{l}\\n\\t" \\' for l in lines[:-1]] + [f'    "{lines[-1]}\\n"']
+
+
+RING3 = [18, 22, 26]
+KINDS = [
+    # name, word bits, look-ahead, ring buffers (first VGPR of each), state registers, s_nop mask over the column's tokens
+    Kind("lev64", 64, 8, RING3, range(60, 64), 0x1B3),
+    Kind("lev32", 32, 8, [42, 46, 22, 26], (60, 61), 0x80),
+    Kind("osa", 64, 7, RING3, range(58, 64), 0x613),
+]
+
+
+def main():
+    out = ["// GENERATED by tools/gen_stream_asm.py -- do not edit.  See that file for the design; rf_stream_asm.hip for the wrapper.",
+           "// kernarg block offsets the asm bodies were generated for (rf_stream_asm.hip static_asserts StreamAsmArgs against them)"]
+    o = 0
+    for name, size in ARGS:
+        out.append(f"#define RF_STREAM_ARG_{name.upper()} {o}")
+        o += size
+    out.append(f"#define RF_STREAM_ARGS_SIZE {o}")
+    out.append('#define RF_STREAM_CLOBBERS ' + ", ".join(f'"v{r}"' for r in range(1, 64)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 72) if r != 32)
+               + ', "vcc", "scc", "memory"')  # (exec is restored to all ones before the body ends)
+    for K in KINDS:
+        for uniform in (True, False):
+            out.append(f"// ---- {K.name}, {'single-length corpus (tile t at t * tile_bytes, slot = index)' if uniform else 'tile descriptors + orig[]'}: "
+                       f"ring of {K.ring} at v{', v'.join(str(b) for b in K.bufs)}, look-ahead {K.la}")
+            out += macro(f"RF_STREAM_{K.name.upper()}_{'UNIFORM' if uniform else 'TILES'}_ASM", kernel(K, uniform))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rapidfuzz_rs_amd", "csrc", "rf_stream_asm.inc")
+    open(path, "w").write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()
