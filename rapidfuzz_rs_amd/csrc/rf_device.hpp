@@ -822,10 +822,11 @@ __device__ __forceinline__ void topk_refresh_bound(const ScanParams& p, uint64_t
 // the scan kernel
 // ---------------------------------------------------------------------------------------------------
 // PM row of one symbol: W consecutive words in LDS (ds_read_b32 / ds_read_b64 / ds_read_b128)
-template <class Word, int W>
+// (kRowWords: the table's row pitch in Words -- more than W when a narrow state reads the low words of a wider table)
+template <class Word, int W, int kRowWords = W>
 __device__ __forceinline__ void load_pm(Word (&dst)[W], const Word* lds_pm, uint32_t ch)
 {
-    const Word* row = lds_pm + ch * W;
+    const Word* row = lds_pm + ch * kRowWords;
 #pragma unroll
     for (int w = 0; w < W; ++w) dst[w] = row[w];
 }
@@ -833,7 +834,7 @@ __device__ __forceinline__ void load_pm(Word (&dst)[W], const Word* lds_pm, uint
 // 16 columns in groups of kGroup symbols.  The LDS reads of group g+1 are issued BEFORE the recurrence of group g
 // (pinned with sched_barrier, otherwise the scheduler sinks them back next to their first use), so their latency
 // -- including the 2-4 way bank conflicts of 64 random slots -- hides behind the VALU work of the current group.
-template <class State, int J0 = 0, int J1 = kChunk>
+template <class State, int J0 = 0, int J1 = kChunk, int kRowWords = State::kWords>
 __device__ __forceinline__ void process_chunk_full(State& st, const typename State::Word* lds_pm, const uint4& c)
 {
     using Word = typename State::Word;
@@ -844,14 +845,14 @@ __device__ __forceinline__ void process_chunk_full(State& st, const typename Sta
     Word cur[kGroup][W], nxt[kGroup][W];
 #pragma unroll
     for (int j = 0; j < kGroup; ++j)
-        if (J0 + j < J1) load_pm<Word, W>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
+        if (J0 + j < J1) load_pm<Word, W, kRowWords>(cur[j], lds_pm, (dw[(J0 + j) / 4] >> (8 * ((J0 + j) % 4))) & 0xFFu);
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
         if (g + 1 < kGroups) {
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
                 const int n = J0 + (g + 1) * kGroup + j;
-                if (n < J1) load_pm<Word, W>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
+                if (n < J1) load_pm<Word, W, kRowWords>(nxt[j], lds_pm, (dw[n / 4] >> (8 * (n % 4))) & 0xFFu);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -110,6 +110,7 @@ struct ScanParams {
     // value-preserving early-out under a distance cutoff (levenshtein, u32 distance output / top-k)
     uint32_t early;
     uint32_t first_check;           // column of the first early-out look inside a tile's first chunk: 4, 6 or 8 (plan())
+    uint32_t narrow_look;           // early_lean_kernel: run the columns before the first look on 32-bit words (set by the launcher)
     // band_kernel (rf_band.hip): long query, raw distance cutoff band_k with 2 * band_k + 1 <= 64; band = 1 selects it
     uint32_t band, band_k;
     // top-k mode (topk_k != 0): no per-candidate output, one k-entry key list per workgroup

@@ -180,6 +180,11 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
     const uint32_t len2 = p.uniform_len, len1 = p.len1;
     const uint32_t nch = (len2 + kChunk - 1) / kChunk;  // >= 1: the launcher sends lengths >= 16 here
     const TileFin fin = tile_fin(p, len1, len2);
+    // the narrow first look (below): 64-bit Levenshtein only, and only when the diagonal through (len1, len2) crosses column kFirst
+    // inside the first 32 rows.  RF_NARROW_LOOK=0 is the A/B switch (read by the launcher into p.flags_narrow).
+    constexpr bool kNarrowLook = std::is_same<State, LevState<1>>::value && kFirst < 16;
+    const int32_t look_row = (int32_t)kFirst + (int32_t)len1 - (int32_t)len2;
+    const bool narrow = kNarrowLook && p.narrow_look && look_row >= 1 && look_row <= 32;
     uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
         const uint8_t* base = p.data + (size_t)lane * sizeof(uint4);
@@ -194,7 +199,22 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
             State st;
             st.init();
             bool dead;
-            if constexpr (kFirst < 16) {
+            if constexpr (kNarrowLook) {
+                // The first look only asks for D[kFirst + len1 - len2][kFirst] (the diagonal bound), i.e. for the first <= 32 pattern
+                // rows: the first columns of a 64-bit Levenshtein scan run on the LOW words of the table with the 32-bit recurrence
+                // (10 instead of 16 VALU instructions per column, profiles/head_plane_r03.txt: a dead tile's cost is its instruction
+                // count).  A surviving tile -- rare -- starts over on the full words.
+                if (narrow) {
+                    Lev32State lo;
+                    lo.init();
+                    process_chunk_full<Lev32State, 0, kFirst, 2>(lo, reinterpret_cast<const uint32_t*>(lds_pm), cur);
+                    dead = __ballot(may_pass(p, fin, lo.bound_first(len1, kFirst, len2))) == 0;
+                    if (!dead) process_chunk_full<State, 0, kFirst>(st, lds_pm, cur);
+                } else {
+                    process_chunk_full<State, 0, kFirst>(st, lds_pm, cur);
+                    dead = __ballot(may_pass(p, fin, st.bound_first(len1, kFirst, len2))) == 0;
+                }
+            } else if constexpr (kFirst < 16) {
                 process_chunk_full<State, 0, kFirst>(st, lds_pm, cur);
                 dead = __ballot(may_pass(p, fin, st.bound_first(len1, kFirst, len2))) == 0;
             } else {
@@ -606,6 +626,9 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             // Gpairs/s, top-16 237 -> 263).  RF_EARLY_STATIC=0 selects the run-time form for A/B.
             static const bool early_static = [] { const char* e = getenv("RF_EARLY_STATIC"); return !e || atoi(e) != 0; }();
             static const bool lean = [] { const char* e = getenv("RF_EARLY_LEAN"); return !e || atoi(e) != 0; }();  // A/B: early_lean_kernel
+            static const bool narrow_look = [] { const char* e = getenv("RF_NARROW_LOOK"); return !e || atoi(e) != 0; }();  // A/B: the 32-bit first look of early_lean_kernel
+            ScanParams pn = p;
+            pn.narrow_look = narrow_look ? 1u : 0u;
             if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value ||
                           std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value) {
                 if (early_static) {
@@ -614,7 +637,7 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
         if (p.tiles)                                                                       \
             hipLaunchKernelGGL((early_kernel<State, false, J>), g, b, 0, stream, p);       \
         else if (lean && p.uniform_len >= (uint32_t)kChunk)                                \
-            hipLaunchKernelGGL((early_lean_kernel<State, J>), g, b, 0, stream, p);         \
+            hipLaunchKernelGGL((early_lean_kernel<State, J>), g, b, 0, stream, pn);        \
         else                                                                               \
             hipLaunchKernelGGL((early_kernel<State, true, J>), g, b, 0, stream, p);        \
         return hipGetLastError();
