@@ -88,6 +88,7 @@ struct rf_corpus {
     uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
     size_t n_slots = 0;          // entries of d_orig: 64 per tile (exact tiles, then the views)
     // large ragged corpora return their results through a slot-ordered temporary + one gather (rf_pack.hip): built on first use
+    mutable uint8_t* d_heads8 = nullptr;       // head plane: the first 8 symbols of every candidate (small-cutoff scans; built on first use)
     mutable uint32_t* d_slot_of = nullptr;     // candidate -> its slot
     mutable uint32_t* d_slot_ident = nullptr;  // slot -> slot, kPad on padding lanes (stands in for d_orig in such a launch)
     uint32_t n_tiles = 0;        // exact tiles, then the virtual (one-length) views of the mixed section
@@ -1072,6 +1073,7 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_data) (void)hipFree(c->d_data);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_orig) (void)hipFree(c->d_orig);
+    if (c->d_heads8) (void)hipFree(c->d_heads8);
     if (c->d_slot_of) (void)hipFree(c->d_slot_of);
     if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
     if (c->d_mixed) (void)hipFree(c->d_mixed);
@@ -1456,6 +1458,33 @@ static size_t launch_scratch_bytes(const ScanParams& p, RawKind raw)
     return 0;
 }
 
+// Small-cutoff Levenshtein scans of large single-length corpora take their first look from the head plane (rf_pack.hip
+// head8_plane_kernel).  Built once per corpus, on the first such scan; RF_HEAD8_MIN=<tiles> moves the threshold (0 = never).
+// Failing to allocate it is not an error: the scan then reads the tiles' first chunk rows as before.
+static const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, RawKind raw, hipStream_t st)
+{
+    static const size_t min_tiles = [] { const char* e = getenv("RF_HEAD8_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 14; }();
+    if (!min_tiles || !p.early || raw != RAW_LEV || p.words != 1 || p.first_check > 8 || !corpus->uniform || corpus->borrowed ||
+        corpus->n_tiles < min_tiles || corpus->uniform_len < (uint32_t)kChunk)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+    if (!corpus->d_heads8) {
+        uint8_t* h = nullptr;
+        if (hipMalloc((void**)&h, (size_t)corpus->n_tiles * kWave * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipError_t e = launch_head8_plane(corpus->d_data, corpus->n_tiles, (uint32_t)tile_bytes(corpus->uniform_len), h, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (other streams may use the plane as soon as the lock is released)
+        if (e != hipSuccess) {
+            (void)hipFree(h);
+            return nullptr;
+        }
+        corpus->d_heads8 = h;
+    }
+    return corpus->d_heads8;
+}
+
 static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out,
                           rf_mem out_mem, void* stream, bool f64_out)
 {
@@ -1485,6 +1514,7 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     if (s != RF_OK) return s;
 
     hipStream_t st = (hipStream_t)stream;
+    p.heads8 = corpus_head8_plane(corpus, p, raw, st);
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     const size_t out_bytes = corpus->n * elem;
     void* d_out = out;
@@ -1753,6 +1783,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     *desc = op == RF_OP_SIMILARITY;
     s = comparator_device_pm(c, corpus->device, &p.pm);
     if (s != RF_OK) return s;
+    p.heads8 = corpus_head8_plane(corpus, p, raw, st);
     // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list
     rf_corpus::TopkScratch sc;
     {

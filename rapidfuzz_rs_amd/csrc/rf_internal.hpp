@@ -64,6 +64,7 @@ struct ScanParams {
     const uint32_t* mixed_orig;    // per lane: original index, kPad = no candidate
     const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w], indexed by ORIGINAL symbol
     const uint8_t* sigma;  // device uint8[256]: original symbol -> the symbol stored in the packed corpus
+    const uint8_t* heads8; // single-length corpora under a small cutoff: the candidates' first 8 symbols, tile t at t * 512 B (rf_pack.hip); nullptr = none
     void* out;             // uint32_t* or double*
     uint32_t n_tiles;
     uint32_t n;            // number of real candidates
@@ -148,6 +149,7 @@ hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes
 int scan_max_grid();
 // results of a ragged corpus in original order without scattered stores (rf_pack.hip): slot -> slot / candidate -> slot maps, and the gather
 hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream);
+hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t tile_bytes, uint8_t* heads, hipStream_t stream);  // rf_pack.hip: the candidates' first 8 symbols
 hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void* out, uint32_t n, bool f64, hipStream_t stream);
 // exact selection over a device score vector (rf_select.hip)
 hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, void* ctl, hipStream_t st);

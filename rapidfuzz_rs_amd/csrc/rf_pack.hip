@@ -262,4 +262,26 @@ hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void*
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Head plane of a single-length corpus: the first 8 symbols of every candidate, tile t's 64 lanes at t * 512 B.
+// A Levenshtein scan under a small cutoff k takes its first look at column k + 3 (rounded up to even) and on a typical corpus
+// abandons nearly every tile there; with k <= 5 that look needs <= 8 symbols, so those scans stream 8 bytes per candidate from
+// this plane instead of 16-byte chunk rows out of the tiles (rf_scan.hip early_head8_kernel).  An acceleration index beside the
+// corpus (+ 12.5 % for 64-symbol candidates), built on the first such scan, never part of a corpus file.  NOT the layout
+// experiment of profiles/head_plane_r03.txt (same bytes, denser: no gain) -- this one halves the bytes.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head8_plane_kernel(const uint8_t* __restrict__ data, uint32_t n_tiles, uint32_t tile_bytes, uint2* __restrict__ heads)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tiles; t += gridDim.x * 4)
+        heads[(size_t)t * kWave + lane] = *reinterpret_cast<const uint2*>(data + (uint64_t)t * tile_bytes + (size_t)lane * kChunk);
+}
+hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t tile_bytes, uint8_t* heads, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(head8_plane_kernel, dim3(std::min<uint32_t>((n_tiles + 3) / 4, 65536u)), dim3(256), 0, stream, data, n_tiles, tile_bytes,
+                       reinterpret_cast<uint2*>(heads));
+    return hipGetLastError();
+}
+
 }  // namespace rf

@@ -159,7 +159,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
 // everything a surviving tile needs (the rest of its first chunk, later chunks fetched on demand, looks at every chunk end,
 // finishing, top-k) sits behind one branch.  scan_body spends 50 scalar instructions and 21 branches on a dead tile even with
 // the look compiled in; four SIMDs share one scalar unit, so that is time the 136 vector instructions cannot overlap.
-template <class State, int kFirst>
+// kHead8: the first look reads the candidates' first 8 symbols from the HEAD PLANE (rf_pack.hip head8_plane_kernel: 8 bytes per
+// candidate, tile t's row at t * 512 B) instead of their first 16-byte chunk rows: a scan under a cutoff <= 5 decides nearly every
+// tile from <= 8 columns, so the bytes it has to move halve (and the look itself runs on 32-bit words: the narrow look below).
+// A surviving tile fetches its first chunk row from the ordinary payload and starts over.
+template <class State, int kFirst, bool kHead8 = false>
 __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
 {
     constexpr int W = State::kWords;
@@ -187,19 +191,41 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
     const bool narrow = kNarrowLook && p.narrow_look && look_row >= 1 && look_row <= 32;
     uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
-        const uint8_t* base = p.data + (size_t)lane * sizeof(uint4);
-        uint4 cur = load_chunk(reinterpret_cast<const uint4*>(base + (uint64_t)t * p.uniform_tile_bytes));
+        static_assert(!kHead8 || kFirst <= 8, "the head plane holds 8 symbols per candidate");
+        using Look = typename std::conditional<std::is_same<State, LevState<1>>::value, Lev32State, State>::type;  // the state the first look runs on
+        constexpr int kLookPitch = std::is_same<State, LevState<1>>::value ? 2 : 1;                                 // its table row pitch, in its words
+        const uint8_t* base = kHead8 ? p.heads8 + (size_t)lane * sizeof(uint2) : p.data + (size_t)lane * sizeof(uint4);
+        const uint32_t row_pitch = kHead8 ? (uint32_t)(kWave * sizeof(uint2)) : p.uniform_tile_bytes;
+        auto load_row = [&](uint32_t tile) -> uint4 {
+            if constexpr (kHead8) {
+                typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+                const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(base + (uint64_t)tile * row_pitch));
+                return make_uint4(v.x, v.y, 0u, 0u);
+            } else {
+                return load_chunk(reinterpret_cast<const uint4*>(base + (uint64_t)tile * row_pitch));
+            }
+        };
+        uint4 cur = load_row(t);
         while (true) {
             const uint32_t t_next = t + stride;
             const bool has_next = t_next < p.tile_end;
             // the first chunk row of the next tile (past the last tile: a cached re-read of this one)
-            const uint4 ahead = load_chunk(reinterpret_cast<const uint4*>(base + (uint64_t)(has_next ? t_next : t) * p.uniform_tile_bytes));
+            const uint4 ahead = load_row(has_next ? t_next : t);
             const uint32_t idx = t * kWave + lane;
             const bool valid = idx < p.n;
             State st;
             st.init();
             bool dead;
-            if constexpr (kNarrowLook) {
+            if constexpr (kHead8) {
+                Look lo;
+                lo.init();
+                process_chunk_full<Look, 0, kFirst, kLookPitch>(lo, reinterpret_cast<const typename Look::Word*>(lds_pm), cur);
+                dead = __ballot(may_pass(p, fin, lo.bound_first(len1, kFirst, len2))) == 0;
+                if (!dead) {  // rare: the whole first chunk row from the tile itself, and the full-width state from column 0
+                    cur = load_chunk(reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes) + lane);
+                    process_chunk_full<State, 0, kFirst>(st, lds_pm, cur);
+                }
+            } else if constexpr (kNarrowLook) {
                 // The first look only asks for D[kFirst + len1 - len2][kFirst] (the diagonal bound), i.e. for the first <= 32 pattern
                 // rows: the first columns of a 64-bit Levenshtein scan run on the LOW words of the table with the 32-bit recurrence
                 // (10 instead of 16 VALU instructions per column, profiles/head_plane_r03.txt: a dead tile's cost is its instruction
@@ -268,6 +294,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void early_lean_kernel(const
     __shared__ typename State::Word lds_pm[256 * State::kWords];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
     early_lean_body<State, kFirst>(p, lds_pm, lds_topk);
+}
+template <class State, int kFirst>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void early_head8_kernel(const ScanParams p)
+{
+    __shared__ typename State::Word lds_pm[256 * State::kWords];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    early_lean_body<State, kFirst, true>(p, lds_pm, lds_topk);
 }
 
 template <class State, bool kUniform, int kFirst>
@@ -636,8 +669,16 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
     case J:                                                                                \
         if (p.tiles)                                                                       \
             hipLaunchKernelGGL((early_kernel<State, false, J>), g, b, 0, stream, p);       \
-        else if (lean && p.uniform_len >= (uint32_t)kChunk)                                \
+        else if (lean && p.uniform_len >= (uint32_t)kChunk) {                              \
+            if constexpr (J <= 8 && (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value)) { \
+                const int32_t look_row = J + (int32_t)p.len1 - (int32_t)p.uniform_len;      \
+                if (p.heads8 && (std::is_same<State, Lev32State>::value || (look_row >= 1 && look_row <= 32))) { \
+                    hipLaunchKernelGGL((early_head8_kernel<State, J>), g, b, 0, stream, pn); \
+                    return hipGetLastError();                                              \
+                }                                                                          \
+            }                                                                              \
             hipLaunchKernelGGL((early_lean_kernel<State, J>), g, b, 0, stream, pn);        \
+        }                                                                                  \
         else                                                                               \
             hipLaunchKernelGGL((early_kernel<State, true, J>), g, b, 0, stream, p);        \
         return hipGetLastError();
