@@ -286,6 +286,38 @@ rf_status rf_topk_merge_u32(rf_op op, const uint32_t *scores, const uint64_t *in
                             uint32_t lists, uint32_t k, uint32_t *out_score, uint64_t *out_index,
                             uint32_t *out_count);
 
+/* ---- top-k entries: the device-resident exchange format for EVERY top-k the engine offers ---------------------------
+ * rf_topk_keys_device packs (u32 score, 32-bit global index) into 8 bytes: k <= 64, usize-valued metrics, at most 2^32
+ * candidates in the logical corpus.  An rf_topk_entry is the general form (a score and a 64-bit global index
+ * per entry): 16 bytes that merge across shards by a plain unsigned comparison of (key, index), for u32 AND f64 scores,
+ * any k, any index_base.
+ *   key   : order-preserving image of the score, smaller = better --
+ *           u32 scores: the score (RF_OP_DISTANCE) or 0xFFFFFFFF - score (RF_OP_SIMILARITY);
+ *           f64 scores: the IEEE bits with the sign bit flipped (negative values: all bits flipped), complemented for the
+ *           descending ops (rf_topk_entry_score_* below invert the map)
+ *   index : index_base + original candidate index
+ * Empty entries (fewer than k candidates passed): key = index = UINT64_MAX.
+ * rf_topk_entries_device fills k entries in DEVICE memory, best first.  usize-valued metrics with k <= 64 take the in-scan
+ * lists and are fully asynchronous on `stream`; every other shape (f64 scores, k > 64, queries beyond 512 symbols, general
+ * weight tables) scores all candidates and selects (rf_topk_f64's path), which synchronizes the stream once.
+ * rf_topk_merge_entries_device: the k best of n entries (e.g. all ranks' lists after an all-gather), asynchronous.
+ * rf_topk_allgather_merge_entries: ncclAllGather of every rank's k entries over the caller's communicator + that merge
+ * (RCCL resolved at run time like rf_topk_allgather_merge).  rf_topk_merge_entries: the same merge on host arrays. */
+typedef struct rf_topk_entry {
+    uint64_t key;
+    uint64_t index;
+} rf_topk_entry;
+rf_status rf_topk_entries_device(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint64_t k,
+                                 uint64_t index_base, rf_topk_entry *d_entries_out, void *stream);
+rf_status rf_topk_merge_entries_device(const rf_topk_entry *d_entries, uint64_t n, uint64_t k, rf_topk_entry *d_out, int device,
+                                       void *stream);
+rf_status rf_topk_allgather_merge_entries(const rf_topk_entry *d_local, uint64_t k, void *nccl_comm, uint32_t world,
+                                          rf_topk_entry *d_all, rf_topk_entry *d_merged, int device, void *stream);
+rf_status rf_topk_merge_entries(const rf_topk_entry *entries, uint64_t n, uint64_t k, rf_topk_entry *out);
+/* the score behind an entry's key (`descending` = the op was a similarity op) */
+uint32_t rf_topk_entry_score_u32(uint64_t key, int descending);
+double rf_topk_entry_score_f64(uint64_t key, int descending);
+
 /* ---- measurement aid (not part of the drop-in surface) ----------------------------------------------------------
  * The single-word scans are bound by VALU issue, not HBM.  rf_probe_issue_rate runs the library's own
  * recurrence column for (metric, query_len) on register-resident pattern words -- no HBM, no LDS, no tile loop -- with

@@ -258,6 +258,21 @@ class BatchComparator:
         N.check(N.lib().rf_topk_keys_device(self._h, corpus._h, op, C.byref(ca), k, index_base, keys_out.data_ptr(), out_ptr, out_mem, st))
         return keys_out
 
+    def topk_entries_device(self, corpus: Corpus, k: int, entries_out, op: int = N.OP_DISTANCE, args: Optional[Args] = None,
+                            index_base: int = 0, stream=None, **kw):
+        """Top-k of ANY metric / op / k as 16-byte entries on the device (rf_topk_entries_device): `entries_out` is a CUDA int64
+        tensor of shape [>= k, 2] -- (order-preserving key, index_base + index), best first, (-1, -1) = empty; entries of
+        different shards merge by (key, index) (parallel.merge_entries_device / decode_entries)."""
+        import torch
+
+        a = _mk_args(args, kw.get("score_cutoff"), kw.get("score_hint"), kw.get("weights"), kw.get("prefix_weight"))
+        is_f = self.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
+        ca = a.to_c(is_f)
+        assert entries_out.is_cuda and entries_out.dtype == torch.int64 and entries_out.is_contiguous() and entries_out.numel() >= 2 * k
+        st = stream if stream is not None else torch.cuda.current_stream(entries_out.device).cuda_stream
+        N.check(N.lib().rf_topk_entries_device(self._h, corpus._h, op, C.byref(ca), k, index_base, entries_out.data_ptr(), st))
+        return entries_out
+
     # ------------------------------------------------------------------ the reference's per-candidate methods
     def _one(self, op: int, s2, args, kw):
         # a u32 query needs the candidate in a u32 corpus even when the candidate itself is plain ASCII

@@ -70,6 +70,8 @@ SYMBOLS = [
     "rf_host_layout_free", "rf_corpus_count", "rf_corpus_payload_bytes", "rf_corpus_device_bytes",
     "rf_corpus_device", "rf_many_u32", "rf_many_f64", "rf_one_u32", "rf_one_f64", "rf_many_multi_u32", "rf_many_multi_f64", "rf_topk_u32", "rf_topk_f64", "rf_topk_keys_device", "rf_topk_merge_keys_device", "rf_topk_merge_u32",
     "rf_probe_issue_rate", "rf_topk_allgather_merge",
+    "rf_topk_entries_device", "rf_topk_merge_entries_device", "rf_topk_allgather_merge_entries", "rf_topk_merge_entries",
+    "rf_topk_entry_score_u32", "rf_topk_entry_score_f64",
 ]
 
 
@@ -157,6 +159,14 @@ def lib() -> C.CDLL:
     L.rf_probe_issue_rate.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.rf_topk_allgather_merge.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_int, vp]
     L.rf_topk_merge_u32.argtypes = [C.c_int, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, u32p]
+    L.rf_topk_entries_device.argtypes = [vp, vp, C.c_int, C.POINTER(RfArgs), C.c_uint64, C.c_uint64, vp, vp]
+    L.rf_topk_merge_entries_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_int, vp]
+    L.rf_topk_allgather_merge_entries.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, C.c_int, vp]
+    L.rf_topk_merge_entries.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+    L.rf_topk_entry_score_u32.argtypes = [C.c_uint64, C.c_int]
+    L.rf_topk_entry_score_u32.restype = C.c_uint32
+    L.rf_topk_entry_score_f64.argtypes = [C.c_uint64, C.c_int]
+    L.rf_topk_entry_score_f64.restype = C.c_double
     _lib = L
     return L
 

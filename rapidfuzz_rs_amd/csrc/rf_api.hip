@@ -2170,6 +2170,122 @@ rf_status rf_topk_allgather_merge(const uint64_t* d_local_keys, uint32_t k, void
 }
 
 // ---------------------------------------------------------------------------------------------------
+// top-k entries: 16 bytes {order-preserving key, 64-bit global index} -- the exchange format for every top-k (rfgpu.h)
+// ---------------------------------------------------------------------------------------------------
+uint32_t rf_topk_entry_score_u32(uint64_t key, int descending) { return descending ? 0xFFFFFFFFu - (uint32_t)key : (uint32_t)key; }
+double rf_topk_entry_score_f64(uint64_t key, int descending)
+{
+    uint64_t b = descending ? ~key : key;
+    b ^= (b >> 63) ? 0x8000000000000000ull : ~0ull;  // undo the order-preserving map of rf_select.hip KeyOf<uint64_t>
+    double d;
+    std::memcpy(&d, &b, sizeof(d));
+    return d;
+}
+
+rf_status rf_topk_entries_device(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, uint64_t index_base,
+                                 rf_topk_entry* d_entries_out, void* stream)
+{
+    if (!c || !corpus || !args || !d_entries_out || k == 0) {
+        set_error("rf_topk_entries_device: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (corpus->n == 0) {
+        RF_HIP(hipMemsetAsync(d_entries_out, 0xFF, (size_t)k * sizeof(rf_topk_entry), st));
+        return RF_OK;
+    }
+    const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
+    const bool f64 = !usize_metric || op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY;
+    if (!f64 && k <= (uint64_t)kWave) {
+        // the in-scan lists: keys with the LOCAL index, widened on the device -- nothing synchronizes
+        uint64_t* d_keys = nullptr;
+        RF_HIP(hipMallocAsync((void**)&d_keys, (size_t)kWave * sizeof(uint64_t), st));
+        bool desc = false;
+        const rf_status s = topk_core(c, corpus, op, args, (uint32_t)k, 0, d_keys, nullptr, RF_MEM_HOST, st, &desc);
+        if (s == RF_OK) {
+            const hipError_t e = launch_keys_to_entries(d_keys, (uint32_t)k, index_base, d_entries_out, st);
+            (void)hipFreeAsync(d_keys, st);
+            RF_HIP(e);
+            return RF_OK;
+        }
+        (void)hipFreeAsync(d_keys, st);
+        if (s != RF_ERR_UNSUPPORTED) return s;  // (long queries, general weight tables: the selection path below)
+    }
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> idx;
+    bool desc = false;
+    const rf_status s = topk_by_selection(c, corpus, op, args, k, f64, nullptr, RF_MEM_HOST, st, &keys, &idx, &desc);
+    if (s != RF_OK) return s;
+    std::vector<rf_topk_entry> host((size_t)k, rf_topk_entry{~0ull, ~0ull});
+    for (size_t i = 0; i < keys.size(); ++i) {
+        // (the u32 selection key of a similarity is 0xFFFFFFFE - score, rf_select.hip: the entry format says 0xFFFFFFFF - score)
+        host[i].key = f64 ? keys[i] : (desc ? keys[i] + 1 : keys[i]);
+        host[i].index = index_base + idx[i];
+    }
+    RF_HIP(hipMemcpyAsync(d_entries_out, host.data(), host.size() * sizeof(rf_topk_entry), hipMemcpyHostToDevice, st));
+    RF_HIP(hipStreamSynchronize(st));  // (`host` dies with this frame)
+    return RF_OK;
+}
+
+rf_status rf_topk_merge_entries_device(const rf_topk_entry* d_entries, uint64_t n, uint64_t k, rf_topk_entry* d_out, int device, void* stream)
+{
+    if (!d_entries || !d_out || k == 0 || n == 0 || n > 0x7FFFFFFFull || k > 0x7FFFFFFFull) {
+        set_error("rf_topk_merge_entries_device: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return RF_ERR_NO_DEVICE;
+    const hipError_t e = launch_merge_entries(d_entries, (uint32_t)n, (uint32_t)k, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        set_error(std::string("top-k entry merge: ") + hipGetErrorString(e));
+        return RF_ERR_HIP;
+    }
+    return RF_OK;
+}
+
+rf_status rf_topk_allgather_merge_entries(const rf_topk_entry* d_local, uint64_t k, void* nccl_comm, uint32_t world, rf_topk_entry* d_all,
+                                          rf_topk_entry* d_merged, int device, void* stream)
+{
+    if (!d_local || !d_all || !d_merged || !nccl_comm || k == 0 || world == 0) {
+        set_error("rf_topk_allgather_merge_entries: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    const nccl_all_gather_fn all_gather = find_nccl_all_gather();
+    if (!all_gather) {
+        set_error("rf_topk_allgather_merge_entries: no RCCL (ncclAllGather) found in this process or on the library path");
+        return RF_ERR_UNSUPPORTED;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return RF_ERR_NO_DEVICE;
+    constexpr int kNcclUint64 = 5;  // ncclDataType_t::ncclUint64 (nccl.h): an entry is two of them
+    const int rc = all_gather(d_local, d_all, (size_t)k * 2, kNcclUint64, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) {
+        set_error("rf_topk_allgather_merge_entries: ncclAllGather failed with ncclResult_t " + std::to_string(rc));
+        return RF_ERR_HIP;
+    }
+    return rf_topk_merge_entries_device(d_all, (uint64_t)world * k, k, d_merged, device, stream);
+}
+
+rf_status rf_topk_merge_entries(const rf_topk_entry* entries, uint64_t n, uint64_t k, rf_topk_entry* out)
+{
+    if ((n && !entries) || !out || k == 0) {
+        set_error("rf_topk_merge_entries: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    std::vector<rf_topk_entry> v;
+    for (uint64_t i = 0; i < n; ++i)
+        if (entries[i].key != ~0ull || entries[i].index != ~0ull) v.push_back(entries[i]);
+    std::sort(v.begin(), v.end(), [](const rf_topk_entry& a, const rf_topk_entry& b) { return a.key != b.key ? a.key < b.key : a.index < b.index; });
+    for (uint64_t i = 0; i < k; ++i) out[i] = i < v.size() ? v[i] : rf_topk_entry{~0ull, ~0ull};
+    return RF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // corpus files, and corpora larger than HBM
 // ---------------------------------------------------------------------------------------------------
 // The packed form is position-independent (tile descriptors hold offsets, tiles ascend by length), so a corpus can

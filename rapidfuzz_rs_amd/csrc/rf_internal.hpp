@@ -156,6 +156,8 @@ hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, 
 hipError_t launch_select_hist(const void* s, bool f64, uint32_t n, bool desc, uint64_t prefix_mask, uint64_t prefix, uint32_t shift, uint32_t bits,
                               unsigned long long* hist, hipStream_t st);
 uint32_t select_blocks(uint32_t n);
+hipError_t launch_keys_to_entries(const uint64_t* keys, uint32_t k, uint64_t index_base, rf_topk_entry* out, hipStream_t st);  // rf_select.hip
+hipError_t launch_merge_entries(const rf_topk_entry* in, uint32_t n, uint32_t k, rf_topk_entry* out, hipStream_t st);
 hipError_t launch_select_count(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, uint32_t* cnt_less, uint32_t* cnt_eq, hipStream_t st);
 hipError_t launch_select_emit(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, const uint32_t* off_less, const uint32_t* off_eq, uint32_t n_less,
                               uint32_t need_eq, void* out_key, uint32_t* out_idx, hipStream_t st);

@@ -237,17 +237,24 @@ __global__ __launch_bounds__(256) void gather_results_kernel(const T* __restrict
     const uint32_t spans = (n + kGatherSpan - 1) / kGatherSpan;
     for (uint32_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
         const uint32_t base = sp * kGatherSpan, end = min(n, base + kGatherSpan);
-        for (uint32_t i0 = base + threadIdx.x; i0 < end; i0 += 256 * kGatherUnroll) {
-            uint32_t s[kGatherUnroll];
-            T v[kGatherUnroll];
+        // software pipeline: the slot loads of trip k + 1 are in flight while trip k's dependent loads and stores run
+        uint32_t s[kGatherUnroll], s_next[kGatherUnroll];
+        uint32_t i0 = base + threadIdx.x;
 #pragma unroll
-            for (uint32_t j = 0; j < kGatherUnroll; ++j) s[j] = i0 + j * 256 < end ? __builtin_nontemporal_load(slot_of + i0 + j * 256) : kPad;
+        for (uint32_t j = 0; j < kGatherUnroll; ++j) s[j] = i0 + j * 256 < end ? __builtin_nontemporal_load(slot_of + i0 + j * 256) : kPad;
+        for (; i0 < end; i0 += 256 * kGatherUnroll) {
+            const uint32_t i1 = i0 + 256 * kGatherUnroll;
+#pragma unroll
+            for (uint32_t j = 0; j < kGatherUnroll; ++j) s_next[j] = i1 + j * 256 < end ? __builtin_nontemporal_load(slot_of + i1 + j * 256) : kPad;
+            T v[kGatherUnroll];
 #pragma unroll
             for (uint32_t j = 0; j < kGatherUnroll; ++j)
                 if (s[j] != kPad) v[j] = tmp[s[j]];
 #pragma unroll
             for (uint32_t j = 0; j < kGatherUnroll; ++j)
                 if (s[j] != kPad) __builtin_nontemporal_store(v[j], out + i0 + j * 256);
+#pragma unroll
+            for (uint32_t j = 0; j < kGatherUnroll; ++j) s[j] = s_next[j];
         }
     }
 }

@@ -265,4 +265,47 @@ hipError_t launch_select_emit(const void* s, bool f64, uint32_t n, bool desc, ui
     return hipGetLastError();
 }
 
+// ---- top-k entries (rfgpu.h rf_topk_entry): 16 bytes {order-preserving key, 64-bit global index} ---------------------------------
+// in-scan keys ((score or ~score) << 32 | local index, UINT64_MAX = empty) -> entries
+__global__ void keys_to_entries_kernel(const uint64_t* __restrict__ keys, uint32_t k, uint64_t index_base, rf_topk_entry* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const uint64_t x = keys[i];
+    rf_topk_entry e;
+    e.key = x == ~0ull ? ~0ull : (x >> 32);  // distance: the score; similarity: ~score as u32 = 0xFFFFFFFF - score
+    e.index = x == ~0ull ? ~0ull : index_base + (uint32_t)x;
+    out[i] = e;
+}
+hipError_t launch_keys_to_entries(const uint64_t* keys, uint32_t k, uint64_t index_base, rf_topk_entry* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(keys_to_entries_kernel, dim3((k + 63) / 64), dim3(64), 0, st, keys, k, index_base, out);
+    return hipGetLastError();
+}
+// merge by ranking: (key, index) pairs are unique, so an entry's position in the merged list is the number of entries below it.
+// n is (ranks x k): hundreds to a few thousand entries -- every workgroup ranks 256 of them against all n.
+__global__ __launch_bounds__(256) void merge_entries_kernel(const rf_topk_entry* __restrict__ in, uint32_t n, uint32_t k, rf_topk_entry* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < k && i >= n) out[i] = rf_topk_entry{~0ull, ~0ull};  // (fewer inputs than k)
+    if (i >= n) return;
+    const rf_topk_entry me = in[i];
+    uint32_t rank = 0, valid = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const rf_topk_entry o = in[j];
+        rank += (o.key < me.key || (o.key == me.key && o.index < me.index)) ? 1u : 0u;
+        valid += (o.key != ~0ull || o.index != ~0ull) ? 1u : 0u;
+    }
+    const bool empty = me.key == ~0ull && me.index == ~0ull;
+    if (!empty && rank < k) out[rank] = me;
+    // the tail behind the valid entries: one writer per position (the thread whose index equals the position)
+    if (i < k && i >= valid) out[i] = rf_topk_entry{~0ull, ~0ull};
+}
+hipError_t launch_merge_entries(const rf_topk_entry* in, uint32_t n, uint32_t k, rf_topk_entry* out, hipStream_t st)
+{
+    const uint32_t cover = n > k ? n : k;
+    hipLaunchKernelGGL(merge_entries_kernel, dim3((cover + 255) / 256), dim3(256), 0, st, in, n, k, out);
+    return hipGetLastError();
+}
+
 }  // namespace rf

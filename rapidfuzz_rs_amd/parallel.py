@@ -73,3 +73,55 @@ def merge_keys_device(all_keys, k: int, out, stream=None):
     st = stream if stream is not None else torch.cuda.current_stream(all_keys.device).cuda_stream
     N.check(N.lib().rf_topk_merge_keys_device(all_keys.data_ptr(), all_keys.numel(), k, out.data_ptr(), all_keys.device.index or 0, st))
     return out
+
+
+# ---- 16-byte top-k entries (rf_topk_entry: order-preserving key, 64-bit global index): any metric, any k, any index space ----
+def merge_entries_device(all_entries, k: int, out, stream=None):
+    """Device-side merge of all-gathered topk_entries_device lists (CUDA int64 tensors [n, 2]) into the k best, best first,
+    (-1, -1) = empty; asynchronous on torch's current stream."""
+    import torch
+
+    assert all_entries.is_cuda and out.is_cuda and all_entries.dtype == torch.int64 and out.dtype == torch.int64
+    assert all_entries.is_contiguous() and out.is_contiguous() and out.numel() >= 2 * k
+    st = stream if stream is not None else torch.cuda.current_stream(all_entries.device).cuda_stream
+    N.check(N.lib().rf_topk_merge_entries_device(all_entries.data_ptr(), all_entries.numel() // 2, k, out.data_ptr(), all_entries.device.index or 0, st))
+    return out
+
+
+def merge_entries(entries: np.ndarray, k: int) -> np.ndarray:
+    """Host merge of entries ([n, 2] uint64) into the k best (rf_topk_merge_entries): what a gloo exchange ends with."""
+    e = np.ascontiguousarray(entries, dtype=np.uint64).reshape(-1, 2)
+    out = np.empty((k, 2), dtype=np.uint64)
+    N.check(N.lib().rf_topk_merge_entries(e.ctypes.data, len(e), k, out.ctypes.data))
+    return out
+
+
+def decode_entries(entries, op: int, is_float: bool):
+    """[(score, global index)] of the non-empty entries of an [n, 2] array / tensor of rf_topk_entry."""
+    e = entries.cpu().numpy() if hasattr(entries, "cpu") else np.asarray(entries)
+    e = e.view(np.uint64).reshape(-1, 2)
+    desc = 1 if op in (N.OP_SIMILARITY, N.OP_NORMALIZED_SIMILARITY) else 0
+    L = N.lib()
+    f = L.rf_topk_entry_score_f64 if is_float else L.rf_topk_entry_score_u32
+    return [(f(int(key), desc), int(idx)) for key, idx in e if not (key == _PAD_INDEX and idx == _PAD_INDEX)]
+
+
+def sharded_topk_entries(scorer, shard_corpus, k: int, shard_start: int, op: int, group=None, stream=None, **kw):
+    """One rank's share of a distributed top-k over ANY metric: local entries (global indices), all-gather of k x 16 bytes per rank
+    (RCCL when the backend is "nccl"; through host tensors for "gloo"), merge.  Every rank returns the same [k, 2] int64 tensor."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", shard_corpus.device)
+    local = torch.empty((k, 2), dtype=torch.int64, device=dev)
+    scorer.topk_entries_device(shard_corpus, k, local, op, index_base=shard_start, stream=stream, **kw)
+    merged = torch.empty((k, 2), dtype=torch.int64, device=dev)
+    if dist.get_backend(group) == "nccl":
+        everyone = torch.empty((world * k, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(everyone, local, group=group)
+        return merge_entries_device(everyone, k, merged, stream=stream)
+    host = [torch.empty((k, 2), dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(host, local.cpu(), group=group)
+    merged.copy_(torch.from_numpy(merge_entries(torch.cat(host).numpy().view(np.uint64), k).view(np.int64)))
+    return merged

@@ -89,6 +89,18 @@ macro_rules! comparator_core {
             }
         }
         impl BatchComparator {
+            /// The multi-GPU step for ANY metric / op / k (16-byte entries: order-preserving key + 64-bit global index, `rf_topk_entry`):
+            /// scan this rank's shard, all-gather k entries per rank over the caller's RCCL communicator, merge -- on the device.
+            ///
+            /// # Safety
+            /// `d_local` (k entries), `d_all` (world * k) and `d_merged` (k) must be device pointers valid on `stream`.
+            #[allow(clippy::too_many_arguments)]
+            pub unsafe fn topk_sharded_entries_device(&self, shard: &crate::Corpus, op: std::os::raw::c_int, k: u64, args: &Args, shard_start: u64,
+                                                      nccl_comm: *mut std::os::raw::c_void, world: u32, d_local: *mut RfTopkEntry, d_all: *mut RfTopkEntry,
+                                                      d_merged: *mut RfTopkEntry, stream: *mut std::os::raw::c_void) -> Result<(), Error> {
+                check(rf_topk_entries_device(self.0, shard.0, op, &args.0, k, shard_start, d_local, stream))?;
+                check(rf_topk_allgather_merge_entries(d_local, k, nccl_comm, world, d_all, d_merged, shard.device(), stream))
+            }
             /// `BatchComparator::new(s1)` over `u8` elements.
             pub fn new<I: IntoIterator<Item = u8>>(s1: I) -> Self {
                 let s1: Vec<u8> = s1.into_iter().collect();

@@ -85,3 +85,58 @@ def test_merge_topk_similarity_order():
     i = np.array([[4, 2, 9, 0], [5, 1, 3, 0]], dtype=np.uint64)
     ms, mi = parallel.merge_topk(N.OP_SIMILARITY, s, i, np.array([3, 3], dtype=np.uint32), 4)
     assert ms.tolist() == [9, 8, 7, 7] and mi.tolist() == [4, 5, 1, 2]
+
+
+def _entries_worker(rank, world, port, lists, k, ret):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = torch.from_numpy(lists[rank].view(np.int64).copy())
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        ret[rank] = parallel.merge_entries(torch.cat(everyone).numpy().view(np.uint64), k).tolist()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_topk_entries_allgather_gloo_world2():
+    """The 16-byte entry exchange (rf_topk_entry: any metric, any k, 64-bit global indices) at world size 2 over gloo: every rank's k
+    entries are all-gathered and merged by (key, index) on the host (rf_topk_merge_entries); both ranks end with the same list,
+    which is the sort of everything.  The entries are what rf_topk_entries_device returns for a Jaro-Winkler similarity scan of
+    the rank's shard: f64 keys, descending, ties broken by global index, index bases beyond 2^32, one list padded with empties."""
+    import torch.multiprocessing as mp
+
+    q = synth.query(20, 7)
+    rows = synth.rows_host(1501, 24, seed=8)
+    synth.plant_near_duplicates(rows, q, every=97, seed=2)
+    world, k, base = 2, 12, 2**35
+    sims = o.jaro_winkler.BatchComparator(q).rows(N.OP_SIMILARITY, rows)
+
+    def entries_of(lo, hi, kk):  # the definition in rfgpu.h: key = order-preserving image of the f64 score, complemented for similarities
+        bits = sims[lo:hi].view(np.uint64) ^ np.uint64(0x8000000000000000)  # (similarities are >= 0)
+        keys = ~bits
+        order = np.lexsort((np.arange(lo, hi), keys))[:kk]
+        e = np.full((k, 2), np.uint64(2**64 - 1), dtype=np.uint64)
+        e[: len(order), 0] = keys[order]
+        e[: len(order), 1] = np.uint64(base) + np.arange(lo, hi, dtype=np.uint64)[order]
+        return e
+
+    lists = [entries_of(0, 800, k), entries_of(800, 1501, 5)]  # the second shard found only 5 (a cutoff, say): 7 empty entries
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_entries_worker, args=(r, world, port, lists, k, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    exp = sorted([tuple(int(x) for x in e) for lst in lists for e in lst if int(e[0]) != 2**64 - 1])[:k]
+    assert ret[0] == ret[1] == [list(e) for e in exp]
+    # and the keys decode to the scores they came from
+    got = parallel.decode_entries(np.array(ret[0], dtype=np.uint64), N.OP_SIMILARITY, True)
+    assert all(v == float(sims[i - base]) for v, i in got) and got[0][0] == float(sims.max())

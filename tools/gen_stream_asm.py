@@ -321,8 +321,8 @@ def macro(name, lines):
 RING3 = [18, 22, 26]
 KINDS = [
     # name, word bits, look-ahead, ring buffers (first VGPR of each), state registers, s_nop mask over the column's tokens
-    Kind("lev64", 64, 8, RING3, range(60, 64), 0x1B3),
-    Kind("lev32", 32, 8, [42, 46, 22, 26], (60, 61), 0x80),
+    Kind("lev64", 64, 8, RING3, range(60, 64), int(os.environ.get("RF_GEN_MASK64", "0x1B3"), 0)),  # (RF_GEN_*: experiment knobs, tools/build_stream_variant.sh)
+    Kind("lev32", 32, 8, [42, 46, 22, 26][: int(os.environ.get("RF_GEN_RING32", "4"))], (60, 61), int(os.environ.get("RF_GEN_MASK32", "0x80"), 0)),
     Kind("osa", 64, 7, RING3, range(58, 64), 0x613),
 ]
 
