@@ -1522,11 +1522,15 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     p.out = d_out;
     // Large ragged corpora: results in slot order into a temporary, then ONE gather into original order (rf_pack.hip
     // "gather_results_kernel" has the why: the scattered out[orig[slot]] stores of a length-bucketed corpus cost more than the scan).
-    // Every tile writes (no cutoff window with pre-filled entries), the mixed section is walked through its one-length views so that
-    // every candidate has exactly one slot.  RF_UNSCATTER_MIN=<candidates> moves the threshold (0 = never).
+    // The mixed section is walked through its one-length views so that every candidate has exactly one slot; a cutoff's length
+    // window pre-fills the TEMPORARY with None (launch_scan: p.out, p.n slots).  RF_UNSCATTER_MIN=<candidates> moves the threshold
+    // (0 = never).
     static const size_t unscatter_min = [] { const char* e = getenv("RF_UNSCATTER_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
     void* d_tmp = nullptr;
-    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && !p.early && !p.prefill_none) {
+    // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 12 bytes per
+    // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
+    const bool wide_window = (uint64_t)(p.tile_end - p.tile_begin) * 10 >= (uint64_t)corpus->n_tiles * 3;
+    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && wide_window) {
         {
             std::lock_guard<std::mutex> lock(corpus->scratch_mu);
             if (!corpus->d_slot_of) {

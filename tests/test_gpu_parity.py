@@ -1788,7 +1788,8 @@ def test_ragged_results_through_the_gather_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sel = ("test_c1_levenshtein or test_query_lengths_ragged or test_long_queries_multi_sweep_kernel or test_osa_ragged or test_levenshtein_generalized_weights or "
            "test_jaro_ragged_bit_exact or test_jaro_multi_word_path_bit_exact or test_jaro_beyond_512 or test_jaro_short_leftovers or test_fuzz_ratio_batch or "
-           "test_u32_elements_equal or test_randomized_differential or test_band_kernel_long_query")
+           "test_u32_elements_equal or test_randomized_differential or test_band_kernel_long_query or test_cutoff_length_window_ragged or "
+           "test_cutoff_early_out_every_op or test_fuzz_ratio_cutoff_early_out")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", sel],
                        capture_output=True, text=True, cwd=root, env=dict(os.environ, RF_UNSCATTER_MIN="1"))
     assert r.returncode == 0, r.stdout[-3000:]
