@@ -358,8 +358,8 @@ def main():
     if args.cutoff is not None and not is_f64 and not weights:
         maximum = (ln + args.query_len) if args.metric == "indel" else max(ln, args.query_len)
         early = args.cutoff / max(maximum, 1) < (0.4 if args.metric in ("indel", "lcs_seq") else 0.7)
-    # (Levenshtein under a cutoff <= 5 on a single-length corpus: the first look reads the 8-symbol head plane, rf_pack.hip)
-    head8 = early and args.metric == "levenshtein" and args.cutoff <= 5 and not args.ragged and args.query_len <= 64 and n >= (1 << 20) and os.environ.get("RF_HEAD8_MIN") != "0"
+    # (Levenshtein / OSA under a cutoff <= 5 on a single-length corpus: the first look reads the 8-symbol head plane, rf_pack.hip)
+    head8 = early and args.metric in ("levenshtein", "osa") and args.cutoff <= 5 and not args.ragged and args.query_len <= 64 and n >= (1 << 20) and os.environ.get("RF_HEAD8_MIN") != "0"
     bytes_per_pair = (min(ln, 8 if head8 else 16) if early else ln) / nq + out_bytes
     pairs_per_gpu = pairs_per_step / world
     achieved = pairs_per_gpu * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s

@@ -1464,7 +1464,7 @@ static size_t launch_scratch_bytes(const ScanParams& p, RawKind raw)
 static const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, RawKind raw, hipStream_t st)
 {
     static const size_t min_tiles = [] { const char* e = getenv("RF_HEAD8_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 14; }();
-    if (!min_tiles || !p.early || raw != RAW_LEV || p.words != 1 || p.first_check > 8 || !corpus->uniform || corpus->borrowed ||
+    if (!min_tiles || !p.early || (raw != RAW_LEV && raw != RAW_OSA) || p.words != 1 || p.first_check > 8 || !corpus->uniform || corpus->borrowed ||
         corpus->n_tiles < min_tiles || corpus->uniform_len < (uint32_t)kChunk)
         return nullptr;
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);

@@ -471,6 +471,57 @@ struct Lev32State {
     }
 };
 
+// OSA on 32-bit words (osa.rs:156-226 as OsaState<1>::step): the first look of the cutoff scans runs on it (rf_scan.hip
+// early_lean_body: the diagonal bound at column kFirst only needs the first <= 32 pattern rows)
+struct Osa32State {
+    using Word = uint32_t;
+    static constexpr int kWords = 1;
+    uint32_t vp, vn, d0, pm_old;
+    __device__ __forceinline__ void init()
+    {
+        vp = ~0u;
+        vn = 0;
+        d0 = 0;
+        pm_old = 0;
+    }
+    __device__ __forceinline__ void step(const uint32_t (&pm_row)[1])
+    {
+        const uint32_t pm_j = pm_row[0];
+        const uint32_t t = lut3w<T_ANDN_BA>(d0, pm_j, pm_j);  // ~d0 & pm_j
+        const uint32_t tr = (t << 1) & pm_old;                  // osa.rs:180
+        const uint32_t sum = (pm_j & vp) + vp;
+        const uint32_t e = lut3w<T_XOR_OR>(sum, vp, pm_j);
+        const uint32_t d = lut3w<T_OR3>(e, vn, tr);             // osa.rs:183
+        const uint32_t hn = d & vp;
+        const uint32_t hp = lut3w<T_OR_NOR>(vn, d, vp);
+        uint32_t hps;
+        asm("v_lshl_or_b32 %0, %1, 1, 1" : "=v"(hps) : "v"(hp));
+        const uint32_t hns = hn << 1;
+        vn = hps & d;
+        vp = lut3w<T_OR_NOR>(hns, hps, d);
+        d0 = d;
+        pm_old = pm_j;
+    }
+    static constexpr bool kCanPrune = true;
+    __device__ __forceinline__ uint32_t bound(uint32_t len1, uint32_t j, uint32_t len2) const
+    {
+        const int32_t last_row = (int32_t)result(len1, j) - (int32_t)(len2 - j);
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;  // the diagonal bound, see OsaState::bound
+        const int32_t diag = i > 0 ? (int32_t)result((uint32_t)i, j) : 0;
+        return (uint32_t)max(max(last_row, diag), 0);
+    }
+    __device__ __forceinline__ uint32_t bound_first(uint32_t len1, uint32_t j, uint32_t len2) const
+    {
+        const int32_t i = (int32_t)j + (int32_t)len1 - (int32_t)len2;
+        return i > 0 ? result((uint32_t)i, j) : bound(len1, j, len2);
+    }
+    __device__ __forceinline__ uint32_t result(uint32_t len1, uint32_t len2) const
+    {
+        const uint32_t valid = len1 >= 32 ? ~0u : ((1u << len1) - 1);
+        return (uint32_t)((int32_t)len2 + __popc(vp & valid) - __popc(vn & valid));
+    }
+};
+
 struct Lcs32State {
     using Word = uint32_t;
     static constexpr int kWords = 1;

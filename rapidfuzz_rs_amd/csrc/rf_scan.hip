@@ -186,14 +186,17 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
     const TileFin fin = tile_fin(p, len1, len2);
     // the narrow first look (below): 64-bit Levenshtein only, and only when the diagonal through (len1, len2) crosses column kFirst
     // inside the first 32 rows.  RF_NARROW_LOOK=0 is the A/B switch (read by the launcher into p.flags_narrow).
-    constexpr bool kNarrowLook = std::is_same<State, LevState<1>>::value && kFirst < 16;
+    constexpr bool kWide = std::is_same<State, LevState<1>>::value || std::is_same<State, OsaState<1>>::value;  // 64-bit states with a 32-bit twin
+    constexpr bool kNarrowLook = kWide && kFirst < 16;
     const int32_t look_row = (int32_t)kFirst + (int32_t)len1 - (int32_t)len2;
     const bool narrow = kNarrowLook && p.narrow_look && look_row >= 1 && look_row <= 32;
     uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
         static_assert(!kHead8 || kFirst <= 8, "the head plane holds 8 symbols per candidate");
-        using Look = typename std::conditional<std::is_same<State, LevState<1>>::value, Lev32State, State>::type;  // the state the first look runs on
-        constexpr int kLookPitch = std::is_same<State, LevState<1>>::value ? 2 : 1;                                 // its table row pitch, in its words
+        // the state the first look runs on, and its table row pitch in its words
+        using Look = typename std::conditional<std::is_same<State, LevState<1>>::value, Lev32State,
+                                               typename std::conditional<std::is_same<State, OsaState<1>>::value, Osa32State, State>::type>::type;
+        constexpr int kLookPitch = kWide ? 2 : 1;
         const uint8_t* base = kHead8 ? p.heads8 + (size_t)lane * sizeof(uint2) : p.data + (size_t)lane * sizeof(uint4);
         const uint32_t row_pitch = kHead8 ? (uint32_t)(kWave * sizeof(uint2)) : p.uniform_tile_bytes;
         auto load_row = [&](uint32_t tile) -> uint4 {
@@ -231,9 +234,9 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
                 // (10 instead of 16 VALU instructions per column, profiles/head_plane_r03.txt: a dead tile's cost is its instruction
                 // count).  A surviving tile -- rare -- starts over on the full words.
                 if (narrow) {
-                    Lev32State lo;
+                    Look lo;
                     lo.init();
-                    process_chunk_full<Lev32State, 0, kFirst, 2>(lo, reinterpret_cast<const uint32_t*>(lds_pm), cur);
+                    process_chunk_full<Look, 0, kFirst, 2>(lo, reinterpret_cast<const uint32_t*>(lds_pm), cur);
                     dead = __ballot(may_pass(p, fin, lo.bound_first(len1, kFirst, len2))) == 0;
                     if (!dead) process_chunk_full<State, 0, kFirst>(st, lds_pm, cur);
                 } else {
@@ -670,7 +673,7 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
         if (p.tiles)                                                                       \
             hipLaunchKernelGGL((early_kernel<State, false, J>), g, b, 0, stream, p);       \
         else if (lean && p.uniform_len >= (uint32_t)kChunk) {                              \
-            if constexpr (J <= 8 && (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value)) { \
+            if constexpr (J <= 8 && (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value)) { \
                 const int32_t look_row = J + (int32_t)p.len1 - (int32_t)p.uniform_len;      \
                 if (p.heads8 && (std::is_same<State, Lev32State>::value || (look_row >= 1 && look_row <= 32))) { \
                     hipLaunchKernelGGL((early_head8_kernel<State, J>), g, b, 0, stream, pn); \
