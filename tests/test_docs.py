@@ -34,3 +34,19 @@ def test_jaro_asm_include_is_the_generators_output(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith("RF_GEN_")}
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_jaro_chunk_asm.py"), str(out)], check=True, env=env)
     assert out.read_text() == open(os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc", "rf_jaro_chunk_asm.inc")).read()
+
+
+def test_stream_asm_include_is_the_generators_output(tmp_path):
+    """rapidfuzz_rs_amd/csrc/rf_stream_asm.inc (the whole-kernel asm bodies of the no-cutoff Levenshtein / OSA scans) is generated:
+    the committed file must be what tools/gen_stream_asm.py writes, and its kernarg offsets those of the struct the wrapper passes
+    (rf_stream_asm.hip static_asserts them at build time; here: every ARGS entry has a field of the same name)."""
+    out = tmp_path / "stream.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RF_GEN_")}
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_stream_asm.py"), str(out)], check=True, env=env)
+    assert out.read_text() == open(os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc", "rf_stream_asm.inc")).read()
+    import re
+
+    hip = open(os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc", "rf_stream_asm.hip")).read()
+    struct = hip[hip.index("struct StreamAsmArgs {"): hip.index("};", hip.index("struct StreamAsmArgs {"))]
+    for name in re.findall(r"#define RF_STREAM_ARG_(\w+) \d+", out.read_text()):
+        assert re.search(rf"\b{name.lower()}\b", struct.lower()), name

@@ -10,6 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROWS = [  # (file stem, label)
     ("c2_levenshtein", "C2 Levenshtein, query 64 x 100 M len 64, no cutoff (the default `bench.py` line)"),
     ("q32_levenshtein", "same corpus, query 32 (32-bit kernel)"),
+    ("ragged_levenshtein", "ragged: 100 M candidates, lengths uniform in [1, 64] (configs[0]'s distribution), Levenshtein query 64 (`--ragged`)"),
+    ("ragged_q32_levenshtein", "ragged, query 32"),
+    ("ragged_osa", "ragged, OSA"),
+    ("ragged_indel", "ragged, Indel"),
+    ("ragged_jaro_winkler", "ragged, Jaro-Winkler (f64 out)"),
     ("c3_levenshtein_256", "C3 Levenshtein, query 256 x 10 M len 256"),
     ("c3_cutoff8", "C3 corpus, `score_cutoff = 8`"),
     ("c4_indel", "C4 Indel"),

@@ -3,24 +3,31 @@
 #   rocprofv3 kernel-trace + PMC summaries of every BASELINE.json config's dominant kernel, and one bench.py JSON line per config.
 # Results land in gpurun_out/profiles/; copy them into profiles/ afterwards.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 mkdir -p gpurun_out/profiles
 cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
 P() { tag=$1; key=$2; shift 2; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
-MATCH="rf::lev1_asm" P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
-P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
+MATCH="rf::stream_lev64" P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
+MATCH="rf::early" P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
 P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
 P c4_indel "indel:q64:n100000000:l64:cutNone:many" --metric indel
 MATCH="rf::jaro" P c4_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many" --metric jaro_winkler
-MATCH="rf::osa1_asm" P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
-MATCH="rf::lev32_asm" P q32_levenshtein "levenshtein:q32:n100000000:l64:cutNone:many" --query-len 32
-P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" --cutoff 3 --mode topk
+MATCH="rf::stream_osa" P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
+MATCH="rf::stream_lev32" P q32_levenshtein "levenshtein:q32:n100000000:l64:cutNone:many" --query-len 32
+MATCH="rf::early" P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" --cutoff 3 --mode topk
 MATCH="rf::lev1_asm" P topk16_nocutoff "levenshtein:q64:n100000000:l64:cutNone:topk" --mode topk
 MATCH="rf::band" P c3_cutoff8_band "levenshtein:q256:n10000000:l256:cut8:many" --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
+MATCH="rf::stream_lev64" P ragged_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:ragged" --ragged
+MATCH="rf::gather" P ragged_gather "none" --ragged
 MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
 b() { name=$1; shift; python bench.py "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
 b c2_levenshtein
+b ragged_levenshtein --ragged
+b ragged_q32_levenshtein --ragged --query-len 32
+b ragged_osa --ragged --metric osa --no-cpu-baseline
+b ragged_indel --ragged --metric indel
+b ragged_jaro_winkler --ragged --metric jaro_winkler
 b q32_levenshtein --query-len 32
 b c3_levenshtein_256 --query-len 256 --cand-len 256 --candidates 10000000
 b c4_indel --metric indel
@@ -51,7 +58,7 @@ for v in lev64 lev64+topk lev64+topk+out indel indel+topk jw; do python tools/ab
 python - > gpurun_out/profiles/clock_ramp_$R.txt <<PY
 import sqlite3
 cur = sqlite3.connect("/tmp/kt_ramp_$R/kt_results.db").cursor()
-d = [(e - s) / 1e3 for n, s, e in cur.execute("select name, start, end from kernels order by start") if ("stream_kernel" in n or "lev1_asm_kernel" in n) and e - s > 1_000_000]
+d = [(e - s) / 1e3 for n, s, e in cur.execute("select name, start, end from kernels order by start") if ("stream_kernel" in n or "lev1_asm_kernel" in n or "stream_lev64" in n) and e - s > 1_000_000]
 print("python bench.py --steps 40 --warmup 0 --settle-ms 0 under rocprofv3 --kernel-trace: duration (us) of each back-to-back scan launch after the idle set-up phase")
 print(" ".join(f"{x:.0f}" for x in d))
 print(f"first 5 avg {sum(d[:5]) / 5:.0f} us; launches 20+ avg {sum(d[20:]) / max(1, len(d[20:])):.0f} us -> bench.py runs --settle-ms (default 200) of untimed steps before the W warm-up steps and reports config.settle_steps")
