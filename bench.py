@@ -586,9 +586,18 @@ def cpu_baseline(args, q, host_sample, ragged=None):
     run(host_sample[:n1], 1)
     t1 = time.perf_counter() - t0
     try:
-        cores = len(os.sched_getaffinity(0))  # the hardware threads this process may actually run on
+        cores = len(os.sched_getaffinity(0))  # the hardware threads this process may run on ...
     except (AttributeError, OSError):
         cores = os.cpu_count() or 1
+    quota = None
+    try:  # ... and the CPU time its cgroup may use: the GPU boxes of this pool show 256 hardware threads but cpu.max = 16 CPUs, which
+        # is why the "all cores" figure of rounds 1-2 read 13-17 x one core
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+            cores = min(cores, quota)
+    except (OSError, ValueError):
+        pass
     # all hardware threads: the whole host sample per call, repeated until >= 2 s of wall time have been measured (a
     # single 0.4 s call is mostly thread start-up and first-touch page faults; the first call is a warm-up and not counted)
     nall = len(host_sample)
@@ -613,7 +622,8 @@ def cpu_baseline(args, q, host_sample, ragged=None):
         "cores": 1,
         "kind": "port",
         "sample": f"first {n1} candidates of the same corpus, oracle/ (C restatement of the reference's single-threaded BatchComparator loop), 1 thread, {t1:.1f} s",
-        "all_cores": {"value": round(nall * reps / tall / 1e9, 6), "cores": cores, "sample": f"first {nall} candidates x {reps} passes, {tall:.1f} s, {cores} threads"},
+        "all_cores": {"value": round(nall * reps / tall / 1e9, 6), "cores": cores, "sample": f"first {nall} candidates x {reps} passes, {tall:.1f} s, {cores} threads"
+                      + (f" (cgroup cpu.max = {quota} CPUs of {os.cpu_count()} hardware threads)" if quota else "")},
         "cpu_model": model,
     }
 

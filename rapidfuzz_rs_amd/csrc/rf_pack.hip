@@ -230,9 +230,8 @@ hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* sl
 // within a few iterations -- out of its own L1 / L2 -- instead of being fetched by whichever workgroups (on whichever XCDs)
 // happen to hold the neighbouring candidates (first version: 4 consecutive candidates per thread, grid-stride: 0.65 ms for
 // 100 M results = 1.9 TB/s of the 1.2 GB it has to move).
-constexpr uint32_t kGatherSpan = 16384, kGatherUnroll = 8;
-template <class T>
-__global__ __launch_bounds__(256) void gather_results_kernel(const T* __restrict__ tmp, const uint32_t* __restrict__ slot_of, T* __restrict__ out, uint32_t n)
+template <class T, uint32_t kGatherUnroll>
+__global__ __launch_bounds__(256) void gather_results_kernel(const T* __restrict__ tmp, const uint32_t* __restrict__ slot_of, T* __restrict__ out, uint32_t n, uint32_t kGatherSpan)
 {
     const uint32_t spans = (n + kGatherSpan - 1) / kGatherSpan;
     for (uint32_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
@@ -261,11 +260,17 @@ __global__ __launch_bounds__(256) void gather_results_kernel(const T* __restrict
 hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void* out, uint32_t n, bool f64, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    const dim3 g(std::min<uint32_t>((n + kGatherSpan - 1) / kGatherSpan, (uint32_t)scan_max_grid())), b(256);
+    static const uint32_t span = [] { const char* e = getenv("RF_GATHER_SPAN"); return e ? (uint32_t)atoi(e) : 16384u; }();  // tuning knobs
+    static const int unroll = [] { const char* e = getenv("RF_GATHER_UNROLL"); return e ? atoi(e) : 8; }();
+    const dim3 g(std::min<uint32_t>((n + span - 1) / span, (uint32_t)scan_max_grid())), b(256);
     if (f64)
-        hipLaunchKernelGGL(gather_results_kernel<double>, g, b, 0, stream, static_cast<const double*>(tmp), slot_of, static_cast<double*>(out), n);
+        hipLaunchKernelGGL((gather_results_kernel<double, 8>), g, b, 0, stream, static_cast<const double*>(tmp), slot_of, static_cast<double*>(out), n, span);
+    else if (unroll == 16)
+        hipLaunchKernelGGL((gather_results_kernel<uint32_t, 16>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), slot_of, static_cast<uint32_t*>(out), n, span);
+    else if (unroll == 4)
+        hipLaunchKernelGGL((gather_results_kernel<uint32_t, 4>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), slot_of, static_cast<uint32_t*>(out), n, span);
     else
-        hipLaunchKernelGGL(gather_results_kernel<uint32_t>, g, b, 0, stream, static_cast<const uint32_t*>(tmp), slot_of, static_cast<uint32_t*>(out), n);
+        hipLaunchKernelGGL((gather_results_kernel<uint32_t, 8>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), slot_of, static_cast<uint32_t*>(out), n, span);
     return hipGetLastError();
 }
 
