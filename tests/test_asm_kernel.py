@@ -47,3 +47,29 @@ def test_compiler_never_touches_the_pinned_registers(tmp_path, source, kernel, p
     assert re.search(r"; ScratchSize: 0\b", meta), "the asm kernel must not spill"
     assert re.search(rf"; Occupancy: {occupancy}\b", meta), f"the asm kernel is budgeted for {occupancy} wavefronts per SIMD"
     assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) <= vgprs
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_whole_kernel_asm_scans_resources(tmp_path):
+    """rf_stream_asm.hip: the six whole-kernel asm scans (Levenshtein 64- / 32-bit, OSA x single-length / tile descriptors).  The
+    wrapper hands the asm body three operands and nothing else, so everything the launch relies on is visible in the compiler's
+    metadata: no scratch, 64 VGPRs = 8 wavefronts per SIMD, the 2 KiB pattern table as the only LDS object, and a body that
+    contains no compiler-generated code between its first and last instruction (ONE asm statement, then s_endpgm)."""
+    src = os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc")
+    out = tmp_path / "stream.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function", "-S", "--cuda-device-only",
+                    "-o", str(out), os.path.join(src, "rf_stream_asm.hip")], check=True, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    lines = text.splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2rf\d+stream_\w+_kernelENS_13StreamAsmArgsE:", l)]
+    assert len(starts) == 6
+    for start in starts:
+        k = lines[start].split(":")[0]
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        assert sum("ASMSTART" in l for l in body) == 1 and "ASMEND" in lines[end - 1]
+        assert sum("global_store_dword" in l for l in body) == 2  # the full-tile store and the masked one of a tile with padding lanes
+        meta = "\n".join(lines[end : end + 80])
+        assert re.search(r"; ScratchSize: 0\b", meta) and re.search(r"; Occupancy: 8\b", meta), k
+        assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) == 64
+        assert re.search(r"\.amdhsa_group_segment_fixed_size 2048\b", meta), k
