@@ -439,6 +439,43 @@ def main():
             if N.lib().rf_probe_issue_rate(metric_id, args.query_len, 2, local_rank, 8, ctypes.byref(rate)) == N.RF_OK and rate.value > 0:
                 # the kernel's own hand-scheduled chunk (rf_lev_asm.hip) with LDS gathers but no HBM traffic and no tile loop
                 result["roofline"]["issue_bound"]["ceiling_asm_chunk"] = round(rate.value * 64.0 / max(ln, 1), 3)
+            # The ceiling above is measured with idle HBM, where the chip clocks ~2.4 GHz.  A scan that streams HBM runs at the package
+            # power cap (rocm-smi: 1378-1400 W of 1400 W) and the governor takes the core clock down to 1.75-2.15 GHz -- for the SAME
+            # number of cycles per launch (tools/clock_of.sh).  Sample both clocks in this run (rf_probe_core_clock: one wavefront on
+            # a stream of its own, beside ~40 queued scans / beside the probe kernel) and restate the ceiling at the scan's clock.
+            try:
+                import threading
+
+                g_sleep, g_cnt = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                for _ in range(40):
+                    step()
+                time.sleep(0.01)
+                ok_scan = N.lib().rf_probe_core_clock(local_rank, 20000, ctypes.byref(g_sleep), ctypes.byref(g_cnt)) == N.RF_OK
+                clk_scan = g_cnt.value
+                # package power: rocm-smi reports an average over a fraction of a second, so keep the scans coming for ~0.7 s
+                for _ in range(int(min(2000, max(40, 700.0 / max(ms_per_step, 0.05))))):
+                    step()
+                time.sleep(0.25)
+                power_w = gpu_power_watts(local_rank)  # best effort
+                finish_exchange()
+                torch.cuda.synchronize()
+                r2 = ctypes.c_double(0.0)
+                th = threading.Thread(target=lambda: N.lib().rf_probe_issue_rate(metric_id, args.query_len, 0, local_rank, 8, ctypes.byref(r2)))
+                th.start()
+                time.sleep(0.01)
+                ok_probe = N.lib().rf_probe_core_clock(local_rank, 10000, ctypes.byref(g_sleep), ctypes.byref(g_cnt)) == N.RF_OK
+                clk_probe = g_cnt.value
+                th.join()
+                if ok_scan and ok_probe and clk_scan > 0 and clk_probe > 0:
+                    ib = result["roofline"]["issue_bound"]
+                    ib["core_clock_ghz"] = {"under_scan": round(clk_scan, 3), "under_probe": round(clk_probe, 3),
+                                            "how": "rf_probe_core_clock: s_memtime / s_memrealtime of one wavefront beside the queued scans / the probe kernel"}
+                    ib["ceiling_at_scan_clock"] = round(ceiling * clk_scan / clk_probe, 3)
+                    ib["frac_at_scan_clock"] = round(per_gpu / (ceiling * clk_scan / clk_probe), 4)
+                    if power_w:
+                        ib["package_power_w_under_scan"] = power_w
+            except Exception as exc:  # a measurement aid: never fails the bench line
+                result["roofline"]["issue_bound"]["core_clock_ghz"] = {"error": str(exc)[:200]}
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,
@@ -532,6 +569,24 @@ def main():
 
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(result), flush=True)
+
+
+def gpu_power_watts(device):
+    """Socket power as rocm-smi reports it right now (None when rocm-smi is missing or says nothing parsable)."""
+    import re
+    import shutil
+    import subprocess
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([exe, "-d", str(device), "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=10)
+    except (OSError, subprocess.SubprocessError):
+        return None
+    cur = re.search(r"(?:Current|Average) Socket Graphics Package Power \(W\):\s*([0-9.]+)", r.stdout)
+    cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", r.stdout)
+    if not cur:
+        return None
+    return {"now": float(cur.group(1)), **({"cap": float(cap.group(1))} if cap else {})}
 
 
 def measured_traffic(args, n, kernel_ms):

@@ -329,6 +329,13 @@ double rf_topk_entry_score_f64(uint64_t key, int descending);
  * chunk of the headline kernel (rf_lev_asm.hip) alone, the same way.  Synchronous; uses the default stream. */
 rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, uint32_t mode, int device, uint32_t blocks_per_cu,
                               double *wave_columns_per_ns);
+/* The core clock the device runs at WHILE the caller's other streams are busy: one wavefront on a stream of its own sleeps a
+ * known number of core cycles (s_sleep) for about `micros` microseconds between two readings of the constant-rate counter.
+ * The issue ceiling above is measured with idle HBM (2.39 GHz on MI355X); a scan that streams HBM runs the same cycle count at
+ * 2.05-2.16 GHz (power management), which is the whole gap between the two -- bench.py samples the clock beside back-to-back
+ * scans and reports the ceiling at that clock.  ghz_sleep: from the s_sleep count; ghz_counter: from s_memtime (a constant-rate
+ * counter on some parts: reported for reference).  Synchronizes only its own stream. */
+rf_status rf_probe_core_clock(int device, uint32_t micros, double *ghz_sleep, double *ghz_counter);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,7 @@ SYMBOLS = [
     "rf_corpus_device", "rf_many_u32", "rf_many_f64", "rf_one_u32", "rf_one_f64", "rf_many_multi_u32", "rf_many_multi_f64", "rf_topk_u32", "rf_topk_f64", "rf_topk_keys_device", "rf_topk_merge_keys_device", "rf_topk_merge_u32",
     "rf_probe_issue_rate", "rf_topk_allgather_merge",
     "rf_topk_entries_device", "rf_topk_merge_entries_device", "rf_topk_allgather_merge_entries", "rf_topk_merge_entries",
-    "rf_topk_entry_score_u32", "rf_topk_entry_score_f64",
+    "rf_topk_entry_score_u32", "rf_topk_entry_score_f64", "rf_probe_core_clock",
 ]
 
 
@@ -167,6 +167,7 @@ def lib() -> C.CDLL:
     L.rf_topk_entry_score_u32.restype = C.c_uint32
     L.rf_topk_entry_score_f64.argtypes = [C.c_uint64, C.c_int]
     L.rf_topk_entry_score_f64.restype = C.c_double
+    L.rf_probe_core_clock.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
     return L
 

@@ -2902,6 +2902,42 @@ rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, uint32_t mod
     return RF_OK;
 }
 
+rf_status rf_probe_core_clock(int device, uint32_t micros, double* ghz_sleep, double* ghz_counter)
+{
+    if (!ghz_sleep || !ghz_counter || micros == 0) {
+        set_error("rf_probe_core_clock: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("rf_probe_core_clock: cannot select device");
+        return RF_ERR_NO_DEVICE;
+    }
+    // a stream of its own (high priority: the sampler's one wavefront has to get a slot beside a scan that fills the chip)
+    hipStream_t st = nullptr;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    RF_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+    uint64_t* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, 16);
+    const uint32_t sleeps = (uint32_t)std::max<uint64_t>(1, (uint64_t)micros * 2400 / (127 * 64));  // ~micros at 2.4 GHz
+    uint64_t h[2] = {0, 0};
+    if (e == hipSuccess) e = launch_core_clock(d, sleeps, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d) (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    RF_HIP(e);
+    if (h[0] == 0) {
+        set_error("rf_probe_core_clock: the sampler did not run");
+        return RF_ERR_HIP;
+    }
+    const double ns = (double)h[0] * 10.0;  // s_memrealtime: 100 MHz
+    *ghz_sleep = (double)sleeps * 127.0 * 64.0 / ns;
+    *ghz_counter = (double)h[1] / ns;
+    return RF_OK;
+}
+
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t* scores, const uint64_t* indices, const uint32_t* counts,
                             uint32_t lists, uint32_t k, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count)
 {

@@ -161,6 +161,7 @@ hipError_t launch_merge_entries(const rf_topk_entry* in, uint32_t n, uint32_t k,
 hipError_t launch_select_count(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, uint32_t* cnt_less, uint32_t* cnt_eq, hipStream_t st);
 hipError_t launch_select_emit(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, const uint32_t* off_less, const uint32_t* off_eq, uint32_t n_less,
                               uint32_t need_eq, void* out_key, uint32_t* out_idx, hipStream_t st);
+hipError_t launch_core_clock(uint64_t* d_out, uint32_t sleeps, hipStream_t stream);  // rf_probe.hip
 hipError_t launch_probe(RawKind raw, uint32_t len1, uint32_t mode, int blocks_per_cu, int iters, double* wave_columns_per_ns);  // rf_probe.hip
 hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,
                                  hipStream_t stream);

@@ -131,4 +131,25 @@ hipError_t launch_probe(RawKind raw, uint32_t len1, uint32_t mode, int blocks_pe
     }
 }
 
+// ---- the core clock the chip actually runs at, sampled WHILE something else runs (rf_probe_core_clock) -------------------------
+// The issue ceiling above is measured with idle HBM; the scans stream HBM, and the chip then clocks lower (power management):
+// GRBM_GUI_ACTIVE / duration reads 2.39 GHz for the probes and 2.05-2.16 GHz for the streaming scans, for the SAME cycle count
+// (tools/clock_of.sh).  One wavefront on a stream of its own sleeps `sleeps` x s_sleep 127 (64 core cycles per unit) between two
+// readings of the constant-rate 100 MHz counter (s_memrealtime) and of s_memtime: bench.py launches it beside back-to-back scans.
+__global__ void core_clock_kernel(uint64_t* out, uint32_t sleeps)
+{
+    const uint64_t r0 = wall_clock64(), c0 = clock64();
+    for (uint32_t i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    const uint64_t r1 = wall_clock64(), c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[0] = r1 - r0;
+        out[1] = c1 - c0;
+    }
+}
+hipError_t launch_core_clock(uint64_t* d_out, uint32_t sleeps, hipStream_t stream)
+{
+    hipLaunchKernelGGL(core_clock_kernel, dim3(1), dim3(64), 0, stream, d_out, sleeps);
+    return hipGetLastError();
+}
+
 }  // namespace rf
