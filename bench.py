@@ -444,6 +444,8 @@ def main():
             # number of cycles per launch (tools/clock_of.sh).  Sample both clocks in this run (rf_probe_core_clock: one wavefront on
             # a stream of its own, beside ~40 queued scans / beside the probe kernel) and restate the ceiling at the scan's clock.
             try:
+                if world > 1 or force_dist:
+                    raise RuntimeError("clock sampling runs extra steps on rank 0 only: single-process runs only (the other ranks have left)")
                 import threading
 
                 g_sleep, g_cnt = ctypes.c_double(0.0), ctypes.c_double(0.0)
@@ -475,7 +477,7 @@ def main():
                     if power_w:
                         ib["package_power_w_under_scan"] = power_w
             except Exception as exc:  # a measurement aid: never fails the bench line
-                result["roofline"]["issue_bound"]["core_clock_ghz"] = {"error": str(exc)[:200]}
+                result["roofline"]["issue_bound"]["core_clock_ghz"] = {"skipped": str(exc)[:200]}
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,
