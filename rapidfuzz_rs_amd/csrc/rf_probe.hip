@@ -77,7 +77,15 @@ static hipError_t probe_run(uint32_t mode, int blocks_per_cu, int iters, double*
     e = hipMalloc((void**)&d_out, 64);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    const dim3 g(cus * blocks_per_cu), b(kWave * kWavesPerBlock);
+    // Exactly as many workgroups as stay resident at once: a grid of 8 per CU for a kernel of which 7 fit (the multi-word states)
+    // runs its last workgroup per CU alone, and the "ceiling" then reads BELOW the real kernel (round 2: configs[2] 1.15 of it).
+    int resident = blocks_per_cu;
+    if (mode != 2) {
+        int occ = 0;
+        const void* fn = mode == 0 ? reinterpret_cast<const void*>(probe_regs_kernel<State>) : reinterpret_cast<const void*>(probe_lds_kernel<State>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kWave * kWavesPerBlock, 0) == hipSuccess && occ > 0) resident = std::min(resident, occ);
+    }
+    const dim3 g(cus * resident), b(kWave * kWavesPerBlock);
     auto launch = [&](int n, uint32_t seed) {
         if (mode == 0)
             hipLaunchKernelGGL((probe_regs_kernel<State>), g, b, 0, 0, d_out, n, seed);
