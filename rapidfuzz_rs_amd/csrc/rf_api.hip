@@ -85,12 +85,15 @@ struct rf_corpus {
     bool no_prefill = false;     // stream segments: the driver pre-fills the whole result vector once
     uint8_t* d_data = nullptr;
     TileDesc* d_tiles = nullptr;
+    TileDesc* d_tiles_by_origin = nullptr;  // the same descriptors with the non-empty exact tiles ordered by their first candidate's original index (tiles_by_origin())
     uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
     size_t n_slots = 0;          // entries of d_orig: 64 per tile (exact tiles, then the views)
     // large ragged corpora return their results through a slot-ordered temporary + one gather (rf_pack.hip): built on first use
     mutable uint8_t* d_heads8 = nullptr;       // head plane: the first 8 symbols of every candidate (small-cutoff scans; built on first use)
     mutable uint32_t* d_slot_of = nullptr;     // candidate -> its slot
     mutable uint32_t* d_slot_ident = nullptr;  // slot -> slot, kPad on padding lanes (stands in for d_orig in such a launch)
+    mutable uint32_t* d_window_table = nullptr;  // the coalesced gather's table (rf_pack.hip window_table_kernel): gather_rows x gather_runs
+    mutable uint32_t gather_runs = 0, gather_rows = 0;
     uint32_t n_tiles = 0;        // exact tiles, then the virtual (one-length) views of the mixed section
     uint32_t n_exact = 0;        // tiles [0, n_exact) are exact-length tiles; [n_exact, n_tiles) virtual views (HostLayout)
     // the mixed section as the Levenshtein / LCS / OSA scans see it: one tile of 64 leftovers with per-lane lengths
@@ -777,6 +780,24 @@ void rf_host_layout_free(rf_host_layout* l)
         }                                                                                              \
     } while (0)
 
+// A second ORDER for the same tiles.  Tiles are stored ascending by length, so the tiles a launch has in flight at any moment
+// hold candidates from all over the corpus and their out[orig[slot]] stores never meet in a cache.  But the k-th tile of every
+// length holds roughly the same stretch of original indices (a stable counting sort keeps each length's candidates in original
+// order): walking the non-empty exact tiles by their first candidate's original index makes concurrently running tiles write one
+// compact window of `out`.  Only launches that do not care about tile order use it (full no-cutoff scans of the register-resident
+// Levenshtein / LCS / OSA kernels); zero-length tiles and the views keep their positions.
+static std::vector<TileDesc> tiles_by_origin(const std::vector<TileDesc>& tiles, uint32_t n_exact, const uint32_t* orig)
+{
+    std::vector<TileDesc> out = tiles;
+    uint32_t z = 0;
+    while (z < n_exact && tiles[z].len == 0) ++z;
+    std::vector<uint32_t> idx(n_exact - z);
+    for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = z + i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return orig[tiles[a].slot0] < orig[tiles[b].slot0]; });
+    for (uint32_t i = 0; i < idx.size(); ++i) out[z + i] = tiles[idx[i]];
+    return out;
+}
+
 static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, rf_corpus** out)
 {
     DeviceGuard guard(device);
@@ -822,6 +843,11 @@ static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, r
         RF_HIP_C(hipMalloc(&c->d_orig, L.orig.size() * sizeof(uint32_t)));
         RF_HIP_C(hipMemcpy(c->d_orig, L.orig.data(), L.orig.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->n_slots = L.orig.size();
+        if (L.n_exact >= 1024) {  // (small corpora fit the caches whatever the order)
+            const std::vector<TileDesc> ordered = tiles_by_origin(L.tiles, L.n_exact, L.orig.data());
+            RF_HIP_C(hipMalloc(&c->d_tiles_by_origin, ordered.size() * sizeof(TileDesc)));
+            RF_HIP_C(hipMemcpy(c->d_tiles_by_origin, ordered.data(), ordered.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        }
         c->device_bytes += L.tiles.size() * sizeof(TileDesc) + L.orig.size() * sizeof(uint32_t);
     }
     if (c->n_mixed) {
@@ -1072,10 +1098,12 @@ void rf_corpus_free(rf_corpus* c)
     DeviceGuard guard(c->device);
     if (c->d_data) (void)hipFree(c->d_data);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
+    if (c->d_tiles_by_origin) (void)hipFree(c->d_tiles_by_origin);
     if (c->d_orig) (void)hipFree(c->d_orig);
     if (c->d_heads8) (void)hipFree(c->d_heads8);
     if (c->d_slot_of) (void)hipFree(c->d_slot_of);
     if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
+    if (c->d_window_table) (void)hipFree(c->d_window_table);
     if (c->d_mixed) (void)hipFree(c->d_mixed);
     if (c->d_mixed_len) (void)hipFree(c->d_mixed_len);
     if (c->d_mixed_orig) (void)hipFree(c->d_mixed_orig);
@@ -1525,28 +1553,75 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     // The mixed section is walked through its one-length views so that every candidate has exactly one slot; a cutoff's length
     // window pre-fills the TEMPORARY with None (launch_scan: p.out, p.n slots).  RF_UNSCATTER_MIN=<candidates> moves the threshold
     // (0 = never).
+    // Full no-cutoff scans of the VALU-bound single-word kernels (Levenshtein for queries > 32, OSA): walk the tiles BY ORIGIN
+    // (tiles_by_origin()) with the workgroups dealt to them XCD by XCD (ScanParams::xcd_deal) and store straight through orig[].
+    // The tiles in flight on one XCD then write one compact window of `out`, the partial lines meet in that XCD's L2, and what is
+    // left of the scatter (64 L2 transactions per wavefront store instead of 4) hides under the kernel's arithmetic: bench.py
+    // --ragged 62.2 -> 74.7 (Levenshtein), 49.5 -> 59.5 (OSA) against the gather below, which stays for the kernels that are
+    // short of memory system instead (query <= 32: 72 -> 66, Indel: 80 -> 68 this way; profiles/ragged_result_order_r03.txt).
+    // RF_TILE_ORDER: 0 = never, 1 = by origin without the deal, 2 = default, 3 = also the kernels that lose by it.
+    static const int tile_order = [] { const char* e = getenv("RF_TILE_ORDER"); return e ? atoi(e) : 2; }();
+    const bool valu_bound = p.words == 1 && ((raw == RAW_LEV && p.len1 > 32) || raw == RAW_OSA);
+    // (Jaro: when every exact tile takes the single-word kernel -- launch_jaro splits the tiles BY POSITION where the lengths pass
+    // 64 symbols, which needs the length order)
+    const bool jaro_word_only = raw == RAW_JARO && !p.has_cutoff && p.jaro_split >= corpus->n_exact && !p.jaro_long;
+    const bool by_origin = tile_order && corpus->d_tiles_by_origin && !corpus->borrowed && !p.early && !p.prefill_none && !p.band && !p.long_words_pad &&
+                           ((valu_bound && !p.out_f64) || jaro_word_only || (tile_order >= 3 && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA))) &&
+                           p.tile_begin == 0 && p.tile_end == corpus->n_tiles;
+    if (by_origin) {
+        p.tiles = corpus->d_tiles_by_origin;
+        p.xcd_deal = tile_order >= 2 ? 1u : 0u;
+    }
     static const size_t unscatter_min = [] { const char* e = getenv("RF_UNSCATTER_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
     void* d_tmp = nullptr;
     // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 12 bytes per
     // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
     const bool wide_window = (uint64_t)(p.tile_end - p.tile_begin) * 10 >= (uint64_t)corpus->n_tiles * 3;
-    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && wide_window) {
+    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && wide_window && !by_origin) {
         {
             std::lock_guard<std::mutex> lock(corpus->scratch_mu);
-            if (!corpus->d_slot_of) {
-                uint32_t *so = nullptr, *si = nullptr;
-                RF_HIP(hipMalloc((void**)&so, corpus->n * sizeof(uint32_t)));
+            if (!corpus->d_slot_ident) {
+                // once per corpus: the slot -> slot map the scans store through, and what the gather needs -- the window table
+                // (rf_pack.hip window_gather_kernel) when the slots are few enough ascending runs, else the candidate -> slot map
+                static const bool use_windows = [] { const char* e = getenv("RF_GATHER_WINDOWS"); return !e || atoi(e) != 0; }();
+                uint32_t *so = nullptr, *si = nullptr, *list = nullptr, *table = nullptr;
+                uint32_t n_runs = 0, n_rows = 0;
+                std::vector<uint32_t> runs(kMaxGatherRuns + 2, 0u);  // [0] = count, then the run starts
                 hipError_t e1 = hipMalloc((void**)&si, corpus->n_slots * sizeof(uint32_t));
-                if (e1 == hipSuccess) e1 = hipMemsetAsync(so, 0xFF, corpus->n * sizeof(uint32_t), st);
+                if (e1 == hipSuccess && use_windows) {
+                    e1 = hipMalloc((void**)&list, runs.size() * sizeof(uint32_t));
+                    if (e1 == hipSuccess) e1 = hipMemsetAsync(list, 0, sizeof(uint32_t), st);
+                    if (e1 == hipSuccess) e1 = launch_run_starts(corpus->d_orig, (uint32_t)corpus->n_slots, list + 1, kMaxGatherRuns, list, st);
+                    if (e1 == hipSuccess) e1 = hipMemcpyAsync(runs.data(), list, (kMaxGatherRuns + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+                    if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+                    if (e1 == hipSuccess && runs[0] >= 1 && runs[0] <= kMaxGatherRuns) {
+                        n_runs = runs[0];
+                        std::sort(runs.begin() + 1, runs.begin() + 1 + n_runs);
+                        runs[1 + n_runs] = (uint32_t)corpus->n_slots;
+                        n_rows = (uint32_t)((corpus->n + kGatherWindow - 1) / kGatherWindow) + 1;
+                        e1 = hipMemcpyAsync(list, runs.data() + 1, (n_runs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+                        if (e1 == hipSuccess) e1 = hipMalloc((void**)&table, (size_t)n_rows * n_runs * sizeof(uint32_t));
+                        if (e1 == hipSuccess) e1 = launch_window_table(corpus->d_orig, list, n_runs, n_rows, table, st);
+                    }
+                }
+                if (e1 == hipSuccess && !table) {
+                    e1 = hipMalloc((void**)&so, corpus->n * sizeof(uint32_t));
+                    if (e1 == hipSuccess) e1 = hipMemsetAsync(so, 0xFF, corpus->n * sizeof(uint32_t), st);
+                }
                 if (e1 == hipSuccess) e1 = launch_slot_maps(corpus->d_orig, (uint32_t)corpus->n_slots, so, si, st);
                 if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);  // (other streams may use the maps as soon as the lock is released)
+                if (list) (void)hipFree(list);
                 if (e1 != hipSuccess) {
-                    (void)hipFree(so);
+                    if (so) (void)hipFree(so);
                     if (si) (void)hipFree(si);
+                    if (table) (void)hipFree(table);
                     if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
                     RF_HIP(e1);
                 }
                 corpus->d_slot_of = so;
+                corpus->d_window_table = table;
+                corpus->gather_runs = n_runs;
+                corpus->gather_rows = n_rows;
                 corpus->d_slot_ident = si;
             }
         }
@@ -1567,7 +1642,10 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     hipError_t e = launch_scan(raw, p, st, nullptr);
     if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
     if (d_tmp) {
-        if (e == hipSuccess) e = launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
+        if (e == hipSuccess)
+            e = corpus->d_window_table ? launch_window_gather(d_tmp, corpus->d_orig, corpus->d_window_table, corpus->gather_runs, corpus->gather_rows, d_out,
+                                                              (uint32_t)corpus->n, f64_out, st)
+                                       : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
         (void)hipFreeAsync(d_tmp, st);
     }
     if (e == hipSuccess && out_mem == RF_MEM_HOST) {
@@ -2653,6 +2731,11 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
         RF_HIP_C(hipMalloc(&c->d_orig, std::max<size_t>(1, orig.size()) * 4));
         RF_HIP_C(hipMemcpy(c->d_orig, orig.data(), orig.size() * 4, hipMemcpyHostToDevice));
         c->n_slots = orig.size();
+        if (c->n_exact >= 1024) {
+            const std::vector<TileDesc> ordered = tiles_by_origin(tiles, c->n_exact, orig.data());
+            RF_HIP_C(hipMalloc(&c->d_tiles_by_origin, ordered.size() * sizeof(TileDesc)));
+            RF_HIP_C(hipMemcpy(c->d_tiles_by_origin, ordered.data(), ordered.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        }
         c->device_bytes += tiles.size() * sizeof(TileDesc) + orig.size() * 4;
     }
     if (c->n_mixed) {

@@ -988,4 +988,12 @@ __device__ __forceinline__ TileView load_tile(const ScanParams& p, uint32_t t)
 }
 
 
+// ScanParams::xcd_deal: the workgroup's place in the deal of tiles.  Workgroups go to the 8 XCDs round-robin, so workgroup w
+// takes the place (w % 8) * (grid / 8) + w / 8 and consecutive tiles are walked by workgroups of one XCD, at about the same time:
+// with the tiles ordered by origin (rf_api.hip tiles_by_origin) their result stores meet in that XCD's L2.
+__device__ __forceinline__ uint32_t dealt_workgroup(const ScanParams& p)
+{
+    return (p.xcd_deal && !(gridDim.x & 7)) ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+}
+
 }  // namespace rf

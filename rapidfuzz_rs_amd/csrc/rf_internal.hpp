@@ -89,6 +89,7 @@ struct ScanParams {
     uint32_t wf_global;             // wf_kernel: the DP row lives in long_scratch (global) instead of LDS: queries beyond ~590 symbols
     uint32_t wf_waves;              // wavefronts per workgroup of wf_kernel (LDS rows per wavefront: (len1 + 1) * 256 B)
     uint32_t tile_step;             // >= 1: visit every tile_step-th tile of the range (the top-k bound sample)
+    uint32_t xcd_deal;              // 1: workgroup w takes the tiles of virtual workgroup (w % 8) * (grid / 8) + w / 8: consecutive tiles stay on one XCD (one L2)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
     uint32_t jaro_split;   // first EXACT tile that needs the multi-word jaro path (n_exact = none)
     uint32_t jaro_split2;  // the same for the one-length views of the mixed section, tiles [n_exact, n_tiles)
@@ -150,6 +151,13 @@ int scan_max_grid();
 // results of a ragged corpus in original order without scattered stores (rf_pack.hip): slot -> slot / candidate -> slot maps, and the gather
 hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream);
 hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t tile_bytes, uint8_t* heads, hipStream_t stream);  // rf_pack.hip: the candidates' first 8 symbols
+// the coalesced gather (rf_pack.hip "window_gather_kernel"): windows of kGatherWindow original indices, at most kMaxGatherRuns runs
+constexpr uint32_t kGatherWindow = 4096;
+constexpr uint32_t kMaxGatherRuns = 512;
+hipError_t launch_run_starts(const uint32_t* orig, uint32_t n_slots, uint32_t* list, uint32_t cap, uint32_t* count, hipStream_t stream);
+hipError_t launch_window_table(const uint32_t* orig, const uint32_t* runs, uint32_t n_runs, uint32_t n_rows, uint32_t* table, hipStream_t stream);
+hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uint32_t* table, uint32_t n_runs, uint32_t n_rows, void* out, uint32_t n, bool f64,
+                                hipStream_t stream);
 hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void* out, uint32_t n, bool f64, hipStream_t stream);
 // exact selection over a device score vector (rf_select.hip)
 hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, void* ctl, hipStream_t st);

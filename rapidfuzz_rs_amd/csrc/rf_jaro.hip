@@ -294,7 +294,7 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
     const uint32_t stride = gridDim.x * kWavesPerBlock;
     const uint32_t q4 = p.query_head;  // first four query bytes, little endian (Winkler prefix)
 
-    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
+    for (uint32_t t = p.tile_begin + dealt_workgroup(p) * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
         const TileView tv = load_tile<kUniform>(p, t);
         const uint32_t len2_orig = tv.len, len1_orig = p.len1;
         const uint32_t slot = tv.slot0 + lane;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_block_kernel(const
     const uint32_t stride = gridDim.x * kWavesPerBlock;
     const uint32_t q4 = p.query_head;
 
-    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
+    for (uint32_t t = p.tile_begin + dealt_workgroup(p) * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
         const TileView tv = load_tile<kUniform>(p, t);
         const uint32_t len2_orig = tv.len, len1_orig = p.len1;
         const uint32_t slot = tv.slot0 + lane;

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void slot_maps_kernel(const uint32_t* __restri
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
         const uint32_t o = orig[s];
         ident[s] = o == kPad ? kPad : s;
-        if (o != kPad) slot_of[o] = s;  // (one-time scattered pass, per corpus)
+        if (o != kPad && slot_of) slot_of[o] = s;  // (one-time scattered pass, per corpus; not needed when the window table serves)
     }
 }
 hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream)
@@ -271,6 +271,121 @@ hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void*
         hipLaunchKernelGGL((gather_results_kernel<uint32_t, 4>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), slot_of, static_cast<uint32_t*>(out), n, span);
     else
         hipLaunchKernelGGL((gather_results_kernel<uint32_t, 8>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), slot_of, static_cast<uint32_t*>(out), n, span);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same gather with every access coalesced.  The slots are a few RUNS in each of which the original indices ascend (one run
+// per candidate length: the packer's counting sort is stable; the views of the mixed section add their own), so the candidates
+// of one WINDOW of kGatherWindow consecutive original indices sit in one contiguous stretch of every run.  A table holds where
+// each window starts in each run (built once per corpus, by binary search: window_table_kernel); a workgroup then reads its
+// window's stretches of tmp and orig front to back, drops the values into an LDS image of the window at orig - base, and writes
+// the image out in one piece.  Same 12 bytes per candidate as gather_results_kernel, but that one issues 64 transactions per
+// wavefront load of tmp (64 candidates of 64 lengths), this one 2-3.  Corpora with more than kMaxGatherRuns runs keep the other.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void run_starts_kernel(const uint32_t* __restrict__ orig, uint32_t n_slots, uint32_t* __restrict__ list, uint32_t cap,
+                                                         uint32_t* __restrict__ count)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
+        const uint32_t o = orig[s];
+        if (o == kPad) continue;
+        const uint32_t prev = s ? orig[s - 1] : kPad;
+        if (prev == kPad || prev > o) {  // (a padding slot ends a run: inside a run padding can then only trail)
+            const uint32_t k = atomicAdd(count, 1u);
+            if (k < cap) list[k] = s;
+        }
+    }
+}
+hipError_t launch_run_starts(const uint32_t* orig, uint32_t n_slots, uint32_t* list, uint32_t cap, uint32_t* count, hipStream_t stream)
+{
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(run_starts_kernel, dim3(std::min<uint32_t>((n_slots + 255) / 256, 65536u)), dim3(256), 0, stream, orig, n_slots, list, cap, count);
+    return hipGetLastError();
+}
+
+// table[w * n_runs + r] = the first slot of run r (slots [runs[r], runs[r + 1])) whose original index is >= w * kGatherWindow;
+// padding slots count as "beyond everything", so row n_rows - 1 (w * kGatherWindow >= n) holds each run's end without its padding
+__global__ __launch_bounds__(256) void window_table_kernel(const uint32_t* __restrict__ orig, const uint32_t* __restrict__ runs, uint32_t n_runs,
+                                                           uint32_t n_rows, uint32_t* __restrict__ table)
+{
+    const uint64_t total = (uint64_t)n_rows * n_runs;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = (uint32_t)(i / n_runs), r = (uint32_t)(i % n_runs);
+        const uint64_t want = (uint64_t)w * kGatherWindow;
+        uint32_t lo = runs[r], hi = runs[r + 1];
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if ((uint64_t)orig[mid] >= want) hi = mid; else lo = mid + 1;
+        }
+        table[i] = lo;
+    }
+}
+hipError_t launch_window_table(const uint32_t* orig, const uint32_t* runs, uint32_t n_runs, uint32_t n_rows, uint32_t* table, hipStream_t stream)
+{
+    const uint64_t total = (uint64_t)n_rows * n_runs;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(window_table_kernel, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536u)), dim3(256), 0, stream, orig, runs, n_runs, n_rows, table);
+    return hipGetLastError();
+}
+
+// kRows table windows per workgroup trip: 2 for u32 results, 1 for f64 (a 32 KiB image either way: 5 workgroups per CU)
+template <class T, uint32_t kRows, uint32_t kFlight>
+__global__ __launch_bounds__(256) void window_gather_kernel(const T* __restrict__ tmp, const uint32_t* __restrict__ orig, const uint32_t* __restrict__ table,
+                                                            uint32_t n_runs, uint32_t n_rows, T* __restrict__ out, uint32_t n)
+{
+    constexpr uint32_t kSpan = kRows * kGatherWindow;
+    __shared__ T image[kSpan];
+    const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const uint32_t spans = (n + kSpan - 1) / kSpan;
+    for (uint32_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
+        const uint32_t base = sp * kSpan;
+        const uint32_t* row0 = table + (size_t)(sp * kRows) * n_runs;
+        const uint32_t* row1 = table + (size_t)min((sp + 1) * kRows, n_rows - 1) * n_runs;
+        // kFlight runs per wavefront in flight: the 2 * kFlight loads of a trip do not depend on each other
+        for (uint32_t r0 = wave * kFlight; r0 < n_runs; r0 += kFlight * (256 / kWave)) {
+            uint32_t a[kFlight], b[kFlight];
+#pragma unroll
+            for (uint32_t j = 0; j < kFlight; ++j) {
+                const bool live = r0 + j < n_runs;
+                a[j] = live ? row0[r0 + j] : 0u;
+                b[j] = live ? row1[r0 + j] : 0u;
+            }
+            uint32_t longest = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kFlight; ++j) longest = max(longest, b[j] - a[j]);
+            for (uint32_t k = lane; k < longest + lane; k += kWave) {  // (uniform trip count; k - lane < longest)
+                uint32_t o[kFlight];
+                T v[kFlight];
+#pragma unroll
+                for (uint32_t j = 0; j < kFlight; ++j) {
+                    const bool in = a[j] + k < b[j];
+                    o[j] = in ? __builtin_nontemporal_load(orig + a[j] + k) : kPad;
+                    if (in) v[j] = __builtin_nontemporal_load(tmp + a[j] + k);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kFlight; ++j)
+                    if (o[j] != kPad) image[o[j] - base] = v[j];
+            }
+        }
+        __syncthreads();
+        const uint32_t count = min(kSpan, n - base);
+        for (uint32_t i = threadIdx.x; i < count; i += 256) __builtin_nontemporal_store(image[i], out + base + i);
+        __syncthreads();
+    }
+}
+hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uint32_t* table, uint32_t n_runs, uint32_t n_rows, void* out, uint32_t n, bool f64,
+                                hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    // (measured, 100 M u32 results of 64 lengths, whole Indel step: 2 windows x 8 runs in flight 1.125 ms; 2 x 4: 1.155; 4 x 4: 1.19;
+    // 4 x 8: 1.15; 1 x 4: 1.165; 2 x 16: 1.15; 1 x 8: 1.185 -- gather_results_kernel: 1.226)
+    const uint32_t span = (f64 ? 1u : 2u) * kGatherWindow;
+    const dim3 g(std::min<uint32_t>((n + span - 1) / span, (uint32_t)scan_max_grid())), b(256);
+    if (f64)
+        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8>), g, b, 0, stream, static_cast<const double*>(tmp), orig, table, n_runs, n_rows, static_cast<double*>(out), n);
+    else
+        hipLaunchKernelGGL((window_gather_kernel<uint32_t, 2, 8>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), orig, table, n_runs, n_rows,
+                           static_cast<uint32_t*>(out), n);
     return hipGetLastError();
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
     // With a cutoff (`early`) the bet is the opposite: after 16 columns nearly every wavefront of a random
     // corpus is past the cutoff, so the prefetch goes to the NEXT TILE and a surviving wavefront fetches its
     // own next chunk on demand -- a dead tile costs 16 of its 64+ bytes per candidate in HBM traffic.
-    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
+    uint32_t t = p.tile_begin + (dealt_workgroup(p) * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
         TileView cur_tile = load_tile<kUniform>(p, t);
         uint4 cur = load_chunk(cur_tile.src + lane);  // the packed buffer carries one chunk of tail padding: always readable
@@ -351,7 +351,7 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
     if (topk) topk_refresh_bound(p, limit);
     uint32_t tiles_done = 0;
 
-    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
+    uint32_t t = p.tile_begin + (dealt_workgroup(p) * kWavesPerBlock + wave) * p.tile_step;
     if (t < p.tile_end) {
         // fetch cursor
         uint32_t ft = t, fc = 0;

@@ -1796,7 +1796,24 @@ def test_ragged_results_through_the_gather_path():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("mode", ["rows", "ragged", "ragged-gather"])
+MULTITILE_ENV = {
+    "rows": {},
+    # ragged corpora as the library runs them at this size: the VALU-bound scans (Levenshtein query > 32, OSA, Jaro) walk the tiles
+    # by origin with the XCD deal and store through orig[]; the rest store through orig[] in storage order
+    "ragged": {},
+    # ... as it runs them from 2^20 candidates on: the others through the slot-ordered temporary + the window gather
+    "ragged-gather": {"RF_UNSCATTER_MIN": "1"},
+    # every scan through the window gather / through the candidate -> slot gather (the fallback beyond 512 runs) / in storage order
+    "ragged-gather-all": {"RF_UNSCATTER_MIN": "1", "RF_TILE_ORDER": "0"},
+    "ragged-gather-slotmap": {"RF_UNSCATTER_MIN": "1", "RF_TILE_ORDER": "0", "RF_GATHER_WINDOWS": "0"},
+    "ragged-storage-order": {"RF_TILE_ORDER": "0"},
+    # every Levenshtein / LCS / OSA scan by origin, without and with the deal
+    "ragged-by-origin-all": {"RF_TILE_ORDER": "3"},
+    "ragged-by-origin-no-deal": {"RF_TILE_ORDER": "1"},
+}
+
+
+@pytest.mark.parametrize("mode", list(MULTITILE_ENV))
 def test_asm_kernels_many_tiles_per_wavefront(mode):
     """with the default grid a wavefront owns a second tile only beyond 16.8 M candidates, so the tests
     above never exercise the hand-scheduled kernels' cross-tile fetch ring, state re-arm, parked fetch cursor and mid-block tail
@@ -1807,9 +1824,7 @@ def test_asm_kernels_many_tiles_per_wavefront(mode):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RF_SCAN_BLOCKS_PER_CU_FULL="1")
-    if mode == "ragged-gather":  # the same ragged corpora with their results going through the slot-ordered temporary + gather
-        env["RF_UNSCATTER_MIN"] = "1"
+    env = dict(os.environ, RF_SCAN_BLOCKS_PER_CU_FULL="1", **MULTITILE_ENV[mode])
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "multitile_check.py"), mode.split("-")[0]], capture_output=True, text=True, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout[-4000:], r.stderr[-2000:])
     assert "FAILURES 0" in r.stdout

@@ -37,10 +37,11 @@ ADDR = [30, 31, 32, 33]
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
         ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
-        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("pad", 4)]
+        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4)]
 # SGPR map
 S_DATA, S_TILES, S_ORIG, S_PM, S_SIGMA, S_OUT = "s[8:9]", "s[10:11]", "s[12:13]", "s[14:15]", "s[16:17]", "s[18:19]"
 (S_TBEGIN, S_TEND, S_N, S_ULEN, S_UBYTES, S_LEN1, S_VS, S_VM, S_VR, S_FLIP, S_CFLIP, S_VLO) = [f"s{i}" for i in range(20, 32)]
+S_FLAGS = "s69"  # StreamAsmArgs::flags (loaded with valid_hi)
 S_VHI = "s68"  # (s32 is the ABI's stack pointer: the compiler refuses it on a clobber list)
 S_STRIDE, S_T, S_C, S_NCH, S_LEN2, S_SLOT0, S_V0 = "s33", "s34", "s35", "s36", "s37", "s38", "s39"
 S_FT, S_FC, S_FN = "s40", "s41", "s42"
@@ -232,7 +233,7 @@ def kernel(K, uniform):
     # ---- kernarg block -> s8..s32
     L += [f"s_load_dwordx8 s[8:15], %[kp], {off['data']}", f"s_load_dwordx4 s[16:19], %[kp], {off['sigma']}",
           f"s_load_dwordx8 s[20:27], %[kp], {off['tile_begin']}", f"s_load_dwordx4 s[28:31], %[kp], {off['fin_vR']}",
-          f"s_load_dword {S_VHI}, %[kp], {off['valid_hi']}", f"s_mov_b32 {S_STRIDE}, %[stride]",
+          f"s_load_dwordx2 s[68:69], %[kp], {off['valid_hi']}", f"s_mov_b32 {S_STRIDE}, %[stride]",
           # ---- stage the pattern table: thread i puts row i at row sigma(i) (the corpus stores renamed symbols)
           "v_and_b32 v1, 0x3ff, %[tid]", "s_waitcnt lgkmcnt(0)",
           f"global_load_ubyte v6, v1, {S_SIGMA}", "v_lshlrev_b32 v7, 3, v1",
@@ -243,7 +244,12 @@ def kernel(K, uniform):
           # ---- lane constants, first tile of this wavefront
           f"v_readfirstlane_b32 {T0}, v1", f"s_lshr_b32 {T0}, {T0}, 6",  # wavefront within the workgroup
           "v_and_b32 v1, 63, v1", "v_lshlrev_b32 v2, 4, v1", "v_lshlrev_b32 v3, 2, v1", "v_mov_b32 v5, 0", f"v_mov_b32 {V_KS}, {K.ks}",
-          f"s_lshl_b32 {T1}, %[wg], 2", f"s_add_u32 {T1}, {T1}, {T0}", f"s_add_u32 {S_T}, {S_TBEGIN}, {T1}",
+          # the workgroup's place in the deal of tiles: its id, or (flags bit 0, "xcd deal") (id % 8) * (grid / 8) + id / 8, so that
+          # consecutive tiles are walked by workgroups of ONE XCD (workgroups are dispatched to the 8 XCDs round-robin)
+          f"s_mov_b32 {T1}, %[wg]", f"s_bitcmp1_b32 {S_FLAGS}, 0", "s_cbranch_scc0 Lnodeal_%=",
+          f"s_and_b32 {T2}, %[wg], 7", f"s_lshr_b32 {T3}, {S_STRIDE}, 5", f"s_mul_i32 {T2}, {T2}, {T3}", f"s_lshr_b32 {T1}, %[wg], 3",
+          f"s_add_u32 {T1}, {T1}, {T2}", "Lnodeal_%=:",
+          f"s_lshl_b32 {T1}, {T1}, 2", f"s_add_u32 {T1}, {T1}, {T0}", f"s_add_u32 {S_T}, {S_TBEGIN}, {T1}",
           f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lexit_%=",
           f"s_mov_b32 {S_FT}, {S_T}", f"s_mov_b32 {S_FC}, 0", f"s_mov_b32 {S_C}, 0", f"s_mov_b32 {S_AFTER}, 0"]
     if uniform:

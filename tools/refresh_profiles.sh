@@ -6,7 +6,8 @@ set -u
 R=${1:-r03}
 mkdir -p gpurun_out/profiles
 cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
-P() { tag=$1; key=$2; shift 2; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
+# ONLY=<substring> restricts the run to the profiles / bench lines whose tag contains it (e.g. ONLY=ragged)
+P() { tag=$1; key=$2; shift 2; [[ -n "${ONLY:-}" && $tag != *$ONLY* ]] && return; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
 MATCH="rf::stream_lev64" P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
 MATCH="rf::early" P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
 P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
@@ -18,10 +19,11 @@ MATCH="rf::early" P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" -
 MATCH="rf::lev1_asm" P topk16_nocutoff "levenshtein:q64:n100000000:l64:cutNone:topk" --mode topk
 MATCH="rf::band" P c3_cutoff8_band "levenshtein:q256:n10000000:l256:cut8:many" --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
 MATCH="rf::stream_lev64" P ragged_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:ragged" --ragged
-MATCH="rf::gather" P ragged_gather "none" --ragged
+MATCH="rf::window_gather" P ragged_gather "none" --ragged --metric indel
+MATCH="rf::jaro" P ragged_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric jaro_winkler
 MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
-b() { name=$1; shift; python bench.py "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
+b() { name=$1; shift; [[ -n "${ONLY:-}" && $name != *$ONLY* ]] && return; python bench.py "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
 b c2_levenshtein
 b ragged_levenshtein --ragged
 b ragged_q32_levenshtein --ragged --query-len 32
@@ -45,6 +47,7 @@ b indel_cutoff12 --metric indel --cutoff 12
 b osa_cutoff3 --metric osa --cutoff 3
 b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
 b c3_cutoff8 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
+if [ -n "${ONLY:-}" ]; then cp gpurun_out/*_$R.txt gpurun_out/*_$R.json gpurun_out/profiles/ 2>/dev/null; ls gpurun_out/profiles | wc -l; exit 0; fi
 RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/profiles/bench_sharded_path_world1.json
 python bench.py --config c5 2>/dev/null | tail -1 > gpurun_out/profiles/bench_c5_1B_world1.json
 python tools/time_mixed.py > gpurun_out/profiles/mixed_tiles_$R.txt 2>/dev/null; RF_NO_MIXED_TILES=1 python tools/time_mixed.py >> gpurun_out/profiles/mixed_tiles_$R.txt 2>/dev/null

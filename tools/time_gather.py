@@ -25,4 +25,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(20): bc.distance_many(corpus, out=out)
 e1.record(); torch.cuda.synchronize()
-print(f"span={os.environ.get('RF_GATHER_SPAN','16384')} unroll={os.environ.get('RF_GATHER_UNROLL','8')}: {e0.elapsed_time(e1)/20:.4f} ms per step (n={n})")
+print(f"windows={os.environ.get('RF_GATHER_WINDOWS','1')} variant={os.environ.get('RF_GATHER_VARIANT','0')}: {e0.elapsed_time(e1)/20:.4f} ms per step (n={n})")
