@@ -125,6 +125,17 @@ struct rf_corpus {
     // selecting in its last workgroup and re-arming it).  Host threads sharing a stream must not interleave those sequences: the enqueue
     // section of topk_core() runs under this lock (kernels of one stream then execute in enqueue order).
     mutable std::mutex topk_enqueue_mu;
+    // The gather path's slot-ordered temporary (run_many), one per stream the corpus has been scanned on that way, kept for the
+    // corpus' lifetime: a stream-ordered hipMallocAsync / hipFreeAsync pair per call made the SUBMISSION of such a step wait for the
+    // previous step (measured: 560 us per call to submit a 575 us step; 11 us with the buffer kept).  A call's scan + gather are
+    // enqueued under gather_enqueue_mu: host threads sharing a stream must not interleave two uses of the same buffer.
+    struct GatherTmp {
+        hipStream_t stream;
+        void* ptr;
+        size_t bytes;
+    };
+    mutable std::vector<GatherTmp> gather_tmp;
+    mutable std::mutex gather_enqueue_mu;
     // u32 ("char") corpora: the stored byte is the symbol's id in THIS corpus' alphabet.  Ids 0..253 are the 254 most
     // frequent symbols, kOverflowId lumps every rarer symbol together, kAbsentId is never stored (see resolve()).
     bool wide = false;
@@ -1104,6 +1115,7 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_slot_of) (void)hipFree(c->d_slot_of);
     if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
     if (c->d_window_table) (void)hipFree(c->d_window_table);
+    for (const rf_corpus::GatherTmp& t : c->gather_tmp) (void)hipFree(t.ptr);
     if (c->d_mixed) (void)hipFree(c->d_mixed);
     if (c->d_mixed_len) (void)hipFree(c->d_mixed_len);
     if (c->d_mixed_orig) (void)hipFree(c->d_mixed_orig);
@@ -1574,6 +1586,8 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     }
     static const size_t unscatter_min = [] { const char* e = getenv("RF_UNSCATTER_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
     void* d_tmp = nullptr;
+    bool tmp_owned = false;                 // d_tmp is this call's own stream-ordered allocation
+    std::unique_lock<std::mutex> tmp_lock;  // held while a kept temporary's scan + gather are enqueued
     // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 12 bytes per
     // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
     const bool wide_window = (uint64_t)(p.tile_end - p.tile_begin) * 10 >= (uint64_t)corpus->n_tiles * 3;
@@ -1625,7 +1639,34 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
                 corpus->d_slot_ident = si;
             }
         }
-        const hipError_t ea = hipMallocAsync(&d_tmp, corpus->n_slots * elem, st);
+        // the temporary: this stream's kept buffer (grown if this call needs f64 where u32 was kept); beyond 4 streams per corpus a
+        // stream-ordered allocation for the call
+        const size_t tmp_bytes = corpus->n_slots * elem;
+        tmp_lock = std::unique_lock<std::mutex>(corpus->gather_enqueue_mu);
+        hipError_t ea = hipSuccess;
+        for (rf_corpus::GatherTmp& t : corpus->gather_tmp)
+            if (t.stream == st) {
+                if (t.bytes < tmp_bytes) {
+                    void* bigger = nullptr;
+                    ea = hipMalloc(&bigger, tmp_bytes);
+                    if (ea == hipSuccess) {
+                        (void)hipFree(t.ptr);  // (synchronizes with the work that used it)
+                        t.ptr = bigger;
+                        t.bytes = tmp_bytes;
+                    }
+                }
+                d_tmp = t.ptr;
+                break;
+            }
+        if (!d_tmp && ea == hipSuccess) {
+            if (corpus->gather_tmp.size() < 4) {
+                ea = hipMalloc(&d_tmp, tmp_bytes);
+                if (ea == hipSuccess) corpus->gather_tmp.push_back({st, d_tmp, tmp_bytes});
+            } else {
+                ea = hipMallocAsync(&d_tmp, tmp_bytes, st);
+                tmp_owned = true;
+            }
+        }
         if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
         RF_HIP(ea);
         p.out = d_tmp;
@@ -1646,7 +1687,8 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
             e = corpus->d_window_table ? launch_window_gather(d_tmp, corpus->d_orig, corpus->d_window_table, corpus->gather_runs, corpus->gather_rows, d_out,
                                                               (uint32_t)corpus->n, f64_out, st)
                                        : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
-        (void)hipFreeAsync(d_tmp, st);
+        if (tmp_owned) (void)hipFreeAsync(d_tmp, st);
+        tmp_lock.unlock();
     }
     if (e == hipSuccess && out_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
