@@ -1525,6 +1525,14 @@ static const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanPara
     return corpus->d_heads8;
 }
 
+// RF_TILE_ORDER (run_many has what it selects): 0 = never by origin, 1 = by origin without the XCD deal, 2 = default, 3 = also the
+// kernels that lose by it
+static int tile_order_knob()
+{
+    static const int v = [] { const char* e = getenv("RF_TILE_ORDER"); return e ? atoi(e) : 2; }();
+    return v;
+}
+
 static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out,
                           rf_mem out_mem, void* stream, bool f64_out)
 {
@@ -1572,7 +1580,7 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     // --ragged 62.2 -> 74.7 (Levenshtein), 49.5 -> 59.5 (OSA) against the gather below, which stays for the kernels that are
     // short of memory system instead (query <= 32: 72 -> 66, Indel: 80 -> 68 this way; profiles/ragged_result_order_r03.txt).
     // RF_TILE_ORDER: 0 = never, 1 = by origin without the deal, 2 = default, 3 = also the kernels that lose by it.
-    static const int tile_order = [] { const char* e = getenv("RF_TILE_ORDER"); return e ? atoi(e) : 2; }();
+    const int tile_order = tile_order_knob();
     const bool valu_bound = p.words == 1 && ((raw == RAW_LEV && p.len1 > 32) || raw == RAW_OSA);
     // (Jaro: when every exact tile takes the single-word kernel -- launch_jaro splits the tiles BY POSITION where the lengths pass
     // 64 symbols, which needs the length order)
@@ -1821,14 +1829,8 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
         ScanParams p = ps[i];
         p.out = d_out + (size_t)i * row_bytes;
         if (group.size() == 1) {
-            status = comparator_device_pm(cs[i], corpus->device, &p.pm);
-            if (status != RF_OK) break;
-            if (const size_t scratch = launch_scratch_bytes(p, raws[i])) {
-                e = hipMallocAsync((void**)&p.long_scratch, scratch, st);
-                if (e != hipSuccess) break;
-            }
-            e = launch_scan(raws[i], p, st, nullptr);
-            if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
+            // (through run_many: a general corpus' results take the cheapest way into original order there)
+            status = run_many(cs_in[i], corpus, op, args, p.out, RF_MEM_DEVICE, stream, f64_out);
         } else {
             p.early = 0;  // the fused kernel always runs every column of every tile (values are the same either way)
             p.tile_begin = 0, p.tile_end = p.n_tiles, p.prefill_none = 0;
@@ -1838,6 +1840,15 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
                 status = comparator_device_pm(cs[group[k]], corpus->device, &p.multi_pm[k]);
             }
             if (status != RF_OK) break;
+            // general corpora, LCS family: the tiles are walked by origin with the XCD deal (run_many has the why).  20 M ragged
+            // candidates x 4 queries: Indel 1.06 -> 0.89 ms.  Not the fused Levenshtein kernels: 1.19 -> 1.68 ms -- their code (4
+            // recurrences x 16 tail entries) is large, and by origin the wavefronts of a CU run different tail lengths at the same
+            // time where the storage order keeps them on the same path (instruction cache); their scatter already hides under 4
+            // queries' arithmetic.
+            if (raws[i] == RAW_LCS && tile_order_knob() && corpus->d_tiles_by_origin && !corpus->borrowed) {
+                p.tiles = corpus->d_tiles_by_origin;
+                p.xcd_deal = tile_order_knob() >= 2 ? 1u : 0u;
+            }
             e = launch_scan_multi(raws[i], p.len1 <= 32, p, st);
         }
     }

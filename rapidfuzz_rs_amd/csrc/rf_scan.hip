@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_multi_kernel(const
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t stride = gridDim.x * kWavesPerBlock;
-    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
+    uint32_t t = dealt_workgroup(p) * kWavesPerBlock + wave;
     if (t >= p.n_tiles) return;
     TileView cur_tile = load_tile<kUniform>(p, t);
     uint4 cur = load_chunk(cur_tile.src + lane);

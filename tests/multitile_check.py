@@ -76,6 +76,23 @@ def check(tag, corpus, host=None, ragged=None):
             failures += len(bad_ops)
 
 
+    # four queries fused per pass (scan_multi_kernel): 64-bit and 32-bit Levenshtein, LCS-family
+    for metric, len1 in (("levenshtein", 64), ("levenshtein", 20), ("indel", 64)):
+        base = QUERIES[len1]
+        qs = [base, base[::-1], base[3:] + base[:3], base[: len1 // 2] + base[: len1 - len1 // 2]]
+        cs = [GPU[metric].BatchComparator(q) for q in qs]
+        got = GPU[metric].BatchComparator.many_multi(cs, N.OP_DISTANCE, corpus)
+        bad_rows = []
+        for j, q in enumerate(qs):
+            ob = ORA[metric].BatchComparator(q)
+            exp = ob.rows(N.OP_DISTANCE, host, nthreads=8) if host is not None else ob.many(N.OP_DISTANCE, ragged[0], ragged[1], nthreads=8)
+            bad = same(got[j], exp)
+            if len(bad):
+                bad_rows.append((j, len(bad), bad[:4].tolist()))
+        print(f"{tag} len1={len1} {metric} x4 fused: {'ok' if not bad_rows else bad_rows}", flush=True)
+        failures += len(bad_rows)
+
+
 rng = np.random.default_rng(20260929)
 QUERIES = {64: bytes(rng.integers(48, 123, size=64, dtype=np.uint8)), 20: bytes(rng.integers(97, 123, size=20, dtype=np.uint8))}
 n = int(os.environ.get("RF_MULTITILE_N", "300007"))
