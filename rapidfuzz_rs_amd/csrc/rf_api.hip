@@ -108,6 +108,7 @@ struct rf_corpus {
     std::vector<uint32_t> lengths;  // the distinct candidate lengths (host copy, ascending)
     std::vector<uint32_t> length_first_tile;  // first tile of each distinct length
     uint8_t sigma[256];           // symbol renaming: the packed corpus stores sigma[c] for candidate byte c
+    float sym_freq[256] = {0};    // relative frequency of candidate byte c (from the histogram sigma is made of; all zero = unknown)
     uint8_t* d_sigma = nullptr;   // device copy
     // top-k scratch, one per stream the corpus has been searched on: [candidate keys by way | root table | bound | counters].  The
     // kernels leave bound/counters re-armed, so a top-k call is two launches (one under a tight cutoff) and no
@@ -136,6 +137,14 @@ struct rf_corpus {
     };
     mutable std::vector<GatherTmp> gather_tmp;
     mutable std::mutex gather_enqueue_mu;
+    // head_filter_kernel's tile lists (rf_scan.hip), one per stream such a cutoff scan has run on: 8 bytes per tile.  The filter
+    // pass and the scan that walks its list are enqueued under filter_enqueue_mu (host threads sharing a stream).
+    struct TileList {
+        hipStream_t stream;
+        uint32_t* ptr;
+    };
+    mutable std::vector<TileList> tile_lists;
+    mutable std::mutex filter_enqueue_mu;
     // u32 ("char") corpora: the stored byte is the symbol's id in THIS corpus' alphabet.  Ids 0..253 are the 254 most
     // frequent symbols, kOverflowId lumps every rarer symbol together, kAbsentId is never stored (see resolve()).
     bool wide = false;
@@ -158,6 +167,12 @@ static std::atomic<uint64_t> g_corpus_uid{1};
 // gather -- ASCII classes collide systematically ('A'/'a', digits/'P'..'Y').  Renaming symbols by frequency rank
 // gives the 32 most frequent symbols of THIS corpus 32 distinct banks and pairs the rest with them one by one.
 // The packed corpus stores sigma(c); the kernels stage PM row c at LDS row sigma(c); nothing else changes.
+static void symbol_frequencies(const uint64_t* hist, float* freq)
+{
+    uint64_t total = 0;
+    for (int c = 0; c < 256; ++c) total += hist[c];
+    for (int c = 0; c < 256; ++c) freq[c] = total ? (float)((double)hist[c] / (double)total) : 0.0f;
+}
 static void make_sigma(const uint64_t* hist, uint8_t* sigma)
 {
     static const bool disabled = getenv("RF_NO_RENAME") != nullptr;  // tuning / A-B knob
@@ -537,6 +552,7 @@ struct HostLayout {
     uint32_t max_len = 0;
     bool identity = true;          // a single length bucket: slot i is candidate i
     uint8_t sigma[256];            // symbol renaming applied to the payload
+    float sym_freq[256] = {0};     // relative symbol frequencies (rf_corpus::sym_freq)
 };
 
 struct PhaseTimer {  // RF_PACK_TIMING=1 prints where rf_corpus_pack spends its time
@@ -648,6 +664,7 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
         for (uint64_t b0 = first; b0 < total; b0 += block * stride)
             for (uint64_t b = b0, e = std::min(total, b0 + block); b < e; ++b) hist[bytes[b]]++;
         make_sigma(hist, L->sigma);
+        symbol_frequencies(hist, L->sym_freq);
     }
     timer.lap("tiles + symbol histogram");
 
@@ -802,10 +819,10 @@ static std::vector<TileDesc> tiles_by_origin(const std::vector<TileDesc>& tiles,
     std::vector<TileDesc> out = tiles;
     uint32_t z = 0;
     while (z < n_exact && tiles[z].len == 0) ++z;
-    std::vector<uint32_t> idx(n_exact - z);
-    for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = z + i;
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return orig[tiles[a].slot0] < orig[tiles[b].slot0]; });
-    for (uint32_t i = 0; i < idx.size(); ++i) out[z + i] = tiles[idx[i]];
+    std::vector<uint64_t> key(n_exact - z);  // (first original index, position): one flat sort, ties keep the storage order
+    for (uint32_t i = 0; i < key.size(); ++i) key[i] = (uint64_t)orig[tiles[z + i].slot0] << 32 | (z + i);
+    std::sort(key.begin(), key.end());
+    for (uint32_t i = 0; i < key.size(); ++i) out[z + i] = tiles[(uint32_t)key[i]];
     return out;
 }
 
@@ -843,6 +860,7 @@ static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, r
     c->device_bytes = L.packed_size;
     c->data_bytes = L.packed_size;
     std::memcpy(c->sigma, L.sigma, 256);
+    std::memcpy(c->sym_freq, L.sym_freq, sizeof(c->sym_freq));
     RF_HIP_C(hipMalloc(&c->d_sigma, 256));
     RF_HIP_C(hipMemcpy(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice));
     if (L.identity) {  // one length bucket in original order: tiles are addressed arithmetically
@@ -1089,6 +1107,7 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
         (void)hipFree(d_hist);
         RF_HIP_C(e);
         make_sigma(hist, c->sigma);
+        symbol_frequencies(hist, c->sym_freq);
         RF_HIP_C(hipMemcpyAsync(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice, st));
     }
     if (data_bytes) RF_HIP_C(launch_pack_rows((const uint8_t*)d_rows, n, (uint32_t)len, stride, c->d_data, c->n_tiles, c->d_sigma, st));
@@ -1116,6 +1135,7 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
     if (c->d_window_table) (void)hipFree(c->d_window_table);
     for (const rf_corpus::GatherTmp& t : c->gather_tmp) (void)hipFree(t.ptr);
+    for (const rf_corpus::TileList& t : c->tile_lists) (void)hipFree(t.ptr);
     if (c->d_mixed) (void)hipFree(c->d_mixed);
     if (c->d_mixed_len) (void)hipFree(c->d_mixed_len);
     if (c->d_mixed_orig) (void)hipFree(c->d_mixed_orig);
@@ -1510,7 +1530,7 @@ static const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanPara
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);
     if (!corpus->d_heads8) {
         uint8_t* h = nullptr;
-        if (hipMalloc((void**)&h, (size_t)corpus->n_tiles * kWave * 8) != hipSuccess) {
+        if (hipMalloc((void**)&h, ((size_t)corpus->n_tiles + 1) * kWave * 8) != hipSuccess) {  // (+ one row: head_filter_kernel reads tiles in pairs)
             (void)hipGetLastError();
             return nullptr;
         }
@@ -1523,6 +1543,80 @@ static const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanPara
         corpus->d_heads8 = h;
     }
     return corpus->d_heads8;
+}
+
+// The BAND PREFILTER of the head-plane cutoff scans (rf_scan.hip early_lean_body has the kernel side and the proof): with at most
+// K edits allowed, at least 8 - K of a candidate's first 8 symbols must equal a query symbol within K positions of their own.
+// Decides whether a launch uses it: K = the largest raw distance that passes the cutoff (the same arithmetic as may_pass() on
+// the device, over every raw value a 64-symbol pair can have) must be <= 3, and by the corpus' symbol frequencies a tile of 64
+// random candidates must be unlikely to have a lane that passes the filter -- otherwise (small alphabets, repetitive queries) the
+// filter is 30 instructions per tile spent for nothing.  RF_BAND_FILTER=0 / 1 forces it off / on wherever K <= 3.
+static void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, ScanParams* p)
+{
+    p->head_need = 0;
+    if (!p->heads8 || !p->early || p->words != 1) return;
+    static const int forced = [] { const char* e = getenv("RF_BAND_FILTER"); return e ? atoi(e) : -1; }();
+    if (forced == 0) return;
+    const uint32_t len2 = corpus->uniform_len, len1 = p->len1;
+    const uint32_t Sv = len1 + len2, Mv = std::max(len1, len2);
+    int K = -1;
+    for (uint32_t raw = 0; raw <= Mv; ++raw) {
+        bool pass;
+        if (!f64_out) {
+            const uint32_t v = (uint32_t)p->fin_vS * Sv + (uint32_t)p->fin_vM * Mv + (uint32_t)p->fin_vR * raw;
+            pass = (v ^ p->fin_flip) <= p->fin_cflip;
+        } else {
+            const uint32_t dist = (uint32_t)p->fin_dS * Sv + (uint32_t)p->fin_dM * Mv + (uint32_t)p->fin_dR * raw;
+            const uint32_t mx = (uint32_t)p->fin_mS * Sv + (uint32_t)p->fin_mM * Mv;
+            const double nd = mx == 0 ? 0.0 : (double)dist / (double)mx;
+            pass = op == RF_OP_NORMALIZED_DISTANCE ? nd <= p->cutoff_f64 : (1.0 - nd) >= p->cutoff_f64;
+        }
+        if (pass) K = (int)raw;
+    }
+    if (K < 0 || K > 3) return;
+    const uint32_t need = 8u - (uint32_t)K;
+    if (forced != 1) {
+        // P(symbol i of a random candidate has a partner in the band) from the symbol frequencies, then the distribution of the
+        // number of such symbols among 8 (independent positions), then a tile of 64 lanes
+        bool known = false;
+        for (int ch = 0; ch < 256; ++ch) known = known || corpus->sym_freq[ch] > 0.0f;
+        if (!known) return;
+        double dist[9] = {1.0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 8; ++i) {
+            double pi = 0.0;
+            for (int j = std::max(0, i - K); j <= i + K && j < (int)c->s1.size(); ++j) {
+                bool seen = false;  // (a symbol that occurs twice in the band counts once)
+                for (int j2 = std::max(0, i - K); j2 < j; ++j2) seen = seen || c->s1[j2] == c->s1[j];
+                if (!seen) pi += corpus->sym_freq[c->s1[j]];
+            }
+            pi = std::min(1.0, pi);
+            for (int m = i + 1; m >= 1; --m) dist[m] = dist[m] * (1.0 - pi) + dist[m - 1] * pi;
+            dist[0] *= 1.0 - pi;
+        }
+        double lane = 0.0;
+        for (uint32_t m = need; m <= 8; ++m) lane += dist[m];
+        const double tile = 1.0 - std::pow(1.0 - lane, 64.0);
+        if (tile > 0.35) return;
+    }
+    p->head_need = need;
+    p->head_k = (uint32_t)K;
+}
+
+// this stream's tile list for head_filter_kernel (the caller holds corpus->filter_enqueue_mu); nullptr = none to be had, the
+// scan then filters inside the cutoff kernel
+static uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
+{
+    for (const rf_corpus::TileList& t : corpus->tile_lists)
+        if (t.stream == st) return t.ptr;
+    if (corpus->tile_lists.size() >= 4) return nullptr;
+    uint32_t* ptr = nullptr;
+    // (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the packed list)
+    if (hipMalloc((void**)&ptr, (2 * (size_t)corpus->n_tiles + 5 * 16384 + 8) * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    corpus->tile_lists.push_back({st, ptr});
+    return ptr;
 }
 
 // RF_TILE_ORDER (run_many has what it selects): 0 = never by origin, 1 = by origin without the XCD deal, 2 = default, 3 = also the
@@ -1563,6 +1657,7 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
 
     hipStream_t st = (hipStream_t)stream;
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
+    plan_band_filter(c, corpus, op, f64_out, &p);
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     const size_t out_bytes = corpus->n * elem;
     void* d_out = out;
@@ -1688,7 +1783,13 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
         if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
         RF_HIP(ea);
     }
+    std::unique_lock<std::mutex> filter_lock;  // held while a filter pass and the scan over its list are enqueued
+    if (p.head_need) {
+        filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
+        p.tile_list_buf = corpus_tile_list(corpus, st);
+    }
     hipError_t e = launch_scan(raw, p, st, nullptr);
+    if (filter_lock.owns_lock()) filter_lock.unlock();
     if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
     if (d_tmp) {
         if (e == hipSuccess)
@@ -1919,6 +2020,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     s = comparator_device_pm(c, corpus->device, &p.pm);
     if (s != RF_OK) return s;
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
+    plan_band_filter(c, corpus, op, false, &p);
     // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list
     rf_corpus::TopkScratch sc;
     {
@@ -1961,6 +2063,11 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
     p.out = d_all;
     std::lock_guard<std::mutex> enqueue_lock(owner->topk_enqueue_mu);
+    std::unique_lock<std::mutex> filter_lock;
+    if (p.head_need) {
+        filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
+        p.tile_list_buf = corpus_tile_list(corpus, st);
+    }
     hipError_t e = hipSuccess;
     // Sample pass: the top-k of ~1000 evenly spaced tiles costs 0.1 % of the scan and its k-th best key is a valid
     // launch-wide bound from the first tile on -- without it every wavefront pays k ln(n_wave / k) list insertions to

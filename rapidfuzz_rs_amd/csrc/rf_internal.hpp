@@ -89,6 +89,13 @@ struct ScanParams {
     uint32_t wf_global;             // wf_kernel: the DP row lives in long_scratch (global) instead of LDS: queries beyond ~590 symbols
     uint32_t wf_waves;              // wavefronts per workgroup of wf_kernel (LDS rows per wavefront: (len1 + 1) * 256 B)
     uint32_t tile_step;             // >= 1: visit every tile_step-th tile of the range (the top-k bound sample)
+    uint32_t head_need, head_k;     // head-plane cutoff scans: >= head_need of the first 8 symbols must have a partner within head_k positions (0 = filter off)
+    // head_filter_kernel's product: the tiles a cutoff scan still has to walk ([0] = their number, then the tiles); tile_list_buf is
+    // the scratch the launcher may use for it (n_tiles + 1 words), tile_list / tile_list_count what early_lean_kernel reads
+    uint32_t* tile_list_buf;
+    const uint32_t* tile_list;
+    const uint32_t* tile_list_count;
+    uint32_t exp_flags;             // measurement switches (bit 0: RF_EXP_NOHBM on the head-plane scans)
     uint32_t xcd_deal;              // 1: workgroup w takes the tiles of virtual workgroup (w % 8) * (grid / 8) + w / 8: consecutive tiles stay on one XCD (one L2)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
     uint32_t jaro_split;   // first EXACT tile that needs the multi-word jaro path (n_exact = none)

@@ -163,18 +163,161 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel(const ScanP
 // candidate, tile t's row at t * 512 B) instead of their first 16-byte chunk rows: a scan under a cutoff <= 5 decides nearly every
 // tile from <= 8 columns, so the bytes it has to move halve (and the look itself runs on 32-bit words: the narrow look below).
 // A surviving tile fetches its first chunk row from the ordinary payload and starts over.
+// the band prefilter's table (below): per STORED symbol, bit i = "the symbol occurs in query[i - K .. i + K]"
+__device__ __forceinline__ void build_band_table(const ScanParams& p, uint8_t* lds_band)
+{
+    const uint32_t K = p.head_k;
+    for (int c = threadIdx.x; c < 256; c += kWave * kWavesPerBlock) {
+        const uint32_t row = (uint32_t)p.pm[(size_t)c * p.words];  // query positions 0..31 hold every band of the first 8 columns (K <= 3)
+        uint32_t bits = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t lo = i > K ? i - K : 0u, hi = i + K;  // rows lo..hi
+            const uint32_t mask = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+            bits |= (row & mask) ? 1u << i : 0u;
+        }
+        lds_band[p.sigma[c]] = (uint8_t)bits;
+    }
+}
+__device__ __forceinline__ uint32_t band_hits(const uint8_t* lds_band, uint32_t lo, uint32_t hi)
+{
+    uint32_t hit = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint32_t sym = ((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xFFu;
+        hit |= (uint32_t)lds_band[sym] & (1u << i);
+    }
+    return (uint32_t)__popc(hit);
+}
+
+// The band prefilter as a pass of its own (full scans, tile_step == 1): a streaming kernel over the head plane that does nothing
+// else -- 16 bytes per lane per load (TWO candidates; a wavefront takes a PAIR of tiles per trip: lanes 0..31 hold tile t, lanes
+// 32..63 tile t + 1), two loads in flight, ~45 instructions per pair -- writes None for the tiles it decides and leaves the others
+// in ITS OWN segment of a list (no atomics: one shared counter took 12 ns per survivor, 0.4 ms of a 0.5 ms pass);
+// tile_list_compact_kernel packs the segments, and the cutoff scan proper (early_lean_kernel) walks the packed list.
+// Inside the cutoff kernel the same filter was held to 4.2-4.6 TB/s of head plane by that kernel's loop (25 scalar instructions
+// and 12 branches per tile around it, one tile per trip); a plain streaming read of the plane in 16-byte-per-lane rows moves
+// 6.7 TB/s (tools/membw.hip).
+// buf: [0] packed count | G per-wavefront counts | G offsets | G segments of `cap` tiles | the packed list     (G = wavefronts of the filter launch)
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
+{
+    __shared__ uint8_t lds_band[256];
+    build_band_table(p, lds_band);
+    __syncthreads();
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2, stride = gridDim.x * kWavesPerBlock;
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
+    uint32_t* seg = buf + 1 + 2 * (size_t)stride + (size_t)gw * cap;
+    uint32_t kept = 0;
+    uint32_t pr = gw;
+    if (pr < pairs) {
+        // (the plane is allocated with one row of slack: the second half of the last pair of an odd tile count is readable)
+        const uint8_t* base = p.heads8 + (size_t)lane * sizeof(v4u);
+        auto load_pair = [&](uint32_t q) { return __builtin_nontemporal_load(reinterpret_cast<const v4u*>(base + ((uint64_t)p.tile_begin + 2ull * q) * (kWave * 8))); };
+        v4u cur = load_pair(pr);
+        v4u ahead = load_pair(pr + stride < pairs ? pr + stride : pr);
+        const uint32_t need = p.head_need;
+        while (true) {
+            const uint32_t pr_next = pr + stride;
+            const v4u ahead2 = load_pair(pr_next + stride < pairs ? pr_next + stride : pr);
+            const uint32_t t0 = p.tile_begin + 2 * pr;
+            const bool pass = band_hits(lds_band, cur.x, cur.y) >= need || band_hits(lds_band, cur.z, cur.w) >= need;
+            const uint64_t m = __ballot(pass);
+            const bool alive0 = (uint32_t)m != 0, alive1 = (uint32_t)(m >> 32) != 0 && t0 + 1 < p.tile_end;
+            if (p.out) {  // the decided tiles' results (this lane: candidates idx and idx + 1)
+                const bool mine_dead = lane < 32 ? !alive0 : (!alive1 && t0 + 1 < p.tile_end);
+                const uint32_t idx = t0 * kWave + 2 * lane;
+                if (mine_dead) {
+                    if (!p.out_f64 && idx + 1 < p.n) {  // (idx is even: one aligned 8-byte store, 512 B per wavefront)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.out) + idx) = make_uint2(RF_NONE_U32, RF_NONE_U32);
+                    } else {
+                        if (idx < p.n) emit_none(p, idx);
+                        if (idx + 1 < p.n) emit_none(p, idx + 1);
+                    }
+                }
+            }
+            if (alive0) {
+                if (lane == 0) seg[kept] = t0;
+                ++kept;
+            }
+            if (alive1) {
+                if (lane == 0) seg[kept] = t0 + 1;
+                ++kept;
+            }
+            if (pr_next >= pairs) break;
+            pr = pr_next;
+            cur = ahead;
+            ahead = ahead2;
+        }
+    }
+    if (lane == 0) buf[1 + gw] = kept;
+}
+// packing the segments: one workgroup turns the G per-wavefront counts into offsets (G <= 16 K: 16 per thread, loaded at once),
+// then one thread per segment copies its few tiles behind its predecessors'.  (First version: one workgroup doing both, every
+// thread walking 16 segments one dependent load after another: 123 us.)
+__global__ __launch_bounds__(1024) void tile_list_offsets_kernel(uint32_t* __restrict__ buf, uint32_t G)
+{
+    __shared__ uint32_t sums[1024];
+    constexpr uint32_t kPer = 16;  // G <= 16384
+    const uint32_t first = threadIdx.x * kPer;
+    uint32_t c[kPer], mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) c[j] = first + j < G ? buf[1 + first + j] : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) mine += c[j];
+    sums[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= d ? sums[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t at = sums[threadIdx.x] - mine;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+        if (first + j < G) buf[1 + G + first + j] = at;
+        at += c[j];
+    }
+    if (threadIdx.x == 1023) buf[0] = sums[1023];
+}
+__global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G) return;
+    const uint32_t n = buf[1 + s], at = buf[1 + G + s];
+    const uint32_t* seg = buf + 1 + 2 * (size_t)G + (size_t)s * cap;
+    uint32_t* packed = buf + 1 + 2 * (size_t)G + (size_t)G * cap;
+    for (uint32_t j = 0; j < n; ++j) packed[at + j] = seg[j];
+}
+
+// THE BAND PREFILTER (kHead8, p.head_need != 0: cutoffs that allow at most K = p.head_k <= 3 edits).  Any alignment of cost <= K
+// stays within K of the main diagonal, and every candidate symbol it does not MATCH costs at least one edit (a substitution or an
+// insertion; an OSA transposition costs one for two symbols that both equal a query symbol one off their path position, which is
+// still within K of their own).  So a candidate within the cutoff has at least 8 - K symbols among its first 8 that equal a query
+// symbol at a position within K of their own -- a necessary condition that costs 3 instructions per symbol: a 256-byte LDS table
+// holds, per stored symbol, bit i = "occurs in query[i - K .. i + K]" (from the table rows the kernel loads anyway), the lane ORs
+// (table[c_i] & (1 << i)) over its 8 head symbols and counts the bits.  A tile in which no lane reaches 8 - K is None as a whole
+// without running the recurrence (which is 14 instructions per column for 6 columns at cutoff 3); any other tile takes the first
+// look as before, all lanes, so no value depends on the filter.  The host switches it on per launch from the corpus' symbol
+// frequencies (plan_band_filter, rf_api.hip): on a 62-symbol alphabet 6 % of the tiles pass at K = 3.
 template <class State, int kFirst, bool kHead8 = false>
-__device__ __forceinline__ void early_lean_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave])
+__device__ __forceinline__ void early_lean_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave], uint8_t* lds_band = nullptr)
 {
     constexpr int W = State::kWords;
     static_assert(W == 1 && kFirst >= 4 && kFirst <= 16, "single-word states, first look inside the first chunk");
     for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock)
         lds_pm[(uint32_t)p.sigma[i / W] * W + i % W] = (typename State::Word)p.pm[i];
+    const bool band_filter = kHead8 && p.head_need != 0;
+    if constexpr (kHead8) {
+        if (band_filter) build_band_table(p, lds_band);
+    }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
-    const uint32_t stride = gridDim.x * kWavesPerBlock * p.tile_step;
     const bool topk = p.topk_k != 0;
     WaveTopK best;
     best.init();
@@ -190,15 +333,20 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
     constexpr bool kNarrowLook = kWide && kFirst < 16;
     const int32_t look_row = (int32_t)kFirst + (int32_t)len1 - (int32_t)len2;
     const bool narrow = kNarrowLook && p.narrow_look && look_row >= 1 && look_row <= 32;
-    uint32_t t = p.tile_begin + (blockIdx.x * kWavesPerBlock + wave) * p.tile_step;
-    if (t < p.tile_end) {
+    // the tiles of this launch: the range [tile_begin, tile_end) in steps of tile_step, or (after head_filter_kernel) a list
+    const uint32_t n_trips = p.tile_list ? *p.tile_list_count : (p.tile_end > p.tile_begin ? (p.tile_end - p.tile_begin + p.tile_step - 1) / p.tile_step : 0u);
+    const uint32_t trip_stride = gridDim.x * kWavesPerBlock;
+    auto tile_of = [&](uint32_t k) { return p.tile_list ? p.tile_list[k] : p.tile_begin + k * p.tile_step; };
+    uint32_t trip = blockIdx.x * kWavesPerBlock + wave;
+    if (trip < n_trips) {
+        uint32_t t = tile_of(trip);
         static_assert(!kHead8 || kFirst <= 8, "the head plane holds 8 symbols per candidate");
         // the state the first look runs on, and its table row pitch in its words
         using Look = typename std::conditional<std::is_same<State, LevState<1>>::value, Lev32State,
                                                typename std::conditional<std::is_same<State, OsaState<1>>::value, Osa32State, State>::type>::type;
         constexpr int kLookPitch = kWide ? 2 : 1;
         const uint8_t* base = kHead8 ? p.heads8 + (size_t)lane * sizeof(uint2) : p.data + (size_t)lane * sizeof(uint4);
-        const uint32_t row_pitch = kHead8 ? (uint32_t)(kWave * sizeof(uint2)) : p.uniform_tile_bytes;
+        const uint32_t row_pitch = kHead8 ? (p.exp_flags & 1u ? 0u : (uint32_t)(kWave * sizeof(uint2))) : p.uniform_tile_bytes;  // (exp_flags bit 0: RF_EXP_NOHBM)
         auto load_row = [&](uint32_t tile) -> uint4 {
             if constexpr (kHead8) {
                 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
@@ -209,21 +357,37 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
             }
         };
         uint4 cur = load_row(t);
+        // The head plane's rows are 512 B per wavefront: with ONE row in flight per wavefront the chip has 8 x 4 x 256 x 512 B = 4 MB
+        // on its way, which at ~1 us of loaded HBM latency is 4 TB/s -- exactly where the head-plane scans stood once the band
+        // prefilter had made a dead tile cheap.  They keep TWO rows in flight (the next tile's and the one after).
+        uint4 ahead_kept = kHead8 ? load_row(trip + trip_stride < n_trips ? tile_of(trip + trip_stride) : t) : cur;
         while (true) {
-            const uint32_t t_next = t + stride;
-            const bool has_next = t_next < p.tile_end;
+            const uint32_t trip_next = trip + trip_stride;
+            const bool has_next = trip_next < n_trips;
+            const uint32_t t_next = has_next ? tile_of(trip_next) : t;
             // the first chunk row of the next tile (past the last tile: a cached re-read of this one)
-            const uint4 ahead = load_row(has_next ? t_next : t);
+            uint4 ahead;
+            if constexpr (kHead8) {
+                ahead = ahead_kept;
+                const uint32_t trip_next2 = trip_next + trip_stride;
+                ahead_kept = load_row(has_next && trip_next2 < n_trips ? tile_of(trip_next2) : t);
+            } else {
+                ahead = load_row(t_next);
+            }
             const uint32_t idx = t * kWave + lane;
             const bool valid = idx < p.n;
             State st;
             st.init();
             bool dead;
             if constexpr (kHead8) {
-                Look lo;
-                lo.init();
-                process_chunk_full<Look, 0, kFirst, kLookPitch>(lo, reinterpret_cast<const typename Look::Word*>(lds_pm), cur);
-                dead = __ballot(may_pass(p, fin, lo.bound_first(len1, kFirst, len2))) == 0;
+                dead = false;
+                if (band_filter) dead = __ballot(band_hits(lds_band, cur.x, cur.y) >= p.head_need) == 0;
+                if (!dead) {
+                    Look lo;
+                    lo.init();
+                    process_chunk_full<Look, 0, kFirst, kLookPitch>(lo, reinterpret_cast<const typename Look::Word*>(lds_pm), cur);
+                    dead = __ballot(may_pass(p, fin, lo.bound_first(len1, kFirst, len2))) == 0;
+                }
                 if (!dead) {  // rare: the whole first chunk row from the tile itself, and the full-width state from column 0
                     cur = load_chunk(reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes) + lane);
                     process_chunk_full<State, 0, kFirst>(st, lds_pm, cur);
@@ -285,6 +449,7 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
                 }
             }
             if (!has_next) break;
+            trip = trip_next;
             t = t_next;
             cur = ahead;
         }
@@ -303,7 +468,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void early_head8_kernel(cons
 {
     __shared__ typename State::Word lds_pm[256 * State::kWords];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
-    early_lean_body<State, kFirst, true>(p, lds_pm, lds_topk);
+    __shared__ uint8_t lds_band[256];
+    early_lean_body<State, kFirst, true>(p, lds_pm, lds_topk, lds_band);
 }
 
 template <class State, bool kUniform, int kFirst>
@@ -665,6 +831,9 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             static const bool narrow_look = [] { const char* e = getenv("RF_NARROW_LOOK"); return !e || atoi(e) != 0; }();  // A/B: the 32-bit first look of early_lean_kernel
             ScanParams pn = p;
             pn.narrow_look = narrow_look ? 1u : 0u;
+            static const bool two_pass = [] { const char* e = getenv("RF_HEAD_TWO_PASS"); return !e || atoi(e) != 0; }();  // A/B: head_filter_kernel + list
+            static const bool exp_nohbm = getenv("RF_EXP_NOHBM") != nullptr;  // measurement: every tile reads tile 0's head row (results are wrong on purpose)
+            pn.exp_flags = exp_nohbm ? 1u : 0u;
             if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value ||
                           std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value) {
                 if (early_static) {
@@ -676,6 +845,21 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             if constexpr (J <= 8 && (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value)) { \
                 const int32_t look_row = J + (int32_t)p.len1 - (int32_t)p.uniform_len;      \
                 if (p.heads8 && (std::is_same<State, Lev32State>::value || (look_row >= 1 && look_row <= 32))) { \
+                    if (two_pass && p.head_need && p.tile_step == 1 && p.tile_list_buf && p.tile_end > p.tile_begin) { \
+                        /* the band prefilter as a streaming pass of its own, then the cutoff scan over the tiles it left */ \
+                        const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
+                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)device_cus() * 16u); \
+                        const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
+                        hipLaunchKernelGGL(head_filter_kernel, dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
+                        hipLaunchKernelGGL(tile_list_offsets_kernel, dim3(1), dim3(1024), 0, stream, p.tile_list_buf, G); \
+                        hipLaunchKernelGGL(tile_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap); \
+                        ScanParams p2 = pn;                                                \
+                        p2.heads8 = nullptr;                                               \
+                        p2.tile_list = p.tile_list_buf + 1 + 2 * (size_t)G + (size_t)G * cap; \
+                        p2.tile_list_count = p.tile_list_buf;                              \
+                        hipLaunchKernelGGL((early_lean_kernel<State, J>), dim3((uint32_t)device_cus() * 8u), b, 0, stream, p2); \
+                        return hipGetLastError();                                          \
+                    }                                                                      \
                     hipLaunchKernelGGL((early_head8_kernel<State, J>), g, b, 0, stream, pn); \
                     return hipGetLastError();                                              \
                 }                                                                          \

@@ -1796,6 +1796,80 @@ def test_ragged_results_through_the_gather_path():
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("alphabet", ["alnum", "abcd"])
+def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
+    """Levenshtein / OSA under a cutoff <= 5 on a single-length corpus of >= 2^14 tiles take their first look from the 8-symbol head
+    plane, and for cutoffs that allow <= 3 edits a BAND PREFILTER (rf_scan.hip head_filter_kernel: a streaming pass that leaves a
+    list of tiles for the cutoff kernel; inside the cutoff kernel for the top-k bound sample) abandons a tile before any recurrence
+    runs when no lane has 8 - K head symbols with a query partner within K positions.  The adversarial corpus: 1.05 M
+    candidates, and in every 5th tile ONE lane holds the query with 0..5 edits packed into its first 8 symbols -- substitutions,
+    deletions / insertions at the very front (the whole head shifted by 1..3), adjacent transpositions, and mixtures -- so that the
+    only reason to keep the tile is a candidate the filter sees at its weakest.  Every value of every cutoff 0..5 against the
+    oracle; on the 4-symbol alphabet the host's frequency estimate switches the filter off, RF_BAND_FILTER=1 in a subprocess
+    forces it on."""
+    import subprocess
+    import sys
+
+    if os.environ.get("RF_TEST_HEAD_CHILD") is None and alphabet == "abcd":
+        # the same two corpora with the filter forced on (also where the host would not use it), with the filter inside the cutoff
+        # kernel instead of head_filter_kernel + tile list, and with no filter at all
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for env in ({"RF_BAND_FILTER": "1"}, {"RF_BAND_FILTER": "1", "RF_HEAD_TWO_PASS": "0"}, {"RF_BAND_FILTER": "0"}):
+            r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                                "test_head_plane_cutoff_scans_with_edits_in_the_head"], capture_output=True, text=True, cwd=root,
+                               env=dict(os.environ, RF_TEST_HEAD_CHILD="1", **env))
+            assert r.returncode == 0 and " passed" in r.stdout, (env, r.stdout[-3000:])
+    rng = np.random.default_rng(4242)
+    n, ln = (1 << 20) + 64 * 7 + 5, 64
+    alpha = synth.ALNUM if alphabet == "alnum" else ABCD
+    host = alpha[rng.integers(0, len(alpha), size=(n, ln))]
+    q = alpha[rng.integers(0, len(alpha), size=ln)]
+    if alphabet == "alnum":
+        q[8:16] = q[0:8]  # (a repeated stretch: band partners at more than one offset)
+    other = np.uint8(126)  # a symbol outside both alphabets
+    kinds = 0
+    for t in range(0, n // 64, 5):
+        row = q.copy()
+        kind = (t // 5) % 14
+        lane = (t * 7) % 64
+        if kind <= 5:  # substitutions at random head positions
+            row[rng.choice(8, size=kind, replace=False)] = other
+        elif kind <= 8:  # the head shifted left: d deletions at the front, d symbols appended
+            d = kind - 5
+            row = np.concatenate([q[d:], alpha[rng.integers(0, len(alpha), size=d)]])
+        elif kind <= 11:  # the head shifted right: d insertions at the front, the last d dropped
+            d = kind - 8
+            row = np.concatenate([np.full(d, other, dtype=np.uint8), q[:-d]])
+        elif kind == 12:  # two adjacent transpositions in the head
+            row[[0, 1]] = row[[1, 0]]
+            row[[5, 6]] = row[[6, 5]]
+        else:  # one insertion at the front, one substitution, one transposition
+            row = np.concatenate([np.full(1, other, dtype=np.uint8), q[:-1]])
+            row[4] = other
+            row[[6, 7]] = row[[7, 6]]
+        host[t * 64 + lane] = row
+        kinds += 1
+    assert kinds > 3000
+    corpus = rf.Corpus.from_rows(host)
+    qb = q.tobytes()
+    for metric in ("levenshtein", "osa"):
+        gb, ob = GPU[metric].BatchComparator(qb), ORA[metric].BatchComparator(qb)
+        for k in range(0, 6):
+            got = gb.many(OPS["distance"], corpus, score_cutoff=k)
+            exp = _expect_u32(ob.rows(OPS["distance"], host, nthreads=8, score_cutoff=k))
+            bad = np.nonzero(got != exp)[0]
+            assert len(bad) == 0, (alphabet, metric, k, bad[:5], got[bad[:5]], exp[bad[:5]])
+            assert int((got != NONE32).sum()) >= (1 if k == 0 else 100)
+        for c in (0.97, 0.95):  # normalized similarity cutoffs that allow 1 and 3 edits of 64
+            got = gb.many(OPS["normalized_similarity"], corpus, score_cutoff=c)
+            exp = ob.rows(OPS["normalized_similarity"], host, nthreads=8, score_cutoff=c)
+            assert _equal_rows(got, exp), (alphabet, metric, c)
+        s, i = gb.topk(corpus, 16, score_cutoff=3)
+        exp = ob.rows(OPS["distance"], host, nthreads=8, score_cutoff=3)
+        order = [j for j in np.lexsort((np.arange(n), exp)) [:16] if exp[j] != U64MAX]
+        assert list(zip(s.tolist(), i.tolist())) == [(int(exp[j]), int(j)) for j in order]
+
+
 def test_gather_path_submits_asynchronously_and_matches_the_oracle():
     """The gather path's temporary is kept per (corpus, stream): a stream-ordered allocation per call made the SUBMISSION of a
     step wait for the previous step (tools/time_submit.py: 560 us to submit a 575 us step).  20 M ragged candidates, Indel (a
