@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
 // thread walking 16 segments one dependent load after another: 123 us.)
 __global__ __launch_bounds__(1024) void tile_list_offsets_kernel(uint32_t* __restrict__ buf, uint32_t G)
 {
-    __shared__ uint32_t sums[1024];
+    __shared__ uint32_t sums[1024 / kWave];
     constexpr uint32_t kPer = 16;  // G <= 16384
     const uint32_t first = threadIdx.x * kPer;
     uint32_t c[kPer], mine = 0;
@@ -267,21 +267,30 @@ __global__ __launch_bounds__(1024) void tile_list_offsets_kernel(uint32_t* __res
     for (uint32_t j = 0; j < kPer; ++j) c[j] = first + j < G ? buf[1 + first + j] : 0u;
 #pragma unroll
     for (uint32_t j = 0; j < kPer; ++j) mine += c[j];
-    sums[threadIdx.x] = mine;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-        const uint32_t v = threadIdx.x >= d ? sums[threadIdx.x - d] : 0u;
-        __syncthreads();
-        sums[threadIdx.x] += v;
-        __syncthreads();
+    // inclusive scan of the 1024 partial sums: inside each wavefront by lane shuffles, then over the 16 wavefront totals
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < (uint32_t)kWave; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += v;
     }
-    uint32_t at = sums[threadIdx.x] - mine;
+    if (lane == kWave - 1) sums[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 1024 / kWave; ++w) {
+        const uint32_t v = sums[w];
+        if (w < wave) before += v;
+        total += v;
+    }
+    uint32_t at = before + incl - mine;
 #pragma unroll
     for (uint32_t j = 0; j < kPer; ++j) {
         if (first + j < G) buf[1 + G + first + j] = at;
         at += c[j];
     }
-    if (threadIdx.x == 1023) buf[0] = sums[1023];
+    if (threadIdx.x == 0) buf[0] = total;
 }
 __global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap)
 {

@@ -1804,8 +1804,8 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
     runs when no lane has 8 - K head symbols with a query partner within K positions.  The adversarial corpus: 1.05 M
     candidates, and in every 5th tile ONE lane holds the query with 0..5 edits packed into its first 8 symbols -- substitutions,
     deletions / insertions at the very front (the whole head shifted by 1..3), adjacent transpositions, and mixtures -- so that the
-    only reason to keep the tile is a candidate the filter sees at its weakest.  Every value of every cutoff 0..5 against the
-    oracle; on the 4-symbol alphabet the host's frequency estimate switches the filter off, RF_BAND_FILTER=1 in a subprocess
+    only reason to keep the tile is a candidate the filter sees at its weakest; the same with 3..8 edits spread over the first 16
+    symbols for the cutoffs above 3 (first looks at columns 8..12).  Every value of every cutoff 0..9 against the oracle; on the 4-symbol alphabet the host's frequency estimate switches the filter off, RF_BAND_FILTER=1 in a subprocess
     forces it on."""
     import subprocess
     import sys
@@ -1830,9 +1830,9 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
     kinds = 0
     for t in range(0, n // 64, 5):
         row = q.copy()
-        kind = (t // 5) % 14
+        kind = (t // 5) % 24
         lane = (t * 7) % 64
-        if kind <= 5:  # substitutions at random head positions
+        if kind <= 5:  # substitutions at random positions of the 8-symbol head
             row[rng.choice(8, size=kind, replace=False)] = other
         elif kind <= 8:  # the head shifted left: d deletions at the front, d symbols appended
             d = kind - 5
@@ -1843,10 +1843,22 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
         elif kind == 12:  # two adjacent transpositions in the head
             row[[0, 1]] = row[[1, 0]]
             row[[5, 6]] = row[[6, 5]]
-        else:  # one insertion at the front, one substitution, one transposition
+        elif kind == 13:  # one insertion at the front, one substitution, one transposition
             row = np.concatenate([np.full(1, other, dtype=np.uint8), q[:-1]])
             row[4] = other
             row[[6, 7]] = row[[7, 6]]
+        elif kind <= 19:  # 3..8 substitutions among the first 16 symbols (cutoffs 4..9: first looks at columns 8..12)
+            row[rng.choice(16, size=kind - 11, replace=False)] = other
+        elif kind <= 21:  # the first 16 shifted by 2 / 3 and two more substitutions behind the shift
+            d = kind - 18
+            row = np.concatenate([np.full(d, other, dtype=np.uint8), q[:-d]])
+            row[[9, 13]] = other
+        else:  # 4 deletions at the front / 3 transpositions among the first 16
+            if kind == 22:
+                row = np.concatenate([q[4:], alpha[rng.integers(0, len(alpha), size=4)]])
+            else:
+                for a in (1, 6, 12):
+                    row[[a, a + 1]] = row[[a + 1, a]]
         host[t * 64 + lane] = row
         kinds += 1
     assert kinds > 3000
@@ -1854,13 +1866,13 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
     qb = q.tobytes()
     for metric in ("levenshtein", "osa"):
         gb, ob = GPU[metric].BatchComparator(qb), ORA[metric].BatchComparator(qb)
-        for k in range(0, 6):
+        for k in range(0, 10):
             got = gb.many(OPS["distance"], corpus, score_cutoff=k)
             exp = _expect_u32(ob.rows(OPS["distance"], host, nthreads=8, score_cutoff=k))
             bad = np.nonzero(got != exp)[0]
             assert len(bad) == 0, (alphabet, metric, k, bad[:5], got[bad[:5]], exp[bad[:5]])
             assert int((got != NONE32).sum()) >= (1 if k == 0 else 100)
-        for c in (0.97, 0.95):  # normalized similarity cutoffs that allow 1 and 3 edits of 64
+        for c in (0.97, 0.95, 0.9):  # normalized similarity cutoffs that allow 1, 3 and 6 edits of 64
             got = gb.many(OPS["normalized_similarity"], corpus, score_cutoff=c)
             exp = ob.rows(OPS["normalized_similarity"], host, nthreads=8, score_cutoff=c)
             assert _equal_rows(got, exp), (alphabet, metric, c)
