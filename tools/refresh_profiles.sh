@@ -9,13 +9,13 @@ cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
 # ONLY=<substring> restricts the run to the profiles / bench lines whose tag contains it (e.g. ONLY=ragged)
 P() { tag=$1; key=$2; shift 2; [[ -n "${ONLY:-}" && $tag != *$ONLY* ]] && return; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
 MATCH="rf::stream_lev64" P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
-MATCH="rf::early" P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
+MATCH="rf::head_filter" P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
 P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
 P c4_indel "indel:q64:n100000000:l64:cutNone:many" --metric indel
 MATCH="rf::jaro" P c4_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many" --metric jaro_winkler
 MATCH="rf::stream_osa" P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
 MATCH="rf::stream_lev32" P q32_levenshtein "levenshtein:q32:n100000000:l64:cutNone:many" --query-len 32
-MATCH="rf::early" P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" --cutoff 3 --mode topk
+MATCH="rf::head_filter" P c5_cutoff3_topk "levenshtein:q64:n100000000:l64:cut3:topk" --cutoff 3 --mode topk
 MATCH="rf::lev1_asm" P topk16_nocutoff "levenshtein:q64:n100000000:l64:cutNone:topk" --mode topk
 MATCH="rf::band" P c3_cutoff8_band "levenshtein:q256:n10000000:l256:cut8:many" --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
 MATCH="rf::stream_lev64" P ragged_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:ragged" --ragged
