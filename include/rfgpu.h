@@ -70,8 +70,11 @@ typedef enum rf_mem { RF_MEM_HOST = 0, RF_MEM_DEVICE = 1 } rf_mem;
  * lcs_seq / indel / jaro / fuzz.  Use rf_args_default() and then set fields.
  *   cutoff_usize : RF_NO_CUTOFF = NoScoreCutoff, else WithScoreCutoff(v) for the usize-valued ops
  *   cutoff_f64   : NaN = NoScoreCutoff, else WithScoreCutoff(v) for the f64-valued ops
- *   score_hint_* : accepted and ignored -- in the reference a hint only steers the CPU band search
- *                  (levenshtein.rs:1069-1088); results never depend on it (levenshtein.rs:2153-2160)
+ *   score_hint_* : results never depend on a hint (levenshtein.rs:2153-2160); in the reference it steers the CPU band search
+ *                  (levenshtein.rs:1069-1088: a band of `hint`, doubled until the distance fits).  The per-candidate scans ignore
+ *                  it.  rf_topk_u32 with RF_OP_DISTANCE and no cutoff uses it the reference's way: the scan first runs under the
+ *                  cutoff `hint` (a cutoff scan costs a fraction of a full one) and the k best are final if k candidates pass,
+ *                  otherwise the hint doubles (past a quarter of the longest possible distance the plain scan runs)
  *
  * Two places where the device deliberately does NOT reproduce what release-mode rapidfuzz 0.5.0 returns (both tested,
  * tests/test_gpu_parity.py, both also in DESIGN.md section 3):

@@ -2288,10 +2288,39 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     uint64_t* d_best = nullptr;
     RF_HIP(hipMallocAsync((void**)&d_best, (size_t)kWave * sizeof(uint64_t), st));
     bool desc = false;
-    rf_status s = topk_core(c, corpus, op, args, k, 0, d_best, out_all, out_all_mem, st, &desc);
     std::vector<uint64_t> best(kWave, ~0ull);
     hipError_t e = hipSuccess;
-    if (s == RF_OK) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    rf_status s = RF_OK;
+    // score_hint (RF_OP_DISTANCE, no cutoff, no per-candidate output): the caller expects the k-th best distance to be <= hint.  The
+    // reference uses the hint per pair the same way (levenshtein.rs:1069-1088: a band of `hint`, doubled until the distance fits).
+    // Here the scan first runs UNDER THE CUTOFF `hint` -- a cutoff scan costs a fraction of a full one (§5.1) -- and if k candidates
+    // pass, they are the k best of the corpus; otherwise the hint doubles, and past a quarter of the longest possible distance the
+    // plain scan runs.  The result never depends on the hint.
+    bool done = false;
+    if (args && op == RF_OP_DISTANCE && args->score_hint_usize != RF_NO_CUTOFF && args->cutoff_usize == RF_NO_CUTOFF && !out_all) {
+        const uint64_t longest = std::max<uint64_t>(rf_comparator_query_len(c), corpus->max_len);
+        for (uint64_t hint = args->score_hint_usize; hint * 4 <= longest; hint = std::max<uint64_t>(1, hint * 2)) {
+            rf_args a2 = *args;
+            a2.cutoff_usize = hint;
+            a2.score_hint_usize = RF_NO_CUTOFF;
+            s = topk_core(c, corpus, op, &a2, k, 0, d_best, nullptr, RF_MEM_DEVICE, st, &desc);
+            if (s != RF_OK) break;  // (shapes the in-scan lists do not cover: the plain path below sorts that out)
+            e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) break;
+            uint32_t found = 0;
+            while (found < k && best[found] != ~0ull) ++found;
+            if (found >= k || found >= corpus->n) {
+                done = true;
+                break;
+            }
+        }
+    }
+    if (!done) {
+        s = topk_core(c, corpus, op, args, k, 0, d_best, out_all, out_all_mem, st, &desc);
+        e = hipSuccess;
+        if (s == RF_OK) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    }
     (void)hipFreeAsync(d_best, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (s == RF_ERR_UNSUPPORTED && (op == RF_OP_DISTANCE || op == RF_OP_SIMILARITY)) {

@@ -857,7 +857,7 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                     if (two_pass && p.head_need && p.tile_step == 1 && p.tile_list_buf && p.tile_end > p.tile_begin) { \
                         /* the band prefilter as a streaming pass of its own, then the cutoff scan over the tiles it left */ \
                         const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
-                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)device_cus() * 16u); \
+                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: tile_list_offsets_kernel */ \
                         const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
                         hipLaunchKernelGGL(head_filter_kernel, dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
                         hipLaunchKernelGGL(tile_list_offsets_kernel, dim3(1), dim3(1024), 0, stream, p.tile_list_buf, G); \

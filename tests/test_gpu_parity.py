@@ -1882,6 +1882,33 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
         assert list(zip(s.tolist(), i.tolist())) == [(int(exp[j]), int(j)) for j in order]
 
 
+@pytest.mark.parametrize("metric", ["levenshtein", "osa", "indel"])
+def test_topk_score_hint_never_changes_the_result(metric):
+    """rf_topk_u32 under a score_hint runs the scan under the cutoff `hint` first and doubles the hint until k candidates pass
+    (rf_api.hip; the reference's use of a hint, levenshtein.rs:1069-1088).  Whatever the hint -- too small, exact, far too large --
+    scores and indices are those of the plain top-k: a 1.05 M single-length corpus (head plane, band prefilter) with a handful of
+    near-duplicates (so that small k are settled by small hints and k = 64 never is), and a ragged one."""
+    rng = np.random.default_rng(31)
+    n = (1 << 20) + 999
+    host = synth.ALNUM[rng.integers(0, 62, size=(n, 64))]
+    q = synth.ALNUM[rng.integers(0, 62, size=64)]
+    for r, edits in zip(rng.choice(n, size=30, replace=False), list(range(0, 10)) * 3):
+        row = q.copy()
+        row[rng.choice(64, size=edits, replace=False)] = 126
+        host[r] = row
+    corpus = rf.Corpus.from_rows(host)
+    data, offsets = synth.ragged_host(50_000, 70, seed=32)
+    ragged = rf.Corpus.from_ragged(data, offsets)
+    bc = GPU[metric].BatchComparator(q.tobytes())
+    for cor in (corpus, ragged):
+        for k in (1, 5, 16, 64):
+            s0, i0 = bc.topk(cor, k)
+            assert len(s0) == k
+            for hint in (0, 1, 2, 3, 7, 12, 40, 10_000):
+                s1, i1 = bc.topk(cor, k, score_hint=hint)
+                assert np.array_equal(s0, s1) and np.array_equal(i0, i1), (metric, k, hint, s0[:4], s1[:4])
+
+
 def test_gather_path_submits_asynchronously_and_matches_the_oracle():
     """The gather path's temporary is kept per (corpus, stream): a stream-ordered allocation per call made the SUBMISSION of a
     step wait for the previous step (tools/time_submit.py: 560 us to submit a 575 us step).  20 M ragged candidates, Indel (a
