@@ -254,52 +254,46 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
     }
     if (lane == 0) buf[1 + gw] = kept;
 }
-// packing the segments: one workgroup turns the G per-wavefront counts into offsets (G <= 16 K: 16 per thread, loaded at once),
-// then one thread per segment copies its few tiles behind its predecessors'.  (First version: one workgroup doing both, every
-// thread walking 16 segments one dependent load after another: 123 us.)
-__global__ __launch_bounds__(1024) void tile_list_offsets_kernel(uint32_t* __restrict__ buf, uint32_t G)
+// packing the segments: ONE launch, a workgroup per 256 segments.  Every workgroup adds up the counts in front of its block itself
+// (<= 16 K coalesced loads spread over 256 threads: cheaper than a launch that would do it once), scans its own 256 counts and
+// copies its segments behind one another; the last workgroup leaves the total in buf[0].  (First version: one workgroup doing
+// everything, every thread walking 16 segments one dependent load after another: 123 us.  Second: an offsets kernel whose threads
+// read 16 CONSECUTIVE counts each -- 64-byte lane stride, 17 us through one CU's L1 -- and a copy kernel, 6 us.)
+// buf: [0] packed count | G per-wavefront counts | G words unused | G segments of `cap` tiles | the packed list
+__global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap)
 {
-    __shared__ uint32_t sums[1024 / kWave];
-    constexpr uint32_t kPer = 16;  // G <= 16384
-    const uint32_t first = threadIdx.x * kPer;
-    uint32_t c[kPer], mine = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) c[j] = first + j < G ? buf[1 + first + j] : 0u;
-#pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) mine += c[j];
-    // inclusive scan of the 1024 partial sums: inside each wavefront by lane shuffles, then over the 16 wavefront totals
+    constexpr uint32_t kWaves = 256 / kWave;
+    __shared__ uint32_t own[kWaves], front[kWaves];
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    uint32_t incl = mine;
+    const uint32_t first = blockIdx.x * 256, s = first + threadIdx.x;
+    uint32_t before = 0;  // this thread's share of the counts in front of the block
+    for (uint32_t k = threadIdx.x; k < first; k += 256) before += buf[1 + k];
+    const uint32_t n = s < G ? buf[1 + s] : 0u;
+    uint32_t incl = n;  // inclusive scan of n inside the wavefront
 #pragma unroll
     for (uint32_t d = 1; d < (uint32_t)kWave; d <<= 1) {
         const uint32_t v = __shfl_up(incl, d, kWave);
         if (lane >= d) incl += v;
     }
-    if (lane == kWave - 1) sums[wave] = incl;
+#pragma unroll
+    for (uint32_t d = kWave / 2; d >= 1; d >>= 1) before += __shfl_xor(before, d, kWave);  // wavefront sum
+    if (lane == kWave - 1) own[wave] = incl;
+    if (lane == 0) front[wave] = before;
     __syncthreads();
-    uint32_t before = 0, total = 0;
+    uint32_t at = incl - n, block_total = 0, in_front = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < 1024 / kWave; ++w) {
-        const uint32_t v = sums[w];
-        if (w < wave) before += v;
-        total += v;
+    for (uint32_t w = 0; w < kWaves; ++w) {
+        in_front += front[w];
+        if (w < wave) at += own[w];
+        block_total += own[w];
     }
-    uint32_t at = before + incl - mine;
-#pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) {
-        if (first + j < G) buf[1 + G + first + j] = at;
-        at += c[j];
+    at += in_front;
+    if (s < G) {
+        const uint32_t* seg = buf + 1 + 2 * (size_t)G + (size_t)s * cap;
+        uint32_t* packed = buf + 1 + 2 * (size_t)G + (size_t)G * cap;
+        for (uint32_t j = 0; j < n; ++j) packed[at + j] = seg[j];
     }
-    if (threadIdx.x == 0) buf[0] = total;
-}
-__global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= G) return;
-    const uint32_t n = buf[1 + s], at = buf[1 + G + s];
-    const uint32_t* seg = buf + 1 + 2 * (size_t)G + (size_t)s * cap;
-    uint32_t* packed = buf + 1 + 2 * (size_t)G + (size_t)G * cap;
-    for (uint32_t j = 0; j < n; ++j) packed[at + j] = seg[j];
+    if (first + 256 >= G && threadIdx.x == 0) buf[0] = in_front + block_total;
 }
 
 // THE BAND PREFILTER (kHead8, p.head_need != 0: cutoffs that allow at most K = p.head_k <= 3 edits).  Any alignment of cost <= K
@@ -857,10 +851,9 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                     if (two_pass && p.head_need && p.tile_step == 1 && p.tile_list_buf && p.tile_end > p.tile_begin) { \
                         /* the band prefilter as a streaming pass of its own, then the cutoff scan over the tiles it left */ \
                         const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
-                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: tile_list_offsets_kernel */ \
+                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: rf_api.hip sizes the list buffer for that */ \
                         const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
                         hipLaunchKernelGGL(head_filter_kernel, dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
-                        hipLaunchKernelGGL(tile_list_offsets_kernel, dim3(1), dim3(1024), 0, stream, p.tile_list_buf, G); \
                         hipLaunchKernelGGL(tile_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap); \
                         ScanParams p2 = pn;                                                \
                         p2.heads8 = nullptr;                                               \
