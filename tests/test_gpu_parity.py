@@ -1909,6 +1909,25 @@ def test_topk_score_hint_never_changes_the_result(metric):
                 assert np.array_equal(s0, s1) and np.array_equal(i0, i1), (metric, k, hint, s0[:4], s1[:4])
 
 
+@pytest.mark.parametrize("two_pass", ["1", "0"])
+def test_head_plane_and_band_filter_forced_on_small_corpora(two_pass):
+    """The head plane, the band prefilter and its tile list start at 2^14 tiles; RF_HEAD8_MIN=1 RF_BAND_FILTER=1 puts every
+    single-length corpus of the cutoff / top-k / randomized parity tests (a few tiles, odd tile counts, fewer pairs than filter
+    wavefronts, every op and weight table that plans onto the cutoff kernels) through them -- as a streaming pass + list
+    (two_pass = 1) and inside the cutoff kernel (0)."""
+    import subprocess
+    import sys
+
+    if os.environ.get("RF_TEST_HEAD_CHILD") is not None:
+        pytest.skip("already inside a forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "(cutoff or topk or randomized) and not forced_on_small and not edits_in_the_head and not score_hint"],
+                       capture_output=True, text=True, cwd=root,
+                       env=dict(os.environ, RF_HEAD8_MIN="1", RF_BAND_FILTER="1", RF_HEAD_TWO_PASS=two_pass, RF_TEST_HEAD_CHILD="1"))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+
+
 def test_gather_path_submits_asynchronously_and_matches_the_oracle():
     """The gather path's temporary is kept per (corpus, stream): a stream-ordered allocation per call made the SUBMISSION of a
     step wait for the previous step (tools/time_submit.py: 560 us to submit a 575 us step).  20 M ragged candidates, Indel (a
