@@ -59,7 +59,20 @@ def allgather_topk(scores: np.ndarray, indices: np.ndarray, k: int, op: int = N.
 def sharded_topk(scorer, shard_corpus, k: int, shard_start: int, op: int = N.OP_DISTANCE, args=None, out=None, group=None,
                  device=None, **kw):
     """One rank's share of a distributed top-k: scan the local shard (global index = shard_start + local),
-    then the k-entry all-gather.  Every rank returns the same (scores, global indices)."""
+    then the k-entry all-gather.  Every rank returns the same (scores, global indices).  score_hint=<expected k-th best
+    distance> turns the scan into cutoff scans (see below); the result never depends on it."""
+    hint = kw.pop("score_hint", None)
+    if hint is not None and op == N.OP_DISTANCE and args is None and out is None and kw.get("score_cutoff") is None:
+        # score_hint across shards (DESIGN.md 5.4): every rank scans its shard under the cutoff `hint`; if the MERGED list holds k
+        # entries they are the k best of the whole corpus, otherwise the hint doubles.  The merged list is the same on every rank, so
+        # all ranks take the same branch; the bound on the rounds depends on the query alone for the same reason.
+        hint, longest = int(hint), len(scorer._s1)
+        while hint * 4 <= longest:
+            s, i = scorer.topk(shard_corpus, k, op, index_base=shard_start, score_cutoff=hint, **kw)
+            ms, mi = allgather_topk(s, i, k, op, group=group, device=device)
+            if len(ms) >= k:
+                return ms, mi
+            hint = max(1, 2 * hint)
     s, i = scorer.topk(shard_corpus, k, op, args, index_base=shard_start, out=out, **kw)
     return allgather_topk(s, i, k, op, group=group, device=device)
 

@@ -1928,6 +1928,41 @@ def test_head_plane_and_band_filter_forced_on_small_corpora(two_pass):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
 
 
+def test_sharded_topk_score_hint_over_a_one_rank_group():
+    """parallel.sharded_topk with a score_hint: cutoff scans + the k-entry exchange per round, the hint doubled until the MERGED list
+    is full (every rank sees the same list, so every rank takes the same branch).  One rank over gloo here; the result equals the
+    plain sharded top-k for hints that are too small, right and never tried."""
+    import torch.distributed as dist
+
+    from rapidfuzz_rs_amd import parallel
+
+    rng = np.random.default_rng(5)
+    n = 300_000
+    host = synth.ALNUM[rng.integers(0, 62, size=(n, 64))]
+    q = synth.ALNUM[rng.integers(0, 62, size=64)]
+    for r, edits in zip(rng.choice(n, size=24, replace=False), list(range(8)) * 3):
+        row = q.copy()
+        row[rng.choice(64, size=edits, replace=False)] = 126
+        host[r] = row
+    corpus = rf.Corpus.from_rows(host)
+    bc = rf.distance.levenshtein.BatchComparator(q.tobytes())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    try:
+        for k in (1, 8, 24):
+            s0, i0 = parallel.sharded_topk(bc, corpus, k, shard_start=1_000_000)
+            assert len(s0) == k and int(i0.min()) >= 1_000_000
+            for hint in (0, 2, 5, 9, 100):
+                s1, i1 = parallel.sharded_topk(bc, corpus, k, shard_start=1_000_000, score_hint=hint)
+                assert np.array_equal(s0, s1) and np.array_equal(i0, i1), (k, hint)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_gather_path_submits_asynchronously_and_matches_the_oracle():
     """The gather path's temporary is kept per (corpus, stream): a stream-ordered allocation per call made the SUBMISSION of a
     step wait for the previous step (tools/time_submit.py: 560 us to submit a 575 us step).  20 M ragged candidates, Indel (a
