@@ -1784,7 +1784,7 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
         RF_HIP(ea);
     }
     std::unique_lock<std::mutex> filter_lock;  // held while a filter pass and the scan over its list are enqueued
-    if (p.head_need) {
+    if (p.heads8) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
         p.tile_list_buf = corpus_tile_list(corpus, st);
     }
@@ -2064,7 +2064,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     p.out = d_all;
     std::lock_guard<std::mutex> enqueue_lock(owner->topk_enqueue_mu);
     std::unique_lock<std::mutex> filter_lock;
-    if (p.head_need) {
+    if (p.heads8) {
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
         p.tile_list_buf = corpus_tile_list(corpus, st);
     }

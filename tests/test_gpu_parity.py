@@ -1801,7 +1801,8 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
     """Levenshtein / OSA under a cutoff <= 5 on a single-length corpus of >= 2^14 tiles take their first look from the 8-symbol head
     plane, and for cutoffs that allow <= 3 edits a BAND PREFILTER (rf_scan.hip head_filter_kernel: a streaming pass that leaves a
     list of tiles for the cutoff kernel; inside the cutoff kernel for the top-k bound sample) abandons a tile before any recurrence
-    runs when no lane has 8 - K head symbols with a query partner within K positions.  The adversarial corpus: 1.05 M
+    runs when no lane has 8 - K head symbols with a query partner within K positions; cutoffs 4..5 (and every cutoff <= 5 when the
+    filter is off) take the first look itself as such a streaming pass (head_look_kernel).  The adversarial corpus: 1.05 M
     candidates, and in every 5th tile ONE lane holds the query with 0..5 edits packed into its first 8 symbols -- substitutions,
     deletions / insertions at the very front (the whole head shifted by 1..3), adjacent transpositions, and mixtures -- so that the
     only reason to keep the tile is a candidate the filter sees at its weakest; the same with 3..8 edits spread over the first 16
@@ -1814,7 +1815,8 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
         # the same two corpora with the filter forced on (also where the host would not use it), with the filter inside the cutoff
         # kernel instead of head_filter_kernel + tile list, and with no filter at all
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for env in ({"RF_BAND_FILTER": "1"}, {"RF_BAND_FILTER": "1", "RF_HEAD_TWO_PASS": "0"}, {"RF_BAND_FILTER": "0"}):
+        for env in ({"RF_BAND_FILTER": "1"}, {"RF_BAND_FILTER": "1", "RF_HEAD_TWO_PASS": "0"}, {"RF_BAND_FILTER": "0"},
+                    {"RF_BAND_FILTER": "0", "RF_HEAD_LOOK_PASS": "0"}):  # (the last: every first look inside early_head8_kernel)
             r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
                                 "test_head_plane_cutoff_scans_with_edits_in_the_head"], capture_output=True, text=True, cwd=root,
                                env=dict(os.environ, RF_TEST_HEAD_CHILD="1", **env))
