@@ -31,6 +31,7 @@ ROWS = [  # (file stem, label)
     ("multi4_indel", "4 queries x C2 corpus, Indel"),
     ("indel_cutoff12", "Indel, `score_cutoff = 12` (a 0.9 `fuzz::ratio` threshold)"),
     ("osa_cutoff3", "OSA, `score_cutoff = 3`"),
+    ("cutoff5_many", "Levenshtein, `score_cutoff = 5` (the first look as a streaming pass over the head plane)"),
     ("jw_cutoff0.9", "Jaro-Winkler, `score_cutoff = 0.9`"),
     ("wf_weights_1_2_3", "Levenshtein weights (1,2,3), 20 M candidates (`wf_reg_kernel<64>`)"),
 ]

@@ -45,6 +45,7 @@ b multi4_indel --metric indel --queries 4 --no-cpu-baseline
 b wf_weights_1_2_3 --weights 1,2,3 --candidates 20000000 --steps 3 --warmup 1
 b indel_cutoff12 --metric indel --cutoff 12
 b osa_cutoff3 --metric osa --cutoff 3
+b cutoff5_many --cutoff 5
 b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
 b c3_cutoff8 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
 if [ -n "${ONLY:-}" ]; then cp gpurun_out/*_$R.txt gpurun_out/*_$R.json gpurun_out/profiles/ 2>/dev/null; ls gpurun_out/profiles | wc -l; exit 0; fi
