@@ -194,80 +194,29 @@ __device__ __forceinline__ uint32_t band_hits(const uint8_t* lds_band, uint32_t 
 // else -- 16 bytes per lane per load (TWO candidates; a wavefront takes a PAIR of tiles per trip: lanes 0..31 hold tile t, lanes
 // 32..63 tile t + 1), two loads in flight, ~45 instructions per pair -- writes None for the tiles it decides and leaves the others
 // in ITS OWN segment of a list (no atomics: one shared counter took 12 ns per survivor, 0.4 ms of a 0.5 ms pass);
-// tile_list_compact_kernel packs the segments, and the cutoff scan proper (early_lean_kernel) walks the packed list.
+// tile_list_pack_kernel packs the segments, and the cutoff scan proper (early_lean_kernel) walks the packed list.
 // Inside the cutoff kernel the same filter was held to 4.2-4.6 TB/s of head plane by that kernel's loop (25 scalar instructions
 // and 12 branches per tile around it, one tile per trip); a plain streaming read of the plane in 16-byte-per-lane rows moves
 // 6.7 TB/s (tools/membw.hip).
-// buf: [0] packed count | G per-wavefront counts | G offsets | G segments of `cap` tiles | the packed list     (G = wavefronts of the filter launch)
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
-{
-    __shared__ uint8_t lds_band[256];
-    build_band_table(p, lds_band);
-    __syncthreads();
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = uniform(threadIdx.x / kWave);
-    const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2, stride = gridDim.x * kWavesPerBlock;
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
-    uint32_t* seg = buf + 1 + 2 * (size_t)stride + (size_t)gw * cap;
-    uint32_t kept = 0;
-    uint32_t pr = gw;
-    if (pr < pairs) {
-        // (the plane is allocated with one row of slack: the second half of the last pair of an odd tile count is readable)
-        const uint8_t* base = p.heads8 + (size_t)lane * sizeof(v4u);
-        auto load_pair = [&](uint32_t q) { return __builtin_nontemporal_load(reinterpret_cast<const v4u*>(base + ((uint64_t)p.tile_begin + 2ull * q) * (kWave * 8))); };
-        v4u cur = load_pair(pr);
-        v4u ahead = load_pair(pr + stride < pairs ? pr + stride : pr);
-        const uint32_t need = p.head_need;
-        while (true) {
-            const uint32_t pr_next = pr + stride;
-            const v4u ahead2 = load_pair(pr_next + stride < pairs ? pr_next + stride : pr);
-            const uint32_t t0 = p.tile_begin + 2 * pr;
-            const bool pass = band_hits(lds_band, cur.x, cur.y) >= need || band_hits(lds_band, cur.z, cur.w) >= need;
-            const uint64_t m = __ballot(pass);
-            const bool alive0 = (uint32_t)m != 0, alive1 = (uint32_t)(m >> 32) != 0 && t0 + 1 < p.tile_end;
-            if (p.out) {  // the decided tiles' results (this lane: candidates idx and idx + 1)
-                const bool mine_dead = lane < 32 ? !alive0 : (!alive1 && t0 + 1 < p.tile_end);
-                const uint32_t idx = t0 * kWave + 2 * lane;
-                if (mine_dead) {
-                    if (!p.out_f64 && idx + 1 < p.n) {  // (idx is even: one aligned 8-byte store, 512 B per wavefront)
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.out) + idx) = make_uint2(RF_NONE_U32, RF_NONE_U32);
-                    } else {
-                        if (idx < p.n) emit_none(p, idx);
-                        if (idx + 1 < p.n) emit_none(p, idx + 1);
-                    }
-                }
-            }
-            if (alive0) {
-                if (lane == 0) seg[kept] = t0;
-                ++kept;
-            }
-            if (alive1) {
-                if (lane == 0) seg[kept] = t0 + 1;
-                ++kept;
-            }
-            if (pr_next >= pairs) break;
-            pr = pr_next;
-            cur = ahead;
-            ahead = ahead2;
-        }
-    }
-    if (lane == 0) buf[1 + gw] = kept;
-}
-// The FIRST LOOK as a streaming pass (head-plane scans that the band prefilter does not serve: cutoffs that allow 4..5 edits, or
-// corpora whose alphabet leaves the filter nothing to decide): the same loop as head_filter_kernel -- a pair of tiles per trip,
-// 16 bytes per lane = two candidates, two loads in flight -- with the 32-bit recurrence over the first kFirst columns of BOTH
-// candidates (two independent chains per lane) and the diagonal bound in place of the filter.  Inside early_head8_kernel that look
-// sits in a loop of 25 scalar instructions and 12 branches per tile, one tile per trip.
+// The pass also takes THE FIRST LOOK itself: for the pairs the band test lets through (a few percent: their bytes are in registers,
+// and a tile that passes the band test but not the look would otherwise cost the cutoff kernel a list entry, a row fetch and the
+// same look), and for every pair when the band filter does not apply (cutoffs that allow 4..5 edits, or corpora whose alphabet
+// leaves the filter nothing to decide): the 32-bit recurrence over the first kFirst columns of BOTH candidates of a lane (two
+// independent chains) and the diagonal bound.  Inside early_head8_kernel that look sits in a loop of 25 scalar instructions and
+// 12 branches per tile, one tile per trip.
+// buf: [0] packed count | G per-wavefront counts | G words unused | G segments of `cap` tiles | the packed list   (G = wavefronts of this launch)
 template <class State, int kFirst>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void head_look_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
 {
     using Look = typename std::conditional<std::is_same<State, LevState<1>>::value, Lev32State,
                                            typename std::conditional<std::is_same<State, OsaState<1>>::value, Osa32State, State>::type>::type;
     constexpr int kLookPitch = (std::is_same<State, LevState<1>>::value || std::is_same<State, OsaState<1>>::value) ? 2 : 1;
     static_assert(kFirst <= 8, "the head plane holds 8 symbols per candidate");
     __shared__ typename State::Word lds_pm[256];
+    __shared__ uint8_t lds_band[256];
     for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm[p.sigma[i]] = (typename State::Word)p.pm[i];
+    const uint32_t need = p.head_need;  // 0 = no band test
+    if (need) build_band_table(p, lds_band);
     __syncthreads();
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -289,13 +238,16 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_look_kernel(const 
             const uint32_t pr_next = pr + stride;
             const v4u ahead2 = load_pair(pr_next + stride < pairs ? pr_next + stride : pr);
             const uint32_t t0 = p.tile_begin + 2 * pr;
-            Look a, b;
-            a.init();
-            b.init();
-            process_chunk_full<Look, 0, kFirst, kLookPitch>(a, pm, make_uint4(cur.x, cur.y, 0u, 0u));
-            process_chunk_full<Look, 0, kFirst, kLookPitch>(b, pm, make_uint4(cur.z, cur.w, 0u, 0u));
-            const bool pass = may_pass(p, fin, a.bound_first(len1, kFirst, len2)) || may_pass(p, fin, b.bound_first(len1, kFirst, len2));
-            const uint64_t m = __ballot(pass);
+            uint64_t m = ~0ull;
+            if (need) m = __ballot(band_hits(lds_band, cur.x, cur.y) >= need || band_hits(lds_band, cur.z, cur.w) >= need);
+            if (m != 0) {
+                Look a, b;
+                a.init();
+                b.init();
+                process_chunk_full<Look, 0, kFirst, kLookPitch>(a, pm, make_uint4(cur.x, cur.y, 0u, 0u));
+                process_chunk_full<Look, 0, kFirst, kLookPitch>(b, pm, make_uint4(cur.z, cur.w, 0u, 0u));
+                m = __ballot(may_pass(p, fin, a.bound_first(len1, kFirst, len2)) || may_pass(p, fin, b.bound_first(len1, kFirst, len2)));
+            }
             const bool alive0 = (uint32_t)m != 0, alive1 = (uint32_t)(m >> 32) != 0 && t0 + 1 < p.tile_end;
             if (p.out) {
                 const bool mine_dead = lane < 32 ? !alive0 : (!alive1 && t0 + 1 < p.tile_end);
@@ -907,7 +859,7 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             ScanParams pn = p;
             pn.narrow_look = narrow_look ? 1u : 0u;
             static const bool two_pass = [] { const char* e = getenv("RF_HEAD_TWO_PASS"); return !e || atoi(e) != 0; }();  // A/B: head_filter_kernel + list
-            static const bool look_pass = [] { const char* e = getenv("RF_HEAD_LOOK_PASS"); return !e || atoi(e) != 0; }();  // A/B: head_look_kernel + list
+            static const bool look_pass = [] { const char* e = getenv("RF_HEAD_LOOK_PASS"); return !e || atoi(e) != 0; }();  // A/B: the first look inside early_head8_kernel where the band filter does not apply
             static const bool exp_nohbm = getenv("RF_EXP_NOHBM") != nullptr;  // measurement: every tile reads tile 0's head row (results are wrong on purpose)
             pn.exp_flags = exp_nohbm ? 1u : 0u;
             if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value ||
@@ -921,26 +873,12 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             if constexpr (J <= 8 && (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value)) { \
                 const int32_t look_row = J + (int32_t)p.len1 - (int32_t)p.uniform_len;      \
                 if (p.heads8 && (std::is_same<State, Lev32State>::value || (look_row >= 1 && look_row <= 32))) { \
-                    if (two_pass && p.head_need && p.tile_step == 1 && p.tile_list_buf && p.tile_end > p.tile_begin) { \
-                        /* the band prefilter as a streaming pass of its own, then the cutoff scan over the tiles it left */ \
+                    if ((p.head_need ? two_pass : look_pass) && p.tile_step == 1 && p.tile_list_buf && p.tile_end > p.tile_begin) { \
+                        /* band prefilter and first look as a streaming pass of its own, then the cutoff scan over the tiles it left */ \
                         const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
                         const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: rf_api.hip sizes the list buffer for that */ \
                         const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
-                        hipLaunchKernelGGL(head_filter_kernel, dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
-                        hipLaunchKernelGGL(tile_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap); \
-                        ScanParams p2 = pn;                                                \
-                        p2.heads8 = nullptr;                                               \
-                        p2.tile_list = p.tile_list_buf + 1 + 2 * (size_t)G + (size_t)G * cap; \
-                        p2.tile_list_count = p.tile_list_buf;                              \
-                        hipLaunchKernelGGL((early_lean_kernel<State, J>), dim3((uint32_t)device_cus() * 8u), b, 0, stream, p2); \
-                        return hipGetLastError();                                          \
-                    }                                                                      \
-                    if (look_pass && !p.head_need && p.tile_step == 1 && p.tile_list_buf && p.tile_end > p.tile_begin) { \
-                        /* the first look as a streaming pass of its own, then the cutoff scan over the tiles it left */ \
-                        const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
-                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); \
-                        const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
-                        hipLaunchKernelGGL((head_look_kernel<State, J>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
+                        hipLaunchKernelGGL((head_filter_kernel<State, J>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
                         hipLaunchKernelGGL(tile_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap); \
                         ScanParams p2 = pn;                                                \
                         p2.heads8 = nullptr;                                               \
