@@ -57,6 +57,10 @@ def parse():
                     help="candidate lengths uniform in [1, --cand-len] instead of one fixed length (BASELINE.json configs[0]'s 'len <= 64' "
                          "distribution at scale): the corpus is packed from host arrays into exact-length tiles + mixed tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
+                    help="after the headline's timed region, run one short leg (own process, --extra-steps steps, own roofline + oracle parity) for "
+                         "each OTHER BASELINE.json config and report them as `extra_configs`.  auto = on for the default workload at N = 1")
+    ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -574,12 +578,66 @@ def main():
                             "what": f"first {chk} candidates + every 1009-th of all {n}, vs oracle/"}
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    is_headline = (args.config in (None, "c2") and args.metric == "levenshtein" and n == 100_000_000 and args.cand_len == 64 and args.query_len == 64
+                   and args.cutoff is None and not weights and not args.ragged and args.mode == "many" and nq == 1 and world == 1 and not force_dist)
+    if args.extras == "on" or (args.extras == "auto" and is_headline):
+        # the headline's numbers are final at this point; give the GPU memory back before the legs start their own processes
+        del corpus, out
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        result["extra_configs"] = extra_configs(args)
+        for e in result["extra_configs"]:  # one short string per leg as well (a flat key survives any summarising of the line)
+            result["config"]["extra_" + e["name"]] = e.get("summary", e.get("error", "?"))[:120]
     # RCCL prints its version banner through C stdio, which flushes after Python's buffer when stdout is a pipe:
     # drain it first so the JSON line is the last line of the output
     import ctypes
 
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(result), flush=True)
+
+
+# The other BASELINE.json configs, as bench.py command lines (the headline -- configs[1] -- is the line itself).  Each leg is this very
+# script in a process of its own: same step definition, same HIP-event timing, same oracle parity leg, a short CPU baseline.
+EXTRA_LEGS = [
+    ("c1_q32_10k_ragged", "configs[0] on the GPU: query 32 x 10 k candidates len <= 64 (launch-bound at this size; the CPU figure beside it is the config itself)",
+     ["--query-len", "32", "--candidates", "10000", "--ragged"]),
+    ("c3_levenshtein_q256_10M", "configs[2]: query 256 x 10 M len-256 candidates (multi-word Hyyro)", ["--query-len", "256", "--cand-len", "256", "--candidates", "10000000"]),
+    ("c4_indel_100M", "configs[3]: Indel over the 100 M corpus", ["--metric", "indel"]),
+    ("c4_jaro_winkler_100M", "configs[3]: Jaro-Winkler over the 100 M corpus (f64 similarity per candidate)", ["--metric", "jaro_winkler"]),
+    ("c5_1B_cutoff3_top16_world1", "configs[4] at N = 1: 1 B candidates, score_cutoff 3, top-16, RCCL all-gather + merge every step", ["--config", "c5"]),
+]
+
+
+def extra_configs(args):
+    import subprocess
+
+    legs = []
+    for name, what, flags in EXTRA_LEGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.extra_steps), "--warmup", "2", "--extras", "off",
+               "--cpu-seconds", "2", "--settle-ms", "100", *flags]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["MASTER_PORT"] = "29577"
+        t0 = time.perf_counter()
+        leg = {"name": name, "config": what, "cmd": "python bench.py " + " ".join(cmd[2:])}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=240)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}")
+            d = json.loads(lines[-1])
+            rl = d["roofline"]
+            leg.update({"value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
+                        "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_pair", "survey_8d") if k in rl},
+                        "parity": d.get("parity"), "cpu_baseline": {k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")} if "cpu_baseline" in d else None})
+            par = d.get("parity") or {}
+            leg["summary"] = (f"{d['value']} Gpairs/s, {d['ms_per_step']} ms/step, {rl['frac']} of HBM peak"
+                              + (f" ({rl['survey_8d']['frac']} by SURVEY 8(d) bytes)" if rl.get("survey_8d", {}).get("frac") != rl["frac"] else "")
+                              + f", parity {par.get('mismatches', '?')}/{par.get('checked', '?')}")
+        except Exception as exc:  # a leg that fails is reported as failed, it never takes the headline with it
+            leg["error"] = str(exc)[:400]
+        leg["wall_s"] = round(time.perf_counter() - t0, 1)
+        legs.append(leg)
+    return legs
 
 
 def gpu_power_watts(device):

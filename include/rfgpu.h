@@ -18,6 +18,34 @@
  *
  * Threading: handles are immutable after creation and may be shared between host threads (the
  * reference's comparators are Send + Sync and take &self); each call uses the stream it is given.
+ *
+ * Environment variables.  The library reads the following variables ONCE per process (first use).  Every one of them selects
+ * between kernels / layouts / launch shapes that return IDENTICAL results -- they exist for A/B measurements and for the
+ * forced-path test runs (tests/multitile_check.py) -- and none is needed in production; the default is what ships.
+ * There is no variable that changes a result: the measurement switch that does (RF_EXP_NOHBM) is compiled only into
+ * -DRF_EXPERIMENTS builds (tools/build_stream_variant.sh), never into librfgpu.so (tests/test_abi.py checks the binary).
+ *   name                          default   meaning
+ *   RF_SCAN_BLOCKS_PER_CU         32        workgroups per CU of short-running launches (cutoff scans, band kernel, long queries)
+ *   RF_SCAN_BLOCKS_PER_CU_FULL    256       workgroups per CU of full (no-cutoff) scans
+ *   RF_STREAM                     1         0: scan_body instead of the streaming loop of the compiled scans
+ *   RF_ASM_STREAM                 1         0: compiled scans instead of the whole-kernel asm scans (rf_stream_asm.hip)
+ *   RF_ASM_CHUNK                  1         0: compiled chunk instead of the hybrid asm chunks (in-scan top-k, Jaro)
+ *   RF_ASM_BLOCK                  1         0: compiled multi-word scan instead of the asm multi-word scan (queries of 65..512 symbols)
+ *   RF_EARLY_STATIC / RF_EARLY_LEAN / RF_NARROW_LOOK / RF_HEAD_TWO_PASS / RF_HEAD_LOOK_PASS
+ *                                 1         0: the older form of the cutoff scans' first look
+ *   RF_FIRST_CHECK                0 (auto)  4..16: column of the cutoff scans' first look
+ *   RF_HEAD8_MIN                  16384     fewest tiles for which a corpus gets an 8-symbol head plane (0: never)
+ *   RF_BAND_FILTER                -1 (auto) 0 / 1: band prefilter of the head-plane scans never / whenever applicable
+ *   RF_NO_BAND                    unset     set: multi-word scan + early-out instead of the band kernel
+ *   RF_TILE_ORDER                 2         0..3: how a length-bucketed corpus' results reach original order
+ *   RF_UNSCATTER_MIN              1048576   fewest candidates for the slot-ordered temporary + gather pass
+ *   RF_GATHER_WINDOWS             1         0: gather_results_kernel instead of the window gather
+ *   RF_GATHER_SPAN / RF_GATHER_UNROLL   16384 / 8   window gather tuning
+ *   RF_TOPK_SAMPLE                1024      tiles of the in-scan top-k's bound sample (0: no sample pass)
+ *   RF_WF_REG                     1         0: LDS rows instead of register rows for generalized weights, queries <= 64
+ *   RF_TRANSLATE_DIRECT           1         0: staged translation of u32 overflow symbols
+ *   RF_NO_RENAME / RF_NO_MIXED_TILES   unset   set at PACK time: no symbol renaming / every length padded to whole tiles
+ *   RF_PACK_TIMING / RF_SELECT_DEBUG   unset   set: phase timings / selection statistics on stderr
  */
 #ifndef RFGPU_H
 #define RFGPU_H

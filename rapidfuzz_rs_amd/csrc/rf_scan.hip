@@ -860,8 +860,12 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             pn.narrow_look = narrow_look ? 1u : 0u;
             static const bool two_pass = [] { const char* e = getenv("RF_HEAD_TWO_PASS"); return !e || atoi(e) != 0; }();  // A/B: head_filter_kernel + list
             static const bool look_pass = [] { const char* e = getenv("RF_HEAD_LOOK_PASS"); return !e || atoi(e) != 0; }();  // A/B: the first look inside early_head8_kernel where the band filter does not apply
-            static const bool exp_nohbm = getenv("RF_EXP_NOHBM") != nullptr;  // measurement: every tile reads tile 0's head row (results are wrong on purpose)
+#ifdef RF_EXPERIMENTS  // measurement builds only (tools/build_stream_variant.sh): the shipping library has no switch that changes a result
+            static const bool exp_nohbm = getenv("RF_EXP_NOHBM") != nullptr;  // every tile reads tile 0's head row (results are wrong on purpose)
             pn.exp_flags = exp_nohbm ? 1u : 0u;
+#else
+            pn.exp_flags = 0u;
+#endif
             if constexpr (std::is_same<State, LevState<1>>::value || std::is_same<State, Lev32State>::value || std::is_same<State, OsaState<1>>::value ||
                           std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value) {
                 if (early_static) {

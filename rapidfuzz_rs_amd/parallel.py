@@ -62,12 +62,15 @@ def sharded_topk(scorer, shard_corpus, k: int, shard_start: int, op: int = N.OP_
     then the k-entry all-gather.  Every rank returns the same (scores, global indices).  score_hint=<expected k-th best
     distance> turns the scan into cutoff scans (see below); the result never depends on it."""
     hint = kw.pop("score_hint", None)
-    if hint is not None and op == N.OP_DISTANCE and args is None and out is None and kw.get("score_cutoff") is None:
+    # (usize-valued metrics only: the rounds below are bounded by the query length, which means nothing for Jaro's f64 distances)
+    if (hint is not None and op == N.OP_DISTANCE and args is None and out is None and kw.get("score_cutoff") is None
+            and not getattr(scorer, "FLOAT", False)):
+        kw.pop("score_cutoff", None)  # an explicit score_cutoff=None must not collide with the round's own cutoff below
         # score_hint across shards (DESIGN.md 5.4): every rank scans its shard under the cutoff `hint`; if the MERGED list holds k
         # entries they are the k best of the whole corpus, otherwise the hint doubles.  The merged list is the same on every rank, so
         # all ranks take the same branch; the bound on the rounds depends on the query alone for the same reason.
         hint, longest = int(hint), len(scorer._s1)
-        while hint * 4 <= longest:
+        while hint <= longest // 4:
             s, i = scorer.topk(shard_corpus, k, op, index_base=shard_start, score_cutoff=hint, **kw)
             ms, mi = allgather_topk(s, i, k, op, group=group, device=device)
             if len(ms) >= k:
@@ -125,16 +128,24 @@ def sharded_topk_entries(scorer, shard_corpus, k: int, shard_start: int, op: int
     import torch
     import torch.distributed as dist
 
+    import contextlib
+
     world = dist.get_world_size(group)
     dev = torch.device("cuda", shard_corpus.device)
-    local = torch.empty((k, 2), dtype=torch.int64, device=dev)
-    scorer.topk_entries_device(shard_corpus, k, local, op, index_base=shard_start, stream=stream, **kw)
-    merged = torch.empty((k, 2), dtype=torch.int64, device=dev)
-    if dist.get_backend(group) == "nccl":
-        everyone = torch.empty((world * k, 2), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(everyone, local, group=group)
-        return merge_entries_device(everyone, k, merged, stream=stream)
-    host = [torch.empty((k, 2), dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(host, local.cpu(), group=group)
-    merged.copy_(torch.from_numpy(merge_entries(torch.cat(host).numpy().view(np.uint64), k).view(np.int64)))
-    return merged
+    # The scan, the collective (or the host copy of the gloo path) and the merge must be ordered on ONE stream: torch's collectives
+    # and .cpu() order against torch's CURRENT stream, so a caller-supplied raw stream is made current for the whole sequence
+    # (with a non-current `stream` the all-gather could read `local` before the scan had written it).
+    ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)) if stream is not None else contextlib.nullcontext()
+    with ctx:
+        st = torch.cuda.current_stream(dev).cuda_stream
+        local = torch.empty((k, 2), dtype=torch.int64, device=dev)
+        scorer.topk_entries_device(shard_corpus, k, local, op, index_base=shard_start, stream=st, **kw)
+        merged = torch.empty((k, 2), dtype=torch.int64, device=dev)
+        if dist.get_backend(group) == "nccl":
+            everyone = torch.empty((world * k, 2), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(everyone, local, group=group)
+            return merge_entries_device(everyone, k, merged, stream=st)
+        host = [torch.empty((k, 2), dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(host, local.cpu(), group=group)
+        merged.copy_(torch.from_numpy(merge_entries(torch.cat(host).numpy().view(np.uint64), k).view(np.int64)))
+        return merged

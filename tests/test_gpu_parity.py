@@ -2244,3 +2244,92 @@ def test_integration_md_python_example():
     assert scorer.distance(b"sitting", score_cutoff=2) is None
     s, i = scorer.topk(corpus, k=2)
     assert (s.tolist(), i.tolist()) == ([1, 2], [1, 2])
+
+
+# ---------------------------------------------------------------- BASELINE configs[4] at its real size; real ranks when the box has them
+def test_full_size_c5_one_billion_candidates_through_the_rccl_path():
+    """BASELINE.json configs[4]'s workload at FULL size on one GPU: ONE logical corpus of 1 000 000 000 len-64
+    candidates (64 GB + the 8 GB head plane), score_cutoff 3, top-16, the k-entry all-gather through the 1-rank RCCL group and the
+    merge, every step.  The merged top-16 must be the oracle's (distance, global index) ranking of ALL planted near-duplicates -- a
+    random alphanumeric row is ~55 edits from the query, so nothing else can be within the cutoff; the test re-derives that ranking
+    itself instead of trusting the line's own parity field.  (The per-candidate form of the same scan, cutoff 3 == where(full <= 3)
+    on all 100 M candidates, is test_full_size_c2_properties item 3.)"""
+    import sys
+    import zlib
+
+    import torch
+
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 150 * 2**30:
+        pytest.skip(f"needs ~140 GB of free HBM for 1 B candidates (rows + packed tiles + head plane), this device has {free >> 30} GiB free")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = "29653"
+    d = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--config", "c5", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5"], env)
+    total_n, every, k = 1_000_000_000, 1_000_000, 16
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["rccl_ranks"] == 1 and d["config"]["candidates_per_gpu"] == total_n
+    assert "configs[4]" in d["config"]["workload"]
+    q = synth.query(64, 0xC0FFEE05)
+    pidx = synth.planted_indices(0, total_n, every)
+    assert len(pidx) == 1000
+    prow = np.stack([synth.planted_row(q, 64, int(i)) for i in pidx])
+    dist_p = o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, prow, nthreads=1, score_cutoff=3)
+    exp = sorted((int(dv) << 32) | int(i) for dv, i in zip(dist_p, pidx) if dv != np.uint64(2**64 - 1))[:k]
+    assert len(exp) == k  # (0..5 substitutions each: plenty within 3)
+    assert d["config"]["topk_found"] == k and [tuple(x) for x in d["config"]["topk_best"]] == [(e >> 32, e & 0xFFFFFFFF) for e in exp[:4]]
+    assert d["config"]["topk_checksum"] == zlib.crc32(np.array(exp, dtype=np.uint64).tobytes())
+    assert d["parity"]["mismatches"] == 0 and d["parity"]["checked"] == 1000
+    assert d["value"] > 50  # Gpairs/s: the cutoff path, not a full scan (a full scan of 1 B x 64 runs at ~45)
+
+
+def _run_ranks_script(nproc, env_extra, port):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "nccl_ranks.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_ranks_script_two_ranks_sharing_one_gpu_over_gloo():
+    """tests/nccl_ranks.py in its single-GPU stand-in mode (two ranks on GPU 0, exchange over gloo): keeps the script that the
+    multi-GPU test below runs alive on the 1-GPU boxes of this pool."""
+    d = _run_ranks_script(2, {"RF_TEST_BACKEND": "gloo", "RF_TEST_N": "600000"}, 29655)
+    assert d["ok"] and d["ranks"] == 2 and d["same_on_every_rank"] and all(d["checks"].values()), d
+    assert set(d["checks"]) == {"host_nocut", "host_cut3", "host_hint2", "entries_lev_cut3", "entries_jw"}
+
+
+def test_real_ranks_over_rccl_when_the_box_has_two_gpus():
+    """>= 2 GPUs: one rank per GPU over RCCL -- every form of the k-entry exchange (torch.distributed collectives
+    and the raw-ncclComm_t entry points rf_topk_allgather_merge[_entries]) against one scan of the whole corpus, then bench.py's own
+    multi-GPU paths: `--gpus 2` (weak scaling, exchange self-check) and `--config c5` at world sizes 1 and 2 to the same checksum.
+    Skips on the 1-GPU boxes of this pool; the first multi-GPU lease runs it."""
+    import sys
+
+    import torch
+
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip(f"needs >= 2 GPUs for real RCCL ranks, this box has {ngpu}")
+    world = 2
+    d = _run_ranks_script(world, {}, 29657)
+    assert d["ok"] and d["backend"] == "nccl" and d["gpus"] == world and d["same_on_every_rank"] and all(d["checks"].values()), d
+    assert {"raw_keys_cut3", "raw_entries_jw"} <= set(d["checks"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RF_BENCH_BACKEND")}
+    b = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--candidates", "2000000", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline"], env)
+    assert b["n_gpus"] == world and b["config"]["rccl_ranks"] == world and b["config"]["exchange_selfcheck"]["inconsistent"] == 0
+    base = [sys.executable, os.path.join(root, "bench.py"), "--config", "c5", "--total-candidates", "6000000", "--plant-every", "50000", "--steps", "3",
+            "--warmup", "1", "--cpu-seconds", "0.3"]
+    d1 = _bench_json(base, env)
+    d2 = _bench_json(base + ["--gpus", str(world)], env)
+    assert d2["n_gpus"] == world and d2["config"]["rccl_ranks"] == world and d2["parity"]["mismatches"] == 0
+    assert d2["config"]["topk_checksum"] == d1["config"]["topk_checksum"] and d2["config"]["topk_best"] == d1["config"]["topk_best"]
