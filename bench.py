@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--ragged", action="store_true",
                     help="candidate lengths uniform in [1, --cand-len] instead of one fixed length (BASELINE.json configs[0]'s 'len <= 64' "
                          "distribution at scale): the corpus is packed from host arrays into exact-length tiles + mixed tiles")
+    ap.add_argument("--min-len", type=int, default=1, help="--ragged: shortest candidate length (lengths uniform in [--min-len, --cand-len])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="after the headline's timed region, run one short leg (own process, --extra-steps steps, own roofline + oracle parity) for "
@@ -179,7 +180,7 @@ def main():
             raise SystemExit("bench.py: --ragged is a single-GPU 'many' workload")
         gen = torch.Generator(device=dev)
         gen.manual_seed(0xC0FFEE07)
-        lens = torch.randint(1, ln + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
+        lens = torch.randint(args.min_len, ln + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
         offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         offsets[1:] = torch.cumsum(lens, 0)
         flat = torch.empty(int(offsets[-1].item()), dtype=torch.uint8, device=dev)
@@ -374,7 +375,7 @@ def main():
         what += (f"{args.total_candidates} random alphanumeric len-{ln} candidates in ONE logical corpus split over {world} GPU(s), score_cutoff=3, "
                  f"top-{args.topk} + all-gather + merge every step" + (", BASELINE.json configs[4]" if args.total_candidates == 1_000_000_000 else ""))
     else:
-        what += ((f"{n} random alphanumeric candidates with lengths uniform in [1, {args.cand_len}] (mean {mean_len:.2f}) per GPU, " if args.ragged
+        what += ((f"{n} random alphanumeric candidates with lengths uniform in [{args.min_len}, {args.cand_len}] (mean {mean_len:.2f}) per GPU, " if args.ragged
                   else f"{n} random alphanumeric len-{ln} candidates per GPU, ") + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
                  + (f", weights={weights}" if weights else "")
                  + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64
@@ -395,7 +396,7 @@ def main():
         "config": {
             "workload": what,
             "candidates_per_gpu": n,
-            "candidate_len": args.cand_len if not args.ragged else f"uniform in [1, {args.cand_len}], mean {mean_len:.3f}",
+            "candidate_len": args.cand_len if not args.ragged else f"uniform in [{args.min_len}, {args.cand_len}], mean {mean_len:.3f}",
             "query_len": args.query_len,
             "queries": nq,
             "output": ("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else f"top-{args.topk} only",

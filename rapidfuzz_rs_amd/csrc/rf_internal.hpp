@@ -64,7 +64,12 @@ struct ScanParams {
     const uint32_t* mixed_orig;    // per lane: original index, kPad = no candidate
     const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w], indexed by ORIGINAL symbol
     const uint8_t* sigma;  // device uint8[256]: original symbol -> the symbol stored in the packed corpus
-    const uint8_t* heads8; // single-length corpora under a small cutoff: the candidates' first 8 symbols, tile t at t * 512 B (rf_pack.hip); nullptr = none
+    const uint8_t* heads8; // small-cutoff scans: the candidates' first 8 symbols, tile t at t * 512 B (rf_pack.hip); nullptr = none
+    // A LENGTH RUN of a length-bucketed corpus seen as a single-length corpus (rf_api.hip launch_scan_runs): tiles == nullptr, data /
+    // heads8 point at the run's first tile, tile indices and idx = t * 64 + lane are relative to it, and run_orig[idx] is the
+    // candidate's original index (kPad = padding lane).  `out` is pre-filled with None: dead tiles store nothing, survivors go
+    // through run_orig.  nullptr everywhere else.
+    const uint32_t* run_orig;
     void* out;             // uint32_t* or double*
     uint32_t n_tiles;
     uint32_t n;            // number of real candidates
@@ -158,6 +163,7 @@ int scan_max_grid();
 // results of a ragged corpus in original order without scattered stores (rf_pack.hip): slot -> slot / candidate -> slot maps, and the gather
 hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream);
 hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t tile_bytes, uint8_t* heads, hipStream_t stream);  // rf_pack.hip: the candidates' first 8 symbols
+hipError_t launch_head8_plane_tiles(const uint8_t* data, const TileDesc* tiles, uint32_t n_tiles, uint8_t* heads, hipStream_t stream);  // the same over tile descriptors
 // the coalesced gather (rf_pack.hip "window_gather_kernel"): windows of kGatherWindow original indices, at most kMaxGatherRuns runs
 constexpr uint32_t kGatherWindow = 4096;
 constexpr uint32_t kMaxGatherRuns = 512;

@@ -410,5 +410,22 @@ hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t ti
                        reinterpret_cast<uint2*>(heads));
     return hipGetLastError();
 }
+// the same over the EXACT tiles of a length-bucketed corpus (round 4): row t = the first 8 stored bytes of tile t's 64 lanes, whatever
+// the tile's length (a candidate shorter than 8 symbols contributes its zero padding -- the cutoff scans only take their first look
+// from the plane for runs of >= 16 symbols, rf_api.hip launch_scan_runs)
+__global__ __launch_bounds__(256) void head8_plane_tiles_kernel(const uint8_t* __restrict__ data, const TileDesc* __restrict__ tiles, uint32_t n_tiles,
+                                                                uint2* __restrict__ heads)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tiles; t += gridDim.x * 4)
+        heads[(size_t)t * kWave + lane] = *reinterpret_cast<const uint2*>(data + tiles[t].data_off + (size_t)lane * kChunk);
+}
+hipError_t launch_head8_plane_tiles(const uint8_t* data, const TileDesc* tiles, uint32_t n_tiles, uint8_t* heads, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(head8_plane_tiles_kernel, dim3(std::min<uint32_t>((n_tiles + 3) / 4, 65536u)), dim3(256), 0, stream, data, tiles, n_tiles,
+                       reinterpret_cast<uint2*>(heads));
+    return hipGetLastError();
+}
 
 }  // namespace rf

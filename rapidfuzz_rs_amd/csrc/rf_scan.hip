@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
                 m = __ballot(may_pass(p, fin, a.bound_first(len1, kFirst, len2)) || may_pass(p, fin, b.bound_first(len1, kFirst, len2)));
             }
             const bool alive0 = (uint32_t)m != 0, alive1 = (uint32_t)(m >> 32) != 0 && t0 + 1 < p.tile_end;
-            if (p.out) {
+            if (p.out && !p.run_orig) {  // (a length run of a bucketed corpus: `out` is pre-filled with None)
                 const bool mine_dead = lane < 32 ? !alive0 : (!alive1 && t0 + 1 < p.tile_end);
                 const uint32_t idx = t0 * kWave + 2 * lane;
                 if (mine_dead) {
@@ -442,7 +442,7 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
                 dead = __ballot(may_pass(p, fin, st.bound(len1, kChunk, len2))) == 0;
             }
             if (dead) {
-                if (p.out && valid) emit_none(p, idx);
+                if (p.out && valid && !p.run_orig) emit_none(p, idx);
             } else {
                 // a tile with a lane still in the race: the general walk (looks at every chunk end, chunks fetched on demand)
                 if constexpr (kFirst < 16) {
@@ -461,18 +461,27 @@ __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename St
                     dead = __ballot(may_pass(p, fin, st.bound(len1, j, len2))) == 0;
                 }
                 const uint32_t raw = st.result(len1, len2);
-                if (p.out && valid) {
-                    if (dead)
-                        emit_none(p, idx);
-                    else
-                        emit_fin(p, fin, raw, idx, p.out);
+                // where this lane's result goes: its index -- or, for a length run of a bucketed corpus, the candidate's original
+                // index (read here, in the rare surviving tile, not per tile)
+                uint32_t oi = idx;
+                bool real = valid;
+                if (p.run_orig) {
+                    oi = p.run_orig[idx];
+                    real = oi != kPad;
+                }
+                if (p.out && real) {
+                    if (dead) {
+                        if (!p.run_orig) emit_none(p, oi);
+                    } else {
+                        emit_fin(p, fin, raw, oi, p.out);
+                    }
                 }
                 if (topk && !dead) {
                     bool keep;
                     const uint32_t v = usize_value(p, raw, len2, &keep, len1);
-                    const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + idx);
+                    const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + oi);
                     if ((tiles_done++ & 7u) == 0) topk_refresh_bound(p, limit);
-                    if (best.offer(mine, valid && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
+                    if (best.offer(mine, real && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
                 }
             }
             if (!has_next) break;
@@ -924,6 +933,31 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
         else
             hipLaunchKernelGGL((scan_kernel_occ8<State, true>), g, b, 0, stream, p);
     } else {
+        // queries of 65 .. 256 symbols, one u32 per candidate, no cutoff: the multi-word asm scans (rf_stream_asm.hip, word planes in
+        // LDS); zero-length tiles go to the compiled kernel like above.  RF_ASM_BLOCK=0 keeps the compiled kernel for A/B.
+        static const bool use_block_asm = [] { const char* e = getenv("RF_ASM_BLOCK"); return !e || atoi(e) != 0; }();
+        constexpr bool kLevW = std::is_same<State, LevState<2>>::value || std::is_same<State, LevState<3>>::value || std::is_same<State, LevState<4>>::value;
+        if (kLevW && use_block_asm && stream_asm_serves(p)) {
+            uint32_t at = p.tile_begin;
+            for (int r = 0; r <= 2 && at < p.tile_end; ++r) {
+                const uint32_t zb = r < 2 ? std::min(std::max(p.zero_begin[r], at), p.tile_end) : p.tile_end;
+                const uint32_t ze = r < 2 ? std::min(std::max(p.zero_end[r], zb), p.tile_end) : p.tile_end;
+                if (r < 2 && p.zero_end[r] <= p.zero_begin[r]) continue;  // no such run
+                if (zb > at) {
+                    ScanParams q = p;
+                    q.tile_begin = at, q.tile_end = zb;
+                    const hipError_t e = launch_stream_asm(3, q, stream, std::max(1, scan_grid_full(zb - at)));
+                    if (e != hipSuccess) return e;
+                }
+                if (ze > zb) {
+                    ScanParams q = p;
+                    q.tile_begin = zb, q.tile_end = ze;
+                    hipLaunchKernelGGL((scan_kernel<State, false>), dim3(std::max(1, scan_grid(ze - zb))), b, 0, stream, q);
+                }
+                at = ze;
+            }
+            return hipGetLastError();
+        }
         if (p.tiles)
             hipLaunchKernelGGL((scan_kernel<State, false>), g, b, 0, stream, p);
         else

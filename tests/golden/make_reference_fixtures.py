@@ -6,7 +6,9 @@ Run once in the build container (needs /root/reference); the outputs are committ
                                          (expected Levenshtein distance 5278, levenshtein.rs:2139-2161)
   jaro_table.json                        names + 20x20 expected similarities (jaro.rs:1094-1141)
   jaro_winkler_table.json                names + 22x22 expected similarities (jaro_winkler.rs:693-770)
-Only numbers and string literals are extracted -- no reference code.
+  reference_api_surface.json             the NAMES of the public items of the modules on the batch path (free functions,
+                                         BatchComparator methods, Args builders): what the Rust companion crate must offer
+Only numbers, string literals and item names are extracted -- no reference code.
 """
 import json
 import os
@@ -41,7 +43,37 @@ def table(src, out):
     print(out, len(names), "names", len(scores), "scores")
 
 
+def api_surface():
+    """names of `pub fn` items: module level, and per `impl` of a public type (levenshtein.rs:1380-1817 and its siblings, fuzz.rs:8-150)"""
+    mods = {"distance::levenshtein": "src/distance/levenshtein.rs", "distance::indel": "src/distance/indel.rs", "distance::lcs_seq": "src/distance/lcs_seq.rs",
+            "distance::osa": "src/distance/osa.rs", "distance::jaro": "src/distance/jaro.rs", "distance::jaro_winkler": "src/distance/jaro_winkler.rs", "fuzz": "src/fuzz.rs"}
+    out = {}
+    for mod, src in mods.items():
+        txt = open(os.path.join(REF, src)).read()
+        txt = txt.split("#[cfg(test)]")[0]
+        free, methods = [], {}
+        cur, depth, impl_depth = None, 0, None
+        for line in txt.splitlines():
+            m = re.match(r"\s*impl(?:<[^>]*>)?\s+(?:\w+\s+for\s+)?(\w+)", line)
+            if m and depth == 0:
+                cur, impl_depth = m.group(1), depth
+            f = re.match(r"\s*pub fn (\w+)", line)
+            if f:
+                if cur is not None and depth > 0:
+                    methods.setdefault(cur, []).append(f.group(1))
+                elif depth == 0:
+                    free.append(f.group(1))
+            depth += line.count("{") - line.count("}")
+            if cur is not None and depth == 0 and "}" in line:
+                cur = None
+        out[mod] = {"free_functions": sorted(set(free)), "methods": {k: sorted(set(v)) for k, v in methods.items() if k in ("BatchComparator", "RatioBatchComparator", "Args")}}
+    json.dump({"source": "pub fn item names of rapidfuzz-rs v0.5.0, extracted by tests/golden/make_reference_fixtures.py", "modules": out},
+              open(os.path.join(OUT, "reference_api_surface.json"), "w"), indent=1, sort_keys=True)
+    print("reference_api_surface.json", {k: (len(v["free_functions"]), {t: len(ms) for t, ms in v["methods"].items()}) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     ocr()
     table("src/distance/jaro.rs", "jaro_table.json")
     table("src/distance/jaro_winkler.rs", "jaro_winkler_table.json")
+    api_surface()

@@ -76,6 +76,20 @@ def check(tag, corpus, host=None, ragged=None):
             failures += len(bad_ops)
 
 
+    # multi-word Levenshtein (queries of 65 .. 256 symbols: the W = 2 / 4 / 4-word asm scans of rf_stream_asm.hip; round 4)
+    for len1 in (100, 200, 256):
+        q = QUERIES[len1]
+        bc, ob = GPU["levenshtein"].BatchComparator(q), ORA["levenshtein"].BatchComparator(q)
+        bad_ops = []
+        for opname, op in OPS.items():
+            got = bc.many(op, corpus)
+            exp = ob.rows(op, host, nthreads=8) if host is not None else ob.many(op, ragged[0], ragged[1], nthreads=8)
+            bad = same(got, exp)
+            if len(bad):
+                bad_ops.append((opname, len(bad), bad[:4].tolist(), got[bad[:4]].tolist(), exp[bad[:4]].tolist()))
+        print(f"{tag} len1={len1} levenshtein (multi-word): {'ok' if not bad_ops else bad_ops}", flush=True)
+        failures += len(bad_ops)
+
     # four queries fused per pass (scan_multi_kernel): 64-bit and 32-bit Levenshtein, LCS-family
     for metric, len1 in (("levenshtein", 64), ("levenshtein", 20), ("indel", 64)):
         base = QUERIES[len1]
@@ -95,13 +109,16 @@ def check(tag, corpus, host=None, ragged=None):
 
 rng = np.random.default_rng(20260929)
 QUERIES = {64: bytes(rng.integers(48, 123, size=64, dtype=np.uint8)), 20: bytes(rng.integers(97, 123, size=20, dtype=np.uint8))}
+for _len1 in (100, 200, 256):  # (a separate generator: the corpora below stay what they were)
+    QUERIES[_len1] = bytes(np.random.default_rng(_len1).integers(48, 123, size=_len1, dtype=np.uint8))
 n = int(os.environ.get("RF_MULTITILE_N", "300007"))
 mode = sys.argv[1] if len(sys.argv) > 1 else "rows"
 if mode == "rows":
-    for len2 in (16, 32, 48, 64, 96, 160):
-        host = rng.integers(48, 123, size=(n, len2), dtype=np.uint8)
+    for len2 in (16, 32, 48, 64, 96, 160, 250):
+        host = rng.integers(48, 123, size=(n if len2 < 200 else n // 3, len2), dtype=np.uint8)
         plant(rng, host, QUERIES[64], 997)
         plant(rng, host[500:], QUERIES[20], 991)
+        plant(rng, host[250:], QUERIES[200], 1993)
         corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
         check(f"rows len2={len2}", corpus, host=host)
         del corpus

@@ -57,6 +57,13 @@ K["and2_nop_lshladd_nop"] = rep([x for i in range(4) for x in (f"v_and_b32 v{16 
 K["and2_lshladd_otherregs"] = rep([x for i in range(4) for x in (f"v_and_b32 v{16 + i}, v1, v2", f"v_and_b32 v{20 + i}, v3, v5", f"v_lshl_add_u64 v[{24 + 2 * i}:{25 + 2 * i}], v[8:9], 1, v[12:13]")], 255)
 K["bitop3x2_lshladd"] = rep([x for i in range(4) for x in (f"v_bitop3_b32 v{16 + i}, v1, v6, v11 bitop3:0x96", f"v_bitop3_b32 v{20 + i}, v2, v7, v10 bitop3:0x96", f"v_lshl_add_u64 v[{24 + 2 * i}:{25 + 2 * i}], v[0:1], 1, v[4:5]")], 255)
 
+K["e64and2_lshladd"] = rep([x for i in range(4) for x in (f"v_and_b32_e64 v{16 + i}, v1, v6", f"v_and_b32_e64 v{20 + i}, v2, v7", f"v_lshl_add_u64 v[{24 + 2 * i}:{25 + 2 * i}], v[0:1], 1, v[6:7]")], 255)
+K["and2_sdwa"] = rep([x for i in range(4) for x in (f"v_and_b32 v{16 + i}, v1, v6", f"v_and_b32 v{20 + i}, v2, v7", f"v_lshlrev_b32_sdwa v{24 + i}, v1, v6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{i % 4}")], 255)
+K["and2_lshlrev"] = rep([x for i in range(4) for x in (f"v_and_b32 v{16 + i}, v1, v6", f"v_and_b32 v{20 + i}, v2, v7", f"v_lshlrev_b32 v{24 + i}, 3, v6")], 255)
+K["bitop3x4_lshladd"] = rep([x for i in range(4) for x in (f"v_bitop3_b32 v{16 + i}, v1, v6, v11 bitop3:0x96", f"v_bitop3_b32 v{20 + i}, v2, v7, v10 bitop3:0x96", f"v_bitop3_b32 v{16 + i}, v3, v5, v11 bitop3:0x96", f"v_bitop3_b32 v{20 + i}, v1, v7, v9 bitop3:0x96", f"v_lshl_add_u64 v[{24 + 2 * i}:{25 + 2 * i}], v[0:1], 1, v[4:5]")], 255)
+K["and_bitop3_lshladd"] = rep([x for i in range(4) for x in (f"v_and_b32 v{16 + i}, v1, v6", f"v_bitop3_b32 v{20 + i}, v2, v7, v10 bitop3:0x96", f"v_lshl_add_u64 v[{24 + 2 * i}:{25 + 2 * i}], v[0:1], 1, v[4:5]")], 255)
+K["bitop3_and_lshladd"] = rep([x for i in range(4) for x in (f"v_bitop3_b32 v{20 + i}, v2, v7, v10 bitop3:0x96", f"v_and_b32 v{16 + i}, v1, v6", f"v_lshl_add_u64 v[{24 + 2 * i}:{25 + 2 * i}], v[0:1], 1, v[4:5]")], 255)
+
 # the Levenshtein column of rf_stream_asm (tools/gen_stream_asm.py lev64), pattern words register-resident (v[34:35] ...), no LDS
 VP, VN, A, E, HN, HP, T = (60, 61), (62, 63), (58, 59), (56, 57), (54, 55), (52, 53), (50, 51)
 
@@ -65,14 +72,15 @@ def pr(r):
     return f"v[{r[0]}:{r[1]}]"
 
 
-def column(i, nop_mask, sdwa=True):
+def column(i, nop_mask, sdwa=True, vop3=False, order=None):
     PM = (34 + 2 * (i % 8), 35 + 2 * (i % 8))
+    AND = (lambda d, a, b: f"v_bitop3_b32 v{d}, v{a}, v{b}, v{b} bitop3:0xc0") if vop3 else (lambda d, a, b: f"v_and_b32 v{d}, v{a}, v{b}")
     toks = [
-        [f"v_and_b32 v{A[h]}, v{PM[h]}, v{VP[h]}" for h in (0, 1)],
+        [AND(A[h], PM[h], VP[h]) for h in (0, 1)],
         [f"v_lshl_add_u64 {pr(A)}, {pr(A)}, 0, {pr(VP)}"],
         [f"v_bitop3_b32 v{E[h]}, v{A[h]}, v{VP[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],
         [f"v_bitop3_b32 v{HP[h]}, v{VN[h]}, v{E[h]}, v{VP[h]} bitop3:0xf1" for h in (0, 1)],
-        [f"v_and_b32 v{HN[h]}, v{E[h]}, v{VP[h]}" for h in (0, 1)],
+        [AND(HN[h], E[h], VP[h]) for h in (0, 1)],
         [f"v_lshl_add_u64 {pr(HP)}, {pr(HP)}, 1, 1"],
         [f"v_bitop3_b32 v{T[h]}, v{E[h]}, v{VN[h]}, v{HP[h]} bitop3:0x01" for h in (0, 1)],
         [f"v_bitop3_b32 v{VN[h]}, v{HP[h]}, v{E[h]}, v{VN[h]} bitop3:0xe0" for h in (0, 1)],
@@ -122,15 +130,18 @@ def cols2(mask, n=8):
     return L
 
 
-def cols(mask, sdwa=True, n=16):
+def cols(mask, sdwa=True, n=16, vop3=False):
     L = []
     for i in range(n):
-        L += column(i, mask, sdwa)
+        L += column(i, mask, sdwa, vop3)
     return L
 
 
 # (name -> (lines, number of VALU instructions in them)); the column kernels count VALU only
 COLS = {"levcol_nonop": cols(0), "levcol_mask1B3": cols(0x1B3), "levcol_mask122": cols(0x122), "levcol_nosdwa_1B3": cols(0x1B3, False),
+        "levcol3_nonop": cols(0, vop3=True), "levcol3_1B3": cols(0x1B3, vop3=True), "levcol3_122": cols(0x122, vop3=True), "levcol3_022": cols(0x022, vop3=True),
+        "levcol3_1A2": cols(0x1A2, vop3=True), "levcol3_0A2": cols(0x0A2, vop3=True), "levcol3_102": cols(0x102, vop3=True), "levcol3_002": cols(0x002, vop3=True),
+        "levcol3_020": cols(0x020, vop3=True), "levcol3_100": cols(0x100, vop3=True), "levcol3_1B2": cols(0x1B2, vop3=True), "levcol3_0B3": cols(0x0B3, vop3=True),
         "lev2col_nonop": cols2(0), "lev2col_mask022": cols2(0x022), "lev2col_mask122": cols2(0x122), "lev2col_mask1B3": cols2(0x1B3)}
 
 clob = ",".join(f'"v{i}"' for i in range(0, 96)) + ',"vcc","scc","s20","s21"'
@@ -205,7 +216,7 @@ int main(int argc, char** argv)
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0); g_cus = p.multiProcessorCount;
     printf("device %s, %d CUs; s_memtime ticks per wavefront around %d x 2000 instructions\\n", p.gcnArchName, g_cus, ''' + str(N) + ''');
     uint64_t* d; (void)hipMalloc(&d, 8 * 3 * 4 * 256 * 16);
-    for (int w : {2, 4, 8}) {''')
+    for (int w : {4, 8}) {''')
 for name, (lines, nv) in ALL.items():
     src.append(f'        run("{name}", k_{name}, d, {nv}, w);')
 src.append("    }\n    return 0;\n}")

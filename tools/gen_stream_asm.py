@@ -37,7 +37,7 @@ ADDR = [30, 31, 32, 33]
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
         ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
-        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4)]
+        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4), ("pad0", 4), ("valid_w", 32), ("pad1", 4)]  # valid_w: (lo, hi) row masks of words 0..3 (multi-word kernels)
 # SGPR map
 S_DATA, S_TILES, S_ORIG, S_PM, S_SIGMA, S_OUT = "s[8:9]", "s[10:11]", "s[12:13]", "s[14:15]", "s[16:17]", "s[18:19]"
 (S_TBEGIN, S_TEND, S_N, S_ULEN, S_UBYTES, S_LEN1, S_VS, S_VM, S_VR, S_FLIP, S_CFLIP, S_VLO) = [f"s{i}" for i in range(20, 32)]
@@ -134,6 +134,67 @@ class Kind:
                 "v_mov_b32 v48, 0", "v_mov_b32 v49, 0"]
 
 
+class BlockKind(Kind):
+    """Levenshtein for queries of 65 .. 256 symbols: W = 2 .. 4 words per column with the horizontal carries of advance_block
+    (levenshtein.rs:838-875) between them; rf_device.hpp LevState<W>::step is the compiled form.  Round 4 (VERDICT r3 #3).
+      * pattern table in LDS as W word PLANES of 2 KiB (plane w at w * 2048, row sigma(c) * 8): a column's row is W ds_read_b64 of
+        one address + immediate plane offsets, each with the 2-way conflicts of the single-word gather -- the compiled kernels'
+        32-byte rows (2 ds_read_b128) put 62 symbols on 8 row positions of the 64 banks: 72 % of their LDS cycles were conflicts;
+      * two row slots (2 x 2W VGPRs), look-ahead of 2 columns; chunk ring of 2 (a chunk is 16 x ~230 cycles: one load ahead is plenty);
+      * carries as values: hp_c in the low half of a register pair whose high half stays zero (the addend of v_lshl_add_u64),
+        hn_c OR-ed into the next word's table row and into T's low half (VP' = (HN << 1) + (T | hn_c): bit 0 of T is clear there);
+      * 64 VGPRs = 8 wavefronts per SIMD: v14..21 ring, v22..23 gather addresses, v24..39 row slots, v40..47 VP, v48..55 VN,
+        v56..63 A E HN HP, v6..7 T, v[8:9] / v[12:13] carry pairs, v11 / v3 hn_c."""
+    TOKENS = "x a S e hp hn hnc hpc hq t tor vn vp".split()
+
+    def __init__(self, W, nop_mask):
+        Kind.__init__(self, f"levw{W}", 64, 2, [14, 18], range(40, 56), nop_mask)
+        self.W = W
+        self.addr = [22, 23]
+        self.slots = [[(24 + 8 * sl + 2 * w, 25 + 8 * sl + 2 * w) for w in range(W)] for sl in range(2)]
+        self.VP = [(40 + 2 * w, 41 + 2 * w) for w in range(W)]
+        self.VN = [(48 + 2 * w, 49 + 2 * w) for w in range(W)]
+
+    def gather(self, j, use, nxt):
+        src = use + (j // 4) if j < 16 else nxt + ((j - 16) // 4)
+        a = self.addr[j % 2]
+        x = f"v_lshlrev_b32_sdwa v{a}, {V_KS}, v{src} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{j % 4}"
+        return [x] + [f"ds_read_b64 {pr(self.slots[j % 2][w])}, v{a}" + (f" offset:{2048 * w}" if w else "") for w in range(self.W)]
+
+    def column(self, i):
+        W = self.W
+        A_, E_, HN_, HP_, T_ = (56, 57), (58, 59), (60, 61), (62, 63), (6, 7)
+        HPC, HNC = [(8, 9), (12, 13)], [11, 3]
+        R = self.slots[i % 2]
+        L = [f"s_waitcnt lgkmcnt({W})"]  # this column's W reads have arrived; the next column's W may still be in flight
+        for w in range(W):
+            VP_, VN_, PM = self.VP[w], self.VN[w], R[w]
+            ops = {"x": [f"v_or_b32 v{PM[0]}, v{HNC[(w - 1) % 2]}, v{PM[0]}"] if w else [],                                  # x |= hn_c (levenshtein.rs:847)
+                   "a": [f"v_and_b32 v{A_[h]}, v{PM[h]}, v{VP_[h]}" for h in (0, 1)],
+                   "S": [f"v_lshl_add_u64 {pr(A_)}, {pr(A_)}, 0, {pr(VP_)}"],
+                   "e": [f"v_bitop3_b32 v{E_[h]}, v{A_[h]}, v{VP_[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],
+                   "hp": [f"v_bitop3_b32 v{HP_[h]}, v{VN_[h]}, v{E_[h]}, v{VP_[h]} bitop3:0xf1" for h in (0, 1)],
+                   "hn": [f"v_and_b32 v{HN_[h]}, v{E_[h]}, v{VP_[h]}" for h in (0, 1)],
+                   "hnc": [f"v_lshrrev_b32 v{HNC[w % 2]}, 31, v{HN_[1]}"] if w + 1 < W else [],                            # :857-858
+                   "hpc": [f"v_lshrrev_b32 v{HPC[w % 2][0]}, 31, v{HP_[1]}"] if w + 1 < W else [],
+                   "hq": [f"v_lshl_add_u64 {pr(HP_)}, {pr(HP_)}, 1, " + ("1" if w == 0 else pr(HPC[(w - 1) % 2]))],      # :865-866
+                   "t": [f"v_bitop3_b32 v{T_[h]}, v{E_[h]}, v{VN_[h]}, v{HP_[h]} bitop3:0x01" for h in (0, 1)],
+                   "tor": [f"v_or_b32 v{T_[0]}, v{HNC[(w - 1) % 2]}, v{T_[0]}"] if w else [],
+                   "vn": [f"v_bitop3_b32 v{VN_[h]}, v{HP_[h]}, v{E_[h]}, v{VN_[h]} bitop3:0xe0" for h in (0, 1)],
+                   "vp": [f"v_lshl_add_u64 {pr(VP_)}, {pr(HN_)}, 1, {pr(T_)}"]}
+            for j, tok in enumerate(self.TOKENS):
+                L += ops[tok]
+                if ops[tok] and self.nop_mask >> j & 1:
+                    L.append("s_nop 0")
+        return L
+
+    def state_init(self):  # levenshtein.rs:454-455 per word; the carry pairs' high halves are zero for the whole tile
+        L = []
+        for w in range(self.W):
+            L += [f"v_mov_b32 v{self.VP[w][0]}, -1", f"v_mov_b32 v{self.VP[w][1]}, -1", f"v_mov_b32 v{self.VN[w][0]}, 0", f"v_mov_b32 v{self.VN[w][1]}, 0"]
+        return L + ["v_mov_b32 v9, 0", "v_mov_b32 v13, 0"]
+
+
 def dispatch(lo, hi, L, sfx):  # binary tree of scalar compares over k in [lo, hi]
     if lo == hi:
         L.append(f"s_branch Ls{lo}_{sfx}")
@@ -217,8 +278,11 @@ def tile_start(K, uniform, sfx):
     if uniform:
         L.append(f"v_lshl_add_u32 {V_IDX}, {S_T}, 6, {V_LANE}")  # slot = index
     else:  # idx = orig[slot0 + lane]: lands long before the tile's epilogue (the next step's counted vmcnt wait is younger)
-        L += [f"s_lshl_b32 {T0}, {S_SLOT0}, 2", f"s_lshr_b32 {T1}, {S_SLOT0}, 30", f"s_add_u32 {T2}, s12, {T0}", f"s_addc_u32 {T3}, s13, {T1}",
-              f"global_load_dword {V_IDX}, {V_OFF4}, s[54:55]"]
+        L += [f"s_lshl_b32 {T0}, {S_SLOT0}, 2", f"s_lshr_b32 {T1}, {S_SLOT0}, 30", f"s_add_u32 {T2}, s12, {T0}", f"s_addc_u32 {T3}, s13, {T1}"]
+        if getattr(K, "W", 1) > 1:  # (v3 carries hn_c there: lane * 4 is made on the spot)
+            L += [f"v_lshlrev_b32 v6, 2, {V_LANE}", f"global_load_dword {V_IDX}, v6, s[54:55]"]
+        else:
+            L.append(f"global_load_dword {V_IDX}, {V_OFF4}, s[54:55]")
     return L + K.state_init()
 
 
@@ -235,12 +299,20 @@ def kernel(K, uniform):
           f"s_load_dwordx8 s[20:27], %[kp], {off['tile_begin']}", f"s_load_dwordx4 s[28:31], %[kp], {off['fin_vR']}",
           f"s_load_dwordx2 s[68:69], %[kp], {off['valid_hi']}", f"s_mov_b32 {S_STRIDE}, %[stride]",
           # ---- stage the pattern table: thread i puts row i at row sigma(i) (the corpus stores renamed symbols)
-          "v_and_b32 v1, 0x3ff, %[tid]", "s_waitcnt lgkmcnt(0)",
-          f"global_load_ubyte v6, v1, {S_SIGMA}", "v_lshlrev_b32 v7, 3, v1",
-          f"global_load_dwordx2 v[8:9], v7, {S_PM}" if K.bits == 64 else f"global_load_dword v8, v7, {S_PM}",
-          "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6",
-          "ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8",
-          "s_waitcnt lgkmcnt(0)", "s_barrier",
+          "v_and_b32 v1, 0x3ff, %[tid]", "s_waitcnt lgkmcnt(0)"]
+    W = getattr(K, "W", 1)
+    if W == 1:
+        L += [f"global_load_ubyte v6, v1, {S_SIGMA}", "v_lshlrev_b32 v7, 3, v1",
+              f"global_load_dwordx2 v[8:9], v7, {S_PM}" if K.bits == 64 else f"global_load_dword v8, v7, {S_PM}",
+              "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6",
+              "ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
+    else:  # row i of the host table (W consecutive words) -> word w to plane w, row sigma(i)
+        L += [f"s_load_dwordx8 s[72:79], %[kp], {off['valid_w']}",
+              f"global_load_ubyte v6, v1, {S_SIGMA}", f"v_mul_u32_u24 v7, {8 * W}, v1"]
+        L += [f"global_load_dwordx2 v[{24 + 2 * w}:{25 + 2 * w}], v7, {S_PM}" + (f" offset:{8 * w}" if w else "") for w in range(W)]
+        L += ["s_waitcnt vmcnt(0)", "v_lshlrev_b32 v6, 3, v6"]
+        L += [f"ds_write_b64 v6, v[{24 + 2 * w}:{25 + 2 * w}]" + (f" offset:{2048 * w}" if w else "") for w in range(W)]
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier",
           # ---- lane constants, first tile of this wavefront
           f"v_readfirstlane_b32 {T0}, v1", f"s_lshr_b32 {T0}, {T0}, 6",  # wavefront within the workgroup
           "v_and_b32 v1, 63, v1", "v_lshlrev_b32 v2, 4, v1", "v_lshlrev_b32 v3, 2, v1", "v_mov_b32 v5, 0", f"v_mov_b32 {V_KS}, {K.ks}",
@@ -291,7 +363,13 @@ def kernel(K, uniform):
             L += [f"s_cbranch_scc1 Lphase0_%=", f"s_mov_b32 {S_NEXT}, 0"]  # falls into the epilogue
     # ---- tile epilogue
     L.append("Lepi_%=:")
-    if K.bits == 64:
+    if W > 1:  # D[len1][len2] = len2 + sum over the words of popcount(VP & valid_w) - popcount(VN & valid_w)
+        L += ["v_mov_b32 v6, 0", "v_mov_b32 v7, 0"]
+        for w in range(W):
+            for h in (0, 1):
+                L += [f"v_and_b32 v8, s{72 + 2 * w + h}, v{K.VP[w][h]}", "v_bcnt_u32_b32 v6, v8, v6",
+                      f"v_and_b32 v8, s{72 + 2 * w + h}, v{K.VN[w][h]}", "v_bcnt_u32_b32 v7, v8, v7"]
+    elif K.bits == 64:
         L += [f"v_and_b32 v6, {S_VLO}, v60", "v_bcnt_u32_b32 v6, v6, 0", f"v_and_b32 v7, {S_VHI}, v61", "v_bcnt_u32_b32 v6, v7, v6",
               f"v_and_b32 v7, {S_VLO}, v62", "v_bcnt_u32_b32 v7, v7, 0", f"v_and_b32 v8, {S_VHI}, v63", "v_bcnt_u32_b32 v7, v8, v7"]
     else:
@@ -330,7 +408,7 @@ KINDS = [
     Kind("lev64", 64, 8, [14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RING64", "3")):], range(60, 64), int(os.environ.get("RF_GEN_MASK64", "0x1B3"), 0)),  # (RF_GEN_*: experiment knobs, tools/build_stream_variant.sh)
     Kind("lev32", 32, 8, [42, 46, 22, 26][: int(os.environ.get("RF_GEN_RING32", "4"))], (60, 61), int(os.environ.get("RF_GEN_MASK32", "0x80"), 0)),
     Kind("osa", 64, 7, RING3, range(58, 64), 0x613),
-]
+] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x1126"), 0)) for W in (2, 3, 4)]  # s_nop behind S, e, hq, vp (hipcc's placement around its own v_lshl_add_u64)
 
 
 def main():
@@ -341,7 +419,7 @@ def main():
         out.append(f"#define RF_STREAM_ARG_{name.upper()} {o}")
         o += size
     out.append(f"#define RF_STREAM_ARGS_SIZE {o}")
-    out.append('#define RF_STREAM_CLOBBERS ' + ", ".join(f'"v{r}"' for r in range(1, 64)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 72) if r != 32)
+    out.append('#define RF_STREAM_CLOBBERS ' + ", ".join(f'"v{r}"' for r in range(1, 64)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 80) if r != 32)
                + ', "vcc", "scc", "memory"')  # (exec is restored to all ones before the body ends)
     for K in KINDS:
         for uniform in (True, False):
