@@ -224,7 +224,10 @@ def step(K, P, extra):
     L = [f"global_load_dwordx4 v[{refill}:{refill + 3}], {V_OFF16}, {S_SRC} nt",  # the chunk RING-1 steps ahead
          f"s_cmp_eq_u32 {S_K}, 0", f"s_cbranch_scc1 Lfull_{sfx}"]
     # ---- a tile's last, partial chunk: shift its bytes up by k positions in place, gather its rows, enter at column k
-    L += wait_vm(R - 2, extra, "t", sfx)  # this chunk and the next one have arrived (only younger operations may still be out)
+    # (a ring of 2 fetches the NEXT chunk at the top of this very step: that load is younger than the epilogue's store and index load,
+    # so nothing may be counted in -- the wait is a drain)
+    late = extra if R > 2 else 0
+    L += wait_vm(R - 2, late, "t", sfx)  # this chunk and the next one have arrived (only younger operations may still be out)
     L.append(f"s_mov_b32 {S_AFTER}, 0")
     u = [use + i for i in range(4)]
     L += [f"s_cmp_eq_u32 {S_R8}, 0", f"s_cbranch_scc1 Lq_{sfx}",
@@ -248,7 +251,7 @@ def step(K, P, extra):
     L += wait_vm(R - 1, extra, "f", sfx)  # this chunk's dwords 2, 3 are about to be read
     for i in range(16):
         if i == 8:
-            L += wait_vm(R - 2, extra, "h", sfx)  # from here on the look-ahead reads the NEXT chunk's dwords 0, 1
+            L += wait_vm(R - 2, late, "h", sfx)  # from here on the look-ahead reads the NEXT chunk's dwords 0, 1
             L.append(f"s_mov_b32 {S_AFTER}, 0")
         L.append(f"Lc{i}_{sfx}:")
         L += K.column(i)
@@ -408,7 +411,7 @@ KINDS = [
     Kind("lev64", 64, 8, [14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RING64", "3")):], range(60, 64), int(os.environ.get("RF_GEN_MASK64", "0x1B3"), 0)),  # (RF_GEN_*: experiment knobs, tools/build_stream_variant.sh)
     Kind("lev32", 32, 8, [42, 46, 22, 26][: int(os.environ.get("RF_GEN_RING32", "4"))], (60, 61), int(os.environ.get("RF_GEN_MASK32", "0x80"), 0)),
     Kind("osa", 64, 7, RING3, range(58, 64), 0x613),
-] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x1126"), 0)) for W in (2, 3, 4)]  # s_nop behind S, e, hq, vp (hipcc's placement around its own v_lshl_add_u64)
+] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x0826"), 0)) for W in (2, 3, 4)]  # s_nop behind a, S, hn, vn: best of 22 placements (profiles/levw_nop_masks_r04.txt)
 
 
 def main():
