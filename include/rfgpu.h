@@ -45,7 +45,10 @@
  *   RF_WF_REG                     1         0: LDS rows instead of register rows for generalized weights, queries <= 64
  *   RF_TRANSLATE_DIRECT           1         0: staged translation of u32 overflow symbols
  *   RF_NO_RENAME / RF_NO_MIXED_TILES   unset   set at PACK time: no symbol renaming / every length padded to whole tiles
- *   RF_PACK_TIMING / RF_SELECT_DEBUG   unset   set: phase timings / selection statistics on stderr
+ *   RF_RUN_MIN_TILES              256       fewest tiles of one length for which a small-cutoff scan of a length-bucketed corpus walks
+ *                                           that length run as a single-length view (head plane, band prefilter)
+ *   RF_PACK_TIMING / RF_SELECT_DEBUG / RF_TRACE_PLAN   unset   set: phase timings / selection statistics / one line per rf_many_* call
+ *                                           naming the path its plan took, on stderr
  */
 #ifndef RFGPU_H
 #define RFGPU_H

@@ -1148,7 +1148,29 @@ void rf_corpus_free(rf_corpus* c)
 
 size_t rf_corpus_count(const rf_corpus* c) { return c->n; }
 uint64_t rf_corpus_payload_bytes(const rf_corpus* c) { return c->payload_bytes; }
-uint64_t rf_corpus_device_bytes(const rf_corpus* c) { return c->device_bytes; }
+// the packed corpus + every acceleration structure built beside it so far (head plane, tile lists, the gather path's maps and kept
+// temporaries -- DESIGN.md 4): what the handle holds in HBM right now
+uint64_t rf_corpus_device_bytes(const rf_corpus* c)
+{
+    if (!c) return 0;
+    uint64_t aux = 0;
+    {
+        std::lock_guard<std::mutex> lock(c->scratch_mu);
+        if (c->d_heads8) aux += ((uint64_t)(c->uniform ? c->n_tiles : c->n_exact) + 1) * kWave * 8;
+        if (c->d_slot_ident) aux += (uint64_t)c->n_slots * sizeof(uint32_t);
+        if (c->d_slot_of) aux += (uint64_t)c->n * sizeof(uint32_t);
+        if (c->d_window_table) aux += (uint64_t)c->gather_rows * c->gather_runs * sizeof(uint32_t);
+    }
+    {
+        std::lock_guard<std::mutex> lock(c->gather_enqueue_mu);
+        for (const rf_corpus::GatherTmp& t : c->gather_tmp) aux += t.bytes;
+    }
+    {
+        std::lock_guard<std::mutex> lock(c->filter_enqueue_mu);
+        aux += (uint64_t)c->tile_lists.size() * (2 * (uint64_t)c->n_tiles + 5 * 16384 + 8) * sizeof(uint32_t);
+    }
+    return c->device_bytes + aux;
+}
 int rf_corpus_device(const rf_corpus* c) { return c->device; }
 size_t rf_corpus_alphabet_size(const rf_corpus* c, size_t* overflow_symbols)
 {
@@ -1612,16 +1634,30 @@ static void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf
 // scan then filters inside the cutoff kernel
 static uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
 {
-    for (const rf_corpus::TileList& t : corpus->tile_lists)
-        if (t.stream == st) return t.ptr;
-    if (corpus->tile_lists.size() >= 4) return nullptr;
+    for (size_t i = 0; i < corpus->tile_lists.size(); ++i)
+        if (corpus->tile_lists[i].stream == st) {  // most recently used first
+            const rf_corpus::TileList hit = corpus->tile_lists[i];
+            corpus->tile_lists.erase(corpus->tile_lists.begin() + (long)i);
+            corpus->tile_lists.insert(corpus->tile_lists.begin(), hit);
+            return hit.ptr;
+        }
+    if (corpus->tile_lists.size() >= 4) {
+        // a fifth stream: the least recently used list changes hands instead of the scan silently falling back to the slower
+        // in-kernel filter.  Its old stream's work is waited for first -- rare, and only then.
+        rf_corpus::TileList lru = corpus->tile_lists.back();
+        corpus->tile_lists.pop_back();
+        (void)hipStreamSynchronize(lru.stream);
+        lru.stream = st;
+        corpus->tile_lists.insert(corpus->tile_lists.begin(), lru);
+        return lru.ptr;
+    }
     uint32_t* ptr = nullptr;
     // (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the packed list)
     if (hipMalloc((void**)&ptr, (2 * (size_t)corpus->n_tiles + 5 * 16384 + 8) * sizeof(uint32_t)) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    corpus->tile_lists.push_back({st, ptr});
+    corpus->tile_lists.insert(corpus->tile_lists.begin(), {st, ptr});
     return ptr;
 }
 
@@ -1816,19 +1852,22 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
                 if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);  // (other streams may use the maps as soon as the lock is released)
                 if (list) (void)hipFree(list);
                 if (e1 != hipSuccess) {
+                    // Not an error: an HBM-tight caller keeps what round 2 gave it -- the launch below stores straight
+                    // through orig[] (scattered, slower, same values).  The next call tries again.
                     if (so) (void)hipFree(so);
                     if (si) (void)hipFree(si);
                     if (table) (void)hipFree(table);
-                    if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
-                    RF_HIP(e1);
+                    (void)hipGetLastError();
+                } else {
+                    corpus->d_slot_of = so;
+                    corpus->d_window_table = table;
+                    corpus->gather_runs = n_runs;
+                    corpus->gather_rows = n_rows;
+                    corpus->d_slot_ident = si;
                 }
-                corpus->d_slot_of = so;
-                corpus->d_window_table = table;
-                corpus->gather_runs = n_runs;
-                corpus->gather_rows = n_rows;
-                corpus->d_slot_ident = si;
             }
         }
+        if (corpus->d_slot_ident) {
         // the temporary: this stream's kept buffer (grown if this call needs f64 where u32 was kept); beyond 4 streams per corpus a
         // stream-ordered allocation for the call
         const size_t tmp_bytes = corpus->n_slots * elem;
@@ -1857,17 +1896,26 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
                 tmp_owned = true;
             }
         }
-        if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
-        RF_HIP(ea);
-        p.out = d_tmp;
-        p.orig = corpus->d_slot_ident;
-        p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
-        p.mixed_end = 0;
-        p.n = (uint32_t)corpus->n_slots;
+        if (ea != hipSuccess) {  // no room for the temporary: scattered stores through orig[] as before (not an error)
+            (void)hipGetLastError();
+            d_tmp = nullptr;
+            tmp_owned = false;
+            tmp_lock.unlock();
+        } else {
+            p.out = d_tmp;
+            p.orig = corpus->d_slot_ident;
+            p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
+            p.mixed_end = 0;
+            p.n = (uint32_t)corpus->n_slots;
+        }
+        }
     }
     if (const size_t scratch = launch_scratch_bytes(p, raw)) {
         const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
-        if (ea != hipSuccess && out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+        if (ea != hipSuccess) {
+            if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+            if (d_tmp && tmp_owned) (void)hipFreeAsync(d_tmp, st);  // (this call's own temporary must not outlive the failure)
+        }
         RF_HIP(ea);
     }
     std::unique_lock<std::mutex> filter_lock;  // held while a filter pass and the scan over its list are enqueued
@@ -1875,6 +1923,12 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
         p.tile_list_buf = corpus_tile_list(corpus, st);
     }
+    static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;  // one line per rf_many_* call on stderr: which path the plan took
+    if (trace_plan)
+        std::fprintf(stderr, "[rf plan] raw=%d words=%u early=%u first_check=%u band=%u heads8=%d head_need=%u head_k=%u tile_list=%d by_runs=%d by_origin=%d gather=%d "
+                             "tiles=[%u,%u) of %u prefill=%u\n",
+                     (int)raw, p.words, p.early, p.first_check, p.band, p.heads8 != nullptr, p.head_need, p.head_k, p.tile_list_buf != nullptr, (int)by_runs, (int)by_origin,
+                     d_tmp != nullptr, p.tile_begin, p.tile_end, corpus->n_tiles, p.prefill_none);
     hipError_t e = by_runs ? launch_scan_runs(raw, p, c, corpus, op, f64_out, st) : launch_scan(raw, p, st, nullptr);
     if (filter_lock.owns_lock()) filter_lock.unlock();
     if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
@@ -1884,7 +1938,7 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
                                                               (uint32_t)corpus->n, f64_out, st)
                                        : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
         if (tmp_owned) (void)hipFreeAsync(d_tmp, st);
-        tmp_lock.unlock();
+        if (tmp_lock.owns_lock()) tmp_lock.unlock();
     }
     if (e == hipSuccess && out_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
@@ -2388,7 +2442,7 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     bool done = false;
     if (args && op == RF_OP_DISTANCE && args->score_hint_usize != RF_NO_CUTOFF && args->cutoff_usize == RF_NO_CUTOFF && !out_all) {
         const uint64_t longest = std::max<uint64_t>(rf_comparator_query_len(c), corpus->max_len);
-        for (uint64_t hint = args->score_hint_usize; hint * 4 <= longest; hint = std::max<uint64_t>(1, hint * 2)) {
+        for (uint64_t hint = args->score_hint_usize; hint <= longest / 4; hint = std::max<uint64_t>(1, hint * 2)) {  // (hint <= longest / 4: no overflow for absurd hints)
             rf_args a2 = *args;
             a2.cutoff_usize = hint;
             a2.score_hint_usize = RF_NO_CUTOFF;
@@ -2581,13 +2635,17 @@ rf_status rf_topk_entries_device(const rf_comparator* c, const rf_corpus* corpus
     bool desc = false;
     const rf_status s = topk_by_selection(c, corpus, op, args, k, f64, nullptr, RF_MEM_HOST, st, &keys, &idx, &desc);
     if (s != RF_OK) return s;
-    std::vector<rf_topk_entry> host((size_t)k, rf_topk_entry{~0ull, ~0ull});
-    for (size_t i = 0; i < keys.size(); ++i) {
+    // (a caller-supplied k far beyond the corpus must not size a host allocation: at most min(k, n) entries exist, the tail of the
+    // caller's k-entry buffer is filled with the empty entry on the device -- ADVICE r3)
+    const size_t have = keys.size();
+    std::vector<rf_topk_entry> host(have);
+    for (size_t i = 0; i < have; ++i) {
         // (the u32 selection key of a similarity is 0xFFFFFFFE - score, rf_select.hip: the entry format says 0xFFFFFFFF - score)
         host[i].key = f64 ? keys[i] : (desc ? keys[i] + 1 : keys[i]);
         host[i].index = index_base + idx[i];
     }
-    RF_HIP(hipMemcpyAsync(d_entries_out, host.data(), host.size() * sizeof(rf_topk_entry), hipMemcpyHostToDevice, st));
+    if (have) RF_HIP(hipMemcpyAsync(d_entries_out, host.data(), have * sizeof(rf_topk_entry), hipMemcpyHostToDevice, st));
+    if (k > have) RF_HIP(hipMemsetAsync(d_entries_out + have, 0xFF, (size_t)(k - have) * sizeof(rf_topk_entry), st));
     RF_HIP(hipStreamSynchronize(st));  // (`host` dies with this frame)
     return RF_OK;
 }
@@ -2978,13 +3036,23 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
     if (s != RF_OK) return fail(s);
     RF_HIP_C(hipMalloc(&c->d_data, std::max<uint64_t>(1, c->data_bytes)));
     std::vector<uint8_t> buf(std::min<uint64_t>(std::max<uint64_t>(c->data_bytes, 1), 64ull << 20));
+    uint64_t stored_hist[256] = {0};  // of the STORED symbols (sigma applied), one 64-byte line in 16: sym_freq is not in the file
     for (uint64_t done = 0; done < c->data_bytes; done += buf.size()) {
         const size_t m = (size_t)std::min<uint64_t>(buf.size(), c->data_bytes - done);
         if (!read_at(fc.f, h.off_data + done, buf.data(), m)) {
             set_error("corpus file truncated");
             return fail(RF_ERR_INVALID_ARG);
         }
+        for (size_t at = 0; at + 64 <= m; at += 1024)
+            for (size_t k = 0; k < 64; ++k) stored_hist[buf[at + k]]++;
         RF_HIP_C(hipMemcpy(c->d_data + done, buf.data(), m, hipMemcpyHostToDevice));
+    }
+    {   // the symbol frequencies the band prefilter's plan reads (plan_band_filter): a loaded corpus must take the same kernel path
+        // as the packed one.  Chunk padding counts as the most frequent symbol's id (0) here -- an over-estimate that can
+        // only make the plan more cautious.
+        uint64_t by_symbol[256];
+        for (int ch = 0; ch < 256; ++ch) by_symbol[ch] = stored_hist[c->sigma[ch]];
+        if (!c->wide) symbol_frequencies(by_symbol, c->sym_freq);
     }
     c->device_bytes = c->data_bytes;
     if (h.flags & kFlagRaw) {

@@ -150,3 +150,22 @@ def test_topk_merge_orders_by_score_then_index():
     cnt = C.c_uint32()
     N.check(N.lib().rf_topk_merge_u32(N.OP_DISTANCE, scores.ctypes.data, idx.ctypes.data, counts.ctypes.data, 2, k, os_.ctypes.data, oi.ctypes.data, C.byref(cnt)))
     assert cnt.value == 3 and list(os_) == [1, 1, 2] and list(oi) == [7, 50, 99]
+
+
+def test_every_environment_knob_is_documented_and_none_changes_results():
+    """every getenv() of the shipping library is listed in include/rfgpu.h with its default, and the one switch
+    that makes results wrong on purpose (RF_EXP_NOHBM, a measurement aid) exists only in -DRF_EXPERIMENTS builds: neither the
+    default build's sources outside that #ifdef nor the built librfgpu.so contain its name."""
+    src = os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc")
+    hdr = open(os.path.join(ROOT, "include", "rfgpu.h")).read()
+    names = set()
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".hpp")):
+            txt = open(os.path.join(src, f)).read()
+            txt = re.sub(r"#ifdef RF_EXPERIMENTS.*?#e(?:lse|ndif)", "", txt, flags=re.S)  # measurement builds only
+            names |= set(re.findall(r'getenv\("(\w+)"\)', txt)) | set(re.findall(r'env_or\("(\w+)"', txt))
+    assert "RF_EXP_NOHBM" not in names
+    missing = [n for n in sorted(names) if n not in hdr]
+    assert not missing, f"environment variables read by the library but not documented in rfgpu.h: {missing}"
+    blob = open(N.LIB_PATH, "rb").read()
+    assert b"RF_EXP_NOHBM" not in blob, "the shipping librfgpu.so must not contain the wrong-answer measurement switch"

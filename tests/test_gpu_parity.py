@@ -2417,3 +2417,55 @@ def test_ragged_cutoff_scans_through_length_run_views(qlen):
         sim = ob.many(OPS["similarity"], data, offsets, nthreads=8)  # (quirk Q2, see _check_many: the cutoff applied to the uncut value)
         exp = _expect_u32(np.where(sim >= np.uint64(qlen - 2), sim, U64MAX))
         assert (got == exp).all(), metric
+
+
+def test_loaded_corpus_plans_the_same_path_as_the_packed_one(tmp_path):
+    """rf_corpus_load did not restore the symbol frequencies plan_band_filter decides on, so a loaded corpus ran the
+    cutoff <= 3 head-plane scans without the band prefilter (same results, 526 instead of 613 Gpairs/s).  RF_TRACE_PLAN=1 prints the
+    plan of every rf_many_* call: packed and loaded must print the same line (and return the same values)."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import rapidfuzz_rs_amd as rf
+from rapidfuzz_rs_amd.utils import synth
+host = synth.rows_host((1 << 20) + 77, 64, seed=5)
+q = synth.query(64, 6)
+host[12345] = np.frombuffer(q, dtype=np.uint8)
+a = rf.Corpus.from_rows(host)
+a.save(%r)
+b = rf.Corpus.load(%r)
+bc = rf.distance.levenshtein.BatchComparator(q)
+ra = bc.distance_many(a, score_cutoff=3)
+rb = bc.distance_many(b, score_cutoff=3)
+assert (ra == rb).all() and int((ra != 0xFFFFFFFF).sum()) >= 1
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "c.rfc"), str(tmp_path / "c.rfc"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RF_TRACE_PLAN="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    plans = [ln for ln in r.stderr.splitlines() if ln.startswith("[rf plan]")]
+    assert len(plans) == 2 and plans[0] == plans[1], plans
+    assert "head_need=5" in plans[0] and "heads8=1" in plans[0], plans  # cutoff 3 on a 62-symbol alphabet: the band prefilter is on
+
+
+def test_five_streams_share_the_tile_lists_of_one_corpus():
+    """the head-plane scans keep one tile list per stream, at most 4 per corpus; a fifth stream used to fall back
+    silently to the in-kernel filter.  Now the least recently used list changes hands: six streams in turn, twice, same values."""
+    import torch
+
+    host = synth.rows_host((1 << 20) + 3, 64, seed=15)
+    q = synth.query(64, 16)
+    host[777] = np.frombuffer(q, dtype=np.uint8)
+    host[100_000, :2] = 33
+    corpus = rf.Corpus.from_rows(host)
+    bc = rf.distance.levenshtein.BatchComparator(q)
+    exp = _expect_u32(o.levenshtein.BatchComparator(q).rows(N.OP_DISTANCE, host, nthreads=8, score_cutoff=3))
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    outs = [torch.empty(len(host), dtype=torch.int32, device="cuda") for _ in streams]
+    for _ in range(2):
+        for st, out in zip(streams, outs):
+            bc.distance_many(corpus, out=out, stream=st.cuda_stream, score_cutoff=3)
+    torch.cuda.synchronize()
+    for out in outs:
+        assert (out.cpu().numpy().view(np.uint32) == exp).all()
