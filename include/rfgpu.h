@@ -42,6 +42,7 @@
  *   RF_GATHER_WINDOWS             1         0: gather_results_kernel instead of the window gather
  *   RF_GATHER_SPAN / RF_GATHER_UNROLL   16384 / 8   window gather tuning
  *   RF_TOPK_SAMPLE                1024      tiles of the in-scan top-k's bound sample (0: no sample pass)
+ *   RF_JARO_PRIV                  0         1: Jaro asm kernel gathers from a conflict-free copy of the pattern table (corpora of <= 64 symbols; measured: no gain)
  *   RF_WF_REG                     1         0: LDS rows instead of register rows for generalized weights, queries <= 64
  *   RF_TRANSLATE_DIRECT           1         0: staged translation of u32 overflow symbols
  *   RF_NO_RENAME / RF_NO_MIXED_TILES   unset   set at PACK time: no symbol renaming / every length padded to whole tiles

@@ -90,6 +90,7 @@ struct rf_corpus {
     size_t n_slots = 0;          // entries of d_orig: 64 per tile (exact tiles, then the views)
     // large ragged corpora return their results through a slot-ordered temporary + one gather (rf_pack.hip): built on first use
     mutable uint8_t* d_heads8 = nullptr;       // head plane: the first 8 symbols of every candidate (small-cutoff scans; built on first use)
+    mutable uint32_t max_stored_sym = 0xFFFFFFFFu;  // largest stored symbol of the payload, exact; 0xFFFFFFFF = not computed yet (corpus_max_stored_symbol)
     mutable uint32_t* d_slot_of = nullptr;     // candidate -> its slot
     mutable uint32_t* d_slot_ident = nullptr;  // slot -> slot, kPad on padding lanes (stands in for d_orig in such a launch)
     mutable uint32_t* d_window_table = nullptr;  // the coalesced gather's table (rf_pack.hip window_table_kernel): gather_rows x gather_runs
@@ -1540,6 +1541,33 @@ static size_t launch_scratch_bytes(const ScanParams& p, RawKind raw)
     return 0;
 }
 
+// The largest stored symbol of the payload (symbols are stored as their frequency rank: a 62-symbol corpus holds 0 .. 61), computed
+// exactly on first use -- one streaming pass -- and kept.  0xFFFFFFFF when it cannot be had.
+static uint32_t corpus_max_stored_symbol(const rf_corpus* corpus, hipStream_t st)
+{
+    if (corpus->borrowed || corpus->wide || !corpus->d_data || corpus->data_bytes < 16) return 0xFFFFFFFFu;
+    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+    if (corpus->max_stored_sym == 0xFFFFFFFFu) {
+        uint32_t* d = nullptr;
+        uint32_t v = 0;
+        if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0xFFFFFFFFu;
+        }
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), st);
+        if (e == hipSuccess) e = launch_max_byte(corpus->d_data, corpus->data_bytes, d, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&v, d, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return 0xFFFFFFFFu;
+        }
+        corpus->max_stored_sym = v;
+    }
+    return corpus->max_stored_sym;
+}
+
 // Small-cutoff Levenshtein scans of large single-length corpora take their first look from the head plane (rf_pack.hip
 // head8_plane_kernel).  Built once per corpus, on the first such scan; RF_HEAD8_MIN=<tiles> moves the threshold (0 = never).
 // Failing to allocate it is not an error: the scan then reads the tiles' first chunk rows as before.
@@ -1780,6 +1808,8 @@ static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in,
     hipStream_t st = (hipStream_t)stream;
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
+    static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
+    p.max_stored_sym = (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) ? corpus_max_stored_symbol(corpus, st) : 0xFFFFFFFFu;
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     const size_t out_bytes = corpus->n * elem;
     void* d_out = out;

@@ -107,6 +107,7 @@ struct ScanParams {
     uint32_t jaro_split2;  // the same for the one-length views of the mixed section, tiles [n_exact, n_tiles)
     uint32_t jaro_long;    // 1: some string exceeds 512 symbols: the multi-word tiles run jaro_long_kernel (flags in long_scratch)
     uint32_t query_head;   // first four query bytes, little endian, zero padded (Winkler prefix)
+    uint32_t max_stored_sym;  // largest stored symbol of the corpus payload, exact (0xFFFFFFFF = not known): < 64 lets the Jaro asm kernel use its conflict-free table
     double cutoff_f64;
     double prefix_weight;
     // finishing coefficients (see "Finishing" in rf_device.hpp): value = vS*S + vM*Mx + vR*raw, dist / maximum likewise
@@ -163,6 +164,7 @@ int scan_max_grid();
 // results of a ragged corpus in original order without scattered stores (rf_pack.hip): slot -> slot / candidate -> slot maps, and the gather
 hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream);
 hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t tile_bytes, uint8_t* heads, hipStream_t stream);  // rf_pack.hip: the candidates' first 8 symbols
+hipError_t launch_max_byte(const uint8_t* data, uint64_t bytes, uint32_t* out, hipStream_t stream);  // rf_pack.hip: largest stored symbol (*out must start at 0)
 hipError_t launch_head8_plane_tiles(const uint8_t* data, const TileDesc* tiles, uint32_t n_tiles, uint8_t* heads, hipStream_t stream);  // the same over tile descriptors
 // the coalesced gather (rf_pack.hip "window_gather_kernel"): windows of kGatherWindow original indices, at most kMaxGatherRuns runs
 constexpr uint32_t kGatherWindow = 4096;

@@ -758,14 +758,32 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_long_kernel(const 
 // offsetof(wtab).  Everything else -- tile loop, Winkler prefix, table epilogue -- is jaro_word_body<true, false, true> again.
 // ---------------------------------------------------------------------------------------------------
 #include "rf_jaro_chunk_asm.inc"
+// kPriv (round 4): corpora whose stored symbols are all < 64 (exact: ScanParams::max_stored_sym) gather the table rows from a second,
+// CONFLICT-FREE copy -- row of symbol s for lane l at s * 256 + (l & 31) * 8, i.e. every lane of a half-wavefront on a bank pair of
+// its own (16 KiB per workgroup).  This kernel keeps the LDS ~80 % busy (2 table gathers + 1 window row per column against the
+// Levenshtein scan's 1 gather), and 62 symbols on 32 bank pairs make every gather a 2-way conflict: the copy halves their cost.
+struct JaroWordLdsPriv {
+    JaroWordLds w;                     // at LDS address 0 (the asm blocks' window / table addresses have no base)
+    uint64_t priv[64 * 32];            // [symbol][lane & 31]
+};
+static_assert(sizeof(JaroWordLds) == RF_JARO_PRIV_OFF, "tools/gen_jaro_chunk_asm.py RF_GEN_JPRIV_OFF must equal sizeof(JaroWordLds)");
+template <bool kPriv>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_asm_kernel(const ScanParams p)
 {
-    __shared__ JaroWordLds lds;
+    __shared__ typename std::conditional<kPriv, JaroWordLdsPriv, JaroWordLds>::type lds_obj;
+    JaroWordLds& lds = *reinterpret_cast<JaroWordLds*>(&lds_obj);
     const uint32_t W = p.words;
     double* tab1 = lds.tabs;
     for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds.pm0[p.sigma[i]] = p.pm[(size_t)i * W];  // renamed rows
     if (threadIdx.x < 65) tab1[threadIdx.x] = (double)threadIdx.x / (double)p.len1;
     __syncthreads();
+    if constexpr (kPriv) {
+        uint64_t* priv = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(&lds_obj) + sizeof(JaroWordLds));
+        for (int i = threadIdx.x; i < 64 * 32; i += kWave * kWavesPerBlock) priv[i] = lds.pm0[i >> 5];
+        __syncthreads();
+    }
+    const uint32_t lane_bank = (threadIdx.x & 31u) * 8u;                                      // [lb]: this lane's bank pair inside a table row
+    const uint32_t sel0 = 0x0C0C0400u, sel1 = 0x0C0C0500u, sel2 = 0x0C0C0600u, sel3 = 0x0C0C0700u;  // v_perm_b32: {0, 0, chunk byte k, lane_bank byte 0}
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
     double* tab2 = tab1 + kJaroTabStride * (1 + wave);
@@ -805,17 +823,35 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_asm_kernel(co
     if (nch > 2) b2 = src[2 * kWave + lane];
     if (nch > 3) b3 = src[3 * kWave + lane];
 #define RF_P1(buf, j0)                                                                                                          \
-    asm volatile(RF_JARO_PASS1_ASM                                                                                              \
-                 : "+v"(pl), "+v"(ph), "+v"(tlo), "+v"(thi)                                                                     \
-                 : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [k3] "v"(three), [wa] "v"(wtab_addr + (j0) * 8u), \
-                   [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u)                                                      \
-                 : RF_JARO_CHUNK_CLOBBERS)
+    do {                                                                                                                        \
+        if constexpr (kPriv)                                                                                                    \
+            asm volatile(RF_JARO_PASS1_PRIV_ASM                                                                                 \
+                         : "+v"(pl), "+v"(ph), "+v"(tlo), "+v"(thi)                                                             \
+                         : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [lb] "v"(lane_bank), [sel0] "s"(sel0), [sel1] "s"(sel1), \
+                           [sel2] "s"(sel2), [sel3] "s"(sel3), [wa] "v"(wtab_addr + (j0) * 8u), [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u) \
+                         : RF_JARO_CHUNK_CLOBBERS);                                                                             \
+        else                                                                                                                    \
+            asm volatile(RF_JARO_PASS1_ASM                                                                                      \
+                         : "+v"(pl), "+v"(ph), "+v"(tlo), "+v"(thi)                                                             \
+                         : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [k3] "v"(three), [wa] "v"(wtab_addr + (j0) * 8u), \
+                           [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u)                                              \
+                         : RF_JARO_CHUNK_CLOBBERS);                                                                             \
+    } while (0)
 #define RF_P2(buf, j0)                                                                                                          \
-    asm volatile(RF_JARO_PASS2_ASM                                                                                              \
-                 : "+v"(pl), "+v"(ph), "+v"(hl), "+v"(hh)                                                                       \
-                 : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [k3] "v"(three), "v"(tlo), "v"(thi),     \
-                   [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u)                                                      \
-                 : RF_JARO_CHUNK_CLOBBERS)
+    do {                                                                                                                        \
+        if constexpr (kPriv)                                                                                                    \
+            asm volatile(RF_JARO_PASS2_PRIV_ASM                                                                                 \
+                         : "+v"(pl), "+v"(ph), "+v"(hl), "+v"(hh)                                                               \
+                         : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [lb] "v"(lane_bank), [sel0] "s"(sel0), [sel1] "s"(sel1), \
+                           [sel2] "s"(sel2), [sel3] "s"(sel3), "v"(tlo), "v"(thi), [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u) \
+                         : RF_JARO_CHUNK_CLOBBERS);                                                                             \
+        else                                                                                                                    \
+            asm volatile(RF_JARO_PASS2_ASM                                                                                      \
+                         : "+v"(pl), "+v"(ph), "+v"(hl), "+v"(hh)                                                               \
+                         : [c0] "v"(buf.x), [c1] "v"(buf.y), [c2] "v"(buf.z), [c3] "v"(buf.w), [k3] "v"(three), "v"(tlo), "v"(thi), \
+                           [sh] "s"((j0) & 16u), [lo] "s"(((j0) & 32u) ? 0u : ~0u)                                              \
+                         : RF_JARO_CHUNK_CLOBBERS);                                                                             \
+    } while (0)
     while (true) {
         const uint32_t idx = t * kWave + lane;
         JaroRaw r;
@@ -901,8 +937,14 @@ static hipError_t launch_jaro_word(const ScanParams& p, ScanParams q, hipStream_
         }
         asm_ok = len2 >= (uint32_t)kChunk && len2 % kChunk == 0 && len2 <= 64;
     }
-    if (asm_ok)
-        hipLaunchKernelGGL(jaro_word_asm_kernel, g, b, 0, stream, q);
+    // RF_JARO_PRIV=1: the conflict-free table copy for corpora of <= 64 stored symbols.  OFF by default -- measured, it buys nothing
+    // (profiles/jaro_lds_r04.txt: bank conflicts 400 M -> 0.5 M, LDS-active cycles -38 %, SQ_WAIT_INST_LDS -46 %, and the same 2.94 ms:
+    // the kernel is bound by VALU issue, not by the LDS, and the copy's 16 KiB cost it one resident workgroup per CU)
+    static const bool use_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();
+    if (asm_ok && use_priv && p.max_stored_sym < 64u)
+        hipLaunchKernelGGL(jaro_word_asm_kernel<true>, g, b, 0, stream, q);
+    else if (asm_ok)
+        hipLaunchKernelGGL(jaro_word_asm_kernel<false>, g, b, 0, stream, q);
     else
         hipLaunchKernelGGL(k, g, b, 0, stream, q);
     return hipGetLastError();

@@ -67,6 +67,30 @@ hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, si
     return hipGetLastError();
 }
 
+// the largest STORED symbol of a packed payload (after the renaming sigma: the corpus' symbols are 0 .. alphabet - 1 by frequency
+// rank).  Exact, over every byte -- the sample sigma was made from may have missed a rare symbol, and a kernel that sizes an LDS
+// table by this number (rf_jaro.hip jaro_word_asm_kernel<true>) must not be told less.
+__global__ __launch_bounds__(256) void max_byte_kernel(const uint4* __restrict__ data, uint64_t n16, uint32_t* __restrict__ out)
+{
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = data[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = max(max(max(m, w[k] & 0xFFu), (w[k] >> 8) & 0xFFu), max((w[k] >> 16) & 0xFFu, w[k] >> 24));
+    }
+#pragma unroll
+    for (int d = kWave / 2; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(out, m);
+}
+hipError_t launch_max_byte(const uint8_t* data, uint64_t bytes, uint32_t* out, hipStream_t stream)
+{
+    if (bytes < 16) return hipSuccess;
+    hipLaunchKernelGGL(max_byte_kernel, dim3((uint32_t)std::min<uint64_t>((bytes / 16 + 255) / 256, 4096)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4*>(data), bytes / 16, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, uint8_t* packed, uint32_t n_tiles,
                             const uint8_t* sigma, hipStream_t stream)
 {

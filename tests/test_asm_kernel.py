@@ -18,7 +18,8 @@ CASES = [  # source file, mangled kernel, pinned registers, wavefronts per SIMD 
     ("rf_lev_asm.hip", "_ZN2rf15lev1_asm_kernelENS_10ScanParamsE", r"(3[4-9]|4[0-9]|6[0-3])", 8, 64),
     ("rf_lev_asm.hip", "_ZN2rf16lev32_asm_kernelENS_10ScanParamsE", r"(3[4-9]|4[01]|6[01])", 8, 64),
     ("rf_lev_asm.hip", "_ZN2rf15osa1_asm_kernelENS_10ScanParamsE", r"(3[4-9]|4[0-9]|5[89]|6[0-3])", 8, 64),
-    ("rf_jaro.hip", "_ZN2rf20jaro_word_asm_kernelENS_10ScanParamsE", r"(5[89]|6[0-3])", 7, 72),
+    ("rf_jaro.hip", "_ZN2rf20jaro_word_asm_kernelILb0EEEvNS_10ScanParamsE", r"(5[89]|6[0-3])", 7, 72),
+    ("rf_jaro.hip", "_ZN2rf20jaro_word_asm_kernelILb1EEEvNS_10ScanParamsE", r"(5[89]|6[0-3])", 7, 72),  # the conflict-free table copy (round 4)
 ]
 
 
@@ -51,10 +52,11 @@ def test_compiler_never_touches_the_pinned_registers(tmp_path, source, kernel, p
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_whole_kernel_asm_scans_resources(tmp_path):
-    """rf_stream_asm.hip: the six whole-kernel asm scans (Levenshtein 64- / 32-bit, OSA x single-length / tile descriptors).  The
-    wrapper hands the asm body three operands and nothing else, so everything the launch relies on is visible in the compiler's
-    metadata: no scratch, 64 VGPRs = 8 wavefronts per SIMD, the 2 KiB pattern table as the only LDS object, and a body that
-    contains no compiler-generated code between its first and last instruction (ONE asm statement, then s_endpgm)."""
+    """rf_stream_asm.hip: the twelve whole-kernel asm scans (Levenshtein 64- / 32-bit, OSA, and -- round 4 -- Levenshtein over
+    2 / 3 / 4 words, each x single-length / tile descriptors).  The wrapper hands the asm body three operands and nothing else, so
+    everything the launch relies on is visible in the compiler's metadata: no scratch, 64 VGPRs = 8 wavefronts per SIMD, the pattern
+    table (2 KiB per word) as the only LDS object, and a body that contains no compiler-generated code between its first and last
+    instruction (ONE asm statement, then s_endpgm)."""
     src = os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc")
     out = tmp_path / "stream.s"
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function", "-S", "--cuda-device-only",
@@ -62,9 +64,10 @@ def test_whole_kernel_asm_scans_resources(tmp_path):
     text = out.read_text()
     lines = text.splitlines()
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2rf\d+stream_\w+_kernelENS_13StreamAsmArgsE:", l)]
-    assert len(starts) == 6
+    assert len(starts) == 12
     for start in starts:
         k = lines[start].split(":")[0]
+        words = int(re.search(r"levw(\d)", k).group(1)) if "levw" in k else 1
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
         body = lines[start:end]
         assert sum("ASMSTART" in l for l in body) == 1 and "ASMEND" in lines[end - 1]
@@ -72,4 +75,4 @@ def test_whole_kernel_asm_scans_resources(tmp_path):
         meta = "\n".join(lines[end : end + 80])
         assert re.search(r"; ScratchSize: 0\b", meta) and re.search(r"; Occupancy: 8\b", meta), k
         assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) == 64
-        assert re.search(r"\.amdhsa_group_segment_fixed_size 2048\b", meta), k
+        assert re.search(rf"\.amdhsa_group_segment_fixed_size {2048 * words}\b", meta), k

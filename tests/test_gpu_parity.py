@@ -1705,6 +1705,16 @@ def test_asm_chunk_kernel_single_length_corpora(len2):
 @pytest.mark.parametrize("metric", ["jaro", "jaro_winkler"])
 @pytest.mark.parametrize("len2", [16, 32, 48, 64])
 def test_asm_jaro_kernel_single_length_corpora(metric, len2):
+    if os.environ.get("RF_JARO_PRIV") is None and metric == "jaro" and len2 == 64:
+        # the same tests through the kernel's conflict-free table copy (off by default: measured, no gain -- profiles/jaro_lds_r04.txt)
+        import subprocess
+        import sys
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                            "test_asm_jaro_kernel_single_length_corpora or test_jaro_fixed_rows_c4"], capture_output=True, text=True, cwd=root,
+                           env=dict(os.environ, RF_JARO_PRIV="1"))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
     """jaro_word_asm_kernel (both passes of the single-word Jaro kernel as hand-scheduled asm, the candidate's chunk rows held in
     registers) serves single-length corpora whose length -- after the reference's window truncation -- is a multiple of 16, when
     there is no cutoff: every op, bit-equal f64, query lengths that do and do not truncate the candidate, a small and a large

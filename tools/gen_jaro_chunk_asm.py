@@ -28,9 +28,24 @@ class Block:
     def wait(self, *tags):  # wait until every tagged LDS operation has returned
         need = max(self.done_id[t] for t in tags)
         self.lines.append(f"s_waitcnt lgkmcnt({self.issued - need})")
-def x(b, j): b.emit(f"v_lshlrev_b32_sdwa v{ADDR[j % 4]}, %[k3], %[c{j // 4}] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{j % 4}")
-def d(b, j): b.lds(f"ds_read_b64 {p(PMB[j % 8])}, v{ADDR[j % 4]}", ("pm", j))
-def w2(b, j): b.lds(f"ds_read2_b64 v[{WIN[j % 4][0]}:{WIN[(j + 1) % 4][1]}], %[wa] offset0:{j} offset1:{j + 1}", ("w", j)); b.done_id[("w", j + 1)] = b.issued
+# PRIV (round 4): the conflict-free table gather for corpora of <= 64 stored symbols.  Row of symbol s for lane l at
+# PRIV_OFF + s * 256 + (l & 31) * 8: the 32 lanes of each half-wavefront read 32 different bank pairs whatever their symbols are (a
+# ds_read_b64 then costs 2 LDS cycles instead of the 4 that 62 symbols on 32 bank pairs average).  The address is ONE v_perm_b32
+# (half rate, like the SDWA it replaces): byte 0 = the lane's bank offset %[lb], byte 1 = the chunk's symbol byte, selected by %[selK].
+PRIV = False
+PRIV_OFF = 0
+def x(b, j):
+    if PRIV: b.emit(f"v_perm_b32 v{ADDR[j % 4]}, %[c{j // 4}], %[lb], %[sel{j % 4}]")
+    else: b.emit(f"v_lshlrev_b32_sdwa v{ADDR[j % 4]}, %[k3], %[c{j // 4}] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{j % 4}")
+def d(b, j): b.lds(f"ds_read_b64 {p(PMB[j % 8])}, v{ADDR[j % 4]}" + (f" offset:{PRIV_OFF}" if PRIV else ""), ("pm", j))
+# window-mask rows j, j + 1: every lane reads the SAME address, which a ds_read_b64 serves as a broadcast in 2 LDS cycles; the
+# ds_read2_b64 of round 2 took 8 for the pair (MI355X_MICROARCH.md LDS table) -- and this kernel keeps the LDS ~80 % busy
+def w2(b, j):
+    if os.environ.get("RF_GEN_JWIN2", "0") == "1":
+        b.lds(f"ds_read2_b64 v[{WIN[j % 4][0]}:{WIN[(j + 1) % 4][1]}], %[wa] offset0:{j} offset1:{j + 1}", ("w", j)); b.done_id[("w", j + 1)] = b.issued
+    else:
+        b.lds(f"ds_read_b64 {p(WIN[j % 4])}, %[wa] offset:{8 * j}", ("w", j))
+        b.lds(f"ds_read_b64 {p(WIN[(j + 1) % 4])}, %[wa] offset:{8 * (j + 1)}", ("w", j + 1))
 def nop(b, m, bit):
     if m >> bit & 1: b.emit("s_nop 0")
 def pass1(m):
@@ -89,5 +104,7 @@ m2 = int(os.environ.get("RF_GEN_JMASK2", "0x3"), 0)
 out = ["// GENERATED by tools/gen_jaro_chunk_asm.py -- do not edit.  See that file.",
        '#define RF_JARO_CHUNK_CLOBBERS ' + ", ".join(f'"v{i}"' for i in range(22, 58))]
 out += macro("RF_JARO_PASS1_ASM", pass1(m1)) + macro("RF_JARO_PASS2_ASM", pass2(m2))
+PRIV, PRIV_OFF = True, int(os.environ.get("RF_GEN_JPRIV_OFF", "6736"))  # = sizeof(JaroWordLds) (rf_jaro.hip static_asserts it)
+out += [f"#define RF_JARO_PRIV_OFF {PRIV_OFF}"] + macro("RF_JARO_PASS1_PRIV_ASM", pass1(m1)) + macro("RF_JARO_PASS2_PRIV_ASM", pass2(m2))
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rapidfuzz_rs_amd", "csrc", "rf_jaro_chunk_asm.inc")
 open(path, "w").write("\n".join(out) + "\n")
