@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <atomic>
 #include <unordered_map>
@@ -2775,7 +2777,10 @@ bool read_at(FILE* f, uint64_t off, void* p, size_t n)
 // which is what bounded the streamed path.
 bool read_parallel(int fd, uint64_t off, uint8_t* dst, size_t n)
 {
-    const size_t nthreads = n < (32u << 20) ? 1 : std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
+    // (RF_STREAM_THREADS: reader threads of the streamed scans and of rf_corpus_load; default 16 -- the page-cache -> pinned-buffer copy
+    // runs at ~5 GB/s per thread, and it is this copy, not the link, that bounds a streamed scan: profiles/stream_r04.txt)
+    static const size_t max_threads = [] { const char* e = getenv("RF_STREAM_THREADS"); const int v = e ? atoi(e) : 16; return (size_t)(v > 0 ? v : 1); }();
+    const size_t nthreads = n < (32u << 20) ? 1 : std::min<size_t>(max_threads, std::max<size_t>(1, std::thread::hardware_concurrency()));
     std::atomic<bool> ok{true};
     auto worker = [&](size_t t) {
         size_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
@@ -3137,6 +3142,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         set_error("rf_stream_many: invalid argument");
         return RF_ERR_INVALID_ARG;
     }
+    const auto t_enter = std::chrono::steady_clock::now();
     FileCloser fc{std::fopen(path, "rb")};
     if (!fc.f) {
         set_error(std::string("rf_stream_many: cannot open ") + path);
@@ -3167,7 +3173,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     const uint64_t uniform_tb = tile_bytes(meta.uniform_len);
     auto tile_off = [&](uint32_t t) { return meta.uniform ? (uint64_t)t * uniform_tb : (t < meta.n_tiles ? tiles[t].data_off : meta.data_bytes - kTailPad); };
     // segment boundaries
-    if (segment_bytes == 0) segment_bytes = 256ull << 20;
+    if (segment_bytes == 0) segment_bytes = 512ull << 20;  // (64 GB file, same box: 256 MiB segments 39.8 GB/s, 512 MiB 47.5: profiles/stream_r04.txt)
     std::vector<uint32_t> cuts{0};
     // (the one-length views of a mixed tile share one payload block: a cut may only fall where the payload offset changes)
     auto block_start = [&](uint32_t t) { return t >= meta.n_tiles || t == 0 || tile_off(t) != tile_off(t - 1); };
@@ -3189,13 +3195,14 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         max_tiles = std::max(max_tiles, cuts[k + 1] - cuts[k]);
     }
 
+    constexpr int kSlots = 3;  // buffer sets in rotation: one being read into, one on the link, one being scanned
     struct Slot {
         uint8_t *d_data = nullptr, *h_data = nullptr;
         TileDesc* d_tiles = nullptr;
         uint32_t* d_orig = nullptr;
         hipEvent_t uploaded = nullptr, scanned = nullptr;
         bool used = false;
-    } slot[2];
+    } slot[kSlots];
     hipStream_t s_copy = nullptr, s_comp = nullptr;
     uint8_t* d_sigma = nullptr;
     void* d_out = nullptr;
@@ -3210,24 +3217,108 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
               hip_ok(hipMemcpy(d_sigma, meta.sigma, 256, hipMemcpyHostToDevice)) && hip_ok(hipMalloc(&d_out, meta.n * elem));
     // None everywhere first: a cutoff run skips whole tile ranges (plan()), and segment views never pre-fill
     if (ok) ok = hip_ok(hipMemsetAsync(d_out, 0xFF, meta.n * elem, s_comp));
-    for (int b = 0; ok && b < 2; ++b) {
-        ok = hip_ok(hipMalloc(&slot[b].d_data, max_seg + kTailPad)) && hip_ok(hipHostMalloc((void**)&slot[b].h_data, max_seg + kTailPad, hipHostMallocDefault)) &&
-             hip_ok(hipEventCreateWithFlags(&slot[b].uploaded, hipEventDisableTiming)) && hip_ok(hipEventCreateWithFlags(&slot[b].scanned, hipEventDisableTiming));
+    // The buffer sets (pinned host + device payload buffers) are KEPT between calls, per process: allocating and pinning 3 x 256 MiB
+    // costs 50-80 ms, a third of a 6.4 GB streamed scan (profiles/stream_r04.txt).  One streamed scan at a time uses the kept sets (a
+    // concurrent one allocates its own); a call that needs larger segments replaces them.  RF_STREAM_KEEP=0: allocate and free per call.
+    struct KeptSets {
+        std::mutex mu;
+        uint8_t *d_data[3] = {nullptr, nullptr, nullptr}, *h_data[3] = {nullptr, nullptr, nullptr};
+        uint64_t cap = 0;
+        int device = -1;
+    };
+    static KeptSets kept;
+    static const bool keep_sets = [] { const char* e = getenv("RF_STREAM_KEEP"); return !e || atoi(e) != 0; }();
+    std::unique_lock<std::mutex> kept_lock(kept.mu, std::defer_lock);
+    const bool use_kept = keep_sets && kept_lock.try_lock();
+    if (use_kept && (kept.cap < max_seg + kTailPad || kept.device != device)) {
+        for (int b = 0; b < kSlots; ++b) {
+            if (kept.d_data[b]) (void)hipFree(kept.d_data[b]);
+            if (kept.h_data[b]) (void)hipHostFree(kept.h_data[b]);
+            kept.d_data[b] = kept.h_data[b] = nullptr;
+        }
+        kept.cap = 0;
+        kept.device = device;
+        bool got = true;
+        for (int b = 0; got && b < kSlots; ++b)
+            got = hipMalloc(&kept.d_data[b], max_seg + kTailPad) == hipSuccess && hipHostMalloc((void**)&kept.h_data[b], max_seg + kTailPad, hipHostMallocDefault) == hipSuccess;
+        if (got) {
+            kept.cap = max_seg + kTailPad;
+        } else {
+            (void)hipGetLastError();
+            for (int b = 0; b < kSlots; ++b) {
+                if (kept.d_data[b]) (void)hipFree(kept.d_data[b]);
+                if (kept.h_data[b]) (void)hipHostFree(kept.h_data[b]);
+                kept.d_data[b] = kept.h_data[b] = nullptr;
+            }
+        }
+    }
+    const bool from_kept = use_kept && kept.cap >= max_seg + kTailPad;
+    for (int b = 0; ok && b < kSlots; ++b) {
+        if (from_kept) {
+            slot[b].d_data = kept.d_data[b];
+            slot[b].h_data = kept.h_data[b];
+        } else {
+            ok = hip_ok(hipMalloc(&slot[b].d_data, max_seg + kTailPad)) && hip_ok(hipHostMalloc((void**)&slot[b].h_data, max_seg + kTailPad, hipHostMallocDefault));
+        }
+        ok = ok && hip_ok(hipEventCreateWithFlags(&slot[b].uploaded, hipEventDisableTiming)) && hip_ok(hipEventCreateWithFlags(&slot[b].scanned, hipEventDisableTiming));
         if (ok && !meta.uniform)
             ok = hip_ok(hipMalloc(&slot[b].d_tiles, (size_t)max_tiles * sizeof(TileDesc))) && hip_ok(hipMalloc(&slot[b].d_orig, (size_t)max_tiles * kWave * 4));
     }
+    // Single-length corpora: a segment's results are a contiguous slice of `out`, so they travel to the host while the later segments
+    // are still being read, copied and scanned -- on a thread of their own (a device-to-pageable-host copy blocks its caller) and a
+    // stream of their own (the link is full duplex).  4 bytes per 64-byte candidate: left to the end they were 15 % of a 64 GB scan.
+    struct ResJob {
+        hipEvent_t ready;
+        size_t off, bytes;
+    };
+    std::mutex res_mu;
+    std::condition_variable res_cv;
+    std::deque<ResJob> res_jobs;
+    bool res_done = false;
+    std::atomic<int> res_err{(int)hipSuccess};
+    hipStream_t s_res = nullptr;
+    std::thread res_thread;
+    const bool early_results = ok && meta.uniform && hip_ok(hipStreamCreateWithFlags(&s_res, hipStreamNonBlocking));
+    if (early_results)
+        res_thread = std::thread([&] {
+            (void)hipSetDevice(device);
+            while (true) {
+                ResJob j;
+                {
+                    std::unique_lock<std::mutex> lk(res_mu);
+                    res_cv.wait(lk, [&] { return res_done || !res_jobs.empty(); });
+                    if (res_jobs.empty()) return;
+                    j = res_jobs.front();
+                    res_jobs.pop_front();
+                }
+                hipError_t er = hipStreamWaitEvent(s_res, j.ready, 0);
+                if (er == hipSuccess) er = hipMemcpyAsync(static_cast<char*>(out_host) + j.off, static_cast<char*>(d_out) + j.off, j.bytes, hipMemcpyDeviceToHost, s_res);
+                if (er == hipSuccess) er = hipStreamSynchronize(s_res);
+                (void)hipEventDestroy(j.ready);
+                if (er != hipSuccess) res_err = (int)er;
+            }
+        });
     std::vector<TileDesc> seg_tiles;
+    static const bool stream_timing = getenv("RF_STREAM_TIMING") != nullptr;  // phase times of a streamed scan on stderr
+    using clk = std::chrono::steady_clock;
+    const auto t_loop = clk::now();
+    double s_wait = 0.0, s_read = 0.0;
+    if (stream_timing) std::fprintf(stderr, "[rf stream] set-up (streams, device + pinned buffers, None pre-fill) %.1f ms\n", std::chrono::duration<double, std::milli>(t_loop - t_enter).count());
     for (size_t k = 0; ok && status == RF_OK && k + 1 < cuts.size(); ++k) {
-        Slot& sl = slot[k & 1];
+        Slot& sl = slot[k % kSlots];
         const uint32_t t0 = cuts[k], t1 = cuts[k + 1];
         const uint64_t base = tile_off(t0), bytes = tile_off(t1) - base;
+        const auto t_a = clk::now();
         if (sl.used) ok = hip_ok(hipEventSynchronize(sl.scanned));  // the scan that last read this buffer set is done
         if (!ok) break;
+        const auto t_b = clk::now();
         if (!read_parallel(fd, h.off_data + base, sl.h_data, (size_t)bytes)) {
             set_error("corpus file truncated");
             status = RF_ERR_INVALID_ARG;
             break;
         }
+        s_wait += std::chrono::duration<double, std::milli>(t_b - t_a).count();
+        s_read += std::chrono::duration<double, std::milli>(clk::now() - t_b).count();
         std::memset(sl.h_data + bytes, 0, kTailPad);
         ok = hip_ok(hipMemcpyAsync(sl.d_data, sl.h_data, bytes + kTailPad, hipMemcpyHostToDevice, s_copy));
         rf_corpus seg;  // a view: owns nothing
@@ -3277,13 +3368,36 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         if (status != RF_OK) break;
         ok = hip_ok(hipEventRecord(sl.scanned, s_comp));
         sl.used = true;
+        if (ok && early_results) {
+            ResJob j{nullptr, (size_t)t0 * kWave * elem, seg.n * elem};
+            ok = hip_ok(hipEventCreateWithFlags(&j.ready, hipEventDisableTiming)) && hip_ok(hipEventRecord(j.ready, s_comp));
+            if (ok) {
+                std::lock_guard<std::mutex> lk(res_mu);
+                res_jobs.push_back(j);
+            }
+            res_cv.notify_one();
+        }
     }
-    if (ok && status == RF_OK) ok = hip_ok(hipMemcpyAsync(out_host, d_out, meta.n * elem, hipMemcpyDeviceToHost, s_comp)) && hip_ok(hipStreamSynchronize(s_comp));
+    const auto t_tail = clk::now();
+    if (res_thread.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(res_mu);
+            res_done = true;
+        }
+        res_cv.notify_one();
+        res_thread.join();
+        if (res_err.load() != (int)hipSuccess) ok = hip_ok((hipError_t)res_err.load());
+    }
+    if (ok && status == RF_OK && !early_results)
+        ok = hip_ok(hipMemcpyAsync(out_host, d_out, meta.n * elem, hipMemcpyDeviceToHost, s_comp)) && hip_ok(hipStreamSynchronize(s_comp));
+    if (stream_timing)
+        std::fprintf(stderr, "[rf stream] %zu segments: loop %.1f ms (reads %.1f, waits for a free buffer set %.1f), drain + results to the host %.1f ms\n", cuts.size() - 1,
+                     std::chrono::duration<double, std::milli>(t_tail - t_loop).count(), s_read, s_wait, std::chrono::duration<double, std::milli>(clk::now() - t_tail).count());
     if (s_copy) (void)hipStreamSynchronize(s_copy);
     if (s_comp) (void)hipStreamSynchronize(s_comp);
-    for (int b = 0; b < 2; ++b) {
-        if (slot[b].d_data) (void)hipFree(slot[b].d_data);
-        if (slot[b].h_data) (void)hipHostFree(slot[b].h_data);
+    for (int b = 0; b < kSlots; ++b) {
+        if (slot[b].d_data && !from_kept) (void)hipFree(slot[b].d_data);
+        if (slot[b].h_data && !from_kept) (void)hipHostFree(slot[b].h_data);
         if (slot[b].d_tiles) (void)hipFree(slot[b].d_tiles);
         if (slot[b].d_orig) (void)hipFree(slot[b].d_orig);
         if (slot[b].uploaded) (void)hipEventDestroy(slot[b].uploaded);
@@ -3298,6 +3412,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     if (d_out) (void)hipFree(d_out);
     if (s_copy) (void)hipStreamDestroy(s_copy);
     if (s_comp) (void)hipStreamDestroy(s_comp);
+    if (s_res) (void)hipStreamDestroy(s_res);
     if (status != RF_OK) return status;
     if (!ok) {
         set_error(std::string("rf_stream_many: ") + hipGetErrorString(e));

@@ -1,8 +1,6 @@
 #!/bin/bash
 set -u
 mkdir -p gpurun_out/r04
-echo "=== JW priv"; tools/pmc_lds.sh jw_priv jaro --metric jaro_winkler
-echo "=== JW shared"; RF_JARO_PRIV=0 tools/pmc_lds.sh jw_shared jaro --metric jaro_winkler
-echo "=== C3 asm"; tools/pmc_lds.sh c3_asm lev --query-len 256 --cand-len 256 --candidates 10000000
-echo "=== C3 compiled"; RF_ASM_BLOCK=0 tools/pmc_lds.sh c3_compiled scan_kernel --query-len 256 --cand-len 256 --candidates 10000000
-cp gpurun_out/pmc_*.txt gpurun_out/r04/
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "corpus_file or corrupt or stream" 2>&1 | tail -3
+RF_STREAM_TIMING=1 python tools/time_stream.py 100000000 256 2>&1 | grep -v amdgpu.ids | tail -8
+RF_STREAM_TIMING=1 python tools/time_stream.py 1000000000 256 512 2>&1 | grep -v amdgpu.ids | tail -14
