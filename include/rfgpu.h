@@ -223,8 +223,10 @@ size_t rf_corpus_alphabet_size(const rf_corpus *c, size_t *overflow_symbols);
  * rf_corpus_save / rf_corpus_load: the packed form (header, length table, tile descriptors, slot -> original
  * index, alphabet of a u32 corpus, page-aligned payload) written once and mapped back without re-packing.
  * rf_stream_many_*: out[i] = scorer.<op>_with_args(candidate_i, &args) over a corpus FILE that need not fit in
- * HBM: the file is scanned in tile ranges of at most `segment_bytes` of payload (0 = 256 MiB) through two device
- * buffer sets, the read + upload of one segment overlapping the scan of the previous one.  `out` is HOST memory
+ * HBM: the file is scanned in tile ranges of at most `segment_bytes` of payload (0 = 512 MiB) through three pinned-host +
+ * device buffer sets (kept per process between calls: 3 x segment_bytes of pinned memory and of HBM; RF_STREAM_KEEP=0 frees them
+ * per call), the read + upload of one segment overlapping the scan of the previous one and -- single-length corpora -- the copy of
+ * the one before's results to the host: 47 GB/s of payload on a 64 GB file, link ceiling 57 (profiles/stream_r04.txt).  `out` is HOST memory
  * with room for `out_capacity` entries; the file's own candidate count n (rf_corpus_file_count) decides how many are
  * written, and a file holding more than out_capacity is refused with RF_ERR_INVALID_ARG before anything is written
  * (the result vector itself does live on the device during the pass).  Values, None encoding and errors are those of
