@@ -62,6 +62,10 @@ def parse():
                     help="after the headline's timed region, run one short leg (own process, --extra-steps steps, own roofline + oracle parity) for "
                          "each OTHER BASELINE.json config and report them as `extra_configs`.  auto = on for the default workload at N = 1")
     ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--traffic", default="auto", choices=["auto", "on", "off"],
+                    help="on: roofline.traffic from two short rocprofv3 --pmc passes of this command run after the timed region (when rocprofv3 is on the "
+                         "box; N = 1), else the committed counters of profiles/traffic.json marked as such; off: only the committed file; auto: on for "
+                         "workloads of >= 10 M candidates outside the extra legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -421,7 +425,8 @@ def main():
             "survey_8d": {"bytes_per_pair": survey_bpp, "achieved": round(survey_achieved, 1), "frac": round(survey_achieved / HBM_PEAK_GBS, 4)},
         },
     }
-    if args.metric in ("levenshtein", "indel", "lcs_seq", "osa") and args.query_len <= (256 if args.metric == "levenshtein" else 64) and not weights and not early:
+    if (args.metric in ("levenshtein", "indel", "lcs_seq", "osa") and args.query_len <= (256 if args.metric == "levenshtein" else 64) and not weights and not early
+            and os.environ.get("RF_BENCH_IN_PMC") != "1"):  # (not inside this command's own counter passes: traffic_in_run)
         # The bit-parallel scans of this family are bound by VALU issue before they are bound by HBM.  The
         # ceiling is MEASURED here, in this process: the library's own recurrence column on register-resident pattern
         # words, no HBM / LDS / tile loop (rf_probe_issue_rate, rapidfuzz_rs_amd/csrc/rf_probe.hip).
@@ -614,7 +619,7 @@ def extra_configs(args):
 
     legs = []
     for name, what, flags in EXTRA_LEGS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.extra_steps), "--warmup", "2", "--extras", "off",
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.extra_steps), "--warmup", "2", "--extras", "off", "--traffic", "off",
                "--cpu-seconds", "2", "--settle-ms", "100", *flags]
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env["MASTER_PORT"] = "29577"
@@ -659,12 +664,72 @@ def gpu_power_watts(device):
     return {"now": float(cur.group(1)), **({"cap": float(cap.group(1))} if cap else {})}
 
 
+def traffic_in_run(args, kernel_ms):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do
+    not fit one pass, MI355X_MICROARCH.md counters table) over this very command at --steps 3, counters of the kernel with the
+    largest total, gfx950 correction read = 2 x FETCH_SIZE KiB (same guide, HBM section).  None when rocprofv3 is not on the box, the
+    passes fail or time out, or this process is itself one of those passes."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("RF_BENCH_IN_PMC") == "1" or args.gpus != 1:
+        return None
+    flags = [a for a in sys.argv[1:]]
+    for drop, has_val in (("--steps", True), ("--warmup", True), ("--extras", True), ("--settle-ms", True), ("--cpu-seconds", True), ("--traffic", True),
+                          ("--no-cpu-baseline", False)):
+        while drop in flags:
+            i = flags.index(drop)
+            del flags[i : i + (2 if has_val else 1)]
+    cmd_tail = [sys.executable, os.path.abspath(__file__), *flags, "--steps", "3", "--warmup", "1", "--extras", "off", "--no-cpu-baseline", "--settle-ms", "0"]
+    env = dict(os.environ, RF_BENCH_IN_PMC="1", TMPDIR="/tmp")
+    got = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp") as w:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            try:
+                r = subprocess.run([exe, "--pmc", counter, "-d", os.path.join(w, counter), "-o", "p", "--", *cmd_tail], cwd="/tmp", env=env, capture_output=True,
+                                   text=True, timeout=150)
+                db = os.path.join(w, counter, "p_results.db")
+                if r.returncode != 0 or not os.path.exists(db):
+                    return None
+                cur = sqlite3.connect(db).cursor()
+                rows = [r for r in cur.execute("select kernel_name, avg(value), count(*), sum(value) from counters_collection where counter_name = ? and "
+                                               "kernel_name like '%rf::%' group by kernel_name", (counter,)) if "probe" not in r[0] and "core_clock" not in r[0]]
+            except (subprocess.SubprocessError, OSError, sqlite3.Error):
+                return None
+            if not rows:
+                return None
+            got[counter] = {name: (avg, cnt, tot) for name, avg, cnt, tot in rows}
+    # the step's kernels: everything of the library that ran once per step or more (3 timed + 1 warm-up + settle-free first call = >= 4 dispatches)
+    names = [k for k, (_, cnt, _) in got["FETCH_SIZE"].items() if cnt >= 4 and k in got["WRITE_SIZE"]]
+    if not names:
+        return None
+    steps_seen = min(got["FETCH_SIZE"][k][1] for k in names)
+    read = sum(2.0 * got["FETCH_SIZE"][k][2] * 1024.0 for k in names) / steps_seen
+    write = sum(got["WRITE_SIZE"][k][2] * 1024.0 for k in names) / steps_seen
+    return {"bytes_per_launch": read + write, "read": read, "write": write, "kernels": sorted(n[:60] for n in names),
+            "source": f"in-run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command at --steps 3, {time.perf_counter() - t0:.0f} s; "
+                      "read = 2 x FETCH_SIZE KiB (gfx950), write = WRITE_SIZE KiB; summed over the step's kernels"}
+
+
 def measured_traffic(args, n, kernel_ms):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload
+    """HBM bytes per launch: measured in this run when rocprofv3 is on the box (traffic_in_run), else from the committed rocprofv3 PMC
+    passes of this exact workload, marked "source": "committed ..."
     (profiles/traffic.json, written by tools/rocpd_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs with the
     gfx950 2x FETCH_SIZE correction of MI355X_MICROARCH.md).  None when no profile matches the workload -- or when the
     kernel has changed since the counters were collected (its steady-state time then differs from this run's by more
     than 15 %): a stale counter is not evidence."""
+    mode = getattr(args, "traffic", "auto")
+    if mode == "on" or (mode == "auto" and n >= 10_000_000 and getattr(args, "config", None) != "c5"):
+        try:
+            live = traffic_in_run(args, kernel_ms)
+        except Exception:  # a measurement aid: never fails the bench line
+            live = None
+        if live is not None:
+            return live
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except OSError:
@@ -676,7 +741,7 @@ def measured_traffic(args, n, kernel_ms):
     at = e.get("kernel_us_at_collection")
     if at and abs(at / 1e3 - kernel_ms) > 0.15 * kernel_ms:
         return None
-    return {"bytes_per_launch": e["total"], "read": e["read"], "write": e["write"], "source": e.get("source", ""),
+    return {"bytes_per_launch": e["total"], "read": e["read"], "write": e["write"], "source": "committed: " + e.get("source", ""),
             **({"kernel_us_at_collection": at} if at else {})}
 
 

@@ -15,7 +15,11 @@ ROWS = [  # (file stem, label)
     ("ragged_osa", "ragged, OSA"),
     ("ragged_indel", "ragged, Indel"),
     ("ragged_jaro_winkler", "ragged, Jaro-Winkler (f64 out)"),
-    ("c3_levenshtein_256", "C3 Levenshtein, query 256 x 10 M len 256"),
+    ("ragged_cutoff3", "ragged [1, 64], `score_cutoff = 3` (4 of 64 lengths inside the window; the rest is the None pre-fill)"),
+    ("ragged57_cutoff3", "ragged, lengths uniform in [57, 64], `score_cutoff = 3` (half the corpus inside the window: length-run views, round 4)"),
+    ("ragged57_osa_cutoff3", "the same, OSA"),
+    ("c3_levenshtein_256", "C3 Levenshtein, query 256 x 10 M len 256 (4-word asm scan, round 4)"),
+    ("q128_levenshtein", "query 128 x 20 M len 128 (2-word asm scan)"),
     ("c3_cutoff8", "C3 corpus, `score_cutoff = 8`"),
     ("c4_indel", "C4 Indel"),
     ("c4_lcs_seq", "C4 LCS"),

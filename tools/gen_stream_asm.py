@@ -34,6 +34,7 @@ import os
 import sys
 
 ADDR = [30, 31, 32, 33]
+ADDS32 = os.environ.get("RF_GEN_ADDS32", "0") == "1"
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
         ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
@@ -98,9 +99,11 @@ class Kind:
             PM = self.rows[i % 8][0]
             return {"a": [f"v_and_b32 v{A32}, v{PM}, v{VP32}"], "S": [f"v_add_u32 v{A32}, v{A32}, v{VP32}"],
                     "e": [f"v_bitop3_b32 v{E32}, v{A32}, v{VP32}, v{PM} bitop3:0xbe"], "hp": [f"v_bitop3_b32 v{HP32}, v{VN32}, v{E32}, v{VP32} bitop3:0xf1"],
-                    "hn": [f"v_and_b32 v{HN32}, v{E32}, v{VP32}"], "hq": [f"v_lshl_or_b32 v{HP32}, v{HP32}, 1, 1"],
+                    "hn": [f"v_and_b32 v{HN32}, v{E32}, v{VP32}"],
+                    # RF_GEN_ADDS32=1 (experiment): the two half-rate shift-and-add forms as pairs of full-rate VOP2 adds
+                    "hq": ([f"v_add_u32 v{HP32}, v{HP32}, v{HP32}", f"v_add_u32 v{HP32}, 1, v{HP32}"] if ADDS32 else [f"v_lshl_or_b32 v{HP32}, v{HP32}, 1, 1"]),
                     "t": [f"v_bitop3_b32 v{T32}, v{E32}, v{VN32}, v{HP32} bitop3:0x01"], "vn": [f"v_bitop3_b32 v{VN32}, v{HP32}, v{E32}, v{VN32} bitop3:0xe0"],
-                    "vp": [f"v_lshl_add_u32 v{VP32}, v{HN32}, 1, v{T32}"]}[tok]
+                    "vp": ([f"v_add_u32 v{HN32}, v{HN32}, v{HN32}", f"v_add_u32 v{VP32}, v{HN32}, v{T32}"] if ADDS32 else [f"v_lshl_add_u32 v{VP32}, v{HN32}, 1, v{T32}"])}[tok]
         PM, PMO = self.rows[i % 8], self.rows[(i - 1) % 8]
         return {"t": [f"v_bitop3_b32 v{R1_[h]}, v{D0_[h]}, v{PM[h]}, v{PM[h]} bitop3:0x0c" for h in (0, 1)],       # ~D0 & PM
                 "ts": [f"v_lshlrev_b64 {pr(R1_)}, 1, {pr(R1_)}"],

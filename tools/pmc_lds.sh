@@ -4,8 +4,8 @@ set -u
 TAG=$1; MATCH=$2; shift 2
 R=$PWD; export TMPDIR=/tmp; W=/tmp/rfpmc_$TAG; rm -rf $W; mkdir -p $W gpurun_out
 cd /tmp
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $W/p1 -o p1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --extras off "$@" > $W/p1.log 2>&1
-rocprofv3 --kernel-trace --stats -d $W/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --extras off "$@" > $W/kt.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $W/p1 -o p1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --extras off --traffic off "$@" > $W/p1.log 2>&1
+rocprofv3 --kernel-trace --stats -d $W/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --extras off --traffic off "$@" > $W/kt.log 2>&1
 cd $R
 python - "$MATCH" $W/p1/p1_results.db $W/kt/kt_results.db > gpurun_out/pmc_$TAG.txt <<'PY'
 import sqlite3, sys

@@ -3,14 +3,14 @@
 #   rocprofv3 kernel-trace + PMC summaries of every BASELINE.json config's dominant kernel, and one bench.py JSON line per config.
 # Results land in gpurun_out/profiles/; copy them into profiles/ afterwards.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 mkdir -p gpurun_out/profiles
 cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
 # ONLY=<substring> restricts the run to the profiles / bench lines whose tag contains it (e.g. ONLY=ragged)
 P() { tag=$1; key=$2; shift 2; [[ -n "${ONLY:-}" && $tag != *$ONLY* ]] && return; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
 MATCH="rf::stream_lev64" P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
 MATCH="rf::head_filter" P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
-P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
+MATCH="rf::stream_levw4" P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
 P c4_indel "indel:q64:n100000000:l64:cutNone:many" --metric indel
 MATCH="rf::jaro" P c4_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many" --metric jaro_winkler
 MATCH="rf::stream_osa" P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
@@ -21,10 +21,17 @@ MATCH="rf::band" P c3_cutoff8_band "levenshtein:q256:n10000000:l256:cut8:many" -
 MATCH="rf::stream_lev64" P ragged_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:ragged" --ragged
 MATCH="rf::window_gather" P ragged_gather "none" --ragged --metric indel
 MATCH="rf::jaro" P ragged_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric jaro_winkler
+MATCH="rf::head_filter" P ragged_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many:ragged" --ragged --min-len 57 --cutoff 3
+MATCH="rf::stream_kernel_occ8" P ragged_indel "indel:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric indel
 MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
-b() { name=$1; shift; [[ -n "${ONLY:-}" && $name != *$ONLY* ]] && return; python bench.py "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
-b c2_levenshtein
+b() { name=$1; shift; [[ -n "${ONLY:-}" && $name != *$ONLY* ]] && return; python bench.py --traffic off --extras off "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
+# the default line exactly as the driver runs it (extra_configs legs, in-run traffic)
+[[ -z "${ONLY:-}" || c2_levenshtein == *$ONLY* ]] && python bench.py 2>/dev/null | tail -1 > gpurun_out/profiles/bench_c2_levenshtein.json
+b ragged_cutoff3 --ragged --cutoff 3
+b ragged57_cutoff3 --ragged --min-len 57 --cutoff 3
+b ragged57_osa_cutoff3 --ragged --min-len 57 --cutoff 3 --metric osa --no-cpu-baseline
+b q128_levenshtein --query-len 128 --cand-len 128 --candidates 20000000
 b ragged_levenshtein --ragged
 b ragged_q32_levenshtein --ragged --query-len 32
 b ragged_osa --ragged --metric osa --no-cpu-baseline
@@ -49,16 +56,16 @@ b cutoff5_many --cutoff 5
 b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
 b c3_cutoff8 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
 if [ -n "${ONLY:-}" ]; then cp gpurun_out/*_$R.txt gpurun_out/*_$R.json gpurun_out/profiles/ 2>/dev/null; ls gpurun_out/profiles | wc -l; exit 0; fi
-RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/profiles/bench_sharded_path_world1.json
-python bench.py --config c5 2>/dev/null | tail -1 > gpurun_out/profiles/bench_c5_1B_world1.json
+RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --no-cpu-baseline --traffic off --extras off 2>/dev/null | tail -1 > gpurun_out/profiles/bench_sharded_path_world1.json
+python bench.py --config c5 --extras off 2>/dev/null | tail -1 > gpurun_out/profiles/bench_c5_1B_world1.json
 python tools/time_mixed.py > gpurun_out/profiles/mixed_tiles_$R.txt 2>/dev/null; RF_NO_MIXED_TILES=1 python tools/time_mixed.py >> gpurun_out/profiles/mixed_tiles_$R.txt 2>/dev/null
 for v in lev256c8; do RF_NO_BAND=1 python tools/ab_time.py $v 2>/dev/null | tail -1 | sed 's/librfgpu.so/RF_NO_BAND=1/'; python tools/ab_time.py $v 2>/dev/null | tail -1; done > gpurun_out/profiles/band_ab_$R.txt
 for v in lev64 lev64+topk lev64+topk+out indel indel+topk jw; do python tools/ab_time.py $v 2>/dev/null | tail -1; done > gpurun_out/profiles/variants_$R.txt
 # kernel timeline of the sharded step (top-16 + every distance + exchange), world size 1
-( cd /tmp && RF_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace -d /tmp/kt_sh_$R -o kt -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/kt_sh_$R.log 2>&1 )
+( cd /tmp && RF_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace -d /tmp/kt_sh_$R -o kt -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic off --extras off > /tmp/kt_sh_$R.log 2>&1 )
 ( echo "sharded step at world size 1 (RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5): rocprofv3 --kernel-trace, last two steps"; python tools/timeline.py /tmp/kt_sh_$R/kt_results.db 3 ) > gpurun_out/profiles/sharded_step_$R.txt
 # the clock ramp after an idle phase: per-launch duration of back-to-back plain scans with the settle phase off
-( cd /tmp && rocprofv3 --kernel-trace -d /tmp/kt_ramp_$R -o kt -- python $OLDPWD/bench.py --steps 40 --warmup 0 --settle-ms 0 --no-cpu-baseline > /tmp/kt_ramp_$R.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace -d /tmp/kt_ramp_$R -o kt -- python $OLDPWD/bench.py --steps 40 --warmup 0 --settle-ms 0 --no-cpu-baseline --traffic off --extras off > /tmp/kt_ramp_$R.log 2>&1 )
 python - > gpurun_out/profiles/clock_ramp_$R.txt <<PY
 import sqlite3
 cur = sqlite3.connect("/tmp/kt_ramp_$R/kt_results.db").cursor()
