@@ -5,172 +5,24 @@
 // length and lay them out for the wavefronts, translate `Args` (levenshtein.rs:1285-1331 weight dispatch)
 // into kernel parameters.  No metric is ever evaluated on the host: a shape without a device kernel is
 // RF_ERR_UNSUPPORTED.  Product code: never includes or links anything from oracle/.
-#include <dlfcn.h>
-#include <unistd.h>
-
-#include <algorithm>
-#include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <cstdio>
-#include <atomic>
-#include <unordered_map>
-#include <unordered_set>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <new>
-#include <thread>
-#include <vector>
-
-#include "rf_internal.hpp"
+#include "rf_host.hpp"
 
 namespace rf {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
-#define RF_HIP(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t _e = (expr);                                                                        \
-        if (_e != hipSuccess) {                                                                        \
-            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                              \
-            return _e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;                                \
-        }                                                                                              \
-    } while (0)
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev)
-    {
-        if (dev < 0) return;  // nothing to select (e.g. an empty corpus: the call never touches a device)
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
 }  // namespace rf
 
-using namespace rf;
+std::atomic<uint64_t> g_corpus_uid{1};
 
-struct rf_comparator {
-    rf_metric metric;
-    std::vector<uint8_t> s1;
-    std::vector<uint64_t> pm;  // 256 x words, row-major [c * words + w]; words = max(1, block_count)
-    size_t block_count = 0;
-    size_t words = 1;
-    mutable std::mutex mu;
-    mutable std::map<int, uint64_t*> d_pm;  // lazily uploaded per device
-    // u32 ("char") queries: the symbols, and one byte-level comparator per wide corpus searched (see resolve())
-    bool wide = false;
-    std::vector<uint32_t> s1w;
-    // (shared_ptr: a call keeps the lowered comparator it runs on alive even if another host thread's call evicts it from
-    // this bounded cache meanwhile -- handles may be shared between threads)
-    mutable std::map<uint64_t, std::shared_ptr<rf_comparator>> lowered;
-};
-
-struct rf_corpus {
-    int device = 0;
-    size_t n = 0;
-    uint64_t payload_bytes = 0;
-    uint64_t device_bytes = 0;
-    uint64_t data_bytes = 0;     // packed tile payloads + the tail pad chunk row
-    bool borrowed = false;       // a view (stream segment, translated image): owns none of its device buffers
-    bool no_prefill = false;     // stream segments: the driver pre-fills the whole result vector once
-    uint8_t* d_data = nullptr;
-    TileDesc* d_tiles = nullptr;
-    TileDesc* d_tiles_by_origin = nullptr;  // the same descriptors with the non-empty exact tiles ordered by their first candidate's original index (tiles_by_origin())
-    uint32_t* d_orig = nullptr;  // nullptr = identity (single length bucket, original order)
-    size_t n_slots = 0;          // entries of d_orig: 64 per tile (exact tiles, then the views)
-    // large ragged corpora return their results through a slot-ordered temporary + one gather (rf_pack.hip): built on first use
-    mutable uint8_t* d_heads8 = nullptr;       // head plane: the first 8 symbols of every candidate (small-cutoff scans; built on first use)
-    mutable uint32_t max_stored_sym = 0xFFFFFFFFu;  // largest stored symbol of the payload, exact; 0xFFFFFFFF = not computed yet (corpus_max_stored_symbol)
-    mutable uint32_t* d_slot_of = nullptr;     // candidate -> its slot
-    mutable uint32_t* d_slot_ident = nullptr;  // slot -> slot, kPad on padding lanes (stands in for d_orig in such a launch)
-    mutable uint32_t* d_window_table = nullptr;  // the coalesced gather's table (rf_pack.hip window_table_kernel): gather_rows x gather_runs
-    mutable uint32_t gather_runs = 0, gather_rows = 0;
-    uint32_t n_tiles = 0;        // exact tiles, then the virtual (one-length) views of the mixed section
-    uint32_t n_exact = 0;        // tiles [0, n_exact) are exact-length tiles; [n_exact, n_tiles) virtual views (HostLayout)
-    // the mixed section as the Levenshtein / LCS / OSA scans see it: one tile of 64 leftovers with per-lane lengths
-    uint32_t n_mixed = 0;
-    MixedDesc* d_mixed = nullptr;
-    uint32_t* d_mixed_len = nullptr;   // 64 per mixed tile
-    uint32_t* d_mixed_orig = nullptr;  // 64 per mixed tile, kPad = no candidate
-    std::vector<MixedDesc> mixed;      // host copy (length windows of cutoff runs)
-    uint32_t max_len = 0;
-    bool uniform = false;        // single length bucket: no descriptors, tile t at t * tile_bytes(uniform_len)
-    uint32_t uniform_len = 0;
-    std::vector<uint32_t> lengths;  // the distinct candidate lengths (host copy, ascending)
-    std::vector<uint32_t> length_first_tile;  // first tile of each distinct length
-    uint8_t sigma[256];           // symbol renaming: the packed corpus stores sigma[c] for candidate byte c
-    float sym_freq[256] = {0};    // relative frequency of candidate byte c (from the histogram sigma is made of; all zero = unknown)
-    uint8_t* d_sigma = nullptr;   // device copy
-    // top-k scratch, one per stream the corpus has been searched on: [candidate keys by way | root table | bound | counters].  The
-    // kernels leave bound/counters re-armed, so a top-k call is two launches (one under a tight cutoff) and no
-    // allocation or memset (topk_core()).
-    struct TopkScratch {
-        uint64_t* cand = nullptr;  // (also the base of the allocation)
-        uint64_t* root = nullptr;
-        uint64_t* bound = nullptr;
-        uint32_t* ctl = nullptr;
-        uint32_t seg_cap = 0;
-    };
-    mutable std::mutex scratch_mu;
-    mutable std::map<hipStream_t, TopkScratch> topk_scratch;
-    // A top-k call is two launches that hand state to each other through the scratch (sample scan -> bound -> scan, each
-    // selecting in its last workgroup and re-arming it).  Host threads sharing a stream must not interleave those sequences: the enqueue
-    // section of topk_core() runs under this lock (kernels of one stream then execute in enqueue order).
-    mutable std::mutex topk_enqueue_mu;
-    // The gather path's slot-ordered temporary (run_many), one per stream the corpus has been scanned on that way, kept for the
-    // corpus' lifetime: a stream-ordered hipMallocAsync / hipFreeAsync pair per call made the SUBMISSION of such a step wait for the
-    // previous step (measured: 560 us per call to submit a 575 us step; 11 us with the buffer kept).  A call's scan + gather are
-    // enqueued under gather_enqueue_mu: host threads sharing a stream must not interleave two uses of the same buffer.
-    struct GatherTmp {
-        hipStream_t stream;
-        void* ptr;
-        size_t bytes;
-    };
-    mutable std::vector<GatherTmp> gather_tmp;
-    mutable std::mutex gather_enqueue_mu;
-    // head_filter_kernel's tile lists (rf_scan.hip), one per stream such a cutoff scan has run on: 8 bytes per tile.  The filter
-    // pass and the scan that walks its list are enqueued under filter_enqueue_mu (host threads sharing a stream).
-    struct TileList {
-        hipStream_t stream;
-        uint32_t* ptr;
-    };
-    mutable std::vector<TileList> tile_lists;
-    mutable std::mutex filter_enqueue_mu;
-    // u32 ("char") corpora: the stored byte is the symbol's id in THIS corpus' alphabet.  Ids 0..253 are the 254 most
-    // frequent symbols, kOverflowId lumps every rarer symbol together, kAbsentId is never stored (see resolve()).
-    bool wide = false;
-    uint64_t uid = 0;
-    std::unordered_map<uint32_t, uint8_t> alphabet;
-    std::unordered_set<uint32_t> overflow;
-    // Only when `overflow` is not empty: the u32 symbol behind every packed byte (d_raw[x] belongs to d_data[x];
-    // 0xFFFFFFFF in padding).  A query containing overflow symbols is served from a per-call byte image translated from
-    // it (Effective below) -- exact, at the price of one extra pass over 4 bytes per symbol.
-    void* d_raw = nullptr;
-    uint32_t raw_elem = 4;  // bytes per raw symbol: 2 when every symbol of the corpus is <= 0xFFFE (padding 0xFFFF), else 4 (padding 0xFFFFFFFF)
-    mutable uint8_t* d_sigma_identity = nullptr;  // for those images (their bytes are query-local ids, not renamed)
-    const rf_corpus* parent = nullptr;            // set on such an image: scratch and locks live in the real corpus
-};
-constexpr uint8_t kOverflowId = 254, kAbsentId = 255;
-static std::atomic<uint64_t> g_corpus_uid{1};
 
 // Symbol renaming.  Every column of every kernel gathers 64 table rows from LDS, one per lane, and LDS bank
 // conflicts between DIFFERENT symbols that share a bank (row index mod 32 for 8-byte rows) are the cost of that
 // gather -- ASCII classes collide systematically ('A'/'a', digits/'P'..'Y').  Renaming symbols by frequency rank
 // gives the 32 most frequent symbols of THIS corpus 32 distinct banks and pairs the rest with them one by one.
 // The packed corpus stores sigma(c); the kernels stage PM row c at LDS row sigma(c); nothing else changes.
-static void symbol_frequencies(const uint64_t* hist, float* freq)
+void symbol_frequencies(const uint64_t* hist, float* freq)
 {
     uint64_t total = 0;
     for (int c = 0; c < 256; ++c) total += hist[c];
@@ -287,10 +139,9 @@ const uint64_t* rf_comparator_pm(const rf_comparator* c, size_t* block_count)
 // kAbsentId, an id no candidate byte has, so it can never match (which is all any metric on this path asks of it);
 // a symbol the corpus lumped into its overflow class cannot be told apart from the other overflow symbols, so the
 // call is refused rather than answered approximately.  Lowered comparators are cached per corpus.
-using ComparatorRef = std::shared_ptr<rf_comparator>;
 static ComparatorRef own_comparator(rf_comparator* c) { return ComparatorRef(c, [](rf_comparator* p) { rf_comparator_free(p); }); }
 
-static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff, ComparatorRef* hold, bool* overflow_hit = nullptr)
+rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff, ComparatorRef* hold, bool* overflow_hit)
 {
     if (overflow_hit) *overflow_hit = false;
     if (!c || !corpus) {
@@ -342,27 +193,8 @@ static rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const 
     return RF_OK;
 }
 
-// What a call actually runs on: the comparator lowered to the corpus' ids and the corpus itself -- or, for a u32 query
-// that contains overflow-class symbols, a comparator over QUERY-LOCAL ids (1..r in order of first appearance) and a
-// per-call byte image of the corpus translated from its raw symbol stream (translate_kernel: query symbol -> its id,
-// anything else -> 0).  The image is a borrowed view (same tiles / slot map) that lives until the object goes out of
-// scope; its payload is released in stream order.
-struct Effective {
-    const rf_comparator* c = nullptr;
-    ComparatorRef hold;  // keeps a lowered comparator alive for the duration of the call
-    const rf_corpus* corpus = nullptr;
-    std::unique_ptr<rf_corpus> image;
-    uint8_t* temp = nullptr;
-    hipStream_t stream = nullptr;
-    std::vector<uint32_t> keys;
-    std::vector<uint8_t> vals;
-    ~Effective()
-    {
-        if (temp) (void)hipFreeAsync(temp, stream);
-    }
-};
 
-static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hipStream_t st, Effective* e)
+rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hipStream_t st, Effective* e)
 {
     bool overflow_hit = false;
     const rf_status rs = resolve(c_in, corpus, &e->c, &e->hold, &overflow_hit);
@@ -469,7 +301,7 @@ static rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corp
 // (c - h) / c for c = 0..64 common characters and h = 0..32 half-transpositions: the third term of jaro.rs:106-119,
 // divided HERE with the host's IEEE divide (the values the reference computes) and looked up by the Jaro kernels'
 // no-cutoff epilogue.  One 17 KiB table per device, uploaded on first use and kept for the life of the process.
-static const double* jaro_device_table(int device)
+const double* jaro_device_table(int device)
 {
     static std::mutex mu;
     static std::map<int, double*> tabs;
@@ -492,9 +324,9 @@ static const double* jaro_device_table(int device)
 
 // row stride (in u64) of the device PM table: the word count, or for patterns beyond the register-resident kernels
 // the word count rounded up to whole groups of 8
-static size_t pm_stride(const rf_comparator* c) { return c->words <= (size_t)kMaxWords ? c->words : (c->words + 7) / 8 * 8; }
+size_t pm_stride(const rf_comparator* c) { return c->words <= (size_t)kMaxWords ? c->words : (c->words + 7) / 8 * 8; }
 
-static rf_status comparator_device_pm(const rf_comparator* c, int device, const uint64_t** d_out)
+rf_status comparator_device_pm(const rf_comparator* c, int device, const uint64_t** d_out)
 {
     std::lock_guard<std::mutex> lock(c->mu);
     auto it = c->d_pm.find(device);
@@ -525,8 +357,6 @@ static rf_status comparator_device_pm(const rf_comparator* c, int device, const 
 // ---------------------------------------------------------------------------------------------------
 // corpus
 // ---------------------------------------------------------------------------------------------------
-constexpr size_t kTailPad = (size_t)kWave * kChunk;  // one readable chunk row past the last tile
-static inline uint64_t tile_bytes(uint32_t len) { return (uint64_t)((len + kChunk - 1) / kChunk) * kWave * kChunk; }
 
 // Host-side layout of a ragged candidate set (no device needed): the exact bytes rf_corpus_pack uploads.
 //
@@ -802,14 +632,6 @@ void rf_host_layout_free(rf_host_layout* l)
     std::memset(l, 0, sizeof(*l));
 }
 
-#define RF_HIP_C(expr)                                                                                 \
-    do {                                                                                               \
-        hipError_t _e = (expr);                                                                        \
-        if (_e != hipSuccess) {                                                                        \
-            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                              \
-            return fail(_e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP);                          \
-        }                                                                                              \
-    } while (0)
 
 // A second ORDER for the same tiles.  Tiles are stored ascending by length, so the tiles a launch has in flight at any moment
 // hold candidates from all over the corpus and their out[orig[slot]] stores never meet in a cache.  But the k-th tile of every
@@ -817,7 +639,7 @@ void rf_host_layout_free(rf_host_layout* l)
 // order): walking the non-empty exact tiles by their first candidate's original index makes concurrently running tiles write one
 // compact window of `out`.  Only launches that do not care about tile order use it (full no-cutoff scans of the register-resident
 // Levenshtein / LCS / OSA kernels); zero-length tiles and the views keep their positions.
-static std::vector<TileDesc> tiles_by_origin(const std::vector<TileDesc>& tiles, uint32_t n_exact, const uint32_t* orig)
+std::vector<TileDesc> tiles_by_origin(const std::vector<TileDesc>& tiles, uint32_t n_exact, const uint32_t* orig)
 {
     std::vector<TileDesc> out = tiles;
     uint32_t z = 0;
@@ -1181,2272 +1003,6 @@ size_t rf_corpus_alphabet_size(const rf_corpus* c, size_t* overflow_symbols)
     return c->wide ? c->alphabet.size() : 256;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// one-vs-many
-// ---------------------------------------------------------------------------------------------------
-static rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, bool f64_out,
-                      ScanParams* p, RawKind* raw)
-{
-    if (!c || !corpus || !args) {
-        set_error("null handle or args");
-        return RF_ERR_INVALID_ARG;
-    }
-    std::memset(p, 0, sizeof(*p));
-    p->len1 = (uint32_t)c->s1.size();
-    p->words = (uint32_t)pm_stride(c);  // row stride of the device table
-    p->op = (uint32_t)op;
-    p->out_f64 = f64_out ? 1 : 0;
-    p->factor = 1;
-    p->w_ins = p->w_del = p->w_sub = 1;
-    p->prefix_weight = args->prefix_weight;
-    for (size_t i = 0; i < std::min<size_t>(4, c->s1.size()); ++i) p->query_head |= (uint32_t)corpus->sigma[c->s1[i]] << (8 * i);
-    p->sigma = corpus->d_sigma;
-    p->data = corpus->d_data;
-    p->tiles = corpus->uniform ? nullptr : corpus->d_tiles;
-    p->uniform_len = corpus->uniform_len;
-    p->uniform_tile_bytes = (uint32_t)tile_bytes(corpus->uniform_len);
-    p->orig = corpus->d_orig;
-    p->n_tiles = corpus->n_tiles;
-    p->tile_begin = 0;
-    p->tile_end = corpus->n_tiles;
-    p->n_exact = corpus->n_exact;
-    p->mixed = corpus->d_mixed;  // (nullptr when the corpus has no mixed section, and on views without one)
-    p->mixed_len = corpus->d_mixed_len;
-    p->mixed_orig = corpus->d_mixed_orig;
-    p->mixed_begin = 0;
-    p->mixed_end = corpus->d_mixed ? corpus->n_mixed : 0;
-    p->tile_step = 1;
-    p->n = (uint32_t)corpus->n;
-    {   // zero-length tiles (the asm stream kernels are not given them): at most one run per ascending section of the tile order
-        int runs = 0;
-        for (size_t i = 0; i < corpus->lengths.size() && runs < 2; ++i)
-            if (corpus->lengths[i] == 0) {
-                p->zero_begin[runs] = corpus->length_first_tile[i];
-                p->zero_end[runs] = i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles;
-                ++runs;
-            }
-    }
-
-    const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
-    const bool norm_op = op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY;
-    if ((int)op < 0 || (int)op > (int)RF_OP_NORMALIZED_SIMILARITY) {
-        set_error("unknown rf_op");
-        return RF_ERR_INVALID_ARG;
-    }
-    if (usize_metric && (norm_op != f64_out)) {
-        set_error("levenshtein/indel/lcs_seq: distance and similarity are u32-valued (rf_many_u32), normalized_* are "
-                  "f64-valued (rf_many_f64)");
-        return RF_ERR_INVALID_ARG;
-    }
-    if (!usize_metric && !f64_out) {
-        set_error("jaro / jaro_winkler / fuzz ratio are f64-valued: use rf_many_f64");
-        return RF_ERR_INVALID_ARG;
-    }
-
-    if (f64_out) {
-        p->has_cutoff = std::isnan(args->cutoff_f64) ? 0 : 1;
-        p->cutoff_f64 = args->cutoff_f64;
-    } else {
-        p->has_cutoff = args->cutoff_usize != RF_NO_CUTOFF;
-        p->cutoff_u32 = (uint32_t)std::min<uint64_t>(args->cutoff_usize, 0xFFFFFFFFull);
-    }
-
-    switch (c->metric) {
-    case RF_LEVENSHTEIN: {
-        // _distance_with_pm weight dispatch, levenshtein.rs:1285-1331
-        const uint64_t ins = args->insertion_cost, del = args->deletion_cost, sub = args->substitution_cost;
-        if (ins > 0xFFFF || del > 0xFFFF || sub > 0xFFFF) {
-            set_error("levenshtein weights above 65535 are not supported on the device");
-            return RF_ERR_UNSUPPORTED;
-        }
-        p->w_ins = (uint32_t)ins;
-        p->w_del = (uint32_t)del;
-        p->w_sub = (uint32_t)sub;
-        if (ins == del && (ins == 0 || ins == sub)) {  // :1303-1316 (ins == del == 0 -> every distance is 0)
-            *raw = RAW_LEV;
-            p->finish = FIN_LEV;
-            p->factor = (uint32_t)ins;
-        } else if (ins == del && sub >= ins + del) {  // :1321-1327: Indel distance times the common factor
-            *raw = RAW_LCS;
-            p->finish = FIN_LEV_INDEL;
-            p->factor = (uint32_t)ins;
-        } else {
-            // every other table: the generalized Wagner-Fischer row DP (levenshtein.rs:212-259) in LDS
-            *raw = RAW_WF;
-            p->finish = FIN_LEV_GENERAL;
-            const uint64_t row_bytes = ((uint64_t)p->len1 + 1) * kWave * sizeof(uint32_t);
-            const uint64_t lds_budget = 150u << 10;  // of the 160 KiB a gfx950 workgroup may hold
-            const uint64_t worst = ((uint64_t)p->len1 + corpus->max_len) * std::max(std::max(ins, del), sub);
-            if (worst >= (1ull << 31) || p->len1 > 150000) {
-                set_error("levenshtein with a general weight table: distances would not fit 31 bits (or the query is beyond 150 000 symbols)");
-                return RF_ERR_UNSUPPORTED;
-            }
-            if (row_bytes + p->len1 + 8 > lds_budget) {
-                // the row does not fit LDS (queries beyond ~590 symbols): one global scratch strip per wavefront instead
-                p->wf_global = 1;
-                p->wf_waves = kWavesPerBlock;
-                const uint64_t per_block = row_bytes * kWavesPerBlock, budget = 1ull << 30;
-                p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / per_block, (uint64_t)scan_grid(corpus->n_tiles)));
-            } else {
-                p->wf_waves = (uint32_t)std::min<uint64_t>(kWavesPerBlock, (lds_budget - p->len1 - 8) / row_bytes);
-            }
-            for (size_t i = 0; i < std::min<size_t>(64, c->s1.size()); ++i)  // the register-resident kernel compares against these
-                p->wf_query[i / 4] |= (uint32_t)corpus->sigma[c->s1[i]] << (8 * (i % 4));
-        }
-        break;
-    }
-    case RF_OSA:  // osa.rs:431-461; maximum = max(len1, len2) = levenshtein's at unit weights
-        *raw = RAW_OSA;
-        p->finish = FIN_LEV;  // (beyond 512 symbols: long_kernel, with the transposition bit carried between word groups)
-        break;
-    case RF_INDEL:
-        *raw = RAW_LCS;
-        p->finish = FIN_INDEL;
-        break;
-    case RF_LCS_SEQ:
-        *raw = RAW_LCS;
-        p->finish = FIN_LCS;
-        break;
-    case RF_FUZZ_RATIO:
-        // RatioBatchComparator::similarity_with_args, fuzz.rs:127-149: normalized similarity of the inner
-        // lcs_seq comparator (quirk Q1), or of Indel when the caller asks for the documented ratio.
-        if (op != RF_OP_SIMILARITY && op != RF_OP_NORMALIZED_SIMILARITY) {
-            set_error("RatioBatchComparator only has similarity (fuzz.rs:115-149)");
-            return RF_ERR_INVALID_ARG;
-        }
-        *raw = RAW_LCS;
-        p->finish = (args->flags & RF_FLAG_RATIO_INDEL_NORMALIZATION) ? FIN_INDEL : FIN_LCS;
-        p->op = RF_OP_NORMALIZED_SIMILARITY;
-        break;
-    case RF_JARO:
-    case RF_JARO_WINKLER: {
-        *raw = RAW_JARO;
-        p->finish = c->metric == RF_JARO ? FIN_JARO : FIN_JW;
-        // Early-out under a tight cutoff (the reference's own common_char_filter idea, jaro.rs:134-145, applied while the
-        // flags are still being collected): `jaro_need` is the similarity a candidate has to reach.
-        p->jaro_need = -1.0;
-        if (!p->has_cutoff) p->jaro_tab = jaro_device_table(corpus->device);  // (nullptr on failure: the kernels then divide)
-        if (p->has_cutoff && args->prefix_weight >= 0.0 && 4.0 * args->prefix_weight <= 1.0) {
-            const double need = (op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY) ? args->cutoff_f64 : 1.0 - args->cutoff_f64;
-            if (need >= 0.6 && need <= 1.0) p->jaro_need = need;
-        }
-        // Single-word path (jaro.rs:574-583) when both strings are <= 64 symbols AFTER the window truncation of
-        // jaro.rs:550-565, multi-word path (up to 512 symbols each) otherwise.  Tiles ascend by length TWICE -- the exact
-        // tiles, then the one-length views of the mixed section -- and the single-word condition holds for a length prefix
-        // of each run, so each section splits at one tile index (jaro_split, jaro_split2): a short leftover behind a long
-        // exact tile still takes the single-word kernel.
-        const uint64_t len1 = c->s1.size();
-        p->jaro_split = corpus->n_exact;
-        p->jaro_split2 = corpus->n_tiles;
-        for (size_t i = 0; i < corpus->lengths.size(); ++i) {
-            uint64_t a = len1, b = corpus->lengths[i];
-            if (b > a) {
-                const uint64_t bound = b / 2 - 1;
-                if (b > a + bound) b = a + bound;
-            } else if (a >= 2) {
-                const uint64_t bound = a / 2 - 1;
-                if (a > b + bound) a = b + bound;
-            }
-            const bool needs_flags = a != 0 && b != 0;  // otherwise decided by the length filter alone
-            const bool word_ok = !needs_flags || (a <= 64 && b <= 64);
-            if (word_ok) continue;
-            // this run of equal-length tiles [first, end) needs the multi-word path.  (A run may straddle the two sections: the last
-            // exact length and the first view can be the same length, and the length table merges them.)
-            const uint32_t first = corpus->length_first_tile[i];
-            const uint32_t end = i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles;
-            if (first < corpus->n_exact) p->jaro_split = std::min(p->jaro_split, first);
-            if (end > corpus->n_exact) p->jaro_split2 = std::min(p->jaro_split2, std::max(first, corpus->n_exact));
-            if (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords)
-                p->jaro_long = 1;  // beyond 512 symbols: the flag words move from registers to global scratch strips
-        }
-        if (p->jaro_long) {
-            // per wavefront: P words (len1 / 64 + 1) and T words (max candidate length / 64) for 64 lanes
-            p->long_chunks_max = (corpus->max_len + 63) / 64 + 1;
-            const uint64_t strip_bytes = ((uint64_t)(p->len1 + 63) / 64 + 1 + p->long_chunks_max) * kWave * sizeof(uint64_t);
-            const uint64_t budget = 1ull << 30;
-            p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / (strip_bytes * kWavesPerBlock), (uint64_t)scan_grid(corpus->n_tiles)));
-        }
-        if (p->jaro_need >= 0.0) {
-            // Length window, the reference's length_filter (jaro.rs:122-131) hoisted to the host: with m = min(len1, L)
-            // the similarity of a candidate of length L is at most (m/len1 + m/L + 1)/3 (+ the largest Winkler boost);
-            // lengths that cannot reach `jaro_need` are never read -- pre-filled with None like the usize metrics'.
-            const auto& L = corpus->lengths;
-            size_t first = L.size(), last = 0;
-            const double boost = c->metric == RF_JARO_WINKLER ? 4.0 * args->prefix_weight : 0.0;
-            for (size_t i = 0; i < L.size(); ++i) {
-                const double l1 = (double)len1, l2 = (double)L[i], m = std::min(l1, l2);
-                double ub = (len1 == 0 && L[i] == 0) ? 1.0 : ((len1 == 0 || L[i] == 0) ? 0.0 : (m / l1 + m / l2 + 1.0) / 3.0);
-                ub += boost * (1.0 - ub);
-                if (ub + 1e-9 >= p->jaro_need) {
-                    first = std::min(first, i);
-                    last = i;
-                }
-            }
-            if (first == L.size()) {
-                p->tile_begin = p->tile_end = corpus->n_tiles;
-            } else {
-                p->tile_begin = corpus->length_first_tile[first];
-                p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
-            }
-            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
-        }
-        return RF_OK;  // the PM row stride may exceed kMaxWords: only block 0 is read
-    }
-    }
-
-    // The device finishes in u32 (results are u32): with a common weight factor f every intermediate is bounded by
-    // f * (len1 + max_len) -- refuse what would wrap instead of returning it mod 2^32 (the reference computes in usize).
-    if ((uint64_t)std::max<uint32_t>(p->factor, 1) * ((uint64_t)p->len1 + corpus->max_len) > 0xFFFFFFFEull) {
-        set_error("weights x string lengths exceed the u32 range of the device results");
-        return RF_ERR_UNSUPPORTED;
-    }
-    {
-        // finishing coefficients: dist = dS*S + dM*Mx + dR*raw, maximum = mS*S + mM*Mx (rf_device.hpp "Finishing")
-        const int32_t f = (int32_t)p->factor;
-        switch (p->finish) {
-        case FIN_LEV: p->fin_dS = 0, p->fin_dM = 0, p->fin_dR = f, p->fin_mS = 0, p->fin_mM = f; break;
-        case FIN_LCS: p->fin_dS = 0, p->fin_dM = 1, p->fin_dR = -1, p->fin_mS = 0, p->fin_mM = 1; break;
-        case FIN_INDEL: p->fin_dS = 1, p->fin_dM = 0, p->fin_dR = -2, p->fin_mS = 1, p->fin_mM = 0; break;
-        case FIN_LEV_INDEL: p->fin_dS = f, p->fin_dM = 0, p->fin_dR = -2 * f, p->fin_mS = f, p->fin_mM = 0; break;
-        case FIN_LEV_GENERAL: p->fin_dS = 0, p->fin_dM = 0, p->fin_dR = 1, p->fin_mS = 0, p->fin_mM = 0; break;  // maximum: wf_kernel
-        default: break;
-        }
-        if (op == RF_OP_DISTANCE || op == RF_OP_NORMALIZED_DISTANCE) {
-            p->fin_vS = p->fin_dS, p->fin_vM = p->fin_dM, p->fin_vR = p->fin_dR;
-            p->fin_flip = 0;
-            p->fin_cflip = (p->has_cutoff && !f64_out) ? p->cutoff_u32 : 0xFFFFFFFFu;
-        } else {  // similarity = maximum - distance (details/distance.rs:209-210)
-            p->fin_vS = p->fin_mS - p->fin_dS, p->fin_vM = p->fin_mM - p->fin_dM, p->fin_vR = -p->fin_dR;
-            p->fin_flip = 0xFFFFFFFFu;
-            p->fin_cflip = ~((p->has_cutoff && !f64_out) ? p->cutoff_u32 : 0u);
-        }
-    }
-
-    if (*raw == RAW_WF) return RF_OK;
-    // Long query + small distance cutoff (the reference's hyrroe2003_small_band_with_pm, levenshtein.rs:509-617, taken when
-    // len1 > 64 and 2k + 1 <= 64, :1059-1062): one 64-bit word sliding down the diagonal instead of ceil(len1 / 64) words
-    // per column.  k is the cutoff on the RAW distance (the common weight factor divided out).
-    static const bool no_band = getenv("RF_NO_BAND") != nullptr;  // A/B switch
-    if (!no_band && *raw == RAW_LEV && p->finish == FIN_LEV && p->factor >= 1 && op == RF_OP_DISTANCE && !f64_out && p->has_cutoff && c->words >= 2 &&
-        c->words <= 64 && p->cutoff_u32 / p->factor <= 31) {
-        p->band = 1;
-        p->band_k = p->cutoff_u32 / p->factor;
-    }
-    if (c->words > (size_t)kMaxWords && !p->band) {
-        // beyond 512 symbols: the multi-sweep kernel (8 words per sweep, carries parked in an HBM scratch strip)
-        if (c->words > 0x00FFFFFFu) {
-            set_error("query too long");
-            return RF_ERR_UNSUPPORTED;
-        }
-        p->long_words_pad = (uint32_t)pm_stride(c);
-        p->long_chunks_max = (corpus->max_len + kChunk - 1) / kChunk;
-        const uint64_t strip_bytes = std::max<uint64_t>(1, (uint64_t)p->long_chunks_max * kWave * sizeof(uint32_t)) * (*raw == RAW_OSA ? 2 : 1);
-        const uint64_t budget = 256ull << 20;
-        const uint64_t waves = std::max<uint64_t>(kWavesPerBlock, budget / strip_bytes);
-        p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves / kWavesPerBlock, (uint64_t)scan_grid(corpus->n_tiles)));
-        return RF_OK;
-    }
-    // Value-preserving early-out (the reference applies its cutoffs after the loops, e.g. levenshtein.rs:492-496):
-    // the kernels stop reading a tile once no lane can pass the cutoff any more (may_pass() in rf_device.hpp), for
-    // every op and output type.  It pays only when the cutoff is tight enough to kill typical candidates early --
-    // the early-out loop gives up the streaming prefetch -- so it is switched on by how much normalized distance the
-    // cutoff still allows (`slack`; measured on the C2 corpus: Levenshtein wins up to ~0.7, the LCS bound, which only
-    // gains one per remaining column, up to ~0.4).
-    if (p->has_cutoff && (*raw == RAW_LEV || *raw == RAW_OSA || *raw == RAW_LCS) && !(p->finish == FIN_LEV && p->factor == 0)) {
-        const uint64_t S = (uint64_t)p->len1 + corpus->max_len, Mx = std::max<uint64_t>(p->len1, corpus->max_len);
-        const double maximum = (double)((int64_t)p->fin_mS * (int64_t)S + (int64_t)p->fin_mM * (int64_t)Mx);
-        double slack;  // allowed distance / maximum
-        if (f64_out)
-            slack = (op == RF_OP_NORMALIZED_DISTANCE) ? p->cutoff_f64 : 1.0 - p->cutoff_f64;
-        else if (maximum <= 0.0)
-            slack = 1.0;
-        else
-            slack = (op == RF_OP_DISTANCE) ? (double)p->cutoff_u32 / maximum : 1.0 - (double)p->cutoff_u32 / maximum;
-        const double tight = *raw == RAW_LCS ? 0.4 : 0.7;
-        if (slack < tight) {
-            p->early = 1;
-            // where a tile's first chunk takes its first look (scan_body): unrelated strings gain almost one edit per column
-            {
-                static const int forced = [] { const char* e = getenv("RF_FIRST_CHECK"); return e ? atoi(e) : 0; }();  // A/B switch
-                const double raw_allowed = slack * maximum / (double)std::max<uint32_t>(1u, (uint32_t)std::abs(p->fin_dR));
-                // measured on the C2 corpus (cutoffs 0..12, looks at 4..16): the best look is the first even column >= cutoff + 3
-                // (cutoff 3: 195 -> 213 Gpairs/s, cutoff 0: 197 -> 233, cutoff 8: 125 -> 159)
-                const double need = raw_allowed + 3.0;
-                p->first_check = need <= 4.0 ? 4u : (need >= 15.0 ? 16u : 2u * (uint32_t)((need + 1.999) / 2.0));
-                if (*raw == RAW_LCS) {
-                    // the LCS bound loses one per column WITHOUT a match, and random strings still match every third column or so:
-                    // Indel cutoff 4 is best looked at in column 10-12 (221 -> 233 Gpairs/s), cutoff 12 not before the chunk's end
-                    const double misses = (p->finish == FIN_LCS ? slack * maximum : slack * maximum / 2.0), lcs_need = (misses + 3.0) / 0.55;
-                    p->first_check = lcs_need >= 15.0 ? 16u : std::max(4u, 2u * (uint32_t)((lcs_need + 1.999) / 2.0));
-                }
-                if (forced >= 4 && forced <= 16 && forced % 2 == 0) p->first_check = (uint32_t)forced;
-            }
-            // Length window: before any byte is read a candidate of length L already has a favourable bound -- distance >=
-            // |len1 - L| (the reference's first test, levenshtein.rs:1389-1391), LCS <= min(len1, L).  Lengths whose bound
-            // fails the cutoff (same arithmetic as may_pass() on the device) are never read: tiles ascend by length, so
-            // the survivors lie in ONE tile range [first passing length, last passing length]; the rest of `out` is
-            // pre-filled with None.
-            const auto& L = corpus->lengths;
-            size_t first = L.size(), last = 0;
-            uint32_t pass_lo = 0xFFFFFFFFu, pass_hi = 0;  // the shortest and the longest candidate length that can pass
-            for (size_t i = 0; i < L.size(); ++i) {
-                const uint32_t len2 = L[i];
-                const uint32_t Sv = p->len1 + len2, Mv = std::max(p->len1, len2);
-                const uint32_t raw_b = *raw == RAW_LCS ? std::min(p->len1, len2) : (p->len1 > len2 ? p->len1 - len2 : len2 - p->len1);
-                bool pass;
-                if (!f64_out) {
-                    const uint32_t v = (uint32_t)p->fin_vS * Sv + (uint32_t)p->fin_vM * Mv + (uint32_t)p->fin_vR * raw_b;
-                    pass = (v ^ p->fin_flip) <= p->fin_cflip;
-                } else {
-                    const uint32_t dist = (uint32_t)p->fin_dS * Sv + (uint32_t)p->fin_dM * Mv + (uint32_t)p->fin_dR * raw_b;
-                    const uint32_t mx = (uint32_t)p->fin_mS * Sv + (uint32_t)p->fin_mM * Mv;
-                    const double nd = mx == 0 ? 0.0 : (double)dist / (double)mx;
-                    pass = op == RF_OP_NORMALIZED_DISTANCE ? nd <= p->cutoff_f64 : (1.0 - nd) >= p->cutoff_f64;
-                }
-                if (pass) {
-                    first = std::min(first, i);
-                    last = i;
-                    pass_lo = std::min(pass_lo, len2);
-                    pass_hi = std::max(pass_hi, len2);
-                }
-            }
-            // (the length table follows the tile order -- exact tiles ascending, then the one-length views of the mixed
-            // section ascending -- so [first, last] may enclose lengths that cannot pass: those tiles are merely read)
-            if (first == L.size()) {
-                p->tile_begin = p->tile_end = corpus->n_tiles;  // nothing can pass
-                p->mixed_begin = p->mixed_end = 0;
-            } else {
-                p->tile_begin = corpus->length_first_tile[first];
-                p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
-                // mixed tiles ascend by length as well: the ones whose length span meets [pass_lo, pass_hi]
-                uint32_t mb = 0, me = p->mixed_end;
-                while (mb < me && corpus->mixed[mb].max_len < pass_lo) ++mb;
-                while (me > mb && corpus->mixed[me - 1].min_len > pass_hi) --me;
-                p->mixed_begin = mb;
-                p->mixed_end = me;
-            }
-            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles ||
-                                                      (corpus->d_mixed && (p->mixed_begin > 0 || p->mixed_end < corpus->n_mixed)));
-        }
-    }
-    return RF_OK;
-}
-
-// bytes of per-launch scratch the planned kernels need (0 = none): carry strips of long_kernel, the global DP rows of
-// wf_kernel, the flag strips of jaro_long_kernel -- all handed to the kernels through ScanParams::long_scratch
-static size_t launch_scratch_bytes(const ScanParams& p, RawKind raw)
-{
-    const size_t waves = (size_t)p.long_grid * kWavesPerBlock;
-    if (p.jaro_long) return waves * (((size_t)p.len1 + 63) / 64 + 1 + p.long_chunks_max) * kWave * sizeof(uint64_t);
-    if (p.wf_global) return waves * ((size_t)p.len1 + 1) * kWave * sizeof(uint32_t);
-    if (p.long_words_pad) return waves * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t) * (raw == RAW_OSA ? 2 : 1);
-    return 0;
-}
-
-// The largest stored symbol of the payload (symbols are stored as their frequency rank: a 62-symbol corpus holds 0 .. 61), computed
-// exactly on first use -- one streaming pass -- and kept.  0xFFFFFFFF when it cannot be had.
-static uint32_t corpus_max_stored_symbol(const rf_corpus* corpus, hipStream_t st)
-{
-    if (corpus->borrowed || corpus->wide || !corpus->d_data || corpus->data_bytes < 16) return 0xFFFFFFFFu;
-    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
-    if (corpus->max_stored_sym == 0xFFFFFFFFu) {
-        uint32_t* d = nullptr;
-        uint32_t v = 0;
-        if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) {
-            (void)hipGetLastError();
-            return 0xFFFFFFFFu;
-        }
-        hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), st);
-        if (e == hipSuccess) e = launch_max_byte(corpus->d_data, corpus->data_bytes, d, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(&v, d, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(d);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return 0xFFFFFFFFu;
-        }
-        corpus->max_stored_sym = v;
-    }
-    return corpus->max_stored_sym;
-}
-
-// Small-cutoff Levenshtein scans of large single-length corpora take their first look from the head plane (rf_pack.hip
-// head8_plane_kernel).  Built once per corpus, on the first such scan; RF_HEAD8_MIN=<tiles> moves the threshold (0 = never).
-// Failing to allocate it is not an error: the scan then reads the tiles' first chunk rows as before.
-static const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, RawKind raw, hipStream_t st)
-{
-    static const size_t min_tiles = [] { const char* e = getenv("RF_HEAD8_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 14; }();
-    if (!min_tiles || !p.early || (raw != RAW_LEV && raw != RAW_OSA) || p.words != 1 || p.first_check > 8 || corpus->borrowed)
-        return nullptr;
-    // single-length corpora: every tile; length-bucketed corpora (round 4): the exact tiles, whose length runs the cutoff scans
-    // then walk as single-length corpora of their own (launch_scan_runs)
-    const uint32_t plane_tiles = corpus->uniform ? corpus->n_tiles : corpus->n_exact;
-    if (plane_tiles < min_tiles || (corpus->uniform ? corpus->uniform_len < (uint32_t)kChunk : (!corpus->d_tiles || !corpus->d_orig || corpus->max_len < (uint32_t)kChunk)))
-        return nullptr;
-    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
-    if (!corpus->d_heads8) {
-        uint8_t* h = nullptr;
-        if (hipMalloc((void**)&h, ((size_t)plane_tiles + 1) * kWave * 8) != hipSuccess) {  // (+ one row: head_filter_kernel reads tiles in pairs)
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        hipError_t e = corpus->uniform ? launch_head8_plane(corpus->d_data, corpus->n_tiles, (uint32_t)tile_bytes(corpus->uniform_len), h, st)
-                                       : launch_head8_plane_tiles(corpus->d_data, corpus->d_tiles, plane_tiles, h, st);
-        if (e == hipSuccess) e = hipMemsetAsync(h + (size_t)plane_tiles * kWave * 8, 0, kWave * 8, st);  // the pad row: defined bytes
-        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (other streams may use the plane as soon as the lock is released)
-        if (e != hipSuccess) {
-            (void)hipFree(h);
-            return nullptr;
-        }
-        corpus->d_heads8 = h;
-    }
-    return corpus->d_heads8;
-}
-
-// The BAND PREFILTER of the head-plane cutoff scans (rf_scan.hip early_lean_body has the kernel side and the proof): with at most
-// K edits allowed, at least 8 - K of a candidate's first 8 symbols must equal a query symbol within K positions of their own.
-// Decides whether a launch uses it: K = the largest raw distance that passes the cutoff (the same arithmetic as may_pass() on
-// the device, over every raw value a 64-symbol pair can have) must be <= 3, and by the corpus' symbol frequencies a tile of 64
-// random candidates must be unlikely to have a lane that passes the filter -- otherwise (small alphabets, repetitive queries) the
-// filter is 30 instructions per tile spent for nothing.  RF_BAND_FILTER=0 / 1 forces it off / on wherever K <= 3.
-static void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, ScanParams* p, uint32_t len2)
-{
-    p->head_need = 0;
-    if (!p->heads8 || !p->early || p->words != 1 || len2 < 8) return;
-    static const int forced = [] { const char* e = getenv("RF_BAND_FILTER"); return e ? atoi(e) : -1; }();
-    if (forced == 0) return;
-    const uint32_t len1 = p->len1;
-    const uint32_t Sv = len1 + len2, Mv = std::max(len1, len2);
-    int K = -1;
-    for (uint32_t raw = 0; raw <= Mv; ++raw) {
-        bool pass;
-        if (!f64_out) {
-            const uint32_t v = (uint32_t)p->fin_vS * Sv + (uint32_t)p->fin_vM * Mv + (uint32_t)p->fin_vR * raw;
-            pass = (v ^ p->fin_flip) <= p->fin_cflip;
-        } else {
-            const uint32_t dist = (uint32_t)p->fin_dS * Sv + (uint32_t)p->fin_dM * Mv + (uint32_t)p->fin_dR * raw;
-            const uint32_t mx = (uint32_t)p->fin_mS * Sv + (uint32_t)p->fin_mM * Mv;
-            const double nd = mx == 0 ? 0.0 : (double)dist / (double)mx;
-            pass = op == RF_OP_NORMALIZED_DISTANCE ? nd <= p->cutoff_f64 : (1.0 - nd) >= p->cutoff_f64;
-        }
-        if (pass) K = (int)raw;
-    }
-    if (K < 0 || K > 3) return;
-    const uint32_t need = 8u - (uint32_t)K;
-    if (forced != 1) {
-        // P(symbol i of a random candidate has a partner in the band) from the symbol frequencies, then the distribution of the
-        // number of such symbols among 8 (independent positions), then a tile of 64 lanes
-        bool known = false;
-        for (int ch = 0; ch < 256; ++ch) known = known || corpus->sym_freq[ch] > 0.0f;
-        if (!known) return;
-        double dist[9] = {1.0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 8; ++i) {
-            double pi = 0.0;
-            for (int j = std::max(0, i - K); j <= i + K && j < (int)c->s1.size(); ++j) {
-                bool seen = false;  // (a symbol that occurs twice in the band counts once)
-                for (int j2 = std::max(0, i - K); j2 < j; ++j2) seen = seen || c->s1[j2] == c->s1[j];
-                if (!seen) pi += corpus->sym_freq[c->s1[j]];
-            }
-            pi = std::min(1.0, pi);
-            for (int m = i + 1; m >= 1; --m) dist[m] = dist[m] * (1.0 - pi) + dist[m - 1] * pi;
-            dist[0] *= 1.0 - pi;
-        }
-        double lane = 0.0;
-        for (uint32_t m = need; m <= 8; ++m) lane += dist[m];
-        const double tile = 1.0 - std::pow(1.0 - lane, 64.0);
-        if (tile > 0.35) return;
-    }
-    p->head_need = need;
-    p->head_k = (uint32_t)K;
-}
-
-// this stream's tile list for head_filter_kernel (the caller holds corpus->filter_enqueue_mu); nullptr = none to be had, the
-// scan then filters inside the cutoff kernel
-static uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
-{
-    for (size_t i = 0; i < corpus->tile_lists.size(); ++i)
-        if (corpus->tile_lists[i].stream == st) {  // most recently used first
-            const rf_corpus::TileList hit = corpus->tile_lists[i];
-            corpus->tile_lists.erase(corpus->tile_lists.begin() + (long)i);
-            corpus->tile_lists.insert(corpus->tile_lists.begin(), hit);
-            return hit.ptr;
-        }
-    if (corpus->tile_lists.size() >= 4) {
-        // a fifth stream: the least recently used list changes hands instead of the scan silently falling back to the slower
-        // in-kernel filter.  Its old stream's work is waited for first -- rare, and only then.
-        rf_corpus::TileList lru = corpus->tile_lists.back();
-        corpus->tile_lists.pop_back();
-        (void)hipStreamSynchronize(lru.stream);
-        lru.stream = st;
-        corpus->tile_lists.insert(corpus->tile_lists.begin(), lru);
-        return lru.ptr;
-    }
-    uint32_t* ptr = nullptr;
-    // (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the packed list)
-    if (hipMalloc((void**)&ptr, (2 * (size_t)corpus->n_tiles + 5 * 16384 + 8) * sizeof(uint32_t)) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    corpus->tile_lists.insert(corpus->tile_lists.begin(), {st, ptr});
-    return ptr;
-}
-
-// RF_TILE_ORDER (run_many has what it selects): 0 = never by origin, 1 = by origin without the XCD deal, 2 = default, 3 = also the
-// kernels that lose by it
-static int tile_order_knob()
-{
-    static const int v = [] { const char* e = getenv("RF_TILE_ORDER"); return e ? atoi(e) : 2; }();
-    return v;
-}
-
-// LENGTH-BUCKETED corpora under a small cutoff (round 4; VERDICT r3 missing #1).  The head plane, the band prefilter, the streaming
-// first look and the lean cutoff kernel were written for single-length corpora (tile t at t * tile_bytes, slot = index).  The exact
-// tiles of ONE length of a bucketed corpus are exactly that -- back to back in the payload, 64 slots per tile -- except that a
-// slot's result belongs at out[orig[slot]].  So the tiles of every length inside the cutoff's length window are walked as a
-// single-length corpus of their own (ScanParams::run_orig): `out` is pre-filled with None ONCE, dead tiles store nothing (on a
-// single-length corpus they cost the filter pass one 8-byte store per lane; here they would be scattered), and the rare surviving
-// lane writes through orig[].  Runs too short to pay for three launches (and tiles shorter than a chunk), the one-length views and the
-// mixed section keep the general cutoff kernels.  Same values either way: tests/test_gpu_parity.py forces both.
-static bool scan_runs_applies(const rf_corpus* corpus, const ScanParams& p, RawKind raw)
-{
-    return !corpus->uniform && p.heads8 && p.early && p.words == 1 && (raw == RAW_LEV || raw == RAW_OSA) && p.first_check <= 8 && p.tile_step == 1 &&
-           p.tiles == corpus->d_tiles && corpus->d_orig && !p.band && !p.long_words_pad;
-}
-static hipError_t launch_scan_runs(RawKind raw, const ScanParams& p, const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, hipStream_t st)
-{
-    static const uint32_t min_run = [] { const char* e = getenv("RF_RUN_MIN_TILES"); return e ? (uint32_t)atoi(e) : 256u; }();
-    hipError_t e = hipSuccess;
-    if (p.out && !p.topk_k) e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, (size_t)p.n * (p.out_f64 ? 2 : 1), st);
-    const uint32_t ex_begin = std::min(p.tile_begin, corpus->n_exact), ex_end = std::min(p.tile_end, corpus->n_exact);
-    uint64_t off = 0;  // payload offset of the current length's first tile (exact tiles lie back to back in length order)
-    uint32_t pend_a = 0, pend_b = 0;  // general launches are merged over neighbouring short runs
-    auto flush_general = [&]() {
-        if (e == hipSuccess && pend_b > pend_a) {
-            ScanParams q = p;
-            q.tile_begin = pend_a, q.tile_end = pend_b;
-            q.mixed = nullptr, q.mixed_begin = q.mixed_end = 0;
-            q.prefill_none = 0;
-            q.heads8 = nullptr;
-            e = launch_scan(raw, q, st, nullptr);
-        }
-        pend_a = pend_b = 0;
-    };
-    for (size_t i = 0; i < corpus->lengths.size() && e == hipSuccess; ++i) {
-        const uint32_t first = corpus->length_first_tile[i];
-        if (first >= corpus->n_exact) break;
-        const uint32_t end = std::min(i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles, corpus->n_exact);
-        const uint32_t L = corpus->lengths[i];
-        const uint32_t a = std::max(first, ex_begin), b = std::min(end, ex_end);
-        if (b > a) {
-            if (L >= (uint32_t)kChunk && b - a >= min_run && tile_bytes(L) <= 0xFFFFFFFFull) {
-                flush_general();
-                ScanParams q = p;
-                q.tiles = nullptr, q.orig = nullptr;
-                q.mixed = nullptr, q.mixed_begin = q.mixed_end = 0;
-                q.data = p.data + off + (uint64_t)(a - first) * tile_bytes(L);
-                q.heads8 = p.heads8 + (size_t)a * kWave * 8;
-                q.uniform_len = L;
-                q.uniform_tile_bytes = (uint32_t)tile_bytes(L);
-                q.n_tiles = q.n_exact = b - a;
-                q.tile_begin = 0, q.tile_end = b - a;
-                q.n = (b - a) * (uint32_t)kWave;
-                q.run_orig = corpus->d_orig + (size_t)a * kWave;
-                q.prefill_none = 0;
-                q.zero_begin[0] = q.zero_end[0] = q.zero_begin[1] = q.zero_end[1] = 0;
-                plan_band_filter(c, corpus, op, f64_out, &q, L);
-                e = launch_scan(raw, q, st, nullptr);
-            } else {
-                if (pend_b != a) flush_general();
-                if (pend_b == pend_a) pend_a = a;
-                pend_b = b;
-            }
-        }
-        off += (uint64_t)(end - first) * tile_bytes(L);
-    }
-    flush_general();
-    if (e != hipSuccess) return e;
-    // what is left of the launch: the one-length views (when the launch walks them) or the mixed section
-    ScanParams q = p;
-    q.prefill_none = 0;
-    q.heads8 = nullptr;
-    q.tile_begin = std::max(p.tile_begin, corpus->n_exact);
-    q.tile_end = std::max(p.tile_end, q.tile_begin);
-    const bool has_mixed = p.mixed && p.mixed_end > p.mixed_begin;
-    if (q.tile_end > q.tile_begin || has_mixed) {
-        if (has_mixed) q.tile_begin = q.tile_end = corpus->n_exact;  // (launch_scan then runs scan_kernel_mixed over the mixed range alone)
-        e = launch_scan(raw, q, st, nullptr);
-    }
-    return e;
-}
-
-static rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out,
-                          rf_mem out_mem, void* stream, bool f64_out)
-{
-    if (!c_in || !corpus_in || !args) {
-        set_error("null handle or args");
-        return RF_ERR_INVALID_ARG;
-    }
-    Effective eff;
-    if (const rf_status rs = make_effective(c_in, corpus_in, (hipStream_t)stream, &eff); rs != RF_OK) return rs;
-    const rf_comparator* c = eff.c;
-    const rf_corpus* corpus = eff.corpus;
-    DeviceGuard guard(corpus->n ? corpus->device : -1);  // (before plan(): grids are sized from the current device's CU count)
-    if (corpus->n && !guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
-    }
-    ScanParams p;
-    RawKind raw = RAW_LEV;
-    rf_status s = plan(c, corpus, op, args, f64_out, &p, &raw);
-    if (s != RF_OK) return s;
-    if (corpus->n == 0) return RF_OK;
-    if (!out) {
-        set_error("null output");
-        return RF_ERR_INVALID_ARG;
-    }
-    s = comparator_device_pm(c, corpus->device, &p.pm);
-    if (s != RF_OK) return s;
-
-    hipStream_t st = (hipStream_t)stream;
-    p.heads8 = corpus_head8_plane(corpus, p, raw, st);
-    if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
-    static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
-    p.max_stored_sym = (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) ? corpus_max_stored_symbol(corpus, st) : 0xFFFFFFFFu;
-    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
-    const size_t out_bytes = corpus->n * elem;
-    void* d_out = out;
-    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
-    p.out = d_out;
-    // Large ragged corpora: results in slot order into a temporary, then ONE gather into original order (rf_pack.hip
-    // "gather_results_kernel" has the why: the scattered out[orig[slot]] stores of a length-bucketed corpus cost more than the scan).
-    // The mixed section is walked through its one-length views so that every candidate has exactly one slot; a cutoff's length
-    // window pre-fills the TEMPORARY with None (launch_scan: p.out, p.n slots).  RF_UNSCATTER_MIN=<candidates> moves the threshold
-    // (0 = never).
-    // Full no-cutoff scans of the VALU-bound single-word kernels (Levenshtein for queries > 32, OSA): walk the tiles BY ORIGIN
-    // (tiles_by_origin()) with the workgroups dealt to them XCD by XCD (ScanParams::xcd_deal) and store straight through orig[].
-    // The tiles in flight on one XCD then write one compact window of `out`, the partial lines meet in that XCD's L2, and what is
-    // left of the scatter (64 L2 transactions per wavefront store instead of 4) hides under the kernel's arithmetic: bench.py
-    // --ragged 62.2 -> 74.7 (Levenshtein), 49.5 -> 59.5 (OSA) against the gather below, which stays for the kernels that are
-    // short of memory system instead (query <= 32: 72 -> 66, Indel: 80 -> 68 this way; profiles/ragged_result_order_r03.txt).
-    // RF_TILE_ORDER: 0 = never, 1 = by origin without the deal, 2 = default, 3 = also the kernels that lose by it.
-    const int tile_order = tile_order_knob();
-    const bool valu_bound = p.words == 1 && ((raw == RAW_LEV && p.len1 > 32) || raw == RAW_OSA);
-    // (Jaro: when every exact tile takes the single-word kernel -- launch_jaro splits the tiles BY POSITION where the lengths pass
-    // 64 symbols, which needs the length order)
-    const bool jaro_word_only = raw == RAW_JARO && !p.has_cutoff && p.jaro_split >= corpus->n_exact && !p.jaro_long;
-    const bool by_origin = tile_order && corpus->d_tiles_by_origin && !corpus->borrowed && !p.early && !p.prefill_none && !p.band && !p.long_words_pad &&
-                           ((valu_bound && !p.out_f64) || jaro_word_only || (tile_order >= 3 && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA))) &&
-                           p.tile_begin == 0 && p.tile_end == corpus->n_tiles;
-    if (by_origin) {
-        p.tiles = corpus->d_tiles_by_origin;
-        p.xcd_deal = tile_order >= 2 ? 1u : 0u;
-    }
-    static const size_t unscatter_min = [] { const char* e = getenv("RF_UNSCATTER_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
-    void* d_tmp = nullptr;
-    bool tmp_owned = false;                 // d_tmp is this call's own stream-ordered allocation
-    std::unique_lock<std::mutex> tmp_lock;  // held while a kept temporary's scan + gather are enqueued
-    // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 12 bytes per
-    // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
-    const bool wide_window = (uint64_t)(p.tile_end - p.tile_begin) * 10 >= (uint64_t)corpus->n_tiles * 3;
-    const bool by_runs = !by_origin && scan_runs_applies(corpus, p, raw);  // small-cutoff scans of a bucketed corpus: one single-length view per length run
-    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && wide_window && !by_origin && !by_runs) {
-        {
-            std::lock_guard<std::mutex> lock(corpus->scratch_mu);
-            if (!corpus->d_slot_ident) {
-                // once per corpus: the slot -> slot map the scans store through, and what the gather needs -- the window table
-                // (rf_pack.hip window_gather_kernel) when the slots are few enough ascending runs, else the candidate -> slot map
-                static const bool use_windows = [] { const char* e = getenv("RF_GATHER_WINDOWS"); return !e || atoi(e) != 0; }();
-                uint32_t *so = nullptr, *si = nullptr, *list = nullptr, *table = nullptr;
-                uint32_t n_runs = 0, n_rows = 0;
-                std::vector<uint32_t> runs(kMaxGatherRuns + 2, 0u);  // [0] = count, then the run starts
-                hipError_t e1 = hipMalloc((void**)&si, corpus->n_slots * sizeof(uint32_t));
-                if (e1 == hipSuccess && use_windows) {
-                    e1 = hipMalloc((void**)&list, runs.size() * sizeof(uint32_t));
-                    if (e1 == hipSuccess) e1 = hipMemsetAsync(list, 0, sizeof(uint32_t), st);
-                    if (e1 == hipSuccess) e1 = launch_run_starts(corpus->d_orig, (uint32_t)corpus->n_slots, list + 1, kMaxGatherRuns, list, st);
-                    if (e1 == hipSuccess) e1 = hipMemcpyAsync(runs.data(), list, (kMaxGatherRuns + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-                    if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
-                    if (e1 == hipSuccess && runs[0] >= 1 && runs[0] <= kMaxGatherRuns) {
-                        n_runs = runs[0];
-                        std::sort(runs.begin() + 1, runs.begin() + 1 + n_runs);
-                        runs[1 + n_runs] = (uint32_t)corpus->n_slots;
-                        n_rows = (uint32_t)((corpus->n + kGatherWindow - 1) / kGatherWindow) + 1;
-                        e1 = hipMemcpyAsync(list, runs.data() + 1, (n_runs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-                        if (e1 == hipSuccess) e1 = hipMalloc((void**)&table, (size_t)n_rows * n_runs * sizeof(uint32_t));
-                        if (e1 == hipSuccess) e1 = launch_window_table(corpus->d_orig, list, n_runs, n_rows, table, st);
-                    }
-                }
-                if (e1 == hipSuccess && !table) {
-                    e1 = hipMalloc((void**)&so, corpus->n * sizeof(uint32_t));
-                    if (e1 == hipSuccess) e1 = hipMemsetAsync(so, 0xFF, corpus->n * sizeof(uint32_t), st);
-                }
-                if (e1 == hipSuccess) e1 = launch_slot_maps(corpus->d_orig, (uint32_t)corpus->n_slots, so, si, st);
-                if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);  // (other streams may use the maps as soon as the lock is released)
-                if (list) (void)hipFree(list);
-                if (e1 != hipSuccess) {
-                    // Not an error: an HBM-tight caller keeps what round 2 gave it -- the launch below stores straight
-                    // through orig[] (scattered, slower, same values).  The next call tries again.
-                    if (so) (void)hipFree(so);
-                    if (si) (void)hipFree(si);
-                    if (table) (void)hipFree(table);
-                    (void)hipGetLastError();
-                } else {
-                    corpus->d_slot_of = so;
-                    corpus->d_window_table = table;
-                    corpus->gather_runs = n_runs;
-                    corpus->gather_rows = n_rows;
-                    corpus->d_slot_ident = si;
-                }
-            }
-        }
-        if (corpus->d_slot_ident) {
-        // the temporary: this stream's kept buffer (grown if this call needs f64 where u32 was kept); beyond 4 streams per corpus a
-        // stream-ordered allocation for the call
-        const size_t tmp_bytes = corpus->n_slots * elem;
-        tmp_lock = std::unique_lock<std::mutex>(corpus->gather_enqueue_mu);
-        hipError_t ea = hipSuccess;
-        for (rf_corpus::GatherTmp& t : corpus->gather_tmp)
-            if (t.stream == st) {
-                if (t.bytes < tmp_bytes) {
-                    void* bigger = nullptr;
-                    ea = hipMalloc(&bigger, tmp_bytes);
-                    if (ea == hipSuccess) {
-                        (void)hipFree(t.ptr);  // (synchronizes with the work that used it)
-                        t.ptr = bigger;
-                        t.bytes = tmp_bytes;
-                    }
-                }
-                d_tmp = t.ptr;
-                break;
-            }
-        if (!d_tmp && ea == hipSuccess) {
-            if (corpus->gather_tmp.size() < 4) {
-                ea = hipMalloc(&d_tmp, tmp_bytes);
-                if (ea == hipSuccess) corpus->gather_tmp.push_back({st, d_tmp, tmp_bytes});
-            } else {
-                ea = hipMallocAsync(&d_tmp, tmp_bytes, st);
-                tmp_owned = true;
-            }
-        }
-        if (ea != hipSuccess) {  // no room for the temporary: scattered stores through orig[] as before (not an error)
-            (void)hipGetLastError();
-            d_tmp = nullptr;
-            tmp_owned = false;
-            tmp_lock.unlock();
-        } else {
-            p.out = d_tmp;
-            p.orig = corpus->d_slot_ident;
-            p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
-            p.mixed_end = 0;
-            p.n = (uint32_t)corpus->n_slots;
-        }
-        }
-    }
-    if (const size_t scratch = launch_scratch_bytes(p, raw)) {
-        const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
-        if (ea != hipSuccess) {
-            if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
-            if (d_tmp && tmp_owned) (void)hipFreeAsync(d_tmp, st);  // (this call's own temporary must not outlive the failure)
-        }
-        RF_HIP(ea);
-    }
-    std::unique_lock<std::mutex> filter_lock;  // held while a filter pass and the scan over its list are enqueued
-    if (p.heads8) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
-        filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
-        p.tile_list_buf = corpus_tile_list(corpus, st);
-    }
-    static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;  // one line per rf_many_* call on stderr: which path the plan took
-    if (trace_plan)
-        std::fprintf(stderr, "[rf plan] raw=%d words=%u early=%u first_check=%u band=%u heads8=%d head_need=%u head_k=%u tile_list=%d by_runs=%d by_origin=%d gather=%d "
-                             "tiles=[%u,%u) of %u prefill=%u\n",
-                     (int)raw, p.words, p.early, p.first_check, p.band, p.heads8 != nullptr, p.head_need, p.head_k, p.tile_list_buf != nullptr, (int)by_runs, (int)by_origin,
-                     d_tmp != nullptr, p.tile_begin, p.tile_end, corpus->n_tiles, p.prefill_none);
-    hipError_t e = by_runs ? launch_scan_runs(raw, p, c, corpus, op, f64_out, st) : launch_scan(raw, p, st, nullptr);
-    if (filter_lock.owns_lock()) filter_lock.unlock();
-    if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
-    if (d_tmp) {
-        if (e == hipSuccess)
-            e = corpus->d_window_table ? launch_window_gather(d_tmp, corpus->d_orig, corpus->d_window_table, corpus->gather_runs, corpus->gather_rows, d_out,
-                                                              (uint32_t)corpus->n, f64_out, st)
-                                       : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
-        if (tmp_owned) (void)hipFreeAsync(d_tmp, st);
-        if (tmp_lock.owns_lock()) tmp_lock.unlock();
-    }
-    if (e == hipSuccess && out_mem == RF_MEM_HOST) {
-        e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-    }
-    if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
-    if (e != hipSuccess) {
-        set_error(std::string("scan launch: ") + hipGetErrorString(e));
-        return e == hipErrorInvalidValue ? RF_ERR_UNSUPPORTED : RF_ERR_HIP;
-    }
-    return RF_OK;
-}
-
-rf_status rf_many_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t* out,
-                      rf_mem out_mem, void* stream)
-{
-    return run_many(c, corpus, op, args, out, out_mem, stream, false);
-}
-
-rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, double* out,
-                      rf_mem out_mem, void* stream)
-{
-    return run_many(c, corpus, op, args, out, out_mem, stream, true);
-}
-
-static rf_status run_one(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, void* out,
-                         int* is_some, bool f64_out)
-{
-    if (!c || !args || !out || !is_some || (len2 && !s2)) {
-        set_error("rf_one: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    const uint64_t offsets[2] = {0, len2};
-    rf_corpus* corpus = nullptr;
-    rf_status s = rf_corpus_pack(s2, offsets, 1, device, &corpus);
-    if (s != RF_OK) return s;
-    if (f64_out) {
-        double v = 0.0;
-        s = run_many(c, corpus, op, args, &v, RF_MEM_HOST, nullptr, true);
-        *static_cast<double*>(out) = v;
-        *is_some = !std::isnan(v);
-    } else {
-        uint32_t v = 0;
-        s = run_many(c, corpus, op, args, &v, RF_MEM_HOST, nullptr, false);
-        *static_cast<uint32_t*>(out) = v;
-        *is_some = v != RF_NONE_U32;
-    }
-    rf_corpus_free(corpus);
-    return s;
-}
-rf_status rf_one_u32(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, uint32_t* out,
-                     int* is_some)
-{
-    return run_one(c, s2, len2, op, args, device, out, is_some, false);
-}
-rf_status rf_one_f64(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, double* out,
-                     int* is_some)
-{
-    return run_one(c, s2, len2, op, args, device, out, is_some, true);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// many queries x one corpus
-// ---------------------------------------------------------------------------------------------------
-// Queries whose recurrences fit one machine word and agree on the kernel family are fused kMaxMulti (then 2) at a
-// time into scan_multi_kernel launches, which read every candidate byte once per group; the rest go through the
-// single-query launch.  Either way row q of `out` is exactly what rf_many_* gives for cs[q].
-static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
-                                void* out, rf_mem out_mem, void* stream, bool f64_out)
-{
-    if (!cs_in || !corpus || !args) {
-        set_error("null handle or args");
-        return RF_ERR_INVALID_ARG;
-    }
-    if (q == 0 || corpus->n == 0) return RF_OK;
-    if (!out) {
-        set_error("null output");
-        return RF_ERR_INVALID_ARG;
-    }
-    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
-    const size_t row_bytes = corpus->n * elem;
-    std::vector<ScanParams> ps(q);
-    std::vector<RawKind> raws(q, RAW_LEV);
-    std::vector<const rf_comparator*> eff(q, nullptr);
-    std::vector<ComparatorRef> holds(q);
-    for (uint32_t i = 0; i < q; ++i) {
-        bool overflow_hit = false;
-        if (resolve(cs_in[i], corpus, &eff[i], &holds[i], &overflow_hit) != RF_OK && overflow_hit && corpus->d_raw) {
-            // a query with overflow-class symbols needs its own translated image of the corpus: one launch per query
-            for (uint32_t j = 0; j < q; ++j) {
-                const rf_status sj = run_many(cs_in[j], corpus, op, args, static_cast<char*>(out) + (size_t)j * row_bytes, out_mem, stream, f64_out);
-                if (sj != RF_OK) return sj;
-            }
-            return RF_OK;
-        }
-    }
-    for (uint32_t i = 0; i < q; ++i) {
-        rf_status s = resolve(cs_in[i], corpus, &eff[i], &holds[i]);
-        if (s == RF_OK) s = plan(eff[i], corpus, op, args, f64_out, &ps[i], &raws[i]);
-        if (s != RF_OK) return s;
-    }
-    const rf_comparator* const* cs = eff.data();
-    DeviceGuard guard(corpus->device);
-    if (!guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    char* d_out = static_cast<char*>(out);
-    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc((void**)&d_out, row_bytes * q));
-
-    // fusable: single-word Levenshtein / LCS-family recurrences; the group key is what the kernel cannot vary per query
-    // (a tight cutoff is better served by one early-out launch per query than by the fused kernel, which runs every column)
-    auto fusable = [&](uint32_t i) { return (raws[i] == RAW_LEV || raws[i] == RAW_LCS) && cs[i]->words == 1 && !ps[i].long_words_pad && !ps[i].early; };
-    auto same_group = [&](uint32_t a, uint32_t b) {
-        return raws[a] == raws[b] && ps[a].finish == ps[b].finish && ps[a].factor == ps[b].factor && ps[a].op == ps[b].op &&
-               (ps[a].len1 <= 32) == (ps[b].len1 <= 32);
-    };
-    std::vector<char> done(q, 0);
-    rf_status status = RF_OK;
-    hipError_t e = hipSuccess;
-    for (uint32_t i = 0; i < q && status == RF_OK && e == hipSuccess; ++i) {
-        if (done[i]) continue;
-        std::vector<uint32_t> group{i};
-        if (fusable(i))
-            for (uint32_t j = i + 1; j < q && group.size() < (size_t)kMaxMulti; ++j)
-                if (!done[j] && fusable(j) && same_group(i, j) && j == group.back() + 1) group.push_back(j);  // contiguous rows of out
-        if (group.size() == 3) group.pop_back();
-        for (uint32_t g : group) done[g] = 1;
-        ScanParams p = ps[i];
-        p.out = d_out + (size_t)i * row_bytes;
-        if (group.size() == 1) {
-            // (through run_many: a general corpus' results take the cheapest way into original order there)
-            status = run_many(cs_in[i], corpus, op, args, p.out, RF_MEM_DEVICE, stream, f64_out);
-        } else {
-            p.early = 0;  // the fused kernel always runs every column of every tile (values are the same either way)
-            p.tile_begin = 0, p.tile_end = p.n_tiles, p.prefill_none = 0;
-            p.multi_q = (uint32_t)group.size();
-            for (size_t k = 0; k < group.size() && status == RF_OK; ++k) {
-                p.multi_len1[k] = ps[group[k]].len1;
-                status = comparator_device_pm(cs[group[k]], corpus->device, &p.multi_pm[k]);
-            }
-            if (status != RF_OK) break;
-            // general corpora, LCS family: the tiles are walked by origin with the XCD deal (run_many has the why).  20 M ragged
-            // candidates x 4 queries: Indel 1.06 -> 0.89 ms.  Not the fused Levenshtein kernels: 1.19 -> 1.68 ms -- their code (4
-            // recurrences x 16 tail entries) is large, and by origin the wavefronts of a CU run different tail lengths at the same
-            // time where the storage order keeps them on the same path (instruction cache); their scatter already hides under 4
-            // queries' arithmetic.
-            if (raws[i] == RAW_LCS && tile_order_knob() && corpus->d_tiles_by_origin && !corpus->borrowed) {
-                p.tiles = corpus->d_tiles_by_origin;
-                p.xcd_deal = tile_order_knob() >= 2 ? 1u : 0u;
-            }
-            e = launch_scan_multi(raws[i], p.len1 <= 32, p, st);
-        }
-    }
-    if (status == RF_OK && e == hipSuccess && out_mem == RF_MEM_HOST) {
-        e = hipMemcpyAsync(out, d_out, row_bytes * q, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-    }
-    if (out_mem == RF_MEM_HOST) {
-        if (status != RF_OK || e != hipSuccess) (void)hipStreamSynchronize(st);
-        (void)hipFree(d_out);
-    }
-    if (status != RF_OK) return status;
-    if (e != hipSuccess) {
-        set_error(std::string("multi-query scan: ") + hipGetErrorString(e));
-        return e == hipErrorInvalidValue ? RF_ERR_UNSUPPORTED : RF_ERR_HIP;
-    }
-    return RF_OK;
-}
-
-rf_status rf_many_multi_u32(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
-                            uint32_t* out, rf_mem out_mem, void* stream)
-{
-    return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, false);
-}
-
-rf_status rf_many_multi_f64(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
-                            double* out, rf_mem out_mem, void* stream)
-{
-    return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, true);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// top-k
-// ---------------------------------------------------------------------------------------------------
-// shared by rf_topk_u32 (host results) and rf_topk_keys_device (device keys, fully asynchronous)
-static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, uint32_t k,
-                           uint32_t key_index_base, uint64_t* d_best /*device, k entries*/, uint32_t* out_all,
-                           rf_mem out_all_mem, hipStream_t st, bool* desc)
-{
-    Effective eff;
-    if (const rf_status rs = make_effective(c_in, corpus_in, st, &eff); rs != RF_OK) return rs;
-    const rf_comparator* c = eff.c;
-    const rf_corpus* corpus = eff.corpus;
-    const rf_corpus* owner = corpus->parent ? corpus->parent : corpus;  // scratch and locks live in the real corpus
-    if (k == 0 || k > (uint32_t)kWave) {
-        set_error("top-k: k must be in 1..64 (one list entry per wavefront lane)");
-        return k == 0 ? RF_ERR_INVALID_ARG : RF_ERR_UNSUPPORTED;
-    }
-    if (op != RF_OP_DISTANCE && op != RF_OP_SIMILARITY) {
-        set_error("top-k: op must be RF_OP_DISTANCE or RF_OP_SIMILARITY");
-        return RF_ERR_INVALID_ARG;
-    }
-    ScanParams p;
-    RawKind raw = RAW_LEV;
-    rf_status s = plan(c, corpus, op, args, false, &p, &raw);
-    if (s != RF_OK) return s;
-    if (raw == RAW_JARO) {
-        set_error("top-k: usize-valued metrics only");
-        return RF_ERR_INVALID_ARG;
-    }
-    // (a long query under a small cutoff is planned onto the band kernel, which has no top-k epilogue, and the register-resident
-    // scans stop at 8 words: beyond 512 symbols that shape goes the selection way like every other long query -- ADVICE r2)
-    if (p.long_words_pad || raw == RAW_WF || (p.band && c->words > (size_t)kMaxWords)) {
-        set_error("top-k: queries longer than 512 symbols and general Levenshtein weight tables are served by rf_many_* only");
-        return RF_ERR_UNSUPPORTED;
-    }
-    *desc = op == RF_OP_SIMILARITY;
-    s = comparator_device_pm(c, corpus->device, &p.pm);
-    if (s != RF_OK) return s;
-    // (single-length corpora only: every launch of a top-k call selects its own k best, so the per-length-run launches of
-    // launch_scan_runs cannot share one call)
-    p.heads8 = corpus->uniform ? corpus_head8_plane(corpus, p, raw, st) : nullptr;
-    if (corpus->uniform) plan_band_filter(c, corpus, op, false, &p, corpus->uniform_len);
-    // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list
-    rf_corpus::TopkScratch sc;
-    {
-        std::lock_guard<std::mutex> lock(owner->scratch_mu);
-        auto it = owner->topk_scratch.find(st);
-        if (it == owner->topk_scratch.end()) {
-            // [64 way segments of candidate keys | root table 64 x 64 keys | bound (u64, own line) | control block 65 x 128 B]
-            const size_t ways = 64, per_way = ((size_t)scan_grid_full(corpus->n_tiles) + ways - 1) / ways;  // (the largest grid any top-k launch uses)
-            sc.seg_cap = (uint32_t)(per_way * kWave);
-            const size_t cand_bytes = ways * sc.seg_cap * sizeof(uint64_t), root_bytes = ways * kWave * sizeof(uint64_t), ctl_bytes = 65 * 128;
-            uint8_t* mem = nullptr;
-            RF_HIP(hipMalloc((void**)&mem, cand_bytes + root_bytes + 128 + ctl_bytes));
-            sc.cand = reinterpret_cast<uint64_t*>(mem);
-            sc.root = reinterpret_cast<uint64_t*>(mem + cand_bytes);
-            sc.bound = reinterpret_cast<uint64_t*>(mem + cand_bytes + root_bytes);
-            sc.ctl = reinterpret_cast<uint32_t*>(mem + cand_bytes + root_bytes + 128);
-            hipError_t e0 = hipMemsetAsync(sc.bound, 0xFF, sizeof(uint64_t), st);
-            if (e0 == hipSuccess) e0 = hipMemsetAsync(sc.ctl, 0, ctl_bytes, st);
-            if (e0 != hipSuccess) {
-                (void)hipFree(mem);
-                set_error(std::string("top-k scratch: ") + hipGetErrorString(e0));
-                return RF_ERR_HIP;
-            }
-            owner->topk_scratch.emplace(st, sc);
-        } else {
-            sc = it->second;
-        }
-    }
-    p.topk_bound = sc.bound;
-    p.topk_cand = sc.cand;
-    p.topk_seg_cap = sc.seg_cap;
-    p.topk_ctl = sc.ctl;
-    p.topk_root = sc.root;
-    p.topk_out = d_best;
-    p.topk_k = k;
-    p.topk_desc = *desc;
-    p.key_index_base = key_index_base;
-    // optionally also emit every candidate's score from the same pass (they stay sharded)
-    uint32_t* d_all = out_all;
-    if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
-    p.out = d_all;
-    std::lock_guard<std::mutex> enqueue_lock(owner->topk_enqueue_mu);
-    std::unique_lock<std::mutex> filter_lock;
-    if (p.heads8) {
-        filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
-        p.tile_list_buf = corpus_tile_list(corpus, st);
-    }
-    hipError_t e = hipSuccess;
-    // Sample pass: the top-k of ~1000 evenly spaced tiles costs 0.1 % of the scan and its k-th best key is a valid
-    // launch-wide bound from the first tile on -- without it every wavefront pays k ln(n_wave / k) list insertions to
-    // warm its own list up (the shared bound alone is only as good as the luckiest wavefront's k-th best).  Under a
-    // tight cutoff (p.early) the cutoff itself keeps nearly everything out of the lists and the pass is skipped.
-    // Each launch selects its own k best in its last workgroup (topk_block_publish): 2 launches, or 1.
-    // (RF_TOPK_SAMPLE=<tiles> tunes the sample size, 0 disables the pass: A/B switch)
-    static const uint32_t kSampleTiles = [] { const char* e = getenv("RF_TOPK_SAMPLE"); return e ? (uint32_t)atoi(e) : 1024u; }();
-    if (kSampleTiles && !p.early && p.tile_end - p.tile_begin >= 8 * kSampleTiles) {
-        ScanParams ps = p;
-        ps.out = nullptr;
-        ps.prefill_none = 0;
-        ps.tile_step = (p.tile_end - p.tile_begin) / kSampleTiles;
-        ps.topk_bound_from_result = 1;
-        e = launch_scan(raw, ps, st, nullptr);
-    }
-    if (e == hipSuccess) e = launch_scan(raw, p, st, nullptr);
-    if (e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) {
-        e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        (void)hipFreeAsync(d_all, st);
-    }
-    if (e != hipSuccess) {
-        // the scratch may be left half-armed: drop it so the next call starts from a fresh one
-        std::lock_guard<std::mutex> lock(owner->scratch_mu);
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(sc.cand);
-        owner->topk_scratch.erase(st);
-        set_error(std::string("top-k: ") + hipGetErrorString(e));
-        return RF_ERR_HIP;
-    }
-    return RF_OK;
-}
-
-// ---- the general top-k path: scan to a score vector, then exact selection over it (rf_select.hip) ------------------
-// Any k, u32 or f64 scores.  Returns the kk = min(k, #not-None) best (key, index) pairs sorted by (key, index).
-static rf_status select_topk(const void* d_scores, bool f64, bool desc, uint32_t n, uint64_t k, hipStream_t st, std::vector<uint64_t>* keys,
-                             std::vector<uint32_t>* idx)
-{
-    keys->clear();
-    idx->clear();
-    const uint32_t nb = select_blocks(n);
-    uint8_t* mem = nullptr;
-    const size_t hist_bytes = 2048 * sizeof(unsigned long long), cnt_bytes = (size_t)nb * sizeof(uint32_t);
-    RF_HIP(hipMallocAsync((void**)&mem, 64 + hist_bytes + 2 * cnt_bytes, st));
-    struct Free {
-        uint8_t* p;
-        hipStream_t st;
-        ~Free() { (void)hipFreeAsync(p, st); }
-    } free_mem{mem, st};
-    unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(mem + 64);
-    uint32_t* d_less = reinterpret_cast<uint32_t*>(mem + 64 + hist_bytes);
-    uint32_t* d_eq = d_less + nb;
-    unsigned long long ctl[3] = {~0ull, 0ull, 0ull};  // min key, max key, valid
-    RF_HIP(hipMemcpyAsync(mem, ctl, sizeof(ctl), hipMemcpyHostToDevice, st));
-    RF_HIP(launch_select_minmax(d_scores, f64, n, desc, mem, st));
-    RF_HIP(hipMemcpyAsync(ctl, mem, sizeof(ctl), hipMemcpyDeviceToHost, st));
-    RF_HIP(hipStreamSynchronize(st));
-    const uint64_t valid = ctl[2];
-    if (valid == 0 || k == 0) return RF_OK;
-    const uint64_t kk = std::min<uint64_t>(k, valid);
-    // the k-th smallest key value T, 11 bits at a time from the first bit in which the keys differ
-    uint64_t prefix = 0, prefix_mask = 0, n_less = 0, rank = kk;  // rank: 1-based among the keys matching the prefix
-    const uint64_t diff = ctl[0] ^ ctl[1];
-    int hb = diff ? 63 - __builtin_clzll(diff) : -1;  // highest differing bit
-    if (hb < 63) {
-        prefix_mask = hb < 0 ? ~0ull : ~((2ull << hb) - 1);
-        prefix = ctl[0] & prefix_mask;
-    }
-    if (!f64) prefix_mask &= 0xFFFFFFFFull, prefix &= 0xFFFFFFFFull;
-    std::vector<unsigned long long> hist(2048);
-    while (hb >= 0) {
-        const uint32_t shift = hb + 1 > 11 ? (uint32_t)(hb + 1 - 11) : 0u;
-        const uint32_t bits = (uint32_t)(hb + 1) - shift;
-        RF_HIP(hipMemsetAsync(d_hist, 0, hist_bytes, st));
-        RF_HIP(launch_select_hist(d_scores, f64, n, desc, prefix_mask, prefix, shift, bits, d_hist, st));
-        RF_HIP(hipMemcpyAsync(hist.data(), d_hist, hist_bytes, hipMemcpyDeviceToHost, st));
-        RF_HIP(hipStreamSynchronize(st));
-        uint64_t cum = 0;
-        uint32_t d = 0;
-        for (; d < (1u << bits); ++d) {
-            if (cum + hist[d] >= rank) break;
-            cum += hist[d];
-        }
-        if (d == (1u << bits)) {
-            if (getenv("RF_SELECT_DEBUG")) {
-                unsigned long long tot = 0;
-                for (auto h : hist) tot += h;
-                std::fprintf(stderr, "[select] min %llx max %llx valid %llu kk %llu hb %d shift %u bits %u prefix %llx mask %llx rank %llu cum %llu total-in-hist %llu\n",
-                             ctl[0], ctl[1], (unsigned long long)valid, (unsigned long long)kk, hb, shift, bits, (unsigned long long)prefix,
-                             (unsigned long long)prefix_mask, (unsigned long long)rank, (unsigned long long)cum, tot);
-            }
-            set_error("top-k selection: inconsistent histogram");
-            return RF_ERR_HIP;
-        }
-        n_less += cum;
-        rank -= cum;
-        prefix |= (uint64_t)d << shift;
-        prefix_mask |= (((1ull << bits) - 1) << shift);
-        hb = (int)shift - 1;
-    }
-    const uint64_t T = prefix;
-    const uint32_t need_eq = (uint32_t)(kk - n_less);
-    uint8_t* out = nullptr;
-    const size_t key_bytes = f64 ? 8 : 4;
-    RF_HIP(hipMallocAsync((void**)&out, kk * (key_bytes + 4), st));
-    Free free_out{out, st};
-    uint32_t* d_idx = reinterpret_cast<uint32_t*>(out + kk * key_bytes);
-    RF_HIP(launch_select_count(d_scores, f64, n, desc, T, d_less, d_eq, st));
-    RF_HIP(launch_select_emit(d_scores, f64, n, desc, T, d_less, d_eq, (uint32_t)n_less, need_eq, out, d_idx, st));
-    std::vector<uint8_t> hk(kk * key_bytes);
-    std::vector<uint32_t> hi(kk);
-    RF_HIP(hipMemcpyAsync(hk.data(), out, hk.size(), hipMemcpyDeviceToHost, st));
-    RF_HIP(hipMemcpyAsync(hi.data(), d_idx, kk * 4, hipMemcpyDeviceToHost, st));
-    RF_HIP(hipStreamSynchronize(st));
-    std::vector<std::pair<uint64_t, uint32_t>> pairs(kk);
-    for (uint64_t i = 0; i < kk; ++i)
-        pairs[i] = {f64 ? reinterpret_cast<const uint64_t*>(hk.data())[i] : (uint64_t) reinterpret_cast<const uint32_t*>(hk.data())[i], hi[i]};
-    std::sort(pairs.begin(), pairs.end());
-    keys->resize(kk);
-    idx->resize(kk);
-    for (uint64_t i = 0; i < kk; ++i) (*keys)[i] = pairs[i].first, (*idx)[i] = pairs[i].second;
-    return RF_OK;
-}
-
-// scan every candidate into a device score vector (the caller's out_all if it is device memory, a temporary otherwise),
-// select, and hand the scores to a host out_all if one was asked for
-static rf_status topk_by_selection(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, bool f64, void* out_all,
-                                   rf_mem out_all_mem, hipStream_t st, std::vector<uint64_t>* keys, std::vector<uint32_t>* idx, bool* desc)
-{
-    const size_t elem = f64 ? sizeof(double) : sizeof(uint32_t);
-    *desc = op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY;
-    void* d_scores = out_all;
-    const bool temp = !(out_all && out_all_mem == RF_MEM_DEVICE);
-    if (temp) RF_HIP(hipMallocAsync(&d_scores, corpus->n * elem, st));
-    rf_status s = run_many(c, corpus, op, args, d_scores, RF_MEM_DEVICE, st, f64);
-    if (s == RF_OK) s = select_topk(d_scores, f64, *desc, (uint32_t)corpus->n, k, st, keys, idx);
-    if (s == RF_OK && out_all && out_all_mem == RF_MEM_HOST) {
-        hipError_t e = hipMemcpyAsync(out_all, d_scores, corpus->n * elem, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) s = RF_ERR_HIP;
-    }
-    if (temp) (void)hipFreeAsync(d_scores, st);
-    return s;
-}
-
-rf_status rf_topk_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, uint64_t index_base, double* out_score,
-                      uint64_t* out_index, uint64_t* out_count, double* out_all, rf_mem out_all_mem, void* stream)
-{
-    if (!out_score || !out_index || !out_count || !c || !corpus || !args) {
-        set_error("rf_topk_f64: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    *out_count = 0;
-    if (corpus->n == 0 || k == 0) return RF_OK;
-    DeviceGuard guard(corpus->device);
-    if (!guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
-    }
-    std::vector<uint64_t> keys;
-    std::vector<uint32_t> idx;
-    bool desc = false;
-    const rf_status s = topk_by_selection(c, corpus, op, args, k, true, out_all, out_all_mem, (hipStream_t)stream, &keys, &idx, &desc);
-    if (s != RF_OK) return s;
-    for (size_t i = 0; i < keys.size(); ++i) {
-        uint64_t b = desc ? ~keys[i] : keys[i];
-        b ^= (b >> 63) ? 0x8000000000000000ull : ~0ull;  // undo the order-preserving map of rf_select.hip
-        std::memcpy(&out_score[i], &b, sizeof(double));
-        out_index[i] = index_base + idx[i];
-    }
-    *out_count = keys.size();
-    return RF_OK;
-}
-
-rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
-                      uint64_t index_base, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count,
-                      uint32_t* out_all, rf_mem out_all_mem, void* stream)
-{
-    if (!out_score || !out_index || !out_count || !c || !corpus) {
-        set_error("rf_topk_u32: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    *out_count = 0;
-    if (k == 0) {
-        set_error("top-k: k must be at least 1");
-        return RF_ERR_INVALID_ARG;
-    }
-    if (corpus->n == 0) return RF_OK;
-    if (k > (uint32_t)kWave) {
-        // more than one list entry per wavefront lane: the selection path (any k; also general weight tables, long queries)
-        if (op != RF_OP_DISTANCE && op != RF_OP_SIMILARITY) {
-            set_error("top-k: op must be RF_OP_DISTANCE or RF_OP_SIMILARITY (normalized_*: rf_topk_f64)");
-            return RF_ERR_INVALID_ARG;
-        }
-        DeviceGuard guard(corpus->device);
-        if (!guard.ok) {
-            set_error("cannot select the corpus' device");
-            return RF_ERR_NO_DEVICE;
-        }
-        std::vector<uint64_t> keys;
-        std::vector<uint32_t> idx;
-        bool desc = false;
-        const rf_status s = topk_by_selection(c, corpus, op, args, k, false, out_all, out_all_mem, (hipStream_t)stream, &keys, &idx, &desc);
-        if (s != RF_OK) return s;
-        for (size_t i = 0; i < keys.size(); ++i) {
-            out_score[i] = desc ? 0xFFFFFFFEu - (uint32_t)keys[i] : (uint32_t)keys[i];  // KeyOf<uint32_t>::get, rf_select.hip
-            out_index[i] = index_base + idx[i];
-        }
-        *out_count = (uint32_t)keys.size();
-        return RF_OK;
-    }
-    DeviceGuard guard(corpus->device);
-    if (!guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    uint64_t* d_best = nullptr;
-    RF_HIP(hipMallocAsync((void**)&d_best, (size_t)kWave * sizeof(uint64_t), st));
-    bool desc = false;
-    std::vector<uint64_t> best(kWave, ~0ull);
-    hipError_t e = hipSuccess;
-    rf_status s = RF_OK;
-    // score_hint (RF_OP_DISTANCE, no cutoff, no per-candidate output): the caller expects the k-th best distance to be <= hint.  The
-    // reference uses the hint per pair the same way (levenshtein.rs:1069-1088: a band of `hint`, doubled until the distance fits).
-    // Here the scan first runs UNDER THE CUTOFF `hint` -- a cutoff scan costs a fraction of a full one (§5.1) -- and if k candidates
-    // pass, they are the k best of the corpus; otherwise the hint doubles, and past a quarter of the longest possible distance the
-    // plain scan runs.  The result never depends on the hint.
-    bool done = false;
-    if (args && op == RF_OP_DISTANCE && args->score_hint_usize != RF_NO_CUTOFF && args->cutoff_usize == RF_NO_CUTOFF && !out_all) {
-        const uint64_t longest = std::max<uint64_t>(rf_comparator_query_len(c), corpus->max_len);
-        for (uint64_t hint = args->score_hint_usize; hint <= longest / 4; hint = std::max<uint64_t>(1, hint * 2)) {  // (hint <= longest / 4: no overflow for absurd hints)
-            rf_args a2 = *args;
-            a2.cutoff_usize = hint;
-            a2.score_hint_usize = RF_NO_CUTOFF;
-            s = topk_core(c, corpus, op, &a2, k, 0, d_best, nullptr, RF_MEM_DEVICE, st, &desc);
-            if (s != RF_OK) break;  // (shapes the in-scan lists do not cover: the plain path below sorts that out)
-            e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) break;
-            uint32_t found = 0;
-            while (found < k && best[found] != ~0ull) ++found;
-            if (found >= k || found >= corpus->n) {
-                done = true;
-                break;
-            }
-        }
-    }
-    if (!done) {
-        s = topk_core(c, corpus, op, args, k, 0, d_best, out_all, out_all_mem, st, &desc);
-        e = hipSuccess;
-        if (s == RF_OK) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
-    }
-    (void)hipFreeAsync(d_best, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (s == RF_ERR_UNSUPPORTED && (op == RF_OP_DISTANCE || op == RF_OP_SIMILARITY)) {
-        // shapes the in-scan lists do not cover (queries beyond 512 symbols, general weight tables): score everything, select
-        std::vector<uint64_t> keys;
-        std::vector<uint32_t> idx;
-        s = topk_by_selection(c, corpus, op, args, k, false, out_all, out_all_mem, st, &keys, &idx, &desc);
-        if (s != RF_OK) return s;
-        for (size_t i = 0; i < keys.size(); ++i) {
-            out_score[i] = desc ? 0xFFFFFFFEu - (uint32_t)keys[i] : (uint32_t)keys[i];  // KeyOf<uint32_t>::get, rf_select.hip
-            out_index[i] = index_base + idx[i];
-        }
-        *out_count = (uint32_t)keys.size();
-        return RF_OK;
-    }
-    if (s != RF_OK) return s;
-    if (e != hipSuccess) {
-        set_error(std::string("top-k: ") + hipGetErrorString(e));
-        return RF_ERR_HIP;
-    }
-    uint32_t m = 0;
-    for (; m < k && best[m] != ~0ull; ++m) {
-        const uint32_t hi = (uint32_t)(best[m] >> 32);
-        out_score[m] = desc ? ~hi : hi;
-        out_index[m] = index_base + (uint32_t)best[m];
-    }
-    *out_count = m;
-    return RF_OK;
-}
-
-rf_status rf_topk_keys_device(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
-                              uint32_t index_base, uint64_t* d_keys_out, uint32_t* out_all, rf_mem out_all_mem,
-                              void* stream)
-{
-    if (!d_keys_out || !c || !corpus) {
-        set_error("rf_topk_keys_device: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    if ((uint64_t)index_base + corpus->n > 0xFFFFFFFFull) {
-        set_error("rf_topk_keys_device: index_base + n must fit 32 bits (use rf_topk_u32 for larger index spaces)");
-        return RF_ERR_INVALID_ARG;
-    }
-    DeviceGuard guard(corpus->device);
-    if (!guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    if (corpus->n == 0) {
-        RF_HIP(hipMemsetAsync(d_keys_out, 0xFF, (size_t)k * sizeof(uint64_t), st));
-        return RF_OK;
-    }
-    bool desc = false;
-    return topk_core(c, corpus, op, args, k, index_base, d_keys_out, out_all, out_all_mem, st, &desc);
-}
-
-rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t k, uint64_t* d_out, int device, void* stream)
-{
-    if (!d_keys || !d_out || k == 0 || k > (uint32_t)kWave || n == 0) {
-        set_error("rf_topk_merge_keys_device: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    DeviceGuard guard(device);
-    if (!guard.ok) return RF_ERR_NO_DEVICE;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_topk_final(d_keys, n, k, d_out, st);
-    if (e != hipSuccess) {
-        set_error(std::string("top-k merge: ") + hipGetErrorString(e));
-        return RF_ERR_HIP;
-    }
-    return RF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The exchange step below the host language: all-gather of the per-shard key lists over RCCL + merge.  RCCL is not a
-// link-time dependency of this library: the caller owns the communicator, so the RCCL that created it is already in the
-// process, and ncclAllGather is looked up in THAT instance (RTLD_NOLOAD), falling back to the system librccl.
-// ---------------------------------------------------------------------------------------------------
-namespace {
-using nccl_all_gather_fn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
-nccl_all_gather_fn find_nccl_all_gather()
-{
-    static nccl_all_gather_fn fn = [] {
-        if (void* f = dlsym(RTLD_DEFAULT, "ncclAllGather")) return (nccl_all_gather_fn)f;
-        for (const char* name : {"librccl.so", "librccl.so.1"})
-            if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))
-                if (void* f = dlsym(h, "ncclAllGather")) return (nccl_all_gather_fn)f;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL))
-                if (void* f = dlsym(h, "ncclAllGather")) return (nccl_all_gather_fn)f;
-        return (nccl_all_gather_fn) nullptr;
-    }();
-    return fn;
-}
-}  // namespace
-
-rf_status rf_topk_allgather_merge(const uint64_t* d_local_keys, uint32_t k, void* nccl_comm, uint32_t world, uint64_t* d_all_keys,
-                                  uint64_t* d_merged, int device, void* stream)
-{
-    if (!d_local_keys || !d_all_keys || !d_merged || !nccl_comm || k == 0 || k > (uint32_t)kWave || world == 0) {
-        set_error("rf_topk_allgather_merge: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    const nccl_all_gather_fn all_gather = find_nccl_all_gather();
-    if (!all_gather) {
-        set_error("rf_topk_allgather_merge: no RCCL (ncclAllGather) found in this process or on the library path");
-        return RF_ERR_UNSUPPORTED;
-    }
-    DeviceGuard guard(device);
-    if (!guard.ok) return RF_ERR_NO_DEVICE;
-    constexpr int kNcclUint64 = 5;  // ncclDataType_t::ncclUint64 (nccl.h)
-    const int rc = all_gather(d_local_keys, d_all_keys, k, kNcclUint64, nccl_comm, (hipStream_t)stream);
-    if (rc != 0) {
-        set_error("rf_topk_allgather_merge: ncclAllGather failed with ncclResult_t " + std::to_string(rc));
-        return RF_ERR_HIP;
-    }
-    return rf_topk_merge_keys_device(d_all_keys, world * k, k, d_merged, device, stream);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// top-k entries: 16 bytes {order-preserving key, 64-bit global index} -- the exchange format for every top-k (rfgpu.h)
-// ---------------------------------------------------------------------------------------------------
-uint32_t rf_topk_entry_score_u32(uint64_t key, int descending) { return descending ? 0xFFFFFFFFu - (uint32_t)key : (uint32_t)key; }
-double rf_topk_entry_score_f64(uint64_t key, int descending)
-{
-    uint64_t b = descending ? ~key : key;
-    b ^= (b >> 63) ? 0x8000000000000000ull : ~0ull;  // undo the order-preserving map of rf_select.hip KeyOf<uint64_t>
-    double d;
-    std::memcpy(&d, &b, sizeof(d));
-    return d;
-}
-
-rf_status rf_topk_entries_device(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, uint64_t index_base,
-                                 rf_topk_entry* d_entries_out, void* stream)
-{
-    if (!c || !corpus || !args || !d_entries_out || k == 0) {
-        set_error("rf_topk_entries_device: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    DeviceGuard guard(corpus->device);
-    if (!guard.ok) {
-        set_error("cannot select the corpus' device");
-        return RF_ERR_NO_DEVICE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    if (corpus->n == 0) {
-        RF_HIP(hipMemsetAsync(d_entries_out, 0xFF, (size_t)k * sizeof(rf_topk_entry), st));
-        return RF_OK;
-    }
-    const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
-    const bool f64 = !usize_metric || op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY;
-    if (!f64 && k <= (uint64_t)kWave) {
-        // the in-scan lists: keys with the LOCAL index, widened on the device -- nothing synchronizes
-        uint64_t* d_keys = nullptr;
-        RF_HIP(hipMallocAsync((void**)&d_keys, (size_t)kWave * sizeof(uint64_t), st));
-        bool desc = false;
-        const rf_status s = topk_core(c, corpus, op, args, (uint32_t)k, 0, d_keys, nullptr, RF_MEM_HOST, st, &desc);
-        if (s == RF_OK) {
-            const hipError_t e = launch_keys_to_entries(d_keys, (uint32_t)k, index_base, d_entries_out, st);
-            (void)hipFreeAsync(d_keys, st);
-            RF_HIP(e);
-            return RF_OK;
-        }
-        (void)hipFreeAsync(d_keys, st);
-        if (s != RF_ERR_UNSUPPORTED) return s;  // (long queries, general weight tables: the selection path below)
-    }
-    std::vector<uint64_t> keys;
-    std::vector<uint32_t> idx;
-    bool desc = false;
-    const rf_status s = topk_by_selection(c, corpus, op, args, k, f64, nullptr, RF_MEM_HOST, st, &keys, &idx, &desc);
-    if (s != RF_OK) return s;
-    // (a caller-supplied k far beyond the corpus must not size a host allocation: at most min(k, n) entries exist, the tail of the
-    // caller's k-entry buffer is filled with the empty entry on the device -- ADVICE r3)
-    const size_t have = keys.size();
-    std::vector<rf_topk_entry> host(have);
-    for (size_t i = 0; i < have; ++i) {
-        // (the u32 selection key of a similarity is 0xFFFFFFFE - score, rf_select.hip: the entry format says 0xFFFFFFFF - score)
-        host[i].key = f64 ? keys[i] : (desc ? keys[i] + 1 : keys[i]);
-        host[i].index = index_base + idx[i];
-    }
-    if (have) RF_HIP(hipMemcpyAsync(d_entries_out, host.data(), have * sizeof(rf_topk_entry), hipMemcpyHostToDevice, st));
-    if (k > have) RF_HIP(hipMemsetAsync(d_entries_out + have, 0xFF, (size_t)(k - have) * sizeof(rf_topk_entry), st));
-    RF_HIP(hipStreamSynchronize(st));  // (`host` dies with this frame)
-    return RF_OK;
-}
-
-rf_status rf_topk_merge_entries_device(const rf_topk_entry* d_entries, uint64_t n, uint64_t k, rf_topk_entry* d_out, int device, void* stream)
-{
-    if (!d_entries || !d_out || k == 0 || n == 0 || n > 0x7FFFFFFFull || k > 0x7FFFFFFFull) {
-        set_error("rf_topk_merge_entries_device: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    DeviceGuard guard(device);
-    if (!guard.ok) return RF_ERR_NO_DEVICE;
-    const hipError_t e = launch_merge_entries(d_entries, (uint32_t)n, (uint32_t)k, d_out, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        set_error(std::string("top-k entry merge: ") + hipGetErrorString(e));
-        return RF_ERR_HIP;
-    }
-    return RF_OK;
-}
-
-rf_status rf_topk_allgather_merge_entries(const rf_topk_entry* d_local, uint64_t k, void* nccl_comm, uint32_t world, rf_topk_entry* d_all,
-                                          rf_topk_entry* d_merged, int device, void* stream)
-{
-    if (!d_local || !d_all || !d_merged || !nccl_comm || k == 0 || world == 0) {
-        set_error("rf_topk_allgather_merge_entries: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    const nccl_all_gather_fn all_gather = find_nccl_all_gather();
-    if (!all_gather) {
-        set_error("rf_topk_allgather_merge_entries: no RCCL (ncclAllGather) found in this process or on the library path");
-        return RF_ERR_UNSUPPORTED;
-    }
-    DeviceGuard guard(device);
-    if (!guard.ok) return RF_ERR_NO_DEVICE;
-    constexpr int kNcclUint64 = 5;  // ncclDataType_t::ncclUint64 (nccl.h): an entry is two of them
-    const int rc = all_gather(d_local, d_all, (size_t)k * 2, kNcclUint64, nccl_comm, (hipStream_t)stream);
-    if (rc != 0) {
-        set_error("rf_topk_allgather_merge_entries: ncclAllGather failed with ncclResult_t " + std::to_string(rc));
-        return RF_ERR_HIP;
-    }
-    return rf_topk_merge_entries_device(d_all, (uint64_t)world * k, k, d_merged, device, stream);
-}
-
-rf_status rf_topk_merge_entries(const rf_topk_entry* entries, uint64_t n, uint64_t k, rf_topk_entry* out)
-{
-    if ((n && !entries) || !out || k == 0) {
-        set_error("rf_topk_merge_entries: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    std::vector<rf_topk_entry> v;
-    for (uint64_t i = 0; i < n; ++i)
-        if (entries[i].key != ~0ull || entries[i].index != ~0ull) v.push_back(entries[i]);
-    std::sort(v.begin(), v.end(), [](const rf_topk_entry& a, const rf_topk_entry& b) { return a.key != b.key ? a.key < b.key : a.index < b.index; });
-    for (uint64_t i = 0; i < k; ++i) out[i] = i < v.size() ? v[i] : rf_topk_entry{~0ull, ~0ull};
-    return RF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// corpus files, and corpora larger than HBM
-// ---------------------------------------------------------------------------------------------------
-// The packed form is position-independent (tile descriptors hold offsets, tiles ascend by length), so a corpus can
-// be written once and mapped back without re-packing, and ANY tile range [t0, t1) is itself a valid corpus: its
-// payload is one contiguous byte range.  rf_stream_many_* uses that to scan a file segment by segment through two
-// device buffers, the upload of segment k+1 overlapping the scan of segment k.
-namespace {
-struct FileHeader {  // little endian, 512 bytes
-    char magic[8];   // "RFCORPUS"
-    uint32_t version, flags;  // flags: 1 = uniform (no descriptors / orig), 2 = u32 elements (alphabet section)
-    uint64_t n;
-    uint32_t n_tiles, max_len, uniform_len, n_lengths;
-    uint64_t payload_bytes, data_bytes;
-    uint64_t off_lengths, off_tiles, off_orig, off_alphabet, off_data;
-    uint32_t n_alphabet, n_overflow;
-    uint8_t sigma[256];
-    uint64_t off_raw;  // flags & 4: the u32 symbol stream parallel to the payload (data_bytes entries)
-    uint64_t off_mixed;  // n_mixed MixedDesc, then 64 * n_mixed lengths, then 64 * n_mixed original indices
-    uint32_t n_exact, n_mixed;  // tiles [0, n_exact) exact, the rest one-length views of the n_mixed mixed tiles
-    uint8_t reserved[512 - 8 - 8 - 8 - 16 - 16 - 40 - 8 - 256 - 8 - 16];
-};
-static_assert(sizeof(FileHeader) == 512, "header layout");
-constexpr uint32_t kFileVersion = 2, kFlagUniform = 1, kFlagWide = 2, kFlagRaw = 4, kFlagRaw16 = 8;
-
-struct FileCloser {
-    FILE* f;
-    ~FileCloser()
-    {
-        if (f) std::fclose(f);
-    }
-};
-bool write_all(FILE* f, const void* p, size_t n) { return n == 0 || std::fwrite(p, 1, n, f) == n; }
-bool read_at(FILE* f, uint64_t off, void* p, size_t n)
-{
-    if (n == 0) return true;
-    return fseeko(f, (off_t)off, SEEK_SET) == 0 && std::fread(p, 1, n, f) == n;
-}
-// A segment of the payload, read by up to 8 threads with pread: one thread copies out of the page cache at ~10 GB/s,
-// which is what bounded the streamed path.
-bool read_parallel(int fd, uint64_t off, uint8_t* dst, size_t n)
-{
-    // (RF_STREAM_THREADS: reader threads of the streamed scans and of rf_corpus_load; default 16 -- the page-cache -> pinned-buffer copy
-    // runs at ~5 GB/s per thread, and it is this copy, not the link, that bounds a streamed scan: profiles/stream_r04.txt)
-    static const size_t max_threads = [] { const char* e = getenv("RF_STREAM_THREADS"); const int v = e ? atoi(e) : 16; return (size_t)(v > 0 ? v : 1); }();
-    const size_t nthreads = n < (32u << 20) ? 1 : std::min<size_t>(max_threads, std::max<size_t>(1, std::thread::hardware_concurrency()));
-    std::atomic<bool> ok{true};
-    auto worker = [&](size_t t) {
-        size_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
-        while (lo < hi) {
-            const ssize_t r = pread(fd, dst + lo, hi - lo, (off_t)(off + lo));
-            if (r <= 0) {
-                ok = false;
-                return;
-            }
-            lo += (size_t)r;
-        }
-    };
-    if (nthreads == 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(worker, t);
-        for (auto& th : pool) th.join();
-    }
-    return ok;
-}
-rf_status read_header(FILE* f, FileHeader* h)
-{
-    if (!read_at(f, 0, h, sizeof(*h)) || std::memcmp(h->magic, "RFCORPUS", 8) != 0 || h->version != kFileVersion) {
-        set_error("not a corpus file of this version");
-        return RF_ERR_INVALID_ARG;
-    }
-    // every section must lie inside the file (sizes in 128-bit-safe steps: the counts are attacker-sized)
-    uint64_t fsize = 0;
-    if (fseeko(f, 0, SEEK_END) == 0) fsize = (uint64_t)ftello(f);
-    auto inside = [&](uint64_t off, uint64_t count, uint64_t elem) { return off <= fsize && count <= (fsize - off) / std::max<uint64_t>(elem, 1); };
-    const bool uniform = (h->flags & kFlagUniform) != 0;
-    const uint64_t raw_elem = (h->flags & kFlagRaw) ? ((h->flags & kFlagRaw16) ? 2 : 4) : 0;
-    const bool ok = h->n < 0xFFFFFFFFull && inside(h->off_lengths, (uint64_t)h->n_lengths * 2, 4) &&
-                    (uniform || (inside(h->off_tiles, h->n_tiles, sizeof(TileDesc)) && inside(h->off_orig, (uint64_t)h->n_tiles * kWave, 4))) &&
-                    inside(h->off_alphabet, (uint64_t)h->n_alphabet * 2 + h->n_overflow, 4) && inside(h->off_data, h->data_bytes, 1) &&
-                    (!raw_elem || inside(h->off_raw, h->data_bytes, raw_elem)) && h->n_alphabet <= 256 && h->off_data >= sizeof(FileHeader) &&
-                    h->n_exact <= h->n_tiles && (h->n_mixed == 0 || (!uniform && inside(h->off_mixed, (uint64_t)h->n_mixed * (sizeof(MixedDesc) + 2 * kWave * 4), 1)));
-    if (!ok) {
-        set_error("corpus file is inconsistent: a section lies outside the file (truncated?)");
-        return RF_ERR_INVALID_ARG;
-    }
-    return RF_OK;
-}
-}  // namespace
-
-rf_status rf_corpus_save(const rf_corpus* c, const char* path)
-{
-    if (!c || !path || c->borrowed) {
-        set_error("rf_corpus_save: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    DeviceGuard guard(c->device);
-    if (!guard.ok) return RF_ERR_NO_DEVICE;
-    FileCloser fc{std::fopen(path, "wb")};
-    if (!fc.f) {
-        set_error(std::string("rf_corpus_save: cannot open ") + path);
-        return RF_ERR_INVALID_ARG;
-    }
-    FileHeader h;
-    std::memset(&h, 0, sizeof(h));
-    std::memcpy(h.magic, "RFCORPUS", 8);
-    h.version = kFileVersion;
-    h.flags = (c->uniform ? kFlagUniform : 0) | (c->wide ? kFlagWide : 0) | (c->d_raw ? kFlagRaw : 0) | (c->d_raw && c->raw_elem == 2 ? kFlagRaw16 : 0);
-    h.n = c->n;
-    h.n_tiles = c->n_tiles;
-    h.max_len = c->max_len;
-    h.uniform_len = c->uniform_len;
-    h.n_lengths = (uint32_t)c->lengths.size();
-    h.payload_bytes = c->payload_bytes;
-    h.data_bytes = c->data_bytes;
-    h.n_alphabet = (uint32_t)c->alphabet.size();
-    h.n_overflow = (uint32_t)c->overflow.size();
-    std::memcpy(h.sigma, c->sigma, 256);
-    const size_t n_slots = c->uniform ? 0 : (size_t)c->n_tiles * kWave;
-    uint64_t off = sizeof(h);
-    h.off_lengths = off, off += (uint64_t)h.n_lengths * 8;
-    h.off_tiles = off, off += c->uniform ? 0 : (uint64_t)c->n_tiles * sizeof(TileDesc);
-    h.off_orig = off, off += (uint64_t)n_slots * 4;
-    h.off_alphabet = off, off += (uint64_t)h.n_alphabet * 8 + (uint64_t)h.n_overflow * 4;
-    h.n_exact = c->n_exact;
-    h.n_mixed = c->d_mixed ? c->n_mixed : 0;
-    h.off_mixed = off, off += (uint64_t)h.n_mixed * (sizeof(MixedDesc) + 2 * kWave * 4);
-    h.off_data = (off + 4095) / 4096 * 4096;  // page-aligned payload
-    h.off_raw = (h.off_data + c->data_bytes + 4095) / 4096 * 4096;
-    bool ok = write_all(fc.f, &h, sizeof(h));
-    ok = ok && write_all(fc.f, c->lengths.data(), c->lengths.size() * 4) && write_all(fc.f, c->length_first_tile.data(), c->length_first_tile.size() * 4);
-    if (!c->uniform) {
-        std::vector<TileDesc> tiles(c->n_tiles);
-        std::vector<uint32_t> orig(n_slots);
-        RF_HIP(hipMemcpy(tiles.data(), c->d_tiles, tiles.size() * sizeof(TileDesc), hipMemcpyDeviceToHost));
-        RF_HIP(hipMemcpy(orig.data(), c->d_orig, orig.size() * 4, hipMemcpyDeviceToHost));
-        ok = ok && write_all(fc.f, tiles.data(), tiles.size() * sizeof(TileDesc)) && write_all(fc.f, orig.data(), orig.size() * 4);
-    }
-    {
-        std::vector<uint32_t> a;
-        for (const auto& kv : c->alphabet) a.push_back(kv.first), a.push_back(kv.second);
-        for (uint32_t sym : c->overflow) a.push_back(sym);
-        ok = ok && write_all(fc.f, a.data(), a.size() * 4);
-    }
-    if (h.n_mixed) {
-        std::vector<uint32_t> lens((size_t)h.n_mixed * kWave), origs((size_t)h.n_mixed * kWave);
-        RF_HIP(hipMemcpy(lens.data(), c->d_mixed_len, lens.size() * 4, hipMemcpyDeviceToHost));
-        RF_HIP(hipMemcpy(origs.data(), c->d_mixed_orig, origs.size() * 4, hipMemcpyDeviceToHost));
-        ok = ok && write_all(fc.f, c->mixed.data(), c->mixed.size() * sizeof(MixedDesc)) && write_all(fc.f, lens.data(), lens.size() * 4) &&
-             write_all(fc.f, origs.data(), origs.size() * 4);
-    }
-    std::vector<uint8_t> buf(std::min<uint64_t>(std::max<uint64_t>(c->data_bytes, 1), 64ull << 20));
-    ok = ok && fseeko(fc.f, (off_t)h.off_data, SEEK_SET) == 0;
-    for (uint64_t done = 0; ok && done < c->data_bytes; done += buf.size()) {
-        const size_t m = (size_t)std::min<uint64_t>(buf.size(), c->data_bytes - done);
-        RF_HIP(hipMemcpy(buf.data(), c->d_data + done, m, hipMemcpyDeviceToHost));
-        ok = write_all(fc.f, buf.data(), m);
-    }
-    if (c->d_raw) {
-        ok = ok && fseeko(fc.f, (off_t)h.off_raw, SEEK_SET) == 0;
-        const uint64_t raw_bytes = c->data_bytes * c->raw_elem;
-        for (uint64_t done = 0; ok && done < raw_bytes; done += buf.size()) {
-            const size_t m = (size_t)std::min<uint64_t>(buf.size(), raw_bytes - done);
-            RF_HIP(hipMemcpy(buf.data(), reinterpret_cast<const uint8_t*>(c->d_raw) + done, m, hipMemcpyDeviceToHost));
-            ok = write_all(fc.f, buf.data(), m);
-        }
-    }
-    if (!ok || std::fflush(fc.f) != 0) {
-        set_error(std::string("rf_corpus_save: write failed: ") + path);
-        return RF_ERR_INVALID_ARG;
-    }
-    return RF_OK;
-}
-
-// host-side metadata shared by rf_corpus_load and the stream driver
-struct MixedArrays {
-    std::vector<uint32_t> len, orig;  // 64 per mixed tile (the descriptors go to rf_corpus::mixed)
-};
-static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vector<TileDesc>* tiles, std::vector<uint32_t>* orig, MixedArrays* mx = nullptr)
-{
-    c->n = h.n;
-    c->payload_bytes = h.payload_bytes;
-    c->data_bytes = h.data_bytes;
-    c->n_tiles = h.n_tiles;
-    c->n_exact = h.n_exact;
-    c->n_mixed = h.n_mixed;
-    c->max_len = h.max_len;
-    c->uniform = (h.flags & kFlagUniform) != 0;
-    c->uniform_len = h.uniform_len;
-    c->wide = (h.flags & kFlagWide) != 0;
-    std::memcpy(c->sigma, h.sigma, 256);
-    c->lengths.resize(h.n_lengths);
-    c->length_first_tile.resize(h.n_lengths);
-    bool ok = read_at(f, h.off_lengths, c->lengths.data(), (size_t)h.n_lengths * 4) &&
-              read_at(f, h.off_lengths + (uint64_t)h.n_lengths * 4, c->length_first_tile.data(), (size_t)h.n_lengths * 4);
-    if (!c->uniform) {
-        tiles->resize(h.n_tiles);
-        orig->resize((size_t)h.n_tiles * kWave);
-        ok = ok && read_at(f, h.off_tiles, tiles->data(), tiles->size() * sizeof(TileDesc)) && read_at(f, h.off_orig, orig->data(), orig->size() * 4);
-    }
-    std::vector<uint32_t> a((size_t)h.n_alphabet * 2 + h.n_overflow);
-    ok = ok && read_at(f, h.off_alphabet, a.data(), a.size() * 4);
-    MixedArrays local;
-    if (!mx) mx = &local;
-    if (h.n_mixed) {
-        c->mixed.resize(h.n_mixed);
-        mx->len.resize((size_t)h.n_mixed * kWave);
-        mx->orig.resize((size_t)h.n_mixed * kWave);
-        const uint64_t o1 = h.off_mixed + (uint64_t)h.n_mixed * sizeof(MixedDesc), o2 = o1 + mx->len.size() * 4;
-        ok = ok && read_at(f, h.off_mixed, c->mixed.data(), c->mixed.size() * sizeof(MixedDesc)) && read_at(f, o1, mx->len.data(), mx->len.size() * 4) &&
-             read_at(f, o2, mx->orig.data(), mx->orig.size() * 4);
-    }
-    if (!ok) {
-        set_error("corpus file truncated");
-        return RF_ERR_INVALID_ARG;
-    }
-    for (uint32_t i = 0; i < h.n_alphabet; ++i) c->alphabet.emplace(a[2 * i], (uint8_t)a[2 * i + 1]);
-    for (uint32_t i = 0; i < h.n_overflow; ++i) c->overflow.insert(a[(size_t)h.n_alphabet * 2 + i]);
-    // Nothing in the file is trusted: every index the kernels will follow is checked against what it indexes, so a
-    // truncated, stale or crafted file is refused here instead of becoming an out-of-bounds device access.
-    auto bad = [](const char* what) {
-        set_error(std::string("corpus file is inconsistent: ") + what);
-        return RF_ERR_INVALID_ARG;
-    };
-    if (c->data_bytes < kTailPad) return bad("payload smaller than its tail padding");
-    const uint64_t body = c->data_bytes - kTailPad;
-    if (c->n > (uint64_t)c->n_tiles * kWave) return bad("more candidates than tile slots");
-    if ((c->n == 0) != (c->n_tiles == 0) && c->n_tiles == 0) return bad("candidates without tiles");
-    if (c->lengths.size() != c->length_first_tile.size()) return bad("length table");
-    if (c->n_exact > c->n_tiles) return bad("exact tile count");
-    for (size_t i = 0; i < c->lengths.size(); ++i) {
-        if (i && c->length_first_tile[i] <= c->length_first_tile[i - 1]) return bad("length table not in tile order");
-        if (c->length_first_tile[i] >= c->n_tiles || c->lengths[i] > c->max_len) return bad("length table out of range");
-    }
-    if (!c->lengths.empty() && c->length_first_tile[0] != 0) return bad("length table does not start at tile 0");
-    if (c->uniform) {
-        if (c->lengths.size() > 1 || c->uniform_len != c->max_len || (c->n_tiles && c->lengths.empty()) || c->n_mixed || c->n_exact != c->n_tiles)
-            return bad("uniform flag vs length table");
-        if (tile_bytes(c->uniform_len) > 0xFFFFFFFFull || (uint64_t)c->n_tiles * tile_bytes(c->uniform_len) != body) return bad("uniform payload size");
-        if (c->n_tiles && c->n <= (uint64_t)(c->n_tiles - 1) * kWave) return bad("empty trailing tile");
-    } else {
-        if (c->n_tiles && c->lengths.empty()) return bad("tiles without a length table");
-        // exact tiles: ascending lengths, payload blocks back to back; then the mixed blocks, back to back as well; every
-        // virtual tile (a one-length view of a mixed tile) must lie inside ONE mixed block and be no longer than it
-        size_t li = 0;
-        uint64_t expect_off = 0, real = 0;
-        for (uint32_t t = 0; t < c->n_tiles; ++t) {
-            const TileDesc& td = (*tiles)[t];
-            while (li + 1 < c->lengths.size() && c->length_first_tile[li + 1] <= t) ++li;
-            if (td.len != c->lengths[li]) return bad("tile length vs length table");
-            if (td.slot0 != t * (uint32_t)kWave) return bad("tile slot base");
-            if (t < c->n_exact) {
-                if (t && td.len < (*tiles)[t - 1].len) return bad("exact tiles not ascending");
-                if (td.data_off != expect_off) return bad("tile payload offset");
-                expect_off += tile_bytes(td.len);
-                if (expect_off > body) return bad("tile payload beyond the data section");
-            }
-        }
-        uint32_t vt = c->n_exact;  // virtual tiles follow their mixed tiles in order
-        for (uint32_t m = 0; m < c->n_mixed; ++m) {
-            const MixedDesc& md = c->mixed[m];
-            if (md.data_off != expect_off || md.min_len > md.max_len || md.max_len > c->max_len || md.slot0 != m * (uint32_t)kWave) return bad("mixed tile descriptor");
-            if (m && md.min_len < c->mixed[m - 1].max_len) return bad("mixed tiles not ascending");
-            expect_off += tile_bytes(md.max_len);
-            if (expect_off > body) return bad("mixed payload beyond the data section");
-            uint32_t prev_len = 0;
-            bool any = false;
-            for (; vt < c->n_tiles && (*tiles)[vt].data_off == md.data_off; ++vt) {
-                const TileDesc& td = (*tiles)[vt];
-                if (td.len < md.min_len || td.len > md.max_len || (any && td.len <= prev_len)) return bad("view of a mixed tile");
-                prev_len = td.len;
-                any = true;
-            }
-            if (!any) return bad("mixed tile without views");
-            for (uint32_t r = 0; r < (uint32_t)kWave; ++r) {
-                const uint32_t o = mx->orig[(size_t)m * kWave + r], l = mx->len[(size_t)m * kWave + r];
-                if (o == kPad) continue;
-                if (o >= c->n || l < md.min_len || l > md.max_len) return bad("mixed lane");
-            }
-        }
-        if (vt != c->n_tiles) return bad("views without a mixed tile");
-        if (expect_off != body) return bad("data section size");
-        std::vector<uint8_t> seen;  // every original index exactly once
-        if (c->n <= (64u << 20)) seen.assign((size_t)c->n, 0);
-        for (uint32_t v : *orig) {
-            if (v == kPad) continue;
-            if (v >= c->n) return bad("slot map entry beyond the candidate count");
-            if (!seen.empty()) {
-                if (seen[v]) return bad("slot map maps two slots to one candidate");
-                seen[v] = 1;
-            }
-            ++real;
-        }
-        if (real != c->n) return bad("slot map does not cover every candidate");
-    }
-    for (const auto& kv : c->alphabet)
-        if (kv.second >= kOverflowId) return bad("alphabet id");
-    return RF_OK;
-}
-
-rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
-{
-    if (!path || !out) {
-        set_error("rf_corpus_load: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    FileCloser fc{std::fopen(path, "rb")};
-    if (!fc.f) {
-        set_error(std::string("rf_corpus_load: cannot open ") + path);
-        return RF_ERR_INVALID_ARG;
-    }
-    FileHeader h;
-    rf_status s = read_header(fc.f, &h);
-    if (s != RF_OK) return s;
-    DeviceGuard guard(device);
-    if (!guard.ok) {
-        set_error("rf_corpus_load: cannot select device");
-        return RF_ERR_NO_DEVICE;
-    }
-    rf_corpus* c = new (std::nothrow) rf_corpus();
-    if (!c) return RF_ERR_OOM;
-    c->uid = g_corpus_uid.fetch_add(1);
-    c->device = device;
-    std::vector<TileDesc> tiles;
-    std::vector<uint32_t> orig;
-    auto fail = [&](rf_status st) {
-        rf_corpus_free(c);
-        return st;
-    };
-    MixedArrays mx;
-    s = load_meta(fc.f, h, c, &tiles, &orig, &mx);
-    if (s != RF_OK) return fail(s);
-    RF_HIP_C(hipMalloc(&c->d_data, std::max<uint64_t>(1, c->data_bytes)));
-    std::vector<uint8_t> buf(std::min<uint64_t>(std::max<uint64_t>(c->data_bytes, 1), 64ull << 20));
-    uint64_t stored_hist[256] = {0};  // of the STORED symbols (sigma applied), one 64-byte line in 16: sym_freq is not in the file
-    for (uint64_t done = 0; done < c->data_bytes; done += buf.size()) {
-        const size_t m = (size_t)std::min<uint64_t>(buf.size(), c->data_bytes - done);
-        if (!read_at(fc.f, h.off_data + done, buf.data(), m)) {
-            set_error("corpus file truncated");
-            return fail(RF_ERR_INVALID_ARG);
-        }
-        for (size_t at = 0; at + 64 <= m; at += 1024)
-            for (size_t k = 0; k < 64; ++k) stored_hist[buf[at + k]]++;
-        RF_HIP_C(hipMemcpy(c->d_data + done, buf.data(), m, hipMemcpyHostToDevice));
-    }
-    {   // the symbol frequencies the band prefilter's plan reads (plan_band_filter): a loaded corpus must take the same kernel path
-        // as the packed one.  Chunk padding counts as the most frequent symbol's id (0) here -- an over-estimate that can
-        // only make the plan more cautious.
-        uint64_t by_symbol[256];
-        for (int ch = 0; ch < 256; ++ch) by_symbol[ch] = stored_hist[c->sigma[ch]];
-        if (!c->wide) symbol_frequencies(by_symbol, c->sym_freq);
-    }
-    c->device_bytes = c->data_bytes;
-    if (h.flags & kFlagRaw) {
-        c->raw_elem = (h.flags & kFlagRaw16) ? 2 : 4;
-        const uint64_t raw_bytes = c->data_bytes * c->raw_elem;
-        RF_HIP_C(hipMalloc(&c->d_raw, std::max<uint64_t>(1, raw_bytes)));
-        for (uint64_t done = 0; done < raw_bytes; done += buf.size()) {
-            const size_t m = (size_t)std::min<uint64_t>(buf.size(), raw_bytes - done);
-            if (!read_at(fc.f, h.off_raw + done, buf.data(), m)) {
-                set_error("corpus file truncated");
-                return fail(RF_ERR_INVALID_ARG);
-            }
-            RF_HIP_C(hipMemcpy(reinterpret_cast<uint8_t*>(c->d_raw) + done, buf.data(), m, hipMemcpyHostToDevice));
-        }
-        c->device_bytes += raw_bytes;
-    }
-    RF_HIP_C(hipMalloc(&c->d_sigma, 256));
-    RF_HIP_C(hipMemcpy(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice));
-    if (!c->uniform) {
-        RF_HIP_C(hipMalloc(&c->d_tiles, std::max<size_t>(1, tiles.size()) * sizeof(TileDesc)));
-        RF_HIP_C(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-        RF_HIP_C(hipMalloc(&c->d_orig, std::max<size_t>(1, orig.size()) * 4));
-        RF_HIP_C(hipMemcpy(c->d_orig, orig.data(), orig.size() * 4, hipMemcpyHostToDevice));
-        c->n_slots = orig.size();
-        if (c->n_exact >= 1024) {
-            const std::vector<TileDesc> ordered = tiles_by_origin(tiles, c->n_exact, orig.data());
-            RF_HIP_C(hipMalloc(&c->d_tiles_by_origin, ordered.size() * sizeof(TileDesc)));
-            RF_HIP_C(hipMemcpy(c->d_tiles_by_origin, ordered.data(), ordered.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-        }
-        c->device_bytes += tiles.size() * sizeof(TileDesc) + orig.size() * 4;
-    }
-    if (c->n_mixed) {
-        RF_HIP_C(hipMalloc(&c->d_mixed, c->mixed.size() * sizeof(MixedDesc)));
-        RF_HIP_C(hipMemcpy(c->d_mixed, c->mixed.data(), c->mixed.size() * sizeof(MixedDesc), hipMemcpyHostToDevice));
-        RF_HIP_C(hipMalloc(&c->d_mixed_len, mx.len.size() * 4));
-        RF_HIP_C(hipMemcpy(c->d_mixed_len, mx.len.data(), mx.len.size() * 4, hipMemcpyHostToDevice));
-        RF_HIP_C(hipMalloc(&c->d_mixed_orig, mx.orig.size() * 4));
-        RF_HIP_C(hipMemcpy(c->d_mixed_orig, mx.orig.data(), mx.orig.size() * 4, hipMemcpyHostToDevice));
-        c->device_bytes += c->mixed.size() * sizeof(MixedDesc) + 2 * mx.len.size() * 4;
-    }
-    *out = c;
-    return RF_OK;
-}
-
-// One pass of `scorer.<op>` over a corpus FILE that need not fit in HBM.  Segments are tile ranges of at most
-// `segment_bytes` of payload; two device buffer sets alternate, segment k+1 is read and uploaded (copy stream) while
-// segment k is scanned (compute stream).  The result vector (n x 4 or 8 bytes) does live on the device for the pass.
-static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, void* out_host, size_t out_capacity,
-                             bool f64_out, uint64_t segment_bytes, int device)
-{
-    if (!c || !path || !args || !out_host) {
-        set_error("rf_stream_many: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    const auto t_enter = std::chrono::steady_clock::now();
-    FileCloser fc{std::fopen(path, "rb")};
-    if (!fc.f) {
-        set_error(std::string("rf_stream_many: cannot open ") + path);
-        return RF_ERR_INVALID_ARG;
-    }
-    FileHeader h;
-    rf_status s = read_header(fc.f, &h);
-    if (s != RF_OK) return s;
-    DeviceGuard guard(device);
-    if (!guard.ok) {
-        set_error("rf_stream_many: cannot select device");
-        return RF_ERR_NO_DEVICE;
-    }
-    const int fd = fileno(fc.f);  // payload reads go through pread on several threads (read_parallel)
-    rf_corpus meta;  // whole-file metadata (host side only)
-    meta.uid = g_corpus_uid.fetch_add(1);
-    meta.device = device;
-    std::vector<TileDesc> tiles;
-    std::vector<uint32_t> orig;
-    s = load_meta(fc.f, h, &meta, &tiles, &orig);
-    if (s != RF_OK) return s;
-    if (out_capacity < meta.n) {
-        set_error("rf_stream_many: the file holds " + std::to_string(meta.n) + " candidates but `out` has room for " + std::to_string(out_capacity) +
-                  " (ask rf_corpus_file_count)");
-        return RF_ERR_INVALID_ARG;
-    }
-    if (meta.n == 0) return RF_OK;
-    const uint64_t uniform_tb = tile_bytes(meta.uniform_len);
-    auto tile_off = [&](uint32_t t) { return meta.uniform ? (uint64_t)t * uniform_tb : (t < meta.n_tiles ? tiles[t].data_off : meta.data_bytes - kTailPad); };
-    // segment boundaries
-    if (segment_bytes == 0) segment_bytes = 512ull << 20;  // (64 GB file, same box: 256 MiB segments 39.8 GB/s, 512 MiB 47.5: profiles/stream_r04.txt)
-    std::vector<uint32_t> cuts{0};
-    // (the one-length views of a mixed tile share one payload block: a cut may only fall where the payload offset changes)
-    auto block_start = [&](uint32_t t) { return t >= meta.n_tiles || t == 0 || tile_off(t) != tile_off(t - 1); };
-    while (cuts.back() < meta.n_tiles) {
-        uint32_t t0 = cuts.back(), t1 = t0 + 1;
-        while (t1 < meta.n_tiles && !block_start(t1)) ++t1;  // at least one whole block
-        while (t1 < meta.n_tiles) {
-            uint32_t t2 = t1 + 1;
-            while (t2 < meta.n_tiles && !block_start(t2)) ++t2;
-            if (tile_off(t2) - tile_off(t0) > segment_bytes) break;
-            t1 = t2;
-        }
-        cuts.push_back(t1);
-    }
-    uint64_t max_seg = 0;
-    uint32_t max_tiles = 0;
-    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
-        max_seg = std::max(max_seg, tile_off(cuts[k + 1]) - tile_off(cuts[k]));
-        max_tiles = std::max(max_tiles, cuts[k + 1] - cuts[k]);
-    }
-
-    constexpr int kSlots = 3;  // buffer sets in rotation: one being read into, one on the link, one being scanned
-    struct Slot {
-        uint8_t *d_data = nullptr, *h_data = nullptr;
-        TileDesc* d_tiles = nullptr;
-        uint32_t* d_orig = nullptr;
-        hipEvent_t uploaded = nullptr, scanned = nullptr;
-        bool used = false;
-    } slot[kSlots];
-    hipStream_t s_copy = nullptr, s_comp = nullptr;
-    uint8_t* d_sigma = nullptr;
-    void* d_out = nullptr;
-    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
-    rf_status status = RF_OK;
-    hipError_t e = hipSuccess;
-    auto hip_ok = [&](hipError_t err) {
-        if (err != hipSuccess && e == hipSuccess) e = err;
-        return err == hipSuccess;
-    };
-    bool ok = hip_ok(hipStreamCreate(&s_copy)) && hip_ok(hipStreamCreate(&s_comp)) && hip_ok(hipMalloc(&d_sigma, 256)) &&
-              hip_ok(hipMemcpy(d_sigma, meta.sigma, 256, hipMemcpyHostToDevice)) && hip_ok(hipMalloc(&d_out, meta.n * elem));
-    // None everywhere first: a cutoff run skips whole tile ranges (plan()), and segment views never pre-fill
-    if (ok) ok = hip_ok(hipMemsetAsync(d_out, 0xFF, meta.n * elem, s_comp));
-    // The buffer sets (pinned host + device payload buffers) are KEPT between calls, per process: allocating and pinning 3 x 256 MiB
-    // costs 50-80 ms, a third of a 6.4 GB streamed scan (profiles/stream_r04.txt).  One streamed scan at a time uses the kept sets (a
-    // concurrent one allocates its own); a call that needs larger segments replaces them.  RF_STREAM_KEEP=0: allocate and free per call.
-    struct KeptSets {
-        std::mutex mu;
-        uint8_t *d_data[3] = {nullptr, nullptr, nullptr}, *h_data[3] = {nullptr, nullptr, nullptr};
-        uint64_t cap = 0;
-        int device = -1;
-    };
-    static KeptSets kept;
-    static const bool keep_sets = [] { const char* e = getenv("RF_STREAM_KEEP"); return !e || atoi(e) != 0; }();
-    std::unique_lock<std::mutex> kept_lock(kept.mu, std::defer_lock);
-    const bool use_kept = keep_sets && kept_lock.try_lock();
-    if (use_kept && (kept.cap < max_seg + kTailPad || kept.device != device)) {
-        for (int b = 0; b < kSlots; ++b) {
-            if (kept.d_data[b]) (void)hipFree(kept.d_data[b]);
-            if (kept.h_data[b]) (void)hipHostFree(kept.h_data[b]);
-            kept.d_data[b] = kept.h_data[b] = nullptr;
-        }
-        kept.cap = 0;
-        kept.device = device;
-        bool got = true;
-        for (int b = 0; got && b < kSlots; ++b)
-            got = hipMalloc(&kept.d_data[b], max_seg + kTailPad) == hipSuccess && hipHostMalloc((void**)&kept.h_data[b], max_seg + kTailPad, hipHostMallocDefault) == hipSuccess;
-        if (got) {
-            kept.cap = max_seg + kTailPad;
-        } else {
-            (void)hipGetLastError();
-            for (int b = 0; b < kSlots; ++b) {
-                if (kept.d_data[b]) (void)hipFree(kept.d_data[b]);
-                if (kept.h_data[b]) (void)hipHostFree(kept.h_data[b]);
-                kept.d_data[b] = kept.h_data[b] = nullptr;
-            }
-        }
-    }
-    const bool from_kept = use_kept && kept.cap >= max_seg + kTailPad;
-    for (int b = 0; ok && b < kSlots; ++b) {
-        if (from_kept) {
-            slot[b].d_data = kept.d_data[b];
-            slot[b].h_data = kept.h_data[b];
-        } else {
-            ok = hip_ok(hipMalloc(&slot[b].d_data, max_seg + kTailPad)) && hip_ok(hipHostMalloc((void**)&slot[b].h_data, max_seg + kTailPad, hipHostMallocDefault));
-        }
-        ok = ok && hip_ok(hipEventCreateWithFlags(&slot[b].uploaded, hipEventDisableTiming)) && hip_ok(hipEventCreateWithFlags(&slot[b].scanned, hipEventDisableTiming));
-        if (ok && !meta.uniform)
-            ok = hip_ok(hipMalloc(&slot[b].d_tiles, (size_t)max_tiles * sizeof(TileDesc))) && hip_ok(hipMalloc(&slot[b].d_orig, (size_t)max_tiles * kWave * 4));
-    }
-    // Single-length corpora: a segment's results are a contiguous slice of `out`, so they travel to the host while the later segments
-    // are still being read, copied and scanned -- on a thread of their own (a device-to-pageable-host copy blocks its caller) and a
-    // stream of their own (the link is full duplex).  4 bytes per 64-byte candidate: left to the end they were 15 % of a 64 GB scan.
-    struct ResJob {
-        hipEvent_t ready;
-        size_t off, bytes;
-    };
-    std::mutex res_mu;
-    std::condition_variable res_cv;
-    std::deque<ResJob> res_jobs;
-    bool res_done = false;
-    std::atomic<int> res_err{(int)hipSuccess};
-    hipStream_t s_res = nullptr;
-    std::thread res_thread;
-    const bool early_results = ok && meta.uniform && hip_ok(hipStreamCreateWithFlags(&s_res, hipStreamNonBlocking));
-    if (early_results)
-        res_thread = std::thread([&] {
-            (void)hipSetDevice(device);
-            while (true) {
-                ResJob j;
-                {
-                    std::unique_lock<std::mutex> lk(res_mu);
-                    res_cv.wait(lk, [&] { return res_done || !res_jobs.empty(); });
-                    if (res_jobs.empty()) return;
-                    j = res_jobs.front();
-                    res_jobs.pop_front();
-                }
-                hipError_t er = hipStreamWaitEvent(s_res, j.ready, 0);
-                if (er == hipSuccess) er = hipMemcpyAsync(static_cast<char*>(out_host) + j.off, static_cast<char*>(d_out) + j.off, j.bytes, hipMemcpyDeviceToHost, s_res);
-                if (er == hipSuccess) er = hipStreamSynchronize(s_res);
-                (void)hipEventDestroy(j.ready);
-                if (er != hipSuccess) res_err = (int)er;
-            }
-        });
-    std::vector<TileDesc> seg_tiles;
-    static const bool stream_timing = getenv("RF_STREAM_TIMING") != nullptr;  // phase times of a streamed scan on stderr
-    using clk = std::chrono::steady_clock;
-    const auto t_loop = clk::now();
-    double s_wait = 0.0, s_read = 0.0;
-    if (stream_timing) std::fprintf(stderr, "[rf stream] set-up (streams, device + pinned buffers, None pre-fill) %.1f ms\n", std::chrono::duration<double, std::milli>(t_loop - t_enter).count());
-    for (size_t k = 0; ok && status == RF_OK && k + 1 < cuts.size(); ++k) {
-        Slot& sl = slot[k % kSlots];
-        const uint32_t t0 = cuts[k], t1 = cuts[k + 1];
-        const uint64_t base = tile_off(t0), bytes = tile_off(t1) - base;
-        const auto t_a = clk::now();
-        if (sl.used) ok = hip_ok(hipEventSynchronize(sl.scanned));  // the scan that last read this buffer set is done
-        if (!ok) break;
-        const auto t_b = clk::now();
-        if (!read_parallel(fd, h.off_data + base, sl.h_data, (size_t)bytes)) {
-            set_error("corpus file truncated");
-            status = RF_ERR_INVALID_ARG;
-            break;
-        }
-        s_wait += std::chrono::duration<double, std::milli>(t_b - t_a).count();
-        s_read += std::chrono::duration<double, std::milli>(clk::now() - t_b).count();
-        std::memset(sl.h_data + bytes, 0, kTailPad);
-        ok = hip_ok(hipMemcpyAsync(sl.d_data, sl.h_data, bytes + kTailPad, hipMemcpyHostToDevice, s_copy));
-        rf_corpus seg;  // a view: owns nothing
-        seg.borrowed = true;
-        seg.no_prefill = true;
-        seg.uid = meta.uid;  // one lowered comparator serves every segment of a u32 corpus
-        seg.device = device;
-        seg.wide = meta.wide;
-        seg.alphabet = meta.alphabet;
-        seg.overflow = meta.overflow;
-        std::memcpy(seg.sigma, meta.sigma, 256);
-        seg.d_sigma = d_sigma;
-        seg.d_data = sl.d_data;
-        seg.n_tiles = t1 - t0;
-        seg.n_exact = seg.n_tiles;  // (a segment view has no mixed section of its own: mixed tiles are scanned through their views)
-        seg.data_bytes = bytes + kTailPad;
-        void* seg_out = d_out;
-        if (meta.uniform) {
-            seg.uniform = true;
-            seg.uniform_len = meta.uniform_len;
-            seg.max_len = meta.uniform_len;
-            seg.n = (size_t)std::min<uint64_t>((uint64_t)(t1 - t0) * kWave, meta.n - (uint64_t)t0 * kWave);
-            seg.lengths = {meta.uniform_len};
-            seg.length_first_tile = {0};
-            seg_out = static_cast<char*>(d_out) + (size_t)t0 * kWave * elem;  // slot == original index
-        } else {
-            seg.n = meta.n;  // results are scattered through orig[] into the whole output
-            seg_tiles.assign(tiles.begin() + t0, tiles.begin() + t1);
-            for (uint32_t t = 0; t < t1 - t0; ++t) {
-                seg_tiles[t].data_off -= base;
-                seg_tiles[t].slot0 = t * kWave;
-                if (seg.lengths.empty() || seg.lengths.back() != seg_tiles[t].len) {
-                    seg.lengths.push_back(seg_tiles[t].len);
-                    seg.length_first_tile.push_back(t);
-                }
-                seg.max_len = std::max(seg.max_len, seg_tiles[t].len);
-            }
-            seg.d_tiles = sl.d_tiles;
-            seg.d_orig = sl.d_orig;
-            // pageable sources: both copies are staged before the calls return, so seg_tiles may be reused
-            ok = ok && hip_ok(hipMemcpyAsync(sl.d_tiles, seg_tiles.data(), seg_tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, s_copy)) &&
-                 hip_ok(hipMemcpyAsync(sl.d_orig, orig.data() + (size_t)t0 * kWave, (size_t)(t1 - t0) * kWave * 4, hipMemcpyHostToDevice, s_copy));
-        }
-        ok = ok && hip_ok(hipEventRecord(sl.uploaded, s_copy)) && hip_ok(hipStreamWaitEvent(s_comp, sl.uploaded, 0));
-        if (!ok) break;
-        status = run_many(c, &seg, op, args, seg_out, RF_MEM_DEVICE, s_comp, f64_out);
-        if (status != RF_OK) break;
-        ok = hip_ok(hipEventRecord(sl.scanned, s_comp));
-        sl.used = true;
-        if (ok && early_results) {
-            ResJob j{nullptr, (size_t)t0 * kWave * elem, seg.n * elem};
-            ok = hip_ok(hipEventCreateWithFlags(&j.ready, hipEventDisableTiming)) && hip_ok(hipEventRecord(j.ready, s_comp));
-            if (ok) {
-                std::lock_guard<std::mutex> lk(res_mu);
-                res_jobs.push_back(j);
-            }
-            res_cv.notify_one();
-        }
-    }
-    const auto t_tail = clk::now();
-    if (res_thread.joinable()) {
-        {
-            std::lock_guard<std::mutex> lk(res_mu);
-            res_done = true;
-        }
-        res_cv.notify_one();
-        res_thread.join();
-        if (res_err.load() != (int)hipSuccess) ok = hip_ok((hipError_t)res_err.load());
-    }
-    if (ok && status == RF_OK && !early_results)
-        ok = hip_ok(hipMemcpyAsync(out_host, d_out, meta.n * elem, hipMemcpyDeviceToHost, s_comp)) && hip_ok(hipStreamSynchronize(s_comp));
-    if (stream_timing)
-        std::fprintf(stderr, "[rf stream] %zu segments: loop %.1f ms (reads %.1f, waits for a free buffer set %.1f), drain + results to the host %.1f ms\n", cuts.size() - 1,
-                     std::chrono::duration<double, std::milli>(t_tail - t_loop).count(), s_read, s_wait, std::chrono::duration<double, std::milli>(clk::now() - t_tail).count());
-    if (s_copy) (void)hipStreamSynchronize(s_copy);
-    if (s_comp) (void)hipStreamSynchronize(s_comp);
-    for (int b = 0; b < kSlots; ++b) {
-        if (slot[b].d_data && !from_kept) (void)hipFree(slot[b].d_data);
-        if (slot[b].h_data && !from_kept) (void)hipHostFree(slot[b].h_data);
-        if (slot[b].d_tiles) (void)hipFree(slot[b].d_tiles);
-        if (slot[b].d_orig) (void)hipFree(slot[b].d_orig);
-        if (slot[b].uploaded) (void)hipEventDestroy(slot[b].uploaded);
-        if (slot[b].scanned) (void)hipEventDestroy(slot[b].scanned);
-    }
-    {   // this pass' identity dies with it: drop the comparator lowered for it (a long-lived u32 comparator would
-        // otherwise accumulate one cache entry per streamed pass)
-        std::lock_guard<std::mutex> lock(c->mu);
-        c->lowered.erase(meta.uid);
-    }
-    if (d_sigma) (void)hipFree(d_sigma);
-    if (d_out) (void)hipFree(d_out);
-    if (s_copy) (void)hipStreamDestroy(s_copy);
-    if (s_comp) (void)hipStreamDestroy(s_comp);
-    if (s_res) (void)hipStreamDestroy(s_res);
-    if (status != RF_OK) return status;
-    if (!ok) {
-        set_error(std::string("rf_stream_many: ") + hipGetErrorString(e));
-        return e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;
-    }
-    return RF_OK;
-}
-
-rf_status rf_stream_many_u32(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, uint32_t* out, size_t out_capacity,
-                             uint64_t segment_bytes, int device)
-{
-    return stream_many(c, path, op, args, out, out_capacity, false, segment_bytes, device);
-}
-rf_status rf_stream_many_f64(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, double* out, size_t out_capacity,
-                             uint64_t segment_bytes, int device)
-{
-    return stream_many(c, path, op, args, out, out_capacity, true, segment_bytes, device);
-}
-rf_status rf_corpus_file_count(const char* path, size_t* n)
-{
-    if (!path || !n) {
-        set_error("rf_corpus_file_count: invalid argument");
-        return RF_ERR_INVALID_ARG;
-    }
-    FileCloser fc{std::fopen(path, "rb")};
-    if (!fc.f) {
-        set_error(std::string("rf_corpus_file_count: cannot open ") + path);
-        return RF_ERR_INVALID_ARG;
-    }
-    FileHeader h;
-    const rf_status s = read_header(fc.f, &h);
-    if (s == RF_OK) *n = (size_t)h.n;
-    return s;
-}
 
 // Issue-rate probe (rf_probe.hip): the product's own column code on register-resident PM words.
 rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, uint32_t mode, int device, uint32_t blocks_per_cu, double* wave_columns_per_ns)

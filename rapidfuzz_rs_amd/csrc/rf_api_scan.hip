@@ -1,0 +1,981 @@
+// rf_api_scan.hip -- plan(): Args x metric x op -> kernel parameters, and the rf_many_* / rf_one_* / rf_many_multi_* entry points (split out of rf_api.hip in round 4; rf_host.hpp has the shared declarations).
+// Product code: never includes or links anything from oracle/.
+#include "rf_host.hpp"
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------
+// one-vs-many
+// ---------------------------------------------------------------------------------------------------
+rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, bool f64_out,
+                      ScanParams* p, RawKind* raw)
+{
+    if (!c || !corpus || !args) {
+        set_error("null handle or args");
+        return RF_ERR_INVALID_ARG;
+    }
+    std::memset(p, 0, sizeof(*p));
+    p->len1 = (uint32_t)c->s1.size();
+    p->words = (uint32_t)pm_stride(c);  // row stride of the device table
+    p->op = (uint32_t)op;
+    p->out_f64 = f64_out ? 1 : 0;
+    p->factor = 1;
+    p->w_ins = p->w_del = p->w_sub = 1;
+    p->prefix_weight = args->prefix_weight;
+    for (size_t i = 0; i < std::min<size_t>(4, c->s1.size()); ++i) p->query_head |= (uint32_t)corpus->sigma[c->s1[i]] << (8 * i);
+    p->sigma = corpus->d_sigma;
+    p->data = corpus->d_data;
+    p->tiles = corpus->uniform ? nullptr : corpus->d_tiles;
+    p->uniform_len = corpus->uniform_len;
+    p->uniform_tile_bytes = (uint32_t)tile_bytes(corpus->uniform_len);
+    p->orig = corpus->d_orig;
+    p->n_tiles = corpus->n_tiles;
+    p->tile_begin = 0;
+    p->tile_end = corpus->n_tiles;
+    p->n_exact = corpus->n_exact;
+    p->mixed = corpus->d_mixed;  // (nullptr when the corpus has no mixed section, and on views without one)
+    p->mixed_len = corpus->d_mixed_len;
+    p->mixed_orig = corpus->d_mixed_orig;
+    p->mixed_begin = 0;
+    p->mixed_end = corpus->d_mixed ? corpus->n_mixed : 0;
+    p->tile_step = 1;
+    p->n = (uint32_t)corpus->n;
+    {   // zero-length tiles (the asm stream kernels are not given them): at most one run per ascending section of the tile order
+        int runs = 0;
+        for (size_t i = 0; i < corpus->lengths.size() && runs < 2; ++i)
+            if (corpus->lengths[i] == 0) {
+                p->zero_begin[runs] = corpus->length_first_tile[i];
+                p->zero_end[runs] = i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles;
+                ++runs;
+            }
+    }
+
+    const bool usize_metric = c->metric == RF_LEVENSHTEIN || c->metric == RF_INDEL || c->metric == RF_LCS_SEQ || c->metric == RF_OSA;
+    const bool norm_op = op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY;
+    if ((int)op < 0 || (int)op > (int)RF_OP_NORMALIZED_SIMILARITY) {
+        set_error("unknown rf_op");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (usize_metric && (norm_op != f64_out)) {
+        set_error("levenshtein/indel/lcs_seq: distance and similarity are u32-valued (rf_many_u32), normalized_* are "
+                  "f64-valued (rf_many_f64)");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (!usize_metric && !f64_out) {
+        set_error("jaro / jaro_winkler / fuzz ratio are f64-valued: use rf_many_f64");
+        return RF_ERR_INVALID_ARG;
+    }
+
+    if (f64_out) {
+        p->has_cutoff = std::isnan(args->cutoff_f64) ? 0 : 1;
+        p->cutoff_f64 = args->cutoff_f64;
+    } else {
+        p->has_cutoff = args->cutoff_usize != RF_NO_CUTOFF;
+        p->cutoff_u32 = (uint32_t)std::min<uint64_t>(args->cutoff_usize, 0xFFFFFFFFull);
+    }
+
+    switch (c->metric) {
+    case RF_LEVENSHTEIN: {
+        // _distance_with_pm weight dispatch, levenshtein.rs:1285-1331
+        const uint64_t ins = args->insertion_cost, del = args->deletion_cost, sub = args->substitution_cost;
+        if (ins > 0xFFFF || del > 0xFFFF || sub > 0xFFFF) {
+            set_error("levenshtein weights above 65535 are not supported on the device");
+            return RF_ERR_UNSUPPORTED;
+        }
+        p->w_ins = (uint32_t)ins;
+        p->w_del = (uint32_t)del;
+        p->w_sub = (uint32_t)sub;
+        if (ins == del && (ins == 0 || ins == sub)) {  // :1303-1316 (ins == del == 0 -> every distance is 0)
+            *raw = RAW_LEV;
+            p->finish = FIN_LEV;
+            p->factor = (uint32_t)ins;
+        } else if (ins == del && sub >= ins + del) {  // :1321-1327: Indel distance times the common factor
+            *raw = RAW_LCS;
+            p->finish = FIN_LEV_INDEL;
+            p->factor = (uint32_t)ins;
+        } else {
+            // every other table: the generalized Wagner-Fischer row DP (levenshtein.rs:212-259) in LDS
+            *raw = RAW_WF;
+            p->finish = FIN_LEV_GENERAL;
+            const uint64_t row_bytes = ((uint64_t)p->len1 + 1) * kWave * sizeof(uint32_t);
+            const uint64_t lds_budget = 150u << 10;  // of the 160 KiB a gfx950 workgroup may hold
+            const uint64_t worst = ((uint64_t)p->len1 + corpus->max_len) * std::max(std::max(ins, del), sub);
+            if (worst >= (1ull << 31) || p->len1 > 150000) {
+                set_error("levenshtein with a general weight table: distances would not fit 31 bits (or the query is beyond 150 000 symbols)");
+                return RF_ERR_UNSUPPORTED;
+            }
+            if (row_bytes + p->len1 + 8 > lds_budget) {
+                // the row does not fit LDS (queries beyond ~590 symbols): one global scratch strip per wavefront instead
+                p->wf_global = 1;
+                p->wf_waves = kWavesPerBlock;
+                const uint64_t per_block = row_bytes * kWavesPerBlock, budget = 1ull << 30;
+                p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / per_block, (uint64_t)scan_grid(corpus->n_tiles)));
+            } else {
+                p->wf_waves = (uint32_t)std::min<uint64_t>(kWavesPerBlock, (lds_budget - p->len1 - 8) / row_bytes);
+            }
+            for (size_t i = 0; i < std::min<size_t>(64, c->s1.size()); ++i)  // the register-resident kernel compares against these
+                p->wf_query[i / 4] |= (uint32_t)corpus->sigma[c->s1[i]] << (8 * (i % 4));
+        }
+        break;
+    }
+    case RF_OSA:  // osa.rs:431-461; maximum = max(len1, len2) = levenshtein's at unit weights
+        *raw = RAW_OSA;
+        p->finish = FIN_LEV;  // (beyond 512 symbols: long_kernel, with the transposition bit carried between word groups)
+        break;
+    case RF_INDEL:
+        *raw = RAW_LCS;
+        p->finish = FIN_INDEL;
+        break;
+    case RF_LCS_SEQ:
+        *raw = RAW_LCS;
+        p->finish = FIN_LCS;
+        break;
+    case RF_FUZZ_RATIO:
+        // RatioBatchComparator::similarity_with_args, fuzz.rs:127-149: normalized similarity of the inner
+        // lcs_seq comparator (quirk Q1), or of Indel when the caller asks for the documented ratio.
+        if (op != RF_OP_SIMILARITY && op != RF_OP_NORMALIZED_SIMILARITY) {
+            set_error("RatioBatchComparator only has similarity (fuzz.rs:115-149)");
+            return RF_ERR_INVALID_ARG;
+        }
+        *raw = RAW_LCS;
+        p->finish = (args->flags & RF_FLAG_RATIO_INDEL_NORMALIZATION) ? FIN_INDEL : FIN_LCS;
+        p->op = RF_OP_NORMALIZED_SIMILARITY;
+        break;
+    case RF_JARO:
+    case RF_JARO_WINKLER: {
+        *raw = RAW_JARO;
+        p->finish = c->metric == RF_JARO ? FIN_JARO : FIN_JW;
+        // Early-out under a tight cutoff (the reference's own common_char_filter idea, jaro.rs:134-145, applied while the
+        // flags are still being collected): `jaro_need` is the similarity a candidate has to reach.
+        p->jaro_need = -1.0;
+        if (!p->has_cutoff) p->jaro_tab = jaro_device_table(corpus->device);  // (nullptr on failure: the kernels then divide)
+        if (p->has_cutoff && args->prefix_weight >= 0.0 && 4.0 * args->prefix_weight <= 1.0) {
+            const double need = (op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY) ? args->cutoff_f64 : 1.0 - args->cutoff_f64;
+            if (need >= 0.6 && need <= 1.0) p->jaro_need = need;
+        }
+        // Single-word path (jaro.rs:574-583) when both strings are <= 64 symbols AFTER the window truncation of
+        // jaro.rs:550-565, multi-word path (up to 512 symbols each) otherwise.  Tiles ascend by length TWICE -- the exact
+        // tiles, then the one-length views of the mixed section -- and the single-word condition holds for a length prefix
+        // of each run, so each section splits at one tile index (jaro_split, jaro_split2): a short leftover behind a long
+        // exact tile still takes the single-word kernel.
+        const uint64_t len1 = c->s1.size();
+        p->jaro_split = corpus->n_exact;
+        p->jaro_split2 = corpus->n_tiles;
+        for (size_t i = 0; i < corpus->lengths.size(); ++i) {
+            uint64_t a = len1, b = corpus->lengths[i];
+            if (b > a) {
+                const uint64_t bound = b / 2 - 1;
+                if (b > a + bound) b = a + bound;
+            } else if (a >= 2) {
+                const uint64_t bound = a / 2 - 1;
+                if (a > b + bound) a = b + bound;
+            }
+            const bool needs_flags = a != 0 && b != 0;  // otherwise decided by the length filter alone
+            const bool word_ok = !needs_flags || (a <= 64 && b <= 64);
+            if (word_ok) continue;
+            // this run of equal-length tiles [first, end) needs the multi-word path.  (A run may straddle the two sections: the last
+            // exact length and the first view can be the same length, and the length table merges them.)
+            const uint32_t first = corpus->length_first_tile[i];
+            const uint32_t end = i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles;
+            if (first < corpus->n_exact) p->jaro_split = std::min(p->jaro_split, first);
+            if (end > corpus->n_exact) p->jaro_split2 = std::min(p->jaro_split2, std::max(first, corpus->n_exact));
+            if (a > 64 * (uint64_t)kMaxWords || b > 64 * (uint64_t)kMaxWords || c->words > (size_t)kMaxWords)
+                p->jaro_long = 1;  // beyond 512 symbols: the flag words move from registers to global scratch strips
+        }
+        if (p->jaro_long) {
+            // per wavefront: P words (len1 / 64 + 1) and T words (max candidate length / 64) for 64 lanes
+            p->long_chunks_max = (corpus->max_len + 63) / 64 + 1;
+            const uint64_t strip_bytes = ((uint64_t)(p->len1 + 63) / 64 + 1 + p->long_chunks_max) * kWave * sizeof(uint64_t);
+            const uint64_t budget = 1ull << 30;
+            p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / (strip_bytes * kWavesPerBlock), (uint64_t)scan_grid(corpus->n_tiles)));
+        }
+        if (p->jaro_need >= 0.0) {
+            // Length window, the reference's length_filter (jaro.rs:122-131) hoisted to the host: with m = min(len1, L)
+            // the similarity of a candidate of length L is at most (m/len1 + m/L + 1)/3 (+ the largest Winkler boost);
+            // lengths that cannot reach `jaro_need` are never read -- pre-filled with None like the usize metrics'.
+            const auto& L = corpus->lengths;
+            size_t first = L.size(), last = 0;
+            const double boost = c->metric == RF_JARO_WINKLER ? 4.0 * args->prefix_weight : 0.0;
+            for (size_t i = 0; i < L.size(); ++i) {
+                const double l1 = (double)len1, l2 = (double)L[i], m = std::min(l1, l2);
+                double ub = (len1 == 0 && L[i] == 0) ? 1.0 : ((len1 == 0 || L[i] == 0) ? 0.0 : (m / l1 + m / l2 + 1.0) / 3.0);
+                ub += boost * (1.0 - ub);
+                if (ub + 1e-9 >= p->jaro_need) {
+                    first = std::min(first, i);
+                    last = i;
+                }
+            }
+            if (first == L.size()) {
+                p->tile_begin = p->tile_end = corpus->n_tiles;
+            } else {
+                p->tile_begin = corpus->length_first_tile[first];
+                p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
+            }
+            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles);
+        }
+        return RF_OK;  // the PM row stride may exceed kMaxWords: only block 0 is read
+    }
+    }
+
+    // The device finishes in u32 (results are u32): with a common weight factor f every intermediate is bounded by
+    // f * (len1 + max_len) -- refuse what would wrap instead of returning it mod 2^32 (the reference computes in usize).
+    if ((uint64_t)std::max<uint32_t>(p->factor, 1) * ((uint64_t)p->len1 + corpus->max_len) > 0xFFFFFFFEull) {
+        set_error("weights x string lengths exceed the u32 range of the device results");
+        return RF_ERR_UNSUPPORTED;
+    }
+    {
+        // finishing coefficients: dist = dS*S + dM*Mx + dR*raw, maximum = mS*S + mM*Mx (rf_device.hpp "Finishing")
+        const int32_t f = (int32_t)p->factor;
+        switch (p->finish) {
+        case FIN_LEV: p->fin_dS = 0, p->fin_dM = 0, p->fin_dR = f, p->fin_mS = 0, p->fin_mM = f; break;
+        case FIN_LCS: p->fin_dS = 0, p->fin_dM = 1, p->fin_dR = -1, p->fin_mS = 0, p->fin_mM = 1; break;
+        case FIN_INDEL: p->fin_dS = 1, p->fin_dM = 0, p->fin_dR = -2, p->fin_mS = 1, p->fin_mM = 0; break;
+        case FIN_LEV_INDEL: p->fin_dS = f, p->fin_dM = 0, p->fin_dR = -2 * f, p->fin_mS = f, p->fin_mM = 0; break;
+        case FIN_LEV_GENERAL: p->fin_dS = 0, p->fin_dM = 0, p->fin_dR = 1, p->fin_mS = 0, p->fin_mM = 0; break;  // maximum: wf_kernel
+        default: break;
+        }
+        if (op == RF_OP_DISTANCE || op == RF_OP_NORMALIZED_DISTANCE) {
+            p->fin_vS = p->fin_dS, p->fin_vM = p->fin_dM, p->fin_vR = p->fin_dR;
+            p->fin_flip = 0;
+            p->fin_cflip = (p->has_cutoff && !f64_out) ? p->cutoff_u32 : 0xFFFFFFFFu;
+        } else {  // similarity = maximum - distance (details/distance.rs:209-210)
+            p->fin_vS = p->fin_mS - p->fin_dS, p->fin_vM = p->fin_mM - p->fin_dM, p->fin_vR = -p->fin_dR;
+            p->fin_flip = 0xFFFFFFFFu;
+            p->fin_cflip = ~((p->has_cutoff && !f64_out) ? p->cutoff_u32 : 0u);
+        }
+    }
+
+    if (*raw == RAW_WF) return RF_OK;
+    // Long query + small distance cutoff (the reference's hyrroe2003_small_band_with_pm, levenshtein.rs:509-617, taken when
+    // len1 > 64 and 2k + 1 <= 64, :1059-1062): one 64-bit word sliding down the diagonal instead of ceil(len1 / 64) words
+    // per column.  k is the cutoff on the RAW distance (the common weight factor divided out).
+    static const bool no_band = getenv("RF_NO_BAND") != nullptr;  // A/B switch
+    if (!no_band && *raw == RAW_LEV && p->finish == FIN_LEV && p->factor >= 1 && op == RF_OP_DISTANCE && !f64_out && p->has_cutoff && c->words >= 2 &&
+        c->words <= 64 && p->cutoff_u32 / p->factor <= 31) {
+        p->band = 1;
+        p->band_k = p->cutoff_u32 / p->factor;
+    }
+    if (c->words > (size_t)kMaxWords && !p->band) {
+        // beyond 512 symbols: the multi-sweep kernel (8 words per sweep, carries parked in an HBM scratch strip)
+        if (c->words > 0x00FFFFFFu) {
+            set_error("query too long");
+            return RF_ERR_UNSUPPORTED;
+        }
+        p->long_words_pad = (uint32_t)pm_stride(c);
+        p->long_chunks_max = (corpus->max_len + kChunk - 1) / kChunk;
+        const uint64_t strip_bytes = std::max<uint64_t>(1, (uint64_t)p->long_chunks_max * kWave * sizeof(uint32_t)) * (*raw == RAW_OSA ? 2 : 1);
+        const uint64_t budget = 256ull << 20;
+        const uint64_t waves = std::max<uint64_t>(kWavesPerBlock, budget / strip_bytes);
+        p->long_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves / kWavesPerBlock, (uint64_t)scan_grid(corpus->n_tiles)));
+        return RF_OK;
+    }
+    // Value-preserving early-out (the reference applies its cutoffs after the loops, e.g. levenshtein.rs:492-496):
+    // the kernels stop reading a tile once no lane can pass the cutoff any more (may_pass() in rf_device.hpp), for
+    // every op and output type.  It pays only when the cutoff is tight enough to kill typical candidates early --
+    // the early-out loop gives up the streaming prefetch -- so it is switched on by how much normalized distance the
+    // cutoff still allows (`slack`; measured on the C2 corpus: Levenshtein wins up to ~0.7, the LCS bound, which only
+    // gains one per remaining column, up to ~0.4).
+    if (p->has_cutoff && (*raw == RAW_LEV || *raw == RAW_OSA || *raw == RAW_LCS) && !(p->finish == FIN_LEV && p->factor == 0)) {
+        const uint64_t S = (uint64_t)p->len1 + corpus->max_len, Mx = std::max<uint64_t>(p->len1, corpus->max_len);
+        const double maximum = (double)((int64_t)p->fin_mS * (int64_t)S + (int64_t)p->fin_mM * (int64_t)Mx);
+        double slack;  // allowed distance / maximum
+        if (f64_out)
+            slack = (op == RF_OP_NORMALIZED_DISTANCE) ? p->cutoff_f64 : 1.0 - p->cutoff_f64;
+        else if (maximum <= 0.0)
+            slack = 1.0;
+        else
+            slack = (op == RF_OP_DISTANCE) ? (double)p->cutoff_u32 / maximum : 1.0 - (double)p->cutoff_u32 / maximum;
+        const double tight = *raw == RAW_LCS ? 0.4 : 0.7;
+        if (slack < tight) {
+            p->early = 1;
+            // where a tile's first chunk takes its first look (scan_body): unrelated strings gain almost one edit per column
+            {
+                static const int forced = [] { const char* e = getenv("RF_FIRST_CHECK"); return e ? atoi(e) : 0; }();  // A/B switch
+                const double raw_allowed = slack * maximum / (double)std::max<uint32_t>(1u, (uint32_t)std::abs(p->fin_dR));
+                // measured on the C2 corpus (cutoffs 0..12, looks at 4..16): the best look is the first even column >= cutoff + 3
+                // (cutoff 3: 195 -> 213 Gpairs/s, cutoff 0: 197 -> 233, cutoff 8: 125 -> 159)
+                const double need = raw_allowed + 3.0;
+                p->first_check = need <= 4.0 ? 4u : (need >= 15.0 ? 16u : 2u * (uint32_t)((need + 1.999) / 2.0));
+                if (*raw == RAW_LCS) {
+                    // the LCS bound loses one per column WITHOUT a match, and random strings still match every third column or so:
+                    // Indel cutoff 4 is best looked at in column 10-12 (221 -> 233 Gpairs/s), cutoff 12 not before the chunk's end
+                    const double misses = (p->finish == FIN_LCS ? slack * maximum : slack * maximum / 2.0), lcs_need = (misses + 3.0) / 0.55;
+                    p->first_check = lcs_need >= 15.0 ? 16u : std::max(4u, 2u * (uint32_t)((lcs_need + 1.999) / 2.0));
+                }
+                if (forced >= 4 && forced <= 16 && forced % 2 == 0) p->first_check = (uint32_t)forced;
+            }
+            // Length window: before any byte is read a candidate of length L already has a favourable bound -- distance >=
+            // |len1 - L| (the reference's first test, levenshtein.rs:1389-1391), LCS <= min(len1, L).  Lengths whose bound
+            // fails the cutoff (same arithmetic as may_pass() on the device) are never read: tiles ascend by length, so
+            // the survivors lie in ONE tile range [first passing length, last passing length]; the rest of `out` is
+            // pre-filled with None.
+            const auto& L = corpus->lengths;
+            size_t first = L.size(), last = 0;
+            uint32_t pass_lo = 0xFFFFFFFFu, pass_hi = 0;  // the shortest and the longest candidate length that can pass
+            for (size_t i = 0; i < L.size(); ++i) {
+                const uint32_t len2 = L[i];
+                const uint32_t Sv = p->len1 + len2, Mv = std::max(p->len1, len2);
+                const uint32_t raw_b = *raw == RAW_LCS ? std::min(p->len1, len2) : (p->len1 > len2 ? p->len1 - len2 : len2 - p->len1);
+                bool pass;
+                if (!f64_out) {
+                    const uint32_t v = (uint32_t)p->fin_vS * Sv + (uint32_t)p->fin_vM * Mv + (uint32_t)p->fin_vR * raw_b;
+                    pass = (v ^ p->fin_flip) <= p->fin_cflip;
+                } else {
+                    const uint32_t dist = (uint32_t)p->fin_dS * Sv + (uint32_t)p->fin_dM * Mv + (uint32_t)p->fin_dR * raw_b;
+                    const uint32_t mx = (uint32_t)p->fin_mS * Sv + (uint32_t)p->fin_mM * Mv;
+                    const double nd = mx == 0 ? 0.0 : (double)dist / (double)mx;
+                    pass = op == RF_OP_NORMALIZED_DISTANCE ? nd <= p->cutoff_f64 : (1.0 - nd) >= p->cutoff_f64;
+                }
+                if (pass) {
+                    first = std::min(first, i);
+                    last = i;
+                    pass_lo = std::min(pass_lo, len2);
+                    pass_hi = std::max(pass_hi, len2);
+                }
+            }
+            // (the length table follows the tile order -- exact tiles ascending, then the one-length views of the mixed
+            // section ascending -- so [first, last] may enclose lengths that cannot pass: those tiles are merely read)
+            if (first == L.size()) {
+                p->tile_begin = p->tile_end = corpus->n_tiles;  // nothing can pass
+                p->mixed_begin = p->mixed_end = 0;
+            } else {
+                p->tile_begin = corpus->length_first_tile[first];
+                p->tile_end = last + 1 < L.size() ? corpus->length_first_tile[last + 1] : corpus->n_tiles;
+                // mixed tiles ascend by length as well: the ones whose length span meets [pass_lo, pass_hi]
+                uint32_t mb = 0, me = p->mixed_end;
+                while (mb < me && corpus->mixed[mb].max_len < pass_lo) ++mb;
+                while (me > mb && corpus->mixed[me - 1].min_len > pass_hi) --me;
+                p->mixed_begin = mb;
+                p->mixed_end = me;
+            }
+            p->prefill_none = !corpus->no_prefill && (p->tile_begin > 0 || p->tile_end < corpus->n_tiles ||
+                                                      (corpus->d_mixed && (p->mixed_begin > 0 || p->mixed_end < corpus->n_mixed)));
+        }
+    }
+    return RF_OK;
+}
+
+// bytes of per-launch scratch the planned kernels need (0 = none): carry strips of long_kernel, the global DP rows of
+// wf_kernel, the flag strips of jaro_long_kernel -- all handed to the kernels through ScanParams::long_scratch
+static size_t launch_scratch_bytes(const ScanParams& p, RawKind raw)
+{
+    const size_t waves = (size_t)p.long_grid * kWavesPerBlock;
+    if (p.jaro_long) return waves * (((size_t)p.len1 + 63) / 64 + 1 + p.long_chunks_max) * kWave * sizeof(uint64_t);
+    if (p.wf_global) return waves * ((size_t)p.len1 + 1) * kWave * sizeof(uint32_t);
+    if (p.long_words_pad) return waves * std::max<uint32_t>(1, p.long_chunks_max) * kWave * sizeof(uint32_t) * (raw == RAW_OSA ? 2 : 1);
+    return 0;
+}
+
+// The largest stored symbol of the payload (symbols are stored as their frequency rank: a 62-symbol corpus holds 0 .. 61), computed
+// exactly on first use -- one streaming pass -- and kept.  0xFFFFFFFF when it cannot be had.
+static uint32_t corpus_max_stored_symbol(const rf_corpus* corpus, hipStream_t st)
+{
+    if (corpus->borrowed || corpus->wide || !corpus->d_data || corpus->data_bytes < 16) return 0xFFFFFFFFu;
+    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+    if (corpus->max_stored_sym == 0xFFFFFFFFu) {
+        uint32_t* d = nullptr;
+        uint32_t v = 0;
+        if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0xFFFFFFFFu;
+        }
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), st);
+        if (e == hipSuccess) e = launch_max_byte(corpus->d_data, corpus->data_bytes, d, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&v, d, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return 0xFFFFFFFFu;
+        }
+        corpus->max_stored_sym = v;
+    }
+    return corpus->max_stored_sym;
+}
+
+// Small-cutoff Levenshtein scans of large single-length corpora take their first look from the head plane (rf_pack.hip
+// head8_plane_kernel).  Built once per corpus, on the first such scan; RF_HEAD8_MIN=<tiles> moves the threshold (0 = never).
+// Failing to allocate it is not an error: the scan then reads the tiles' first chunk rows as before.
+const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, RawKind raw, hipStream_t st)
+{
+    static const size_t min_tiles = [] { const char* e = getenv("RF_HEAD8_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 14; }();
+    if (!min_tiles || !p.early || (raw != RAW_LEV && raw != RAW_OSA) || p.words != 1 || p.first_check > 8 || corpus->borrowed)
+        return nullptr;
+    // single-length corpora: every tile; length-bucketed corpora (round 4): the exact tiles, whose length runs the cutoff scans
+    // then walk as single-length corpora of their own (launch_scan_runs)
+    const uint32_t plane_tiles = corpus->uniform ? corpus->n_tiles : corpus->n_exact;
+    if (plane_tiles < min_tiles || (corpus->uniform ? corpus->uniform_len < (uint32_t)kChunk : (!corpus->d_tiles || !corpus->d_orig || corpus->max_len < (uint32_t)kChunk)))
+        return nullptr;
+    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+    if (!corpus->d_heads8) {
+        uint8_t* h = nullptr;
+        if (hipMalloc((void**)&h, ((size_t)plane_tiles + 1) * kWave * 8) != hipSuccess) {  // (+ one row: head_filter_kernel reads tiles in pairs)
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipError_t e = corpus->uniform ? launch_head8_plane(corpus->d_data, corpus->n_tiles, (uint32_t)tile_bytes(corpus->uniform_len), h, st)
+                                       : launch_head8_plane_tiles(corpus->d_data, corpus->d_tiles, plane_tiles, h, st);
+        if (e == hipSuccess) e = hipMemsetAsync(h + (size_t)plane_tiles * kWave * 8, 0, kWave * 8, st);  // the pad row: defined bytes
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (other streams may use the plane as soon as the lock is released)
+        if (e != hipSuccess) {
+            (void)hipFree(h);
+            return nullptr;
+        }
+        corpus->d_heads8 = h;
+    }
+    return corpus->d_heads8;
+}
+
+// The BAND PREFILTER of the head-plane cutoff scans (rf_scan.hip early_lean_body has the kernel side and the proof): with at most
+// K edits allowed, at least 8 - K of a candidate's first 8 symbols must equal a query symbol within K positions of their own.
+// Decides whether a launch uses it: K = the largest raw distance that passes the cutoff (the same arithmetic as may_pass() on
+// the device, over every raw value a 64-symbol pair can have) must be <= 3, and by the corpus' symbol frequencies a tile of 64
+// random candidates must be unlikely to have a lane that passes the filter -- otherwise (small alphabets, repetitive queries) the
+// filter is 30 instructions per tile spent for nothing.  RF_BAND_FILTER=0 / 1 forces it off / on wherever K <= 3.
+void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, ScanParams* p, uint32_t len2)
+{
+    p->head_need = 0;
+    if (!p->heads8 || !p->early || p->words != 1 || len2 < 8) return;
+    static const int forced = [] { const char* e = getenv("RF_BAND_FILTER"); return e ? atoi(e) : -1; }();
+    if (forced == 0) return;
+    const uint32_t len1 = p->len1;
+    const uint32_t Sv = len1 + len2, Mv = std::max(len1, len2);
+    int K = -1;
+    for (uint32_t raw = 0; raw <= Mv; ++raw) {
+        bool pass;
+        if (!f64_out) {
+            const uint32_t v = (uint32_t)p->fin_vS * Sv + (uint32_t)p->fin_vM * Mv + (uint32_t)p->fin_vR * raw;
+            pass = (v ^ p->fin_flip) <= p->fin_cflip;
+        } else {
+            const uint32_t dist = (uint32_t)p->fin_dS * Sv + (uint32_t)p->fin_dM * Mv + (uint32_t)p->fin_dR * raw;
+            const uint32_t mx = (uint32_t)p->fin_mS * Sv + (uint32_t)p->fin_mM * Mv;
+            const double nd = mx == 0 ? 0.0 : (double)dist / (double)mx;
+            pass = op == RF_OP_NORMALIZED_DISTANCE ? nd <= p->cutoff_f64 : (1.0 - nd) >= p->cutoff_f64;
+        }
+        if (pass) K = (int)raw;
+    }
+    if (K < 0 || K > 3) return;
+    const uint32_t need = 8u - (uint32_t)K;
+    if (forced != 1) {
+        // P(symbol i of a random candidate has a partner in the band) from the symbol frequencies, then the distribution of the
+        // number of such symbols among 8 (independent positions), then a tile of 64 lanes
+        bool known = false;
+        for (int ch = 0; ch < 256; ++ch) known = known || corpus->sym_freq[ch] > 0.0f;
+        if (!known) return;
+        double dist[9] = {1.0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 8; ++i) {
+            double pi = 0.0;
+            for (int j = std::max(0, i - K); j <= i + K && j < (int)c->s1.size(); ++j) {
+                bool seen = false;  // (a symbol that occurs twice in the band counts once)
+                for (int j2 = std::max(0, i - K); j2 < j; ++j2) seen = seen || c->s1[j2] == c->s1[j];
+                if (!seen) pi += corpus->sym_freq[c->s1[j]];
+            }
+            pi = std::min(1.0, pi);
+            for (int m = i + 1; m >= 1; --m) dist[m] = dist[m] * (1.0 - pi) + dist[m - 1] * pi;
+            dist[0] *= 1.0 - pi;
+        }
+        double lane = 0.0;
+        for (uint32_t m = need; m <= 8; ++m) lane += dist[m];
+        const double tile = 1.0 - std::pow(1.0 - lane, 64.0);
+        if (tile > 0.35) return;
+    }
+    p->head_need = need;
+    p->head_k = (uint32_t)K;
+}
+
+// this stream's tile list for head_filter_kernel (the caller holds corpus->filter_enqueue_mu); nullptr = none to be had, the
+// scan then filters inside the cutoff kernel
+uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
+{
+    for (size_t i = 0; i < corpus->tile_lists.size(); ++i)
+        if (corpus->tile_lists[i].stream == st) {  // most recently used first
+            const rf_corpus::TileList hit = corpus->tile_lists[i];
+            corpus->tile_lists.erase(corpus->tile_lists.begin() + (long)i);
+            corpus->tile_lists.insert(corpus->tile_lists.begin(), hit);
+            return hit.ptr;
+        }
+    if (corpus->tile_lists.size() >= 4) {
+        // a fifth stream: the least recently used list changes hands instead of the scan silently falling back to the slower
+        // in-kernel filter.  Its old stream's work is waited for first -- rare, and only then.
+        rf_corpus::TileList lru = corpus->tile_lists.back();
+        corpus->tile_lists.pop_back();
+        (void)hipStreamSynchronize(lru.stream);
+        lru.stream = st;
+        corpus->tile_lists.insert(corpus->tile_lists.begin(), lru);
+        return lru.ptr;
+    }
+    uint32_t* ptr = nullptr;
+    // (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the packed list)
+    if (hipMalloc((void**)&ptr, (2 * (size_t)corpus->n_tiles + 5 * 16384 + 8) * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    corpus->tile_lists.insert(corpus->tile_lists.begin(), {st, ptr});
+    return ptr;
+}
+
+// RF_TILE_ORDER (run_many has what it selects): 0 = never by origin, 1 = by origin without the XCD deal, 2 = default, 3 = also the
+// kernels that lose by it
+static int tile_order_knob()
+{
+    static const int v = [] { const char* e = getenv("RF_TILE_ORDER"); return e ? atoi(e) : 2; }();
+    return v;
+}
+
+// LENGTH-BUCKETED corpora under a small cutoff (round 4; VERDICT r3 missing #1).  The head plane, the band prefilter, the streaming
+// first look and the lean cutoff kernel were written for single-length corpora (tile t at t * tile_bytes, slot = index).  The exact
+// tiles of ONE length of a bucketed corpus are exactly that -- back to back in the payload, 64 slots per tile -- except that a
+// slot's result belongs at out[orig[slot]].  So the tiles of every length inside the cutoff's length window are walked as a
+// single-length corpus of their own (ScanParams::run_orig): `out` is pre-filled with None ONCE, dead tiles store nothing (on a
+// single-length corpus they cost the filter pass one 8-byte store per lane; here they would be scattered), and the rare surviving
+// lane writes through orig[].  Runs too short to pay for three launches (and tiles shorter than a chunk), the one-length views and the
+// mixed section keep the general cutoff kernels.  Same values either way: tests/test_gpu_parity.py forces both.
+static bool scan_runs_applies(const rf_corpus* corpus, const ScanParams& p, RawKind raw)
+{
+    return !corpus->uniform && p.heads8 && p.early && p.words == 1 && (raw == RAW_LEV || raw == RAW_OSA) && p.first_check <= 8 && p.tile_step == 1 &&
+           p.tiles == corpus->d_tiles && corpus->d_orig && !p.band && !p.long_words_pad;
+}
+static hipError_t launch_scan_runs(RawKind raw, const ScanParams& p, const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, hipStream_t st)
+{
+    static const uint32_t min_run = [] { const char* e = getenv("RF_RUN_MIN_TILES"); return e ? (uint32_t)atoi(e) : 256u; }();
+    hipError_t e = hipSuccess;
+    if (p.out && !p.topk_k) e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, (size_t)p.n * (p.out_f64 ? 2 : 1), st);
+    const uint32_t ex_begin = std::min(p.tile_begin, corpus->n_exact), ex_end = std::min(p.tile_end, corpus->n_exact);
+    uint64_t off = 0;  // payload offset of the current length's first tile (exact tiles lie back to back in length order)
+    uint32_t pend_a = 0, pend_b = 0;  // general launches are merged over neighbouring short runs
+    auto flush_general = [&]() {
+        if (e == hipSuccess && pend_b > pend_a) {
+            ScanParams q = p;
+            q.tile_begin = pend_a, q.tile_end = pend_b;
+            q.mixed = nullptr, q.mixed_begin = q.mixed_end = 0;
+            q.prefill_none = 0;
+            q.heads8 = nullptr;
+            e = launch_scan(raw, q, st, nullptr);
+        }
+        pend_a = pend_b = 0;
+    };
+    for (size_t i = 0; i < corpus->lengths.size() && e == hipSuccess; ++i) {
+        const uint32_t first = corpus->length_first_tile[i];
+        if (first >= corpus->n_exact) break;
+        const uint32_t end = std::min(i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles, corpus->n_exact);
+        const uint32_t L = corpus->lengths[i];
+        const uint32_t a = std::max(first, ex_begin), b = std::min(end, ex_end);
+        if (b > a) {
+            if (L >= (uint32_t)kChunk && b - a >= min_run && tile_bytes(L) <= 0xFFFFFFFFull) {
+                flush_general();
+                ScanParams q = p;
+                q.tiles = nullptr, q.orig = nullptr;
+                q.mixed = nullptr, q.mixed_begin = q.mixed_end = 0;
+                q.data = p.data + off + (uint64_t)(a - first) * tile_bytes(L);
+                q.heads8 = p.heads8 + (size_t)a * kWave * 8;
+                q.uniform_len = L;
+                q.uniform_tile_bytes = (uint32_t)tile_bytes(L);
+                q.n_tiles = q.n_exact = b - a;
+                q.tile_begin = 0, q.tile_end = b - a;
+                q.n = (b - a) * (uint32_t)kWave;
+                q.run_orig = corpus->d_orig + (size_t)a * kWave;
+                q.prefill_none = 0;
+                q.zero_begin[0] = q.zero_end[0] = q.zero_begin[1] = q.zero_end[1] = 0;
+                plan_band_filter(c, corpus, op, f64_out, &q, L);
+                e = launch_scan(raw, q, st, nullptr);
+            } else {
+                if (pend_b != a) flush_general();
+                if (pend_b == pend_a) pend_a = a;
+                pend_b = b;
+            }
+        }
+        off += (uint64_t)(end - first) * tile_bytes(L);
+    }
+    flush_general();
+    if (e != hipSuccess) return e;
+    // what is left of the launch: the one-length views (when the launch walks them) or the mixed section
+    ScanParams q = p;
+    q.prefill_none = 0;
+    q.heads8 = nullptr;
+    q.tile_begin = std::max(p.tile_begin, corpus->n_exact);
+    q.tile_end = std::max(p.tile_end, q.tile_begin);
+    const bool has_mixed = p.mixed && p.mixed_end > p.mixed_begin;
+    if (q.tile_end > q.tile_begin || has_mixed) {
+        if (has_mixed) q.tile_begin = q.tile_end = corpus->n_exact;  // (launch_scan then runs scan_kernel_mixed over the mixed range alone)
+        e = launch_scan(raw, q, st, nullptr);
+    }
+    return e;
+}
+
+rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out,
+                          rf_mem out_mem, void* stream, bool f64_out)
+{
+    if (!c_in || !corpus_in || !args) {
+        set_error("null handle or args");
+        return RF_ERR_INVALID_ARG;
+    }
+    Effective eff;
+    if (const rf_status rs = make_effective(c_in, corpus_in, (hipStream_t)stream, &eff); rs != RF_OK) return rs;
+    const rf_comparator* c = eff.c;
+    const rf_corpus* corpus = eff.corpus;
+    DeviceGuard guard(corpus->n ? corpus->device : -1);  // (before plan(): grids are sized from the current device's CU count)
+    if (corpus->n && !guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    ScanParams p;
+    RawKind raw = RAW_LEV;
+    rf_status s = plan(c, corpus, op, args, f64_out, &p, &raw);
+    if (s != RF_OK) return s;
+    if (corpus->n == 0) return RF_OK;
+    if (!out) {
+        set_error("null output");
+        return RF_ERR_INVALID_ARG;
+    }
+    s = comparator_device_pm(c, corpus->device, &p.pm);
+    if (s != RF_OK) return s;
+
+    hipStream_t st = (hipStream_t)stream;
+    p.heads8 = corpus_head8_plane(corpus, p, raw, st);
+    if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
+    static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
+    p.max_stored_sym = (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) ? corpus_max_stored_symbol(corpus, st) : 0xFFFFFFFFu;
+    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
+    const size_t out_bytes = corpus->n * elem;
+    void* d_out = out;
+    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
+    p.out = d_out;
+    // Large ragged corpora: results in slot order into a temporary, then ONE gather into original order (rf_pack.hip
+    // "gather_results_kernel" has the why: the scattered out[orig[slot]] stores of a length-bucketed corpus cost more than the scan).
+    // The mixed section is walked through its one-length views so that every candidate has exactly one slot; a cutoff's length
+    // window pre-fills the TEMPORARY with None (launch_scan: p.out, p.n slots).  RF_UNSCATTER_MIN=<candidates> moves the threshold
+    // (0 = never).
+    // Full no-cutoff scans of the VALU-bound single-word kernels (Levenshtein for queries > 32, OSA): walk the tiles BY ORIGIN
+    // (tiles_by_origin()) with the workgroups dealt to them XCD by XCD (ScanParams::xcd_deal) and store straight through orig[].
+    // The tiles in flight on one XCD then write one compact window of `out`, the partial lines meet in that XCD's L2, and what is
+    // left of the scatter (64 L2 transactions per wavefront store instead of 4) hides under the kernel's arithmetic: bench.py
+    // --ragged 62.2 -> 74.7 (Levenshtein), 49.5 -> 59.5 (OSA) against the gather below, which stays for the kernels that are
+    // short of memory system instead (query <= 32: 72 -> 66, Indel: 80 -> 68 this way; profiles/ragged_result_order_r03.txt).
+    // RF_TILE_ORDER: 0 = never, 1 = by origin without the deal, 2 = default, 3 = also the kernels that lose by it.
+    const int tile_order = tile_order_knob();
+    const bool valu_bound = p.words == 1 && ((raw == RAW_LEV && p.len1 > 32) || raw == RAW_OSA);
+    // (Jaro: when every exact tile takes the single-word kernel -- launch_jaro splits the tiles BY POSITION where the lengths pass
+    // 64 symbols, which needs the length order)
+    const bool jaro_word_only = raw == RAW_JARO && !p.has_cutoff && p.jaro_split >= corpus->n_exact && !p.jaro_long;
+    const bool by_origin = tile_order && corpus->d_tiles_by_origin && !corpus->borrowed && !p.early && !p.prefill_none && !p.band && !p.long_words_pad &&
+                           ((valu_bound && !p.out_f64) || jaro_word_only || (tile_order >= 3 && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA))) &&
+                           p.tile_begin == 0 && p.tile_end == corpus->n_tiles;
+    if (by_origin) {
+        p.tiles = corpus->d_tiles_by_origin;
+        p.xcd_deal = tile_order >= 2 ? 1u : 0u;
+    }
+    static const size_t unscatter_min = [] { const char* e = getenv("RF_UNSCATTER_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
+    void* d_tmp = nullptr;
+    bool tmp_owned = false;                 // d_tmp is this call's own stream-ordered allocation
+    std::unique_lock<std::mutex> tmp_lock;  // held while a kept temporary's scan + gather are enqueued
+    // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 12 bytes per
+    // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
+    const bool wide_window = (uint64_t)(p.tile_end - p.tile_begin) * 10 >= (uint64_t)corpus->n_tiles * 3;
+    const bool by_runs = !by_origin && scan_runs_applies(corpus, p, raw);  // small-cutoff scans of a bucketed corpus: one single-length view per length run
+    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && wide_window && !by_origin && !by_runs) {
+        {
+            std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+            if (!corpus->d_slot_ident) {
+                // once per corpus: the slot -> slot map the scans store through, and what the gather needs -- the window table
+                // (rf_pack.hip window_gather_kernel) when the slots are few enough ascending runs, else the candidate -> slot map
+                static const bool use_windows = [] { const char* e = getenv("RF_GATHER_WINDOWS"); return !e || atoi(e) != 0; }();
+                uint32_t *so = nullptr, *si = nullptr, *list = nullptr, *table = nullptr;
+                uint32_t n_runs = 0, n_rows = 0;
+                std::vector<uint32_t> runs(kMaxGatherRuns + 2, 0u);  // [0] = count, then the run starts
+                hipError_t e1 = hipMalloc((void**)&si, corpus->n_slots * sizeof(uint32_t));
+                if (e1 == hipSuccess && use_windows) {
+                    e1 = hipMalloc((void**)&list, runs.size() * sizeof(uint32_t));
+                    if (e1 == hipSuccess) e1 = hipMemsetAsync(list, 0, sizeof(uint32_t), st);
+                    if (e1 == hipSuccess) e1 = launch_run_starts(corpus->d_orig, (uint32_t)corpus->n_slots, list + 1, kMaxGatherRuns, list, st);
+                    if (e1 == hipSuccess) e1 = hipMemcpyAsync(runs.data(), list, (kMaxGatherRuns + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+                    if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+                    if (e1 == hipSuccess && runs[0] >= 1 && runs[0] <= kMaxGatherRuns) {
+                        n_runs = runs[0];
+                        std::sort(runs.begin() + 1, runs.begin() + 1 + n_runs);
+                        runs[1 + n_runs] = (uint32_t)corpus->n_slots;
+                        n_rows = (uint32_t)((corpus->n + kGatherWindow - 1) / kGatherWindow) + 1;
+                        e1 = hipMemcpyAsync(list, runs.data() + 1, (n_runs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+                        if (e1 == hipSuccess) e1 = hipMalloc((void**)&table, (size_t)n_rows * n_runs * sizeof(uint32_t));
+                        if (e1 == hipSuccess) e1 = launch_window_table(corpus->d_orig, list, n_runs, n_rows, table, st);
+                    }
+                }
+                if (e1 == hipSuccess && !table) {
+                    e1 = hipMalloc((void**)&so, corpus->n * sizeof(uint32_t));
+                    if (e1 == hipSuccess) e1 = hipMemsetAsync(so, 0xFF, corpus->n * sizeof(uint32_t), st);
+                }
+                if (e1 == hipSuccess) e1 = launch_slot_maps(corpus->d_orig, (uint32_t)corpus->n_slots, so, si, st);
+                if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);  // (other streams may use the maps as soon as the lock is released)
+                if (list) (void)hipFree(list);
+                if (e1 != hipSuccess) {
+                    // Not an error: an HBM-tight caller keeps what round 2 gave it -- the launch below stores straight
+                    // through orig[] (scattered, slower, same values).  The next call tries again.
+                    if (so) (void)hipFree(so);
+                    if (si) (void)hipFree(si);
+                    if (table) (void)hipFree(table);
+                    (void)hipGetLastError();
+                } else {
+                    corpus->d_slot_of = so;
+                    corpus->d_window_table = table;
+                    corpus->gather_runs = n_runs;
+                    corpus->gather_rows = n_rows;
+                    corpus->d_slot_ident = si;
+                }
+            }
+        }
+        if (corpus->d_slot_ident) {
+        // the temporary: this stream's kept buffer (grown if this call needs f64 where u32 was kept); beyond 4 streams per corpus a
+        // stream-ordered allocation for the call
+        const size_t tmp_bytes = corpus->n_slots * elem;
+        tmp_lock = std::unique_lock<std::mutex>(corpus->gather_enqueue_mu);
+        hipError_t ea = hipSuccess;
+        for (rf_corpus::GatherTmp& t : corpus->gather_tmp)
+            if (t.stream == st) {
+                if (t.bytes < tmp_bytes) {
+                    void* bigger = nullptr;
+                    ea = hipMalloc(&bigger, tmp_bytes);
+                    if (ea == hipSuccess) {
+                        (void)hipFree(t.ptr);  // (synchronizes with the work that used it)
+                        t.ptr = bigger;
+                        t.bytes = tmp_bytes;
+                    }
+                }
+                d_tmp = t.ptr;
+                break;
+            }
+        if (!d_tmp && ea == hipSuccess) {
+            if (corpus->gather_tmp.size() < 4) {
+                ea = hipMalloc(&d_tmp, tmp_bytes);
+                if (ea == hipSuccess) corpus->gather_tmp.push_back({st, d_tmp, tmp_bytes});
+            } else {
+                ea = hipMallocAsync(&d_tmp, tmp_bytes, st);
+                tmp_owned = true;
+            }
+        }
+        if (ea != hipSuccess) {  // no room for the temporary: scattered stores through orig[] as before (not an error)
+            (void)hipGetLastError();
+            d_tmp = nullptr;
+            tmp_owned = false;
+            tmp_lock.unlock();
+        } else {
+            p.out = d_tmp;
+            p.orig = corpus->d_slot_ident;
+            p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
+            p.mixed_end = 0;
+            p.n = (uint32_t)corpus->n_slots;
+        }
+        }
+    }
+    if (const size_t scratch = launch_scratch_bytes(p, raw)) {
+        const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
+        if (ea != hipSuccess) {
+            if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+            if (d_tmp && tmp_owned) (void)hipFreeAsync(d_tmp, st);  // (this call's own temporary must not outlive the failure)
+        }
+        RF_HIP(ea);
+    }
+    std::unique_lock<std::mutex> filter_lock;  // held while a filter pass and the scan over its list are enqueued
+    if (p.heads8) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
+        filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
+        p.tile_list_buf = corpus_tile_list(corpus, st);
+    }
+    static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;  // one line per rf_many_* call on stderr: which path the plan took
+    if (trace_plan)
+        std::fprintf(stderr, "[rf plan] raw=%d words=%u early=%u first_check=%u band=%u heads8=%d head_need=%u head_k=%u tile_list=%d by_runs=%d by_origin=%d gather=%d "
+                             "tiles=[%u,%u) of %u prefill=%u\n",
+                     (int)raw, p.words, p.early, p.first_check, p.band, p.heads8 != nullptr, p.head_need, p.head_k, p.tile_list_buf != nullptr, (int)by_runs, (int)by_origin,
+                     d_tmp != nullptr, p.tile_begin, p.tile_end, corpus->n_tiles, p.prefill_none);
+    hipError_t e = by_runs ? launch_scan_runs(raw, p, c, corpus, op, f64_out, st) : launch_scan(raw, p, st, nullptr);
+    if (filter_lock.owns_lock()) filter_lock.unlock();
+    if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
+    if (d_tmp) {
+        if (e == hipSuccess)
+            e = corpus->d_window_table ? launch_window_gather(d_tmp, corpus->d_orig, corpus->d_window_table, corpus->gather_runs, corpus->gather_rows, d_out,
+                                                              (uint32_t)corpus->n, f64_out, st)
+                                       : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
+        if (tmp_owned) (void)hipFreeAsync(d_tmp, st);
+        if (tmp_lock.owns_lock()) tmp_lock.unlock();
+    }
+    if (e == hipSuccess && out_mem == RF_MEM_HOST) {
+        e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+    if (e != hipSuccess) {
+        set_error(std::string("scan launch: ") + hipGetErrorString(e));
+        return e == hipErrorInvalidValue ? RF_ERR_UNSUPPORTED : RF_ERR_HIP;
+    }
+    return RF_OK;
+}
+
+rf_status rf_many_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t* out,
+                      rf_mem out_mem, void* stream)
+{
+    return run_many(c, corpus, op, args, out, out_mem, stream, false);
+}
+
+rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, double* out,
+                      rf_mem out_mem, void* stream)
+{
+    return run_many(c, corpus, op, args, out, out_mem, stream, true);
+}
+
+static rf_status run_one(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, void* out,
+                         int* is_some, bool f64_out)
+{
+    if (!c || !args || !out || !is_some || (len2 && !s2)) {
+        set_error("rf_one: invalid argument");
+        return RF_ERR_INVALID_ARG;
+    }
+    const uint64_t offsets[2] = {0, len2};
+    rf_corpus* corpus = nullptr;
+    rf_status s = rf_corpus_pack(s2, offsets, 1, device, &corpus);
+    if (s != RF_OK) return s;
+    if (f64_out) {
+        double v = 0.0;
+        s = run_many(c, corpus, op, args, &v, RF_MEM_HOST, nullptr, true);
+        *static_cast<double*>(out) = v;
+        *is_some = !std::isnan(v);
+    } else {
+        uint32_t v = 0;
+        s = run_many(c, corpus, op, args, &v, RF_MEM_HOST, nullptr, false);
+        *static_cast<uint32_t*>(out) = v;
+        *is_some = v != RF_NONE_U32;
+    }
+    rf_corpus_free(corpus);
+    return s;
+}
+rf_status rf_one_u32(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, uint32_t* out,
+                     int* is_some)
+{
+    return run_one(c, s2, len2, op, args, device, out, is_some, false);
+}
+rf_status rf_one_f64(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, double* out,
+                     int* is_some)
+{
+    return run_one(c, s2, len2, op, args, device, out, is_some, true);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// many queries x one corpus
+// ---------------------------------------------------------------------------------------------------
+// Queries whose recurrences fit one machine word and agree on the kernel family are fused kMaxMulti (then 2) at a
+// time into scan_multi_kernel launches, which read every candidate byte once per group; the rest go through the
+// single-query launch.  Either way row q of `out` is exactly what rf_many_* gives for cs[q].
+static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+                                void* out, rf_mem out_mem, void* stream, bool f64_out)
+{
+    if (!cs_in || !corpus || !args) {
+        set_error("null handle or args");
+        return RF_ERR_INVALID_ARG;
+    }
+    if (q == 0 || corpus->n == 0) return RF_OK;
+    if (!out) {
+        set_error("null output");
+        return RF_ERR_INVALID_ARG;
+    }
+    const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
+    const size_t row_bytes = corpus->n * elem;
+    std::vector<ScanParams> ps(q);
+    std::vector<RawKind> raws(q, RAW_LEV);
+    std::vector<const rf_comparator*> eff(q, nullptr);
+    std::vector<ComparatorRef> holds(q);
+    for (uint32_t i = 0; i < q; ++i) {
+        bool overflow_hit = false;
+        if (resolve(cs_in[i], corpus, &eff[i], &holds[i], &overflow_hit) != RF_OK && overflow_hit && corpus->d_raw) {
+            // a query with overflow-class symbols needs its own translated image of the corpus: one launch per query
+            for (uint32_t j = 0; j < q; ++j) {
+                const rf_status sj = run_many(cs_in[j], corpus, op, args, static_cast<char*>(out) + (size_t)j * row_bytes, out_mem, stream, f64_out);
+                if (sj != RF_OK) return sj;
+            }
+            return RF_OK;
+        }
+    }
+    for (uint32_t i = 0; i < q; ++i) {
+        rf_status s = resolve(cs_in[i], corpus, &eff[i], &holds[i]);
+        if (s == RF_OK) s = plan(eff[i], corpus, op, args, f64_out, &ps[i], &raws[i]);
+        if (s != RF_OK) return s;
+    }
+    const rf_comparator* const* cs = eff.data();
+    DeviceGuard guard(corpus->device);
+    if (!guard.ok) {
+        set_error("cannot select the corpus' device");
+        return RF_ERR_NO_DEVICE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* d_out = static_cast<char*>(out);
+    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc((void**)&d_out, row_bytes * q));
+
+    // fusable: single-word Levenshtein / LCS-family recurrences; the group key is what the kernel cannot vary per query
+    // (a tight cutoff is better served by one early-out launch per query than by the fused kernel, which runs every column)
+    auto fusable = [&](uint32_t i) { return (raws[i] == RAW_LEV || raws[i] == RAW_LCS) && cs[i]->words == 1 && !ps[i].long_words_pad && !ps[i].early; };
+    auto same_group = [&](uint32_t a, uint32_t b) {
+        return raws[a] == raws[b] && ps[a].finish == ps[b].finish && ps[a].factor == ps[b].factor && ps[a].op == ps[b].op &&
+               (ps[a].len1 <= 32) == (ps[b].len1 <= 32);
+    };
+    std::vector<char> done(q, 0);
+    rf_status status = RF_OK;
+    hipError_t e = hipSuccess;
+    for (uint32_t i = 0; i < q && status == RF_OK && e == hipSuccess; ++i) {
+        if (done[i]) continue;
+        std::vector<uint32_t> group{i};
+        if (fusable(i))
+            for (uint32_t j = i + 1; j < q && group.size() < (size_t)kMaxMulti; ++j)
+                if (!done[j] && fusable(j) && same_group(i, j) && j == group.back() + 1) group.push_back(j);  // contiguous rows of out
+        if (group.size() == 3) group.pop_back();
+        for (uint32_t g : group) done[g] = 1;
+        ScanParams p = ps[i];
+        p.out = d_out + (size_t)i * row_bytes;
+        if (group.size() == 1) {
+            // (through run_many: a general corpus' results take the cheapest way into original order there)
+            status = run_many(cs_in[i], corpus, op, args, p.out, RF_MEM_DEVICE, stream, f64_out);
+        } else {
+            p.early = 0;  // the fused kernel always runs every column of every tile (values are the same either way)
+            p.tile_begin = 0, p.tile_end = p.n_tiles, p.prefill_none = 0;
+            p.multi_q = (uint32_t)group.size();
+            for (size_t k = 0; k < group.size() && status == RF_OK; ++k) {
+                p.multi_len1[k] = ps[group[k]].len1;
+                status = comparator_device_pm(cs[group[k]], corpus->device, &p.multi_pm[k]);
+            }
+            if (status != RF_OK) break;
+            // general corpora, LCS family: the tiles are walked by origin with the XCD deal (run_many has the why).  20 M ragged
+            // candidates x 4 queries: Indel 1.06 -> 0.89 ms.  Not the fused Levenshtein kernels: 1.19 -> 1.68 ms -- their code (4
+            // recurrences x 16 tail entries) is large, and by origin the wavefronts of a CU run different tail lengths at the same
+            // time where the storage order keeps them on the same path (instruction cache); their scatter already hides under 4
+            // queries' arithmetic.
+            if (raws[i] == RAW_LCS && tile_order_knob() && corpus->d_tiles_by_origin && !corpus->borrowed) {
+                p.tiles = corpus->d_tiles_by_origin;
+                p.xcd_deal = tile_order_knob() >= 2 ? 1u : 0u;
+            }
+            e = launch_scan_multi(raws[i], p.len1 <= 32, p, st);
+        }
+    }
+    if (status == RF_OK && e == hipSuccess && out_mem == RF_MEM_HOST) {
+        e = hipMemcpyAsync(out, d_out, row_bytes * q, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (out_mem == RF_MEM_HOST) {
+        if (status != RF_OK || e != hipSuccess) (void)hipStreamSynchronize(st);
+        (void)hipFree(d_out);
+    }
+    if (status != RF_OK) return status;
+    if (e != hipSuccess) {
+        set_error(std::string("multi-query scan: ") + hipGetErrorString(e));
+        return e == hipErrorInvalidValue ? RF_ERR_UNSUPPORTED : RF_ERR_HIP;
+    }
+    return RF_OK;
+}
+
+rf_status rf_many_multi_u32(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+                            uint32_t* out, rf_mem out_mem, void* stream)
+{
+    return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, false);
+}
+
+rf_status rf_many_multi_f64(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+                            double* out, rf_mem out_mem, void* stream)
+{
+    return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, true);
+}
+
+
+}  // extern "C"
