@@ -176,6 +176,7 @@ def main():
     sample_rows = min(n, 32_000_000)
     host_sample = None
     host_strided = None
+    in_window = 1.0
     ragged_sample = None  # (data, offsets) of the first candidates / of every 1009-th candidate
     ragged_strided = None
     mean_len = float(ln)
@@ -194,6 +195,9 @@ def main():
             flat[int(offsets[a].item()) : int(offsets[b].item())] = rows[a:b][col < lens[a:b, None]]  # row-major: candidate a's symbols, then a + 1's, ...
         del rows, col
         mean_len = float(offsets[-1].item()) / n
+        # (cutoff runs: the share of candidates whose length lies inside the cutoff's window |len2 - len1| <= cutoff -- the rest is decided by
+        # length alone and costs only its `None`)
+        in_window = float(((lens - args.query_len).abs() <= (args.cutoff if args.cutoff is not None else 1 << 30)).float().mean().item())
         h_data, h_off = flat.cpu().numpy(), offsets.cpu().numpy().astype(np.uint64)
         del flat, offsets, lens
         if rank == 0 and not args.no_cpu_baseline:
@@ -370,6 +374,11 @@ def main():
     # (Levenshtein / OSA under a cutoff <= 5 on a single-length corpus: the first look reads the 8-symbol head plane, rf_pack.hip)
     head8 = early and args.metric in ("levenshtein", "osa") and args.cutoff <= 5 and not args.ragged and args.query_len <= 64 and n >= (1 << 20) and os.environ.get("RF_HEAD8_MIN") != "0"
     bytes_per_pair = (min(ln, 8 if head8 else 16) if early else ln) / nq + out_bytes
+    if args.ragged and early and args.metric in ("levenshtein", "osa"):
+        # a length-bucketed corpus under a small cutoff: only the candidates inside the length window are looked at (their 8-symbol head from
+        # the plane when the runs are walked as single-length views, DESIGN.md 5.1 v; their first chunk row otherwise); every candidate has its result
+        views = args.cutoff <= 5 and args.query_len <= 64 and n >= (1 << 20) and os.environ.get("RF_HEAD8_MIN") != "0"
+        bytes_per_pair = in_window * (8 if views else 16) + out_bytes
     pairs_per_gpu = pairs_per_step / world
     achieved = pairs_per_gpu * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
     survey_achieved = pairs_per_gpu * survey_bpp / (kernel_ms * 1e-3) / 1e9
@@ -618,7 +627,17 @@ def extra_configs(args):
     import subprocess
 
     legs = []
+    scale = float(os.environ.get("RF_BENCH_EXTRA_SCALE", "1"))  # (tests: the same legs over 1/1000 of the candidates)
     for name, what, flags in EXTRA_LEGS:
+        if scale != 1.0:
+            flags = list(flags)
+            if "--config" in flags:
+                flags += ["--total-candidates", str(max(100_000, int(1_000_000_000 * scale))), "--plant-every", "10000"]
+            elif "--candidates" in flags:
+                i = flags.index("--candidates")
+                flags[i + 1] = str(max(5_000, int(int(flags[i + 1]) * scale)))
+            else:
+                flags += ["--candidates", str(max(100_000, int(100_000_000 * scale)))]
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.extra_steps), "--warmup", "2", "--extras", "off", "--traffic", "off",
                "--cpu-seconds", "2", "--settle-ms", "100", *flags]
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}

@@ -555,7 +555,7 @@ __device__ __forceinline__ double norm_sim_to_norm_dist(double c) { return fmin(
 //     lcs_seq                          dist = Mx - raw         maximum = Mx     (details/distance.rs:157-179)
 //     indel                            dist = S - 2*raw        maximum = S      (indel.rs:365-367)
 //     Levenshtein (f,f,>=2f)           dist = f*(S - 2*raw)    maximum = f*S    (levenshtein.rs:1321-1327)
-// so the host folds metric, weights and op into a few coefficients (rf_api.hip plan()) and the kernels do one
+// so the host folds metric, weights and op into a few coefficients (rf_api_scan.hip plan()) and the kernels do one
 // multiply-add per candidate with tile-uniform (scalar) S and Mx -- no per-tile branching on the metric.
 // All arithmetic is mod 2^32 like the reference's usize arithmetic is mod 2^64.
 struct TileFin {

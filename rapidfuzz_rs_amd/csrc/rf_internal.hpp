@@ -1,4 +1,4 @@
-// rf_internal.hpp -- shared between the host side of the C ABI (rf_api.hip) and the gfx950 kernels
+// rf_internal.hpp -- shared between the host side of the C ABI (rf_api*.hip, rf_host.hpp) and the gfx950 kernels
 // (rf_scan.hip, rf_long.hip, rf_jaro.hip, rf_pack.hip; device helpers in rf_device.hpp).  Product code: never includes or links anything from oracle/.
 #pragma once
 
@@ -65,7 +65,7 @@ struct ScanParams {
     const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w], indexed by ORIGINAL symbol
     const uint8_t* sigma;  // device uint8[256]: original symbol -> the symbol stored in the packed corpus
     const uint8_t* heads8; // small-cutoff scans: the candidates' first 8 symbols, tile t at t * 512 B (rf_pack.hip); nullptr = none
-    // A LENGTH RUN of a length-bucketed corpus seen as a single-length corpus (rf_api.hip launch_scan_runs): tiles == nullptr, data /
+    // A LENGTH RUN of a length-bucketed corpus seen as a single-length corpus (rf_api_scan.hip launch_scan_runs): tiles == nullptr, data /
     // heads8 point at the run's first tile, tile indices and idx = t * 64 + lane are relative to it, and run_orig[idx] is the
     // candidate's original index (kPad = padding lane).  `out` is pre-filled with None: dead tiles store nothing, survivors go
     // through run_orig.  nullptr everywhere else.

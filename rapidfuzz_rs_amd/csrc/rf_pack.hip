@@ -436,7 +436,7 @@ hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t ti
 }
 // the same over the EXACT tiles of a length-bucketed corpus (round 4): row t = the first 8 stored bytes of tile t's 64 lanes, whatever
 // the tile's length (a candidate shorter than 8 symbols contributes its zero padding -- the cutoff scans only take their first look
-// from the plane for runs of >= 16 symbols, rf_api.hip launch_scan_runs)
+// from the plane for runs of >= 16 symbols, rf_api_scan.hip launch_scan_runs)
 __global__ __launch_bounds__(256) void head8_plane_tiles_kernel(const uint8_t* __restrict__ data, const TileDesc* __restrict__ tiles, uint32_t n_tiles,
                                                                 uint2* __restrict__ heads)
 {

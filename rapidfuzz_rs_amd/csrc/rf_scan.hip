@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restric
 // (table[c_i] & (1 << i)) over its 8 head symbols and counts the bits.  A tile in which no lane reaches 8 - K is None as a whole
 // without running the recurrence (which is 14 instructions per column for 6 columns at cutoff 3); any other tile takes the first
 // look as before, all lanes, so no value depends on the filter.  The host switches it on per launch from the corpus' symbol
-// frequencies (plan_band_filter, rf_api.hip): on a 62-symbol alphabet 6 % of the tiles pass at K = 3.
+// frequencies (plan_band_filter, rf_api_scan.hip): on a 62-symbol alphabet 6 % of the tiles pass at K = 3.
 template <class State, int kFirst, bool kHead8 = false>
 __device__ __forceinline__ void early_lean_body(const ScanParams& p, typename State::Word* lds_pm, uint64_t (*lds_topk)[kWave], uint8_t* lds_band = nullptr)
 {
@@ -889,7 +889,7 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                     if ((p.head_need ? two_pass : look_pass) && p.tile_step == 1 && p.tile_list_buf && p.tile_end > p.tile_begin) { \
                         /* band prefilter and first look as a streaming pass of its own, then the cutoff scan over the tiles it left */ \
                         const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
-                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: rf_api.hip sizes the list buffer for that */ \
+                        const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: rf_api_scan.hip sizes the list buffer for that */ \
                         const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
                         hipLaunchKernelGGL((head_filter_kernel<State, J>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
                         hipLaunchKernelGGL(tile_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap); \

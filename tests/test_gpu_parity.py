@@ -1302,6 +1302,27 @@ def test_bench_contract_small():
     assert d["config"]["exchange_selfcheck"]["inconsistent"] == 0 and d["config"]["exchange_selfcheck"]["rank0_shard_entries_checked"] == 16
 
 
+def test_bench_extra_configs_legs():
+    """the default bench line carries `extra_configs` -- one short leg per other BASELINE config, each with its own
+    roofline and oracle parity.  Here the same code path over 1/1000 of the candidates (`RF_BENCH_EXTRA_SCALE`): five legs, none
+    failed, parity 0 everywhere, the one-line summaries repeated in `config`."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--candidates", "200000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.3", "--extras", "on",
+                        "--traffic", "off"], capture_output=True, text=True, cwd=root, env=dict(env, RF_BENCH_EXTRA_SCALE="0.001"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    legs = d["extra_configs"]
+    assert [e["name"] for e in legs] == ["c1_q32_10k_ragged", "c3_levenshtein_q256_10M", "c4_indel_100M", "c4_jaro_winkler_100M", "c5_1B_cutoff3_top16_world1"]
+    for e in legs:
+        assert "error" not in e, e
+        assert e["value"] > 0 and e["parity"]["mismatches"] == 0 and e["parity"]["checked"] > 0 and 0 < e["roofline"]["frac"], e
+        assert d["config"]["extra_" + e["name"]].startswith(str(e["value"]))
+
+
 def test_bench_two_ranks_share_one_gpu():
     """The multi-rank logic of bench.py (per-rank shards, global index bases, k-entry exchange, merge, max-over-ranks
     timing, rank 0 prints) with two processes sharing this box's one GPU and the exchange over gloo -- a test mode, not a
@@ -1631,7 +1652,7 @@ def test_corrupt_corpus_files_are_refused(tmp_path):
     a = rf.Args().to_c(False)
     st = N.lib().rf_stream_many_u32(bc._h, path.encode(), N.OP_DISTANCE, C.byref(a), out.ctypes.data, 10, 0, 0)
     assert st == N.RF_ERR_INVALID_ARG
-    # header layout (rf_api.hip FileHeader): magic 8, version 4, flags 4, n 8, n_tiles 4, max_len 4, uniform_len 4, n_lengths 4,
+    # header layout (rf_api_files.hip FileHeader): magic 8, version 4, flags 4, n 8, n_tiles 4, max_len 4, uniform_len 4, n_lengths 4,
     # payload_bytes 8, data_bytes 8, off_lengths 8, off_tiles 8, off_orig 8, off_alphabet 8, off_data 8
     n_tiles = struct.unpack_from("<I", good, 24)[0]
     off_tiles, off_orig = struct.unpack_from("<QQ", good, 64)
@@ -1897,7 +1918,7 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
 @pytest.mark.parametrize("metric", ["levenshtein", "osa", "indel"])
 def test_topk_score_hint_never_changes_the_result(metric):
     """rf_topk_u32 under a score_hint runs the scan under the cutoff `hint` first and doubles the hint until k candidates pass
-    (rf_api.hip; the reference's use of a hint, levenshtein.rs:1069-1088).  Whatever the hint -- too small, exact, far too large --
+    (rf_api_topk.hip; the reference's use of a hint, levenshtein.rs:1069-1088).  Whatever the hint -- too small, exact, far too large --
     scores and indices are those of the plain top-k: a 1.05 M single-length corpus (head plane, band prefilter) with a handful of
     near-duplicates (so that small k are settled by small hints and k = 64 never is), and a ragged one."""
     rng = np.random.default_rng(31)
@@ -2350,7 +2371,7 @@ def test_real_ranks_over_rccl_when_the_box_has_two_gpus():
 @pytest.mark.parametrize("qlen", [64, 37])
 def test_ragged_cutoff_scans_through_length_run_views(qlen):
     """VERDICT r3 missing #1: the head plane / band prefilter / streaming first look / lean cutoff kernel served single-length corpora
-    only.  A length-bucketed corpus now walks every length run inside the cutoff's window as a single-length view (rf_api.hip
+    only.  A length-bucketed corpus now walks every length run inside the cutoff's window as a single-length view (rf_api_scan.hip
     launch_scan_runs): `out` pre-filled with None, dead tiles store nothing, survivors write through orig[].  1.35 M candidates of
     EVERY length 1..70 (~290 tiles per length, > 2^14 exact tiles), ~4000 planted near-duplicates of the query whose 0..5 edits sit in
     the first 8 symbols -- substitutions, insertions and deletions at the very front (which move the candidate into the NEIGHBOURING

@@ -72,6 +72,8 @@ class Kind:
     def __init__(self, name, bits, la, bufs, state, nop_mask):
         self.name, self.bits, self.la, self.bufs, self.state, self.nop_mask = name, bits, la, bufs, list(state), nop_mask
         self.ring = len(bufs)
+        o = os.environ.get({"lev64": "RF_GEN_ORDER64", "lev32": "RF_GEN_ORDER32"}.get(name, "RF_GEN_ORDER_NONE"), "")
+        self.order = o.split() if o else None
         self.rows = [(34 + 2 * k, 35 + 2 * k) for k in range(8)] if bits == 64 else [(34 + k,) for k in range(8)]
         self.ks = 3 if bits == 64 else 2
 
@@ -119,11 +121,18 @@ class Kind:
                 "vn": [f"v_and_b32 v{VN[h]}, v{R2_[h]}, v{D0_[h]}" for h in (0, 1)],
                 "vp": [f"v_bitop3_b32 v{VP[h]}, v{R1_[h]}, v{R2_[h]}, v{D0_[h]} bitop3:0xf1" for h in (0, 1)]}[tok]  # hns | ~(hps | D0)
 
-    def column(self, i):  # one recurrence column on row slot i % 8
+    def column(self, i, gather=()):
+        """one recurrence column on row slot i % 8, and the look-ahead gather (`gather`: the lines of K.gather(i + la, ...)) where the
+        kind's token order puts it -- token "x"; behind the column by default (RF_GEN_ORDER32 / RF_GEN_ORDER64: experiment knobs)"""
         L = [f"s_waitcnt lgkmcnt({self.la - 1})"]  # `la` reads in flight, in order: column i's row has arrived
-        for j, tok in enumerate(OSA_BASE if self.name == "osa" else LEV_BASE):
+        order = self.order or ((OSA_BASE if self.name == "osa" else LEV_BASE) + ["x"])
+        base = OSA_BASE if self.name == "osa" else LEV_BASE
+        for tok in order:
+            if tok == "x":
+                L += list(gather)
+                continue
             L += self.op(tok, i)
-            if self.nop_mask >> j & 1:
+            if self.nop_mask >> base.index(tok) & 1:  # (mask bits are indexed by the canonical token list, whatever the order)
                 L.append("s_nop 0")
         return L
 
@@ -164,7 +173,7 @@ class BlockKind(Kind):
         x = f"v_lshlrev_b32_sdwa v{a}, {V_KS}, v{src} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{j % 4}"
         return [x] + [f"ds_read_b64 {pr(self.slots[j % 2][w])}, v{a}" + (f" offset:{2048 * w}" if w else "") for w in range(self.W)]
 
-    def column(self, i):
+    def column(self, i, gather=()):
         W = self.W
         A_, E_, HN_, HP_, T_ = (56, 57), (58, 59), (60, 61), (62, 63), (6, 7)
         HPC, HNC = [(8, 9), (12, 13)], [11, 3]
@@ -189,7 +198,7 @@ class BlockKind(Kind):
                 L += ops[tok]
                 if ops[tok] and self.nop_mask >> j & 1:
                     L.append("s_nop 0")
-        return L
+        return L + list(gather)
 
     def state_init(self):  # levenshtein.rs:454-455 per word; the carry pairs' high halves are zero for the whole tile
         L = []
@@ -257,8 +266,7 @@ def step(K, P, extra):
             L += wait_vm(R - 2, late, "h", sfx)  # from here on the look-ahead reads the NEXT chunk's dwords 0, 1
             L.append(f"s_mov_b32 {S_AFTER}, 0")
         L.append(f"Lc{i}_{sfx}:")
-        L += K.column(i)
-        L += K.gather(i + K.la, use, nxt)
+        L += K.column(i, K.gather(i + K.la, use, nxt))
     return L
 
 
