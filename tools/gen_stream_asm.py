@@ -73,7 +73,7 @@ class Kind:
         self.name, self.bits, self.la, self.bufs, self.state, self.nop_mask = name, bits, la, bufs, list(state), nop_mask
         self.ring = len(bufs)
         o = os.environ.get({"lev64": "RF_GEN_ORDER64", "lev32": "RF_GEN_ORDER32"}.get(name, "RF_GEN_ORDER_NONE"), "")
-        self.order = o.split() if o else None
+        self.order = o.replace(",", " ").split() if o else None
         self.rows = [(34 + 2 * k, 35 + 2 * k) for k in range(8)] if bits == 64 else [(34 + k,) for k in range(8)]
         self.ks = 3 if bits == 64 else 2
 

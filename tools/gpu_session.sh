@@ -1,3 +1,4 @@
 #!/bin/bash
 set -u
-tools/ab_many.sh lev32 2 librfgpu.so librfgpu_a32_0x80.so librfgpu_a32_0x0.so librfgpu_a32_0x100.so librfgpu_a32_0x120.so librfgpu_a32_0x1A0.so
+mkdir -p gpurun_out/r04
+tools/ab_many.sh lev32 2 librfgpu.so librfgpu_o32_1.so librfgpu_o32_2.so librfgpu_o32_3.so librfgpu_o32_4.so librfgpu_o32_5.so
