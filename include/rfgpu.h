@@ -41,6 +41,7 @@
  *   RF_UNSCATTER_MIN              1048576   fewest candidates for the slot-ordered temporary + gather pass
  *   RF_GATHER_WINDOWS             1         0: gather_results_kernel instead of the window gather
  *   RF_GATHER_SPAN / RF_GATHER_UNROLL   16384 / 8   window gather tuning
+ *   RF_TOPK_VIA_SCORES            1         top-k (k <= 64) as scan + one pass over the scores: 0 never, 1 multi-word Levenshtein, 2 every shape with an asm scan
  *   RF_TOPK_SAMPLE                1024      tiles of the in-scan top-k's bound sample (0: no sample pass)
  *   RF_JARO_PRIV                  0         1: Jaro asm kernel gathers from a conflict-free copy of the pattern table (corpora of <= 64 symbols; measured: no gain)
  *   RF_WF_REG                     1         0: LDS rows instead of register rows for generalized weights, queries <= 64

@@ -967,7 +967,10 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_sigma) (void)hipFree(c->d_sigma);
     if (c->d_raw) (void)hipFree(c->d_raw);
     if (c->d_sigma_identity) (void)hipFree(c->d_sigma_identity);
-    for (auto& kv : c->topk_scratch) (void)hipFree(kv.second.cand);
+    for (auto& kv : c->topk_scratch) {
+        (void)hipFree(kv.second.cand);
+        if (kv.second.scores) (void)hipFree(kv.second.scores);
+    }
     delete c;
 }
 
@@ -985,6 +988,7 @@ uint64_t rf_corpus_device_bytes(const rf_corpus* c)
         if (c->d_slot_ident) aux += (uint64_t)c->n_slots * sizeof(uint32_t);
         if (c->d_slot_of) aux += (uint64_t)c->n * sizeof(uint32_t);
         if (c->d_window_table) aux += (uint64_t)c->gather_rows * c->gather_runs * sizeof(uint32_t);
+        for (const auto& kv : c->topk_scratch) aux += (uint64_t)kv.second.scores_cap * sizeof(uint32_t);
     }
     {
         std::lock_guard<std::mutex> lock(c->gather_enqueue_mu);

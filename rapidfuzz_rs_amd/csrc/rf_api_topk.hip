@@ -88,6 +88,48 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
     p.out = d_all;
     std::lock_guard<std::mutex> enqueue_lock(owner->topk_enqueue_mu);
+    // Round 4: a top-k as the scan into a score vector + ONE pass over it (rf_select.hip topk_scores_kernel) -- for the shapes whose
+    // plain scan is a whole-kernel asm scan WITHOUT a fast in-scan top-k form: Levenshtein over 2..4 words (queries of 65..256 symbols),
+    // whose in-scan lists live in the compiled multi-word kernel: configs[2] corpus top-16 2.53 -> 2.74 Gpairs/s.  Single-word shapes keep
+    // their in-scan lists (sampled bound, selection inside the launch: +3 % over the plain scan; scan + pass measured +8 %, and +50 % on a
+    // 20 M ragged corpus where the pass's fixed ~0.2 ms shows: profiles/topk_via_scores_r04.txt).  The score vector is the caller's
+    // `out_all` when there is one, else a buffer kept per (corpus, stream) like the rest of the top-k scratch.
+    // RF_TOPK_VIA_SCORES: 0 = never, 1 = default, 2 = every shape with an asm scan (tests).
+    static const int via_scores = [] { const char* e = getenv("RF_TOPK_VIA_SCORES"); return e ? atoi(e) : 1; }();
+    const bool asm_scan = !p.early && !p.band && !p.long_words_pad && p.tile_step == 1 && ((raw == RAW_LEV && p.words <= 4) || (raw == RAW_OSA && p.words == 1));
+    if (asm_scan && (via_scores >= 2 || (via_scores == 1 && raw == RAW_LEV && p.words >= 2))) {
+        uint32_t* d_scores = d_all;
+        if (!d_scores) {
+            std::lock_guard<std::mutex> lock(owner->scratch_mu);
+            rf_corpus::TopkScratch& slot = owner->topk_scratch[st];
+            if (slot.scores_cap < corpus->n) {
+                if (slot.scores) (void)hipFree(slot.scores);  // (synchronizes with the work that used it)
+                slot.scores = nullptr;
+                slot.scores_cap = 0;
+                RF_HIP(hipMalloc((void**)&slot.scores, corpus->n * sizeof(uint32_t)));
+                slot.scores_cap = corpus->n;
+            }
+            d_scores = slot.scores;
+        }
+        const rf_status rs = run_many(c_in, corpus_in, op, args, d_scores, RF_MEM_DEVICE, st, false);
+        hipError_t e = rs == RF_OK ? launch_topk_scores(p, d_scores, (uint32_t)corpus->n, st) : hipSuccess;
+        if (rs == RF_OK && e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (out_all && out_all_mem == RF_MEM_HOST) (void)hipFreeAsync(d_all, st);
+        if (rs != RF_OK) return rs;
+        if (e != hipSuccess) {
+            std::lock_guard<std::mutex> lock(owner->scratch_mu);
+            (void)hipStreamSynchronize(st);
+            auto it = owner->topk_scratch.find(st);
+            if (it != owner->topk_scratch.end()) {
+                (void)hipFree(it->second.cand);
+                if (it->second.scores) (void)hipFree(it->second.scores);
+                owner->topk_scratch.erase(it);
+            }
+            set_error(std::string("top-k: ") + hipGetErrorString(e));
+            return RF_ERR_HIP;
+        }
+        return RF_OK;
+    }
     std::unique_lock<std::mutex> filter_lock;
     if (p.heads8) {
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
@@ -119,6 +161,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         std::lock_guard<std::mutex> lock(owner->scratch_mu);
         (void)hipStreamSynchronize(st);
         (void)hipFree(sc.cand);
+        if (sc.scores) (void)hipFree(sc.scores);
         owner->topk_scratch.erase(st);
         set_error(std::string("top-k: ") + hipGetErrorString(e));
         return RF_ERR_HIP;

@@ -120,6 +120,8 @@ struct rf_corpus {
         uint64_t* bound = nullptr;
         uint32_t* ctl = nullptr;
         uint32_t seg_cap = 0;
+        uint32_t* scores = nullptr;  // score vector of the scan + one-pass top-k (rf_api_topk.hip), kept like the rest; own allocation
+        size_t scores_cap = 0;       // in candidates
     };
     mutable std::mutex scratch_mu;
     mutable std::map<hipStream_t, TopkScratch> topk_scratch;

@@ -179,6 +179,7 @@ hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, 
 hipError_t launch_select_hist(const void* s, bool f64, uint32_t n, bool desc, uint64_t prefix_mask, uint64_t prefix, uint32_t shift, uint32_t bits,
                               unsigned long long* hist, hipStream_t st);
 uint32_t select_blocks(uint32_t n);
+hipError_t launch_topk_scores(const ScanParams& p, const uint32_t* scores, uint32_t n, hipStream_t st);  // rf_select.hip: top-k (k <= 64) of a u32 score vector in one pass; p: the topk_* fields
 hipError_t launch_keys_to_entries(const uint64_t* keys, uint32_t k, uint64_t index_base, rf_topk_entry* out, hipStream_t st);  // rf_select.hip
 hipError_t launch_merge_entries(const rf_topk_entry* in, uint32_t n, uint32_t k, rf_topk_entry* out, hipStream_t st);
 hipError_t launch_select_count(const void* s, bool f64, uint32_t n, bool desc, uint64_t T, uint32_t* cnt_less, uint32_t* cnt_eq, hipStream_t st);

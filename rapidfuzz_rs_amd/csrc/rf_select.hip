@@ -15,6 +15,8 @@
 //                             original candidate order, so index order is position order) -> exactly min(k, #valid) pairs
 // The k pairs are sorted by (key, index) on the host (they are going to host arrays anyway).  Every pass streams the
 // score vector once: 4 + ceil(significant bits / 11) reads of 4 or 8 bytes per candidate.
+#include <algorithm>
+
 #include "rf_device.hpp"
 
 namespace rf {
@@ -277,6 +279,75 @@ __global__ void keys_to_entries_kernel(const uint64_t* __restrict__ keys, uint32
     e.index = x == ~0ull ? ~0ull : index_base + (uint32_t)x;
     out[i] = e;
 }
+// ---------------------------------------------------------------------------------------------------
+// Top-k (k <= 64, u32 scores) as ONE streaming pass over a score vector in original candidate order (round 4).  The scans that have a
+// whole-kernel asm form (Levenshtein up to 4 words, OSA; any corpus) carry no top-k epilogue -- their per-tile code is a store -- so a
+// top-k over such a shape is that scan into a score vector + this pass: 4 bytes per candidate read once (0.08 ms per 100 M) with the
+// wavefront lists, the launch-wide bound and the in-launch selection of the scan kernels' top-k mode (rf_device.hpp WaveTopK,
+// topk_block_publish).  Replaces round 2's fixed-shape hybrid kernels (single-length corpora, lengths that are multiples of 16) and
+// the compiled scans that served every other shape in top-k mode; key = (score or ~score) << 32 | (key_index_base + index), as there.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void topk_scores_kernel(const ScanParams p, const uint32_t* __restrict__ scores, uint32_t n)
+{
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = uniform(threadIdx.x / kWave);
+    WaveTopK best;
+    best.init();
+    uint64_t limit = ~0ull, published = ~0ull;
+    // a lane takes 4 consecutive scores (one 16-byte load; rows of 1 KiB per wavefront), kRows rows in flight: a small grid -- few lists to
+    // warm up and to merge -- still keeps ~8 MB on its way
+    constexpr uint32_t kRows = 4, kPer = 4;
+    const bool vec = (reinterpret_cast<uintptr_t>(scores) & 15u) == 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kWavesPerBlock * kWave * kPer;
+    uint32_t trips = 0;
+    for (uint64_t base = ((uint64_t)blockIdx.x * kWavesPerBlock + wave) * kWave * kPer; base < n; base += kRows * stride) {
+        uint32_t v[kRows][kPer];
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const uint64_t i = base + (uint64_t)r * stride + (uint64_t)lane * kPer;
+            if (vec && i + kPer <= n) {
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v4u q = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(scores + i));
+                v[r][0] = q.x, v[r][1] = q.y, v[r][2] = q.z, v[r][3] = q.w;
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < kPer; ++j) v[r][j] = i + j < n ? scores[i + j] : RF_NONE_U32;
+            }
+        }
+        // The launch-wide bound is published and re-read every 4th trip only, and only by a wavefront whose own k-th best beats what it
+        // published before: this pass has no sampled bound to start from, so every list warms up with ~k ln(n / k) improvements, and one
+        // atomic per improvement (what the scan kernels do behind their sampled bound) was 870 k same-address atomics = 2 ms.
+        if ((trips++ & 3u) == 0) {
+            const uint64_t w = best.worst(p.topk_k);
+            if (w < published && w <= limit) {
+                if (lane == 0) asm volatile("global_atomic_umin_x2 %0, %1, off" ::"v"(p.topk_bound), "v"(w) : "memory");
+                published = w;
+            }
+            topk_refresh_bound(p, limit);
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r)
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; ++j) {
+                const uint32_t idx = (uint32_t)(base + (uint64_t)r * stride + (uint64_t)lane * kPer + j);
+                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v[r][j] : v[r][j]) << 32) | (p.key_index_base + idx);
+                if (best.offer(mine, v[r][j] != RF_NONE_U32, p.topk_k, lane, limit)) {
+                    const uint64_t w = best.worst(p.topk_k);
+                    limit = w < limit ? w : limit;
+                }
+            }
+    }
+    topk_block_publish(p, best, lds_topk, wave, lane, limit);
+}
+hipError_t launch_topk_scores(const ScanParams& p, const uint32_t* scores, uint32_t n, hipStream_t st)
+{
+    // 2 workgroups per CU (scan_max_grid = 32 per CU): 2048 lists at most; never more workgroups than there are 4 KiB stretches of scores
+    const uint32_t chunks = (n + kWave * kWavesPerBlock * 4 - 1) / (kWave * kWavesPerBlock * 4);
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(chunks, (uint32_t)std::max(1, scan_max_grid() / 16)));
+    hipLaunchKernelGGL(topk_scores_kernel, dim3(grid), dim3(kWave * kWavesPerBlock), 0, st, p, scores, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_keys_to_entries(const uint64_t* keys, uint32_t k, uint64_t index_base, rf_topk_entry* out, hipStream_t st)
 {
     hipLaunchKernelGGL(keys_to_entries_kernel, dim3((k + 63) / 64), dim3(64), 0, st, keys, k, index_base, out);

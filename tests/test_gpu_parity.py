@@ -1942,6 +1942,22 @@ def test_topk_score_hint_never_changes_the_result(metric):
                 assert np.array_equal(s0, s1) and np.array_equal(i0, i1), (metric, k, hint, s0[:4], s1[:4])
 
 
+def test_topk_as_scan_plus_one_pass_forced_for_every_asm_shape():
+    """Round 4: top-k (k <= 64) as the asm scan into a score vector + one pass over it (rf_select.hip topk_scores_kernel) is the default
+    for multi-word Levenshtein only; RF_TOPK_VIA_SCORES=2 sends every shape with an asm scan (single-word Levenshtein, 32-bit, OSA, any
+    corpus) through it: the whole top-k / sharded / multitile family of tests must hold there too."""
+    import subprocess
+    import sys
+
+    if os.environ.get("RF_TOPK_VIA_SCORES") is not None:
+        pytest.skip("already inside a forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "(topk or sharded or many_tiles) and not forced and not one_billion and not real_ranks"],
+                       capture_output=True, text=True, cwd=root, env=dict(os.environ, RF_TOPK_VIA_SCORES="2"))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("two_pass", ["1", "0"])
 def test_head_plane_and_band_filter_forced_on_small_corpora(two_pass):
     """The head plane, the band prefilter and its tile list start at 2^14 tiles; RF_HEAD8_MIN=1 RF_BAND_FILTER=1 puts every

@@ -1,4 +1,3 @@
 #!/bin/bash
 set -u
-mkdir -p gpurun_out/r04
-tools/ab_many.sh lev32 2 librfgpu.so librfgpu_o32_1.so librfgpu_o32_2.so librfgpu_o32_3.so librfgpu_o32_4.so librfgpu_o32_5.so
+timeout 2400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -n 4 -k "topk or sharded or bench_extra" 2>&1 | tail -4
