@@ -213,8 +213,9 @@ int rf_corpus_device(const rf_corpus *c);
  * corpus does not contain at all.  A corpus with overflow symbols also keeps its raw symbol stream on the device
  * (2 more bytes per symbol inside the Basic Multilingual Plane, else 4); a query that contains overflow symbols is then served from a per-call byte image
  * translated from it (query symbol -> query-local id, anything else -> 0): still exact, one extra pass over the
- * stream per call.  Refused with RF_ERR_UNSUPPORTED only: such a query with more than 255 distinct symbols, and such
- * a query on the streamed path (rf_stream_many_*, which keeps no raw stream).
+ * stream per call (rf_stream_many_* ships each segment's slice of the raw stream with it, for those queries only).
+ * Query symbols the corpus does not store share one never-matching id; refused with RF_ERR_UNSUPPORTED only: such a
+ * query with more than 254 distinct symbols that the corpus DOES store (8-bit ids cannot tell them apart).
  * rf_corpus_alphabet_size: symbols with an id of their own (256 for a byte corpus), and how many share the
  * overflow id. */
 rf_status rf_corpus_pack_u32(const uint32_t *elems, const uint64_t *offsets, size_t n, int device, rf_corpus **out);

@@ -202,25 +202,39 @@ rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hip
     e->stream = st;
     if (rs == RF_OK || !overflow_hit || !corpus->d_raw) return rs;
 
-    // query-local ids
+    // query-local ids: 1, 2, ... in order of first appearance.  When the query has at most 255 distinct symbols that numbering does
+    // not depend on the corpus and the lowered comparator is kept.  A longer alphabet is still served when the symbols this corpus
+    // STORES among them number at most 254: the ones it does not store can never match, so they share the id 255, which the
+    // translated image never contains (that lowering belongs to this corpus and is rebuilt per call).
     const size_t len = c_in->wide ? c_in->s1w.size() : c_in->s1.size();
     std::unordered_map<uint32_t, uint8_t> local;
     std::vector<uint8_t> ids(len);
-    for (size_t i = 0; i < len; ++i) {
-        const uint32_t ch = c_in->wide ? c_in->s1w[i] : (uint32_t)c_in->s1[i];
-        auto it = local.find(ch);
-        if (it == local.end()) {
-            if (local.size() >= 255) {
-                set_error("a query with more than 255 distinct symbols cannot be searched in a corpus with an overflow class");
-                return RF_ERR_UNSUPPORTED;
+    auto number = [&](bool stored_only) {
+        local.clear();
+        for (size_t i = 0; i < len; ++i) {
+            const uint32_t ch = c_in->wide ? c_in->s1w[i] : (uint32_t)c_in->s1[i];
+            if (stored_only && !corpus->alphabet.count(ch) && !corpus->overflow.count(ch)) {
+                ids[i] = 255;
+                continue;
             }
-            it = local.emplace(ch, (uint8_t)(local.size() + 1)).first;
+            auto it = local.find(ch);
+            if (it == local.end()) {
+                if (local.size() >= (stored_only ? 254u : 255u)) return false;
+                it = local.emplace(ch, (uint8_t)(local.size() + 1)).first;
+            }
+            ids[i] = it->second;
         }
-        ids[i] = it->second;
+        return true;
+    };
+    const bool portable = number(false);
+    if (!portable && !number(true)) {
+        set_error("the query has more than 254 distinct symbols that this corpus stores, and the corpus has an overflow class: "
+                  "8-bit ids cannot tell them apart");
+        return RF_ERR_UNSUPPORTED;
     }
-    {
+    if (portable) {
         std::lock_guard<std::mutex> lock(c_in->mu);
-        auto it = c_in->lowered.find(~0ull);  // the query-local lowering does not depend on the corpus
+        auto it = c_in->lowered.find(~0ull);  // this lowering does not depend on the corpus
         if (it == c_in->lowered.end()) {
             rf_comparator* low = nullptr;
             const rf_status s = rf_comparator_new(c_in->metric, ids.data(), ids.size(), &low);
@@ -229,6 +243,12 @@ rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hip
         }
         e->hold = it->second;
         e->c = e->hold.get();
+    } else {
+        rf_comparator* low = nullptr;
+        const rf_status s = rf_comparator_new(c_in->metric, ids.data(), ids.size(), &low);
+        if (s != RF_OK) return s;
+        e->hold = own_comparator(low);
+        e->c = low;
     }
     // (symbol -> id) as an open-addressing table the kernel stages in LDS
     uint32_t cap = 8;
@@ -272,6 +292,7 @@ rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hip
     rf_corpus& v = *e->image;
     v.borrowed = true;
     v.parent = corpus;
+    v.no_prefill = corpus->no_prefill;
     v.uid = corpus->uid;
     v.device = corpus->device;
     v.n = corpus->n;

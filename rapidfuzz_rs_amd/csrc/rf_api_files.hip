@@ -464,16 +464,28 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         max_tiles = std::max(max_tiles, cuts[k + 1] - cuts[k]);
     }
 
+    // A u32 query with a symbol of the file's overflow class is served from a per-segment translated image (make_effective): then the
+    // raw symbol stream of each segment travels with its payload (2 or 4 more bytes per stored symbol on the link, for those queries only).
+    const uint64_t raw_elem = (h.flags & kFlagRaw) ? ((h.flags & kFlagRaw16) ? 2 : 4) : 0;
+    bool need_raw = false;
+    if (meta.wide && raw_elem) {
+        const rf_comparator* eff = nullptr;
+        ComparatorRef hold;
+        bool hit = false;
+        need_raw = resolve(c, &meta, &eff, &hold, &hit) != RF_OK && hit;
+    }
+
     constexpr int kSlots = 3;  // buffer sets in rotation: one being read into, one on the link, one being scanned
     struct Slot {
         uint8_t *d_data = nullptr, *h_data = nullptr;
+        uint8_t *d_raw = nullptr, *h_raw = nullptr;
         TileDesc* d_tiles = nullptr;
         uint32_t* d_orig = nullptr;
         hipEvent_t uploaded = nullptr, scanned = nullptr;
         bool used = false;
     } slot[kSlots];
     hipStream_t s_copy = nullptr, s_comp = nullptr;
-    uint8_t* d_sigma = nullptr;
+    uint8_t *d_sigma = nullptr, *d_identity = nullptr;
     void* d_out = nullptr;
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     rf_status status = RF_OK;
@@ -484,6 +496,11 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     };
     bool ok = hip_ok(hipStreamCreate(&s_copy)) && hip_ok(hipStreamCreate(&s_comp)) && hip_ok(hipMalloc(&d_sigma, 256)) &&
               hip_ok(hipMemcpy(d_sigma, meta.sigma, 256, hipMemcpyHostToDevice)) && hip_ok(hipMalloc(&d_out, meta.n * elem));
+    if (ok && need_raw) {
+        uint8_t ident[256];
+        for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
+        ok = hip_ok(hipMalloc(&d_identity, 256)) && hip_ok(hipMemcpy(d_identity, ident, 256, hipMemcpyHostToDevice));
+    }
     // None everywhere first: a cutoff run skips whole tile ranges (plan()), and segment views never pre-fill
     if (ok) ok = hip_ok(hipMemsetAsync(d_out, 0xFF, meta.n * elem, s_comp));
     // The buffer sets (pinned host + device payload buffers) are KEPT between calls, per process: allocating and pinning 3 x 256 MiB
@@ -530,6 +547,8 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
             ok = hip_ok(hipMalloc(&slot[b].d_data, max_seg + kTailPad)) && hip_ok(hipHostMalloc((void**)&slot[b].h_data, max_seg + kTailPad, hipHostMallocDefault));
         }
         ok = ok && hip_ok(hipEventCreateWithFlags(&slot[b].uploaded, hipEventDisableTiming)) && hip_ok(hipEventCreateWithFlags(&slot[b].scanned, hipEventDisableTiming));
+        if (ok && need_raw)
+            ok = hip_ok(hipMalloc(&slot[b].d_raw, (max_seg + kTailPad) * raw_elem)) && hip_ok(hipHostMalloc((void**)&slot[b].h_raw, (max_seg + kTailPad) * raw_elem, hipHostMallocDefault));
         if (ok && !meta.uniform)
             ok = hip_ok(hipMalloc(&slot[b].d_tiles, (size_t)max_tiles * sizeof(TileDesc))) && hip_ok(hipMalloc(&slot[b].d_orig, (size_t)max_tiles * kWave * 4));
     }
@@ -590,6 +609,15 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         s_read += std::chrono::duration<double, std::milli>(clk::now() - t_b).count();
         std::memset(sl.h_data + bytes, 0, kTailPad);
         ok = hip_ok(hipMemcpyAsync(sl.d_data, sl.h_data, bytes + kTailPad, hipMemcpyHostToDevice, s_copy));
+        if (ok && need_raw) {
+            if (!read_parallel(fd, h.off_raw + base * raw_elem, sl.h_raw, (size_t)(bytes * raw_elem))) {
+                set_error("corpus file truncated");
+                status = RF_ERR_INVALID_ARG;
+                break;
+            }
+            std::memset(sl.h_raw + bytes * raw_elem, 0xFF, kTailPad * raw_elem);  // the raw stream's padding value
+            ok = hip_ok(hipMemcpyAsync(sl.d_raw, sl.h_raw, (bytes + kTailPad) * raw_elem, hipMemcpyHostToDevice, s_copy));
+        }
         rf_corpus seg;  // a view: owns nothing
         seg.borrowed = true;
         seg.no_prefill = true;
@@ -601,6 +629,11 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         std::memcpy(seg.sigma, meta.sigma, 256);
         seg.d_sigma = d_sigma;
         seg.d_data = sl.d_data;
+        if (need_raw) {
+            seg.d_raw = sl.d_raw;
+            seg.raw_elem = (uint32_t)raw_elem;
+            seg.d_sigma_identity = d_identity;
+        }
         seg.n_tiles = t1 - t0;
         seg.n_exact = seg.n_tiles;  // (a segment view has no mixed section of its own: mixed tiles are scanned through their views)
         seg.data_bytes = bytes + kTailPad;
@@ -667,6 +700,8 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     for (int b = 0; b < kSlots; ++b) {
         if (slot[b].d_data && !from_kept) (void)hipFree(slot[b].d_data);
         if (slot[b].h_data && !from_kept) (void)hipHostFree(slot[b].h_data);
+        if (slot[b].d_raw) (void)hipFree(slot[b].d_raw);
+        if (slot[b].h_raw) (void)hipHostFree(slot[b].h_raw);
         if (slot[b].d_tiles) (void)hipFree(slot[b].d_tiles);
         if (slot[b].d_orig) (void)hipFree(slot[b].d_orig);
         if (slot[b].uploaded) (void)hipEventDestroy(slot[b].uploaded);
@@ -678,6 +713,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         c->lowered.erase(meta.uid);
     }
     if (d_sigma) (void)hipFree(d_sigma);
+    if (d_identity) (void)hipFree(d_identity);
     if (d_out) (void)hipFree(d_out);
     if (s_copy) (void)hipStreamDestroy(s_copy);
     if (s_comp) (void)hipStreamDestroy(s_comp);

@@ -843,6 +843,58 @@ def test_u32_overflow_class_is_exact_or_refused():
         rf.distance.levenshtein.BatchComparator("hεllo").distance_many(bcorp)
 
 
+def test_u32_overflow_class_streamed_and_wide_query_alphabets(tmp_path):
+    """The two u32 holes of round 3: (1) a query with overflow-class symbols over a corpus FILE (each segment's raw symbol stream
+    travels with its payload and is translated per segment), ragged and single-length; (2) a query with more than 255 distinct
+    symbols, most of which the corpus does not store (they share one never-matching id)."""
+    import textbook as tb
+
+    rng = np.random.default_rng(23)
+    alphabet = list("abcdefghijklmnopqrstuvwxyz ") + CJK
+    w = 1.0 / np.arange(1, len(alphabet) + 1) ** 1.1
+    for uniform in (False, True):
+        cands = _rand_strings(rng, alphabet, 6000, 48, probs=w / w.sum())
+        if uniform:
+            cands = [(c + "abcdefgh" * 6)[:48] for c in cands]
+        corpus = rf.Corpus.from_list(cands)
+        own, overflow = corpus.alphabet_size()
+        assert own == 254 and overflow > 0
+        counts = {}
+        for c in cands:
+            for ch in c:
+                counts[ch] = counts.get(ch, 0) + 1
+        ranked = sorted(counts, key=lambda ch: (-counts[ch], ord(ch)))
+        frequent, rare = ranked[:254], ranked[254:]
+        q_rare = rare[0] + "".join(rng.choice(frequent, size=25)) + rare[1] + rare[0] + rare[-1] + "\U0001F642"
+        path = str(tmp_path / f"overflow{int(uniform)}.rfc")
+        corpus.save(path)
+        for metric, op, kw, ref in (("levenshtein", N.OP_DISTANCE, {}, tb.levenshtein_unit), ("indel", N.OP_DISTANCE, {}, tb.indel),
+                                    ("osa", N.OP_DISTANCE, {}, tb.osa), ("levenshtein", N.OP_DISTANCE, {"score_cutoff": 40}, None),
+                                    ("jaro_winkler", N.OP_SIMILARITY, {}, None)):
+            bc = GPU[metric].BatchComparator(q_rare)
+            resident = bc.many(op, corpus, **kw)
+            if ref is not None:
+                for i in range(0, len(cands), 37):
+                    assert int(resident[i]) == ref(rf.corpus.to_u32(q_rare), rf.corpus.to_u32(cands[i])), (metric, i)
+            for seg in (32 << 10, 0):
+                got = bc.stream_many(op, path, len(cands), segment_bytes=seg, **kw)
+                assert _equal_rows(got, resident), (uniform, metric, kw, seg)
+        # 300 distinct query symbols: 20 stored by the corpus (4 of them in the overflow class), 280 it has never seen
+        unseen = [chr(0x20000 + i) for i in range(280)]
+        q_wide = list(rng.choice(frequent, size=16)) + rare[:4] + unseen
+        rng.shuffle(q_wide)
+        q_wide = "".join(q_wide)
+        assert len(set(q_wide)) > 255
+        got = rf.distance.levenshtein.BatchComparator(q_wide).distance_many(corpus)
+        for i in range(0, len(cands), 53):
+            assert int(got[i]) == tb.levenshtein_unit(rf.corpus.to_u32(q_wide), rf.corpus.to_u32(cands[i])), i
+        streamed = rf.distance.levenshtein.BatchComparator(q_wide).stream_many(N.OP_DISTANCE, path, len(cands), segment_bytes=64 << 10)
+        assert (streamed == got).all()
+        # more than 254 STORED symbols in one query is what 8-bit ids cannot serve: refused, not approximated
+        with pytest.raises(rf.RfError):
+            rf.distance.levenshtein.BatchComparator("".join(ranked[:250] + rare[:6])).distance_many(corpus)
+
+
 # ---------------------------------------------------------------- corpus files and streamed scans (widening row f4)
 @pytest.mark.parametrize("kind", ["ragged", "uniform", "u32"])
 def test_corpus_file_roundtrip_and_streamed_scan(kind, tmp_path):
