@@ -49,6 +49,8 @@
  *   RF_NO_RENAME / RF_NO_MIXED_TILES   unset   set at PACK time: no symbol renaming / every length padded to whole tiles
  *   RF_RUN_MIN_TILES              256       fewest tiles of one length for which a small-cutoff scan of a length-bucketed corpus walks
  *                                           that length run as a single-length view (head plane, band prefilter)
+ *   RF_JOINT_MAX_TILES            16384     a length-bucketed corpus of at most this many exact tiles is scanned in ONE launch (exact and
+ *                                           mixed tiles together; the launch is the cost there); 0: always two launches
  *   RF_STREAM_KEEP                1         0: rf_stream_many_* allocates and frees its pinned / device buffer sets per call instead of keeping them
  *   RF_STREAM_THREADS             16        host threads that read a corpus file's payload (rf_stream_many_*, rf_corpus_load)
  *   RF_PACK_TIMING / RF_SELECT_DEBUG / RF_TRACE_PLAN / RF_STREAM_TIMING   unset   set: phase timings / selection statistics / one line per

@@ -40,15 +40,28 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel_mixed(const
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const bool early = State::kCanPrune && p.early != 0;
-    for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += gridDim.x * kWavesPerBlock) {
+    // JOINT launches (small corpora, launch_scan): the exact tiles [joint_begin, joint_end) come first, as tiles whose lanes all have
+    // the same length, then the mixed tiles -- one launch instead of two where the launch IS the cost.
+    const uint32_t n_joint = p.joint_end - p.joint_begin, n_virtual = n_joint + (p.tile_end - p.tile_begin);
+    for (uint32_t v = blockIdx.x * kWavesPerBlock + wave; v < n_virtual; v += gridDim.x * kWavesPerBlock) {
         // the descriptor is wavefront-uniform and read-only: scalar loads through the constant address space
         typedef const __attribute__((address_space(4))) uint32_t* cptr;
-        cptr md = (cptr)(uintptr_t)(p.mixed + t);
-        const uint64_t off = ((uint64_t)md[1] << 32) | md[0];
-        const uint32_t max_len = md[2], min_len = md[3], slot0 = md[4];
+        uint64_t off;
+        uint32_t max_len, min_len, my_len, idx;
+        if (v < n_joint) {
+            cptr td = (cptr)(uintptr_t)(p.tiles + p.joint_begin + v);
+            off = ((uint64_t)td[1] << 32) | td[0];
+            max_len = min_len = my_len = td[2];
+            idx = p.orig[td[3] + lane];
+        } else {
+            cptr md = (cptr)(uintptr_t)(p.mixed + p.tile_begin + (v - n_joint));
+            off = ((uint64_t)md[1] << 32) | md[0];
+            max_len = md[2], min_len = md[3];
+            const uint32_t slot0 = md[4];
+            my_len = p.mixed_len[slot0 + lane];
+            idx = p.mixed_orig[slot0 + lane];
+        }
         const uint4* src = reinterpret_cast<const uint4*>(p.data + off);
-        const uint32_t my_len = p.mixed_len[slot0 + lane];
-        const uint32_t idx = p.mixed_orig[slot0 + lane];
         const bool valid = idx != kPad;
 
         State st;
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void scan_kernel_mixed(const
 template <class State>
 static hipError_t launch_mixed_state(const ScanParams& p, hipStream_t stream)
 {
-    const uint32_t tiles = p.tile_end - p.tile_begin;
+    const uint32_t tiles = p.tile_end - p.tile_begin + (p.joint_end - p.joint_begin);
     const dim3 g(std::max(1, scan_grid(tiles))), b(kWave * kWavesPerBlock);
     hipLaunchKernelGGL((scan_kernel_mixed<State>), g, b, 0, stream, p);
     return hipGetLastError();
@@ -109,7 +122,7 @@ static hipError_t launch_mixed_words(const ScanParams& p, hipStream_t stream)
 // p.mixed / p.mixed_len / p.mixed_orig and [p.tile_begin, p.tile_end) describe the mixed section to scan
 hipError_t launch_scan_mixed(RawKind raw, const ScanParams& p, hipStream_t stream)
 {
-    if (p.tile_end <= p.tile_begin) return hipSuccess;
+    if (p.tile_end <= p.tile_begin && p.joint_end <= p.joint_begin) return hipSuccess;
     switch (raw) {
     case RAW_LEV: return p.len1 <= 32 ? launch_mixed_state<Lev32State>(p, stream) : launch_mixed_words<LevState>(p, stream);
     case RAW_LCS: return p.len1 <= 32 ? launch_mixed_state<Lcs32State>(p, stream) : launch_mixed_words<LcsState>(p, stream);

@@ -1003,6 +1003,19 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int
         q.mixed = nullptr;
         q.tile_end = std::min(p.tile_end, p.n_exact);
         q.tile_begin = std::min(p.tile_begin, q.tile_end);
+        // A small corpus costs two launches and the gap between them: up to RF_JOINT_MAX_TILES exact tiles the mixed kernel walks them
+        // too, as tiles whose 64 lanes share one length.  configs[0] (query 32 x 10 k candidates): 12.5 -> 6.9 us per call; 500 k
+        // candidates 18.0 -> 11.2; 1 M 30 -> 22; 2 M 38.6 -> 38.1 (beyond that the asm kernels' rate wins): profiles/joint_launch_r04.txt
+        static const uint32_t joint_max = [] { const char* e = getenv("RF_JOINT_MAX_TILES"); return e ? (uint32_t)atoi(e) : 16384u; }();
+        if (!p.prefill_none && p.tiles && p.orig && !p.run_orig && q.tile_end - q.tile_begin <= joint_max) {
+            ScanParams m = p;
+            m.joint_begin = q.tile_begin;
+            m.joint_end = q.tile_end;
+            m.tile_begin = p.mixed_begin;
+            m.tile_end = p.mixed_end;
+            if (grid_used) *grid_used = scan_grid(m.tile_end - m.tile_begin + m.joint_end - m.joint_begin);
+            return launch_scan_mixed(raw, m, stream);
+        }
         hipError_t e = hipSuccess;
         if (q.tile_end > q.tile_begin || p.prefill_none) e = launch_scan(raw, q, stream, grid_used);  // (also does the None pre-fill)
         if (e != hipSuccess) return e;
