@@ -113,14 +113,20 @@ typedef enum rf_mem { RF_MEM_HOST = 0, RF_MEM_DEVICE = 1 } rf_mem;
  *                  cutoff `hint` (a cutoff scan costs a fraction of a full one) and the k best are final if k candidates pass,
  *                  otherwise the hint doubles (past a quarter of the longest possible distance the plain scan runs)
  *
- * Two places where the device deliberately does NOT reproduce what release-mode rapidfuzz 0.5.0 returns (both tested,
- * tests/test_gpu_parity.py, both also in DESIGN.md section 3):
+ * Three places where the device deliberately does NOT reproduce what release-mode rapidfuzz 0.5.0 returns (all tested,
+ * tests/test_gpu_parity.py, all also in DESIGN.md section 3):
  *   Q7  For len1 > 64 and an explicit score_hint with 2 * max(hint, 31) < len1 - len2, the reference's hint-doubling loop
  *       (levenshtein.rs:1069-1088) calls the small-band kernel without the |len1 - len2| guard hyrroe2003_block has, and
  *       its result then DEPENDS on the hint (an upstream defect, reproduced by the oracle).  The device ignores hints and
  *       returns the exact distance -- what the reference returns for every other hint.
  *   Q2  levenshtein similarity_with_args above its cutoff evaluates `maximum - usize::MAX` (details/distance.rs:209-210:
  *       a panic in debug builds, a wrapped value in release builds).  The device returns None.
+ *   Q8  lcs_seq / indel / fuzz::ratio with a query of more than 64 symbols under a cutoff: the reference's banded multi-word LCS
+ *       (lcs_seq.rs:297-331) moves the band's last block with ceil_div(row + 1 + band_width_left, 64) and so leaves out, for one
+ *       row, the block that starts at bit row + 1 + band_width_left when that index is a multiple of 64.  A pair aligned along the
+ *       band's edge there loses a match: the reference reports a similarity below the true LCS, or None for a pair that IS within
+ *       the cutoff (an upstream defect, reproduced by the oracle: tests/golden/q8_lcs_band_pair.json).  The device walks every
+ *       block and returns the exact value -- what the reference returns without the cutoff.
  */
 typedef struct rf_args {
     uint64_t cutoff_usize;

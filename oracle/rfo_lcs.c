@@ -113,6 +113,8 @@ static size_t lcs_blockwise(const rfo_pm *pm, size_t len1, rfo_str s2, size_t sc
             s[word] = x | (s[word] - u);
         }
         if (row > band_width_right) first_block = (row - band_width_right) / word_size;
+        /* (quirk Q8: the next row needs block (row + 1 + band_width_left) / 64 + 1; the reference's ceil_div is one short when that
+           index is a multiple of 64 -- restated as it stands, tests/test_oracle_vs_textbook.py) */
         if (row + 1 + band_width_left <= len1) last_block = rfo_ceil_div(row + 1 + band_width_left, word_size);
     }
 

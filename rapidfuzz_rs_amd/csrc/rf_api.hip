@@ -1009,7 +1009,8 @@ uint64_t rf_corpus_device_bytes(const rf_corpus* c)
         if (c->d_slot_ident) aux += (uint64_t)c->n_slots * sizeof(uint32_t);
         if (c->d_slot_of) aux += (uint64_t)c->n * sizeof(uint32_t);
         if (c->d_window_table) aux += (uint64_t)c->gather_rows * c->gather_runs * sizeof(uint32_t);
-        for (const auto& kv : c->topk_scratch) aux += (uint64_t)kv.second.scores_cap * sizeof(uint32_t);
+        for (const auto& kv : c->topk_scratch)  // (candidate ways + root table + bound line + control block, and the score vector if any)
+            aux += (uint64_t)64 * kv.second.seg_cap * sizeof(uint64_t) + 64 * kWave * sizeof(uint64_t) + 128 + 65 * 128 + (uint64_t)kv.second.scores_cap * sizeof(uint32_t);
     }
     {
         std::lock_guard<std::mutex> lock(c->gather_enqueue_mu);

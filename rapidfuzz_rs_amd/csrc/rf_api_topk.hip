@@ -46,12 +46,30 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     // launch_scan_runs cannot share one call)
     p.heads8 = corpus->uniform ? corpus_head8_plane(corpus, p, raw, st) : nullptr;
     if (corpus->uniform) plan_band_filter(c, corpus, op, false, &p, corpus->uniform_len);
-    // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list
+    // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list.  At most kTopkStreams
+    // streams hold one: a further stream takes over the least recently used stream's scratch (after that stream's work has drained) --
+    // a process that makes a stream per request must not grow the corpus by 2 MB (+ 4 bytes per candidate for the score vector of
+    // the multi-word path) per stream it has ever used.  The lookup and the enqueue section are ONE critical section (a takeover
+    // between a thread's lookup and its launches would hand its scratch to another stream).
+    std::lock_guard<std::mutex> enqueue_lock(owner->topk_enqueue_mu);
+    constexpr size_t kTopkStreams = 8;
     rf_corpus::TopkScratch sc;
     {
         std::lock_guard<std::mutex> lock(owner->scratch_mu);
+        auto& lru = owner->topk_lru;  // most recently used first
         auto it = owner->topk_scratch.find(st);
-        if (it == owner->topk_scratch.end()) {
+        if (it != owner->topk_scratch.end()) {
+            sc = it->second;
+            lru.erase(std::remove(lru.begin(), lru.end(), st), lru.end());
+        } else if (owner->topk_scratch.size() >= kTopkStreams && !lru.empty()) {
+            const hipStream_t victim = lru.back();
+            lru.pop_back();
+            (void)hipStreamSynchronize(victim);  // (a stream its owner has destroyed has nothing in flight: the error is the answer)
+            (void)hipGetLastError();
+            sc = owner->topk_scratch[victim];  // bound and counters are left re-armed by every call
+            owner->topk_scratch.erase(victim);
+            owner->topk_scratch.emplace(st, sc);
+        } else {
             // [64 way segments of candidate keys | root table 64 x 64 keys | bound (u64, own line) | control block 65 x 128 B]
             const size_t ways = 64, per_way = ((size_t)scan_grid_full(corpus->n_tiles) + ways - 1) / ways;  // (the largest grid any top-k launch uses)
             sc.seg_cap = (uint32_t)(per_way * kWave);
@@ -70,9 +88,8 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
                 return RF_ERR_HIP;
             }
             owner->topk_scratch.emplace(st, sc);
-        } else {
-            sc = it->second;
         }
+        lru.insert(lru.begin(), st);
     }
     p.topk_bound = sc.bound;
     p.topk_cand = sc.cand;
@@ -87,7 +104,6 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     uint32_t* d_all = out_all;
     if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
     p.out = d_all;
-    std::lock_guard<std::mutex> enqueue_lock(owner->topk_enqueue_mu);
     // Round 4: a top-k as the scan into a score vector + ONE pass over it (rf_select.hip topk_scores_kernel) -- for the shapes whose
     // plain scan is a whole-kernel asm scan WITHOUT a fast in-scan top-k form: Levenshtein over 2..4 words (queries of 65..256 symbols),
     // whose in-scan lists live in the compiled multi-word kernel: configs[2] corpus top-16 2.53 -> 2.74 Gpairs/s.  Single-word shapes keep
@@ -124,6 +140,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
                 (void)hipFree(it->second.cand);
                 if (it->second.scores) (void)hipFree(it->second.scores);
                 owner->topk_scratch.erase(it);
+                owner->topk_lru.erase(std::remove(owner->topk_lru.begin(), owner->topk_lru.end(), st), owner->topk_lru.end());
             }
             set_error(std::string("top-k: ") + hipGetErrorString(e));
             return RF_ERR_HIP;
@@ -163,6 +180,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         (void)hipFree(sc.cand);
         if (sc.scores) (void)hipFree(sc.scores);
         owner->topk_scratch.erase(st);
+        owner->topk_lru.erase(std::remove(owner->topk_lru.begin(), owner->topk_lru.end(), st), owner->topk_lru.end());
         set_error(std::string("top-k: ") + hipGetErrorString(e));
         return RF_ERR_HIP;
     }

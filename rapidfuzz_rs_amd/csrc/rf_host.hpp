@@ -125,6 +125,7 @@ struct rf_corpus {
     };
     mutable std::mutex scratch_mu;
     mutable std::map<hipStream_t, TopkScratch> topk_scratch;
+    mutable std::vector<hipStream_t> topk_lru;  // the streams of topk_scratch, most recently used first (rf_api_topk.hip: at most 8 hold a scratch)
     // A top-k call is two launches that hand state to each other through the scratch (sample scan -> bound -> scan, each
     // selecting in its last workgroup and re-arming it).  Host threads sharing a stream must not interleave those sequences: the enqueue
     // section of topk_core() runs under this lock (kernels of one stream then execute in enqueue order).

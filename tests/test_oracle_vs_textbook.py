@@ -145,6 +145,29 @@ def test_reference_quirk_levenshtein_similarity_cutoff_sentinel():
     assert o.levenshtein.BatchComparator(b"aaaa").similarity(b"bbbb", score_cutoff=2) is None
 
 
+def test_reference_quirk_lcs_band_leaves_out_a_block():
+    """Quirk Q8 (found by tests/test_gpu_parity.py::test_randomized_differential, seed 9149; not documented upstream): lcs_blockwise
+    (lcs_seq.rs:297-331) walks an Ukkonen band of blocks [first_block, last_block) and moves its right edge with
+    `last_block = ceil_div(row + 1 + band_width_left, 64)` (:321-323).  The next row needs bit row + 1 + band_width_left, i.e. block
+    (row + 1 + band_width_left) / 64 + 1 -- the two differ when that index is a multiple of 64, and for one row the block the band
+    has just reached is left out.  A pair whose alignment runs along the band's edge at such a row loses one match: the reference
+    then reports a similarity below the true LCS, or None.  Only queries of more than 64 symbols under a cutoff tight enough for
+    `full_band_words < words` (:362-366) and loose enough for max_misses >= 5 (:469) get there.  The oracle restates the loop
+    faithfully (this test); the device returns the exact value (tests/test_gpu_known_answers.py)."""
+    import json
+    import os
+
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "q8_lcs_band_pair.json")))
+    a, b = fx["s1"].encode(), fx["s2"].encode()
+    l = tb.lcs_len(a, b)
+    assert (len(a), len(b), l) == (300, 299, fx["lcs"])
+    lb, ib = o.lcs_seq.BatchComparator(a), o.indel.BatchComparator(a)
+    assert lb.similarity(b) == l and lb.distance(b) == 3 and ib.distance(b) == 5  # no cutoff: exact
+    assert lb.distance(b, score_cutoff=3) is None      # the upstream defect, reproduced: the true distance is 3
+    assert lb.similarity(b, score_cutoff=297) is None  # likewise
+    assert lb.distance(b, score_cutoff=4) == 3 and lb.similarity(b, score_cutoff=296) == 297  # a wider band is exact again
+
+
 def test_osa_exact_and_cutoff():
     rng = np.random.default_rng(77)
     pairs = SHORT[:250] + LONG[:12]
