@@ -1223,20 +1223,19 @@ def test_concurrent_host_threads_share_corpus_and_comparators():
 
     def worker(tid):
         try:
-            stream = torch.cuda.Stream()
-            with torch.cuda.stream(stream):
-                for it in range(12):
-                    j = (tid + it) % 4
-                    got = shared[j].distance_many(corpus)
-                    assert (got == expect[j]).all()
-                    s, i = shared[j].topk(corpus, 8)
-                    assert (s == expect_topk[j][0]).all() and (i == expect_topk[j][1]).all()
-                    mine = rf.distance.levenshtein.BatchComparator(queries[j])
-                    assert (mine.distance_many(corpus, score_cutoff=30) == np.where(expect[j] <= 30, expect[j], NONE32)).all()
-                    m = rf.distance.levenshtein.BatchComparator.many_multi(shared, N.OP_DISTANCE, corpus)
-                    assert all((m[q] == expect[q]).all() for q in range(4))
-                    assert (wide.distance_many(wcorpus) == expect_wide).all()
-                    assert fresh[(tid + it) % 4].distance_many(wcorpus)[3] == 2 + (tid + it) % 4
+            st = torch.cuda.Stream().cuda_stream  # (passed explicitly: with host results the wrappers use the null stream otherwise)
+            for it in range(12):
+                j = (tid + it) % 4
+                got = shared[j].distance_many(corpus, stream=st)
+                assert (got == expect[j]).all()
+                s, i = shared[j].topk(corpus, 8, stream=st)
+                assert (s == expect_topk[j][0]).all() and (i == expect_topk[j][1]).all()
+                mine = rf.distance.levenshtein.BatchComparator(queries[j])
+                assert (mine.distance_many(corpus, stream=st, score_cutoff=30) == np.where(expect[j] <= 30, expect[j], NONE32)).all()
+                m = rf.distance.levenshtein.BatchComparator.many_multi(shared, N.OP_DISTANCE, corpus, stream=st)
+                assert all((m[q] == expect[q]).all() for q in range(4))
+                assert (wide.distance_many(wcorpus, stream=st) == expect_wide).all()
+                assert fresh[(tid + it) % 4].distance_many(wcorpus, stream=st)[3] == 2 + (tid + it) % 4
         except Exception as e:  # noqa: BLE001
             errors.append((tid, repr(e)))
 
@@ -1262,12 +1261,11 @@ def test_topk_scratch_is_bounded_over_many_streams():
     sizes = []
     for rep in range(2):
         for s in streams:
-            with torch.cuda.stream(s):
-                for q, e in ((q1, e1), (q2, e2)):
-                    got = q.topk(corpus, 9)
-                    assert (got[0] == e[0]).all() and (got[1] == e[1]).all()
+            for q, e in ((q1, e1), (q2, e2)):
+                got = q.topk(corpus, 9, stream=s.cuda_stream)
+                assert (got[0] == e[0]).all() and (got[1] == e[1]).all()
             sizes.append(corpus.device_bytes)
-    assert sizes[7] > sizes[0] and sizes[-1] == sizes[8] == sizes[7], sizes  # (the default stream's scratch was the first of the 8)
+    assert sizes[6] > sizes[0] and sizes[-1] == sizes[7] == sizes[6], sizes  # (the null stream of the expected values holds the first of the 8)
 
 
 def test_concurrent_host_threads_on_the_cached_acceleration_structures():
@@ -1311,26 +1309,26 @@ def test_concurrent_host_threads_on_the_cached_acceleration_structures():
 
     L, I, J = rf.distance.levenshtein.BatchComparator, rf.distance.indel.BatchComparator, rf.distance.jaro_winkler.BatchComparator
     jobs = [
-        ("uniform", lambda c: L(q64).distance_many(c)),
-        ("uniform", lambda c: L(q64).distance_many(c, score_cutoff=3)),
-        ("uniform", lambda c: L(q64).distance_many(c, score_cutoff=1)),
-        ("uniform", lambda c: L(q64).normalized_similarity_many(c, score_cutoff=0.9)),
-        ("uniform", lambda c: np.stack(L(q64).topk(c, 16, score_cutoff=3))),
-        ("uniform", lambda c: np.stack(L(q64).topk(c, 16))),
-        ("uniform", lambda c: np.stack(L(q128).topk(c, 8))),  # multi-word: scan into the score vector + one pass
-        ("uniform", lambda c: J(q64).similarity_many(c, score_cutoff=0.9)),
-        ("uniform", lambda c: rf.distance.osa.BatchComparator(q64).distance_many(c, score_cutoff=2)),
-        ("ragged", lambda c: L(q64).distance_many(c)),
-        ("ragged", lambda c: L(q64).distance_many(c, score_cutoff=3)),
-        ("ragged", lambda c: I(q64).distance_many(c)),
-        ("ragged", lambda c: I(q64).distance_many(c, score_cutoff=12)),
-        ("ragged", lambda c: np.stack(L(q64).topk(c, 16, score_cutoff=4))),
-        ("ragged", lambda c: J(q64).similarity_many(c)),
-        ("wide", lambda c: L(q_rare).distance_many(c)),
-        ("wide", lambda c: np.stack(L(q_rare).topk(c, 5))),
+        ("uniform", lambda c, st: L(q64).distance_many(c, stream=st)),
+        ("uniform", lambda c, st: L(q64).distance_many(c, stream=st, score_cutoff=3)),
+        ("uniform", lambda c, st: L(q64).distance_many(c, stream=st, score_cutoff=1)),
+        ("uniform", lambda c, st: L(q64).normalized_similarity_many(c, stream=st, score_cutoff=0.9)),
+        ("uniform", lambda c, st: np.stack(L(q64).topk(c, 16, stream=st, score_cutoff=3))),
+        ("uniform", lambda c, st: np.stack(L(q64).topk(c, 16, stream=st))),
+        ("uniform", lambda c, st: np.stack(L(q128).topk(c, 8, stream=st))),  # multi-word: scan into the score vector + one pass
+        ("uniform", lambda c, st: J(q64).similarity_many(c, stream=st, score_cutoff=0.9)),
+        ("uniform", lambda c, st: rf.distance.osa.BatchComparator(q64).distance_many(c, stream=st, score_cutoff=2)),
+        ("ragged", lambda c, st: L(q64).distance_many(c, stream=st)),
+        ("ragged", lambda c, st: L(q64).distance_many(c, stream=st, score_cutoff=3)),
+        ("ragged", lambda c, st: I(q64).distance_many(c, stream=st)),
+        ("ragged", lambda c, st: I(q64).distance_many(c, stream=st, score_cutoff=12)),
+        ("ragged", lambda c, st: np.stack(L(q64).topk(c, 16, stream=st, score_cutoff=4))),
+        ("ragged", lambda c, st: J(q64).similarity_many(c, stream=st)),
+        ("wide", lambda c, st: L(q_rare).distance_many(c, stream=st)),
+        ("wide", lambda c, st: np.stack(L(q_rare).topk(c, 5, stream=st))),
     ]
     ref = dict(zip(("uniform", "ragged", "wide"), pack()))
-    expect = [np.asarray(fn(ref[which])) for which, fn in jobs]
+    expect = [np.asarray(fn(ref[which], None)) for which, fn in jobs]
     del ref
     shared = dict(zip(("uniform", "ragged", "wide"), pack()))  # fresh objects: every cache is still empty
     errors = []
@@ -1339,13 +1337,13 @@ def test_concurrent_host_threads_on_the_cached_acceleration_structures():
     def worker(tid):
         try:
             order = np.random.default_rng(tid).permutation(len(jobs))
-            with torch.cuda.stream(torch.cuda.Stream()):
-                start.wait()
-                for rep in range(3):
-                    for j in order:
-                        which, fn = jobs[j]
-                        got = np.asarray(fn(shared[which]))
-                        assert _equal_rows(got, expect[j]) if got.dtype.kind == "f" else (got == expect[j]).all(), (tid, rep, int(j))
+            mine = torch.cuda.Stream()  # host results: the stream is passed explicitly (the wrappers use the null stream otherwise)
+            start.wait()
+            for rep in range(3):
+                for j in order:
+                    which, fn = jobs[j]
+                    got = np.asarray(fn(shared[which], mine.cuda_stream))
+                    assert _equal_rows(got, expect[j]) if got.dtype.kind == "f" else (got == expect[j]).all(), (tid, rep, int(j))
         except Exception as e:  # noqa: BLE001
             errors.append((tid, repr(e)))
 
