@@ -51,6 +51,8 @@
  *                                           that length run as a single-length view (head plane, band prefilter)
  *   RF_JOINT_MAX_TILES            16384     a length-bucketed corpus of at most this many exact tiles is scanned in ONE launch (exact and
  *                                           mixed tiles together; the launch is the cost there); 0: always two launches
+ *   RF_SCRATCH_CACHE_MB           1024      bound on the per-call scratch the library keeps parked between calls (its own stream-ordered
+ *                                           allocator, rf_scratch.hip); 0: every block is released as soon as the work behind it is done
  *   RF_STREAM_KEEP                1         0: rf_stream_many_* allocates and frees its pinned / device buffer sets per call instead of keeping them
  *   RF_STREAM_THREADS             16        host threads that read a corpus file's payload (rf_stream_many_*, rf_corpus_load)
  *   RF_PACK_TIMING / RF_SELECT_DEBUG / RF_TRACE_PLAN / RF_STREAM_TIMING   unset   set: phase timings / selection statistics / one line per

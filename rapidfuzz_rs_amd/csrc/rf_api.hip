@@ -277,7 +277,7 @@ rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hip
         }
     }
     const size_t table_off = (corpus->data_bytes + 15) / 16 * 16;
-    RF_HIP(hipMallocAsync((void**)&e->temp, table_off + (size_t)cap * 5, st));
+    RF_HIP(scratch_alloc((void**)&e->temp, table_off + (size_t)cap * 5, st));
     uint32_t* d_keys = reinterpret_cast<uint32_t*>(e->temp + table_off);
     uint8_t* d_vals = reinterpret_cast<uint8_t*>(d_keys + cap);
     RF_HIP(hipMemcpyAsync(d_keys, e->keys.data(), (size_t)cap * 4, hipMemcpyHostToDevice, st));
@@ -981,7 +981,10 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
     if (c->d_window_table) (void)hipFree(c->d_window_table);
     for (const rf_corpus::GatherTmp& t : c->gather_tmp) (void)hipFree(t.ptr);
-    for (const rf_corpus::TileList& t : c->tile_lists) (void)hipFree(t.ptr);
+    for (const rf_corpus::TileList& t : c->tile_lists) {
+        (void)hipFree(t.ptr);
+        (void)hipEventDestroy(t.done);
+    }
     if (c->d_mixed) (void)hipFree(c->d_mixed);
     if (c->d_mixed_len) (void)hipFree(c->d_mixed_len);
     if (c->d_mixed_orig) (void)hipFree(c->d_mixed_orig);
@@ -991,6 +994,7 @@ void rf_corpus_free(rf_corpus* c)
     for (auto& kv : c->topk_scratch) {
         (void)hipFree(kv.second.cand);
         if (kv.second.scores) (void)hipFree(kv.second.scores);
+        if (kv.second.done) (void)hipEventDestroy(kv.second.done);
     }
     delete c;
 }

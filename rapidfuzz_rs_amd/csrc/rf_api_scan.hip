@@ -499,7 +499,7 @@ uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
         // in-kernel filter.  Its old stream's work is waited for first -- rare, and only then.
         rf_corpus::TileList lru = corpus->tile_lists.back();
         corpus->tile_lists.pop_back();
-        (void)hipStreamSynchronize(lru.stream);
+        (void)hipEventSynchronize(lru.done);  // (the event, not the stream handle: that stream may no longer exist)
         lru.stream = st;
         corpus->tile_lists.insert(corpus->tile_lists.begin(), lru);
         return lru.ptr;
@@ -510,8 +510,23 @@ uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
         (void)hipGetLastError();
         return nullptr;
     }
-    corpus->tile_lists.insert(corpus->tile_lists.begin(), {st, ptr});
+    hipEvent_t done = nullptr;
+    if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(ptr);
+        return nullptr;
+    }
+    corpus->tile_lists.insert(corpus->tile_lists.begin(), {st, ptr, done});
     return ptr;
+}
+// the scan that walks this stream's list has been enqueued (the caller still holds corpus->filter_enqueue_mu)
+void corpus_tile_list_done(const rf_corpus* corpus, hipStream_t st)
+{
+    for (const rf_corpus::TileList& t : corpus->tile_lists)
+        if (t.stream == st) {
+            (void)hipEventRecord(t.done, st);
+            return;
+        }
 }
 
 // RF_TILE_ORDER (run_many has what it selects): 0 = never by origin, 1 = by origin without the XCD deal, 2 = default, 3 = also the
@@ -638,7 +653,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     const size_t out_bytes = corpus->n * elem;
     void* d_out = out;
-    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc(&d_out, out_bytes));
+    if (out_mem == RF_MEM_HOST) RF_HIP(scratch_alloc(&d_out, out_bytes, st));  // (kept by the pool: no hipMalloc / hipFree pair -- and no device-wide sync -- per call)
     p.out = d_out;
     // Large ragged corpora: results in slot order into a temporary, then ONE gather into original order (rf_pack.hip
     // "gather_results_kernel" has the why: the scattered out[orig[slot]] stores of a length-bucketed corpus cost more than the scan).
@@ -747,7 +762,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                 ea = hipMalloc(&d_tmp, tmp_bytes);
                 if (ea == hipSuccess) corpus->gather_tmp.push_back({st, d_tmp, tmp_bytes});
             } else {
-                ea = hipMallocAsync(&d_tmp, tmp_bytes, st);
+                ea = scratch_alloc(&d_tmp, tmp_bytes, st);
                 tmp_owned = true;
             }
         }
@@ -766,10 +781,10 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
         }
     }
     if (const size_t scratch = launch_scratch_bytes(p, raw)) {
-        const hipError_t ea = hipMallocAsync((void**)&p.long_scratch, scratch, st);
+        const hipError_t ea = scratch_alloc((void**)&p.long_scratch, scratch, st);
         if (ea != hipSuccess) {
-            if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
-            if (d_tmp && tmp_owned) (void)hipFreeAsync(d_tmp, st);  // (this call's own temporary must not outlive the failure)
+            if (out_mem == RF_MEM_HOST) scratch_free(d_out, st);
+            if (d_tmp && tmp_owned) (void)scratch_free(d_tmp, st);  // (this call's own temporary must not outlive the failure)
         }
         RF_HIP(ea);
     }
@@ -785,21 +800,24 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                      (int)raw, p.words, p.early, p.first_check, p.band, p.heads8 != nullptr, p.head_need, p.head_k, p.tile_list_buf != nullptr, (int)by_runs, (int)by_origin,
                      d_tmp != nullptr, p.tile_begin, p.tile_end, corpus->n_tiles, p.prefill_none);
     hipError_t e = by_runs ? launch_scan_runs(raw, p, c, corpus, op, f64_out, st) : launch_scan(raw, p, st, nullptr);
-    if (filter_lock.owns_lock()) filter_lock.unlock();
-    if (p.long_scratch) (void)hipFreeAsync(p.long_scratch, st);
+    if (filter_lock.owns_lock()) {
+        if (p.tile_list_buf) corpus_tile_list_done(corpus, st);
+        filter_lock.unlock();
+    }
+    if (p.long_scratch) (void)scratch_free(p.long_scratch, st);
     if (d_tmp) {
         if (e == hipSuccess)
             e = corpus->d_window_table ? launch_window_gather(d_tmp, corpus->d_orig, corpus->d_window_table, corpus->gather_runs, corpus->gather_rows, d_out,
                                                               (uint32_t)corpus->n, f64_out, st)
                                        : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
-        if (tmp_owned) (void)hipFreeAsync(d_tmp, st);
+        if (tmp_owned) (void)scratch_free(d_tmp, st);
         if (tmp_lock.owns_lock()) tmp_lock.unlock();
     }
     if (e == hipSuccess && out_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    if (out_mem == RF_MEM_HOST) (void)hipFree(d_out);
+    if (out_mem == RF_MEM_HOST) scratch_free(d_out, st);
     if (e != hipSuccess) {
         set_error(std::string("scan launch: ") + hipGetErrorString(e));
         return e == hipErrorInvalidValue ? RF_ERR_UNSUPPORTED : RF_ERR_HIP;
@@ -903,7 +921,7 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
     }
     hipStream_t st = (hipStream_t)stream;
     char* d_out = static_cast<char*>(out);
-    if (out_mem == RF_MEM_HOST) RF_HIP(hipMalloc((void**)&d_out, row_bytes * q));
+    if (out_mem == RF_MEM_HOST) RF_HIP(scratch_alloc((void**)&d_out, row_bytes * q, st));
 
     // fusable: single-word Levenshtein / LCS-family recurrences; the group key is what the kernel cannot vary per query
     // (a tight cutoff is better served by one early-out launch per query than by the fused kernel, which runs every column)
@@ -955,7 +973,7 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
     }
     if (out_mem == RF_MEM_HOST) {
         if (status != RF_OK || e != hipSuccess) (void)hipStreamSynchronize(st);
-        (void)hipFree(d_out);
+        scratch_free(d_out, st);
     }
     if (status != RF_OK) return status;
     if (e != hipSuccess) {

@@ -64,9 +64,8 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         } else if (owner->topk_scratch.size() >= kTopkStreams && !lru.empty()) {
             const hipStream_t victim = lru.back();
             lru.pop_back();
-            (void)hipStreamSynchronize(victim);  // (a stream its owner has destroyed has nothing in flight: the error is the answer)
-            (void)hipGetLastError();
             sc = owner->topk_scratch[victim];  // bound and counters are left re-armed by every call
+            (void)hipEventSynchronize(sc.done);  // (the event behind its last call -- not the stream handle, whose stream may be gone)
             owner->topk_scratch.erase(victim);
             owner->topk_scratch.emplace(st, sc);
         } else {
@@ -82,6 +81,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
             sc.ctl = reinterpret_cast<uint32_t*>(mem + cand_bytes + root_bytes + 128);
             hipError_t e0 = hipMemsetAsync(sc.bound, 0xFF, sizeof(uint64_t), st);
             if (e0 == hipSuccess) e0 = hipMemsetAsync(sc.ctl, 0, ctl_bytes, st);
+            if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&sc.done, hipEventDisableTiming);
             if (e0 != hipSuccess) {
                 (void)hipFree(mem);
                 set_error(std::string("top-k scratch: ") + hipGetErrorString(e0));
@@ -102,7 +102,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     p.key_index_base = key_index_base;
     // optionally also emit every candidate's score from the same pass (they stay sharded)
     uint32_t* d_all = out_all;
-    if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(hipMallocAsync((void**)&d_all, corpus->n * sizeof(uint32_t), st));
+    if (out_all && out_all_mem == RF_MEM_HOST) RF_HIP(scratch_alloc((void**)&d_all, corpus->n * sizeof(uint32_t), st));
     p.out = d_all;
     // Round 4: a top-k as the scan into a score vector + ONE pass over it (rf_select.hip topk_scores_kernel) -- for the shapes whose
     // plain scan is a whole-kernel asm scan WITHOUT a fast in-scan top-k form: Levenshtein over 2..4 words (queries of 65..256 symbols),
@@ -130,7 +130,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         const rf_status rs = run_many(c_in, corpus_in, op, args, d_scores, RF_MEM_DEVICE, st, false);
         hipError_t e = rs == RF_OK ? launch_topk_scores(p, d_scores, (uint32_t)corpus->n, st) : hipSuccess;
         if (rs == RF_OK && e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        if (out_all && out_all_mem == RF_MEM_HOST) (void)hipFreeAsync(d_all, st);
+        if (out_all && out_all_mem == RF_MEM_HOST) (void)scratch_free(d_all, st);
         if (rs != RF_OK) return rs;
         if (e != hipSuccess) {
             std::lock_guard<std::mutex> lock(owner->scratch_mu);
@@ -139,12 +139,14 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
             if (it != owner->topk_scratch.end()) {
                 (void)hipFree(it->second.cand);
                 if (it->second.scores) (void)hipFree(it->second.scores);
+                if (it->second.done) (void)hipEventDestroy(it->second.done);
                 owner->topk_scratch.erase(it);
                 owner->topk_lru.erase(std::remove(owner->topk_lru.begin(), owner->topk_lru.end(), st), owner->topk_lru.end());
             }
             set_error(std::string("top-k: ") + hipGetErrorString(e));
             return RF_ERR_HIP;
         }
+        (void)hipEventRecord(sc.done, st);
         return RF_OK;
     }
     std::unique_lock<std::mutex> filter_lock;
@@ -171,7 +173,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     if (e == hipSuccess) e = launch_scan(raw, p, st, nullptr);
     if (e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) {
         e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        (void)hipFreeAsync(d_all, st);
+        (void)scratch_free(d_all, st);
     }
     if (e != hipSuccess) {
         // the scratch may be left half-armed: drop it so the next call starts from a fresh one
@@ -179,11 +181,14 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         (void)hipStreamSynchronize(st);
         (void)hipFree(sc.cand);
         if (sc.scores) (void)hipFree(sc.scores);
+        if (sc.done) (void)hipEventDestroy(sc.done);
         owner->topk_scratch.erase(st);
         owner->topk_lru.erase(std::remove(owner->topk_lru.begin(), owner->topk_lru.end(), st), owner->topk_lru.end());
         set_error(std::string("top-k: ") + hipGetErrorString(e));
         return RF_ERR_HIP;
     }
+    (void)hipEventRecord(sc.done, st);  // what a later take-over of this scratch / tile list waits for
+    if (p.tile_list_buf) corpus_tile_list_done(corpus, st);
     return RF_OK;
 }
 
@@ -197,11 +202,11 @@ static rf_status select_topk(const void* d_scores, bool f64, bool desc, uint32_t
     const uint32_t nb = select_blocks(n);
     uint8_t* mem = nullptr;
     const size_t hist_bytes = 2048 * sizeof(unsigned long long), cnt_bytes = (size_t)nb * sizeof(uint32_t);
-    RF_HIP(hipMallocAsync((void**)&mem, 64 + hist_bytes + 2 * cnt_bytes, st));
+    RF_HIP(scratch_alloc((void**)&mem, 64 + hist_bytes + 2 * cnt_bytes, st));
     struct Free {
         uint8_t* p;
         hipStream_t st;
-        ~Free() { (void)hipFreeAsync(p, st); }
+        ~Free() { (void)scratch_free(p, st); }
     } free_mem{mem, st};
     unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(mem + 64);
     uint32_t* d_less = reinterpret_cast<uint32_t*>(mem + 64 + hist_bytes);
@@ -258,7 +263,7 @@ static rf_status select_topk(const void* d_scores, bool f64, bool desc, uint32_t
     const uint32_t need_eq = (uint32_t)(kk - n_less);
     uint8_t* out = nullptr;
     const size_t key_bytes = f64 ? 8 : 4;
-    RF_HIP(hipMallocAsync((void**)&out, kk * (key_bytes + 4), st));
+    RF_HIP(scratch_alloc((void**)&out, kk * (key_bytes + 4), st));
     Free free_out{out, st};
     uint32_t* d_idx = reinterpret_cast<uint32_t*>(out + kk * key_bytes);
     RF_HIP(launch_select_count(d_scores, f64, n, desc, T, d_less, d_eq, st));
@@ -287,7 +292,7 @@ static rf_status topk_by_selection(const rf_comparator* c, const rf_corpus* corp
     *desc = op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY;
     void* d_scores = out_all;
     const bool temp = !(out_all && out_all_mem == RF_MEM_DEVICE);
-    if (temp) RF_HIP(hipMallocAsync(&d_scores, corpus->n * elem, st));
+    if (temp) RF_HIP(scratch_alloc(&d_scores, corpus->n * elem, st));
     rf_status s = run_many(c, corpus, op, args, d_scores, RF_MEM_DEVICE, st, f64);
     if (s == RF_OK) s = select_topk(d_scores, f64, *desc, (uint32_t)corpus->n, k, st, keys, idx);
     if (s == RF_OK && out_all && out_all_mem == RF_MEM_HOST) {
@@ -295,7 +300,7 @@ static rf_status topk_by_selection(const rf_comparator* c, const rf_corpus* corp
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) s = RF_ERR_HIP;
     }
-    if (temp) (void)hipFreeAsync(d_scores, st);
+    if (temp) (void)scratch_free(d_scores, st);
     return s;
 }
 
@@ -372,7 +377,7 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     }
     hipStream_t st = (hipStream_t)stream;
     uint64_t* d_best = nullptr;
-    RF_HIP(hipMallocAsync((void**)&d_best, (size_t)kWave * sizeof(uint64_t), st));
+    RF_HIP(scratch_alloc((void**)&d_best, (size_t)kWave * sizeof(uint64_t), st));
     bool desc = false;
     std::vector<uint64_t> best(kWave, ~0ull);
     hipError_t e = hipSuccess;
@@ -407,7 +412,7 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
         e = hipSuccess;
         if (s == RF_OK) e = hipMemcpyAsync(best.data(), d_best, k * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
     }
-    (void)hipFreeAsync(d_best, st);
+    (void)scratch_free(d_best, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (s == RF_ERR_UNSUPPORTED && (op == RF_OP_DISTANCE || op == RF_OP_SIMILARITY)) {
         // shapes the in-scan lists do not cover (queries beyond 512 symbols, general weight tables): score everything, select
@@ -561,16 +566,16 @@ rf_status rf_topk_entries_device(const rf_comparator* c, const rf_corpus* corpus
     if (!f64 && k <= (uint64_t)kWave) {
         // the in-scan lists: keys with the LOCAL index, widened on the device -- nothing synchronizes
         uint64_t* d_keys = nullptr;
-        RF_HIP(hipMallocAsync((void**)&d_keys, (size_t)kWave * sizeof(uint64_t), st));
+        RF_HIP(scratch_alloc((void**)&d_keys, (size_t)kWave * sizeof(uint64_t), st));
         bool desc = false;
         const rf_status s = topk_core(c, corpus, op, args, (uint32_t)k, 0, d_keys, nullptr, RF_MEM_HOST, st, &desc);
         if (s == RF_OK) {
             const hipError_t e = launch_keys_to_entries(d_keys, (uint32_t)k, index_base, d_entries_out, st);
-            (void)hipFreeAsync(d_keys, st);
+            (void)scratch_free(d_keys, st);
             RF_HIP(e);
             return RF_OK;
         }
-        (void)hipFreeAsync(d_keys, st);
+        (void)scratch_free(d_keys, st);
         if (s != RF_ERR_UNSUPPORTED) return s;  // (long queries, general weight tables: the selection path below)
     }
     std::vector<uint64_t> keys;

@@ -120,6 +120,7 @@ struct rf_corpus {
         uint64_t* bound = nullptr;
         uint32_t* ctl = nullptr;
         uint32_t seg_cap = 0;
+        hipEvent_t done = nullptr;   // recorded behind the last call's launches on this scratch (what a take-over waits for)
         uint32_t* scores = nullptr;  // score vector of the scan + one-pass top-k (rf_api_topk.hip), kept like the rest; own allocation
         size_t scores_cap = 0;       // in candidates
     };
@@ -146,6 +147,8 @@ struct rf_corpus {
     struct TileList {
         hipStream_t stream;
         uint32_t* ptr;
+        hipEvent_t done;  // recorded behind the last scan that walked the list (corpus_tile_list_done): a take-over waits for THIS, never
+                          // for the stream handle -- its owner may have destroyed the stream long ago, and the runtime crashes on a dead handle
     };
     mutable std::vector<TileList> tile_lists;
     mutable std::mutex filter_enqueue_mu;
@@ -177,6 +180,7 @@ using ComparatorRef = std::shared_ptr<rf_comparator>;
 // per-call byte image of the corpus translated from its raw symbol stream (translate_kernel: query symbol -> its id,
 // anything else -> 0).  The image is a borrowed view (same tiles / slot map) that lives until the object goes out of
 // scope; its payload is released in stream order.
+extern "C" __attribute__((visibility("hidden"))) void scratch_free(void* p, hipStream_t st);  // rf_scratch.hip
 struct Effective {
     const rf_comparator* c = nullptr;
     ComparatorRef hold;  // keeps a lowered comparator alive for the duration of the call
@@ -188,7 +192,7 @@ struct Effective {
     std::vector<uint8_t> vals;
     ~Effective()
     {
-        if (temp) (void)hipFreeAsync(temp, stream);
+        if (temp) scratch_free(temp, stream);
     }
 };
 constexpr size_t kTailPad = (size_t)kWave * kChunk;  // one readable chunk row past the last tile
@@ -207,6 +211,11 @@ static inline uint64_t tile_bytes(uint32_t len) { return (uint64_t)((len + kChun
 // (hidden: these are internal to librfgpu.so -- only the rf_* entry points of include/rfgpu.h are exported)
 #define RF_LOCAL __attribute__((visibility("hidden")))
 extern "C" {
+// the library's stream-ordered scratch allocator (rf_scratch.hip: why it is not hipMallocAsync).  scratch_free parks the block behind
+// everything enqueued on `st` so far; neither call ever waits.
+RF_LOCAL hipError_t scratch_alloc(void** out, size_t bytes, hipStream_t st);
+RF_LOCAL void scratch_free(void* p, hipStream_t st);
+RF_LOCAL void scratch_trim(void);
 RF_LOCAL void symbol_frequencies(const uint64_t* hist, float* freq);                                                      // rf_api.hip
 RF_LOCAL rf_status resolve(const rf_comparator* c, const rf_corpus* corpus, const rf_comparator** eff, ComparatorRef* hold, bool* overflow_hit = nullptr);  // rf_api.hip
 RF_LOCAL rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hipStream_t st, Effective* e);     // rf_api.hip
@@ -217,6 +226,7 @@ RF_LOCAL std::vector<TileDesc> tiles_by_origin(const std::vector<TileDesc>& tile
 RF_LOCAL rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, bool f64_out, ScanParams* p, RawKind* raw);  // rf_api_scan.hip
 RF_LOCAL const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, RawKind raw, hipStream_t st);    // rf_api_scan.hip
 RF_LOCAL void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, ScanParams* p, uint32_t len2);  // rf_api_scan.hip
+RF_LOCAL void corpus_tile_list_done(const rf_corpus* corpus, hipStream_t st);                                           // rf_api_scan.hip
 RF_LOCAL uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st);                                             // rf_api_scan.hip
 RF_LOCAL rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out, rf_mem out_mem, void* stream, bool f64_out);  // rf_api_scan.hip
 }  // extern "C"

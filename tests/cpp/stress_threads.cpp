@@ -1,0 +1,277 @@
+// Host-thread stress driver over the C ABI (include/rfgpu.h), meant for a ThreadSanitizer build of the library
+// (tools/build_tsan.sh): eight host threads, each on its own HIP stream, run a shuffled mix of every call that fills one of the
+// per-corpus caches lazily -- head plane, band-filter tile lists, length-run views, gather temporaries, top-k scratch and score
+// vectors, translated images of u32 corpora, lowered comparators -- on three SHARED corpora whose caches are still empty when the
+// threads start.  Every result is compared with the same call made single-threaded on separate corpus objects beforehand.
+// Exit code 0 = all results equal (TSan's own reports go to stderr and its exit code).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "rfgpu.h"
+
+#define CHECK(x)                                                                      \
+    do {                                                                              \
+        rf_status s_ = (x);                                                           \
+        if (s_ != RF_OK) {                                                            \
+            fprintf(stderr, "%s:%d %s -> %d (%s)\n", __FILE__, __LINE__, #x, (int)s_, rf_last_error()); \
+            exit(2);                                                                  \
+        }                                                                             \
+    } while (0)
+
+static const char kAlnum[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789";
+
+struct Corpora {
+    rf_corpus *uniform = nullptr, *ragged = nullptr, *wide = nullptr;
+};
+
+struct Data {
+    std::vector<uint8_t> rows, flat;
+    std::vector<uint64_t> row_off, flat_off, wide_off;
+    std::vector<uint32_t> wide;
+    std::vector<uint8_t> q64, q128;
+    std::vector<uint32_t> q_rare;
+};
+
+static void make_data(Data& d)
+{
+    std::mt19937_64 rng(12345);
+    const size_t n1 = 1100000, len = 64;
+    d.q64.resize(64);
+    for (auto& b : d.q64) b = (uint8_t)kAlnum[rng() % 62];
+    d.q128.resize(128);
+    for (auto& b : d.q128) b = (uint8_t)kAlnum[rng() % 62];
+    d.rows.resize(n1 * len);
+    for (auto& b : d.rows) b = (uint8_t)kAlnum[rng() % 62];
+    for (size_t i = 450; i < n1; i += 900) {  // near-duplicates of the query: something for cutoffs and top-k to find
+        memcpy(&d.rows[i * len], d.q64.data(), len);
+        for (unsigned e = 0; e < rng() % 5; ++e) d.rows[i * len + rng() % len] = '#';
+    }
+    d.row_off.resize(n1 + 1);
+    for (size_t i = 0; i <= n1; ++i) d.row_off[i] = i * len;
+    const size_t n2 = 2000000;
+    d.flat_off.assign(1, 0);
+    for (size_t i = 0; i < n2; ++i) {
+        const size_t l = 57 + rng() % 8;
+        const size_t at = d.flat.size();
+        d.flat.resize(at + l);
+        if (i % 997 == 0 && l == 64) {
+            memcpy(&d.flat[at], d.q64.data(), 64);
+            d.flat[at + rng() % 8] = '~';
+        } else {
+            for (size_t j = 0; j < l; ++j) d.flat[at + j] = (uint8_t)kAlnum[rng() % 62];
+        }
+        d.flat_off.push_back(d.flat.size());
+    }
+    // u32 candidates over ~600 symbols with a long tail: more than 254 distinct symbols -> an overflow class
+    d.wide_off.assign(1, 0);
+    std::vector<uint32_t> count(700, 0);
+    for (size_t i = 0; i < 3000; ++i) {
+        const size_t l = rng() % 41;
+        for (size_t j = 0; j < l; ++j) {
+            const double u = (double)(rng() % 1000000) / 1e6;
+            const uint32_t sym = (uint32_t)(600.0 * u * u * u);  // skewed towards small ids
+            d.wide.push_back(0x4E00 + sym);
+            count[sym]++;
+        }
+        d.wide_off.push_back(d.wide.size());
+    }
+    uint32_t rare = 599;
+    while (rare > 0 && count[rare] == 0) --rare;  // a symbol that occurs, and rarely: overflow class
+    for (int i = 0; i < 20; ++i) d.q_rare.push_back(0x4E00 + (uint32_t)i);
+    d.q_rare.push_back(0x4E00 + rare);
+    d.q_rare.insert(d.q_rare.begin(), 0x4E00 + rare);
+}
+
+static Corpora pack(const Data& d)
+{
+    Corpora c;
+    CHECK(rf_corpus_pack(d.rows.data(), d.row_off.data(), d.row_off.size() - 1, 0, &c.uniform));
+    CHECK(rf_corpus_pack(d.flat.data(), d.flat_off.data(), d.flat_off.size() - 1, 0, &c.ragged));
+    CHECK(rf_corpus_pack_u32(d.wide.data(), d.wide_off.data(), d.wide_off.size() - 1, 0, &c.wide));
+    return c;
+}
+
+using Result = std::vector<uint64_t>;  // raw 8-byte words of whatever the call returned
+using Job = std::function<Result(const Corpora&, void*)>;
+
+static rf_args cutoff_u(uint64_t c)
+{
+    rf_args a;
+    rf_args_default(&a);
+    a.cutoff_usize = c;
+    return a;
+}
+static rf_args cutoff_f(double c)
+{
+    rf_args a;
+    rf_args_default(&a);
+    a.cutoff_f64 = c;
+    return a;
+}
+
+static Result many_u32(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, rf_op op, const rf_args& a, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    std::vector<uint32_t> out(rf_corpus_count(corpus) + 1, 0);
+    CHECK(rf_many_u32(c, corpus, op, &a, out.data(), RF_MEM_HOST, st));
+    rf_comparator_free(c);
+    Result r((out.size() + 1) / 2, 0);
+    memcpy(r.data(), out.data(), out.size() * 4);
+    return r;
+}
+static Result many_f64(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, rf_op op, const rf_args& a, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    std::vector<double> out(rf_corpus_count(corpus));
+    CHECK(rf_many_f64(c, corpus, op, &a, out.data(), RF_MEM_HOST, st));
+    rf_comparator_free(c);
+    Result r(out.size());
+    memcpy(r.data(), out.data(), out.size() * 8);
+    return r;
+}
+static Result topk_u32(rf_comparator* c, const rf_corpus* corpus, const rf_args& a, uint32_t k, void* st)
+{
+    std::vector<uint32_t> score(k);
+    std::vector<uint64_t> index(k);
+    uint32_t cnt = 0;
+    CHECK(rf_topk_u32(c, corpus, RF_OP_DISTANCE, &a, k, 0, score.data(), index.data(), &cnt, nullptr, RF_MEM_HOST, st));
+    Result r;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        r.push_back(score[i]);
+        r.push_back(index[i]);
+    }
+    return r;
+}
+static Result topk_bytes(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, const rf_args& a, uint32_t k, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    Result r = topk_u32(c, corpus, a, k, st);
+    rf_comparator_free(c);
+    return r;
+}
+
+int main(int argc, char** argv)
+{
+    bool warm = false, noreuse = false;
+    std::vector<size_t> only;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "warm")) warm = true;        // experiment: fill every cache single-threaded first
+        if (!strcmp(argv[i], "noreuse")) noreuse = true;  // experiment: no cross-stream reuse in the default memory pool
+        if (!strncmp(argv[i], "jobs=", 5)) {                // only these jobs (comma-separated indices)
+            for (const char* q = argv[i] + 5; *q;) {
+                only.push_back((size_t)strtoul(q, (char**)&q, 10));
+                if (*q == ',') ++q;
+            }
+        }
+    }
+    if (rf_device_count() < 1) {
+        printf("no device: nothing to stress\n");
+        return 0;
+    }
+    Data d;
+    make_data(d);
+    rf_args none;
+    rf_args_default(&none);
+    rf_comparator* shared_rare = nullptr;  // ONE u32 comparator shared by every thread: its lowered forms are cached inside it
+    CHECK(rf_comparator_new_u32(RF_LEVENSHTEIN, d.q_rare.data(), d.q_rare.size(), &shared_rare));
+    std::vector<Job> jobs = {
+        [&](const Corpora& c, void* st) { return many_u32(RF_LEVENSHTEIN, d.q64, c.uniform, RF_OP_DISTANCE, none, st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_LEVENSHTEIN, d.q64, c.uniform, RF_OP_DISTANCE, cutoff_u(3), st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_LEVENSHTEIN, d.q64, c.uniform, RF_OP_DISTANCE, cutoff_u(1), st); },
+        [&](const Corpora& c, void* st) { return many_f64(RF_LEVENSHTEIN, d.q64, c.uniform, RF_OP_NORMALIZED_SIMILARITY, cutoff_f(0.9), st); },
+        [&](const Corpora& c, void* st) { return topk_bytes(RF_LEVENSHTEIN, d.q64, c.uniform, cutoff_u(3), 16, st); },
+        [&](const Corpora& c, void* st) { return topk_bytes(RF_LEVENSHTEIN, d.q64, c.uniform, none, 16, st); },
+        [&](const Corpora& c, void* st) { return topk_bytes(RF_LEVENSHTEIN, d.q128, c.uniform, none, 8, st); },
+        [&](const Corpora& c, void* st) { return many_f64(RF_JARO_WINKLER, d.q64, c.uniform, RF_OP_SIMILARITY, cutoff_f(0.9), st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_OSA, d.q64, c.uniform, RF_OP_DISTANCE, cutoff_u(2), st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_LEVENSHTEIN, d.q64, c.ragged, RF_OP_DISTANCE, none, st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_LEVENSHTEIN, d.q64, c.ragged, RF_OP_DISTANCE, cutoff_u(3), st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_INDEL, d.q64, c.ragged, RF_OP_DISTANCE, none, st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_INDEL, d.q64, c.ragged, RF_OP_DISTANCE, cutoff_u(12), st); },
+        [&](const Corpora& c, void* st) { return topk_bytes(RF_LEVENSHTEIN, d.q64, c.ragged, cutoff_u(4), 16, st); },
+        [&](const Corpora& c, void* st) { return many_f64(RF_JARO_WINKLER, d.q64, c.ragged, RF_OP_SIMILARITY, none, st); },
+        [&](const Corpora& c, void* st) {
+            std::vector<uint32_t> out(rf_corpus_count(c.wide) + 1, 0);
+            CHECK(rf_many_u32(shared_rare, c.wide, RF_OP_DISTANCE, &none, out.data(), RF_MEM_HOST, st));
+            Result r((out.size() + 1) / 2, 0);
+            memcpy(r.data(), out.data(), out.size() * 4);
+            return r;
+        },
+        [&](const Corpora& c, void* st) { return topk_u32(shared_rare, c.wide, none, 5, st); },
+    };
+    std::vector<Result> expect;
+    {
+        Corpora ref = pack(d);
+        for (auto& j : jobs) expect.push_back(j(ref, nullptr));
+        rf_corpus_free(ref.uniform);
+        rf_corpus_free(ref.ragged);
+        rf_corpus_free(ref.wide);
+    }
+    Corpora shared = pack(d);  // fresh objects: every cache is still empty
+    if (noreuse) {
+        hipMemPool_t pool;
+        int off = 0;
+        if (hipDeviceGetDefaultMemPool(&pool, 0) == hipSuccess) {
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowOpportunistic, &off);
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseAllowInternalDependencies, &off);
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolReuseFollowEventDependencies, &off);
+        }
+    }
+    if (warm)
+        for (auto& j : jobs) (void)j(shared, nullptr);
+    std::atomic<int> bad{0}, ready{0};
+    const int kThreads = 8;
+    std::vector<std::thread> threads;
+    for (int t = 0; t < kThreads; ++t)
+        threads.emplace_back([&, t] {
+            hipStream_t st = nullptr;
+            if (hipSetDevice(0) != hipSuccess || hipStreamCreate(&st) != hipSuccess) {
+                bad++;
+                return;
+            }
+            std::vector<size_t> order;
+            for (size_t i = 0; i < jobs.size(); ++i)
+                if (only.empty() || std::find(only.begin(), only.end(), i) != only.end()) order.push_back(i);
+            std::mt19937 rng(t);
+            ready++;
+            while (ready.load() < kThreads) std::this_thread::yield();
+            for (int rep = 0; rep < (only.empty() ? 3 : 12); ++rep) {
+                std::shuffle(order.begin(), order.end(), rng);
+                for (size_t j : order) {
+                    const Result got = jobs[j](shared, st);
+                    if (got != expect[j]) {
+                        size_t at = 0, differing = 0;
+                        for (size_t i = 0; i < std::min(got.size(), expect[j].size()); ++i)
+                            if (got[i] != expect[j][i]) {
+                                if (!differing) at = i;
+                                ++differing;
+                            }
+                        fprintf(stderr, "thread %d rep %d job %zu: result differs (%zu vs %zu words, %zu differ, first at %zu: %016llx vs %016llx)\n", t, rep, j,
+                                got.size(), expect[j].size(), differing, at, at < got.size() ? (unsigned long long)got[at] : 0ull,
+                                at < expect[j].size() ? (unsigned long long)expect[j][at] : 0ull);
+                        bad++;
+                    }
+                }
+            }
+            (void)hipStreamDestroy(st);
+        });
+    for (auto& th : threads) th.join();
+    rf_comparator_free(shared_rare);
+    rf_corpus_free(shared.uniform);
+    rf_corpus_free(shared.ragged);
+    rf_corpus_free(shared.wide);
+    printf("stress_threads: %d threads x 3 x %zu jobs, %d mismatches\n", kThreads, jobs.size(), bad.load());
+    return bad.load() ? 1 : 0;
+}

@@ -102,6 +102,16 @@ def test_randomized_long_queries_near_duplicates_tight_cutoffs(seed):
                 cutoffs = [qlen - int(c) for c in rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 12, 20], size=2, replace=False)]
             for c in cutoffs:
                 _check_many(metric, q.tobytes(), data, offsets, op, score_cutoff=c)
+    # Jaro / Jaro-Winkler: cutoffs that ARE some candidate's value, and the doubles next to it on either side -- the `>=` of
+    # every filter and of the final compare (jaro.rs:533-598, jaro_winkler.rs:125-138) has to fall the same way, bit for bit
+    for metric in ("jaro", "jaro_winkler"):
+        pw = {"prefix_weight": float(rng.choice([0.1, 0.25]))} if metric == "jaro_winkler" and rng.random() < 0.5 else {}
+        for op in ("similarity", "distance", "normalized_similarity", "normalized_distance"):
+            uncut = ORA[metric].BatchComparator(q.tobytes()).many(OPS[op], data, offsets, nthreads=8, **pw)
+            for v in rng.choice(uncut, size=2, replace=False):
+                for c in (float(v), float(np.nextafter(v, 2.0)), float(np.nextafter(v, -1.0))):
+                    if 0.0 <= c <= 1.0:
+                        _check_many(metric, q.tobytes(), data, offsets, op, score_cutoff=c, **pw)
 
 
 def test_reference_quirk_q8_pair_is_exact_on_the_device(golden_dir):
