@@ -30,15 +30,18 @@
 static const char kAlnum[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789";
 
 struct Corpora {
-    rf_corpus *uniform = nullptr, *ragged = nullptr, *wide = nullptr;
+    rf_corpus *uniform = nullptr, *ragged = nullptr, *wide = nullptr, *small = nullptr;
 };
 
 struct Data {
     std::vector<uint8_t> rows, flat;
     std::vector<uint64_t> row_off, flat_off, wide_off;
     std::vector<uint32_t> wide;
-    std::vector<uint8_t> q64, q128;
+    std::vector<uint8_t> q64, q128, q600;
     std::vector<uint32_t> q_rare;
+    std::vector<uint8_t> small;  // 20 000 candidates of 0..700 symbols for the heavy kernels (long patterns, general weights, Jaro blocks)
+    std::vector<uint64_t> small_off;
+    std::vector<std::vector<uint8_t>> q4;  // four short queries for the fused multi-query kernel
 };
 
 static void make_data(Data& d)
@@ -49,6 +52,18 @@ static void make_data(Data& d)
     for (auto& b : d.q64) b = (uint8_t)kAlnum[rng() % 62];
     d.q128.resize(128);
     for (auto& b : d.q128) b = (uint8_t)kAlnum[rng() % 62];
+    d.q600.resize(600);
+    for (auto& b : d.q600) b = (uint8_t)kAlnum[rng() % 4];
+    for (int i = 0; i < 4; ++i) {
+        d.q4.emplace_back(20 + 11 * i);
+        for (auto& b : d.q4.back()) b = (uint8_t)kAlnum[rng() % 62];
+    }
+    d.small_off.assign(1, 0);
+    for (size_t i = 0; i < 20000; ++i) {
+        const size_t l = i % 50 == 0 ? 500 + rng() % 200 : rng() % 100;
+        for (size_t j = 0; j < l; ++j) d.small.push_back(i % 50 == 0 && j < 600 && rng() % 20 ? d.q600[j] : (uint8_t)kAlnum[rng() % 4]);
+        d.small_off.push_back(d.small.size());
+    }
     d.rows.resize(n1 * len);
     for (auto& b : d.rows) b = (uint8_t)kAlnum[rng() % 62];
     for (size_t i = 450; i < n1; i += 900) {  // near-duplicates of the query: something for cutoffs and top-k to find
@@ -97,6 +112,7 @@ static Corpora pack(const Data& d)
     CHECK(rf_corpus_pack(d.rows.data(), d.row_off.data(), d.row_off.size() - 1, 0, &c.uniform));
     CHECK(rf_corpus_pack(d.flat.data(), d.flat_off.data(), d.flat_off.size() - 1, 0, &c.ragged));
     CHECK(rf_corpus_pack_u32(d.wide.data(), d.wide_off.data(), d.wide_off.size() - 1, 0, &c.wide));
+    CHECK(rf_corpus_pack(d.small.data(), d.small_off.data(), d.small_off.size() - 1, 0, &c.small));
     return c;
 }
 
@@ -162,6 +178,38 @@ static Result topk_bytes(rf_metric m, const std::vector<uint8_t>& q, const rf_co
     return r;
 }
 
+static Result topk_f64(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, rf_op op, const rf_args& a, uint64_t k, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    std::vector<double> score(k);
+    std::vector<uint64_t> index(k);
+    uint64_t cnt = 0;
+    CHECK(rf_topk_f64(c, corpus, op, &a, k, 0, score.data(), index.data(), &cnt, nullptr, RF_MEM_HOST, st));
+    rf_comparator_free(c);
+    Result r;
+    for (uint64_t i = 0; i < cnt; ++i) {
+        uint64_t bits;
+        memcpy(&bits, &score[i], 8);
+        r.push_back(bits);
+        r.push_back(index[i]);
+    }
+    return r;
+}
+static Result entries(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, rf_op op, const rf_args& a, uint64_t k, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    rf_topk_entry* d = nullptr;
+    if (hipMalloc((void**)&d, k * sizeof(rf_topk_entry)) != hipSuccess) exit(3);
+    CHECK(rf_topk_entries_device(c, corpus, op, &a, k, 1000, d, st));
+    Result r(2 * k);
+    if (hipMemcpyAsync(r.data(), d, k * sizeof(rf_topk_entry), hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess || hipStreamSynchronize((hipStream_t)st) != hipSuccess) exit(3);
+    (void)hipFree(d);
+    rf_comparator_free(c);
+    return r;
+}
+
 int main(int argc, char** argv)
 {
     bool warm = false, noreuse = false;
@@ -210,14 +258,70 @@ int main(int argc, char** argv)
             return r;
         },
         [&](const Corpora& c, void* st) { return topk_u32(shared_rare, c.wide, none, 5, st); },
+        // 17: four queries fused into one pass
+        [&](const Corpora& c, void* st) {
+            rf_comparator* cs[4];
+            for (int i = 0; i < 4; ++i) CHECK(rf_comparator_new(RF_INDEL, d.q4[i].data(), d.q4[i].size(), &cs[i]));
+            const size_t n = rf_corpus_count(c.uniform);
+            std::vector<uint32_t> out(4 * n);
+            CHECK(rf_many_multi_u32(cs, 4, c.uniform, RF_OP_DISTANCE, &none, out.data(), RF_MEM_HOST, st));
+            for (int i = 0; i < 4; ++i) rf_comparator_free(cs[i]);
+            Result r(2 * n);
+            memcpy(r.data(), out.data(), out.size() * 4);
+            return r;
+        },
+        // 18, 19: the selection path (f64 scores; k beyond the in-scan lists)
+        [&](const Corpora& c, void* st) { return topk_f64(RF_JARO_WINKLER, d.q64, c.ragged, RF_OP_SIMILARITY, none, 10, st); },
+        [&](const Corpora& c, void* st) { return topk_f64(RF_LEVENSHTEIN, d.q64, c.uniform, RF_OP_NORMALIZED_DISTANCE, none, 100, st); },
+        // 20: 16-byte entries on the device
+        [&](const Corpora& c, void* st) { return entries(RF_INDEL, d.q64, c.ragged, RF_OP_NORMALIZED_SIMILARITY, none, 70, st); },
+        // 21..25: the kernels with per-launch scratch -- general weights (rows in registers / LDS / global), long patterns, the band
+        // kernel, multi-word and long Jaro
+        [&](const Corpora& c, void* st) {
+            rf_args a = none;
+            a.insertion_cost = 1, a.deletion_cost = 2, a.substitution_cost = 3;
+            return many_u32(RF_LEVENSHTEIN, d.q64, c.small, RF_OP_DISTANCE, a, st);
+        },
+        [&](const Corpora& c, void* st) {
+            rf_args a = none;
+            a.insertion_cost = 2, a.deletion_cost = 1, a.substitution_cost = 2;
+            return many_u32(RF_LEVENSHTEIN, d.q600, c.small, RF_OP_DISTANCE, a, st);
+        },
+        [&](const Corpora& c, void* st) { return many_u32(RF_LEVENSHTEIN, d.q600, c.small, RF_OP_DISTANCE, none, st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_LEVENSHTEIN, d.q600, c.small, RF_OP_DISTANCE, cutoff_u(20), st); },
+        [&](const Corpora& c, void* st) { return many_f64(RF_JARO_WINKLER, d.q600, c.small, RF_OP_SIMILARITY, none, st); },
+        [&](const Corpora& c, void* st) { return many_u32(RF_OSA, d.q600, c.small, RF_OP_DISTANCE, none, st); },
+        // 27: the per-candidate method (a one-candidate corpus per call)
+        [&](const Corpora&, void*) {
+            rf_comparator* cc = nullptr;
+            CHECK(rf_comparator_new(RF_LEVENSHTEIN, d.q64.data(), d.q64.size(), &cc));
+            uint32_t v = 0;
+            int some = 0;
+            CHECK(rf_one_u32(cc, d.q128.data(), d.q128.size(), RF_OP_DISTANCE, &none, 0, &v, &some));
+            rf_comparator_free(cc);
+            return Result{v, (uint64_t)some};
+        },
+        // 28: a streamed scan of the ragged corpus' file (kept buffer sets: one scan at a time uses them, the others bring their own)
+        [&](const Corpora& c, void*) {
+            rf_comparator* cc = nullptr;
+            CHECK(rf_comparator_new(RF_LEVENSHTEIN, d.q64.data(), d.q64.size(), &cc));
+            std::vector<uint32_t> out(rf_corpus_count(c.ragged) + 1, 0);
+            CHECK(rf_stream_many_u32(cc, "/tmp/rf_stress_ragged.rfc", RF_OP_DISTANCE, &none, out.data(), out.size(), 32u << 20, 0));
+            rf_comparator_free(cc);
+            Result r((out.size() + 1) / 2, 0);
+            memcpy(r.data(), out.data(), out.size() * 4);
+            return r;
+        },
     };
     std::vector<Result> expect;
     {
         Corpora ref = pack(d);
+        CHECK(rf_corpus_save(ref.ragged, "/tmp/rf_stress_ragged.rfc"));
         for (auto& j : jobs) expect.push_back(j(ref, nullptr));
         rf_corpus_free(ref.uniform);
         rf_corpus_free(ref.ragged);
         rf_corpus_free(ref.wide);
+        rf_corpus_free(ref.small);
     }
     Corpora shared = pack(d);  // fresh objects: every cache is still empty
     if (noreuse) {
@@ -272,6 +376,8 @@ int main(int argc, char** argv)
     rf_corpus_free(shared.uniform);
     rf_corpus_free(shared.ragged);
     rf_corpus_free(shared.wide);
+    rf_corpus_free(shared.small);
+    remove("/tmp/rf_stress_ragged.rfc");
     printf("stress_threads: %d threads x 3 x %zu jobs, %d mismatches\n", kThreads, jobs.size(), bad.load());
     return bad.load() ? 1 : 0;
 }
