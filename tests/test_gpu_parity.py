@@ -1278,6 +1278,42 @@ def test_topk_scratch_is_bounded_over_many_streams():
     assert sizes[6] > sizes[0] and sizes[-1] == sizes[7] == sizes[6], sizes  # (the null stream of the expected values holds the first of the 8)
 
 
+def test_scratch_allocator_keeps_a_bounded_cache():
+    """rf_scratch.hip parks per-call scratch between calls, at most RF_SCRATCH_CACHE_MB (default 1024) of it: host-result calls over
+    an 8 M-candidate corpus (32 MB of u32 / 64 MB of f64 results each, + selection scratch) on 24 streams may not cost more device
+    memory than that bound (+ what the corpus itself caches per stream), and a tighter bound in a child process holds too."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if os.environ.get("RF_TEST_SCRATCH_CHILD") is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                            "test_scratch_allocator_keeps_a_bounded_cache"], capture_output=True, text=True, cwd=root,
+                           env=dict(os.environ, RF_TEST_SCRATCH_CHILD="1", RF_SCRATCH_CACHE_MB="64"))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+    bound = int(os.environ.get("RF_SCRATCH_CACHE_MB", "1024")) << 20
+    rows = synth.rows_host(8_000_000, 16, seed=71)
+    corpus = rf.Corpus.from_rows(rows)
+    lv, jw = rf.distance.levenshtein.BatchComparator(synth.query(16, 72)), rf.distance.jaro_winkler.BatchComparator(synth.query(16, 73))
+    ref_d, ref_s = lv.distance_many(corpus), jw.similarity_many(corpus)
+    ref_k = jw.topk(corpus, 100)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    streams = [torch.cuda.Stream() for _ in range(24)]
+    for rep in range(2):
+        for s in streams:
+            assert (lv.distance_many(corpus, stream=s.cuda_stream) == ref_d).all()
+            assert _equal_rows(jw.similarity_many(corpus, stream=s.cuda_stream), ref_s)
+            got = jw.topk(corpus, 100, stream=s.cuda_stream)
+            assert (got[0] == ref_k[0]).all() and (got[1] == ref_k[1]).all()
+    torch.cuda.synchronize()
+    grown = free0 - torch.cuda.mem_get_info()[0]
+    # (one f64 result vector may be parked above the bound until the next call sweeps it; the runtime rounds its own pools up)
+    assert grown <= bound + (64 << 20) + (96 << 20), (grown >> 20, bound >> 20)
+
+
 def test_concurrent_host_threads_on_the_cached_acceleration_structures():
     """plan() + run_many and the per-corpus caches they fill lazily (head plane, band-filter tile lists per stream
     (an LRU), length-run views, gather temporaries per stream, top-k scratch and score vectors, per-call translated images of u32
