@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="after the headline's timed region, run one short leg (own process, --extra-steps steps, own roofline + oracle parity) for "
                          "each OTHER BASELINE.json config and report them as `extra_configs`.  auto = on for the default workload at N = 1")
-    ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each extra_configs leg (the launch-bound configs[0] leg runs 25 x as many)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "on", "off"],
                     help="on: roofline.traffic from two short rocprofv3 --pmc passes of this command run after the timed region (when rocprofv3 is on the "
                          "box; N = 1), else the committed counters of profiles/traffic.json marked as such; off: only the committed file; auto: on for "
@@ -640,7 +640,8 @@ def extra_configs(args):
                 flags[i + 1] = str(max(5_000, int(int(flags[i + 1]) * scale)))
             else:
                 flags += ["--candidates", str(max(100_000, int(100_000_000 * scale)))]
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.extra_steps), "--warmup", "2", "--extras", "off", "--traffic", "off",
+        steps = args.extra_steps * (25 if name.startswith("c1_") else 1)  # (7 us steps: a handful of them measures the clock ramp, not the call)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "5", "--extras", "off", "--traffic", "off",
                "--cpu-seconds", "2", "--settle-ms", "100", *flags]
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env["MASTER_PORT"] = "29577"
