@@ -65,7 +65,7 @@ void rf_args_default(rf_args* a)
 // comparator
 // ---------------------------------------------------------------------------------------------------
 rf_status rf_comparator_new(rf_metric metric, const uint8_t* s1, size_t len1, rf_comparator** out)
-{
+try {
     if (!out || (len1 && !s1) || (int)metric < 0 || (int)metric > (int)RF_OSA) {
         set_error("rf_comparator_new: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -87,12 +87,13 @@ rf_status rf_comparator_new(rf_metric metric, const uint8_t* s1, size_t len1, rf
     *out = c;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 // BatchComparator::new over `char` (or any u32) elements.  The reference hashes non-ASCII symbols into its
 // pattern-match table (pattern_match_vector.rs:5-65, :228-260); here the table is built per corpus, in terms of that
 // corpus' symbol ids, the first time the comparator meets it (resolve()).
 rf_status rf_comparator_new_u32(rf_metric metric, const uint32_t* s1, size_t len1, rf_comparator** out)
-{
+try {
     if (!out || (len1 && !s1) || (int)metric < 0 || (int)metric > (int)RF_OSA) {
         set_error("rf_comparator_new_u32: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -107,13 +108,15 @@ rf_status rf_comparator_new_u32(rf_metric metric, const uint32_t* s1, size_t len
     *out = c;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_comparator_clone(const rf_comparator* c, rf_comparator** out)
-{
+try {
     if (!c || !out) return RF_ERR_INVALID_ARG;
     if (c->wide) return rf_comparator_new_u32(c->metric, c->s1w.data(), c->s1w.size(), out);
     return rf_comparator_new(c->metric, c->s1.data(), c->s1.size(), out);
 }
+RF_ABI_CATCH
 
 void rf_comparator_free(rf_comparator* c)
 {
@@ -610,7 +613,7 @@ static rf_status build_layout(const uint8_t* bytes, const uint64_t* offsets, siz
 }
 
 rf_status rf_corpus_layout_host(const uint8_t* bytes, const uint64_t* offsets, size_t n, rf_host_layout* out)
-{
+try {
     if (!out) return RF_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof(*out));
     HostLayout L;
@@ -641,6 +644,7 @@ rf_status rf_corpus_layout_host(const uint8_t* bytes, const uint64_t* offsets, s
     std::memcpy(out->sigma, L.sigma, 256);
     return RF_OK;
 }
+RF_ABI_CATCH
 
 void rf_host_layout_free(rf_host_layout* l)
 {
@@ -739,7 +743,7 @@ static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, r
 }
 
 rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n, int device, rf_corpus** out)
-{
+try {
     if (!out) {
         set_error("rf_corpus_pack: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -749,6 +753,7 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
     if (s != RF_OK) return s;
     return corpus_from_layout(L, n, device, out);
 }
+RF_ABI_CATCH
 
 // Candidates over `char` (or any u32) elements.  The corpus gets its own alphabet: the 254 most frequent symbols
 // become byte ids 0..253 (frequency order, so the LDS rows the kernels touch most sit in distinct banks), every rarer
@@ -756,7 +761,7 @@ rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n
 // query that contains no overflow symbol (resolve()): candidate symbols outside the query only ever need to be
 // "not equal", and the lumped ones still are.
 rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, size_t n, int device, rf_corpus** out)
-{
+try {
     if (!out || (n && !offsets)) {
         set_error("rf_corpus_pack_u32: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -900,10 +905,11 @@ rf_status rf_corpus_pack_u32(const uint32_t* elems, const uint64_t* offsets, siz
     *out = c;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, size_t stride, int device, void* stream,
                                      rf_corpus** out)
-{
+try {
     if (!out || (n && len && !d_rows) || n >= 0xFFFFFFFFull - kWave || len > 0xFFFFFFF0ull || stride < len) {
         set_error("rf_corpus_pack_rows_device: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -963,6 +969,7 @@ rf_status rf_corpus_pack_rows_device(const void* d_rows, size_t n, size_t len, s
     *out = c;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 void rf_corpus_free(rf_corpus* c)
 {
@@ -1036,7 +1043,7 @@ size_t rf_corpus_alphabet_size(const rf_corpus* c, size_t* overflow_symbols)
 
 // Issue-rate probe (rf_probe.hip): the product's own column code on register-resident PM words.
 rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, uint32_t mode, int device, uint32_t blocks_per_cu, double* wave_columns_per_ns)
-{
+try {
     if (!wave_columns_per_ns) return RF_ERR_INVALID_ARG;
     *wave_columns_per_ns = 0.0;
     RawKind raw;
@@ -1061,9 +1068,10 @@ rf_status rf_probe_issue_rate(rf_metric metric, uint32_t query_len, uint32_t mod
     RF_HIP(e);
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_probe_core_clock(int device, uint32_t micros, double* ghz_sleep, double* ghz_counter)
-{
+try {
     if (!ghz_sleep || !ghz_counter || micros == 0) {
         set_error("rf_probe_core_clock: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -1097,10 +1105,11 @@ rf_status rf_probe_core_clock(int device, uint32_t micros, double* ghz_sleep, do
     *ghz_counter = (double)h[1] / ns;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_topk_merge_u32(rf_op op, const uint32_t* scores, const uint64_t* indices, const uint32_t* counts,
                             uint32_t lists, uint32_t k, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count)
-{
+try {
     if (!scores || !indices || !counts || !out_score || !out_index || !out_count) return RF_ERR_INVALID_ARG;
     struct E {
         uint32_t s;
@@ -1122,5 +1131,6 @@ rf_status rf_topk_merge_u32(rf_op op, const uint32_t* scores, const uint64_t* in
     *out_count = m;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 }  // extern "C"

@@ -97,7 +97,7 @@ rf_status read_header(FILE* f, FileHeader* h)
 }  // namespace
 
 rf_status rf_corpus_save(const rf_corpus* c, const char* path)
-{
+try {
     if (!c || !path || c->borrowed) {
         set_error("rf_corpus_save: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -179,6 +179,7 @@ rf_status rf_corpus_save(const rf_corpus* c, const char* path)
     }
     return RF_OK;
 }
+RF_ABI_CATCH
 
 // host-side metadata shared by rf_corpus_load and the stream driver
 struct MixedArrays {
@@ -307,7 +308,7 @@ static rf_status load_meta(FILE* f, const FileHeader& h, rf_corpus* c, std::vect
 }
 
 rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
-{
+try {
     if (!path || !out) {
         set_error("rf_corpus_load: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -400,6 +401,7 @@ rf_status rf_corpus_load(const char* path, int device, rf_corpus** out)
     *out = c;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 // One pass of `scorer.<op>` over a corpus FILE that need not fit in HBM.  Segments are tile ranges of at most
 // `segment_bytes` of payload; two device buffer sets alternate, segment k+1 is read and uploaded (copy stream) while
@@ -728,16 +730,18 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
 
 rf_status rf_stream_many_u32(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, uint32_t* out, size_t out_capacity,
                              uint64_t segment_bytes, int device)
-{
+try {
     return stream_many(c, path, op, args, out, out_capacity, false, segment_bytes, device);
 }
+RF_ABI_CATCH
 rf_status rf_stream_many_f64(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, double* out, size_t out_capacity,
                              uint64_t segment_bytes, int device)
-{
+try {
     return stream_many(c, path, op, args, out, out_capacity, true, segment_bytes, device);
 }
+RF_ABI_CATCH
 rf_status rf_corpus_file_count(const char* path, size_t* n)
-{
+try {
     if (!path || !n) {
         set_error("rf_corpus_file_count: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -752,6 +756,7 @@ rf_status rf_corpus_file_count(const char* path, size_t* n)
     if (s == RF_OK) *n = (size_t)h.n;
     return s;
 }
+RF_ABI_CATCH
 
 
 }  // extern "C"

@@ -827,15 +827,17 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
 
 rf_status rf_many_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t* out,
                       rf_mem out_mem, void* stream)
-{
+try {
     return run_many(c, corpus, op, args, out, out_mem, stream, false);
 }
+RF_ABI_CATCH
 
 rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, double* out,
                       rf_mem out_mem, void* stream)
-{
+try {
     return run_many(c, corpus, op, args, out, out_mem, stream, true);
 }
+RF_ABI_CATCH
 
 static rf_status run_one(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, void* out,
                          int* is_some, bool f64_out)
@@ -864,14 +866,16 @@ static rf_status run_one(const rf_comparator* c, const uint8_t* s2, size_t len2,
 }
 rf_status rf_one_u32(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, uint32_t* out,
                      int* is_some)
-{
+try {
     return run_one(c, s2, len2, op, args, device, out, is_some, false);
 }
+RF_ABI_CATCH
 rf_status rf_one_f64(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, double* out,
                      int* is_some)
-{
+try {
     return run_one(c, s2, len2, op, args, device, out, is_some, true);
 }
+RF_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------------
 // many queries x one corpus
@@ -985,15 +989,17 @@ static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, c
 
 rf_status rf_many_multi_u32(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
                             uint32_t* out, rf_mem out_mem, void* stream)
-{
+try {
     return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, false);
 }
+RF_ABI_CATCH
 
 rf_status rf_many_multi_f64(const rf_comparator* const* cs, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
                             double* out, rf_mem out_mem, void* stream)
-{
+try {
     return run_many_multi(cs, q, corpus, op, args, out, out_mem, stream, true);
 }
+RF_ABI_CATCH
 
 
 }  // extern "C"

@@ -306,7 +306,7 @@ static rf_status topk_by_selection(const rf_comparator* c, const rf_corpus* corp
 
 rf_status rf_topk_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, uint64_t index_base, double* out_score,
                       uint64_t* out_index, uint64_t* out_count, double* out_all, rf_mem out_all_mem, void* stream)
-{
+try {
     if (!out_score || !out_index || !out_count || !c || !corpus || !args) {
         set_error("rf_topk_f64: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -332,11 +332,12 @@ rf_status rf_topk_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     *out_count = keys.size();
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
                       uint64_t index_base, uint32_t* out_score, uint64_t* out_index, uint32_t* out_count,
                       uint32_t* out_all, rf_mem out_all_mem, void* stream)
-{
+try {
     if (!out_score || !out_index || !out_count || !c || !corpus) {
         set_error("rf_topk_u32: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -441,11 +442,12 @@ rf_status rf_topk_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     *out_count = m;
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_topk_keys_device(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t k,
                               uint32_t index_base, uint64_t* d_keys_out, uint32_t* out_all, rf_mem out_all_mem,
                               void* stream)
-{
+try {
     if (!d_keys_out || !c || !corpus) {
         set_error("rf_topk_keys_device: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -467,9 +469,10 @@ rf_status rf_topk_keys_device(const rf_comparator* c, const rf_corpus* corpus, r
     bool desc = false;
     return topk_core(c, corpus, op, args, k, index_base, d_keys_out, out_all, out_all_mem, st, &desc);
 }
+RF_ABI_CATCH
 
 rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t k, uint64_t* d_out, int device, void* stream)
-{
+try {
     if (!d_keys || !d_out || k == 0 || k > (uint32_t)kWave || n == 0) {
         set_error("rf_topk_merge_keys_device: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -484,6 +487,7 @@ rf_status rf_topk_merge_keys_device(const uint64_t* d_keys, uint32_t n, uint32_t
     }
     return RF_OK;
 }
+RF_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------------
 // The exchange step below the host language: all-gather of the per-shard key lists over RCCL + merge.  RCCL is not a
@@ -510,7 +514,7 @@ nccl_all_gather_fn find_nccl_all_gather()
 
 rf_status rf_topk_allgather_merge(const uint64_t* d_local_keys, uint32_t k, void* nccl_comm, uint32_t world, uint64_t* d_all_keys,
                                   uint64_t* d_merged, int device, void* stream)
-{
+try {
     if (!d_local_keys || !d_all_keys || !d_merged || !nccl_comm || k == 0 || k > (uint32_t)kWave || world == 0) {
         set_error("rf_topk_allgather_merge: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -530,6 +534,7 @@ rf_status rf_topk_allgather_merge(const uint64_t* d_local_keys, uint32_t k, void
     }
     return rf_topk_merge_keys_device(d_all_keys, world * k, k, d_merged, device, stream);
 }
+RF_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------------
 // top-k entries: 16 bytes {order-preserving key, 64-bit global index} -- the exchange format for every top-k (rfgpu.h)
@@ -546,7 +551,7 @@ double rf_topk_entry_score_f64(uint64_t key, int descending)
 
 rf_status rf_topk_entries_device(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, uint64_t index_base,
                                  rf_topk_entry* d_entries_out, void* stream)
-{
+try {
     if (!c || !corpus || !args || !d_entries_out || k == 0) {
         set_error("rf_topk_entries_device: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -597,9 +602,10 @@ rf_status rf_topk_entries_device(const rf_comparator* c, const rf_corpus* corpus
     RF_HIP(hipStreamSynchronize(st));  // (`host` dies with this frame)
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_topk_merge_entries_device(const rf_topk_entry* d_entries, uint64_t n, uint64_t k, rf_topk_entry* d_out, int device, void* stream)
-{
+try {
     if (!d_entries || !d_out || k == 0 || n == 0 || n > 0x7FFFFFFFull || k > 0x7FFFFFFFull) {
         set_error("rf_topk_merge_entries_device: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -613,10 +619,11 @@ rf_status rf_topk_merge_entries_device(const rf_topk_entry* d_entries, uint64_t 
     }
     return RF_OK;
 }
+RF_ABI_CATCH
 
 rf_status rf_topk_allgather_merge_entries(const rf_topk_entry* d_local, uint64_t k, void* nccl_comm, uint32_t world, rf_topk_entry* d_all,
                                           rf_topk_entry* d_merged, int device, void* stream)
-{
+try {
     if (!d_local || !d_all || !d_merged || !nccl_comm || k == 0 || world == 0) {
         set_error("rf_topk_allgather_merge_entries: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -636,9 +643,10 @@ rf_status rf_topk_allgather_merge_entries(const rf_topk_entry* d_local, uint64_t
     }
     return rf_topk_merge_entries_device(d_all, (uint64_t)world * k, k, d_merged, device, stream);
 }
+RF_ABI_CATCH
 
 rf_status rf_topk_merge_entries(const rf_topk_entry* entries, uint64_t n, uint64_t k, rf_topk_entry* out)
-{
+try {
     if ((n && !entries) || !out || k == 0) {
         set_error("rf_topk_merge_entries: invalid argument");
         return RF_ERR_INVALID_ARG;
@@ -650,6 +658,7 @@ rf_status rf_topk_merge_entries(const rf_topk_entry* entries, uint64_t n, uint64
     for (uint64_t i = 0; i < k; ++i) out[i] = i < v.size() ? v[i] : rf_topk_entry{~0ull, ~0ull};
     return RF_OK;
 }
+RF_ABI_CATCH
 
 
 }  // extern "C"

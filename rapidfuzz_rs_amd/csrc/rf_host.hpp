@@ -206,6 +206,20 @@ static inline uint64_t tile_bytes(uint32_t len) { return (uint64_t)((len + kChun
         }                                                                                              \
     } while (0)
 
+// Every exported rf_status function is a function-try-block ending in this: no C++ exception may cross the C ABI (a Rust or C caller
+// cannot unwind it; host-side std::vector growth is where one would come from).
+#define RF_ABI_CATCH                                                                                    \
+    catch (const std::bad_alloc&)                                                                       \
+    {                                                                                                   \
+        rf::set_error("out of host memory");                                                            \
+        return RF_ERR_OOM;                                                                              \
+    }                                                                                                   \
+    catch (const std::exception& ex)                                                                    \
+    {                                                                                                   \
+        rf::set_error(std::string("internal error: ") + ex.what());                                     \
+        return RF_ERR_INVALID_ARG;                                                                      \
+    }
+
 // ---- shared between the translation units (definitions: the file named in the comment; they sit inside the files' extern "C" blocks)
 #pragma clang diagnostic ignored "-Wreturn-type-c-linkage"
 // (hidden: these are internal to librfgpu.so -- only the rf_* entry points of include/rfgpu.h are exported)

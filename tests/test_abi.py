@@ -169,3 +169,29 @@ def test_every_environment_knob_is_documented_and_none_changes_results():
     assert not missing, f"environment variables read by the library but not documented in rfgpu.h: {missing}"
     blob = open(N.LIB_PATH, "rb").read()
     assert b"RF_EXP_NOHBM" not in blob, "the shipping librfgpu.so must not contain the wrong-answer measurement switch"
+
+
+def test_no_exception_can_cross_the_c_abi():
+    """Every exported rf_status function is a function-try-block that ends in RF_ABI_CATCH (rf_host.hpp): std::bad_alloc and friends
+    become RF_ERR_OOM / RF_ERR_INVALID_ARG + rf_last_error() instead of unwinding into a C or Rust caller."""
+    import glob
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rapidfuzz_rs_amd", "csrc")
+    seen = 0
+    for path in glob.glob(os.path.join(root, "*.hip")):
+        lines = open(path).read().split("\n")
+        for i, ln in enumerate(lines):
+            if re.match(r"^rf_status rf_[a-z_0-9]+\(", ln):
+                j = i
+                while not lines[j].rstrip().endswith(")"):
+                    j += 1
+                assert lines[j + 1] == "try {", (path, ln)
+                k = j + 2
+                while lines[k] != "}":
+                    k += 1
+                assert lines[k + 1] == "RF_ABI_CATCH", (path, ln)
+                seen += 1
+    header = open(os.path.join(os.path.dirname(root), "..", "include", "rfgpu.h")).read()
+    declared = set(re.findall(r"^rf_status (rf_[a-z_0-9]+)\(", header, flags=re.M))
+    assert seen == len(declared) >= 30, (seen, len(declared))
