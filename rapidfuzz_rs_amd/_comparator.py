@@ -143,7 +143,9 @@ class BatchComparator:
              score_hint=None, weights=None, prefix_weight=None):
         """scores of every candidate of `corpus`, original order.  Returns a numpy array (uint32 with
         0xFFFFFFFF = None, or float64 with NaN = None); pass a CUDA torch tensor as `out` to keep the result
-        on the device (the call is then asynchronous on `stream` / torch's current stream)."""
+        on the device (the call is then asynchronous on `stream` / torch's current stream).  With host results the
+        call runs on `stream` if given, else on the NULL stream (torch's current stream is NOT consulted: host threads
+        that want to overlap pass their own `stream=torch.cuda.Stream().cuda_stream`)."""
         a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
         is_f = self.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
         ca = a.to_c(is_f)
