@@ -35,6 +35,8 @@
  *                                 1         0: the older form of the cutoff scans' first look
  *   RF_FIRST_CHECK                0 (auto)  4..16: column of the cutoff scans' first look
  *   RF_HEAD8_MIN                  16384     fewest tiles for which a corpus gets an 8-symbol head plane (0: never)
+ *   RF_HEAD6                      1         0: no 6-bit head plane (single-length corpora of < 64 distinct symbols stream 6 instead of 8 bytes
+ *                                           per candidate through the band prefilter; costs 6 more bytes per candidate of HBM)
  *   RF_BAND_FILTER                -1 (auto) 0 / 1: band prefilter of the head-plane scans never / whenever applicable
  *   RF_NO_BAND                    unset     set: multi-word scan + early-out instead of the band kernel
  *   RF_TILE_ORDER                 2         0..3: how a length-bucketed corpus' results reach original order

@@ -426,6 +426,36 @@ const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, 
     return corpus->d_heads8;
 }
 
+// The head plane at 6 bits per symbol (ScanParams::heads6): single-length corpora whose payload holds no stored symbol above 63 -- the
+// band prefilter pass then streams 6 instead of 8 bytes per candidate.  Built from the 8-byte plane on first use, kept beside it
+// (+ 6 bytes per candidate); RF_HEAD6=0 switches it off.  nullptr = not to be had.
+const uint32_t* corpus_head6_plane(const rf_corpus* corpus, hipStream_t st)
+{
+    static const bool on = [] { const char* e = getenv("RF_HEAD6"); return !e || atoi(e) != 0; }();
+    if (!on || !corpus->uniform || !corpus->d_heads8 || corpus->borrowed) return nullptr;
+    if (corpus_max_stored_symbol(corpus, st) >= 64u) return nullptr;
+    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+    if (!corpus->d_heads6 && !corpus->heads6_tried) {
+        corpus->heads6_tried = true;
+        uint32_t* h = nullptr;
+        const size_t rows = ((size_t)corpus->n_tiles + 1) / 2 + 1;  // (+ one pair: the pass reads a pair ahead)
+        if (hipMalloc((void**)&h, rows * 3 * kWave * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipError_t e = launch_head6_plane(corpus->d_heads8, corpus->n_tiles, h, st);
+        if (e == hipSuccess) e = hipMemsetAsync(h + (rows - 1) * 3 * kWave, 0, 3 * kWave * sizeof(uint32_t), st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (other streams may use the plane as soon as the lock is released)
+        if (e != hipSuccess) {
+            (void)hipFree(h);
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        corpus->d_heads6 = h;
+    }
+    return corpus->d_heads6;
+}
+
 // The BAND PREFILTER of the head-plane cutoff scans (rf_scan.hip early_lean_body has the kernel side and the proof): with at most
 // K edits allowed, at least 8 - K of a candidate's first 8 symbols must equal a query symbol within K positions of their own.
 // Decides whether a launch uses it: K = the largest raw distance that passes the cutoff (the same arithmetic as may_pass() on
@@ -647,6 +677,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
 
     hipStream_t st = (hipStream_t)stream;
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
+    p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
     static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
     p.max_stored_sym = (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) ? corpus_max_stored_symbol(corpus, st) : 0xFFFFFFFFu;

@@ -45,6 +45,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     // (single-length corpora only: every launch of a top-k call selects its own k best, so the per-length-run launches of
     // launch_scan_runs cannot share one call)
     p.heads8 = corpus->uniform ? corpus_head8_plane(corpus, p, raw, st) : nullptr;
+    p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
     if (corpus->uniform) plan_band_filter(c, corpus, op, false, &p, corpus->uniform_len);
     // persistent per-(corpus, stream) scratch; capacity = every workgroup publishing a full 64-entry list.  At most kTopkStreams
     // streams hold one: a further stream takes over the least recently used stream's scratch (after that stream's work has drained) --

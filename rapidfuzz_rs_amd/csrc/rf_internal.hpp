@@ -65,6 +65,10 @@ struct ScanParams {
     const uint64_t* pm;    // device PM table, 256 x words, row-major [c * words + w], indexed by ORIGINAL symbol
     const uint8_t* sigma;  // device uint8[256]: original symbol -> the symbol stored in the packed corpus
     const uint8_t* heads8; // small-cutoff scans: the candidates' first 8 symbols, tile t at t * 512 B (rf_pack.hip); nullptr = none
+    // the same 8 symbols at 6 bits each (single-length corpora that store fewer than 64 distinct symbols): tile PAIR q at q * 768 B as
+    // three dword planes of 64 lanes -- lane l holds candidates 2l, 2l + 1 of the pair: A[31:0] | A[47:32] + B[15:0] << 16 | B[47:16]
+    // (rf_pack.hip head6_plane_kernel; head_filter_kernel reads 6 instead of 8 bytes per candidate).  nullptr = none
+    const uint32_t* heads6;
     // A LENGTH RUN of a length-bucketed corpus seen as a single-length corpus (rf_api_scan.hip launch_scan_runs): tiles == nullptr, data /
     // heads8 point at the run's first tile, tile indices and idx = t * 64 + lane are relative to it, and run_orig[idx] is the
     // candidate's original index (kPad = padding lane).  `out` is pre-filled with None: dead tiles store nothing, survivors go
@@ -166,6 +170,7 @@ int scan_max_grid();
 hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream);
 hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t tile_bytes, uint8_t* heads, hipStream_t stream);  // rf_pack.hip: the candidates' first 8 symbols
 hipError_t launch_max_byte(const uint8_t* data, uint64_t bytes, uint32_t* out, hipStream_t stream);  // rf_pack.hip: largest stored symbol (*out must start at 0)
+hipError_t launch_head6_plane(const uint8_t* heads8, uint32_t n_tiles, uint32_t* heads6, hipStream_t stream);
 hipError_t launch_head8_plane_tiles(const uint8_t* data, const TileDesc* tiles, uint32_t n_tiles, uint8_t* heads, hipStream_t stream);  // the same over tile descriptors
 // the coalesced gather (rf_pack.hip "window_gather_kernel"): windows of kGatherWindow original indices, at most kMaxGatherRuns runs
 constexpr uint32_t kGatherWindow = 4096;

@@ -434,6 +434,33 @@ hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t ti
                        reinterpret_cast<uint2*>(heads));
     return hipGetLastError();
 }
+// The head plane at 6 bits per symbol (round 4): a corpus that stores fewer than 64 distinct symbols (symbols are stored as frequency
+// ranks) needs 48 bits for a candidate's first 8 symbols, and the band prefilter pass is a pure stream over the plane -- 6 instead of
+// 8 bytes per candidate.  Built from the 8-byte plane; layout in rf_internal.hpp (ScanParams::heads6).
+__global__ __launch_bounds__(256) void head6_plane_kernel(const uint2* __restrict__ heads8, uint32_t n_tiles, uint32_t* __restrict__ heads6)
+{
+    const uint32_t lane = threadIdx.x & 63, pairs = (n_tiles + 1) / 2;
+    auto pack = [](uint2 h) {  // 8 bytes -> 48 bits, symbol i on bits 6 i ..
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= (uint64_t)(((i < 4 ? h.x : h.y) >> (8 * (i & 3))) & 63u) << (6 * i);
+        return v;
+    };
+    for (uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6); q < pairs; q += gridDim.x * 4) {
+        const size_t c0 = (size_t)q * 2 * kWave + 2 * lane;  // candidates 2l, 2l + 1 of the pair (the 8-byte plane has a pad row behind the last tile)
+        const uint64_t a = pack(heads8[c0]), b = pack(heads8[c0 + 1]);
+        uint32_t* row = heads6 + (size_t)q * 3 * kWave;
+        row[lane] = (uint32_t)a;
+        row[kWave + lane] = (uint32_t)(a >> 32) | ((uint32_t)b << 16);
+        row[2 * kWave + lane] = (uint32_t)(b >> 16);
+    }
+}
+hipError_t launch_head6_plane(const uint8_t* heads8, uint32_t n_tiles, uint32_t* heads6, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(head6_plane_kernel, dim3(std::min<uint32_t>(((n_tiles + 1) / 2 + 3) / 4, 65536u)), dim3(256), 0, stream, reinterpret_cast<const uint2*>(heads8), n_tiles, heads6);
+    return hipGetLastError();
+}
 // the same over the EXACT tiles of a length-bucketed corpus (round 4): row t = the first 8 stored bytes of tile t's 64 lanes, whatever
 // the tile's length (a candidate shorter than 8 symbols contributes its zero padding -- the cutoff scans only take their first look
 // from the plane for runs of >= 16 symbols, rf_api_scan.hip launch_scan_runs)

@@ -205,7 +205,14 @@ __device__ __forceinline__ uint32_t band_hits(const uint8_t* lds_band, uint32_t 
 // independent chains) and the diagonal bound.  Inside early_head8_kernel that look sits in a loop of 25 scalar instructions and
 // 12 branches per tile, one tile per trip.
 // buf: [0] packed count | G per-wavefront counts | G words unused | G segments of `cap` tiles | the packed list   (G = wavefronts of this launch)
-template <class State, int kFirst>
+// kPlane6: the pass reads the 6-bit plane (ScanParams::heads6: three coalesced dword loads per lane and pair, 768 B per wavefront instead
+// of 1024) and widens the two candidates to the byte form of the 8-byte plane in registers -- ~30 more vector instructions per pair in a
+// pass that is bound by the stream (C5 shape, 100 M candidates: 138 -> ~105 us).
+__device__ __forceinline__ uint32_t widen24(uint32_t x)  // four 6-bit symbols on bits 0..23 -> four bytes
+{
+    return (x & 0x3Fu) | ((x << 2) & 0x3F00u) | ((x << 4) & 0x3F0000u) | ((x << 6) & 0x3F000000u);
+}
+template <class State, int kFirst, bool kPlane6>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
 {
     using Look = typename std::conditional<std::is_same<State, LevState<1>>::value, Lev32State,
@@ -231,12 +238,38 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
         const TileFin fin = tile_fin(p, len1, len2);
         const typename Look::Word* pm = reinterpret_cast<const typename Look::Word*>(lds_pm);
         const uint8_t* base = p.heads8 + (size_t)lane * sizeof(v4u);
-        auto load_pair = [&](uint32_t q) { return __builtin_nontemporal_load(reinterpret_cast<const v4u*>(base + ((uint64_t)p.tile_begin + 2ull * q) * (kWave * 8))); };
-        v4u cur = load_pair(pr);
+        const uint32_t* base6 = kPlane6 ? p.heads6 + (size_t)(p.tile_begin / 2) * (3 * kWave) + lane : nullptr;  // (the launcher sends even tile_begin here)
+        auto load_pair = [&](uint32_t q) {
+            if constexpr (kPlane6) {
+                const uint32_t* row = base6 + (size_t)q * (3 * kWave);
+                v4u v;
+                v.x = __builtin_nontemporal_load(row);
+                v.y = __builtin_nontemporal_load(row + kWave);
+                v.z = __builtin_nontemporal_load(row + 2 * kWave);
+                v.w = 0u;
+                return v;
+            } else {
+                return __builtin_nontemporal_load(reinterpret_cast<const v4u*>(base + ((uint64_t)p.tile_begin + 2ull * q) * (kWave * 8)));
+            }
+        };
+        auto widen = [&](v4u v) {  // A[31:0] | A[47:32] + B[15:0] << 16 | B[47:16] -> the two candidates' 8 bytes each
+            if constexpr (kPlane6) {
+                v4u r;
+                r.x = widen24(v.x);
+                r.y = widen24(__builtin_amdgcn_alignbit(v.y, v.x, 24) & 0xFFFFFFu);
+                r.z = widen24(__builtin_amdgcn_alignbit(v.z, v.y, 16));
+                r.w = widen24(v.z >> 8);
+                return r;
+            } else {
+                return v;
+            }
+        };
+        v4u packed = load_pair(pr);
         v4u ahead = load_pair(pr + stride < pairs ? pr + stride : pr);
         while (true) {
             const uint32_t pr_next = pr + stride;
             const v4u ahead2 = load_pair(pr_next + stride < pairs ? pr_next + stride : pr);
+            const v4u cur = widen(packed);
             const uint32_t t0 = p.tile_begin + 2 * pr;
             uint64_t m = ~0ull;
             if (need) m = __ballot(band_hits(lds_band, cur.x, cur.y) >= need || band_hits(lds_band, cur.z, cur.w) >= need);
@@ -271,7 +304,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
             }
             if (pr_next >= pairs) break;
             pr = pr_next;
-            cur = ahead;
+            packed = ahead;
             ahead = ahead2;
         }
     }
@@ -891,7 +924,10 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                         const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
                         const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: rf_api_scan.hip sizes the list buffer for that */ \
                         const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
-                        hipLaunchKernelGGL((head_filter_kernel<State, J>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
+                        if (pn.heads6 && (p.tile_begin & 1u) == 0)                         \
+                            hipLaunchKernelGGL((head_filter_kernel<State, J, true>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
+                        else                                                               \
+                            hipLaunchKernelGGL((head_filter_kernel<State, J, false>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
                         hipLaunchKernelGGL(tile_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap); \
                         ScanParams p2 = pn;                                                \
                         p2.heads8 = nullptr;                                               \

@@ -2125,8 +2125,10 @@ def test_head_plane_cutoff_scans_with_edits_in_the_head(alphabet):
         # the same two corpora with the filter forced on (also where the host would not use it), with the filter inside the cutoff
         # kernel instead of head_filter_kernel + tile list, and with no filter at all
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        # (both alphabets store fewer than 64 distinct symbols, so by default the filter pass reads the 6-bit plane: RF_HEAD6=0 is the 8-byte one)
         for env in ({"RF_BAND_FILTER": "1"}, {"RF_BAND_FILTER": "1", "RF_HEAD_TWO_PASS": "0"}, {"RF_BAND_FILTER": "0"},
-                    {"RF_BAND_FILTER": "0", "RF_HEAD_LOOK_PASS": "0"}):  # (the last: every first look inside early_head8_kernel)
+                    {"RF_BAND_FILTER": "0", "RF_HEAD_LOOK_PASS": "0"},  # (every first look inside early_head8_kernel)
+                    {"RF_HEAD6": "0"}, {"RF_HEAD6": "0", "RF_BAND_FILTER": "1"}):
             r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
                                 "test_head_plane_cutoff_scans_with_edits_in_the_head"], capture_output=True, text=True, cwd=root,
                                env=dict(os.environ, RF_TEST_HEAD_CHILD="1", **env))
