@@ -373,7 +373,10 @@ def main():
         early = args.cutoff / max(maximum, 1) < (0.4 if args.metric in ("indel", "lcs_seq") else 0.7)
     # (Levenshtein / OSA under a cutoff <= 5 on a single-length corpus: the first look reads the 8-symbol head plane, rf_pack.hip)
     head8 = early and args.metric in ("levenshtein", "osa") and args.cutoff <= 5 and not args.ragged and args.query_len <= 64 and n >= (1 << 20) and os.environ.get("RF_HEAD8_MIN") != "0"
-    bytes_per_pair = (min(ln, 8 if head8 else 16) if early else ln) / nq + out_bytes
+    # (cutoffs <= 3 go through the band prefilter, which streams the 6-bit plane -- 6 bytes per candidate -- when the corpus stores fewer than
+    # 64 distinct symbols, rf_pack.hip head6_plane_kernel; RF_HEAD6=0 / RF_BAND_FILTER=0 keep the 8-byte plane)
+    head6 = head8 and args.cutoff <= 3 and args.symbols < 64 and os.environ.get("RF_HEAD6", "1") != "0" and os.environ.get("RF_BAND_FILTER", "1") != "0"
+    bytes_per_pair = (min(ln, (6 if head6 else 8) if head8 else 16) if early else ln) / nq + out_bytes
     if args.ragged and early and args.metric in ("levenshtein", "osa"):
         # a length-bucketed corpus under a small cutoff: only the candidates inside the length window are looked at (their 8-symbol head from
         # the plane when the runs are walked as single-length views, DESIGN.md 5.1 v; their first chunk row otherwise); every candidate has its result

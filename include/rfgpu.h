@@ -26,7 +26,8 @@
  * -DRF_EXPERIMENTS builds (tools/build_stream_variant.sh), never into librfgpu.so (tests/test_abi.py checks the binary).
  *   name                          default   meaning
  *   RF_SCAN_BLOCKS_PER_CU         32        workgroups per CU of short-running launches (cutoff scans, band kernel, long queries)
- *   RF_SCAN_BLOCKS_PER_CU_FULL    256       workgroups per CU of full (no-cutoff) scans
+ *   RF_SCAN_BLOCKS_PER_CU_FULL    256       most workgroups per CU of full (no-cutoff) scans
+ *   RF_SCAN_TILES_PER_WAVE        5         tiles per wavefront the grid of a full scan aims at (below the cap above; at least 32 workgroups per CU)
  *   RF_STREAM                     1         0: scan_body instead of the streaming loop of the compiled scans
  *   RF_ASM_STREAM                 1         0: compiled scans instead of the whole-kernel asm scans (rf_stream_asm.hip)
  *   RF_ASM_CHUNK                  1         0: compiled chunk instead of the hybrid asm chunks (in-scan top-k, Jaro)

@@ -177,10 +177,15 @@ __device__ __forceinline__ uint64_t dec64(uint64_t x)
 // built the T bit with 3 more; the CU's one scalar unit serves four SIMDs, and at 9 SALU per column x 4 wavefronts it --
 // not the vector unit (10 VALU per column) -- was what bounded this pass (ISA tally of the r01 kernel: 144 SALU next to
 // 160 VALU per chunk).  T bits are gathered at compile-time positions 0..15 and shifted into place once per chunk.
-template <bool kFull>
-__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint64_t* wtab, const uint4 c, uint32_t j0, uint32_t cols)
+// kCols = 4, 8, 12 or 16 columns (round 4): a tile's last, partial chunk runs the unrolled, pipelined block rounded up to four columns
+// instead of one branch per column -- the columns behind the candidate's end are no-ops because their window rows are zero
+// (jaro_window_table), so no T bit and no pattern flag is set there.  On a corpus of lengths 1..64 a quarter of all columns sit in
+// partial chunks.
+template <int kCols>
+__device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint64_t* wtab, const uint4 c, uint32_t j0)
 {
-    constexpr int G = kJaroGroup, NG = kChunk / G;
+    static_assert(kCols % kJaroGroup == 0 && kCols >= kJaroGroup && kCols <= kChunk, "whole groups");
+    constexpr int G = kJaroGroup, NG = kCols / G;
     const uint64_t* wrow = wtab + j0;
     uint32_t t16 = 0;
     uint64_t cur[G], nxt[G];
@@ -195,22 +200,19 @@ __device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) {
-            if (kFull || (uint32_t)(g * G + b) < cols) {
-                const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], wrow[g * G + b], st.p_flag);  // PM & window & ~P
-                const uint64_t below = dec64(pm_j);
-                st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
-                // T bit of this column = (pm_j != 0) = the sign of pm_j | -pm_j, and -pm_j == ~below: one LUT on the high
-                // halves and one funnel shift that pushes the sign into t16 -- a 64-bit compare + select + or costs 4.7 ns
-                // per wavefront and SIMD on this chip, this 3.0 (tools/microbench_issue).  Column j lands on bit 15 - j.
-                const uint32_t y = (uint32_t)(pm_j >> 32) | ~(uint32_t)(below >> 32);
-                t16 = __builtin_amdgcn_alignbit(t16, y, 31);           // (t16 << 1) | (y >> 31)      jaro.rs:174 / :183
-            } else {
-                t16 <<= 1;
-            }
+            const uint64_t pm_j = lut3<T_AND_ANDN>(cur[b], wrow[g * G + b], st.p_flag);  // PM & window & ~P
+            const uint64_t below = dec64(pm_j);
+            st.p_flag = lut3<T_OR_ANDN_B>(st.p_flag, pm_j, below);  // P |= blsi(pm_j)
+            // T bit of this column = (pm_j != 0) = the sign of pm_j | -pm_j, and -pm_j == ~below: one LUT on the high
+            // halves and one funnel shift that pushes the sign into t16 -- a 64-bit compare + select + or costs 4.7 ns
+            // per wavefront and SIMD on this chip, this 3.0 (tools/microbench_issue).  Column j lands on bit 15 - j.
+            const uint32_t y = (uint32_t)(pm_j >> 32) | ~(uint32_t)(below >> 32);
+            t16 = __builtin_amdgcn_alignbit(t16, y, 31);           // (t16 << 1) | (y >> 31)      jaro.rs:174 / :183
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) cur[b] = nxt[b];
     }
+    t16 <<= kChunk - kCols;  // (the columns not run)
     const uint32_t v = t16 << (j0 & 16), in_lo = (j0 & 32) ? 0u : ~0u;  // j0 is wavefront-uniform: the mask is scalar
     st.t_lo |= v & in_lo;
     st.t_hi |= v & ~in_lo;
@@ -218,16 +220,19 @@ __device__ __forceinline__ void jaro_flag_chunk(JaroWordState& st, const uint64_
 
 // the window mask of every column for this bound (closed form of the recurrence bm' = (bm << 1) | (j < bound) started
 // at the low bound + 1 bits): bits [max(j - bound, 0), min(j + bound + 1, 64))
-__device__ __forceinline__ void jaro_window_table(uint64_t* wtab, uint32_t lane, uint32_t bound)
+// Rows of columns at or behind the (truncated) candidate length are ZERO: a partial last chunk runs whole groups of four columns, and a
+// zero window row makes a column a no-op (no pattern flag, no T bit).
+__device__ __forceinline__ void jaro_window_table(uint64_t* wtab, uint32_t lane, uint32_t bound, uint32_t len2)
 {
     const uint32_t lo = lane > bound ? lane - bound : 0, hi = min(lane + bound + 1, 64u);
-    wtab[lane] = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & (~0ull << lo);
+    const uint64_t row = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & (~0ull << lo);
+    wtab[lane] = lane < len2 ? row : 0ull;
 }
 
-template <bool kFull>
-__device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4 c, uint32_t j0, uint32_t cols)
+template <int kCols>  // (columns behind the candidate's end have no T bit: no-ops here too)
+__device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const uint64_t* lds_pm0, const uint4 c, uint32_t j0)
 {
-    constexpr int G = kJaroGroup, NG = kChunk / G;
+    constexpr int G = kJaroGroup, NG = kCols / G;
     const uint32_t in_lo = (j0 & 32) ? 0u : ~0u;
     const uint32_t thalf = (st.t_lo & in_lo) | (st.t_hi & ~in_lo);
     const uint32_t t16 = thalf >> (j0 & 16);  // this chunk's T bits, column j at position 15 - j (no scalar address arithmetic per column)
@@ -243,14 +248,12 @@ __device__ __forceinline__ void jaro_transpose_chunk(JaroWordState& st, const ui
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) {
-            if (kFull || (uint32_t)(g * G + b) < cols) {
-                const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)t16, 15 - (g * G + b), 1);  // all ones iff T bit j
-                const uint64_t f = ((uint64_t)f32 << 32) | f32;
-                const uint64_t below = dec64(st.p_flag);
-                const uint64_t m = lut3<T_ANDN_AND>(st.p_flag, below, f);  // lowest remaining pattern flag, if flagged
-                st.hits = lut3<T_OR_AND>(st.hits, cur[b], m);              // match iff PM[text char] has that bit
-                st.p_flag = lut3<T_AND_ORN>(st.p_flag, below, f);          // consume it, if flagged
-            }
+            const uint32_t f32 = (uint32_t)__builtin_amdgcn_sbfe((int)t16, 15 - (g * G + b), 1);  // all ones iff T bit j
+            const uint64_t f = ((uint64_t)f32 << 32) | f32;
+            const uint64_t below = dec64(st.p_flag);
+            const uint64_t m = lut3<T_ANDN_AND>(st.p_flag, below, f);  // lowest remaining pattern flag, if flagged
+            st.hits = lut3<T_OR_AND>(st.hits, cur[b], m);              // match iff PM[text char] has that bit
+            st.p_flag = lut3<T_AND_ORN>(st.p_flag, below, f);          // consume it, if flagged
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) cur[b] = nxt[b];
@@ -327,9 +330,9 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
         JaroWordState st;
         st.p_flag = st.hits = 0;
         st.t_lo = st.t_hi = 0;
-        if (bound != wtab_bound) {  // wavefront-uniform; this wavefront's own table: no barrier
-            jaro_window_table(wtab, lane, bound);
-            wtab_bound = bound;
+        if ((bound | (len2 << 8)) != wtab_bound) {  // wavefront-uniform; this wavefront's own table: no barrier
+            jaro_window_table(wtab, lane, bound, len2);
+            wtab_bound = bound | (len2 << 8);
         }
         // Early-out under a tight cutoff: after j text symbols the number of common characters can still grow by at most
         // one per remaining symbol, the similarity is at most (m/len1 + m/len2 + 1) / 3 (common_char_filter, jaro.rs:134-145)
@@ -346,10 +349,14 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
         for (uint32_t k = 0; k < nch; ++k) {  // pass 1
             const uint4 nxt = tv.src[(size_t)(k + 1 < nch ? k + 1 : 0) * kWave + lane];  // next chunk, then chunk 0 again
             const uint32_t cols = len2 - k * kChunk;
-            if (cols >= (uint32_t)kChunk)
-                jaro_flag_chunk<true>(st, lds_pm0, wtab, cur, k * kChunk, kChunk);
+            if (cols > 12u)
+                jaro_flag_chunk<16>(st, lds_pm0, wtab, cur, k * kChunk);
+            else if (cols > 8u)
+                jaro_flag_chunk<12>(st, lds_pm0, wtab, cur, k * kChunk);
+            else if (cols > 4u)
+                jaro_flag_chunk<8>(st, lds_pm0, wtab, cur, k * kChunk);
             else
-                jaro_flag_chunk<false>(st, lds_pm0, wtab, cur, k * kChunk, cols);
+                jaro_flag_chunk<4>(st, lds_pm0, wtab, cur, k * kChunk);
             if (early) {
                 const uint32_t j = min(len2, (k + 1) * kChunk);
                 const uint32_t m_ub = min((uint32_t)__popcll(st.p_flag) + (len2 - j), min(len1, len2));
@@ -373,10 +380,14 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
             uint4 nxt = cur;
             if (k + 1 < nch) nxt = tv.src[(size_t)(k + 1) * kWave + lane];
             const uint32_t cols = len2 - k * kChunk;
-            if (cols >= (uint32_t)kChunk)
-                jaro_transpose_chunk<true>(st, lds_pm0, cur, k * kChunk, kChunk);
+            if (cols > 12u)
+                jaro_transpose_chunk<16>(st, lds_pm0, cur, k * kChunk);
+            else if (cols > 8u)
+                jaro_transpose_chunk<12>(st, lds_pm0, cur, k * kChunk);
+            else if (cols > 4u)
+                jaro_transpose_chunk<8>(st, lds_pm0, cur, k * kChunk);
             else
-                jaro_transpose_chunk<false>(st, lds_pm0, cur, k * kChunk, cols);
+                jaro_transpose_chunk<4>(st, lds_pm0, cur, k * kChunk);
             cur = nxt;
         }
         r.transpositions = r.common - __popcll(st.hits);
@@ -804,7 +815,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_asm_kernel(co
         if (len1 > len2 + bound) len1 = len2 + bound;
     }
     const uint32_t nch = len2 / kChunk;  // the launcher sends only whole-chunk lengths here
-    jaro_window_table(wtab, lane, bound);
+    jaro_window_table(wtab, lane, bound, len2);
     tab2[lane] = (double)lane / (double)len2_orig;
     if (lane == 0) tab2[64] = 64.0 / (double)len2_orig;
 

@@ -1022,9 +1022,24 @@ int scan_grid(uint32_t n_tiles)
 {
     return (int)std::min<uint32_t>((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)scan_max_grid());
 }
-int scan_grid_full(uint32_t n_tiles)  // full (no-cutoff) scans of the register-resident kernels; also the capacity of the top-k scratch
+// Full (no-cutoff) scans of the register-resident kernels; also the capacity of the top-k scratch.  A wavefront walks tiles t, t + stride,
+// ...: what matters is HOW MANY.  One or two tiles per wavefront and the launch is made of workgroup prologues (pattern table into the
+// LDS behind two dependent global loads and a barrier, a cold first chunk): 20 M ragged candidates ran at 46.5 (Levenshtein) / 27.7
+// (Jaro-Winkler) Gpairs/s on 256 workgroups per CU = 1.2 tiles per wavefront and run at 64.0 / 43.1 on 64 per CU.  Dozens of tiles per
+// wavefront and the statically dealt wavefronts drift apart (tile lengths differ), the stores of one output window no longer meet in the
+// L2 and the last partial round of resident workgroups weighs more: 100 M ragged Jaro-Winkler 47.6 (6 tiles per wavefront) -> 43.4 (24)
+// -> 40.9 (95).  So: RF_SCAN_TILES_PER_WAVE (5) tiles per wavefront, at least 32 workgroups per CU where the corpus has them (3 M candidates
+// on 8 per CU lost 6-9 % to the old one-tile-per-wavefront grid), at most
+// RF_SCAN_BLOCKS_PER_CU_FULL (256) per CU, a multiple of 8 (the XCD deal).  profiles/grid_sweep_r04.txt
+int scan_grid_full(uint32_t n_tiles)
 {
-    return (int)std::min<uint32_t>((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)scan_max_grid_full());
+    static const uint32_t per_wave = (uint32_t)env_or("RF_SCAN_TILES_PER_WAVE", 5);
+    const uint32_t by_tiles = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;  // one tile per wavefront
+    const uint32_t want = (n_tiles + kWavesPerBlock * per_wave - 1) / (kWavesPerBlock * per_wave);
+    const uint32_t fill = std::min<uint32_t>(by_tiles, (uint32_t)device_cus() * 32u);  // (below ~10 M candidates: as many workgroups as there are)
+    uint32_t g = std::min<uint32_t>(std::max(want, fill), (uint32_t)scan_max_grid_full());
+    if (g >= 8u) g = std::min<uint32_t>((g + 7u) & ~7u, std::max<uint32_t>(8u, (uint32_t)scan_max_grid_full() & ~7u));
+    return (int)std::max<uint32_t>(g, 1u);
 }
 hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
 {

@@ -12,7 +12,8 @@ n = int(os.environ.get("AB_N", 100_000_000))
 cfg = {
     "lev64": ("levenshtein", 64, 64, {}), "lev32": ("levenshtein", 32, 64, {}), "indel": ("indel", 64, 64, {}), "osa": ("osa", 64, 64, {}),
     "lev256": ("levenshtein", 256, 256, {}), "indel256": ("indel", 256, 256, {}), "levrag": ("levenshtein", 64, 64, {}), "levragc3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "indelragc12": ("indel", 64, 64, {"score_cutoff": 12}), "indelrag": ("indel", 64, 64, {}), "osarag": ("osa", 64, 64, {}), "lev32rag": ("levenshtein", 32, 64, {}), "indel128": ("indel", 128, 64, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
-    "jaro": ("jaro", 64, 64, {}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
+    "jaro": ("jaro", 64, 64, {}), "jwrag": ("jaro_winkler", 64, 64, {}), "jarorag": ("jaro", 64, 64, {}), "jwc9": ("jaro_winkler", 64, 64, {"score_cutoff": 0.9}),
+    "jwragc9": ("jaro_winkler", 64, 64, {"score_cutoff": 0.9}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
 }
 import re as _re
 _m = _re.fullmatch(r"lev64c(\d+)", what.split("+")[0])
@@ -26,7 +27,7 @@ if "rag" in what.split("+")[0]:  # ragged corpus: lengths uniform in [20, 64] ->
     import numpy as np
     n = int(os.environ.get("AB_N", 20_000_000))
     rng = np.random.default_rng(5)
-    lens = rng.integers(20, 65, size=n).astype(np.uint64)
+    lens = rng.integers(int(os.environ.get('AB_MINLEN', 20)), 65, size=n).astype(np.uint64)
     offsets = np.zeros(n + 1, dtype=np.uint64); offsets[1:] = np.cumsum(lens)
     data = synth.ALNUM[rng.integers(0, 62, size=int(offsets[-1]))]
     corpus = rf.Corpus.from_ragged(data, offsets)
@@ -53,4 +54,5 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"{os.path.basename(os.environ.get('RF_LIB', 'librfgpu.so')):18s} {what:18s} {ms:8.3f} ms  {n / ms / 1e6:8.2f} Gpairs/s")
+chk = int(out.view(torch.int64).sum().item()) if is_f else int(out.to(torch.int64).sum().item())  # (bit pattern sum: equal builds agree exactly)
+print(f"{os.path.basename(os.environ.get('RF_LIB', 'librfgpu.so')):18s} {what:18s} {ms:8.3f} ms  {n / ms / 1e6:8.2f} Gpairs/s  chk {chk & 0xFFFFFFFFFFFF:012x}")

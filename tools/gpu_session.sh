@@ -1,9 +1,12 @@
 #!/bin/bash
-# scratch: new tests, then randomized differential tests with many seeds under several forced paths
+# scratch: Jaro partial chunks as 4-column groups: parity tests, then A/B against the old rf_jaro.hip (librfgpu_JA.so)
 set -u
-mkdir -p gpurun_out/r04
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "q8 or scratch_is_bounded or cached_acceleration or concurrent" 2>&1 | tail -15
-fz() { echo "== fuzz $*"; env "$@" RF_FUZZ_SEEDS=20000 timeout 1500 python -m pytest tests/test_gpu_parity.py -q -m gpu -n 4 -x -k "randomized" 2>&1 | grep -v "^\.\|^$" | tail -30; }
-fz RF_X=0
-fz RF_RUN_MIN_TILES=1 RF_HEAD8_MIN=1 RF_BAND_FILTER=1
-fz RF_JOINT_MAX_TILES=0 RF_TOPK_VIA_SCORES=2
+mkdir -p gpurun_out/s3
+{
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_known_answers.py tests/test_asm_kernel.py -q -m gpu -x -k "jaro or Jaro or jw or winkler or randomized or f64" -n 4 2>&1 | tail -5
+export AB_MINLEN=1 AB_LIBS="librfgpu_JA.so librfgpu.so"
+AB_N=100000000 bash tools/ab.sh jwrag
+AB_N=20000000 bash tools/ab.sh jwrag jarorag jwragc9
+bash tools/ab.sh jw
+} > gpurun_out/s3/jaro_cols.txt 2>&1
+cat gpurun_out/s3/jaro_cols.txt
