@@ -324,7 +324,7 @@ rf_status make_effective(const rf_comparator* c_in, const rf_corpus* corpus, hip
 
 // (c - h) / c for c = 0..64 common characters and h = 0..32 half-transpositions: the third term of jaro.rs:106-119,
 // divided HERE with the host's IEEE divide (the values the reference computes) and looked up by the Jaro kernels'
-// no-cutoff epilogue.  One 17 KiB table per device, uploaded on first use and kept for the life of the process.
+// no-cutoff epilogue.  One 83 KiB table per device, uploaded on first use and kept for the life of the process.
 const double* jaro_device_table(int device)
 {
     static std::mutex mu;
@@ -332,9 +332,14 @@ const double* jaro_device_table(int device)
     std::lock_guard<std::mutex> lock(mu);
     auto it = tabs.find(device);
     if (it != tabs.end()) return it->second;
-    std::vector<double> h(65 * 33);
+    // behind it (round 4): common / len2 for every candidate length that can take the single-word path, [130][65] -- the kernels
+    // used to keep this quotient in a per-wavefront LDS table rebuilt with one division per lane whenever the tile length changed,
+    // which by origin (run_many) is every tile
+    std::vector<double> h(65 * 33 + 130 * 65);
     for (int c = 0; c <= 64; ++c)
         for (int t = 0; t <= 32; ++t) h[(size_t)c * 33 + t] = c == 0 ? 0.0 : ((double)c - (double)t) / (double)c;
+    for (int l = 0; l < 130; ++l)
+        for (int c = 0; c <= 64; ++c) h[(size_t)65 * 33 + (size_t)l * 65 + c] = l == 0 ? 0.0 : (double)c / (double)l;
     DeviceGuard guard(device);
     double* d = nullptr;
     if (!guard.ok || hipMalloc((void**)&d, h.size() * sizeof(double)) != hipSuccess) return nullptr;

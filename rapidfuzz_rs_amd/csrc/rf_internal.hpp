@@ -93,7 +93,7 @@ struct ScanParams {
     uint32_t zero_begin[2], zero_end[2];  // the (at most two) runs of zero-length tiles in tile order: one per ascending section (plan())
     uint32_t mixed_begin, mixed_end;  // the mixed tiles (indices into `mixed`) a Levenshtein / LCS / OSA scan has to visit
     uint32_t joint_begin, joint_end;  // scan_kernel_mixed: exact tiles to walk in the same launch, before the mixed ones (small corpora)
-    const double* jaro_tab;         // jaro kernels: device table [65][33] of (c - h) / c (rf_api.hip jaro_device_table); nullptr = compute
+    const double* jaro_tab;         // jaro kernels: device tables [65][33] of (c - h) / c, then [130][65] of c / len2 (rf_api.hip jaro_device_table); nullptr = compute
     double jaro_need;               // jaro kernels: the similarity a candidate must reach to pass the cutoff; < 0 = no early-out
     uint32_t wf_query[16];          // wf_reg_kernel: the (renamed) query bytes, 4 per word, for queries of <= 64 symbols
     uint32_t wf_global;             // wf_kernel: the DP row lives in long_scratch (global) instead of LDS: queries beyond ~590 symbols

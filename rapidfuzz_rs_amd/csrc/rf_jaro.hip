@@ -171,6 +171,31 @@ __device__ __forceinline__ uint64_t dec64(uint64_t x)
     return r;
 }
 
+// x / 3.0, correctly rounded, without the division (the table epilogue's one remaining quotient, jaro.rs:119): z = RN(1/3) =
+// (1/3)(1 - 2^-54), q = RN(x z) is within 2 ulp of x / 3, r = x - 3 q is exact in one fma, and q + r z = x/3 - (r/3) 2^-54 rounds to
+// RN(x / 3) because x / 3 is never closer than ulp / 6 to a rounding boundary (3 x an odd 54-bit integer is not a double).  Three
+// f64 instructions instead of the ~23 of the IEEE division sequence; tests/test_div3.py checks every value the epilogue can produce
+// against the host's divide.
+__device__ __forceinline__ double div3(double x)
+{
+    const double z = 0x1.5555555555555p-2;
+    const double q = x * z;
+    const double r = __builtin_fma(-3.0, q, x);
+    return __builtin_fma(r, z, q);
+}
+
+// Compile-time knobs of the compiled single-word kernels (A/B builds: tools/build_jaro_variant.sh)
+#ifndef RF_JARO_PREFETCH
+#define RF_JARO_PREFETCH 1  // the next tile's descriptor and first chunk row are fetched at the top of the current tile
+#endif
+#ifndef RF_JARO_TAB2G
+#define RF_JARO_TAB2G 1  // common / len2 from the device table (rf_api.hip jaro_device_table) instead of a per-wavefront LDS table
+#endif
+#ifndef RF_JARO_DIV3
+#define RF_JARO_DIV3 1
+#endif
+constexpr uint32_t kJaroTab2Rows = 130;  // common / len2 for len2 < 130 (beyond that no candidate takes the single-word path)
+
 // Pass 1 over one 16-column chunk.  The sliding window mask of column j (jaro.rs:168,176,185) depends on j and the
 // tile's bound only, so it comes from a 64-entry table this wavefront keeps in LDS (jaro_window_table, rebuilt when the
 // bound changes): one broadcast ds_read per column.  Round 1 advanced the mask with 6 scalar instructions per column and
@@ -297,8 +322,29 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
     const uint32_t stride = gridDim.x * kWavesPerBlock;
     const uint32_t q4 = p.query_head;  // first four query bytes, little endian (Winkler prefix)
 
-    for (uint32_t t = p.tile_begin + dealt_workgroup(p) * kWavesPerBlock + wave; t < p.tile_end; t += stride) {
-        const TileView tv = load_tile<kUniform>(p, t);
+    // The next tile's descriptor and first chunk row are on their way while this tile runs (RF_JARO_PREFETCH): a tile used to begin
+    // with a full HBM latency in front of its first column.
+    uint32_t t = p.tile_begin + dealt_workgroup(p) * kWavesPerBlock + wave;
+    TileView tv_ahead;
+    uint4 head_ahead;
+    if (RF_JARO_PREFETCH && t < p.tile_end) {
+        tv_ahead = load_tile<kUniform>(p, t);
+        head_ahead = tv_ahead.src[lane];
+    }
+    for (; t < p.tile_end; t += stride) {
+        TileView tv;
+        uint4 cur;
+        if (RF_JARO_PREFETCH) {
+            tv = tv_ahead;
+            cur = head_ahead;
+            if (t + stride < p.tile_end) {  // (wavefront-uniform)
+                tv_ahead = load_tile<kUniform>(p, t + stride);
+                head_ahead = tv_ahead.src[lane];
+            }
+        } else {
+            tv = load_tile<kUniform>(p, t);
+            cur = tv.src[lane];
+        }
         const uint32_t len2_orig = tv.len, len1_orig = p.len1;
         const uint32_t slot = tv.slot0 + lane;
         uint32_t idx = slot;
@@ -317,7 +363,6 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
         const uint32_t nch = (len2 + kChunk - 1) / kChunk;  // <= 4 on this path
 
         // the candidate (<= 64 bytes = 4 chunk rows) is streamed twice: HBM once, the second pass hits L1/L2
-        uint4 cur = tv.src[lane];
         JaroRaw r;
         r.eq11 = (cur.x & 0xFFu) == (q4 & 0xFFu);
         {  // Winkler prefix: equal leading bytes among the first min(4, len1_orig, len2_orig), jaro_winkler.rs:118-123
@@ -376,6 +421,9 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
             continue;
         }
         r.common = __popcll(st.p_flag);
+        double quot2 = 0.0;  // common / len2 from the device table, on its way during pass 2
+        const bool tab2_global = kFast && RF_JARO_TAB2G && len2_orig < kJaroTab2Rows;
+        if (tab2_global) quot2 = p.jaro_tab[65u * 33u + len2_orig * 65u + r.common];
         for (uint32_t k = 0; k < nch; ++k) {  // pass 2
             uint4 nxt = cur;
             if (k + 1 < nch) nxt = tv.src[(size_t)(k + 1) * kWave + lane];
@@ -396,7 +444,7 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
         if (kFast) {
             // jaro::similarity_with_pm with score_cutoff = 0.0 (jaro.rs:533-598): the filters reduce to the empty-string
             // and common == 0 cases; calculate_similarity (:106-119) from the tables, in the reference's order
-            if (len2_orig != tab2_len) {  // wavefront-uniform; this wavefront's own table: no barrier
+            if (!tab2_global && len2_orig != tab2_len) {  // wavefront-uniform; this wavefront's own table: no barrier
                 tab2[lane] = (double)lane / (double)len2_orig;
                 if (lane == 0) tab2[64] = 64.0 / (double)len2_orig;
                 tab2_len = len2_orig;
@@ -409,9 +457,9 @@ __device__ __forceinline__ void jaro_word_body(const ScanParams& p, JaroWordLds&
             } else {
                 double acc = 0.0;
                 acc += tab1[r.common];
-                acc += tab2[r.common];
+                acc += tab2_global ? quot2 : tab2[r.common];
                 acc += p.jaro_tab[r.common * 33u + r.transpositions / 2u];
-                acc = acc / 3.0;
+                acc = RF_JARO_DIV3 ? div3(acc) : acc / 3.0;
                 sim = select_f64(r.common == 0, 0.0, acc);                  // :579-581
             }
             if (p.finish == FIN_JW) sim = select_f64(sim > 0.7, sim + (double)r.prefix * p.prefix_weight * (1.0 - sim), sim);  // jaro_winkler.rs:136-138
@@ -914,7 +962,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void jaro_word_asm_kernel(co
             acc += tab1[r.common];
             acc += tab2[r.common];
             acc += p.jaro_tab[r.common * 33u + r.transpositions / 2u];
-            acc = acc / 3.0;
+            acc = RF_JARO_DIV3 ? div3(acc) : acc / 3.0;
             sim = select_f64(r.common == 0, 0.0, acc);
         }
         if (p.finish == FIN_JW) sim = select_f64(sim > 0.7, sim + (double)r.prefix * p.prefix_weight * (1.0 - sim), sim);

@@ -1,12 +1,11 @@
 #!/bin/bash
-# scratch: Jaro partial chunks as 4-column groups: parity tests, then A/B against the old rf_jaro.hip (librfgpu_JA.so)
+# scratch: Jaro per-tile costs under the new grid policy: prefetch (JP), global common/len2 table (JT), div3 (JV), none (JB), all (librfgpu.so)
 set -u
 mkdir -p gpurun_out/s3
 {
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_known_answers.py tests/test_asm_kernel.py -q -m gpu -x -k "jaro or Jaro or jw or winkler or randomized or f64" -n 4 2>&1 | tail -5
-export AB_MINLEN=1 AB_LIBS="librfgpu_JA.so librfgpu.so"
+export AB_MINLEN=1 AB_LIBS="librfgpu_JB.so librfgpu.so librfgpu_JP.so librfgpu_JT.so librfgpu_JV.so"
+AB_N=20000000 bash tools/ab.sh jwrag jarorag
 AB_N=100000000 bash tools/ab.sh jwrag
-AB_N=20000000 bash tools/ab.sh jwrag jarorag jwragc9
 bash tools/ab.sh jw
-} > gpurun_out/s3/jaro_cols.txt 2>&1
-cat gpurun_out/s3/jaro_cols.txt
+} > gpurun_out/s3/jaro_tile.txt 2>&1
+cat gpurun_out/s3/jaro_tile.txt
