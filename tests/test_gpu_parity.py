@@ -1672,7 +1672,7 @@ def test_bench_c5_preset_same_answer_for_every_world_size():
     d1 = _bench_json(base, env)
     assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["config"]["rccl_ranks"] == 1
     assert d1["parity"]["mismatches"] == 0 and d1["parity"]["checked"] == 60 and "cpu_baseline" in d1
-    assert d1["roofline"]["survey_8d"]["bytes_per_pair"] == 64 and d1["roofline"]["algorithmic_bytes_per_pair"] == 8  # (the 8-symbol head plane)
+    assert d1["roofline"]["survey_8d"]["bytes_per_pair"] == 64 and d1["roofline"]["algorithmic_bytes_per_pair"] == 6  # (the 8-symbol head plane at 6 bits per symbol: 62 stored symbols)
     d2 = _bench_json(base + ["--gpus", "2"], dict(env, RF_BENCH_BACKEND="gloo"))
     assert d2["n_gpus"] == 2 and d2["parity"]["mismatches"] == 0
     assert d2["config"]["topk_checksum"] == d1["config"]["topk_checksum"] and d2["config"]["topk_best"] == d1["config"]["topk_best"]
