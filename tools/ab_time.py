@@ -11,7 +11,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "lev64"
 n = int(os.environ.get("AB_N", 100_000_000))
 cfg = {
     "lev64": ("levenshtein", 64, 64, {}), "lev32": ("levenshtein", 32, 64, {}), "indel": ("indel", 64, 64, {}), "osa": ("osa", 64, 64, {}),
-    "lev256": ("levenshtein", 256, 256, {}), "indel256": ("indel", 256, 256, {}), "levrag": ("levenshtein", 64, 64, {}), "levragc3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "indelragc12": ("indel", 64, 64, {"score_cutoff": 12}), "indelrag": ("indel", 64, 64, {}), "osarag": ("osa", 64, 64, {}), "lev32rag": ("levenshtein", 32, 64, {}), "indel128": ("indel", 128, 64, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
+    "lev256": ("levenshtein", 256, 256, {}), "lev128": ("levenshtein", 128, 128, {}), "lev192": ("levenshtein", 192, 192, {}), "indel256": ("indel", 256, 256, {}), "levrag": ("levenshtein", 64, 64, {}), "levragc3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "indelragc12": ("indel", 64, 64, {"score_cutoff": 12}), "indelrag": ("indel", 64, 64, {}), "osarag": ("osa", 64, 64, {}), "lev32rag": ("levenshtein", 32, 64, {}), "indel128": ("indel", 128, 64, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
     "jaro": ("jaro", 64, 64, {}), "jwrag": ("jaro_winkler", 64, 64, {}), "jarorag": ("jaro", 64, 64, {}), "jwc9": ("jaro_winkler", 64, 64, {"score_cutoff": 0.9}),
     "jwragc9": ("jaro_winkler", 64, 64, {"score_cutoff": 0.9}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
 }

@@ -35,6 +35,9 @@ import sys
 
 ADDR = [30, 31, 32, 33]
 ADDS32 = os.environ.get("RF_GEN_ADDS32", "0") == "1"
+# RF_GEN_ADDC: which kinds shift HP through the carry flag (v_addc_co_u32 pairs, VCC = the carry between halves and between words) instead of
+# v_lshl_add_u64 + one v_lshrrev_b32 per inter-word carry: "w" = the multi-word kernels, "64" = the single-word kernel, "w,64" = both
+ADDC = set(filter(None, os.environ.get("RF_GEN_ADDC", "w").replace(" ", "").split(",")))  # (measured: profiles/levw_addc_r04.txt -- "w" +4.6 % on configs[2], "64" -1.4 %)
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
         ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
@@ -93,7 +96,8 @@ class Kind:
                     "e": [f"v_bitop3_b32 v{E[h]}, v{A[h]}, v{VP[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],       # e = (sum ^ VP) | x
                     "hp": [f"v_bitop3_b32 v{HP[h]}, v{VN[h]}, v{E[h]}, v{VP[h]} bitop3:0xf1" for h in (0, 1)],     # HP = VN | ~(e | VP)
                     "hn": [f"v_and_b32 v{HN[h]}, v{E[h]}, v{VP[h]}" for h in (0, 1)],                              # HN = e & VP
-                    "hq": [f"v_lshl_add_u64 {pr(HP)}, {pr(HP)}, 1, 1"],                                            # HP' = (HP << 1) + 1
+                    "hq": ([f"s_mov_b64 vcc, -1", f"v_addc_co_u32 v{HP[0]}, vcc, v{HP[0]}, v{HP[0]}, vcc", f"v_addc_co_u32 v{HP[1]}, vcc, v{HP[1]}, v{HP[1]}, vcc"]
+                           if "64" in ADDC else [f"v_lshl_add_u64 {pr(HP)}, {pr(HP)}, 1, 1"]),                     # HP' = (HP << 1) + 1
                     "t": [f"v_bitop3_b32 v{T[h]}, v{E[h]}, v{VN[h]}, v{HP[h]} bitop3:0x01" for h in (0, 1)],       # T = ~(e | VN | HP')
                     "vn": [f"v_bitop3_b32 v{VN[h]}, v{HP[h]}, v{E[h]}, v{VN[h]} bitop3:0xe0" for h in (0, 1)],     # VN' = HP' & (e | VN)
                     "vp": [f"v_lshl_add_u64 {pr(VP)}, {pr(HN)}, 1, {pr(T)}"]}[tok]                                 # VP' = (HN << 1) + T
@@ -153,8 +157,11 @@ class BlockKind(Kind):
         one address + immediate plane offsets, each with the 2-way conflicts of the single-word gather -- the compiled kernels'
         32-byte rows (2 ds_read_b128) put 62 symbols on 8 row positions of the 64 banks: 72 % of their LDS cycles were conflicts;
       * two row slots (2 x 2W VGPRs), look-ahead of 2 columns; chunk ring of 2 (a chunk is 16 x ~230 cycles: one load ahead is plenty);
-      * carries as values: hp_c in the low half of a register pair whose high half stays zero (the addend of v_lshl_add_u64),
-        hn_c OR-ed into the next word's table row and into T's low half (VP' = (HN << 1) + (T | hn_c): bit 0 of T is clear there);
+      * carries: hp_c never leaves the carry flag -- HP' = HP + HP + carry as two v_addc_co_u32 per word, VCC set to all ones at the top of
+        the column (word 0's + 1) and handed from each word's high half to the next word's low half (nothing else in a column touches
+        VCC); this replaced v_lshl_add_u64 + one half-rate v_lshrrev_b32 ..., 31 per inter-word carry: configs[2] 2.83 -> 2.96 Gpairs/s
+        (RF_GEN_ADDC; the single-word kernel LOSES 1.4 % by the same change and keeps v_lshl_add_u64).  hn_c as a value, OR-ed into
+        the next word's table row and into T's low half (VP' = (HN << 1) + (T | hn_c): bit 0 of T is clear there);
       * 64 VGPRs = 8 wavefronts per SIMD: v14..21 ring, v22..23 gather addresses, v24..39 row slots, v40..47 VP, v48..55 VN,
         v56..63 A E HN HP, v6..7 T, v[8:9] / v[12:13] carry pairs, v11 / v3 hn_c."""
     TOKENS = "x a S e hp hn hnc hpc hq t tor vn vp".split()
@@ -179,6 +186,8 @@ class BlockKind(Kind):
         HPC, HNC = [(8, 9), (12, 13)], [11, 3]
         R = self.slots[i % 2]
         L = [f"s_waitcnt lgkmcnt({W})"]  # this column's W reads have arrived; the next column's W may still be in flight
+        if "w" in ADDC:
+            L.append("s_mov_b64 vcc, -1")
         for w in range(W):
             VP_, VN_, PM = self.VP[w], self.VN[w], R[w]
             ops = {"x": [f"v_or_b32 v{PM[0]}, v{HNC[(w - 1) % 2]}, v{PM[0]}"] if w else [],                                  # x |= hn_c (levenshtein.rs:847)
@@ -188,8 +197,11 @@ class BlockKind(Kind):
                    "hp": [f"v_bitop3_b32 v{HP_[h]}, v{VN_[h]}, v{E_[h]}, v{VP_[h]} bitop3:0xf1" for h in (0, 1)],
                    "hn": [f"v_and_b32 v{HN_[h]}, v{E_[h]}, v{VP_[h]}" for h in (0, 1)],
                    "hnc": [f"v_lshrrev_b32 v{HNC[w % 2]}, 31, v{HN_[1]}"] if w + 1 < W else [],                            # :857-858
-                   "hpc": [f"v_lshrrev_b32 v{HPC[w % 2][0]}, 31, v{HP_[1]}"] if w + 1 < W else [],
-                   "hq": [f"v_lshl_add_u64 {pr(HP_)}, {pr(HP_)}, 1, " + ("1" if w == 0 else pr(HPC[(w - 1) % 2]))],      # :865-866
+                   "hpc": [f"v_lshrrev_b32 v{HPC[w % 2][0]}, 31, v{HP_[1]}"] if w + 1 < W and "w" not in ADDC else [],
+                   # (RF_GEN_ADDC: HP' = HP + HP + carry, two v_addc_co_u32; VCC starts the column as all ones -- the + 1 of word 0 -- and
+                   # leaves word w's high half as word w + 1's carry: nothing else in a column touches VCC)
+                   "hq": ([f"v_addc_co_u32 v{HP_[h]}, vcc, v{HP_[h]}, v{HP_[h]}, vcc" for h in (0, 1)] if "w" in ADDC else
+                          [f"v_lshl_add_u64 {pr(HP_)}, {pr(HP_)}, 1, " + ("1" if w == 0 else pr(HPC[(w - 1) % 2]))]),      # :865-866
                    "t": [f"v_bitop3_b32 v{T_[h]}, v{E_[h]}, v{VN_[h]}, v{HP_[h]} bitop3:0x01" for h in (0, 1)],
                    "tor": [f"v_or_b32 v{T_[0]}, v{HNC[(w - 1) % 2]}, v{T_[0]}"] if w else [],
                    "vn": [f"v_bitop3_b32 v{VN_[h]}, v{HP_[h]}, v{E_[h]}, v{VN_[h]} bitop3:0xe0" for h in (0, 1)],
