@@ -2610,7 +2610,7 @@ def test_full_size_c5_one_billion_candidates_through_the_rccl_path():
     assert d["parity"]["mismatches"] == 0 and d["parity"]["checked"] == 1000
     # the cutoff path, not a full scan: the step's first look streams the 8-symbol head plane (no timing assertion: under pytest-xdist this
     # process shares the GPU with other tests)
-    assert d["roofline"]["algorithmic_bytes_per_pair"] == 8 and d["roofline"]["survey_8d"]["bytes_per_pair"] == 64
+    assert d["roofline"]["algorithmic_bytes_per_pair"] == 6 and d["roofline"]["survey_8d"]["bytes_per_pair"] == 64
 
 
 def _run_ranks_script(nproc, env_extra, port):
@@ -2799,3 +2799,29 @@ def test_five_streams_share_the_tile_lists_of_one_corpus():
     torch.cuda.synchronize()
     for out in outs:
         assert (out.cpu().numpy().view(np.uint32) == exp).all()
+
+
+def test_mid_size_corpora_on_the_tiles_per_wavefront_grid():
+    """The grid of a full scan is sized by tiles per wavefront (rf_scan.hip scan_grid_full: 5 per wavefront, floor 32 / cap 256 workgroups
+    per CU, rounded up to a multiple of 8).  The small parity tests run one tile per wavefront, the 100 M tests and multitile_check.py
+    run at the cap; the regime in between -- 10.5 M .. 84 M candidates, a rounded grid with workgroups past the last tile -- gets its own
+    full-array oracle compare here: 12 M ragged candidates (every length 1..64; by origin / gather / window paths as the library picks
+    them at this size) and 12 M single-length ones, every asm scan + the compiled Indel and Jaro-Winkler scans."""
+    rng = np.random.default_rng(20260930)
+    n = 12_000_000
+    lens = rng.integers(1, 65, size=n).astype(np.uint64)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    data = synth.ALNUM[rng.integers(0, 62, size=int(offsets[-1]))]
+    q64, q20 = synth.query(64, 0xC0FFEE02), synth.query(20, 0xC0FFEE05)
+    for r in range(0, n, 100_003):  # a few near-duplicates so that the values are not all "far"
+        a, b = int(offsets[r]), int(offsets[r + 1])
+        data[a:b] = np.frombuffer(q64, dtype=np.uint8)[: b - a]
+    for metric, q in (("levenshtein", q64), ("levenshtein", q20), ("osa", q64), ("indel", q64), ("jaro_winkler", q64)):
+        _check_many(metric, q, data, offsets, "similarity" if metric == "jaro_winkler" else "distance")
+    # single-length corpus of the same size (the uniform kernels, out[slot] stores)
+    ln = 40
+    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(ln))
+    rows = data[: n * ln]
+    for metric, q in (("levenshtein", q64), ("jaro_winkler", q64)):
+        _check_many(metric, q, rows, offs, "similarity" if metric == "jaro_winkler" else "distance")
