@@ -45,6 +45,17 @@ def ragged(candidates: Iterable) -> tuple[np.ndarray, np.ndarray]:
     return data, offsets
 
 
+def _check_offsets(offsets: np.ndarray, n_elems: int) -> None:
+    """The C ABI takes a pointer and trusts the offsets (rf_corpus_pack reads elems[offsets[i] .. offsets[i + 1])); this mirror owns the
+    buffer, so it can refuse offsets that run past it instead of letting the packer read beyond the array."""
+    if offsets.ndim != 1 or len(offsets) < 1:
+        raise ValueError("offsets must be a 1-D array of n + 1 entries")
+    if len(offsets) > 1 and bool(np.any(offsets[1:] < offsets[:-1])):
+        raise ValueError("offsets must not decrease")
+    if int(offsets[-1]) > n_elems or int(offsets[0]) > n_elems:
+        raise ValueError(f"offsets run to element {int(offsets[-1])} of a buffer of {n_elems}")
+
+
 class Corpus:
     """Owns an `rf_corpus*`.  Build with one of the constructors below; results of `*_many` calls always
     come back in the original candidate order."""
@@ -76,6 +87,7 @@ class Corpus:
     def from_ragged(cls, data: np.ndarray, offsets: np.ndarray, device: int = 0) -> "Corpus":
         data = np.ascontiguousarray(data, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check_offsets(offsets, len(data))
         h = C.c_void_p()
         N.check(N.lib().rf_corpus_pack(data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, device, C.byref(h)))
         return cls(h.value, device)
@@ -102,6 +114,7 @@ class Corpus:
     def from_ragged_u32(cls, data: np.ndarray, offsets: np.ndarray, device: int = 0) -> "Corpus":
         data = np.ascontiguousarray(data, dtype=np.uint32)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check_offsets(offsets, len(data))
         h = C.c_void_p()
         N.check(N.lib().rf_corpus_pack_u32(data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, device, C.byref(h)))
         return cls(h.value, device)

@@ -195,3 +195,14 @@ def test_no_exception_can_cross_the_c_abi():
     header = open(os.path.join(os.path.dirname(root), "..", "include", "rfgpu.h")).read()
     declared = set(re.findall(r"^rf_status (rf_[a-z_0-9]+)\(", header, flags=re.M))
     assert seen == len(declared) >= 30, (seen, len(declared))
+
+
+def test_python_mirror_refuses_offsets_that_run_past_the_buffer():
+    """rf_corpus_pack trusts its offsets (a C pointer has no length); the Python mirror owns the buffer and refuses bad offsets before the
+    packer can read beyond the array (found by a test of this repo whose offsets outran its data: SIGSEGV in the packer)."""
+    data = np.zeros(100, dtype=np.uint8)
+    for offs in ([0, 50, 101], [0, 60, 40], [200, 200]):
+        with pytest.raises(ValueError):
+            rf.Corpus.from_ragged(data, np.array(offs, dtype=np.uint64))
+        with pytest.raises(ValueError):
+            rf.Corpus.from_ragged_u32(data.astype(np.uint32), np.array(offs, dtype=np.uint64))

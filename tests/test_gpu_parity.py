@@ -2822,6 +2822,7 @@ def test_mid_size_corpora_on_the_tiles_per_wavefront_grid():
     # single-length corpus of the same size (the uniform kernels, out[slot] stores)
     ln = 40
     offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(ln))
-    rows = data[: n * ln]
+    rows = synth.ALNUM[rng.integers(0, 62, size=n * ln)]
+    rows[: 64] = np.frombuffer(q64, dtype=np.uint8)  # (candidate 0 = the query's first 40 symbols, candidate 1 its next 24 + ...)
     for metric, q in (("levenshtein", q64), ("jaro_winkler", q64)):
         _check_many(metric, q, rows, offs, "similarity" if metric == "jaro_winkler" else "distance")
