@@ -163,7 +163,7 @@ class BlockKind(Kind):
         (RF_GEN_ADDC; the single-word kernel LOSES 1.4 % by the same change and keeps v_lshl_add_u64).  hn_c as a value, OR-ed into
         the next word's table row and into T's low half (VP' = (HN << 1) + (T | hn_c): bit 0 of T is clear there);
       * 64 VGPRs = 8 wavefronts per SIMD: v14..21 ring, v22..23 gather addresses, v24..39 row slots, v40..47 VP, v48..55 VN,
-        v56..63 A E HN HP, v6..7 T, v[8:9] / v[12:13] carry pairs, v11 / v3 hn_c."""
+        v56..63 A E HN HP, v6..7 T, v[8:9] / v[12:13] hp_c pairs of the RF_GEN_ADDC-less form (idle since the carry flag took hp_c over), v11 / v3 hn_c."""
     TOKENS = "x a S e hp hn hnc hpc hq t tor vn vp".split()
 
     def __init__(self, W, nop_mask):
