@@ -805,6 +805,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
         } else {
             p.out = d_tmp;
             p.orig = corpus->d_slot_ident;
+            p.slot_store = 1;  // (d_slot_ident is kPad on padding lanes and the identity elsewhere; the temporary has n_slots entries)
             p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
             p.mixed_end = 0;
             p.n = (uint32_t)corpus->n_slots;

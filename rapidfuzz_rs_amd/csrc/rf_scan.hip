@@ -617,8 +617,10 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
         // process cursor
         TileView cur_tile = load_tile<kUniform>(p, t);
         uint32_t c = 0;
+        // (gather path: `orig` is the identity, 4 bytes per slot the HBM-bound scans can leave unread -- ScanParams::slot_store)
+        const bool by_slot = !kUniform && p.slot_store && !topk;
         uint32_t idx = cur_tile.slot0 + lane;
-        if (!kUniform) idx = p.orig[idx];
+        if (!kUniform && !by_slot) idx = p.orig[idx];
         State st;
         st.init();
         bool done = false;
@@ -657,7 +659,7 @@ __device__ __forceinline__ void stream_body(const ScanParams& p, typename State:
             cur_tile = load_tile<kUniform>(p, t);
             c = 0;
             idx = cur_tile.slot0 + lane;
-            if (!kUniform) idx = p.orig[idx];
+            if (!kUniform && !by_slot) idx = p.orig[idx];
             st.init();
         };
         while (!done) {

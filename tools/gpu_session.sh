@@ -1,15 +1,9 @@
 #!/bin/bash
-# scratch: one wavefront per workgroup for the compiled Jaro kernels on ragged corpora (RF_JARO_WPB=1) against four
+# scratch: parity of the build with ScanParams::slot_store: the gather-path tests, then the randomized campaigns with every corpus on the gather path
 set -u
 mkdir -p gpurun_out/s3
-export AB_MINLEN=1 RF_LIB=$PWD/rapidfuzz_rs_amd/librfgpu.so
-run() { echo -n "wpb=$1 tiles_per_wave=$2 n=$AB_N "; RF_JARO_WPB=$1 RF_SCAN_TILES_PER_WAVE=$2 python tools/ab_time.py $3 2>/dev/null | tail -1; }
-{
-for n in 20000000 100000000; do export AB_N=$n
-  for rep in 1 2; do run 4 5 jwrag; run 1 5 jwrag; done
-  run 1 3 jwrag; run 1 8 jwrag; run 1 12 jwrag
-done
-export AB_N=20000000
-run 4 5 jwragc9; run 1 5 jwragc9
-} > gpurun_out/s3/jaro_wpb.txt 2>&1
-cat gpurun_out/s3/jaro_wpb.txt
+(timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -n 4 -k "gather or many_tiles or mid_size or query_lengths_ragged or osa_ragged or cutoff_length_window or distinct_lengths or large_scan or full_size_c3" 2>&1 | grep -v "^  File\|^Extension" | tail -4) > gpurun_out/s3/gputests6.log 2>&1
+cat gpurun_out/s3/gputests6.log
+fz() { echo "== fuzz $*"; env "$@" RF_FUZZ_SEEDS=6000 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -n 4 -x -k "randomized" 2>&1 | grep -v "^\.\|^$" | tail -4; }
+{ fz RF_UNSCATTER_MIN=1; fz RF_UNSCATTER_MIN=1 RF_TILE_ORDER=0 RF_GATHER_WINDOWS=0; } > gpurun_out/s3/fuzz5.log 2>&1
+cat gpurun_out/s3/fuzz5.log
