@@ -304,7 +304,10 @@ def tile_start(K, uniform, sfx):
     if uniform:
         L.append(f"v_lshl_add_u32 {V_IDX}, {S_T}, 6, {V_LANE}")  # slot = index
     else:  # idx = orig[slot0 + lane]: lands long before the tile's epilogue (the next step's counted vmcnt wait is younger)
-        L += [f"s_lshl_b32 {T0}, {S_SLOT0}, 2", f"s_lshr_b32 {T1}, {S_SLOT0}, 30", f"s_add_u32 {T2}, s12, {T0}", f"s_addc_u32 {T3}, s13, {T1}"]
+        # (flags bit 1, "slot store": `orig` is the slot -> slot identity of the gather path, rf_api_scan.hip run_many -- the load then reads the map's first
+        # line over and over (same instruction stream, same vmcnt accounting, no HBM traffic) and the epilogue makes the index itself)
+        L += [f"s_lshl_b32 {T0}, {S_SLOT0}, 2", f"s_lshr_b32 {T1}, {S_SLOT0}, 30", f"s_bitcmp1_b32 {S_FLAGS}, 1", f"s_cselect_b32 {T0}, 0, {T0}",
+              f"s_cselect_b32 {T1}, 0, {T1}", f"s_add_u32 {T2}, s12, {T0}", f"s_addc_u32 {T3}, s13, {T1}"]
         if getattr(K, "W", 1) > 1:  # (v3 carries hn_c there: lane * 4 is made on the spot)
             L += [f"v_lshlrev_b32 v6, 2, {V_LANE}", f"global_load_dword {V_IDX}, v6, s[54:55]"]
         else:
@@ -407,6 +410,8 @@ def kernel(K, uniform):
         # the index load was issued at the tile's start, BEHIND the ring loads then in flight: all but the newest operation done
         # means it has landed (the over-wait is the chunk fetched one step ago, which the next block needs at its column 8 anyway)
         L.append("s_waitcnt vmcnt(1)")
+        # slot store (flags bit 1): index = slot, every lane stores (padding lanes own a slot of the temporary)
+        L += [f"s_bitcmp1_b32 {S_FLAGS}, 1", "s_cbranch_scc0 Lnoslot_%=", f"v_add_u32 {V_IDX}, {S_SLOT0}, {V_LANE}", "Lnoslot_%=:"]
     L += [f"v_cmp_gt_u32 vcc, {S_N}, {V_IDX}" if uniform else f"v_cmp_ne_u32 vcc, -1, {V_IDX}",                 # real candidates only
           f"v_lshl_add_u64 v[8:9], v[4:5], 2, {S_OUT}",
           "s_cmp_eq_u64 vcc, -1", "s_cbranch_scc0 Lpart_%=",
