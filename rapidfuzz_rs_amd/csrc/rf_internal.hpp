@@ -108,7 +108,7 @@ struct ScanParams {
     uint32_t exp_flags;             // measurement switches (bit 0: RF_EXP_NOHBM on the head-plane scans)
     uint32_t slot_store;            // 1: `orig` is the slot -> slot identity of the gather path (run_many: results into a slot-ordered temporary), so a kernel may
                                     // store lane l of a tile at out[slot0 + l] without reading it -- padding lanes included: the temporary has a slot for them and
-                                    // the gather never looks there.  A hint: kernels that do not know it read `orig` as always (stream_body honours it)
+                                    // the gather never looks there.  A hint: kernels that do not know it read `orig` as always (stream_body and the asm tiles kernels honour it)
     uint32_t xcd_deal;              // 1: workgroup w takes the tiles of virtual workgroup (w % 8) * (grid / 8) + w / 8: consecutive tiles stay on one XCD (one L2)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
     uint32_t jaro_split;   // first EXACT tile that needs the multi-word jaro path (n_exact = none)
