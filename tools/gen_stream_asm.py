@@ -36,7 +36,8 @@ import sys
 ADDR = [30, 31, 32, 33]
 ADDS32 = os.environ.get("RF_GEN_ADDS32", "0") == "1"
 # RF_GEN_ADDC: which kinds shift HP through the carry flag (v_addc_co_u32 pairs, VCC = the carry between halves and between words) instead of
-# v_lshl_add_u64 + one v_lshrrev_b32 per inter-word carry: "w" = the multi-word kernels, "64" = the single-word kernel, "w,64" = both
+# v_lshl_add_u64 + one v_lshrrev_b32 per inter-word carry: "w" = the multi-word kernels, "64" = the single-word kernel, "w,64" = both;
+# "n" (with "w"): hn_c through a second carry chain over s[70:71] as well -- measured 17 % slower, an experiment knob only
 ADDC = set(filter(None, os.environ.get("RF_GEN_ADDC", "w").replace(" ", "").split(",")))  # (measured: profiles/levw_addc_r04.txt -- "w" +4.6 % on configs[2], "64" -1.4 %)
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
@@ -190,22 +191,27 @@ class BlockKind(Kind):
             L.append("s_mov_b64 vcc, -1")
         for w in range(W):
             VP_, VN_, PM = self.VP[w], self.VN[w], R[w]
-            ops = {"x": [f"v_or_b32 v{PM[0]}, v{HNC[(w - 1) % 2]}, v{PM[0]}"] if w else [],                                  # x |= hn_c (levenshtein.rs:847)
+            NC = "n" in ADDC  # (experiment) hn_c through an SGPR-pair carry chain as well: HN + HN + carry, VP' = that | T, hn_c made a value by 0 + 0 + carry
+            ops = {"x": ([f"v_addc_co_u32_e64 v{HNC[0]}, s[56:57], 0, 0, s[70:71]", f"v_or_b32 v{PM[0]}, v{HNC[0]}, v{PM[0]}"] if NC else
+                         [f"v_or_b32 v{PM[0]}, v{HNC[(w - 1) % 2]}, v{PM[0]}"]) if w else [],                                  # x |= hn_c (levenshtein.rs:847)
                    "a": [f"v_and_b32 v{A_[h]}, v{PM[h]}, v{VP_[h]}" for h in (0, 1)],
                    "S": [f"v_lshl_add_u64 {pr(A_)}, {pr(A_)}, 0, {pr(VP_)}"],
                    "e": [f"v_bitop3_b32 v{E_[h]}, v{A_[h]}, v{VP_[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],
                    "hp": [f"v_bitop3_b32 v{HP_[h]}, v{VN_[h]}, v{E_[h]}, v{VP_[h]} bitop3:0xf1" for h in (0, 1)],
                    "hn": [f"v_and_b32 v{HN_[h]}, v{E_[h]}, v{VP_[h]}" for h in (0, 1)],
-                   "hnc": [f"v_lshrrev_b32 v{HNC[w % 2]}, 31, v{HN_[1]}"] if w + 1 < W else [],                            # :857-858
+                   "hnc": [f"v_lshrrev_b32 v{HNC[w % 2]}, 31, v{HN_[1]}"] if w + 1 < W and not NC else [],                            # :857-858
                    "hpc": [f"v_lshrrev_b32 v{HPC[w % 2][0]}, 31, v{HP_[1]}"] if w + 1 < W and "w" not in ADDC else [],
                    # (RF_GEN_ADDC: HP' = HP + HP + carry, two v_addc_co_u32; VCC starts the column as all ones -- the + 1 of word 0 -- and
                    # leaves word w's high half as word w + 1's carry: nothing else in a column touches VCC)
                    "hq": ([f"v_addc_co_u32 v{HP_[h]}, vcc, v{HP_[h]}, v{HP_[h]}, vcc" for h in (0, 1)] if "w" in ADDC else
                           [f"v_lshl_add_u64 {pr(HP_)}, {pr(HP_)}, 1, " + ("1" if w == 0 else pr(HPC[(w - 1) % 2]))]),      # :865-866
                    "t": [f"v_bitop3_b32 v{T_[h]}, v{E_[h]}, v{VN_[h]}, v{HP_[h]} bitop3:0x01" for h in (0, 1)],
-                   "tor": [f"v_or_b32 v{T_[0]}, v{HNC[(w - 1) % 2]}, v{T_[0]}"] if w else [],
+                   "tor": [f"v_or_b32 v{T_[0]}, v{HNC[(w - 1) % 2]}, v{T_[0]}"] if w and not NC else [],
                    "vn": [f"v_bitop3_b32 v{VN_[h]}, v{HP_[h]}, v{E_[h]}, v{VN_[h]} bitop3:0xe0" for h in (0, 1)],
-                   "vp": [f"v_lshl_add_u64 {pr(VP_)}, {pr(HN_)}, 1, {pr(T_)}"]}
+                   "vp": ([(f"v_addc_co_u32_e64 v{HN_[0]}, s[70:71], v{HN_[0]}, v{HN_[0]}, s[70:71]" if w else f"v_add_co_u32_e64 v{HN_[0]}, s[70:71], v{HN_[0]}, v{HN_[0]}"),
+                           f"v_addc_co_u32_e64 v{HN_[1]}, s[70:71], v{HN_[1]}, v{HN_[1]}, s[70:71]",
+                           f"v_or_b32 v{VP_[0]}, v{HN_[0]}, v{T_[0]}", f"v_or_b32 v{VP_[1]}, v{HN_[1]}, v{T_[1]}"] if NC else
+                          [f"v_lshl_add_u64 {pr(VP_)}, {pr(HN_)}, 1, {pr(T_)}"])}
             for j, tok in enumerate(self.TOKENS):
                 L += ops[tok]
                 if ops[tok] and self.nop_mask >> j & 1:
