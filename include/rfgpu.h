@@ -254,6 +254,11 @@ rf_status rf_stream_many_u32(const rf_comparator *c, const char *path, rf_op op,
                              size_t out_capacity, uint64_t segment_bytes, int device);
 rf_status rf_stream_many_f64(const rf_comparator *c, const char *path, rf_op op, const rf_args *args, double *out,
                              size_t out_capacity, uint64_t segment_bytes, int device);
+/* Gives back what the library keeps per PROCESS between calls (no reference analogue; a long-lived service calls it after a burst):
+ * the streamed scans' three pinned-host + device buffer sets (unless a streamed scan is running: its sets stay) and every block of
+ * the stream-ordered scratch allocator whose last use has completed.  What a corpus keeps (acceleration structures, per-stream
+ * temporaries) goes with rf_corpus_free.  Always RF_OK; later calls re-allocate what they need. */
+rf_status rf_release_caches(void);
 
 /* ---- one-vs-many ------------------------------------------------------------------------------
  * out[i] = scorer.<op>_with_args(candidate_i, &args) for every candidate, original order.

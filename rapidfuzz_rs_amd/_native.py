@@ -71,7 +71,7 @@ SYMBOLS = [
     "rf_corpus_device", "rf_many_u32", "rf_many_f64", "rf_one_u32", "rf_one_f64", "rf_many_multi_u32", "rf_many_multi_f64", "rf_topk_u32", "rf_topk_f64", "rf_topk_keys_device", "rf_topk_merge_keys_device", "rf_topk_merge_u32",
     "rf_probe_issue_rate", "rf_topk_allgather_merge",
     "rf_topk_entries_device", "rf_topk_merge_entries_device", "rf_topk_allgather_merge_entries", "rf_topk_merge_entries",
-    "rf_topk_entry_score_u32", "rf_topk_entry_score_f64", "rf_probe_core_clock",
+    "rf_topk_entry_score_u32", "rf_topk_entry_score_f64", "rf_probe_core_clock", "rf_release_caches",
 ]
 
 
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
     L.rf_stream_many_u32.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(RfArgs), vp, C.c_size_t, C.c_uint64, C.c_int]
     L.rf_stream_many_f64.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(RfArgs), vp, C.c_size_t, C.c_uint64, C.c_int]
     L.rf_corpus_file_count.argtypes = [C.c_char_p, C.POINTER(C.c_size_t)]
+    L.rf_release_caches.argtypes = []
     L.rf_corpus_pack_rows_device.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp, C.POINTER(vp)]
     L.rf_corpus_free.argtypes = [vp]
     L.rf_corpus_layout_host.argtypes = [vp, vp, C.c_size_t, C.POINTER(RfHostLayout)]

@@ -993,7 +993,10 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_slot_of) (void)hipFree(c->d_slot_of);
     if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
     if (c->d_window_table) (void)hipFree(c->d_window_table);
-    for (const rf_corpus::GatherTmp& t : c->gather_tmp) (void)hipFree(t.ptr);
+    for (const rf_corpus::GatherTmp& t : c->gather_tmp) {
+        if (t.done) (void)hipEventDestroy(t.done);
+        (void)hipFree(t.ptr);
+    }
     for (const rf_corpus::TileList& t : c->tile_lists) {
         (void)hipFree(t.ptr);
         (void)hipEventDestroy(t.done);

@@ -403,6 +403,20 @@ try {
 }
 RF_ABI_CATCH
 
+// The streamed scans' buffer sets (pinned host + device payload buffers), kept between calls per process (stream_many below says why);
+// rf_release_caches() gives them back.
+struct KeptSets {
+    std::mutex mu;
+    uint8_t *d_data[3] = {nullptr, nullptr, nullptr}, *h_data[3] = {nullptr, nullptr, nullptr};
+    uint64_t cap = 0;
+    int device = -1;
+};
+static KeptSets& kept_sets()
+{
+    static KeptSets k;
+    return k;
+}
+
 // One pass of `scorer.<op>` over a corpus FILE that need not fit in HBM.  Segments are tile ranges of at most
 // `segment_bytes` of payload; two device buffer sets alternate, segment k+1 is read and uploaded (copy stream) while
 // segment k is scanned (compute stream).  The result vector (n x 4 or 8 bytes) does live on the device for the pass.
@@ -508,13 +522,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     // The buffer sets (pinned host + device payload buffers) are KEPT between calls, per process: allocating and pinning 3 x 256 MiB
     // costs 50-80 ms, a third of a 6.4 GB streamed scan (profiles/stream_r04.txt).  One streamed scan at a time uses the kept sets (a
     // concurrent one allocates its own); a call that needs larger segments replaces them.  RF_STREAM_KEEP=0: allocate and free per call.
-    struct KeptSets {
-        std::mutex mu;
-        uint8_t *d_data[3] = {nullptr, nullptr, nullptr}, *h_data[3] = {nullptr, nullptr, nullptr};
-        uint64_t cap = 0;
-        int device = -1;
-    };
-    static KeptSets kept;
+    KeptSets& kept = kept_sets();
     static const bool keep_sets = [] { const char* e = getenv("RF_STREAM_KEEP"); return !e || atoi(e) != 0; }();
     std::unique_lock<std::mutex> kept_lock(kept.mu, std::defer_lock);
     const bool use_kept = keep_sets && kept_lock.try_lock();
@@ -568,7 +576,15 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     std::atomic<int> res_err{(int)hipSuccess};
     hipStream_t s_res = nullptr;
     std::thread res_thread;
-    const bool early_results = ok && meta.uniform && hip_ok(hipStreamCreateWithFlags(&s_res, hipStreamNonBlocking));
+    // From here to the join below nothing may unwind past the result thread (a joinable std::thread destroyed during unwinding is
+    // std::terminate) or past the buffers, events and streams released after it: an exception (bad_alloc from the per-segment vectors, a
+    // std::string of set_error) is parked, the common clean-up runs, and it is rethrown for RF_ABI_CATCH to translate.
+    std::exception_ptr pending;
+    bool early_results = false;
+    const auto t_loop = std::chrono::steady_clock::now();
+    double s_wait = 0.0, s_read = 0.0;
+    try {
+    early_results = ok && meta.uniform && hip_ok(hipStreamCreateWithFlags(&s_res, hipStreamNonBlocking));
     if (early_results)
         res_thread = std::thread([&] {
             (void)hipSetDevice(device);
@@ -591,8 +607,6 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     std::vector<TileDesc> seg_tiles;
     static const bool stream_timing = getenv("RF_STREAM_TIMING") != nullptr;  // phase times of a streamed scan on stderr
     using clk = std::chrono::steady_clock;
-    const auto t_loop = clk::now();
-    double s_wait = 0.0, s_read = 0.0;
     if (stream_timing) std::fprintf(stderr, "[rf stream] set-up (streams, device + pinned buffers, None pre-fill) %.1f ms\n", std::chrono::duration<double, std::milli>(t_loop - t_enter).count());
     for (size_t k = 0; ok && status == RF_OK && k + 1 < cuts.size(); ++k) {
         Slot& sl = slot[k % kSlots];
@@ -682,6 +696,11 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
             res_cv.notify_one();
         }
     }
+    } catch (...) {
+        pending = std::current_exception();
+    }
+    using clk = std::chrono::steady_clock;
+    static const bool stream_timing = getenv("RF_STREAM_TIMING") != nullptr;  // phase times of a streamed scan on stderr
     const auto t_tail = clk::now();
     if (res_thread.joinable()) {
         {
@@ -692,7 +711,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
         res_thread.join();
         if (res_err.load() != (int)hipSuccess) ok = hip_ok((hipError_t)res_err.load());
     }
-    if (ok && status == RF_OK && !early_results)
+    if (!pending && ok && status == RF_OK && !early_results)
         ok = hip_ok(hipMemcpyAsync(out_host, d_out, meta.n * elem, hipMemcpyDeviceToHost, s_comp)) && hip_ok(hipStreamSynchronize(s_comp));
     if (stream_timing)
         std::fprintf(stderr, "[rf stream] %zu segments: loop %.1f ms (reads %.1f, waits for a free buffer set %.1f), drain + results to the host %.1f ms\n", cuts.size() - 1,
@@ -720,6 +739,7 @@ static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op,
     if (s_copy) (void)hipStreamDestroy(s_copy);
     if (s_comp) (void)hipStreamDestroy(s_comp);
     if (s_res) (void)hipStreamDestroy(s_res);
+    if (pending) std::rethrow_exception(pending);
     if (status != RF_OK) return status;
     if (!ok) {
         set_error(std::string("rf_stream_many: ") + hipGetErrorString(e));
@@ -738,6 +758,28 @@ rf_status rf_stream_many_f64(const rf_comparator* c, const char* path, rf_op op,
                              uint64_t segment_bytes, int device)
 try {
     return stream_many(c, path, op, args, out, out_capacity, true, segment_bytes, device);
+}
+RF_ABI_CATCH
+rf_status rf_release_caches(void)
+try {
+    {   // the kept buffer sets of the streamed scans (a scan in flight holds the lock: its sets stay)
+        KeptSets& kept = kept_sets();
+        std::unique_lock<std::mutex> lk(kept.mu, std::try_to_lock);
+        if (lk.owns_lock()) {
+            int prev = 0;
+            const bool switched = kept.device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != kept.device && hipSetDevice(kept.device) == hipSuccess;
+            for (int b = 0; b < 3; ++b) {
+                if (kept.d_data[b]) (void)hipFree(kept.d_data[b]);
+                if (kept.h_data[b]) (void)hipHostFree(kept.h_data[b]);
+                kept.d_data[b] = kept.h_data[b] = nullptr;
+            }
+            kept.cap = 0;
+            kept.device = -1;
+            if (switched) (void)hipSetDevice(prev);
+        }
+    }
+    scratch_trim();  // parked blocks of the stream-ordered scratch allocator whose work is done
+    return RF_OK;
 }
 RF_ABI_CATCH
 rf_status rf_corpus_file_count(const char* path, size_t* n)

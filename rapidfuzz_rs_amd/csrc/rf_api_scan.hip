@@ -15,6 +15,7 @@ rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const 
         return RF_ERR_INVALID_ARG;
     }
     std::memset(p, 0, sizeof(*p));
+    p->max_stored_sym = 0xFFFFFFFFu;  // not known (run_many lowers it)
     p->len1 = (uint32_t)c->s1.size();
     p->words = (uint32_t)pm_stride(c);  // row stride of the device table
     p->op = (uint32_t)op;
@@ -255,6 +256,8 @@ rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const 
         p->band = 1;
         p->band_k = p->cutoff_u32 / p->factor;
     }
+    // a distance cutoff also narrows the band of the multi-word scans (rf_stream_asm.hip): raw distances beyond it only have to come out beyond it
+    if (*raw == RAW_LEV && p->finish == FIN_LEV && p->factor >= 1 && op == RF_OP_DISTANCE && !f64_out && p->has_cutoff) p->trim_k1 = p->cutoff_u32 / p->factor + 1;
     if (c->words > (size_t)kMaxWords && !p->band) {
         // beyond 512 symbols: the multi-sweep kernel (8 words per sweep, carries parked in an HBM scratch strip)
         if (c->words > 0x00FFFFFFu) {
@@ -713,6 +716,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     static const size_t unscatter_min = [] { const char* e = getenv("RF_UNSCATTER_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
     void* d_tmp = nullptr;
     bool tmp_owned = false;                 // d_tmp is this call's own stream-ordered allocation
+    rf_corpus::GatherTmp* kept_tmp = nullptr;  // ... or this kept buffer of the corpus (valid while tmp_lock is held)
     std::unique_lock<std::mutex> tmp_lock;  // held while a kept temporary's scan + gather are enqueued
     // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 12 bytes per
     // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
@@ -786,12 +790,19 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                     }
                 }
                 d_tmp = t.ptr;
+                kept_tmp = &t;
+                if (t.done && hipStreamWaitEvent(st, t.done, 0) != hipSuccess) (void)hipGetLastError();
                 break;
             }
         if (!d_tmp && ea == hipSuccess) {
             if (corpus->gather_tmp.size() < 4) {
                 ea = hipMalloc(&d_tmp, tmp_bytes);
-                if (ea == hipSuccess) corpus->gather_tmp.push_back({st, d_tmp, tmp_bytes});
+                if (ea == hipSuccess) {
+                    hipEvent_t ev = nullptr;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) (void)hipGetLastError(), ev = nullptr;
+                    corpus->gather_tmp.push_back({st, d_tmp, tmp_bytes, ev});
+                    kept_tmp = &corpus->gather_tmp.back();
+                }
             } else {
                 ea = scratch_alloc(&d_tmp, tmp_bytes, st);
                 tmp_owned = true;
@@ -843,6 +854,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                                                               (uint32_t)corpus->n, f64_out, st)
                                        : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
         if (tmp_owned) (void)scratch_free(d_tmp, st);
+        else if (kept_tmp && kept_tmp->done && hipEventRecord(kept_tmp->done, st) != hipSuccess) (void)hipGetLastError();
         if (tmp_lock.owns_lock()) tmp_lock.unlock();
     }
     if (e == hipSuccess && out_mem == RF_MEM_HOST) {

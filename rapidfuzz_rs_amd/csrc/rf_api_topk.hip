@@ -172,10 +172,8 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
         e = launch_scan(raw, ps, st, nullptr);
     }
     if (e == hipSuccess) e = launch_scan(raw, p, st, nullptr);
-    if (e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) {
-        e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        (void)scratch_free(d_all, st);
-    }
+    if (e == hipSuccess && out_all && out_all_mem == RF_MEM_HOST) e = hipMemcpyAsync(out_all, d_all, corpus->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (out_all && out_all_mem == RF_MEM_HOST) (void)scratch_free(d_all, st);  // (on the failure paths too: ADVICE r4)
     if (e != hipSuccess) {
         // the scratch may be left half-armed: drop it so the next call starts from a fresh one
         std::lock_guard<std::mutex> lock(owner->scratch_mu);

@@ -141,6 +141,8 @@ struct rf_corpus {
         hipStream_t stream;
         void* ptr;
         size_t bytes;
+        hipEvent_t done;  // recorded behind the gather that last read the buffer; the next use makes its stream wait for it (free on the stream the
+                          // buffer was used on, and what orders a NEW stream that was handed a destroyed stream's handle value: ADVICE r4)
     };
     mutable std::vector<GatherTmp> gather_tmp;
     mutable std::mutex gather_enqueue_mu;

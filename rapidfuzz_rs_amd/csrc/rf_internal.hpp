@@ -136,6 +136,9 @@ struct ScanParams {
     uint32_t narrow_look;           // early_lean_kernel: run the columns before the first look on 32-bit words (set by the launcher)
     // band_kernel (rf_band.hip): long query, raw distance cutoff band_k with 2 * band_k + 1 <= 64; band = 1 selects it
     uint32_t band, band_k;
+    // the multi-word asm scans (rf_stream_asm.hip, tools/gen_stream_asm.py BlockKind): raw distances above trim_k1 - 1 need not be exact (they must come out above
+    // it), which narrows the Ukkonen band the kernels trim their word-columns to; 0 = no bound beyond max(len1, len2)
+    uint32_t trim_k1;
     // top-k mode (topk_k != 0): no per-candidate output, one k-entry key list per workgroup
     uint32_t topk_k;       // <= 64
     uint32_t topk_desc;    // 1: larger score is better (similarity)

@@ -9,9 +9,11 @@
 //
 // What this is: a caching allocator with the one rule that makes stream-ordered reuse safe.  scratch_free(p, st) records an event on
 // `st` behind everything enqueued so far and parks the block; scratch_alloc(bytes, st) may take a parked block
-//   * at once if it was parked on the SAME stream (stream order: the new use is enqueued behind the old one), or
+//   * at once if it was parked on the SAME stream handle -- behind a hipStreamWaitEvent(st, done) that costs the host nothing: on the
+//     stream the block was parked on it is a no-op (stream order already puts the new use behind the old one), and on a NEW stream
+//     that got a destroyed stream's handle value it is what orders the two (round 5), or
 //   * if its event has completed (hipEventQuery), whatever the stream;
-// otherwise it calls hipMalloc.  Nothing here ever waits.  Parked bytes are bounded (RF_SCRATCH_CACHE_MB, default 1024): beyond the
+// otherwise it calls hipMalloc.  The host never waits here.  Parked bytes are bounded (RF_SCRATCH_CACHE_MB, default 1024): beyond the
 // bound the completed blocks are released, largest first; blocks larger than the bound are released as soon as their event is done.
 // The pool is per process and device, never destroyed (the HIP runtime may be gone before static destructors run).
 #include "rf_host.hpp"
@@ -106,6 +108,10 @@ hipError_t scratch_alloc(void** out, size_t bytes, hipStream_t st)
             if (b.device != device || b.bytes < bytes || b.bytes > 2 * bytes + (1u << 20)) continue;
             if (b.stream != st && !completed(b)) continue;
             if (best < 0 || b.bytes < P.parked[(size_t)best].bytes) best = (long)i;
+        }
+        if (best >= 0 && !completed(P.parked[(size_t)best]) && hipStreamWaitEvent(st, P.parked[(size_t)best].done, 0) != hipSuccess) {
+            (void)hipGetLastError();  // cannot order this stream behind the block's last use: leave it parked
+            best = -1;
         }
         if (best >= 0) {
             Block b = P.parked[(size_t)best];

@@ -2366,6 +2366,25 @@ def test_asm_kernels_many_tiles_per_wavefront(mode):
     assert "FAILURES 0" in r.stdout
 
 
+@pytest.mark.parametrize("mode", ["rows", "ragged", "ragged-gather-all", "ragged-storage-order", "ragged-by-origin-all", "ragged-by-origin-no-deal", "ragged-default-grid"])
+def test_multiword_levenshtein_band_trimming(mode):
+    """the multi-word Levenshtein scans skip the words outside the Ukkonen band of each 16-column chunk
+    (tools/gen_stream_asm.py BlockKind; levenshtein.rs:810-825, :906-985).  tests/band_check.py walks the band's edges: block shifts
+    of the query by 63..65 / 127..129 / len1 / 2 +- 1 symbols cut to every candidate length 1..300, 4-symbol strings, prefixes and
+    suffixes, for queries of 100 / 192 / 200 / 256 symbols, all four ops, distance cutoffs that narrow the band, the top-16; every value
+    against the oracle, through every forced path of the asm tiles kernels, several tiles per wavefront."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **MULTITILE_ENV.get(mode, {}))
+    if mode != "ragged-default-grid":
+        env["RF_SCAN_BLOCKS_PER_CU_FULL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "band_check.py"), mode.split("-")[0]], capture_output=True, text=True, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-4000:], r.stderr[-2000:])
+    assert "FAILURES 0" in r.stdout
+
+
 def test_full_size_osa_and_query32_properties():
     """VERDICT r2 item 1a, second half: osa1_asm_kernel and lev32_asm_kernel at BASELINE's full 100 M x 64 size (6 tiles per
     wavefront with the product grid), like test_full_size_c2_properties does for lev1_asm_kernel: an oracle-checked prefix plus

@@ -35,14 +35,15 @@ import sys
 
 ADDR = [30, 31, 32, 33]
 ADDS32 = os.environ.get("RF_GEN_ADDS32", "0") == "1"
-# RF_GEN_ADDC: which kinds shift HP through the carry flag (v_addc_co_u32 pairs, VCC = the carry between halves and between words) instead of
-# v_lshl_add_u64 + one v_lshrrev_b32 per inter-word carry: "w" = the multi-word kernels, "64" = the single-word kernel, "w,64" = both;
-# "n" (with "w"): hn_c through a second carry chain over s[70:71] as well -- measured 17 % slower, an experiment knob only
-ADDC = set(filter(None, os.environ.get("RF_GEN_ADDC", "w").replace(" ", "").split(",")))  # (measured: profiles/levw_addc_r04.txt -- "w" +4.6 % on configs[2], "64" -1.4 %)
+# RF_GEN_ADDC=64: the single-word kernel shifts HP through the carry flag too (v_addc_co_u32 pairs instead of v_lshl_add_u64) -- measured -1.4 %, an
+# experiment knob.  The multi-word kernels always do (+4.6 % on configs[2], profiles/levw_addc_r04.txt; their hn_c through a second carry chain over an
+# SGPR pair was built and measured 17 % slower in round 4 and is gone from the generator).
+ADDC = set(filter(None, os.environ.get("RF_GEN_ADDC", "").replace(" ", "").split(",")))
+BAND = os.environ.get("RF_GEN_BAND", "1") == "1"  # 0: the multi-word kernels run every word in every column (round 4's kernels: the A/B)
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
         ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
-        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4), ("pad0", 4), ("valid_w", 32), ("pad1", 4)]  # valid_w: (lo, hi) row masks of words 0..3 (multi-word kernels)
+        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4), ("band_k", 4), ("valid_w", 32), ("pad1", 4)]  # valid_w: (lo, hi) row masks of words 0..3; band_k: distances above it need not be exact (multi-word kernels)
 # SGPR map
 S_DATA, S_TILES, S_ORIG, S_PM, S_SIGMA, S_OUT = "s[8:9]", "s[10:11]", "s[12:13]", "s[14:15]", "s[16:17]", "s[18:19]"
 (S_TBEGIN, S_TEND, S_N, S_ULEN, S_UBYTES, S_LEN1, S_VS, S_VM, S_VR, S_FLIP, S_CFLIP, S_VLO) = [f"s{i}" for i in range(20, 32)]
@@ -56,6 +57,7 @@ S_K, S_Q, S_R8, S_SH = "s48", "s49", "s50", "s51"
 T0, T1, T2, T3 = "s52", "s53", "s54", "s55"
 S_DESC = "s[60:63]"  # TileDesc {u64 data_off, u32 len, u32 slot0}
 S_NEXT, S_AFTER, S_EXEC = "s64", "s65", "s[66:67]"  # S_AFTER: this step follows a tile epilogue whose store (and index load) are still younger than the ring
+S_KBAND, S_DHI, S_DLO, S_LIVE = "s80", "s81", "s82", "s83"  # multi-word kernels: the Ukkonen band (BlockKind)
 V_LANE, V_OFF16, V_OFF4, V_IDX, V_ZERO, V_KS = "v1", "v2", "v3", "v4", "v5", "v10"
 
 
@@ -161,11 +163,24 @@ class BlockKind(Kind):
       * carries: hp_c never leaves the carry flag -- HP' = HP + HP + carry as two v_addc_co_u32 per word, VCC set to all ones at the top of
         the column (word 0's + 1) and handed from each word's high half to the next word's low half (nothing else in a column touches
         VCC); this replaced v_lshl_add_u64 + one half-rate v_lshrrev_b32 ..., 31 per inter-word carry: configs[2] 2.83 -> 2.96 Gpairs/s
-        (RF_GEN_ADDC; the single-word kernel LOSES 1.4 % by the same change and keeps v_lshl_add_u64).  hn_c as a value, OR-ed into
-        the next word's table row and into T's low half (VP' = (HN << 1) + (T | hn_c): bit 0 of T is clear there);
+        (round 4, profiles/levw_addc_r04.txt; the single-word kernel LOSES 1.4 % by the same change and keeps v_lshl_add_u64).  hn_c as a
+        value, one register per word boundary, OR-ed into the next word's table row and into T's low half (VP' = (HN << 1) + (T | hn_c):
+        bit 0 of T is clear there);
+      * THE BAND (round 5; the reference's Ukkonen trimming, levenshtein.rs:810-825, :906-985).  D <= k := min(band_k, max(len1, len2)), so
+        a cell (i, j) with |i - j| + |(len1 - len2) - (i - j)| > k lies on no path that matters: with s = (k - |len1 - len2|) / 2 only rows
+        j + dlo <= i <= j + dhi, dlo = min(0, len1 - len2) - s, dhi = max(0, len1 - len2) + s, have to be right in column j.  Word w is
+        NOT RUN in a 16-column chunk in which all of its rows are outside that range (S_LIVE, one bit per word, made from the chunk index by
+        a dozen scalar instructions; every word block of a column sits behind s_bitcmp1 + s_cbranch).  No other instruction changes:
+        a word that has not started yet still holds its initial state VP = ~0, VN = 0 (D[i][j] = D[64w][j] + (i - 64w): an upper bound, which
+        is all the cells outside the band have to be -- the min-recurrence is monotone); a word that is done keeps its last deltas, and the
+        first live word above it runs with hp_c = 1 (VCC still holds the column's initial all-ones) and hn_c = 0 (the boundary register is
+        cleared at the top of the chunk): its top boundary rises by one per column, again an upper bound, and exactly the one that keeps the
+        epilogue's len2 + sum of popcounts right (frozen deltas + one per skipped column).  Results <= k are exact, results beyond are > k.
+        At 256 x 256 that is word 3 in columns 1..64 and word 0 in columns 193..256: 12.5 % of the word-columns.
       * 64 VGPRs = 8 wavefronts per SIMD: v14..21 ring, v22..23 gather addresses, v24..39 row slots, v40..47 VP, v48..55 VN,
-        v56..63 A E HN HP, v6..7 T, v[8:9] / v[12:13] hp_c pairs of the RF_GEN_ADDC-less form (idle since the carry flag took hp_c over), v11 / v3 hn_c."""
-    TOKENS = "x a S e hp hn hnc hpc hq t tor vn vp".split()
+        v56..63 A E HN HP, v6..7 T, v11 / v3 / v12 hn_c of words 0 / 1 / 2 (v8, v9, v13 idle)."""
+    TOKENS = "x a S e hp hn hnc hq t tor vn vp".split()
+    HNC = [11, 3, 12]
 
     def __init__(self, W, nop_mask):
         Kind.__init__(self, f"levw{W}", 64, 2, [14, 18], range(40, 56), nop_mask)
@@ -174,6 +189,7 @@ class BlockKind(Kind):
         self.slots = [[(24 + 8 * sl + 2 * w, 25 + 8 * sl + 2 * w) for w in range(W)] for sl in range(2)]
         self.VP = [(40 + 2 * w, 41 + 2 * w) for w in range(W)]
         self.VN = [(48 + 2 * w, 49 + 2 * w) for w in range(W)]
+        self.uid = 0
 
     def gather(self, j, use, nxt):
         src = use + (j // 4) if j < 16 else nxt + ((j - 16) // 4)
@@ -181,48 +197,61 @@ class BlockKind(Kind):
         x = f"v_lshlrev_b32_sdwa v{a}, {V_KS}, v{src} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{j % 4}"
         return [x] + [f"ds_read_b64 {pr(self.slots[j % 2][w])}, v{a}" + (f" offset:{2048 * w}" if w else "") for w in range(self.W)]
 
+    def tile_band(self):
+        """per tile: S_DHI = dhi + 15, S_DLO = dlo of the band (class comment) from len1, len2 and band_k"""
+        return [f"s_sub_i32 {T0}, {S_LEN1}, {S_LEN2}", f"s_max_u32 {T1}, {S_LEN1}, {S_LEN2}", f"s_min_u32 {T1}, {T1}, {S_KBAND}",  # k
+                f"s_abs_i32 {T2}, {T0}", f"s_sub_i32 {T1}, {T1}, {T2}", f"s_max_i32 {T1}, {T1}, 0", f"s_lshr_b32 {T1}, {T1}, 1",    # s (0 when nothing can pass)
+                f"s_max_i32 {T2}, {T0}, 0", f"s_add_i32 {S_DHI}, {T2}, {T1}", f"s_add_i32 {S_DHI}, {S_DHI}, 15",
+                f"s_min_i32 {T2}, {T0}, 0", f"s_sub_i32 {S_DLO}, {T2}, {T1}"]
+
+    def chunk_band(self):
+        """per chunk c = S_C (columns 16c + 1 .. 16c + 16): S_LIVE = the words [lo, hi) with a row inside the band in one of these columns,
+        hi = min(W, (16c + 16 + dhi - 1) / 64 + 1), lo = max(0, 16c + 1 + dlo - 1) / 64; the hn_c of every word that does not run is zero"""
+        L = [f"s_lshl_b32 {T0}, {S_C}, 4", f"s_add_u32 {T1}, {T0}, {S_DHI}", f"s_lshr_b32 {T1}, {T1}, 6", f"s_add_u32 {T1}, {T1}, 1", f"s_min_u32 {T1}, {T1}, {self.W}",
+             f"s_add_i32 {T2}, {T0}, {S_DLO}", f"s_max_i32 {T2}, {T2}, 0", f"s_lshr_b32 {T2}, {T2}, 6",
+             f"s_bfm_b32 {S_LIVE}, {T1}, 0", f"s_bfm_b32 {T2}, {T2}, 0", f"s_andn2_b32 {S_LIVE}, {S_LIVE}, {T2}"]
+        for w in range(self.W - 1):
+            L += [f"s_bitcmp1_b32 {S_LIVE}, {w}", f"s_cselect_b32 {T0}, -1, 0", f"v_and_b32 v{self.HNC[w]}, {T0}, v{self.HNC[w]}"]
+        return L
+
     def column(self, i, gather=()):
-        W = self.W
+        W, HNC = self.W, self.HNC
         A_, E_, HN_, HP_, T_ = (56, 57), (58, 59), (60, 61), (62, 63), (6, 7)
-        HPC, HNC = [(8, 9), (12, 13)], [11, 3]
         R = self.slots[i % 2]
-        L = [f"s_waitcnt lgkmcnt({W})"]  # this column's W reads have arrived; the next column's W may still be in flight
-        if "w" in ADDC:
-            L.append("s_mov_b64 vcc, -1")
+        # this column's W reads have arrived; the next column's W may still be in flight.  VCC = all ones: word 0's (or the first live word's) + 1
+        L = [f"s_waitcnt lgkmcnt({W})", "s_mov_b64 vcc, -1"]
+        self.uid += 1
         for w in range(W):
             VP_, VN_, PM = self.VP[w], self.VN[w], R[w]
-            NC = "n" in ADDC  # (experiment) hn_c through an SGPR-pair carry chain as well: HN + HN + carry, VP' = that | T, hn_c made a value by 0 + 0 + carry
-            ops = {"x": ([f"v_addc_co_u32_e64 v{HNC[0]}, s[56:57], 0, 0, s[70:71]", f"v_or_b32 v{PM[0]}, v{HNC[0]}, v{PM[0]}"] if NC else
-                         [f"v_or_b32 v{PM[0]}, v{HNC[(w - 1) % 2]}, v{PM[0]}"]) if w else [],                                  # x |= hn_c (levenshtein.rs:847)
+            ops = {"x": [f"v_or_b32 v{PM[0]}, v{HNC[w - 1]}, v{PM[0]}"] if w else [],                                      # x |= hn_c (levenshtein.rs:847)
                    "a": [f"v_and_b32 v{A_[h]}, v{PM[h]}, v{VP_[h]}" for h in (0, 1)],
                    "S": [f"v_lshl_add_u64 {pr(A_)}, {pr(A_)}, 0, {pr(VP_)}"],
                    "e": [f"v_bitop3_b32 v{E_[h]}, v{A_[h]}, v{VP_[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],
                    "hp": [f"v_bitop3_b32 v{HP_[h]}, v{VN_[h]}, v{E_[h]}, v{VP_[h]} bitop3:0xf1" for h in (0, 1)],
                    "hn": [f"v_and_b32 v{HN_[h]}, v{E_[h]}, v{VP_[h]}" for h in (0, 1)],
-                   "hnc": [f"v_lshrrev_b32 v{HNC[w % 2]}, 31, v{HN_[1]}"] if w + 1 < W and not NC else [],                            # :857-858
-                   "hpc": [f"v_lshrrev_b32 v{HPC[w % 2][0]}, 31, v{HP_[1]}"] if w + 1 < W and "w" not in ADDC else [],
-                   # (RF_GEN_ADDC: HP' = HP + HP + carry, two v_addc_co_u32; VCC starts the column as all ones -- the + 1 of word 0 -- and
-                   # leaves word w's high half as word w + 1's carry: nothing else in a column touches VCC)
-                   "hq": ([f"v_addc_co_u32 v{HP_[h]}, vcc, v{HP_[h]}, v{HP_[h]}, vcc" for h in (0, 1)] if "w" in ADDC else
-                          [f"v_lshl_add_u64 {pr(HP_)}, {pr(HP_)}, 1, " + ("1" if w == 0 else pr(HPC[(w - 1) % 2]))]),      # :865-866
+                   "hnc": [f"v_lshrrev_b32 v{HNC[w]}, 31, v{HN_[1]}"] if w + 1 < W else [],                                  # :857-858
+                   # HP' = HP + HP + carry, two v_addc_co_u32; VCC leaves word w's high half as word w + 1's carry (:865-866)
+                   "hq": [f"v_addc_co_u32 v{HP_[h]}, vcc, v{HP_[h]}, v{HP_[h]}, vcc" for h in (0, 1)],
                    "t": [f"v_bitop3_b32 v{T_[h]}, v{E_[h]}, v{VN_[h]}, v{HP_[h]} bitop3:0x01" for h in (0, 1)],
-                   "tor": [f"v_or_b32 v{T_[0]}, v{HNC[(w - 1) % 2]}, v{T_[0]}"] if w and not NC else [],
+                   "tor": [f"v_or_b32 v{T_[0]}, v{HNC[w - 1]}, v{T_[0]}"] if w else [],
                    "vn": [f"v_bitop3_b32 v{VN_[h]}, v{HP_[h]}, v{E_[h]}, v{VN_[h]} bitop3:0xe0" for h in (0, 1)],
-                   "vp": ([(f"v_addc_co_u32_e64 v{HN_[0]}, s[70:71], v{HN_[0]}, v{HN_[0]}, s[70:71]" if w else f"v_add_co_u32_e64 v{HN_[0]}, s[70:71], v{HN_[0]}, v{HN_[0]}"),
-                           f"v_addc_co_u32_e64 v{HN_[1]}, s[70:71], v{HN_[1]}, v{HN_[1]}, s[70:71]",
-                           f"v_or_b32 v{VP_[0]}, v{HN_[0]}, v{T_[0]}", f"v_or_b32 v{VP_[1]}, v{HN_[1]}, v{T_[1]}"] if NC else
-                          [f"v_lshl_add_u64 {pr(VP_)}, {pr(HN_)}, 1, {pr(T_)}"])}
+                   "vp": [f"v_lshl_add_u64 {pr(VP_)}, {pr(HN_)}, 1, {pr(T_)}"]}
+            skip = f"Lb{self.uid}w{w}_%="
+            if BAND:
+                L += [f"s_bitcmp1_b32 {S_LIVE}, {w}", f"s_cbranch_scc0 {skip}"]
             for j, tok in enumerate(self.TOKENS):
                 L += ops[tok]
                 if ops[tok] and self.nop_mask >> j & 1:
                     L.append("s_nop 0")
+            if BAND:
+                L.append(f"{skip}:")
         return L + list(gather)
 
-    def state_init(self):  # levenshtein.rs:454-455 per word; the carry pairs' high halves are zero for the whole tile
+    def state_init(self):  # levenshtein.rs:454-455 per word
         L = []
         for w in range(self.W):
             L += [f"v_mov_b32 v{self.VP[w][0]}, -1", f"v_mov_b32 v{self.VP[w][1]}, -1", f"v_mov_b32 v{self.VN[w][0]}, 0", f"v_mov_b32 v{self.VN[w][1]}, 0"]
-        return L + ["v_mov_b32 v9, 0", "v_mov_b32 v13, 0"]
+        return L
 
 
 def dispatch(lo, hi, L, sfx):  # binary tree of scalar compares over k in [lo, hi]
@@ -307,6 +336,8 @@ def tile_start(K, uniform, sfx):
     """per tile: the finishing map's constant term, the candidate index of every lane, the recurrence state"""
     L = [f"s_add_u32 {T0}, {S_LEN1}, {S_LEN2}", f"s_max_u32 {T1}, {S_LEN1}, {S_LEN2}", f"s_mul_i32 {T0}, {T0}, {S_VS}", f"s_mul_i32 {T1}, {T1}, {S_VM}",
          f"s_add_u32 {S_V0}, {T0}, {T1}"]
+    if getattr(K, "W", 1) > 1 and BAND:
+        L += K.tile_band()
     if uniform:
         L.append(f"v_lshl_add_u32 {V_IDX}, {S_T}, 6, {V_LANE}")  # slot = index
     else:  # idx = orig[slot0 + lane]: lands long before the tile's epilogue (the next step's counted vmcnt wait is younger)
@@ -342,7 +373,7 @@ def kernel(K, uniform):
               "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6",
               "ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
     else:  # row i of the host table (W consecutive words) -> word w to plane w, row sigma(i)
-        L += [f"s_load_dwordx8 s[72:79], %[kp], {off['valid_w']}",
+        L += [f"s_load_dwordx8 s[72:79], %[kp], {off['valid_w']}", f"s_load_dword {S_KBAND}, %[kp], {off['band_k']}",
               f"global_load_ubyte v6, v1, {S_SIGMA}", f"v_mul_u32_u24 v7, {8 * W}, v1"]
         L += [f"global_load_dwordx2 v[{24 + 2 * w}:{25 + 2 * w}], v7, {S_PM}" + (f" offset:{8 * w}" if w else "") for w in range(W)]
         L += ["s_waitcnt vmcnt(0)", "v_lshlrev_b32 v6, 3, v6"]
@@ -390,6 +421,8 @@ def kernel(K, uniform):
               f"s_cmp_ge_u32 {T0}, 16", f"s_cbranch_scc1 Lkok_{P}_%=",
               f"s_sub_u32 {S_K}, 16, {T0}", f"s_lshr_b32 {S_Q}, {S_K}, 2", f"s_and_b32 {S_R8}, {S_K}, 3", f"s_lshl_b32 {S_R8}, {S_R8}, 3",
               f"s_sub_u32 {S_SH}, 32, {S_R8}", f"Lkok_{P}_%=:"]
+        if W > 1 and BAND:
+            L += K.chunk_band()
         L += step(K, P, extra)
         L += [f"s_add_u32 {S_C}, {S_C}, 1", f"s_cmp_lt_u32 {S_C}, {S_NCH}"]
         if P + 1 < R:
@@ -445,7 +478,7 @@ KINDS = [
     Kind("lev64", 64, 8, [14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RING64", "3")):], range(60, 64), int(os.environ.get("RF_GEN_MASK64", "0x1B3"), 0)),  # (RF_GEN_*: experiment knobs, tools/build_stream_variant.sh)
     Kind("lev32", 32, 8, [42, 46, 22, 26][: int(os.environ.get("RF_GEN_RING32", "4"))], (60, 61), int(os.environ.get("RF_GEN_MASK32", "0x80"), 0)),
     Kind("osa", 64, 7, RING3, range(58, 64), 0x613),
-] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x0826"), 0)) for W in (2, 3, 4)]  # s_nop behind a, S, hn, vn: best of 22 placements (profiles/levw_nop_masks_r04.txt)
+] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x0426"), 0)) for W in (2, 3, 4)]  # s_nop behind a, S, hn, vn: best of 22 placements (profiles/levw_nop_masks_r04.txt)
 
 
 def main():
@@ -456,7 +489,7 @@ def main():
         out.append(f"#define RF_STREAM_ARG_{name.upper()} {o}")
         o += size
     out.append(f"#define RF_STREAM_ARGS_SIZE {o}")
-    out.append('#define RF_STREAM_CLOBBERS ' + ", ".join(f'"v{r}"' for r in range(1, 64)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 80) if r != 32)
+    out.append('#define RF_STREAM_CLOBBERS ' + ", ".join(f'"v{r}"' for r in range(1, 64)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 84) if r != 32)
                + ', "vcc", "scc", "memory"')  # (exec is restored to all ones before the body ends)
     for K in KINDS:
         for uniform in (True, False):
