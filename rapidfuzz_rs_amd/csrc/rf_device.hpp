@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rf_internal.hpp"
 
@@ -104,17 +105,46 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 //   D[len1][len2] = len2 + popcount(VP & valid) - popcount(VN & valid)        (D[0][len2] = len2)
 // which removes the per-column mask tests from the hot loop.
 // ---------------------------------------------------------------------------------------------------
+// does a State trim its columns to a band (LevState<W >= 2>::set_band)?
+template <class S, class = void>
+struct has_band : std::false_type {};
+template <class S>
+struct has_band<S, std::void_t<decltype(S::kHasBand)>> : std::bool_constant<S::kHasBand> {};
+
 template <int W>
 struct LevState {
     using Word = uint64_t;
     static constexpr int kWords = W;
     uint64_t vp[W], vn[W];
+    // W >= 2, the Ukkonen band (round 5; the reference's trimming, levenshtein.rs:810-825, :906-985; tools/gen_stream_asm.py BlockKind has the
+    // derivation): bit w = word w runs in the current 16-column chunk.  Wavefront-uniform; all ones (what init() leaves, and what every kernel
+    // that never calls set_band() computes with: the tests below fold away) = every word in every column.
+    static constexpr bool kHasBand = W >= 2;
+    uint32_t live;
     __device__ __forceinline__ void init()
     {
+        live = ~0u;
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             vp[w] = ~0ull;  // levenshtein.rs:454-455
             vn[w] = 0;
+        }
+    }
+    // chunk c (columns 16c + 1 .. 16c + 16) of a tile of candidates of len2 symbols: D <= k := min(k_bound, max(len1, len2)), so only rows
+    // j + dlo <= i <= j + dhi of column j can lie on a path that matters (s = (k - |len1 - len2|) / 2, dlo = min(0, len1 - len2) - s,
+    // dhi = max(0, len1 - len2) + s).  A word outside is not run: one that has not started keeps VP = ~0, VN = 0, one that is done keeps its
+    // deltas and the first live word above it runs with hp_c = 1, hn_c = 0 -- upper bounds of the cells they stand for (the recurrence is
+    // monotone), and result() stays len2 + the popcounts.  Values <= k are exact, values beyond come out > k.  All arguments are scalars.
+    __device__ __forceinline__ void set_band(uint32_t len1, uint32_t len2, uint32_t k_bound, uint32_t c)
+    {
+        if constexpr (W >= 2) {
+            const int32_t d = (int32_t)len1 - (int32_t)len2;
+            const uint32_t k = min(k_bound, max(len1, len2));
+            const int32_t s = max((int32_t)k - (d < 0 ? -d : d), 0) >> 1;
+            const int32_t dhi = max(d, 0) + s, dlo = min(d, 0) - s;
+            const uint32_t hi = min((uint32_t)W, ((uint32_t)((int32_t)(16u * c + 15u) + dhi) >> 6) + 1u);
+            const uint32_t lo = (uint32_t)max((int32_t)(16u * c) + dlo, 0) >> 6;
+            live = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
         }
     }
     // One column, after algebra on levenshtein.rs:467-484 (D0 is never materialised):
@@ -134,6 +164,7 @@ struct LevState {
         uint32_t hp_c = 1, hn_c = 0;  // levenshtein.rs:824-825
 #pragma unroll
         for (int w = 0; w < W; ++w) {
+            if (W >= 2 && !((live >> w) & 1u)) continue;     // outside the band (set_band): a skipped word leaves hp_c = 1, hn_c = 0 to the next
             uint64_t x = pm_row[w];
             if (w > 0) x |= hn_c;                            // :847
             const uint64_t p = vp[w], n = vn[w];

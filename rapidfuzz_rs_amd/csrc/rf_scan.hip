@@ -72,6 +72,9 @@ __device__ __forceinline__ void scan_body(const ScanParams& p, typename State::W
                     nxt = load_chunk(nsrc + lane);
                 }
                 const uint32_t cols = len2 - c * kChunk;
+#ifndef RF_NO_COMPILED_BAND  // (measurement builds: tools/build_scan_variants.sh "-DRF_NO_COMPILED_BAND=" 1 -- round 4's multi-word scan for the A/B)
+                if constexpr (has_band<State>::value) st.set_band(p.len1, len2, p.trim_k1 ? p.trim_k1 - 1u : 0xFFFFFFFFu, c);
+#endif
                 if (cols >= kChunk) {
                     if (early && c == 0) {
                         // first chance to stop: an unrelated candidate gains almost one edit per column, so the first look is

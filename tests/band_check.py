@@ -6,7 +6,7 @@ words whose rows lie outside the Ukkonen band of a chunk of columns (the referen
 exact only if no optimal path leaves the band, so the corpus here is built to walk the band's EDGES: block shifts of the query by 63..65,
 127..129 and len1 / 2 - 1 .. len1 / 2 + 1 symbols (the optimal path runs along the diagonal |i - j| = shift), cut or padded to every candidate
 length 1..300, plus 4-symbol random strings (many equally good paths, wandering), prefixes / suffixes of the query, and plain random rows.
-Queries of 100 / 192 / 200 / 256 symbols; every candidate length 1..300 (70 of each: one exact tile + leftovers for the mixed tiles);
+Queries of 100 / 192 / 200 / 256 symbols (the asm scans) and 320 / 449 / 512 (the compiled LevState<5..8>, whose step() takes the same band); every candidate length 1..300 (1..len1 + 90 for the longer queries; 70 of each: one exact tile + leftovers for the mixed tiles);
 single-length corpora of a few lengths for the uniform kernels; no cutoff, distance cutoffs that reach the asm scans (they narrow the
 band), similarity and the normalized ops.  Every value is compared with the oracle.
 
@@ -39,7 +39,7 @@ def candidate(rng, q, len2, kind):
         row = np.resize(np.roll(q, -sh), len2)
     elif kind == 9:  # tail of the query first, then noise
         sh = int(rng.integers(1, len1))
-        row = np.resize(np.concatenate([q[sh:], rng.integers(48, 123, size=300, dtype=np.uint8)]), len2)
+        row = np.resize(np.concatenate([q[sh:], rng.integers(48, 123, size=700, dtype=np.uint8)]), len2)
     elif kind == 10:  # noise first, then the head of the query
         k = int(rng.integers(0, len2 + 1))
         row = np.concatenate([rng.integers(48, 123, size=k, dtype=np.uint8), np.resize(q, len2 - k)])
@@ -73,7 +73,7 @@ def check(tag, q, corpus, host=None, ragged=None):
         if len(bad):
             bad_ops.append((opname, len(bad), bad[:4].tolist()))
     len1 = len(q)
-    for cut in sorted({len1 // 2 + 40, (3 * len1) // 4, (7 * len1) // 8, len1 - 1, len1, len1 + 30, 299, 1000}):
+    for cut in sorted({40, len1 // 3, len1 // 2 + 40, (3 * len1) // 4, (7 * len1) // 8, len1 - 1, len1, len1 + 30, 299, 1000}):  # (the smaller ones: the early-out kernels)
         got, exp = bc.many(N.OP_DISTANCE, corpus, score_cutoff=cut), expect(N.OP_DISTANCE, score_cutoff=cut)
         bad = same(got, exp)
         if len(bad):
@@ -90,23 +90,23 @@ def check(tag, q, corpus, host=None, ragged=None):
 
 rng = np.random.default_rng(5)
 mode = sys.argv[1] if len(sys.argv) > 1 else "ragged"
-for len1 in (100, 192, 200, 256):
+for len1 in (100, 192, 200, 256, 320, 449, 512):  # W = 2 .. 4: the asm scans; 5 .. 8: the compiled LevState<W>
     q = np.random.default_rng(len1).integers(48, 123, size=len1, dtype=np.uint8)
     if mode == "rows":
-        for len2 in (64, 100, 129, 200, 256, 300):
+        for len2 in (64, 100, 129, 200, 256, 300) + ((449, 512, 600) if len1 > 256 else ()):
             host = np.stack([candidate(rng, q, len2, r % 14) for r in range(3000)])
             corpus = rf.Corpus.from_device_rows(torch.from_numpy(host).cuda())
             check(f"rows len2={len2}", bytes(q), corpus, host=host)
             del corpus
     else:
-        rows = [candidate(rng, q, len2, r % 14) for len2 in range(1, 301) for r in range(70)]
+        rows = [candidate(rng, q, len2, r % 14) for len2 in range(1, max(301, len1 + 91)) for r in range(70)]
         order = rng.permutation(len(rows))
         rows = [rows[i] for i in order]
         offsets = np.zeros(len(rows) + 1, dtype=np.uint64)
         offsets[1:] = np.cumsum([len(r) for r in rows])
         data = np.concatenate(rows)
         corpus = rf.Corpus.from_ragged(data, offsets)
-        check("ragged 1..300", bytes(q), corpus, ragged=(data, offsets))
+        check(f"ragged 1..{max(300, len1 + 90)}", bytes(q), corpus, ragged=(data, offsets))
         del corpus
 print("FAILURES", failures)
 sys.exit(1 if failures else 0)
