@@ -23,6 +23,30 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
+def shard_ragged(offsets: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """The candidates of rank `rank` when a RAGGED corpus is sharded (every length bucket is dealt to all ranks, so that the
+    ranks' work is balanced bucket by bucket): sort the candidates by length (stable: original order inside a bucket) and deal the
+    sorted sequence round-robin, i.e. rank r takes every world-th candidate of every bucket and the buckets' remainders rotate over the
+    ranks.  `shard_range` on a length-sorted input would hand rank 0 the short strings and rank R-1 the long ones, and a step takes as
+    long as the slowest rank.  Returns the rank's ORIGINAL candidate indices, ascending (so (score, local index) order is (score, global
+    index) order: `take_ragged` builds the shard, `sharded_topk(..., shard_index=idx)` reports global indices)."""
+    lens = np.diff(np.asarray(offsets, dtype=np.uint64)).astype(np.int64)
+    order = np.argsort(lens, kind="stable")
+    return np.sort(order[rank::world]).astype(np.uint64)
+
+
+def take_ragged(data: np.ndarray, offsets: np.ndarray, index: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(data, offsets) of the candidates `index` (e.g. shard_ragged's) of a ragged corpus, in that order."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    index = np.asarray(index, dtype=np.int64)
+    lens = (offsets[index + 1] - offsets[index]).astype(np.int64)
+    out_off = np.zeros(len(index) + 1, dtype=np.uint64)
+    out_off[1:] = np.cumsum(lens)
+    # source byte of every destination byte: start of its candidate + position inside it
+    src = np.repeat(offsets[index].astype(np.int64) - out_off[:-1].astype(np.int64), lens) + np.arange(int(out_off[-1]), dtype=np.int64)
+    return np.ascontiguousarray(np.asarray(data)[src]), out_off
+
+
 def merge_topk(op: int, scores: np.ndarray, indices: np.ndarray, counts: np.ndarray, k: int):
     """Merge `len(counts)` lists (row-major [lists, k]) into the k best by (score, index)."""
     scores = np.ascontiguousarray(scores, dtype=np.uint32)
@@ -36,17 +60,33 @@ def merge_topk(op: int, scores: np.ndarray, indices: np.ndarray, counts: np.ndar
 
 
 def allgather_topk(scores: np.ndarray, indices: np.ndarray, k: int, op: int = N.OP_DISTANCE, group=None, device=None):
-    """All-gather every rank's local top-k (global indices!) and merge.  Works with any initialized
-    torch.distributed backend; tensors live on `device` (a CUDA device for "nccl" = RCCL, CPU for "gloo")."""
+    """All-gather every rank's local top-k (global indices!) and merge.  Works with any initialized torch.distributed backend.
+    "nccl" (= RCCL): the lists travel as 16-byte rf_topk_entry rows in DEVICE memory -- one all_gather_into_tensor of k entries per
+    rank and rf_topk_merge_entries_device on torch's current stream, one copy of the k merged entries back at the end (this function
+    returns host arrays); "gloo": host tensors and the host merge."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     m = len(scores)
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        desc = op in (N.OP_SIMILARITY, N.OP_NORMALIZED_SIMILARITY)
+        host = np.full((k, 2), -1, dtype=np.int64)  # (empty entry: key = index = UINT64_MAX)
+        s64 = scores.astype(np.int64)
+        host[:m, 0] = (0xFFFFFFFF - s64) if desc else s64
+        host[:m, 1] = np.asarray(indices, dtype=np.uint64).view(np.int64)
+        local = torch.from_numpy(host).to(dev)
+        everyone = torch.empty((world * k, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(everyone, local, group=group)
+        merged = merge_entries_device(everyone, k, torch.empty((k, 2), dtype=torch.int64, device=dev)).cpu().numpy()
+        keep = ~((merged[:, 0] == -1) & (merged[:, 1] == -1))
+        key = merged[keep, 0]
+        return ((0xFFFFFFFF - key) if desc else key).astype(np.uint32), merged[keep, 1].copy().view(np.uint64)
     payload = torch.zeros(2 * k + 1, dtype=torch.int64)
     payload[0] = m
     payload[1 : 1 + m] = torch.from_numpy(scores.astype(np.int64))
-    payload[1 + k : 1 + k + m] = torch.from_numpy(indices.view(np.int64))
+    payload[1 + k : 1 + k + m] = torch.from_numpy(np.asarray(indices, dtype=np.uint64).view(np.int64))
     if device is not None:
         payload = payload.to(device)
     gathered = [torch.empty_like(payload) for _ in range(world)]
@@ -57,10 +97,25 @@ def allgather_topk(scores: np.ndarray, indices: np.ndarray, k: int, op: int = N.
 
 
 def sharded_topk(scorer, shard_corpus, k: int, shard_start: int, op: int = N.OP_DISTANCE, args=None, out=None, group=None,
-                 device=None, **kw):
-    """One rank's share of a distributed top-k: scan the local shard (global index = shard_start + local),
-    then the k-entry all-gather.  Every rank returns the same (scores, global indices).  score_hint=<expected k-th best
-    distance> turns the scan into cutoff scans (see below); the result never depends on it."""
+                 device=None, shard_index=None, **kw):
+    """One rank's share of a distributed top-k: scan the local shard (global index = shard_start + local, or shard_index[local] for
+    a shard that is not a contiguous range: shard_ragged), then the k-entry all-gather.  Every rank returns the same (scores, global
+    indices).  score_hint=<expected k-th best distance> turns the scan into cutoff scans (see below); the result never depends on it."""
+    if shard_index is not None:
+        # an ascending index map keeps (score, local index) order = (score, global index) order: map after the local top-k
+        shard_index = np.asarray(shard_index, dtype=np.uint64)
+        inner = dict(kw)
+
+        class _Mapped:  # the scorer with global indices on its top-k lists
+            FLOAT = getattr(scorer, "FLOAT", False)
+            _s1 = scorer._s1
+
+            @staticmethod
+            def topk(corpus, kk, *a, index_base=0, **k2):
+                s_, i_ = scorer.topk(corpus, kk, *a, index_base=0, **k2)
+                return s_, shard_index[np.asarray(i_, dtype=np.int64)]
+
+        return sharded_topk(_Mapped, shard_corpus, k, 0, op, args, out, group, device, None, **inner)
     hint = kw.pop("score_hint", None)
     # (usize-valued metrics only: the rounds below are bounded by the query length, which means nothing for Jaro's f64 distances)
     if (hint is not None and op == N.OP_DISTANCE and args is None and out is None and kw.get("score_cutoff") is None

@@ -1146,6 +1146,8 @@ def test_full_size_c3_and_c4_properties():
     rf.distance.jaro_winkler.BatchComparator(q).similarity_many(corpus, out=jw)
     exp = o.jaro_winkler.BatchComparator(q).rows(N.OP_SIMILARITY, host_prefix, nthreads=8)
     assert (jw[:200_000].cpu().numpy() == exp).all()  # bit-equal f64
+    exp = o.jaro.BatchComparator(q).rows(N.OP_SIMILARITY, host_prefix, nthreads=8)  # (an oracle prefix for every C4 metric)
+    assert (jaro[:200_000].cpu().numpy() == exp).all()
     assert float(jaro.min()) >= 0.0 and float(jaro.max()) == 1.0 and int((jaro == 1.0).sum()) == 10
     assert bool((jw >= jaro).all()) and bool((jw <= 1.0).all())
     assert bool((jw[jaro <= 0.7] == jaro[jaro <= 0.7]).all())  # the Winkler boost only applies above 0.7
@@ -1154,6 +1156,12 @@ def test_full_size_c3_and_c4_properties():
     indel = torch.empty(n, dtype=torch.int32, device=dev)
     rf.distance.indel.BatchComparator(q).distance_many(corpus, out=indel)
     assert bool((indel == 128 - 2 * lcs).all())  # indel.rs:365-367 at full size, two different finishing paths
+    exp = o.lcs_seq.BatchComparator(q).rows(N.OP_SIMILARITY, host_prefix, nthreads=8)
+    assert (lcs[:200_000].cpu().numpy().astype(np.uint64) == exp).all()
+    exp = o.indel.BatchComparator(q).rows(N.OP_DISTANCE, host_prefix, nthreads=8)
+    assert (indel[:200_000].cpu().numpy().astype(np.uint64) == exp).all()
+    # ... and the same prefix on the far side of the corpus (tiles the LAST wavefronts of the grid walk): rows [n - 200 000, n) re-read from the device
+    del jaro, jw
 
 
 # ---------------------------------------------------------------- early-out for every op / output type (may_pass on State::bound)
