@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--queries", type=int, default=1, help="Q > 1: Q queries x the corpus through rf_many_multi_u32 (N=1, many mode)")
     ap.add_argument("--cutoff", type=int, default=None)
     ap.add_argument("--fcutoff", type=float, default=None, help="similarity cutoff for jaro / jaro_winkler (e.g. 0.9)")
+    ap.add_argument("--hint", type=int, default=None, help="score_hint of the scan (levenshtein.rs:1069-1088: queries beyond 64 symbols; results never depend on it)")
+    ap.add_argument("--near-dup-share", type=float, default=0.0,
+                    help="this share of the candidates is the query with 0..8 random substitutions (the corpus a score_hint is for); the rest stays random")
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--mode", default="many", choices=["many", "topk"],
                     help="many: one score per candidate (configs[1]); topk: top-k only, no per-candidate output (configs[4])")
@@ -173,6 +176,21 @@ def main():
                 sel = torch.nonzero(hit).flatten()
                 planted[sel, pos[sel]] = sub[sel]
             rows[pidx] = planted
+    if args.near_dup_share > 0.0 and not c5:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4242 + rank)
+        pidx = torch.nonzero(torch.rand(n, device=dev, generator=gen) < args.near_dup_share).flatten()
+        qrow = torch.tensor(list(q[:ln].ljust(ln, b"0")), dtype=torch.uint8, device=dev)
+        for a in range(0, len(pidx), 1 << 22):
+            sel_rows = pidx[a : a + (1 << 22)]
+            planted = qrow.repeat(len(sel_rows), 1)
+            for _ in range(8):
+                hit = torch.nonzero(torch.rand(len(sel_rows), device=dev, generator=gen) < 0.5).flatten()
+                pos = torch.randint(0, ln, (len(sel_rows),), device=dev, generator=gen)
+                sub = torch.randint(48, 58, (len(sel_rows),), device=dev, generator=gen, dtype=torch.int64).to(torch.uint8)
+                planted[hit, pos[hit]] = sub[hit]
+            rows[sel_rows] = planted
+        del pidx
     sample_rows = min(n, 32_000_000)
     host_sample = None
     host_strided = None
@@ -225,6 +243,8 @@ def main():
     call_args = rf.Args()
     if args.cutoff is not None:
         call_args = call_args.score_cutoff(args.cutoff)
+    if args.hint is not None:
+        call_args = call_args.score_hint(args.hint)
     if args.fcutoff is not None:
         args.cutoff = args.fcutoff  # the oracle legs below pass it on unchanged
         call_args = call_args.score_cutoff(args.fcutoff)
@@ -394,8 +414,10 @@ def main():
         what += ((f"{n} random alphanumeric candidates with lengths uniform in [{args.min_len}, {args.cand_len}] (mean {mean_len:.2f}) per GPU, " if args.ragged
                   else f"{n} random alphanumeric len-{ln} candidates per GPU, ") + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
                  + (f", weights={weights}" if weights else "")
+                 + (f", {args.near_dup_share:.0%} of them the query with 0..8 substitutions" if args.near_dup_share > 0 else "")
+                 + (f", score_hint={args.hint}" if args.hint is not None else "")
                  + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64
-                                                     and args.cutoff is None and not weights and not args.ragged) else ""))
+                                                     and args.cutoff is None and not weights and not args.ragged and args.near_dup_share == 0 and args.hint is None) else ""))
     result = {
         "metric": "Gpairs/s (1 query x N candidates, Levenshtein BatchComparator semantics)" if args.metric == "levenshtein" else f"Gpairs/s ({args.metric})",
         "value": round(gpairs, 3),

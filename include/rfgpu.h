@@ -56,6 +56,8 @@
  *                                           mixed tiles together; the launch is the cost there); 0: always two launches
  *   RF_SCRATCH_CACHE_MB           1024      bound on the per-call scratch the library keeps parked between calls (its own stream-ordered
  *                                           allocator, rf_scratch.hip); 0: every block is released as soon as the work behind it is done
+ *   RF_HINT_MIN_TILES             1024      fewest tiles of a corpus for which a per-candidate Levenshtein scan of a query beyond 64 symbols honours
+ *                                           score_hint (pass under max(hint, 31), then only what it left unresolved: rf_hint.hip); 4294967295: never
  *   RF_STREAM_KEEP                1         0: rf_stream_many_* allocates and frees its pinned / device buffer sets per call instead of keeping them
  *   RF_STREAM_THREADS             16        host threads that read a corpus file's payload (rf_stream_many_*, rf_corpus_load)
  *   RF_PACK_TIMING / RF_SELECT_DEBUG / RF_TRACE_PLAN / RF_STREAM_TIMING   unset   set: phase timings / selection statistics / one line per
@@ -113,16 +115,23 @@ typedef enum rf_mem { RF_MEM_HOST = 0, RF_MEM_DEVICE = 1 } rf_mem;
  *   cutoff_usize : RF_NO_CUTOFF = NoScoreCutoff, else WithScoreCutoff(v) for the usize-valued ops
  *   cutoff_f64   : NaN = NoScoreCutoff, else WithScoreCutoff(v) for the f64-valued ops
  *   score_hint_* : results never depend on a hint (levenshtein.rs:2153-2160); in the reference it steers the CPU band search
- *                  (levenshtein.rs:1069-1088: a band of `hint`, doubled until the distance fits).  The per-candidate scans ignore
- *                  it.  rf_topk_u32 with RF_OP_DISTANCE and no cutoff uses it the reference's way: the scan first runs under the
+ *                  (levenshtein.rs:1069-1088: a band of `hint`, doubled until the distance fits).  Two callers honour it:
+ *                  rf_many_u32, Levenshtein RF_OP_DISTANCE with one common weight (the path that reads the hint in the reference), a
+ *                  query beyond 64 symbols, max(hint, 31) below the cutoff and below the longest string: the corpus is first scanned
+ *                  under the cutoff max(hint, 31) (the one-word band kernel, or the banded multi-word scans), then only the candidates
+ *                  that left unresolved are gathered into dense tiles and scanned under the caller's own cutoff (rf_hint.hip) -- a
+ *                  corpus of near-duplicates costs the band pass, an unrelated one the full scan + a few percent.  Such a call
+ *                  synchronizes `stream` once between the passes (RF_MEM_DEVICE too).
+ *                  rf_topk_u32 with RF_OP_DISTANCE and no cutoff: the scan first runs under the
  *                  cutoff `hint` (a cutoff scan costs a fraction of a full one) and the k best are final if k candidates pass,
- *                  otherwise the hint doubles (past a quarter of the longest possible distance the plain scan runs)
+ *                  otherwise the hint doubles (past a quarter of the longest possible distance the plain scan runs).
+ *                  Every other call ignores it.
  *
  * Three places where the device deliberately does NOT reproduce what release-mode rapidfuzz 0.5.0 returns (all tested,
  * tests/test_gpu_parity.py, all also in DESIGN.md section 3):
  *   Q7  For len1 > 64 and an explicit score_hint with 2 * max(hint, 31) < len1 - len2, the reference's hint-doubling loop
  *       (levenshtein.rs:1069-1088) calls the small-band kernel without the |len1 - len2| guard hyrroe2003_block has, and
- *       its result then DEPENDS on the hint (an upstream defect, reproduced by the oracle).  The device ignores hints and
+ *       its result then DEPENDS on the hint (an upstream defect, reproduced by the oracle).  The device's hinted passes are exact and it
  *       returns the exact distance -- what the reference returns for every other hint.
  *   Q2  levenshtein similarity_with_args above its cutoff evaluates `maximum - usize::MAX` (details/distance.rs:209-210:
  *       a panic in debug builds, a wrapped value in release builds).  The device returns None.

@@ -650,6 +650,151 @@ static hipError_t launch_scan_runs(RawKind raw, const ScanParams& p, const rf_co
     return e;
 }
 
+rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out, rf_mem out_mem, void* stream, bool f64_out);
+// score_hint on a per-candidate scan of a long query (reference: levenshtein.rs:1069-1088, the band of max(hint, 31) doubled until the
+// distance fits -- results never depend on the hint, :2153-2160).  rf_hint.hip has the scheme: pass 1 over everything under the cutoff k1 = max(hint, 31)
+// (the band kernel, or the banded multi-word scans), then the candidates it left unresolved are gathered into dense tiles and scanned under the caller's own
+// cutoff.  Applies to Levenshtein distance with a common weight factor (the path that reads the hint in the reference, levenshtein.rs:1307-1316), queries of
+// more than 64 symbols, k1 below the caller's cutoff and below the longest string, corpora of >= RF_HINT_MIN_TILES tiles (default 1024: the pass costs a
+// stream synchronization and four launches); everything else ignores the hint, as before.  Returns false when it does not apply.
+static bool hint_pass_applies(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, bool f64_out, uint32_t* k1, uint32_t* factor)
+{
+    static const uint32_t min_tiles = [] { const char* e = getenv("RF_HINT_MIN_TILES"); return e ? (uint32_t)atoll(e) : 1024u; }();  // 0xFFFFFFFF: hints are ignored (A/B)
+    if (f64_out || op != RF_OP_DISTANCE || c->metric != RF_LEVENSHTEIN || args->score_hint_usize == RF_NO_CUTOFF || c->words < 2) return false;
+    const uint64_t f = args->insertion_cost;
+    if (f < 1 || f > 0xFFFF || args->deletion_cost != f || args->substitution_cost != f) return false;
+    if (corpus->n_tiles < min_tiles || corpus->borrowed || corpus->n >= 0xFFFFFFFFull / 2) return false;
+    const uint64_t longest = std::max<uint64_t>(c->s1.size(), corpus->max_len);
+    const uint64_t raw_hint = args->score_hint_usize / f + (args->score_hint_usize % f != 0);  // ceil_div, levenshtein.rs:1308-1311
+    const uint64_t k = std::max<uint64_t>(raw_hint, 31);                                      // :1069
+    const uint64_t raw_cut = args->cutoff_usize == RF_NO_CUTOFF ? UINT64_MAX : args->cutoff_usize / f;
+    if (k >= raw_cut || k >= longest) return false;
+    *k1 = (uint32_t)k;
+    *factor = (uint32_t)f;
+    return true;
+}
+
+static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* corpus_in, const rf_comparator* c, const rf_corpus* corpus, const rf_args* args,
+                                 uint32_t* out, rf_mem out_mem, hipStream_t st, uint32_t k1, uint32_t factor)
+{
+    const rf_op op = RF_OP_DISTANCE;
+    const size_t out_bytes = corpus->n * sizeof(uint32_t);
+    // everything this call allocates, released in stream order on every way out
+    struct Scratch {
+        hipStream_t st;
+        std::vector<void*> blocks;
+        ~Scratch()
+        {
+            for (void* b : blocks) scratch_free(b, st);
+        }
+        hipError_t get(void** p, size_t bytes)
+        {
+            const hipError_t e = scratch_alloc(p, bytes, st);
+            if (e == hipSuccess) blocks.push_back(*p);
+            return e;
+        }
+    } sc{st, {}};
+    uint32_t* d_out = out;
+    if (out_mem == RF_MEM_HOST) RF_HIP(sc.get((void**)&d_out, out_bytes));
+    // ---- pass 1: everything under the cutoff k1 (in result units: times the common factor)
+    rf_args a1 = *args;
+    a1.score_hint_usize = RF_NO_CUTOFF;
+    a1.cutoff_usize = (uint64_t)k1 * factor;
+    if (const rf_status rs = run_many(c_in, corpus_in, op, &a1, d_out, RF_MEM_DEVICE, st, false); rs != RF_OK) return rs;
+    // ---- the caller's own scan, planned for the corpus and re-aimed at the dense tiles below
+    rf_args a2 = *args;
+    a2.score_hint_usize = RF_NO_CUTOFF;
+    ScanParams p;
+    RawKind raw = RAW_LEV;
+    if (const rf_status rs = plan(c, corpus, op, &a2, false, &p, &raw); rs != RF_OK) return rs;
+    if (const rf_status rs = comparator_device_pm(c, corpus->device, &p.pm); rs != RF_OK) return rs;
+    const uint64_t raw_cut64 = args->cutoff_usize == RF_NO_CUTOFF ? 0xFFFFFFFFull : std::min<uint64_t>(args->cutoff_usize / factor, 0xFFFFFFFFull);
+    const uint32_t raw_cut = (uint32_t)raw_cut64;
+    const uint64_t zero64 = (uint64_t)p.len1 * factor;
+    const uint32_t zero_value = (args->cutoff_usize == RF_NO_CUTOFF || zero64 <= args->cutoff_usize) ? (uint32_t)zero64 : RF_NONE_U32;
+    // ---- mark: per tile the lanes pass 1 left unresolved, numbered in slot order; the sums at the length runs' boundaries come to the host
+    const uint32_t R = (uint32_t)corpus->lengths.size();
+    std::vector<uint32_t> run_first(corpus->length_first_tile.begin(), corpus->length_first_tile.end());
+    run_first.push_back(corpus->n_tiles);
+    uint32_t *d_run_first = nullptr, *d_count = nullptr, *d_prefix = nullptr, *d_run_prefix = nullptr;
+    uint64_t* d_mask = nullptr;
+    void* d_temp = nullptr;
+    const size_t temp_bytes = hint_scan_temp_bytes(corpus->n_tiles);
+    RF_HIP(sc.get((void**)&d_run_first, (R + 1) * sizeof(uint32_t)));
+    RF_HIP(sc.get((void**)&d_run_prefix, (R + 1) * sizeof(uint32_t)));
+    RF_HIP(sc.get((void**)&d_count, ((size_t)corpus->n_tiles + 1) * sizeof(uint32_t)));
+    RF_HIP(sc.get((void**)&d_prefix, ((size_t)corpus->n_tiles + 1) * sizeof(uint32_t)));
+    RF_HIP(sc.get((void**)&d_mask, (size_t)corpus->n_tiles * sizeof(uint64_t)));
+    RF_HIP(sc.get(&d_temp, temp_bytes));
+    RF_HIP(hipMemcpyAsync(d_run_first, run_first.data(), (R + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    RF_HIP(launch_hint_mark(p, d_out, raw_cut, zero_value, d_mask, d_count, d_prefix, d_temp, temp_bytes, d_run_first, R, d_run_prefix, st));
+    std::vector<uint32_t> run_prefix(R + 1);
+    RF_HIP(hipMemcpyAsync(run_prefix.data(), d_run_prefix, (R + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RF_HIP(hipStreamSynchronize(st));  // (the one synchronization of a hinted call: the dense tiles are sized by what pass 1 left)
+    std::vector<uint32_t> cnt(R);
+    for (uint32_t r = 0; r < R; ++r) cnt[r] = run_prefix[r + 1] - run_prefix[r];
+    std::vector<uint32_t> tile_base(R + 1, 0u), run_len(R);
+    std::vector<uint64_t> data_base(R, 0ull);
+    uint64_t bytes2 = 0, tiles2_64 = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        tile_base[r] = (uint32_t)tiles2_64;
+        data_base[r] = bytes2;
+        run_len[r] = corpus->lengths[r];
+        const uint64_t t = ((uint64_t)cnt[r] + kWave - 1) / kWave;
+        tiles2_64 += t;
+        bytes2 += t * tile_bytes(corpus->lengths[r]);
+    }
+    tile_base[R] = (uint32_t)tiles2_64;
+    static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;
+    if (trace_plan) std::fprintf(stderr, "[rf plan] hint pass: k1=%u, %llu dense tiles (%llu bytes) of %u left for the full scan\n", k1, (unsigned long long)tiles2_64, (unsigned long long)bytes2, corpus->n_tiles);
+    if ((uint64_t)run_prefix[R] * 4 > (uint64_t)corpus->n * 3) {
+        // the hint was wrong for more than three quarters of the corpus: gathering them costs more than scanning the few resolved ones again
+        if (const rf_status rs = run_many(c_in, corpus_in, op, &a2, d_out, RF_MEM_DEVICE, st, false); rs != RF_OK) return rs;
+    } else if (tiles2_64 != 0) {
+        const uint32_t n_tiles2 = (uint32_t)tiles2_64;
+        uint32_t *d_tile_base = nullptr, *d_run_len = nullptr, *d_orig2 = nullptr;
+        uint64_t* d_data_base = nullptr;
+        uint8_t* d_data2 = nullptr;
+        TileDesc* d_tiles2 = nullptr;
+        RF_HIP(sc.get((void**)&d_tile_base, (R + 1) * sizeof(uint32_t)));
+        RF_HIP(sc.get((void**)&d_run_len, R * sizeof(uint32_t)));
+        RF_HIP(sc.get((void**)&d_data_base, R * sizeof(uint64_t)));
+        RF_HIP(sc.get((void**)&d_data2, bytes2 + kTailPad));
+        RF_HIP(sc.get((void**)&d_tiles2, (size_t)n_tiles2 * sizeof(TileDesc)));
+        RF_HIP(sc.get((void**)&d_orig2, (size_t)n_tiles2 * kWave * sizeof(uint32_t)));
+        RF_HIP(hipMemcpyAsync(d_tile_base, tile_base.data(), (R + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        RF_HIP(hipMemcpyAsync(d_run_len, run_len.data(), R * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        RF_HIP(hipMemcpyAsync(d_data_base, data_base.data(), R * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        RF_HIP(hipMemsetAsync(d_data2 + bytes2, 0, kTailPad, st));  // (the scans prefetch one chunk row past the last tile)
+        RF_HIP(launch_hint_gather(p, d_run_first, R, d_run_prefix, d_prefix, d_mask, d_tile_base, d_data_base, d_run_len, n_tiles2, d_data2, d_tiles2, d_orig2, st));
+        // ---- pass 2: a general corpus of exact tiles whose orig[] holds ORIGINAL candidate indices: results land in the caller's vector
+        p.data = d_data2;
+        p.tiles = d_tiles2;
+        p.orig = d_orig2;
+        p.n_tiles = p.n_exact = n_tiles2;
+        p.tile_begin = 0, p.tile_end = n_tiles2;
+        p.mixed = nullptr, p.mixed_len = nullptr, p.mixed_orig = nullptr;
+        p.mixed_begin = p.mixed_end = 0;
+        p.joint_begin = p.joint_end = 0;
+        p.zero_begin[0] = p.zero_end[0] = p.zero_begin[1] = p.zero_end[1] = 0;
+        p.uniform_len = 0, p.uniform_tile_bytes = 0;
+        p.heads8 = nullptr, p.heads6 = nullptr, p.run_orig = nullptr;
+        p.head_need = p.head_k = 0;
+        p.prefill_none = 0;
+        p.out = d_out;
+        if (p.long_words_pad) {  // (queries beyond 512 symbols: the multi-sweep kernel's scratch strips, sized for the dense tiles)
+            p.long_grid = (uint32_t)std::max(1, std::min<int>((int)p.long_grid, scan_grid(n_tiles2)));
+            if (const size_t scratch = launch_scratch_bytes(p, raw)) RF_HIP(sc.get((void**)&p.long_scratch, scratch));
+        }
+        RF_HIP(launch_scan(raw, p, st, nullptr));
+    }
+    if (out_mem == RF_MEM_HOST) {
+        RF_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        RF_HIP(hipStreamSynchronize(st));
+    }
+    return RF_OK;
+}
+
 rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out,
                           rf_mem out_mem, void* stream, bool f64_out)
 {
@@ -679,6 +824,11 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     if (s != RF_OK) return s;
 
     hipStream_t st = (hipStream_t)stream;
+    {
+        uint32_t k1 = 0, factor = 1;
+        if (corpus == corpus_in && hint_pass_applies(c, corpus, op, args, f64_out, &k1, &factor))
+            return run_many_hinted(c_in, corpus_in, c, corpus, args, static_cast<uint32_t*>(out), out_mem, st, k1, factor);
+    }
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
     p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)

@@ -160,6 +160,13 @@ bool stream_asm_serves(const ScanParams& p);  // rf_stream_asm.hip: whole-kernel
 hipError_t launch_stream_asm(int kind, const ScanParams& p, hipStream_t stream, int grid);  // kind: 0 Lev64, 1 Lev32, 2 OSA; no zero-length tile in [tile_begin, tile_end)
 hipError_t launch_lev1_asm(const ScanParams& p, hipStream_t stream, int grid);  // rf_lev_asm.hip: single-word Levenshtein, single-length corpus, no early-out
 void launch_lev1_asm_probe(dim3 g, dim3 b, uint32_t* out, int iters, uint32_t seed);  // rf_lev_asm.hip: the asm chunk alone (rf_probe_issue_rate mode 2)
+// rf_hint.hip: what a score_hint pass left unresolved, gathered into dense tiles (rf_api_scan.hip run_many_hinted)
+size_t hint_scan_temp_bytes(uint32_t n_tiles);
+hipError_t launch_hint_mark(const ScanParams& p, uint32_t* out, uint32_t raw_cutoff, uint32_t zero_value, uint64_t* mask, uint32_t* count, uint32_t* prefix, void* temp,
+                            size_t temp_bytes, const uint32_t* run_first, uint32_t R, uint32_t* run_prefix, hipStream_t st);
+hipError_t launch_hint_gather(const ScanParams& p, const uint32_t* run_first, uint32_t R, const uint32_t* run_prefix, const uint32_t* prefix, const uint64_t* mask,
+                              const uint32_t* run_tile_base, const uint64_t* run_data_base, const uint32_t* run_len, uint32_t n_tiles2, uint8_t* data2, TileDesc* tiles2,
+                              uint32_t* orig2, hipStream_t st);
 hipError_t launch_band(const ScanParams& p, hipStream_t stream);  // rf_band.hip: exact tiles [tile_begin, tile_end)
 hipError_t launch_scan_mixed(RawKind raw, const ScanParams& p, hipStream_t stream);  // p.mixed / tile_begin / tile_end: the mixed section
 hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid);

@@ -2393,6 +2393,63 @@ def test_multiword_levenshtein_band_trimming(mode):
     assert "FAILURES 0" in r.stdout
 
 
+@pytest.mark.parametrize("kind", ["ragged", "uniform"])
+@pytest.mark.parametrize("qlen", [100, 256, 600])
+def test_score_hint_on_long_query_scans_never_changes_a_result(kind, qlen):
+    """VERDICT r4 item 2 (levenshtein.rs:1069-1088, :2153-2160): with a score_hint a scan of a query beyond 64 symbols runs under the band
+    max(hint, 31) first and re-scans only what that left unresolved, gathered into dense tiles (rf_hint.hip).  Half of the corpus are
+    near-duplicates of the query (0..40 edits: some resolve under every hint, some under none), the rest random; corpora of > 1024 tiles
+    (below that the hint is ignored).  Hints 0 / 1 / 31 / 32 / 100 / none x no cutoff / cutoffs on both sides of the hint x unit and
+    (3, 3, 3) weights: every result equals the oracle's UN-hinted one (the reference's own hinted path has quirk Q7)."""
+    rng = np.random.default_rng(qlen)
+    q = bytes(rng.integers(48, 123, size=qlen, dtype=np.uint8))
+    qa = np.frombuffer(q, dtype=np.uint8)
+    n = 100_000 if kind == "ragged" else 70_000
+    rows = []
+    for i in range(n):
+        len2 = int(rng.integers(max(1, qlen - 150), qlen + 60)) if kind == "ragged" else qlen + 7
+        if i % 97 == 0:
+            len2 = 0 if kind == "ragged" else len2
+        if i % 2:
+            b = list(qa)
+            for _ in range(int(rng.integers(0, 41))):
+                r, pos = int(rng.integers(0, 3)), int(rng.integers(0, len(b) + 1))
+                if r == 0:
+                    b.insert(pos, 35)
+                elif b:
+                    if r == 1:
+                        del b[min(pos, len(b) - 1)]
+                    else:
+                        b[min(pos, len(b) - 1)] = 36
+            row = np.resize(np.array(b if b else [37], dtype=np.uint8), len2) if len2 else np.zeros(0, dtype=np.uint8)
+        else:
+            row = rng.integers(48, 123, size=len2, dtype=np.uint8)
+        rows.append(row)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in rows])
+    data = np.concatenate(rows)
+    if kind == "uniform":
+        import torch
+
+        corpus = rf.Corpus.from_device_rows(torch.from_numpy(data.reshape(n, -1)).cuda())
+    else:
+        corpus = rf.Corpus.from_ragged(data, offsets)
+    bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
+    for weights in (None, (3, 3, 3)):
+        f = 1 if weights is None else 3
+        kw = {} if weights is None else {"weights": rf.WeightTable(*weights)}
+        okw = {} if weights is None else {"weights": weights}
+        for cutoff in (None, 20 * f, 45 * f, 120 * f, 10_000):
+            exp = _expect_u32(ob.many(N.OP_DISTANCE, data, offsets, nthreads=8, score_cutoff=cutoff, **okw))
+            for hint in (None, 0, 1, 31 * f, 32 * f, 100 * f, 10**9):
+                got = bc.many(N.OP_DISTANCE, corpus, score_cutoff=cutoff, score_hint=hint, **kw)
+                bad = np.nonzero(got != exp)[0]
+                assert len(bad) == 0, (kind, qlen, weights, cutoff, hint, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
+    # host-memory results and a second stream take the same path
+    got = bc.many(N.OP_DISTANCE, corpus, score_hint=16)
+    assert np.array_equal(got, _expect_u32(ob.many(N.OP_DISTANCE, data, offsets, nthreads=8)))
+
+
 def test_full_size_osa_and_query32_properties():
     """VERDICT r2 item 1a, second half: osa1_asm_kernel and lev32_asm_kernel at BASELINE's full 100 M x 64 size (6 tiles per
     wavefront with the product grid), like test_full_size_c2_properties does for lev1_asm_kernel: an oracle-checked prefix plus
