@@ -39,6 +39,7 @@ ADDS32 = os.environ.get("RF_GEN_ADDS32", "0") == "1"
 # experiment knob.  The multi-word kernels always do (+4.6 % on configs[2], profiles/levw_addc_r04.txt; their hn_c through a second carry chain over an
 # SGPR pair was built and measured 17 % slower in round 4 and is gone from the generator).
 ADDC = set(filter(None, os.environ.get("RF_GEN_ADDC", "").replace(" ", "").split(",")))
+EARLY_FETCH = os.environ.get("RF_GEN_EARLY_FETCH", "1") == "1"  # 0: the first chunks are requested after the pattern table is staged (rounds 3-4: the A/B)
 BAND = os.environ.get("RF_GEN_BAND", "1") == "1"  # 0: the multi-word kernels run every word in every column (round 4's kernels: the A/B)
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
@@ -360,42 +361,7 @@ def kernel(K, uniform):
         off[name] = o
         o += size
     L = []
-    # ---- kernarg block -> s8..s32
-    L += [f"s_load_dwordx8 s[8:15], %[kp], {off['data']}", f"s_load_dwordx4 s[16:19], %[kp], {off['sigma']}",
-          f"s_load_dwordx8 s[20:27], %[kp], {off['tile_begin']}", f"s_load_dwordx4 s[28:31], %[kp], {off['fin_vR']}",
-          f"s_load_dwordx2 s[68:69], %[kp], {off['valid_hi']}", f"s_mov_b32 {S_STRIDE}, %[stride]",
-          # ---- stage the pattern table: thread i puts row i at row sigma(i) (the corpus stores renamed symbols)
-          "v_and_b32 v1, 0x3ff, %[tid]", "s_waitcnt lgkmcnt(0)"]
     W = getattr(K, "W", 1)
-    if W == 1:
-        L += [f"global_load_ubyte v6, v1, {S_SIGMA}", "v_lshlrev_b32 v7, 3, v1",
-              f"global_load_dwordx2 v[8:9], v7, {S_PM}" if K.bits == 64 else f"global_load_dword v8, v7, {S_PM}",
-              "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6",
-              "ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
-    else:  # row i of the host table (W consecutive words) -> word w to plane w, row sigma(i)
-        L += [f"s_load_dwordx8 s[72:79], %[kp], {off['valid_w']}", f"s_load_dword {S_KBAND}, %[kp], {off['band_k']}",
-              f"global_load_ubyte v6, v1, {S_SIGMA}", f"v_mul_u32_u24 v7, {8 * W}, v1"]
-        L += [f"global_load_dwordx2 v[{24 + 2 * w}:{25 + 2 * w}], v7, {S_PM}" + (f" offset:{8 * w}" if w else "") for w in range(W)]
-        L += ["s_waitcnt vmcnt(0)", "v_lshlrev_b32 v6, 3, v6"]
-        L += [f"ds_write_b64 v6, v[{24 + 2 * w}:{25 + 2 * w}]" + (f" offset:{2048 * w}" if w else "") for w in range(W)]
-    L += ["s_waitcnt lgkmcnt(0)", "s_barrier",
-          # ---- lane constants, first tile of this wavefront
-          f"v_readfirstlane_b32 {T0}, v1", f"s_lshr_b32 {T0}, {T0}, 6",  # wavefront within the workgroup
-          "v_and_b32 v1, 63, v1", "v_lshlrev_b32 v2, 4, v1", "v_lshlrev_b32 v3, 2, v1", "v_mov_b32 v5, 0", f"v_mov_b32 {V_KS}, {K.ks}",
-          # the workgroup's place in the deal of tiles: its id, or (flags bit 0, "xcd deal") (id % 8) * (grid / 8) + id / 8, so that
-          # consecutive tiles are walked by workgroups of ONE XCD (workgroups are dispatched to the 8 XCDs round-robin)
-          f"s_mov_b32 {T1}, %[wg]", f"s_bitcmp1_b32 {S_FLAGS}, 0", "s_cbranch_scc0 Lnodeal_%=",
-          f"s_and_b32 {T2}, %[wg], 7", f"s_lshr_b32 {T3}, {S_STRIDE}, 5", f"s_mul_i32 {T2}, {T2}, {T3}", f"s_lshr_b32 {T1}, %[wg], 3",
-          f"s_add_u32 {T1}, {T1}, {T2}", "Lnodeal_%=:",
-          f"s_lshl_b32 {T1}, {T1}, 2", f"s_add_u32 {T1}, {T1}, {T0}", f"s_add_u32 {S_T}, {S_TBEGIN}, {T1}",
-          f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lexit_%=",
-          f"s_mov_b32 {S_FT}, {S_T}", f"s_mov_b32 {S_FC}, 0", f"s_mov_b32 {S_C}, 0", f"s_mov_b32 {S_AFTER}, 0"]
-    if uniform:
-        L += [f"s_mov_b32 {S_LEN2}, {S_ULEN}", f"s_add_u32 {S_NCH}, {S_ULEN}, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4", f"s_mov_b32 {S_FN}, {S_NCH}"]
-    L += tile_desc(S_T, uniform, fetch=True)
-    if not uniform:
-        L += [f"s_mov_b32 {S_LEN2}, s62", f"s_mov_b32 {S_SLOT0}, s63", f"s_mov_b32 {S_NCH}, {S_FN}"]
-    L += tile_start(K, uniform, "%=")
 
     def fetch_glue(tag):  # src = address of the chunk under the fetch cursor; advance the cursor (parks on the last valid chunk)
         G = [f"s_lshl_b32 {T0}, {S_FC}, 10", f"s_add_u32 {S_SRC_LO}, {S_FBASE_LO}, {T0}", f"s_addc_u32 {S_SRC_HI}, {S_FBASE_HI}, 0",
@@ -406,10 +372,58 @@ def kernel(K, uniform):
         G += [f"s_mov_b32 {S_FC}, 0", f"s_branch Lfok_{tag}_%=", f"Lfpark_{tag}_%=:", f"s_sub_u32 {S_FC}, {S_FN}, 1", f"Lfok_{tag}_%=:"]
         return G
 
-    # ---- the first RING-1 chunks of the stream, then the rows of the first chunk's first columns
+    # ---- kernarg block -> s8..s32
+    L += [f"s_load_dwordx8 s[8:15], %[kp], {off['data']}", f"s_load_dwordx4 s[16:19], %[kp], {off['sigma']}",
+          f"s_load_dwordx8 s[20:27], %[kp], {off['tile_begin']}", f"s_load_dwordx4 s[28:31], %[kp], {off['fin_vR']}",
+          f"s_load_dwordx2 s[68:69], %[kp], {off['valid_hi']}", f"s_mov_b32 {S_STRIDE}, %[stride]"]
+    if W > 1:
+        L += [f"s_load_dwordx8 s[72:79], %[kp], {off['valid_w']}", f"s_load_dword {S_KBAND}, %[kp], {off['band_k']}"]
+    L += ["v_and_b32 v1, 0x3ff, %[tid]", "s_waitcnt lgkmcnt(0)"]
+    # ---- this wavefront's first tile: the workgroup's place in the deal of tiles is its id, or (flags bit 0, "xcd deal") (id % 8) * (grid / 8) + id / 8,
+    # so that consecutive tiles are walked by workgroups of ONE XCD (workgroups are dispatched to the 8 XCDs round-robin)
+    first_tile = [f"v_readfirstlane_b32 {T0}, v1", f"s_lshr_b32 {T0}, {T0}, 6",  # wavefront within the workgroup
+                  f"s_mov_b32 {T1}, %[wg]", f"s_bitcmp1_b32 {S_FLAGS}, 0", "s_cbranch_scc0 Lnodeal_%=",
+                  f"s_and_b32 {T2}, %[wg], 7", f"s_lshr_b32 {T3}, {S_STRIDE}, 5", f"s_mul_i32 {T2}, {T2}, {T3}", f"s_lshr_b32 {T1}, %[wg], 3",
+                  f"s_add_u32 {T1}, {T1}, {T2}", "Lnodeal_%=:",
+                  f"s_lshl_b32 {T1}, {T1}, 2", f"s_add_u32 {T1}, {T1}, {T0}", f"s_add_u32 {S_T}, {S_TBEGIN}, {T1}"]
+    cursors = [f"s_mov_b32 {S_FT}, {S_T}", f"s_mov_b32 {S_FC}, 0"]
+    if uniform:
+        cursors += [f"s_mov_b32 {S_LEN2}, {S_ULEN}", f"s_add_u32 {S_NCH}, {S_ULEN}, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4", f"s_mov_b32 {S_FN}, {S_NCH}"]
+    cursors += tile_desc(S_T, uniform, fetch=True)
+    if not uniform:
+        cursors += [f"s_mov_b32 {S_LEN2}, s62", f"s_mov_b32 {S_SLOT0}, s63", f"s_mov_b32 {S_NCH}, {S_FN}"]
+    prefetch = []  # the first RING-1 chunks of the stream
     for b in range(R - 1):
-        L += fetch_glue(f"pre{b}")
-        L.append(f"global_load_dwordx4 v[{K.bufs[b]}:{K.bufs[b] + 3}], {V_OFF16}, {S_SRC} nt")
+        prefetch += fetch_glue(f"pre{b}")
+        prefetch.append(f"global_load_dwordx4 v[{K.bufs[b]}:{K.bufs[b] + 3}], {V_OFF16}, {S_SRC} nt")
+    if EARLY_FETCH:
+        # (round 5) the stream's first chunks are requested BEFORE the pattern table is staged: the two round trips overlap instead of following each
+        # other at the head of every workgroup (a wavefront without a tile still stages its share of the table and meets the barrier)
+        L += first_tile + ["v_and_b32 v2, 63, v1", "v_lshlrev_b32 v2, 4, v2", f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lnotile_%="]
+        L += cursors + prefetch + ["Lnotile_%=:"]
+    # ---- stage the pattern table: thread i puts row i at row sigma(i) (the corpus stores renamed symbols)
+    if W == 1:
+        L += [f"global_load_ubyte v6, v1, {S_SIGMA}", "v_lshlrev_b32 v7, 3, v1",
+              f"global_load_dwordx2 v[8:9], v7, {S_PM}" if K.bits == 64 else f"global_load_dword v8, v7, {S_PM}",
+              "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6",
+              "ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
+    else:  # row i of the host table (W consecutive words) -> word w to plane w, row sigma(i)
+        L += [f"global_load_ubyte v6, v1, {S_SIGMA}", f"v_mul_u32_u24 v7, {8 * W}, v1"]
+        L += [f"global_load_dwordx2 v[{24 + 2 * w}:{25 + 2 * w}], v7, {S_PM}" + (f" offset:{8 * w}" if w else "") for w in range(W)]
+        L += ["s_waitcnt vmcnt(0)", "v_lshlrev_b32 v6, 3, v6"]
+        L += [f"ds_write_b64 v6, v[{24 + 2 * w}:{25 + 2 * w}]" + (f" offset:{2048 * w}" if w else "") for w in range(W)]
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    if not EARLY_FETCH:
+        L += first_tile
+    # ---- lane constants
+    L += ["v_and_b32 v1, 63, v1", "v_lshlrev_b32 v2, 4, v1", "v_lshlrev_b32 v3, 2, v1", "v_mov_b32 v5, 0", f"v_mov_b32 {V_KS}, {K.ks}",
+          f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lexit_%=", f"s_mov_b32 {S_C}, 0", f"s_mov_b32 {S_AFTER}, 0"]
+    if not EARLY_FETCH:
+        L += cursors
+    L += tile_start(K, uniform, "%=")
+    if not EARLY_FETCH:
+        L += prefetch
+    # ---- the rows of the first chunk's first columns
     L.append(f"s_waitcnt vmcnt({R - 2})")  # buffer 0 has arrived (a partial first chunk gathers its own rows again: harmless)
     for j in range(K.la):
         L += K.gather(j, K.bufs[0], K.bufs[1])
