@@ -137,6 +137,48 @@ def cols(mask, sdwa=True, n=16, vop3=False):
     return L
 
 
+# the two passes of the single-word Jaro kernel (tools/gen_jaro_chunk_asm.py: jaro.rs:147-190 flags, :339-368 transpositions) over one 16-column chunk,
+# table rows and window rows register-resident (no LDS, no waits), the product's s_nop placement by default (round 5)
+def jaro_pass1(m):
+    P, PMJ, BELOW, Y, T16 = (60, 61), (26, 27), (24, 25), 23, 22
+    L = [f"v_mov_b32 v{T16}, 0"]
+    for i in range(16):
+        pm, wn = (40 + 2 * (i % 8), 41 + 2 * (i % 8)), (32 + 2 * (i % 4), 33 + 2 * (i % 4))
+        L += [f"v_bitop3_b32 v{PMJ[h]}, v{pm[h]}, v{wn[h]}, v{P[h]} bitop3:0x40" for h in (0, 1)]
+        L += ["s_nop 0"] * (m & 1)
+        L.append(f"v_lshl_add_u64 {pr(BELOW)}, {pr(PMJ)}, 0, -1")
+        L += ["s_nop 0"] * (m >> 1 & 1)
+        L += [f"v_bitop3_b32 v{P[h]}, v{P[h]}, v{PMJ[h]}, v{BELOW[h]} bitop3:0xf4" for h in (0, 1)]
+        L.append(f"v_bitop3_b32 v{Y}, v{PMJ[1]}, v{BELOW[1]}, v{PMJ[1]} bitop3:0xf3")
+        L += ["s_nop 0"] * (m >> 2 & 1)
+        L.append(f"v_alignbit_b32 v{T16}, v{T16}, v{Y}, 31")
+        L += ["s_nop 0"] * (m >> 3 & 1)
+        L.append(f"v_lshlrev_b32_sdwa v{28 + i % 4}, v10, v{18 + i % 4} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{i % 4}")
+    L += [f"v_lshlrev_b32 v{T16}, s20, v{T16}", f"v_bitop3_b32 v58, v58, v{T16}, s21 bitop3:0xf8", f"v_bitop3_b32 v59, v59, v{T16}, s21 bitop3:0xf4"]
+    return L
+
+
+def jaro_pass2(m):
+    P, HITS, BELOW, M, Y, T16 = (60, 61), (62, 63), (24, 25), (56, 57), 23, 22
+    L = [f"v_bitop3_b32 v{T16}, v58, v59, s21 bitop3:0xe4", f"v_lshrrev_b32 v{T16}, s20, v{T16}"]
+    for i in range(16):
+        pm = (40 + 2 * (i % 8), 41 + 2 * (i % 8))
+        L += ["s_nop 0"] * (m & 1)
+        L.append(f"v_bfe_i32 v{Y}, v{T16}, {15 - i}, 1")
+        L += ["s_nop 0"] * (m >> 1 & 1)
+        L.append(f"v_lshl_add_u64 {pr(BELOW)}, {pr(P)}, 0, -1")
+        L += ["s_nop 0"] * (m >> 2 & 1)
+        L += [f"v_bitop3_b32 v{M[h]}, v{P[h]}, v{BELOW[h]}, v{Y} bitop3:0x20" for h in (0, 1)]
+        L += [f"v_bitop3_b32 v{HITS[h]}, v{HITS[h]}, v{pm[h]}, v{M[h]} bitop3:0xf8" for h in (0, 1)]
+        L += [f"v_bitop3_b32 v{P[h]}, v{P[h]}, v{BELOW[h]}, v{Y} bitop3:0xd0" for h in (0, 1)]
+        L += ["s_nop 0"] * (m >> 3 & 1)
+        L.append(f"v_lshlrev_b32_sdwa v{28 + i % 4}, v10, v{18 + i % 4} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{i % 4}")
+    return L
+
+
+JARO = {"jaro_p1_prod": jaro_pass1(0x5), "jaro_p1_nonop": jaro_pass1(0), "jaro_p1_all": jaro_pass1(0xF), "jaro_p2_prod": jaro_pass2(0x3), "jaro_p2_nonop": jaro_pass2(0),
+        "jaro_p2_all": jaro_pass2(0xF), "jaro_both_prod": jaro_pass1(0x5) + jaro_pass2(0x3)}
+
 # (name -> (lines, number of VALU instructions in them)); the column kernels count VALU only
 COLS = {"levcol_nonop": cols(0), "levcol_mask1B3": cols(0x1B3), "levcol_mask122": cols(0x122), "levcol_nosdwa_1B3": cols(0x1B3, False),
         "levcol3_nonop": cols(0, vop3=True), "levcol3_1B3": cols(0x1B3, vop3=True), "levcol3_122": cols(0x122, vop3=True), "levcol3_022": cols(0x022, vop3=True),
@@ -150,8 +192,10 @@ src = ["// GENERATED by tools/gen_cycle_bench.py", "#include <hip/hip_runtime.h>
 ALL = {}
 for name, lines in K.items():
     ALL[name] = (lines, sum(1 for l in lines if l.startswith("v_")))
-for name, lines in COLS.items():
+for name, lines in list(COLS.items()) + list(JARO.items()):
     ALL[name] = (lines, sum(1 for l in lines if l.startswith("v_")))
+if os.environ.get("RF_CYCLE_ONLY"):  # e.g. RF_CYCLE_ONLY=jaro,levcol_mask1B3: only the kernels whose name starts with one of these
+    ALL = {k: v for k, v in ALL.items() if any(k.startswith(x) for x in os.environ["RF_CYCLE_ONLY"].split(","))}
 for name, (lines, nv) in ALL.items():
     body = "".join(f'        "{l}\\n"\n' for l in lines)
     src.append(f"""__global__ __launch_bounds__(256) void k_{name}(uint64_t* out, int iters)
@@ -208,7 +252,7 @@ static void run(const char* name, kern_t k, uint64_t* d, int valu_per_iter, int 
     std::sort(cpi.begin(), cpi.end());
     double med = cpi.empty() ? 0 : cpi[cpi.size() / 2], mn = cpi.empty() ? 0 : cpi.front(), mx = cpi.empty() ? 0 : cpi.back();
     double ns = ms * 1e6 / (instr * waves_per_simd);        // wall clock, same unit (blocks == CUs x waves: one residency of the chip)
-    printf("%-22s w/SIMD %d  cycles/VALU/SIMD %6.3f (min %6.3f max %6.3f; %zu SIMDs, %zu irregular)  ns %6.3f  -> clock %5.3f GHz\\n", name, waves_per_simd,
+    printf("%-30s w/SIMD %d  cycles/VALU/SIMD %6.3f (min %6.3f max %6.3f; %zu SIMDs, %zu irregular)  ns %6.3f  -> clock %5.3f GHz\\n", name, waves_per_simd,
            med, mn, mx, cpi.size(), odd, ns, med / ns);
 }
 int main(int argc, char** argv)
@@ -218,6 +262,6 @@ int main(int argc, char** argv)
     uint64_t* d; (void)hipMalloc(&d, 8 * 3 * 4 * 256 * 16);
     for (int w : {4, 8}) {''')
 for name, (lines, nv) in ALL.items():
-    src.append(f'        run("{name}", k_{name}, d, {nv}, w);')
+    src.append(f'        run("{name} ({nv} VALU)", k_{name}, d, {nv}, w);')
 src.append("    }\n    return 0;\n}")
 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "microbench_cycles.hip"), "w").write("\n".join(src) + "\n")
