@@ -459,6 +459,39 @@ const uint32_t* corpus_head6_plane(const rf_corpus* corpus, hipStream_t st)
     return corpus->d_heads6;
 }
 
+// The payload at 6 bits per symbol (ScanParams::data6, rf_pack.hip pack6_kernel): single-length corpora whose payload holds no stored symbol above 63
+// (exact: corpus_max_stored_symbol) and at least RF_PACK6_MIN_TILES tiles (default 16384: a scan that does not fill the chip is not HBM-bound).  Built
+// from the 8-bit payload on first use by a scan that streams it, kept beside it (+ 75 % of the payload in HBM); RF_PACK6=0 switches it off.
+const uint32_t* corpus_data6(const rf_corpus* corpus, hipStream_t st)
+{
+    static const bool on = [] { const char* e = getenv("RF_PACK6"); return !e || atoi(e) != 0; }();
+    static const uint32_t min_tiles = [] { const char* e = getenv("RF_PACK6_MIN_TILES"); return e ? (uint32_t)atoll(e) : 16384u; }();
+    if (!on || !corpus->uniform || corpus->borrowed || corpus->n_tiles < min_tiles || corpus->uniform_len == 0 || corpus->uniform_len % kChunk != 0) return nullptr;
+    if (corpus_max_stored_symbol(corpus, st) >= 64u) return nullptr;
+    std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+    if (!corpus->d_data6 && !corpus->data6_tried) {
+        corpus->data6_tried = true;
+        const uint32_t nch = (corpus->uniform_len + kChunk - 1) / kChunk;
+        const uint64_t rows = (uint64_t)corpus->n_tiles * nch;
+        if (rows * kWave >= 0xFFFFFFFFull) return nullptr;
+        uint32_t* d = nullptr;
+        if (hipMalloc((void**)&d, (rows + 1) * kWave * 12) != hipSuccess) {  // (+ one chunk row: the scans prefetch past the last tile)
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipError_t e = launch_pack6(corpus->d_data, corpus->n_tiles, nch, d, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d + rows * kWave * 3, 0, kWave * 12, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // (other streams may use it as soon as the lock is released)
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        corpus->d_data6 = d;
+    }
+    return corpus->d_data6;
+}
+
 // The BAND PREFILTER of the head-plane cutoff scans (rf_scan.hip early_lean_body has the kernel side and the proof): with at most
 // K edits allowed, at least 8 - K of a candidate's first 8 symbols must equal a query symbol within K positions of their own.
 // Decides whether a launch uses it: K = the largest raw distance that passes the cutoff (the same arithmetic as may_pass() on
@@ -831,6 +864,9 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     }
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
     p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
+    // the HBM-bound scans of a single-length corpus stream the 6-bit payload where there is one (Indel / LCS, one word, no early-out)
+    // (where the asm scan over it applies: u32 results, lengths that are whole chunks -- rf_scan.hip launch_state)
+    p.data6 = (raw == RAW_LCS && p.words == 1 && p.len1 > 32 && !p.early && !f64_out && corpus->uniform && corpus->uniform_len % kChunk == 0) ? corpus_data6(corpus, st) : nullptr;
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
     static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
     p.max_stored_sym = (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) ? corpus_max_stored_symbol(corpus, st) : 0xFFFFFFFFu;
@@ -989,9 +1025,9 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;  // one line per rf_many_* call on stderr: which path the plan took
     if (trace_plan)
         std::fprintf(stderr, "[rf plan] raw=%d words=%u early=%u first_check=%u band=%u heads8=%d head_need=%u head_k=%u tile_list=%d by_runs=%d by_origin=%d gather=%d "
-                             "tiles=[%u,%u) of %u prefill=%u\n",
+                             "tiles=[%u,%u) of %u prefill=%u data6=%d\n",
                      (int)raw, p.words, p.early, p.first_check, p.band, p.heads8 != nullptr, p.head_need, p.head_k, p.tile_list_buf != nullptr, (int)by_runs, (int)by_origin,
-                     d_tmp != nullptr, p.tile_begin, p.tile_end, corpus->n_tiles, p.prefill_none);
+                     d_tmp != nullptr, p.tile_begin, p.tile_end, corpus->n_tiles, p.prefill_none, p.data6 != nullptr);
     hipError_t e = by_runs ? launch_scan_runs(raw, p, c, corpus, op, f64_out, st) : launch_scan(raw, p, st, nullptr);
     if (filter_lock.owns_lock()) {
         if (p.tile_list_buf) corpus_tile_list_done(corpus, st);

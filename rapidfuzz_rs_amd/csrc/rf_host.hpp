@@ -92,6 +92,8 @@ struct rf_corpus {
     mutable uint8_t* d_heads8 = nullptr;       // head plane: the first 8 symbols of every candidate (small-cutoff scans; built on first use)
     mutable uint32_t* d_heads6 = nullptr;      // the same at 6 bits per symbol (single-length corpora of < 64 distinct symbols; ScanParams::heads6)
     mutable bool heads6_tried = false;
+    mutable uint32_t* d_data6 = nullptr;       // the payload at 6 bits per symbol (single-length corpora of < 64 distinct symbols; ScanParams::data6); built on first use
+    mutable bool data6_tried = false;
     mutable uint32_t max_stored_sym = 0xFFFFFFFFu;  // largest stored symbol of the payload, exact; 0xFFFFFFFF = not computed yet (corpus_max_stored_symbol)
     mutable uint32_t* d_slot_of = nullptr;     // candidate -> its slot
     mutable uint32_t* d_slot_ident = nullptr;  // slot -> slot, kPad on padding lanes (stands in for d_orig in such a launch)
@@ -243,6 +245,7 @@ RF_LOCAL rf_status comparator_device_pm(const rf_comparator* c, int device, cons
 RF_LOCAL std::vector<TileDesc> tiles_by_origin(const std::vector<TileDesc>& tiles, uint32_t n_exact, const uint32_t* orig);  // rf_api.hip
 RF_LOCAL rf_status plan(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, bool f64_out, ScanParams* p, RawKind* raw);  // rf_api_scan.hip
 RF_LOCAL const uint32_t* corpus_head6_plane(const rf_corpus* corpus, hipStream_t st);                                  // rf_api_scan.hip
+RF_LOCAL const uint32_t* corpus_data6(const rf_corpus* corpus, hipStream_t st);                                        // rf_api_scan.hip
 RF_LOCAL const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, RawKind raw, hipStream_t st);    // rf_api_scan.hip
 RF_LOCAL void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, ScanParams* p, uint32_t len2);  // rf_api_scan.hip
 RF_LOCAL void corpus_tile_list_done(const rf_corpus* corpus, hipStream_t st);                                           // rf_api_scan.hip

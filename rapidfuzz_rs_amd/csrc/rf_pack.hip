@@ -461,6 +461,38 @@ hipError_t launch_head6_plane(const uint8_t* heads8, uint32_t n_tiles, uint32_t*
     hipLaunchKernelGGL(head6_plane_kernel, dim3(std::min<uint32_t>(((n_tiles + 1) / 2 + 3) / 4, 65536u)), dim3(256), 0, stream, reinterpret_cast<const uint2*>(heads8), n_tiles, heads6);
     return hipGetLastError();
 }
+// The PAYLOAD at 6 bits per symbol (round 5): a single-length corpus that stores fewer than 64 distinct symbols kept a second
+// time with 16 symbols in 12 bytes -- symbol j of a chunk on bits 6 j .. 6 j + 5 of the 96-bit little-endian value -- chunk k of lane r of tile t
+// at ((t * nch + k) * 64 + r) * 12: a wavefront's load of "my next 16 columns" is one contiguous 768-byte read (global_load_dwordx3) instead of 1 KiB.
+// The HBM-bound scans (Indel / LCS, single word) stream it instead of the 8-bit payload: stream6_kernel, rf_scan.hip.
+__global__ __launch_bounds__(256) void pack6_kernel(const uint4* __restrict__ data, uint32_t n_tiles, uint32_t nch, uint32_t* __restrict__ data6)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t rows = (uint64_t)n_tiles * nch;  // chunk rows of 64 lanes
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (uint64_t)gridDim.x * 4) {
+        const uint4 c = data[r * kWave + lane];
+        const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+        uint32_t w[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t sym = (dw[j / 4] >> (8 * (j % 4))) & 63u;
+            const int o = 6 * j;
+            w[o / 32] |= sym << (o % 32);
+            if (o % 32 > 26) w[o / 32 + 1] |= sym >> (32 - o % 32);
+        }
+        uint32_t* dst = data6 + (r * kWave + lane) * 3;
+        dst[0] = w[0];
+        dst[1] = w[1];
+        dst[2] = w[2];
+    }
+}
+hipError_t launch_pack6(const uint8_t* data, uint32_t n_tiles, uint32_t nch, uint32_t* data6, hipStream_t stream)
+{
+    if (n_tiles == 0 || nch == 0) return hipSuccess;
+    const uint64_t rows = (uint64_t)n_tiles * nch;
+    hipLaunchKernelGGL(pack6_kernel, dim3((uint32_t)std::min<uint64_t>((rows + 3) / 4, 262144u)), dim3(256), 0, stream, reinterpret_cast<const uint4*>(data), n_tiles, nch, data6);
+    return hipGetLastError();
+}
 // the same over the EXACT tiles of a length-bucketed corpus (round 4): row t = the first 8 stored bytes of tile t's 64 lanes, whatever
 // the tile's length (a candidate shorter than 8 symbols contributes its zero padding -- the cutoff scans only take their first look
 // from the plane for runs of >= 16 symbols, rf_api_scan.hip launch_scan_runs)

@@ -859,6 +859,10 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             // keeps round 2's fixed-shape asm kernels + the compiled loop for A/B.
             static const bool use_stream_asm = [] { const char* e = getenv("RF_ASM_STREAM"); return !e || atoi(e) != 0; }();
             constexpr int kAsmKind = std::is_same<State, LevState<1>>::value ? 0 : (std::is_same<State, Lev32State>::value ? 1 : (std::is_same<State, OsaState<1>>::value ? 2 : -1));
+            // the single-word LCS scans of a single-length corpus that keeps its payload at 6 bits per symbol too (ScanParams::data6): the asm scan over that
+            // (whole chunks only: lengths that are multiples of 16; u32 results).  RF_PACK6=0 (no such payload) is the A/B switch.
+            if (std::is_same<State, LcsState<1>>::value && use_asm && use_stream_asm && p.data6 && !p.tiles && p.uniform_len % kChunk == 0 && stream_asm_serves(p))
+                return launch_stream_asm(5, p, stream, std::max(1, scan_grid_full(p.tile_end - p.tile_begin)));
             if (kAsmKind >= 0 && use_asm && use_stream_asm && stream_asm_serves(p)) {
                 uint32_t at = p.tile_begin;
                 for (int r = 0; r <= 2 && at < p.tile_end; ++r) {
@@ -1046,9 +1050,18 @@ int scan_grid_full(uint32_t n_tiles)
     if (g >= 8u) g = std::min<uint32_t>((g + 7u) & ~7u, std::max<uint32_t>(8u, (uint32_t)scan_max_grid_full() & ~7u));
     return (int)std::max<uint32_t>(g, 1u);
 }
-hipError_t launch_scan(RawKind raw, const ScanParams& p, hipStream_t stream, int* grid_used)
+hipError_t launch_scan(RawKind raw, const ScanParams& p_in, hipStream_t stream, int* grid_used)
 {
-    if (p.n_tiles == 0) return hipSuccess;
+    if (p_in.n_tiles == 0) return hipSuccess;
+#ifdef RF_EXPERIMENTS  // measurement builds only: RF_EXP_TILE_BYTES=<bytes> walks a single-length corpus at another tile pitch (results are wrong on purpose:
+                       // what would a scan gain if its payload were that much smaller, with its arithmetic unchanged?)
+    ScanParams p_exp = p_in;
+    static const uint32_t exp_tile_bytes = [] { const char* e = getenv("RF_EXP_TILE_BYTES"); return e ? (uint32_t)atoi(e) : 0u; }();
+    if (exp_tile_bytes && !p_exp.tiles) p_exp.uniform_tile_bytes = exp_tile_bytes;
+    const ScanParams& p = p_exp;
+#else
+    const ScanParams& p = p_in;
+#endif
     // A corpus with a mixed section (leftovers of every length pooled into tiles with per-lane lengths) is scanned in two
     // launches by the register-resident Levenshtein / LCS / OSA kernels: the exact tiles as always, the mixed tiles by
     // scan_kernel_mixed.  Top-k, multi-query and the other kernel families walk the one-length views instead (p stays as is).

@@ -44,6 +44,12 @@ K["sdwa_lshl"] = rep([f"v_lshlrev_b32_sdwa v{16 + i}, v1, v6 dst_sel:DWORD dst_u
 K["perm_b32"] = rep([f"v_perm_b32 v{16 + i}, v1, v6, v11" for i in range(8)])
 K["and_nop_alt"] = rep([x for i in range(8) for x in (f"v_and_b32 v{16 + i}, v1, v6", "s_nop 0")])
 
+# (round 5: what unpacking a 6-bit symbol would cost -- v_bfe_u32 + v_and with a literal against the one SDWA shift of the 8-bit payload)
+K["bfe_u32"] = rep([f"v_bfe_u32 v{16 + i}, v6, {3 + 6 * (i % 4)}, 9" for i in range(8)])
+K["bfe_and_lit"] = rep([x for i in range(8) for x in (f"v_bfe_u32 v{16 + i}, v6, {3 + 6 * (i % 4)}, 9", f"v_and_b32 v{16 + i}, 0x1f8, v{16 + i}")])
+K["bfe_and_vgpr"] = rep([x for i in range(8) for x in (f"v_bfe_u32 v{16 + i}, v6, {3 + 6 * (i % 4)}, 9", f"v_and_b32 v{16 + i}, v11, v{16 + i}")])
+K["alignbit_and"] = rep([x for i in range(8) for x in (f"v_alignbit_b32 v{16 + i}, v7, v6, 27", f"v_and_b32 v{16 + i}, v11, v{16 + i}")])
+K["lshr_and"] = rep([x for i in range(8) for x in (f"v_lshrrev_b32 v{16 + i}, {3 + 6 * (i % 4)}, v6", f"v_and_b32 v{16 + i}, v11, v{16 + i}")])
 K["and_lit8"] = rep([f"v_and_b32 v{16 + i}, 0x12345678, v6" for i in range(8)])                       # VOP2 + 32-bit literal: 8 bytes
 K["bitop3_nop_alt"] = rep([x for i in range(8) for x in (f"v_bitop3_b32 v{16 + i}, v1, v6, v11 bitop3:0x96", "s_nop 0")])
 K["bitop3_2nop"] = rep([x for i in range(8) for x in (f"v_bitop3_b32 v{16 + i}, v1, v6, v11 bitop3:0x96", "s_nop 0", "s_nop 0")])
@@ -176,6 +182,71 @@ def jaro_pass2(m):
     return L
 
 
+# the LCS column (lcs_seq.rs:222-231; rf_device.hpp LcsState<1>::step): u = S & M; x = S + u; S = x | (S & ~u), + the gather address of a later column.
+# Variants (round 5): how the 64-bit add and the address are made -- half-rate single instructions (what hipcc emits) or pairs of full-rate 4-byte ones
+def lcs_column(i, add, addr, and3=False, nop=0):
+    S, U, X = (60, 61), (58, 59), (56, 57)
+    M = (34 + 2 * (i % 8), 35 + 2 * (i % 8))
+    L = [(f"v_bitop3_b32 v{U[h]}, v{S[h]}, v{M[h]}, v{M[h]} bitop3:0xc0" if and3 else f"v_and_b32 v{U[h]}, v{S[h]}, v{M[h]}") for h in (0, 1)]
+    L += ["s_nop 0"] * (nop & 1)
+    if add == "u64":
+        L.append(f"v_lshl_add_u64 {pr(X)}, {pr(S)}, 0, {pr(U)}")
+    else:
+        L += [f"v_add_co_u32 v{X[0]}, vcc, v{S[0]}, v{U[0]}", f"v_addc_co_u32 v{X[1]}, vcc, v{S[1]}, v{U[1]}, vcc"]
+    L += ["s_nop 0"] * (nop >> 1 & 1)
+    L += [f"v_bitop3_b32 v{S[h]}, v{X[h]}, v{S[h]}, v{U[h]} bitop3:0xf4" for h in (0, 1)]   # x | (s & ~u)
+    if addr == "sdwa":
+        L.append(f"v_lshlrev_b32_sdwa v{28 + i % 4}, v10, v{18 + i % 4} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{i % 4}")
+    elif i % 4 == 0:  # byte 0: mask, then x 8
+        L += [f"v_and_b32 v{28 + i % 4}, v11, v{18 + i % 4}", f"v_mul_u32_u24 v{28 + i % 4}, 8, v{28 + i % 4}"]
+    else:  # (dw >> (8 k - 3)) & 0x7f8
+        L += [f"v_lshrrev_b32 v{28 + i % 4}, {8 * (i % 4) - 3}, v{18 + i % 4}", f"v_and_b32 v{28 + i % 4}, v12, v{28 + i % 4}"]
+    return L
+
+
+def lcs_cols(add, addr, and3=False, nop=0):
+    L = []
+    for i in range(16):
+        L += lcs_column(i, add, addr, and3, nop)
+    return L
+
+
+LCS = {"lcs_u64_sdwa": lcs_cols("u64", "sdwa"), "lcs_u64_sdwa_nop3": lcs_cols("u64", "sdwa", nop=3), "lcs_u64_sdwa_and3": lcs_cols("u64", "sdwa", and3=True),
+       "lcs_addc_sdwa": lcs_cols("addc", "sdwa"), "lcs_u64_shift": lcs_cols("u64", "shift"), "lcs_addc_shift": lcs_cols("addc", "shift"),
+       "lcs_addc_shift_and3": lcs_cols("addc", "shift", and3=True)}
+# ... and over the 6-bit payload (rf_device.hpp row_offset6): the address of column j's table row is a shift (v_alignbit_b32 for the two fields that
+# straddle a dword) and a mask instead of one SDWA shift.  Variants: the shift as VOP2 / VOP3, the mask as a literal v_and / v_and with a VGPR / v_bitop3
+def addr6(i, shift, mask):
+    o = 6 * i
+    d, sh = o // 32, o % 32
+    src, dst = 18 + d, 28 + i % 4
+    if sh + 6 > 32:
+        first = f"v_alignbit_b32 v{dst}, v{src + 1}, v{src}, {sh - 3}"
+    elif sh >= 3:
+        first = (f"v_lshrrev_b32_e64 v{dst}, {sh - 3}, v{src}" if shift == "e64" else f"v_lshrrev_b32 v{dst}, {sh - 3}, v{src}") if sh > 3 else None
+    else:
+        first = f"v_lshlrev_b32_e64 v{dst}, {3 - sh}, v{src}" if shift == "e64" else f"v_lshlrev_b32 v{dst}, {3 - sh}, v{src}"
+    a = dst if first else src
+    second = {"lit": f"v_and_b32 v{dst}, 0x1f8, v{a}", "vgpr": f"v_and_b32 v{dst}, v12, v{a}", "bitop3": f"v_bitop3_b32 v{dst}, v{a}, v12, v12 bitop3:0xc0"}[mask]
+    return ([first] if first else []) + [second]
+
+
+def lcs6_cols(shift, mask, nop=0, and3=True):
+    L = []
+    for i in range(16):
+        c = lcs_column(i, "u64", "sdwa", and3, nop)[:-1]  # the column without its SDWA address ...
+        L += c + addr6(i, shift, mask)                     # ... and the 6-bit one
+    return L
+
+
+LCS.update({"lcs6_e32_lit": lcs6_cols("e32", "lit"), "lcs6_e32_vgpr": lcs6_cols("e32", "vgpr"), "lcs6_e64_lit": lcs6_cols("e64", "lit"), "lcs6_e64_bitop3": lcs6_cols("e64", "bitop3"),
+            "lcs6_e32_bitop3": lcs6_cols("e32", "bitop3"), "lcs6_e64_lit_nop1": lcs6_cols("e64", "lit", 1), "lcs6_e64_lit_nop2": lcs6_cols("e64", "lit", 2),
+            "lcs6_e64_lit_nop3": lcs6_cols("e64", "lit", 3), "lcs6_e32_lit_plainand": lcs6_cols("e32", "lit", 0, False), "lcs6_e64_bitop3_nop3": lcs6_cols("e64", "bitop3", 3)})
+# what decides?  isolated probes of the suspects
+K["mul_u24"] = rep([f"v_mul_u32_u24 v{16 + i}, 8, v6" for i in range(8)])
+K["lshrrev_b32"] = rep([f"v_lshrrev_b32 v{16 + i}, {5 + i}, v6" for i in range(8)])
+K["add_co_addc"] = rep([x for i in range(4) for x in (f"v_add_co_u32 v{16 + 2 * i}, vcc, v1, v6", f"v_addc_co_u32 v{17 + 2 * i}, vcc, v2, v7, vcc")])
+
 JARO = {"jaro_p1_prod": jaro_pass1(0x5), "jaro_p1_nonop": jaro_pass1(0), "jaro_p1_all": jaro_pass1(0xF), "jaro_p2_prod": jaro_pass2(0x3), "jaro_p2_nonop": jaro_pass2(0),
         "jaro_p2_all": jaro_pass2(0xF), "jaro_both_prod": jaro_pass1(0x5) + jaro_pass2(0x3)}
 
@@ -192,7 +263,7 @@ src = ["// GENERATED by tools/gen_cycle_bench.py", "#include <hip/hip_runtime.h>
 ALL = {}
 for name, lines in K.items():
     ALL[name] = (lines, sum(1 for l in lines if l.startswith("v_")))
-for name, lines in list(COLS.items()) + list(JARO.items()):
+for name, lines in list(COLS.items()) + list(JARO.items()) + list(LCS.items()):
     ALL[name] = (lines, sum(1 for l in lines if l.startswith("v_")))
 if os.environ.get("RF_CYCLE_ONLY"):  # e.g. RF_CYCLE_ONLY=jaro,levcol_mask1B3: only the kernels whose name starts with one of these
     ALL = {k: v for k, v in ALL.items() if any(k.startswith(x) for x in os.environ["RF_CYCLE_ONLY"].split(","))}

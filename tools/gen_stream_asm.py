@@ -73,6 +73,9 @@ VP32, VN32, A32, E32, HN32, HP32, T32 = 60, 61, 58, 56, 54, 52, 50
 # still in the ring (7 columns of look-ahead instead of 8, so slot (i - 1) % 8 has not been overwritten yet)
 D0_, R1_, R2_ = (58, 59), (56, 57), (54, 55)
 OSA_BASE = "t ts tr a S e d hn hp hq hs vn vp".split()
+# LCS (Indel, LCS, fuzz::ratio; round 5): state S = v[60:61], u = v[58:59], x = v[56:57]
+LS, LU, LX = (60, 61), (58, 59), (56, 57)
+LCS_BASE = "u p s".split()
 
 
 class Kind:
@@ -114,6 +117,14 @@ class Kind:
                     "hq": ([f"v_add_u32 v{HP32}, v{HP32}, v{HP32}", f"v_add_u32 v{HP32}, 1, v{HP32}"] if ADDS32 else [f"v_lshl_or_b32 v{HP32}, v{HP32}, 1, 1"]),
                     "t": [f"v_bitop3_b32 v{T32}, v{E32}, v{VN32}, v{HP32} bitop3:0x01"], "vn": [f"v_bitop3_b32 v{VN32}, v{HP32}, v{E32}, v{VN32} bitop3:0xe0"],
                     "vp": ([f"v_add_u32 v{HN32}, v{HN32}, v{HN32}", f"v_add_u32 v{VP32}, v{HN32}, v{T32}"] if ADDS32 else [f"v_lshl_add_u32 v{VP32}, v{HN32}, 1, v{T32}"])}[tok]
+        if self.name == "lcs64":
+            # lcs_seq.rs:222-231 (rf_device.hpp LcsState<1>::step): u = S & M; x = S + u; S = x | (S & ~u).  The two ands are written as v_bitop3_b32 ON
+            # PURPOSE: 4-byte full-rate instructions next to half-rate ones (v_lshl_add_u64, SDWA) issue at 4 cycles each, 8-byte ones add up --
+            # 24.0 -> 18.6 cycles per column in the register-only microbenchmark (profiles/lcs_cycles_r05.txt)
+            PM = self.rows[i % 8]
+            return {"u": [f"v_bitop3_b32 v{LU[h]}, v{LS[h]}, v{PM[h]}, v{PM[h]} bitop3:0xc0" for h in (0, 1)],
+                    "p": [f"v_lshl_add_u64 {pr(LX)}, {pr(LS)}, 0, {pr(LU)}"],
+                    "s": [f"v_bitop3_b32 v{LS[h]}, v{LX[h]}, v{LS[h]}, v{LU[h]} bitop3:0xf4" for h in (0, 1)]}[tok]
         PM, PMO = self.rows[i % 8], self.rows[(i - 1) % 8]
         return {"t": [f"v_bitop3_b32 v{R1_[h]}, v{D0_[h]}, v{PM[h]}, v{PM[h]} bitop3:0x0c" for h in (0, 1)],       # ~D0 & PM
                 "ts": [f"v_lshlrev_b64 {pr(R1_)}, 1, {pr(R1_)}"],
@@ -133,8 +144,8 @@ class Kind:
         """one recurrence column on row slot i % 8, and the look-ahead gather (`gather`: the lines of K.gather(i + la, ...)) where the
         kind's token order puts it -- token "x"; behind the column by default (RF_GEN_ORDER32 / RF_GEN_ORDER64: experiment knobs)"""
         L = [f"s_waitcnt lgkmcnt({self.la - 1})"]  # `la` reads in flight, in order: column i's row has arrived
-        order = self.order or ((OSA_BASE if self.name == "osa" else LEV_BASE) + ["x"])
-        base = OSA_BASE if self.name == "osa" else LEV_BASE
+        base = {"osa": OSA_BASE, "lcs64": LCS_BASE}.get(self.name, LEV_BASE)
+        order = self.order or (base + ["x"])
         for tok in order:
             if tok == "x":
                 L += list(gather)
@@ -149,6 +160,8 @@ class Kind:
             return ["v_mov_b32 v60, -1", "v_mov_b32 v61, -1", "v_mov_b32 v62, 0", "v_mov_b32 v63, 0"]
         if self.name == "lev32":
             return ["v_mov_b32 v60, -1", "v_mov_b32 v61, 0"]
+        if self.name == "lcs64":  # lcs_seq.rs:215
+            return ["v_mov_b32 v60, -1", "v_mov_b32 v61, -1"]
         # osa.rs:74-77, :125-135: D0 = 0 and no previous column: its table row (slot 7) is zero
         return ["v_mov_b32 v60, -1", "v_mov_b32 v61, -1", "v_mov_b32 v62, 0", "v_mov_b32 v63, 0", "v_mov_b32 v58, 0", "v_mov_b32 v59, 0",
                 "v_mov_b32 v48, 0", "v_mov_b32 v49, 0"]
@@ -255,6 +268,36 @@ class BlockKind(Kind):
         return L
 
 
+class Lcs6Kind(Kind):
+    """The LCS recurrence (Kind "lcs64") over the 6-BIT PAYLOAD of a single-length corpus (rf_pack.hip pack6_kernel; round 5): a chunk is three
+    dwords per lane -- symbol j on bits 6 j .. 6 j + 5 of the 96-bit value -- fetched with global_load_dwordx3 (768 contiguous bytes per wavefront instead of 1 KiB).
+    The Indel / LCS scans wait for HBM on the 8-bit payload (25 % fewer bytes: nothing, as long as the column costs the 25 cycles hipcc's form of it does;
+    a 21-cycle column: nothing on 8-bit bytes; both together: this kernel).  The table row address of column j is a shift and a mask instead of one SDWA shift:
+    v_lshrrev_b32 in its LONG encoding (a 4-byte one next to the half-rate v_lshl_add_u64 issues at 4 cycles) + v_and_b32 with the literal 0x1f8, v_alignbit_b32
+    for the two fields that straddle a dword (profiles/lcs_cycles_r05.txt: 21.0 cycles per column register-only, 25.1 as hipcc writes it).
+    Single-length corpora whose length is a multiple of 16 only (no partial chunks: the launcher keeps the others on the 8-bit kernels)."""
+    chunk_dwords, no_partial, chunk_pitch = 3, True, 768
+
+    def __init__(self, bufs, nop_mask):
+        Kind.__init__(self, "lcs64", 64, 8, bufs, (60, 61), nop_mask)
+        self.name6 = "lcs6"
+
+    def gather(self, j, use, nxt):
+        base, jj = (use, j) if j < 16 else (nxt, j - 16)
+        o = 6 * jj
+        d, sh = o // 32, o % 32
+        a, src = ADDR[j % 4], base + d
+        if sh + 6 > 32:
+            x = [f"v_alignbit_b32 v{a}, v{src + 1}, v{src}, {sh - 3}", f"v_and_b32 v{a}, 0x1f8, v{a}"]
+        elif sh > 3:
+            x = [f"v_lshrrev_b32_e64 v{a}, {sh - 3}, v{src}", f"v_and_b32 v{a}, 0x1f8, v{a}"]
+        elif sh == 3:
+            x = [f"v_and_b32 v{a}, 0x1f8, v{src}"]
+        else:
+            x = [f"v_lshlrev_b32_e64 v{a}, {3 - sh}, v{src}", f"v_and_b32 v{a}, 0x1f8, v{a}"]
+        return x + [f"ds_read_b64 {pr(self.rows[j % 8])}, v{a}"]
+
+
 def dispatch(lo, hi, L, sfx):  # binary tree of scalar compares over k in [lo, hi]
     if lo == hi:
         L.append(f"s_branch Ls{lo}_{sfx}")
@@ -277,12 +320,27 @@ def wait_vm(n, extra, tag, sfx):
             f"Lw{tag}a_{sfx}:", f"s_waitcnt vmcnt({n})", f"Lw{tag}b_{sfx}:"]
 
 
+def chunk_load(K, buf):
+    """this lane's next chunk into ring buffer `buf`: 16 bytes (the 8-bit payload), or 12 (the 6-bit one); v2 = lane x that"""
+    n = getattr(K, "chunk_dwords", 4)
+    return f"global_load_dwordx{n} v[{buf}:{buf + n - 1}], {V_OFF16}, {S_SRC} nt"
+
+
 def step(K, P, extra):
     """fetch + the 16 columns of ring phase P; labels carry the phase and the statement's unique id"""
     R, sfx = K.ring, f"p{P}_%="
     use, nxt, refill = K.bufs[P], K.bufs[(P + 1) % R], K.bufs[(P + R - 1) % R]
-    L = [f"global_load_dwordx4 v[{refill}:{refill + 3}], {V_OFF16}, {S_SRC} nt",  # the chunk RING-1 steps ahead
-         f"s_cmp_eq_u32 {S_K}, 0", f"s_cbranch_scc1 Lfull_{sfx}"]
+    L = [chunk_load(K, refill)]  # the chunk RING-1 steps ahead
+    if getattr(K, "no_partial", False):  # (every chunk is whole: the launcher's condition)
+        late = extra if R > 2 else 0
+        L += wait_vm(R - 1, extra, "f", sfx)
+        for i in range(16):
+            if i == 8:
+                L += wait_vm(R - 2, late, "h", sfx)
+                L.append(f"s_mov_b32 {S_AFTER}, 0")
+            L += K.column(i, K.gather(i + K.la, use, nxt))
+        return L
+    L += [f"s_cmp_eq_u32 {S_K}, 0", f"s_cbranch_scc1 Lfull_{sfx}"]
     # ---- a tile's last, partial chunk: shift its bytes up by k positions in place, gather its rows, enter at column k
     # (a ring of 2 fetches the NEXT chunk at the top of this very step: that load is younger than the epilogue's store and index load,
     # so nothing may be counted in -- the wait is a drain)
@@ -364,13 +422,17 @@ def kernel(K, uniform):
     W = getattr(K, "W", 1)
 
     def fetch_glue(tag):  # src = address of the chunk under the fetch cursor; advance the cursor (parks on the last valid chunk)
-        G = [f"s_lshl_b32 {T0}, {S_FC}, 10", f"s_add_u32 {S_SRC_LO}, {S_FBASE_LO}, {T0}", f"s_addc_u32 {S_SRC_HI}, {S_FBASE_HI}, 0",
+        G = [f"s_mul_i32 {T0}, {S_FC}, {K.chunk_pitch}" if hasattr(K, "chunk_pitch") else f"s_lshl_b32 {T0}, {S_FC}, 10",
+             f"s_add_u32 {S_SRC_LO}, {S_FBASE_LO}, {T0}", f"s_addc_u32 {S_SRC_HI}, {S_FBASE_HI}, 0",
              f"s_add_u32 {S_FC}, {S_FC}, 1", f"s_cmp_lt_u32 {S_FC}, {S_FN}", f"s_cbranch_scc1 Lfok_{tag}_%=",
              f"s_add_u32 {T0}, {S_FT}, {S_STRIDE}", f"s_cmp_lt_u32 {T0}, {S_TEND}", f"s_cbranch_scc0 Lfpark_{tag}_%=",
              f"s_mov_b32 {S_FT}, {T0}"]
         G += tile_desc(S_FT, uniform, fetch=True)
         G += [f"s_mov_b32 {S_FC}, 0", f"s_branch Lfok_{tag}_%=", f"Lfpark_{tag}_%=:", f"s_sub_u32 {S_FC}, {S_FN}, 1", f"Lfok_{tag}_%=:"]
         return G
+
+    def off_of_lane(dst, lane):  # the lane's byte offset inside a chunk row: x 16, or x 12 on the 6-bit payload
+        return f"v_mul_u32_u24 {dst}, 12, {lane}" if getattr(K, "chunk_dwords", 4) == 3 else f"v_lshlrev_b32 {dst}, 4, {lane}"
 
     # ---- kernarg block -> s8..s32
     L += [f"s_load_dwordx8 s[8:15], %[kp], {off['data']}", f"s_load_dwordx4 s[16:19], %[kp], {off['sigma']}",
@@ -395,11 +457,11 @@ def kernel(K, uniform):
     prefetch = []  # the first RING-1 chunks of the stream
     for b in range(R - 1):
         prefetch += fetch_glue(f"pre{b}")
-        prefetch.append(f"global_load_dwordx4 v[{K.bufs[b]}:{K.bufs[b] + 3}], {V_OFF16}, {S_SRC} nt")
+        prefetch.append(chunk_load(K, K.bufs[b]))
     if EARLY_FETCH:
         # (round 5) the stream's first chunks are requested BEFORE the pattern table is staged: the two round trips overlap instead of following each
         # other at the head of every workgroup (a wavefront without a tile still stages its share of the table and meets the barrier)
-        L += first_tile + ["v_and_b32 v2, 63, v1", "v_lshlrev_b32 v2, 4, v2", f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lnotile_%="]
+        L += first_tile + ["v_and_b32 v2, 63, v1", off_of_lane("v2", "v2"), f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lnotile_%="]
         L += cursors + prefetch + ["Lnotile_%=:"]
     # ---- stage the pattern table: thread i puts row i at row sigma(i) (the corpus stores renamed symbols)
     if W == 1:
@@ -416,7 +478,7 @@ def kernel(K, uniform):
     if not EARLY_FETCH:
         L += first_tile
     # ---- lane constants
-    L += ["v_and_b32 v1, 63, v1", "v_lshlrev_b32 v2, 4, v1", "v_lshlrev_b32 v3, 2, v1", "v_mov_b32 v5, 0", f"v_mov_b32 {V_KS}, {K.ks}",
+    L += ["v_and_b32 v1, 63, v1", off_of_lane("v2", "v1"), "v_lshlrev_b32 v3, 2, v1", "v_mov_b32 v5, 0", f"v_mov_b32 {V_KS}, {K.ks}",
           f"s_cmp_ge_u32 {S_T}, {S_TEND}", "s_cbranch_scc1 Lexit_%=", f"s_mov_b32 {S_C}, 0", f"s_mov_b32 {S_AFTER}, 0"]
     if not EARLY_FETCH:
         L += cursors
@@ -451,18 +513,26 @@ def kernel(K, uniform):
             for h in (0, 1):
                 L += [f"v_and_b32 v8, s{72 + 2 * w + h}, v{K.VP[w][h]}", "v_bcnt_u32_b32 v6, v8, v6",
                       f"v_and_b32 v8, s{72 + 2 * w + h}, v{K.VN[w][h]}", "v_bcnt_u32_b32 v7, v8, v7"]
+    elif K.name == "lcs64":  # the LCS length: the zero bits of S among the query's rows (rf_device.hpp LcsState::result)
+        L += ["v_not_b32 v6, v60", f"v_and_b32 v6, {S_VLO}, v6", "v_bcnt_u32_b32 v6, v6, 0", "v_not_b32 v7, v61", f"v_and_b32 v7, {S_VHI}, v7", "v_bcnt_u32_b32 v6, v7, v6"]
     elif K.bits == 64:
         L += [f"v_and_b32 v6, {S_VLO}, v60", "v_bcnt_u32_b32 v6, v6, 0", f"v_and_b32 v7, {S_VHI}, v61", "v_bcnt_u32_b32 v6, v7, v6",
               f"v_and_b32 v7, {S_VLO}, v62", "v_bcnt_u32_b32 v7, v7, 0", f"v_and_b32 v8, {S_VHI}, v63", "v_bcnt_u32_b32 v7, v8, v7"]
     else:
         L += [f"v_and_b32 v6, {S_VLO}, v60", "v_bcnt_u32_b32 v6, v6, 0", f"v_and_b32 v7, {S_VLO}, v61", "v_bcnt_u32_b32 v7, v7, 0"]
-    L += ["v_sub_u32 v6, v6, v7", f"v_add_u32 v6, {S_LEN2}, v6",                       # raw = len2 + pp - pn
-          f"v_mul_lo_u32 v6, v6, {S_VR}", f"v_add_u32 v6, {S_V0}, v6",                  # value = v0 + vR * raw
+    if K.name != "lcs64":
+        L += ["v_sub_u32 v6, v6, v7", f"v_add_u32 v6, {S_LEN2}, v6"]                   # raw = len2 + pp - pn
+    L += [f"v_mul_lo_u32 v6, v6, {S_VR}", f"v_add_u32 v6, {S_V0}, v6",                  # value = v0 + vR * raw
           f"v_xor_b32 v7, {S_FLIP}, v6", f"v_cmp_ge_u32 vcc, {S_CFLIP}, v7", "v_cndmask_b32 v6, -1, v6, vcc"]  # None unless (value ^ flip) <= cflip
     if not uniform:
         # the index load was issued at the tile's start, BEHIND the ring loads then in flight: all but the newest operation done
         # means it has landed (the over-wait is the chunk fetched one step ago, which the next block needs at its column 8 anyway)
-        L.append("s_waitcnt vmcnt(1)")
+        # (round 5: not vmcnt(1) whatever the ring -- since the index load one chunk per step has been requested, nch of them, and at most R - 1 ring loads are
+        # outstanding at a tile's end, all younger than it once nch >= R - 1: "no more than min(nch, R - 1) operations outstanding" is exactly "the index has
+        # landed", and a ring of 3 or 4 no longer drains to its newest chunk at the end of every tile)
+        for y in range(1, R - 1):
+            L += [f"s_cmp_lt_u32 {S_NCH}, {y + 1}", f"s_cbranch_scc0 Lix{y}_%=", f"s_waitcnt vmcnt({y})", "s_branch Lixd_%=", f"Lix{y}_%=:"]
+        L += [f"s_waitcnt vmcnt({R - 1})", "Lixd_%=:"]
         # slot store (flags bit 1): index = slot, every lane stores (padding lanes own a slot of the temporary)
         L += [f"s_bitcmp1_b32 {S_FLAGS}, 1", "s_cbranch_scc0 Lnoslot_%=", f"v_add_u32 {V_IDX}, {S_SLOT0}, {V_LANE}", "Lnoslot_%=:"]
     L += [f"v_cmp_gt_u32 vcc, {S_N}, {V_IDX}" if uniform else f"v_cmp_ne_u32 vcc, -1, {V_IDX}",                 # real candidates only
@@ -492,6 +562,10 @@ KINDS = [
     Kind("lev64", 64, 8, [14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RING64", "3")):], range(60, 64), int(os.environ.get("RF_GEN_MASK64", "0x1B3"), 0)),  # (RF_GEN_*: experiment knobs, tools/build_stream_variant.sh)
     Kind("lev32", 32, 8, [42, 46, 22, 26][: int(os.environ.get("RF_GEN_RING32", "4"))], (60, 61), int(os.environ.get("RF_GEN_MASK32", "0x80"), 0)),
     Kind("osa", 64, 7, RING3, range(58, 64), 0x613),
+    # (the LCS column over the 8-bit payload -- Kind("lcs64", 64, 8, [14, 18, 22, 26], (60, 61), 0), any corpus -- was built and measured in round 5: its
+    # 18.6-cycle column buys nothing where the compiled scan already waits for HBM (single-length 100 M: 78.6 vs 79.9 Gpairs/s, ragged 20 M: 72.9 vs 73.9):
+    # only the 6-bit form below ships, profiles/lcs_cycles_r05.txt)
+    Lcs6Kind([14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RINGLCS6", "4")):], int(os.environ.get("RF_GEN_MASKLCS6", "0"), 0)),
 ] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x0426"), 0)) for W in (2, 3, 4)]  # s_nop behind a, S, hn, vn: best of 22 placements (profiles/levw_nop_masks_r04.txt)
 
 
@@ -507,9 +581,11 @@ def main():
                + ', "vcc", "scc", "memory"')  # (exec is restored to all ones before the body ends)
     for K in KINDS:
         for uniform in (True, False):
-            out.append(f"// ---- {K.name}, {'single-length corpus (tile t at t * tile_bytes, slot = index)' if uniform else 'tile descriptors + orig[]'}: "
+            if getattr(K, "no_partial", False) and not uniform:
+                continue  # (single-length corpora only)
+            out.append(f"// ---- {getattr(K, 'name6', K.name)}, {'single-length corpus (tile t at t * tile_bytes, slot = index)' if uniform else 'tile descriptors + orig[]'}: "
                        f"ring of {K.ring} at v{', v'.join(str(b) for b in K.bufs)}, look-ahead {K.la}")
-            out += macro(f"RF_STREAM_{K.name.upper()}_{'UNIFORM' if uniform else 'TILES'}_ASM", kernel(K, uniform))
+            out += macro(f"RF_STREAM_{getattr(K, 'name6', K.name).upper()}_{'UNIFORM' if uniform else 'TILES'}_ASM", kernel(K, uniform))
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rapidfuzz_rs_amd", "csrc", "rf_stream_asm.inc")
     open(path, "w").write("\n".join(out) + "\n")
 
