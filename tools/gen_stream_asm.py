@@ -39,6 +39,8 @@ ADDS32 = os.environ.get("RF_GEN_ADDS32", "0") == "1"
 # experiment knob.  The multi-word kernels always do (+4.6 % on configs[2], profiles/levw_addc_r04.txt; their hn_c through a second carry chain over an
 # SGPR pair was built and measured 17 % slower in round 4 and is gone from the generator).
 ADDC = set(filter(None, os.environ.get("RF_GEN_ADDC", "").replace(" ", "").split(",")))
+VOP3_32 = os.environ.get("RF_GEN_VOP3_32", "0") == "1"
+VOP3_OSA = os.environ.get("RF_GEN_VOP3_OSA", "0") == "1"
 EARLY_FETCH = os.environ.get("RF_GEN_EARLY_FETCH", "1") == "1"  # 0: the first chunks are requested after the pattern table is staged (rounds 3-4: the A/B)
 BAND = os.environ.get("RF_GEN_BAND", "1") == "1"  # 0: the multi-word kernels run every word in every column (round 4's kernels: the A/B)
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
@@ -110,6 +112,12 @@ class Kind:
                     "vp": [f"v_lshl_add_u64 {pr(VP)}, {pr(HN)}, 1, {pr(T)}"]}[tok]                                 # VP' = (HN << 1) + T
         if self.name == "lev32":
             PM = self.rows[i % 8][0]
+            if VOP3_32:  # (experiment, round 5: the three 4-byte instructions in their long encodings -- the rule of profiles/lcs_cycles_r05.txt)
+                return {"a": [f"v_and_b32_e64 v{A32}, v{PM}, v{VP32}"], "S": [f"v_add_u32_e64 v{A32}, v{A32}, v{VP32}"],
+                        "e": [f"v_bitop3_b32 v{E32}, v{A32}, v{VP32}, v{PM} bitop3:0xbe"], "hp": [f"v_bitop3_b32 v{HP32}, v{VN32}, v{E32}, v{VP32} bitop3:0xf1"],
+                        "hn": [f"v_and_b32_e64 v{HN32}, v{E32}, v{VP32}"], "hq": [f"v_lshl_or_b32 v{HP32}, v{HP32}, 1, 1"],
+                        "t": [f"v_bitop3_b32 v{T32}, v{E32}, v{VN32}, v{HP32} bitop3:0x01"], "vn": [f"v_bitop3_b32 v{VN32}, v{HP32}, v{E32}, v{VN32} bitop3:0xe0"],
+                        "vp": [f"v_lshl_add_u32 v{VP32}, v{HN32}, 1, v{T32}"]}[tok]
             return {"a": [f"v_and_b32 v{A32}, v{PM}, v{VP32}"], "S": [f"v_add_u32 v{A32}, v{A32}, v{VP32}"],
                     "e": [f"v_bitop3_b32 v{E32}, v{A32}, v{VP32}, v{PM} bitop3:0xbe"], "hp": [f"v_bitop3_b32 v{HP32}, v{VN32}, v{E32}, v{VP32} bitop3:0xf1"],
                     "hn": [f"v_and_b32 v{HN32}, v{E32}, v{VP32}"],
@@ -126,6 +134,21 @@ class Kind:
                     "p": [f"v_lshl_add_u64 {pr(LX)}, {pr(LS)}, 0, {pr(LU)}"],
                     "s": [f"v_bitop3_b32 v{LS[h]}, v{LX[h]}, v{LS[h]}, v{LU[h]} bitop3:0xf4" for h in (0, 1)]}[tok]
         PM, PMO = self.rows[i % 8], self.rows[(i - 1) % 8]
+        AND = (lambda d, a, b: f"v_bitop3_b32 v{d}, v{a}, v{b}, v{b} bitop3:0xc0") if VOP3_OSA else (lambda d, a, b: f"v_and_b32 v{d}, v{a}, v{b}")
+        if VOP3_OSA:  # (experiment, round 5: the eight ands in the long encoding)
+            return {"t": [f"v_bitop3_b32 v{R1_[h]}, v{D0_[h]}, v{PM[h]}, v{PM[h]} bitop3:0x0c" for h in (0, 1)],
+                    "ts": [f"v_lshlrev_b64 {pr(R1_)}, 1, {pr(R1_)}"],
+                    "tr": [AND(R1_[h], R1_[h], PMO[h]) for h in (0, 1)],
+                    "a": [AND(R2_[h], PM[h], VP[h]) for h in (0, 1)],
+                    "S": [f"v_lshl_add_u64 {pr(R2_)}, {pr(R2_)}, 0, {pr(VP)}"],
+                    "e": [f"v_bitop3_b32 v{R2_[h]}, v{R2_[h]}, v{VP[h]}, v{PM[h]} bitop3:0xbe" for h in (0, 1)],
+                    "d": [f"v_bitop3_b32 v{D0_[h]}, v{R2_[h]}, v{VN[h]}, v{R1_[h]} bitop3:0xfe" for h in (0, 1)],
+                    "hn": [AND(R1_[h], D0_[h], VP[h]) for h in (0, 1)],
+                    "hp": [f"v_bitop3_b32 v{R2_[h]}, v{VN[h]}, v{D0_[h]}, v{VP[h]} bitop3:0xf1" for h in (0, 1)],
+                    "hq": [f"v_lshl_add_u64 {pr(R2_)}, {pr(R2_)}, 1, 1"],
+                    "hs": [f"v_lshlrev_b64 {pr(R1_)}, 1, {pr(R1_)}"],
+                    "vn": [AND(VN[h], R2_[h], D0_[h]) for h in (0, 1)],
+                    "vp": [f"v_bitop3_b32 v{VP[h]}, v{R1_[h]}, v{R2_[h]}, v{D0_[h]} bitop3:0xf1" for h in (0, 1)]}[tok]
         return {"t": [f"v_bitop3_b32 v{R1_[h]}, v{D0_[h]}, v{PM[h]}, v{PM[h]} bitop3:0x0c" for h in (0, 1)],       # ~D0 & PM
                 "ts": [f"v_lshlrev_b64 {pr(R1_)}, 1, {pr(R1_)}"],
                 "tr": [f"v_and_b32 v{R1_[h]}, v{R1_[h]}, v{PMO[h]}" for h in (0, 1)],                              # & PM_old
@@ -561,7 +584,7 @@ KINDS = [
     # name, word bits, look-ahead, ring buffers (first VGPR of each), state registers, s_nop mask over the column's tokens
     Kind("lev64", 64, 8, [14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RING64", "3")):], range(60, 64), int(os.environ.get("RF_GEN_MASK64", "0x1B3"), 0)),  # (RF_GEN_*: experiment knobs, tools/build_stream_variant.sh)
     Kind("lev32", 32, 8, [42, 46, 22, 26][: int(os.environ.get("RF_GEN_RING32", "4"))], (60, 61), int(os.environ.get("RF_GEN_MASK32", "0x80"), 0)),
-    Kind("osa", 64, 7, RING3, range(58, 64), 0x613),
+    Kind("osa", 64, 7, RING3, range(58, 64), int(os.environ.get("RF_GEN_MASKOSA", "0x613"), 0)),
     # (the LCS column over the 8-bit payload -- Kind("lcs64", 64, 8, [14, 18, 22, 26], (60, 61), 0), any corpus -- was built and measured in round 5: its
     # 18.6-cycle column buys nothing where the compiled scan already waits for HBM (single-length 100 M: 78.6 vs 79.9 Gpairs/s, ragged 20 M: 72.9 vs 73.9):
     # only the 6-bit form below ships, profiles/lcs_cycles_r05.txt)
