@@ -978,10 +978,10 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
         else
             hipLaunchKernelGGL((scan_kernel_occ8<State, true>), g, b, 0, stream, p);
     } else {
-        // queries of 65 .. 256 symbols, one u32 per candidate, no cutoff: the multi-word asm scans (rf_stream_asm.hip, word planes in
+        // queries of 65 .. 512 symbols, one u32 per candidate, no cutoff: the multi-word asm scans (rf_stream_asm.hip, word planes in
         // LDS); zero-length tiles go to the compiled kernel like above.  RF_ASM_BLOCK=0 keeps the compiled kernel for A/B.
         static const bool use_block_asm = [] { const char* e = getenv("RF_ASM_BLOCK"); return !e || atoi(e) != 0; }();
-        constexpr bool kLevW = std::is_same<State, LevState<2>>::value || std::is_same<State, LevState<3>>::value || std::is_same<State, LevState<4>>::value;
+        constexpr bool kLevW = std::is_same<State, LevState<State::kWords>>::value && State::kWords >= 2 && State::kWords <= 8;  // (round 5: 5 .. 8 words too)
         if (kLevW && use_block_asm && stream_asm_serves(p)) {
             uint32_t at = p.tile_begin;
             for (int r = 0; r <= 2 && at < p.tile_end; ++r) {

@@ -46,7 +46,7 @@ BAND = os.environ.get("RF_GEN_BAND", "1") == "1"  # 0: the multi-word kernels ru
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
         ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
-        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4), ("band_k", 4), ("valid_w", 32), ("pad1", 4)]  # valid_w: (lo, hi) row masks of words 0..3; band_k: distances above it need not be exact (multi-word kernels)
+        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4), ("band_k", 4), ("valid_w", 64), ("pad1", 4)]  # valid_w: (lo, hi) row masks of words 0..7; band_k: distances above it need not be exact (multi-word kernels)
 # SGPR map
 S_DATA, S_TILES, S_ORIG, S_PM, S_SIGMA, S_OUT = "s[8:9]", "s[10:11]", "s[12:13]", "s[14:15]", "s[16:17]", "s[18:19]"
 (S_TBEGIN, S_TEND, S_N, S_ULEN, S_UBYTES, S_LEN1, S_VS, S_VM, S_VR, S_FLIP, S_CFLIP, S_VLO) = [f"s{i}" for i in range(20, 32)]
@@ -60,7 +60,7 @@ S_K, S_Q, S_R8, S_SH = "s48", "s49", "s50", "s51"
 T0, T1, T2, T3 = "s52", "s53", "s54", "s55"
 S_DESC = "s[60:63]"  # TileDesc {u64 data_off, u32 len, u32 slot0}
 S_NEXT, S_AFTER, S_EXEC = "s64", "s65", "s[66:67]"  # S_AFTER: this step follows a tile epilogue whose store (and index load) are still younger than the ring
-S_KBAND, S_DHI, S_DLO, S_LIVE = "s80", "s81", "s82", "s83"  # multi-word kernels: the Ukkonen band (BlockKind)
+S_KBAND, S_DHI, S_DLO, S_LIVE = "s88", "s89", "s90", "s91"  # multi-word kernels: the Ukkonen band (BlockKind)
 V_LANE, V_OFF16, V_OFF4, V_IDX, V_ZERO, V_KS = "v1", "v2", "v3", "v4", "v5", "v10"
 
 
@@ -217,15 +217,23 @@ class BlockKind(Kind):
       * 64 VGPRs = 8 wavefronts per SIMD: v14..21 ring, v22..23 gather addresses, v24..39 row slots, v40..47 VP, v48..55 VN,
         v56..63 A E HN HP, v6..7 T, v11 / v3 / v12 hn_c of words 0 / 1 / 2 (v8, v9, v13 idle)."""
     TOKENS = "x a S e hp hn hnc hq t tor vn vp".split()
-    HNC = [11, 3, 12]
 
     def __init__(self, W, nop_mask):
         Kind.__init__(self, f"levw{W}", 64, 2, [14, 18], range(40, 56), nop_mask)
         self.W = W
         self.addr = [22, 23]
-        self.slots = [[(24 + 8 * sl + 2 * w, 25 + 8 * sl + 2 * w) for w in range(W)] for sl in range(2)]
-        self.VP = [(40 + 2 * w, 41 + 2 * w) for w in range(W)]
-        self.VN = [(48 + 2 * w, 49 + 2 * w) for w in range(W)]
+        if W <= 4:  # 64 VGPRs = 8 wavefronts per SIMD
+            self.slots = [[(24 + 8 * sl + 2 * w, 25 + 8 * sl + 2 * w) for w in range(W)] for sl in range(2)]
+            self.VP = [(40 + 2 * w, 41 + 2 * w) for w in range(W)]
+            self.VN = [(48 + 2 * w, 49 + 2 * w) for w in range(W)]
+            self.TMP = [(56, 57), (58, 59), (60, 61), (62, 63)]  # A E HN HP
+            self.HNC = [11, 3, 12]
+        else:  # queries of 257 .. 512 symbols (round 5): 104 VGPRs = 4 wavefronts per SIMD -- the compiled LevState<5..8> holds 133..184 = 3..2
+            self.slots = [[(24 + 16 * sl + 2 * w, 25 + 16 * sl + 2 * w) for w in range(W)] for sl in range(2)]  # v24..55
+            self.VP = [(56 + 2 * w, 57 + 2 * w) for w in range(W)]                                               # v56..71
+            self.VN = [(72 + 2 * w, 73 + 2 * w) for w in range(W)]                                               # v72..87
+            self.TMP = [(88, 89), (90, 91), (92, 93), (94, 95)]
+            self.HNC = [11, 3, 12, 13, 9, 96, 97]
         self.uid = 0
 
     def gather(self, j, use, nxt):
@@ -253,7 +261,7 @@ class BlockKind(Kind):
 
     def column(self, i, gather=()):
         W, HNC = self.W, self.HNC
-        A_, E_, HN_, HP_, T_ = (56, 57), (58, 59), (60, 61), (62, 63), (6, 7)
+        (A_, E_, HN_, HP_), T_ = self.TMP, (6, 7)
         R = self.slots[i % 2]
         # this column's W reads have arrived; the next column's W may still be in flight.  VCC = all ones: word 0's (or the first live word's) + 1
         L = [f"s_waitcnt lgkmcnt({W})", "s_mov_b64 vcc, -1"]
@@ -462,7 +470,7 @@ def kernel(K, uniform):
           f"s_load_dwordx8 s[20:27], %[kp], {off['tile_begin']}", f"s_load_dwordx4 s[28:31], %[kp], {off['fin_vR']}",
           f"s_load_dwordx2 s[68:69], %[kp], {off['valid_hi']}", f"s_mov_b32 {S_STRIDE}, %[stride]"]
     if W > 1:
-        L += [f"s_load_dwordx8 s[72:79], %[kp], {off['valid_w']}", f"s_load_dword {S_KBAND}, %[kp], {off['band_k']}"]
+        L += [f"s_load_dwordx{16 if W > 4 else 8} s[72:{87 if W > 4 else 79}], %[kp], {off['valid_w']}", f"s_load_dword {S_KBAND}, %[kp], {off['band_k']}"]
     L += ["v_and_b32 v1, 0x3ff, %[tid]", "s_waitcnt lgkmcnt(0)"]
     # ---- this wavefront's first tile: the workgroup's place in the deal of tiles is its id, or (flags bit 0, "xcd deal") (id % 8) * (grid / 8) + id / 8,
     # so that consecutive tiles are walked by workgroups of ONE XCD (workgroups are dispatched to the 8 XCDs round-robin)
@@ -589,7 +597,7 @@ KINDS = [
     # 18.6-cycle column buys nothing where the compiled scan already waits for HBM (single-length 100 M: 78.6 vs 79.9 Gpairs/s, ragged 20 M: 72.9 vs 73.9):
     # only the 6-bit form below ships, profiles/lcs_cycles_r05.txt)
     Lcs6Kind([14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RINGLCS6", "4")):], int(os.environ.get("RF_GEN_MASKLCS6", "0"), 0)),
-] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x0426"), 0)) for W in (2, 3, 4)]  # s_nop behind a, S, hn, vn: best of 22 placements (profiles/levw_nop_masks_r04.txt)
+] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x0426"), 0)) for W in (2, 3, 4, 5, 6, 7, 8)]  # s_nop behind a, S, hn, vn: best of 22 placements (profiles/levw_nop_masks_r04.txt)
 
 
 def main():
@@ -600,8 +608,10 @@ def main():
         out.append(f"#define RF_STREAM_ARG_{name.upper()} {o}")
         o += size
     out.append(f"#define RF_STREAM_ARGS_SIZE {o}")
-    out.append('#define RF_STREAM_CLOBBERS ' + ", ".join(f'"v{r}"' for r in range(1, 64)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 84) if r != 32)
+    out.append('#define RF_STREAM_CLOBBERS ' + ", ".join(f'"v{r}"' for r in range(1, 64)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 92) if r != 32)
                + ', "vcc", "scc", "memory"')  # (exec is restored to all ones before the body ends)
+    out.append('#define RF_STREAM_CLOBBERS_WIDE ' + ", ".join(f'"v{r}"' for r in range(1, 104)) + ", " + ", ".join(f'"s{r}"' for r in range(8, 92) if r != 32)
+               + ', "vcc", "scc", "memory"')  # (queries of 257 .. 512 symbols: 104 VGPRs = 4 wavefronts per SIMD)
     for K in KINDS:
         for uniform in (True, False):
             if getattr(K, "no_partial", False) and not uniform:
