@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
         L.rfo_free_usize.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(CallArgs), C.POINTER(C.c_size_t)]
         L.rfo_free_f64.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(CallArgs), C.POINTER(C.c_double)]
         L.rfo_last_lev_path.restype = C.c_int
+        L.rfo_last_lcs_q8_edges.restype = C.c_uint
         vp = C.c_void_p
         L.rfo_batch_many_usize.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(CallArgs), vp, C.c_int]
         L.rfo_batch_many_f64.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(CallArgs), vp, C.c_int]
@@ -108,6 +109,11 @@ def make_args(score_cutoff=None, score_hint=None, weights=(1, 1, 1), prefix_weig
     a.weights = _Weights(*[int(w) for w in weights])
     a.prefix_weight = float(prefix_weight)
     return a
+
+
+def last_lcs_q8_edges() -> int:
+    """rows of the last banded multi-word LCS call on this thread that met quirk Q8's precondition (rfo_oracle.h)"""
+    return int(lib().rfo_last_lcs_q8_edges())
 
 
 def last_lev_path() -> str:

@@ -299,6 +299,8 @@ int rfo_free_f64(int metric, int op, const uint8_t *s1, size_t len1, const uint8
     return call_f64(metric, NULL, op, a1, a2, a, out);
 }
 int rfo_last_lev_path(void) { return rfo_last_path; }
+extern __thread unsigned rfo_q8_edges;
+unsigned rfo_last_lcs_q8_edges(void) { return rfo_q8_edges; }
 
 /* ---- one-vs-many loops (what a user of the reference writes around BatchComparator, cf.
  *      rapidfuzz-benches/benches/bench_levenshtein.rs:51-60), optionally split over threads ---- */

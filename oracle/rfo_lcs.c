@@ -84,6 +84,10 @@ static size_t lcs_unroll(const rfo_pm *pm, size_t n_words, rfo_str s2, size_t sc
     return sim >= score_cutoff ? sim : 0;
 }
 
+/* instrumentation (tests only): how often the last lcs_blockwise call on this thread moved its band's last block with a row index that is a multiple of 64 --
+ * the precondition of quirk Q8 below (rfo_last_lcs_q8_edges) */
+__thread unsigned rfo_q8_edges = 0;
+
 /* lcs_seq.rs:267-341 lcs_blockwise<0> */
 static size_t lcs_blockwise(const rfo_pm *pm, size_t len1, rfo_str s2, size_t score_cutoff)
 {
@@ -98,6 +102,7 @@ static size_t lcs_blockwise(const rfo_pm *pm, size_t len1, rfo_str s2, size_t sc
 
     size_t first_block = 0;
     size_t last_block = rfo_min(words, rfo_ceil_div(band_width_left + 1, word_size));
+    rfo_q8_edges = 0;
 
     for (size_t row = 0; row < len2; ++row) {
         uint8_t ch2 = s2.p[row];
@@ -115,7 +120,12 @@ static size_t lcs_blockwise(const rfo_pm *pm, size_t len1, rfo_str s2, size_t sc
         if (row > band_width_right) first_block = (row - band_width_right) / word_size;
         /* (quirk Q8: the next row needs block (row + 1 + band_width_left) / 64 + 1; the reference's ceil_div is one short when that
            index is a multiple of 64 -- restated as it stands, tests/test_oracle_vs_textbook.py) */
-        if (row + 1 + band_width_left <= len1) last_block = rfo_ceil_div(row + 1 + band_width_left, word_size);
+        if (row + 1 + band_width_left <= len1) {
+            last_block = rfo_ceil_div(row + 1 + band_width_left, word_size);
+            /* (instrumentation only: pattern bit row + 1 + band_width_left lives in block (row + 1 + band_width_left) / 64 = last_block when the index
+               is a multiple of 64 -- one past what the next row will walk) */
+            if ((row + 1 + band_width_left) % word_size == 0 && last_block < words) ++rfo_q8_edges;
+        }
     }
 
     size_t sim = 0;
@@ -157,6 +167,7 @@ static size_t longest_common_subsequence_without_pm(rfo_str s1, rfo_str s2, size
 size_t rfo_lcs_similarity_with_pm(const rfo_pm *pm, rfo_str s1, rfo_str s2, size_t score_cutoff)
 {
     size_t len1 = s1.len, len2 = s2.len;
+    rfo_q8_edges = 0; /* (instrumentation: a call that never reaches lcs_blockwise reports none) */
     if (score_cutoff > len1 || score_cutoff > len2) return 0;
 
     size_t max_misses = len1 + len2 - 2 * score_cutoff;

@@ -49,6 +49,9 @@ int rfo_free_f64(int metric, int op, const uint8_t *s1, size_t len1, const uint8
                  const rfo_call_args *a, double *out);
 /* instrumentation: which levenshtein kernel the last call on this thread ended in (RFO_PATH_* in rfo_common.h) */
 int rfo_last_lev_path(void);
+/* instrumentation: in the last banded multi-word LCS call on this thread (lcs_seq.rs:297-331), how many rows moved the band's last block with
+ * ceil_div(row + 1 + band_width_left, 64) at a multiple of 64 while a block was left -- the precondition of quirk Q8 (0 = the call cannot have lost a match) */
+unsigned rfo_last_lcs_q8_edges(void);
 
 /* the user loop `for c in corpus { scorer.f(c) }`; None is UINT64_MAX / NaN; nthreads splits the
  * candidates into contiguous ranges (1 = what the single-threaded reference does) */

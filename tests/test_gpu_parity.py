@@ -54,7 +54,18 @@ def _check_many(metric, q, data, offsets, op, **kw):
         kw2 = {k: v for k, v in kw.items() if k != "score_cutoff"}
         uncut = ORA[metric].BatchComparator(q).many(OPS[op], data, offsets, nthreads=8, **kw2)
         uncut = _expect_u32(uncut) if got.dtype == np.uint32 else uncut
-        bad = bad[got[bad] != uncut[bad]]
+        # ... and only where the defect's own precondition is SHOWN to occur: the oracle, run on that one pair on this thread,
+        # reports how many rows moved the band's last block at a multiple of 64 with a block still left (rfo_last_lcs_q8_edges)
+        ob1 = ORA[metric].BatchComparator(q)
+        excused = []
+        for i in bad:
+            if got[i] != uncut[i]:
+                continue
+            cand = bytes(data[int(offsets[i]) : int(offsets[i + 1])])
+            ob1.many(OPS[op], np.frombuffer(cand, dtype=np.uint8), np.array([0, len(cand)], dtype=np.uint64), nthreads=1, **kw)
+            if o.last_lcs_q8_edges() > 0:
+                excused.append(i)
+        bad = np.array([i for i in bad if i not in set(excused)], dtype=bad.dtype)
     assert len(bad) == 0, (metric, op, kw, len(q), bad[:5], got[bad[:5]], exp[bad[:5]])
     return got
 

@@ -165,7 +165,11 @@ def test_reference_quirk_lcs_band_leaves_out_a_block():
     assert lb.similarity(b) == l and lb.distance(b) == 3 and ib.distance(b) == 5  # no cutoff: exact
     assert lb.distance(b, score_cutoff=3) is None      # the upstream defect, reproduced: the true distance is 3
     assert lb.similarity(b, score_cutoff=297) is None  # likewise
+    assert o.last_lcs_q8_edges() > 0  # (instrumentation: the call above met the defect's precondition -- rfo_last_lcs_q8_edges ...)
     assert lb.distance(b, score_cutoff=4) == 3 and lb.similarity(b, score_cutoff=296) == 297  # a wider band is exact again
+    # ... and a call that never walks a band of blocks reports none (70 x 66 symbols, LCS cutoff 60: full_band_words == words -> lcs_unroll)
+    c, d = bytes(range(48, 118)), bytes(range(48, 114))
+    assert o.lcs_seq.BatchComparator(c).similarity(d, score_cutoff=60) == 66 and o.last_lcs_q8_edges() == 0
 
 
 def test_osa_exact_and_cutoff():
