@@ -3,7 +3,7 @@
 #   rocprofv3 kernel-trace + PMC summaries of every BASELINE.json config's dominant kernel, and one bench.py JSON line per config.
 # Results land in gpurun_out/profiles/; copy them into profiles/ afterwards.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 mkdir -p gpurun_out/profiles
 cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
 # ONLY=<substring> restricts the run to the profiles / bench lines whose tag contains it (e.g. ONLY=ragged)
@@ -11,7 +11,7 @@ P() { tag=$1; key=$2; shift 2; [[ -n "${ONLY:-}" && $tag != *$ONLY* ]] && return
 MATCH="rf::stream_lev64" P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
 MATCH="rf::head_filter" P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
 MATCH="rf::stream_levw4" P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
-P c4_indel "indel:q64:n100000000:l64:cutNone:many" --metric indel
+MATCH="rf::stream_lcs6" P c4_indel "indel:q64:n100000000:l64:cutNone:many" --metric indel
 MATCH="rf::jaro" P c4_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many" --metric jaro_winkler
 MATCH="rf::stream_osa" P osa "osa:q64:n100000000:l64:cutNone:many" --metric osa
 MATCH="rf::stream_lev32" P q32_levenshtein "levenshtein:q32:n100000000:l64:cutNone:many" --query-len 32
@@ -23,6 +23,7 @@ MATCH="rf::window_gather" P ragged_gather "none" --ragged --metric indel
 MATCH="rf::jaro" P ragged_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric jaro_winkler
 MATCH="rf::head_filter" P ragged_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many:ragged" --ragged --min-len 57 --cutoff 3
 MATCH="rf::stream_kernel_occ8" P ragged_indel "indel:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric indel
+MATCH="rf::stream_levw8" P levenshtein_512 "levenshtein:q512:n2500000:l512:cutNone:many" --query-len 512 --cand-len 512 --candidates 2500000
 MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
 b() { name=$1; shift; [[ -n "${ONLY:-}" && $name != *$ONLY* ]] && return; python bench.py --traffic off --extras off "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
@@ -39,6 +40,12 @@ b ragged_indel --ragged --metric indel
 b ragged_jaro_winkler --ragged --metric jaro_winkler
 b q32_levenshtein --query-len 32
 b c3_levenshtein_256 --query-len 256 --cand-len 256 --candidates 10000000
+b levenshtein_512 --query-len 512 --cand-len 512 --candidates 2500000
+b levenshtein_320 --query-len 320 --cand-len 320 --candidates 4000000
+b hint16_neardup99 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.99 --hint 16 --no-cpu-baseline
+b hint16_neardup90 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --hint 16 --no-cpu-baseline
+b hint16_neardup50 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.5 --hint 16 --no-cpu-baseline
+b nohint_neardup90 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --no-cpu-baseline
 b c4_indel --metric indel
 b c4_lcs_seq --metric lcs_seq
 b c4_jaro --metric jaro
