@@ -466,7 +466,7 @@ def main():
                           "what": "the scan streams the 6-bit copy of the payload (12 bytes per 16 symbols)"}} if pack6 else {}),
         },
     }
-    if (args.metric in ("levenshtein", "indel", "lcs_seq", "osa") and args.query_len <= (256 if args.metric == "levenshtein" else 64) and not weights and not early
+    if (args.metric in ("levenshtein", "indel", "lcs_seq", "osa") and args.query_len <= (512 if args.metric == "levenshtein" else 64) and not weights and not early
             and os.environ.get("RF_BENCH_IN_PMC") != "1"):  # (not inside this command's own counter passes: traffic_in_run)
         # The bit-parallel scans of this family are bound by VALU issue before they are bound by HBM.  The
         # ceiling is MEASURED here, in this process: the library's own recurrence column on register-resident pattern

@@ -18,10 +18,16 @@ ROWS = [  # (file stem, label)
     ("ragged_cutoff3", "ragged [1, 64], `score_cutoff = 3` (4 of 64 lengths inside the window; the rest is the None pre-fill)"),
     ("ragged57_cutoff3", "ragged, lengths uniform in [57, 64], `score_cutoff = 3` (half the corpus inside the window: length-run views, round 4)"),
     ("ragged57_osa_cutoff3", "the same, OSA"),
-    ("c3_levenshtein_256", "C3 Levenshtein, query 256 x 10 M len 256 (4-word asm scan, round 4)"),
+    ("c3_levenshtein_256", "C3 Levenshtein, query 256 x 10 M len 256 (4-word asm scan, Ukkonen band: round 5)"),
+    ("levenshtein_320", "query 320 x 4 M len 320 (5-word asm scan, round 5)"),
+    ("levenshtein_512", "query 512 x 2.5 M len 512 (8-word asm scan, round 5)"),
+    ("nohint_neardup90", "C3 shape, 90 % of the candidates near-duplicates of the query, no hint"),
+    ("hint16_neardup90", "the same, `score_hint = 16` (band pass + dense re-scan of the unresolved, round 5)"),
+    ("hint16_neardup99", "99 % near-duplicates, `score_hint = 16`"),
+    ("hint16_neardup50", "50 % near-duplicates, `score_hint = 16` (the hint is wrong for half the corpus: slower than no hint)"),
     ("q128_levenshtein", "query 128 x 20 M len 128 (2-word asm scan)"),
     ("c3_cutoff8", "C3 corpus, `score_cutoff = 8`"),
-    ("c4_indel", "C4 Indel"),
+    ("c4_indel", "C4 Indel (asm scan over the 6-bit payload, round 5)"),
     ("c4_lcs_seq", "C4 LCS"),
     ("c4_jaro", "C4 Jaro (f64 out)"),
     ("c4_jaro_winkler", "C4 Jaro-Winkler (f64 out)"),
