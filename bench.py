@@ -405,7 +405,7 @@ def main():
     # (Indel / LCS with u32 results on a single-length corpus of < 64 symbols whose length is a whole number of chunks: the scan streams the 6-bit copy of the
     # payload, 0.75 bytes per symbol -- rf_stream_asm.hip stream_lcs6_uniform_kernel.  `roofline` keeps the survey's byte-per-symbol figure (what the
     # north star's 0.60 is about); what is MOVED is reported beside it and is what the traffic counters see)
-    pack6 = (args.metric in ("indel", "lcs_seq") and args.mode == "many" and not args.ragged and not early and nq == 1 and 32 < args.query_len <= 64
+    pack6 = (args.metric in ("indel", "lcs_seq") and args.mode == "many" and not args.ragged and not early and nq == 1 and args.query_len <= 64
              and args.cand_len % 16 == 0 and args.symbols < 64 and n >= (1 << 20) and os.environ.get("RF_PACK6", "1") != "0" and not c5 and world == 1)
     pairs_per_gpu = pairs_per_step / world
     achieved = pairs_per_gpu * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s

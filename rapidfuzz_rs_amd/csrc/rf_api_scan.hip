@@ -866,7 +866,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
     // the HBM-bound scans of a single-length corpus stream the 6-bit payload where there is one (Indel / LCS, one word, no early-out)
     // (where the asm scan over it applies: u32 results, lengths that are whole chunks -- rf_scan.hip launch_state)
-    p.data6 = (raw == RAW_LCS && p.words == 1 && p.len1 > 32 && !p.early && !f64_out && corpus->uniform && corpus->uniform_len % kChunk == 0) ? corpus_data6(corpus, st) : nullptr;
+    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && !f64_out && corpus->uniform && corpus->uniform_len % kChunk == 0) ? corpus_data6(corpus, st) : nullptr;
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
     static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
     p.max_stored_sym = (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) ? corpus_max_stored_symbol(corpus, st) : 0xFFFFFFFFu;

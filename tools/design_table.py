@@ -28,6 +28,7 @@ ROWS = [  # (file stem, label)
     ("q128_levenshtein", "query 128 x 20 M len 128 (2-word asm scan)"),
     ("c3_cutoff8", "C3 corpus, `score_cutoff = 8`"),
     ("c4_indel", "C4 Indel (asm scan over the 6-bit payload, round 5)"),
+    ("q32_indel", "same corpus, Indel, query 32 (32-bit words over the 6-bit payload, round 5)"),
     ("c4_lcs_seq", "C4 LCS"),
     ("c4_jaro", "C4 Jaro (f64 out)"),
     ("c4_jaro_winkler", "C4 Jaro-Winkler (f64 out)"),

@@ -125,6 +125,11 @@ class Kind:
                     "hq": ([f"v_add_u32 v{HP32}, v{HP32}, v{HP32}", f"v_add_u32 v{HP32}, 1, v{HP32}"] if ADDS32 else [f"v_lshl_or_b32 v{HP32}, v{HP32}, 1, 1"]),
                     "t": [f"v_bitop3_b32 v{T32}, v{E32}, v{VN32}, v{HP32} bitop3:0x01"], "vn": [f"v_bitop3_b32 v{VN32}, v{HP32}, v{E32}, v{VN32} bitop3:0xe0"],
                     "vp": ([f"v_add_u32 v{HN32}, v{HN32}, v{HN32}", f"v_add_u32 v{VP32}, v{HN32}, v{T32}"] if ADDS32 else [f"v_lshl_add_u32 v{VP32}, v{HN32}, 1, v{T32}"])}[tok]
+        if self.name == "lcs32":  # the same on 32-bit words (queries of <= 32 symbols; rf_device.hpp Lcs32State): every instruction full rate, in its long encoding
+            PM = self.rows[i % 8][0]
+            return {"u": [f"v_bitop3_b32 v{LU[0]}, v{LS[0]}, v{PM}, v{PM} bitop3:0xc0"],
+                    "p": [f"v_add_u32_e64 v{LX[0]}, v{LS[0]}, v{LU[0]}"],
+                    "s": [f"v_bitop3_b32 v{LS[0]}, v{LX[0]}, v{LS[0]}, v{LU[0]} bitop3:0xf4"]}[tok]
         if self.name == "lcs64":
             # lcs_seq.rs:222-231 (rf_device.hpp LcsState<1>::step): u = S & M; x = S + u; S = x | (S & ~u).  The two ands are written as v_bitop3_b32 ON
             # PURPOSE: 4-byte full-rate instructions next to half-rate ones (v_lshl_add_u64, SDWA) issue at 4 cycles each, 8-byte ones add up --
@@ -167,7 +172,7 @@ class Kind:
         """one recurrence column on row slot i % 8, and the look-ahead gather (`gather`: the lines of K.gather(i + la, ...)) where the
         kind's token order puts it -- token "x"; behind the column by default (RF_GEN_ORDER32 / RF_GEN_ORDER64: experiment knobs)"""
         L = [f"s_waitcnt lgkmcnt({self.la - 1})"]  # `la` reads in flight, in order: column i's row has arrived
-        base = {"osa": OSA_BASE, "lcs64": LCS_BASE}.get(self.name, LEV_BASE)
+        base = {"osa": OSA_BASE, "lcs64": LCS_BASE, "lcs32": LCS_BASE}.get(self.name, LEV_BASE)
         order = self.order or (base + ["x"])
         for tok in order:
             if tok == "x":
@@ -185,6 +190,8 @@ class Kind:
             return ["v_mov_b32 v60, -1", "v_mov_b32 v61, 0"]
         if self.name == "lcs64":  # lcs_seq.rs:215
             return ["v_mov_b32 v60, -1", "v_mov_b32 v61, -1"]
+        if self.name == "lcs32":
+            return ["v_mov_b32 v60, -1"]
         # osa.rs:74-77, :125-135: D0 = 0 and no previous column: its table row (slot 7) is zero
         return ["v_mov_b32 v60, -1", "v_mov_b32 v61, -1", "v_mov_b32 v62, 0", "v_mov_b32 v63, 0", "v_mov_b32 v58, 0", "v_mov_b32 v59, 0",
                 "v_mov_b32 v48, 0", "v_mov_b32 v49, 0"]
@@ -309,24 +316,25 @@ class Lcs6Kind(Kind):
     Single-length corpora whose length is a multiple of 16 only (no partial chunks: the launcher keeps the others on the 8-bit kernels)."""
     chunk_dwords, no_partial, chunk_pitch = 3, True, 768
 
-    def __init__(self, bufs, nop_mask):
-        Kind.__init__(self, "lcs64", 64, 8, bufs, (60, 61), nop_mask)
-        self.name6 = "lcs6"
+    def __init__(self, bits, bufs, nop_mask):
+        Kind.__init__(self, f"lcs{bits}", bits, 8, bufs, (60, 61)[: bits // 32], nop_mask)
+        self.name6 = "lcs6" if bits == 64 else "lcs6n"  # (n = narrow: queries of <= 32 symbols, 32-bit words)
 
     def gather(self, j, use, nxt):
         base, jj = (use, j) if j < 16 else (nxt, j - 16)
         o = 6 * jj
         d, sh = o // 32, o % 32
         a, src = ADDR[j % 4], base + d
+        ks, mask = self.ks, hex(63 << self.ks)  # row offset = symbol x 8 (64-bit rows) or x 4
         if sh + 6 > 32:
-            x = [f"v_alignbit_b32 v{a}, v{src + 1}, v{src}, {sh - 3}", f"v_and_b32 v{a}, 0x1f8, v{a}"]
-        elif sh > 3:
-            x = [f"v_lshrrev_b32_e64 v{a}, {sh - 3}, v{src}", f"v_and_b32 v{a}, 0x1f8, v{a}"]
-        elif sh == 3:
-            x = [f"v_and_b32 v{a}, 0x1f8, v{src}"]
+            x = [f"v_alignbit_b32 v{a}, v{src + 1}, v{src}, {sh - ks}", f"v_and_b32 v{a}, {mask}, v{a}"]
+        elif sh > ks:
+            x = [f"v_lshrrev_b32_e64 v{a}, {sh - ks}, v{src}", f"v_and_b32 v{a}, {mask}, v{a}"]
+        elif sh == ks:
+            x = [f"v_and_b32 v{a}, {mask}, v{src}"]
         else:
-            x = [f"v_lshlrev_b32_e64 v{a}, {3 - sh}, v{src}", f"v_and_b32 v{a}, 0x1f8, v{a}"]
-        return x + [f"ds_read_b64 {pr(self.rows[j % 8])}, v{a}"]
+            x = [f"v_lshlrev_b32_e64 v{a}, {ks - sh}, v{src}", f"v_and_b32 v{a}, {mask}, v{a}"]
+        return x + [f"ds_read_b64 {pr(self.rows[j % 8])}, v{a}" if self.bits == 64 else f"ds_read_b32 v{self.rows[j % 8][0]}, v{a}"]
 
 
 def dispatch(lo, hi, L, sfx):  # binary tree of scalar compares over k in [lo, hi]
@@ -544,6 +552,8 @@ def kernel(K, uniform):
             for h in (0, 1):
                 L += [f"v_and_b32 v8, s{72 + 2 * w + h}, v{K.VP[w][h]}", "v_bcnt_u32_b32 v6, v8, v6",
                       f"v_and_b32 v8, s{72 + 2 * w + h}, v{K.VN[w][h]}", "v_bcnt_u32_b32 v7, v8, v7"]
+    elif K.name == "lcs32":
+        L += ["v_not_b32 v6, v60", f"v_and_b32 v6, {S_VLO}, v6", "v_bcnt_u32_b32 v6, v6, 0"]
     elif K.name == "lcs64":  # the LCS length: the zero bits of S among the query's rows (rf_device.hpp LcsState::result)
         L += ["v_not_b32 v6, v60", f"v_and_b32 v6, {S_VLO}, v6", "v_bcnt_u32_b32 v6, v6, 0", "v_not_b32 v7, v61", f"v_and_b32 v7, {S_VHI}, v7", "v_bcnt_u32_b32 v6, v7, v6"]
     elif K.bits == 64:
@@ -551,7 +561,7 @@ def kernel(K, uniform):
               f"v_and_b32 v7, {S_VLO}, v62", "v_bcnt_u32_b32 v7, v7, 0", f"v_and_b32 v8, {S_VHI}, v63", "v_bcnt_u32_b32 v7, v8, v7"]
     else:
         L += [f"v_and_b32 v6, {S_VLO}, v60", "v_bcnt_u32_b32 v6, v6, 0", f"v_and_b32 v7, {S_VLO}, v61", "v_bcnt_u32_b32 v7, v7, 0"]
-    if K.name != "lcs64":
+    if K.name not in ("lcs64", "lcs32"):
         L += ["v_sub_u32 v6, v6, v7", f"v_add_u32 v6, {S_LEN2}, v6"]                   # raw = len2 + pp - pn
     L += [f"v_mul_lo_u32 v6, v6, {S_VR}", f"v_add_u32 v6, {S_V0}, v6",                  # value = v0 + vR * raw
           f"v_xor_b32 v7, {S_FLIP}, v6", f"v_cmp_ge_u32 vcc, {S_CFLIP}, v7", "v_cndmask_b32 v6, -1, v6, vcc"]  # None unless (value ^ flip) <= cflip
@@ -596,7 +606,8 @@ KINDS = [
     # (the LCS column over the 8-bit payload -- Kind("lcs64", 64, 8, [14, 18, 22, 26], (60, 61), 0), any corpus -- was built and measured in round 5: its
     # 18.6-cycle column buys nothing where the compiled scan already waits for HBM (single-length 100 M: 78.6 vs 79.9 Gpairs/s, ragged 20 M: 72.9 vs 73.9):
     # only the 6-bit form below ships, profiles/lcs_cycles_r05.txt)
-    Lcs6Kind([14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RINGLCS6", "4")):], int(os.environ.get("RF_GEN_MASKLCS6", "0"), 0)),
+    Lcs6Kind(64, [14, 18, 22, 26][4 - int(os.environ.get("RF_GEN_RINGLCS6", "4")):], int(os.environ.get("RF_GEN_MASKLCS6", "0"), 0)),
+    Lcs6Kind(32, [14, 18, 22, 26], 0),
 ] + [BlockKind(W, int(os.environ.get("RF_GEN_MASKW", "0x0426"), 0)) for W in (2, 3, 4, 5, 6, 7, 8)]  # s_nop behind a, S, hn, vn: best of 22 placements (profiles/levw_nop_masks_r04.txt)
 
 

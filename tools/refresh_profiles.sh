@@ -47,6 +47,7 @@ b hint16_neardup90 --query-len 256 --cand-len 256 --candidates 10000000 --near-d
 b hint16_neardup50 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.5 --hint 16 --no-cpu-baseline
 b nohint_neardup90 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --no-cpu-baseline
 b c4_indel --metric indel
+b q32_indel --metric indel --query-len 32
 b c4_lcs_seq --metric lcs_seq
 b c4_jaro --metric jaro
 b c4_jaro_winkler --metric jaro_winkler
