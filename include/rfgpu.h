@@ -62,6 +62,8 @@
  *   RF_PACK6_MIN_TILES            16384     fewest tiles of a corpus for which that copy is made
  *   RF_HINT_MIN_TILES             1024      fewest tiles of a corpus for which a per-candidate Levenshtein scan of a query beyond 64 symbols honours
  *                                           score_hint (pass under max(hint, 31), then only what it left unresolved: rf_hint.hip); 4294967295: never
+ *   RF_HINT_SAMPLE_MIN_TILES      16384     fewest tiles for which such a call first runs the hint pass over every (tiles / 512)-th tile and drops the hint when fewer
+ *                                           than 70 % of the candidates are within it (a wrong hint then costs ~3 % instead of up to + 55 %); 4294967295: never sample
  *   RF_STREAM_KEEP                1         0: rf_stream_many_* allocates and frees its pinned / device buffer sets per call instead of keeping them
  *   RF_STREAM_THREADS             16        host threads that read a corpus file's payload (rf_stream_many_*, rf_corpus_load)
  *   RF_PACK_TIMING / RF_SELECT_DEBUG / RF_TRACE_PLAN / RF_STREAM_TIMING   unset   set: phase timings / selection statistics / one line per
@@ -124,8 +126,9 @@ typedef enum rf_mem { RF_MEM_HOST = 0, RF_MEM_DEVICE = 1 } rf_mem;
  *                  query beyond 64 symbols, max(hint, 31) below the cutoff and below the longest string: the corpus is first scanned
  *                  under the cutoff max(hint, 31) (the one-word band kernel, or the banded multi-word scans), then only the candidates
  *                  that left unresolved are gathered into dense tiles and scanned under the caller's own cutoff (rf_hint.hip) -- a
- *                  corpus of near-duplicates costs the band pass, an unrelated one the full scan + a few percent.  Such a call
- *                  synchronizes `stream` once between the passes (RF_MEM_DEVICE too).
+ *                  corpus of near-duplicates costs the band pass, an unrelated one the full scan + a few percent (corpora of >= 16384 tiles sample the
+ *                  band pass first and drop a hint that is wrong for more than 30 % of the candidates).  Such a call synchronizes `stream`
+ *                  once or twice between the passes (RF_MEM_DEVICE too).
  *                  rf_topk_u32 with RF_OP_DISTANCE and no cutoff: the scan first runs under the
  *                  cutoff `hint` (a cutoff scan costs a fraction of a full one) and the k best are final if k candidates pass,
  *                  otherwise the hint doubles (past a quarter of the longest possible distance the plain scan runs).

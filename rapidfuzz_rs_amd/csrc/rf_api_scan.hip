@@ -729,20 +729,70 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
     } sc{st, {}};
     uint32_t* d_out = out;
     if (out_mem == RF_MEM_HOST) RF_HIP(sc.get((void**)&d_out, out_bytes));
-    // ---- pass 1: everything under the cutoff k1 (in result units: times the common factor)
-    rf_args a1 = *args;
+    rf_args a1 = *args;  // pass 1: everything under the cutoff k1 (in result units: times the common factor)
     a1.score_hint_usize = RF_NO_CUTOFF;
     a1.cutoff_usize = (uint64_t)k1 * factor;
+    rf_args a2 = *args;  // the caller's own scan
+    a2.score_hint_usize = RF_NO_CUTOFF;
+    const uint64_t raw_cut64 = args->cutoff_usize == RF_NO_CUTOFF ? 0xFFFFFFFFull : std::min<uint64_t>(args->cutoff_usize / factor, 0xFFFFFFFFull);
+    const uint32_t raw_cut = (uint32_t)raw_cut64;
+    // ---- is the hint any good?  Pass 1 over a corpus with near-duplicates in every tile is a full-length band scan -- 1.6 of the 3.0 ms a full scan of 10 M x 256
+    // takes -- so a hint that is wrong for most candidates costs up to + 55 % (profiles/bench_hint16_neardup50.json).  Corpora of >= RF_HINT_SAMPLE_MIN_TILES tiles
+    // (default 16384) first run pass 1's scan over every (tiles / 512)-th tile of its length window (ONE launch of the compiled multi-word kernel, which takes a
+    // tile step) and count: with fewer than 70 % of the candidates that matter resolved (break-even is ~73 %) the hint is dropped and the plain scan runs.  Costs
+    // one more stream synchronization.
+    static const uint32_t sample_min = [] { const char* e = getenv("RF_HINT_SAMPLE_MIN_TILES"); return e ? (uint32_t)atoll(e) : 16384u; }();
+    if (corpus->n_tiles >= sample_min) {
+        ScanParams p1;
+        RawKind raw1 = RAW_LEV;
+        if (const rf_status rs = plan(c, corpus, op, &a1, false, &p1, &raw1); rs != RF_OK) return rs;
+        if (!p1.long_words_pad && p1.tile_end > p1.tile_begin) {
+            if (const rf_status rs = comparator_device_pm(c, corpus->device, &p1.pm); rs != RF_OK) return rs;
+            p1.out = d_out;
+            p1.prefill_none = 0;
+            p1.band = 0;  // (the compiled LevState<W> scan under the same cutoff: the same values, and it walks every tile_step-th tile)
+            p1.mixed = nullptr, p1.mixed_begin = p1.mixed_end = 0;  // (the views of the mixed section are ordinary tiles to that kernel)
+            p1.heads8 = nullptr, p1.heads6 = nullptr;
+            p1.tile_step = std::max<uint32_t>(1, (p1.tile_end - p1.tile_begin) / 512);
+            uint32_t* d_acc = nullptr;
+            RF_HIP(sc.get((void**)&d_acc, 2 * sizeof(uint32_t)));
+            RF_HIP(hipMemsetAsync(d_acc, 0, 2 * sizeof(uint32_t), st));
+            RF_HIP(launch_scan(raw1, p1, st, nullptr));
+            RF_HIP(launch_hint_sample(p1, d_out, p1.tile_begin, p1.tile_end, p1.tile_step, d_acc, st));
+            uint32_t acc[2] = {0, 0};
+            RF_HIP(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+            RF_HIP(hipStreamSynchronize(st));
+            // candidates outside pass 1's length window but inside the caller's: unresolved without looking (tiles are 64 slots; the estimate ignores padding lanes)
+            uint64_t in_k1 = 0, in_cut = 0;
+            for (size_t i = 0; i < corpus->lengths.size(); ++i) {
+                const uint32_t first = corpus->length_first_tile[i], end = i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles;
+                const uint32_t L = corpus->lengths[i], gap = p1.len1 > L ? p1.len1 - L : L - p1.len1;
+                if (L == 0) continue;
+                if (gap <= k1) in_k1 += end - first;
+                if (gap <= raw_cut) in_cut += end - first;
+            }
+            const double share = acc[0] ? (double)acc[1] / (double)acc[0] : 0.0;
+            const double resolved = in_cut ? share * (double)in_k1 / (double)in_cut : 1.0;
+            static const bool trace_sample = getenv("RF_TRACE_PLAN") != nullptr;
+            if (trace_sample) std::fprintf(stderr, "[rf plan] hint sample: %u of %u sampled candidates within max(hint, 31) = %u, ~%.2f of the candidates that matter\n", acc[1], acc[0], k1, resolved);
+            if (resolved < 0.70) {
+                const rf_status rs = run_many(c_in, corpus_in, op, &a2, d_out, RF_MEM_DEVICE, st, false);
+                if (rs != RF_OK) return rs;
+                if (out_mem == RF_MEM_HOST) {
+                    RF_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+                    RF_HIP(hipStreamSynchronize(st));
+                }
+                return RF_OK;
+            }
+        }
+    }
+    // ---- pass 1
     if (const rf_status rs = run_many(c_in, corpus_in, op, &a1, d_out, RF_MEM_DEVICE, st, false); rs != RF_OK) return rs;
     // ---- the caller's own scan, planned for the corpus and re-aimed at the dense tiles below
-    rf_args a2 = *args;
-    a2.score_hint_usize = RF_NO_CUTOFF;
     ScanParams p;
     RawKind raw = RAW_LEV;
     if (const rf_status rs = plan(c, corpus, op, &a2, false, &p, &raw); rs != RF_OK) return rs;
     if (const rf_status rs = comparator_device_pm(c, corpus->device, &p.pm); rs != RF_OK) return rs;
-    const uint64_t raw_cut64 = args->cutoff_usize == RF_NO_CUTOFF ? 0xFFFFFFFFull : std::min<uint64_t>(args->cutoff_usize / factor, 0xFFFFFFFFull);
-    const uint32_t raw_cut = (uint32_t)raw_cut64;
     const uint64_t zero64 = (uint64_t)p.len1 * factor;
     const uint32_t zero_value = (args->cutoff_usize == RF_NO_CUTOFF || zero64 <= args->cutoff_usize) ? (uint32_t)zero64 : RF_NONE_U32;
     // ---- mark: per tile the lanes pass 1 left unresolved, numbered in slot order; the sums at the length runs' boundaries come to the host

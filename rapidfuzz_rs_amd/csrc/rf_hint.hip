@@ -73,6 +73,29 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void hint_mark_kernel(const 
     }
 }
 
+// The sample taken BEFORE pass 1 (run_many_hinted): one wavefront per sampled tile -- tiles tile_begin, tile_begin + step, ... below tile_end, all inside pass 1's
+// length window -- after pass 1's kernel has run over exactly those tiles.  acc[0] += real candidates seen, acc[1] += those of them the pass resolved.
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void hint_sample_kernel(const TileDesc* __restrict__ tiles, const uint32_t* __restrict__ orig,
+                                                                            const uint32_t* __restrict__ out, uint32_t n, uint32_t uniform_len, uint32_t tile_begin,
+                                                                            uint32_t tile_end, uint32_t step, uint32_t* __restrict__ acc)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t t64 = (uint64_t)tile_begin + (uint64_t)(blockIdx.x * kWavesPerBlock + threadIdx.x / kWave) * step;
+    if (t64 >= tile_end) return;
+    const uint32_t t = (uint32_t)t64;
+    const uint32_t len2 = tiles ? tiles[t].len : uniform_len;
+    if (len2 == 0) return;
+    const uint32_t slot = (tiles ? tiles[t].slot0 : t * kWave) + lane;
+    const uint32_t idx = orig ? orig[slot] : slot;
+    const bool valid = orig ? idx != kPad : idx < n;
+    const uint64_t seen = __ballot(valid);
+    const uint64_t resolved = __ballot(valid && out[idx] != RF_NONE_U32);
+    if (lane == 0) {
+        atomicAdd(&acc[0], (uint32_t)__popcll(seen));
+        atomicAdd(&acc[1], (uint32_t)__popcll(resolved));
+    }
+}
+
 __global__ void hint_run_prefix_kernel(const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ run_first, uint32_t R, uint32_t* __restrict__ run_prefix)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -119,6 +142,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void hint_gather_kernel(cons
 }
 
 }  // namespace
+
+hipError_t launch_hint_sample(const ScanParams& p, const uint32_t* out, uint32_t tile_begin, uint32_t tile_end, uint32_t step, uint32_t* acc, hipStream_t st)
+{
+    const uint32_t count = tile_end > tile_begin ? (tile_end - tile_begin + step - 1) / step : 0;
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(hint_sample_kernel, dim3((count + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kWave * kWavesPerBlock), 0, st, p.tiles, p.orig, out, p.n, p.uniform_len,
+                       tile_begin, tile_end, step, acc);
+    return hipGetLastError();
+}
 
 size_t hint_scan_temp_bytes(uint32_t n_tiles)
 {

@@ -165,6 +165,7 @@ hipError_t launch_lev1_asm(const ScanParams& p, hipStream_t stream, int grid);  
 void launch_lev1_asm_probe(dim3 g, dim3 b, uint32_t* out, int iters, uint32_t seed);  // rf_lev_asm.hip: the asm chunk alone (rf_probe_issue_rate mode 2)
 // rf_hint.hip: what a score_hint pass left unresolved, gathered into dense tiles (rf_api_scan.hip run_many_hinted)
 size_t hint_scan_temp_bytes(uint32_t n_tiles);
+hipError_t launch_hint_sample(const ScanParams& p, const uint32_t* out, uint32_t tile_begin, uint32_t tile_end, uint32_t step, uint32_t* acc, hipStream_t st);
 hipError_t launch_hint_mark(const ScanParams& p, uint32_t* out, uint32_t raw_cutoff, uint32_t zero_value, uint64_t* mask, uint32_t* count, uint32_t* prefix, void* temp,
                             size_t temp_bytes, const uint32_t* run_first, uint32_t R, uint32_t* run_prefix, hipStream_t st);
 hipError_t launch_hint_gather(const ScanParams& p, const uint32_t* run_first, uint32_t R, const uint32_t* run_prefix, const uint32_t* prefix, const uint64_t* mask,

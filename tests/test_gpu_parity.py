@@ -2415,6 +2415,7 @@ def test_score_hint_on_long_query_scans_never_changes_a_result(kind, qlen):
     near-duplicates of the query (0..40 edits: some resolve under every hint, some under none), the rest random; corpora of > 1024 tiles
     (below that the hint is ignored).  Hints 0 / 1 / 31 / 32 / 100 / none x no cutoff / cutoffs on both sides of the hint x unit and
     (3, 3, 3) weights: every result equals the oracle's UN-hinted one (the reference's own hinted path has quirk Q7)."""
+    every = int(os.environ.get("RF_TEST_HINT_EVERY", "2"))
     rng = np.random.default_rng(qlen)
     q = bytes(rng.integers(48, 123, size=qlen, dtype=np.uint8))
     qa = np.frombuffer(q, dtype=np.uint8)
@@ -2424,9 +2425,9 @@ def test_score_hint_on_long_query_scans_never_changes_a_result(kind, qlen):
         len2 = int(rng.integers(max(1, qlen - 150), qlen + 60)) if kind == "ragged" else qlen + 7
         if i % 97 == 0:
             len2 = 0 if kind == "ragged" else len2
-        if i % 2:
+        if i % every:  # (every = 2: half of the corpus; the sampled-first child below runs it with 10: nine in ten)
             b = list(qa)
-            for _ in range(int(rng.integers(0, 41))):
+            for _ in range(int(rng.integers(0, 41 if every == 2 else 12))):
                 r, pos = int(rng.integers(0, 3)), int(rng.integers(0, len(b) + 1))
                 if r == 0:
                     b.insert(pos, 35)
@@ -2462,6 +2463,30 @@ def test_score_hint_on_long_query_scans_never_changes_a_result(kind, qlen):
     # host-memory results and a second stream take the same path
     got = bc.many(N.OP_DISTANCE, corpus, score_hint=16)
     assert np.array_equal(got, _expect_u32(ob.many(N.OP_DISTANCE, data, offsets, nthreads=8)))
+
+
+@pytest.mark.parametrize("every", [2, 10])
+def test_score_hint_is_sampled_first_on_large_corpora(every):
+    """run_many_hinted runs the hint pass over a 0.3 % sample first (corpora of >= 16384 tiles) and drops the hint when fewer than 70 % of the sampled
+    candidates are within it.  The hint test above in a child process with RF_HINT_SAMPLE_MIN_TILES=1 (its corpora have ~1500 tiles): with half of the
+    corpus near-duplicates the sample says no and the plain scan runs, with nine in ten it says yes and the two passes run -- both must give the oracle's
+    values, and RF_TRACE_PLAN shows which way each call went."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RF_HINT_SAMPLE_MIN_TILES="1", RF_TEST_HINT_EVERY=str(every), RF_TRACE_PLAN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-p", "no:xdist", "-s", "-k",
+                        "test_score_hint_on_long_query_scans_never_changes_a_result and 256"], capture_output=True, text=True, cwd=root, env=env)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    text = r.stdout + r.stderr
+    sampled = text.count("[rf plan] hint sample:")
+    passes = text.count("[rf plan] hint pass:")
+    assert sampled > 0
+    if every == 2:
+        assert passes == 0, passes  # half the corpus is random: every sample says the hint is not worth it
+    else:
+        assert passes > 0  # nine in ten within the hint: the sampled calls go on to the two passes
 
 
 @pytest.mark.parametrize("len2,qlen", [(64, 64), (57, 60), (16, 20), (100, 64), (7, 33), (64, 32)])
