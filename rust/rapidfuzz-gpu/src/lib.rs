@@ -14,6 +14,13 @@ mod corpus;
 mod metric;
 
 pub use corpus::Corpus;
+
+/// `rf_release_caches`: gives back what the library keeps per process between calls (the streamed scans' pinned + device buffer sets, parked scratch
+/// blocks).  No reference analogue; a long-lived service calls it after a burst.  What a [`Corpus`] keeps goes with the corpus.
+pub fn release_caches() {
+    // (always RF_OK)
+    let _ = unsafe { sys::rf_release_caches() };
+}
 pub use metric::{Args, DistanceCutoff, Element, Error, NoScoreCutoff, SimilarityCutoff, TopK, WeightTable, WithScoreCutoff};
 
 /// `rapidfuzz::distance::*` -- one module per metric with a bit-parallel batch path.  Each has `BatchComparator<Elem1>` with the

@@ -103,7 +103,8 @@ impl<ResultType> Default for Args<ResultType, NoScoreCutoff> {
     }
 }
 impl<ResultType: Copy, CutoffType> Args<ResultType, CutoffType> {
-    /// accepted and ignored by per-candidate scans, like the reference's results (levenshtein.rs:2153-2160); `topk` uses it
+    /// never changes a result (levenshtein.rs:2153-2160).  Used the reference's way (levenshtein.rs:1069-1088) by `distance_many` of Levenshtein with a query of
+    /// more than 64 symbols (a pass under max(hint, 31), then only what that left unresolved: DESIGN.md 5.3) and by `topk`; ignored elsewhere
     pub fn score_hint(mut self, score_hint: ResultType) -> Self {
         self.score_hint = Some(score_hint);
         self
