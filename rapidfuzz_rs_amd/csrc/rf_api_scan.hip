@@ -746,7 +746,7 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
         ScanParams p1;
         RawKind raw1 = RAW_LEV;
         if (const rf_status rs = plan(c, corpus, op, &a1, false, &p1, &raw1); rs != RF_OK) return rs;
-        if (!p1.long_words_pad && p1.tile_end > p1.tile_begin) {
+        if (!p1.long_words_pad && p1.words <= (uint32_t)kMaxWords && p1.tile_end > p1.tile_begin) {  // (the sample runs the register-resident scan: queries of <= 512 symbols)
             if (const rf_status rs = comparator_device_pm(c, corpus->device, &p1.pm); rs != RF_OK) return rs;
             p1.out = d_out;
             p1.prefill_none = 0;

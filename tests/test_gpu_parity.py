@@ -113,6 +113,16 @@ def test_randomized_long_queries_near_duplicates_tight_cutoffs(seed):
                 cutoffs = [qlen - int(c) for c in rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 12, 20], size=2, replace=False)]
             for c in cutoffs:
                 _check_many(metric, q.tobytes(), data, offsets, op, score_cutoff=c)
+    # score_hint on the per-candidate Levenshtein scan (levenshtein.rs:1069-1088; rf_hint.hip): whatever the hint, the device returns what it returns
+    # without one -- which the calls above and below hold to the oracle (the reference's own hinted path has quirk Q7).  RF_HINT_MIN_TILES=1 in a
+    # campaign's environment sends these small corpora through the two passes; by default they are too small and the hint is ignored.
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    lev = GPU["levenshtein"].BatchComparator(q.tobytes())
+    for cut in (None, int(rng.choice([33, 40, 64, 100, 300]))):
+        plain = _check_many("levenshtein", q.tobytes(), data, offsets, "distance", score_cutoff=cut)
+        for hint in (0, int(rng.integers(1, 64)), int(rng.integers(64, 400))):
+            assert np.array_equal(lev.many(N.OP_DISTANCE, corpus, score_cutoff=cut, score_hint=hint), plain), (seed, cut, hint)
+    del corpus
     # Jaro / Jaro-Winkler: cutoffs that ARE some candidate's value, and the doubles next to it on either side -- the `>=` of
     # every filter and of the final compare (jaro.rs:533-598, jaro_winkler.rs:125-138) has to fall the same way, bit for bit
     for metric in ("jaro", "jaro_winkler"):
