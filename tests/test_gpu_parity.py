@@ -1037,6 +1037,16 @@ def test_corpus_file_roundtrip_and_streamed_scan(kind, tmp_path):
     s0, i0 = GPU["levenshtein"].BatchComparator(q).topk(corpus, 5)
     s1, i1 = GPU["levenshtein"].BatchComparator(q).topk(loaded, 5)
     assert (s0 == s1).all() and (i0 == i1).all()
+    # rf_release_caches gives the streamed scans' kept buffer sets and the parked scratch back; the next calls allocate again and agree
+    import torch
+
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    assert N.lib().rf_release_caches() == N.RF_OK
+    if os.environ.get("PYTEST_XDIST_WORKER") is None:
+        assert torch.cuda.mem_get_info()[0] >= before  # (free memory is GPU-wide: only a serial run may compare)
+    bc = GPU["levenshtein"].BatchComparator(q)
+    assert _equal_rows(bc.stream_many(N.OP_DISTANCE, path, n, segment_bytes=1 << 20), bc.many(N.OP_DISTANCE, corpus))
     with pytest.raises(rf.RfError):
         rf.Corpus.load(str(tmp_path / "missing.rfc"))
     bad = tmp_path / "bad.rfc"
