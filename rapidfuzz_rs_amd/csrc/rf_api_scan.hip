@@ -466,8 +466,9 @@ const uint32_t* corpus_data6(const rf_corpus* corpus, hipStream_t st)
 {
     static const bool on = [] { const char* e = getenv("RF_PACK6"); return !e || atoi(e) != 0; }();
     static const uint32_t min_tiles = [] { const char* e = getenv("RF_PACK6_MIN_TILES"); return e ? (uint32_t)atoll(e) : 16384u; }();
-    if (!on || !corpus->uniform || corpus->borrowed || corpus->n_tiles < min_tiles || corpus->uniform_len == 0 || corpus->uniform_len % kChunk != 0) return nullptr;
-    if (corpus_max_stored_symbol(corpus, st) >= 64u) return nullptr;
+    if (!on || !corpus->uniform || corpus->borrowed || corpus->n_tiles < min_tiles || corpus->uniform_len == 0) return nullptr;
+    // (whole chunks: any 64 codes; a partial last chunk is filled up with the code 63, which must then be free)
+    if (corpus_max_stored_symbol(corpus, st) >= (corpus->uniform_len % kChunk == 0 ? 64u : 63u)) return nullptr;
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);
     if (!corpus->d_data6 && !corpus->data6_tried) {
         corpus->data6_tried = true;
@@ -479,7 +480,7 @@ const uint32_t* corpus_data6(const rf_corpus* corpus, hipStream_t st)
             (void)hipGetLastError();
             return nullptr;
         }
-        hipError_t e = launch_pack6(corpus->d_data, corpus->n_tiles, nch, d, st);
+        hipError_t e = launch_pack6(corpus->d_data, corpus->n_tiles, corpus->uniform_len, d, st);
         if (e == hipSuccess) e = hipMemsetAsync(d + rows * kWave * 3, 0, kWave * 12, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // (other streams may use it as soon as the lock is released)
         if (e != hipSuccess) {
@@ -916,10 +917,13 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
     // the HBM-bound scans of a single-length corpus stream the 6-bit payload where there is one (Indel / LCS, one word, no early-out)
     // (where the asm scan over it applies: u32 results, lengths that are whole chunks -- rf_scan.hip launch_state)
-    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && !f64_out && corpus->uniform && corpus->uniform_len % kChunk == 0) ? corpus_data6(corpus, st) : nullptr;
+    // (lengths that are not whole chunks run their fill columns too: that pays on 32-bit words -- 57 symbols, query 30: 83.8 -> 100.7 Gpairs/s -- and not on the
+    // issue-bound 64-bit column: 75.7 -> 74.6)
+    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && !f64_out && corpus->uniform && (corpus->uniform_len % kChunk == 0 || p.len1 <= 32)) ? corpus_data6(corpus, st) : nullptr;
+    if (p.data6) p.max_stored_sym = corpus_max_stored_symbol(corpus, st);  // (< 63: the scans may zero the table row of the fill code)
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
     static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
-    p.max_stored_sym = (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) ? corpus_max_stored_symbol(corpus, st) : 0xFFFFFFFFu;
+    if (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) p.max_stored_sym = corpus_max_stored_symbol(corpus, st);
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     const size_t out_bytes = corpus->n * elem;
     void* d_out = out;

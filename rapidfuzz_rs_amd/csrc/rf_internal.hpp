@@ -70,7 +70,8 @@ struct ScanParams {
     // (rf_pack.hip head6_plane_kernel; head_filter_kernel reads 6 instead of 8 bytes per candidate).  nullptr = none
     const uint32_t* heads6;
     // the whole payload of a single-length corpus at 6 bits per symbol: 16 symbols in 12 bytes, chunk k of lane r of tile t at ((t * nch + k) * 64 + r) * 12
-    // (rf_pack.hip pack6_kernel; corpora that store fewer than 64 distinct symbols).  The single-word LCS scans stream it instead of `data`.  nullptr = none
+    // (rf_pack.hip pack6_kernel; corpora that store fewer than 64 distinct symbols; a length that is not a whole number of chunks is filled up with the code 63,
+    // which the corpus then must not store: max_stored_sym < 63, and the scans zero that table row).  The single-word LCS scans stream it instead of `data`.  nullptr = none
     const uint32_t* data6;
     // A LENGTH RUN of a length-bucketed corpus seen as a single-length corpus (rf_api_scan.hip launch_scan_runs): tiles == nullptr, data /
     // heads8 point at the run's first tile, tile indices and idx = t * 64 + lane are relative to it, and run_orig[idx] is the
@@ -188,7 +189,7 @@ hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* sl
 hipError_t launch_head8_plane(const uint8_t* data, uint32_t n_tiles, uint32_t tile_bytes, uint8_t* heads, hipStream_t stream);  // rf_pack.hip: the candidates' first 8 symbols
 hipError_t launch_max_byte(const uint8_t* data, uint64_t bytes, uint32_t* out, hipStream_t stream);  // rf_pack.hip: largest stored symbol (*out must start at 0)
 hipError_t launch_head6_plane(const uint8_t* heads8, uint32_t n_tiles, uint32_t* heads6, hipStream_t stream);
-hipError_t launch_pack6(const uint8_t* data, uint32_t n_tiles, uint32_t nch, uint32_t* data6, hipStream_t stream);  // rf_pack.hip: the payload at 6 bits per symbol
+hipError_t launch_pack6(const uint8_t* data, uint32_t n_tiles, uint32_t len, uint32_t* data6, hipStream_t stream);  // rf_pack.hip: the payload at 6 bits per symbol
 hipError_t launch_head8_plane_tiles(const uint8_t* data, const TileDesc* tiles, uint32_t n_tiles, uint8_t* heads, hipStream_t stream);  // the same over tile descriptors
 // the coalesced gather (rf_pack.hip "window_gather_kernel"): windows of kGatherWindow original indices, at most kMaxGatherRuns runs
 constexpr uint32_t kGatherWindow = 4096;

@@ -465,17 +465,20 @@ hipError_t launch_head6_plane(const uint8_t* heads8, uint32_t n_tiles, uint32_t*
 // time with 16 symbols in 12 bytes -- symbol j of a chunk on bits 6 j .. 6 j + 5 of the 96-bit little-endian value -- chunk k of lane r of tile t
 // at ((t * nch + k) * 64 + r) * 12: a wavefront's load of "my next 16 columns" is one contiguous 768-byte read (global_load_dwordx3) instead of 1 KiB.
 // The HBM-bound scans (Indel / LCS, single word) stream it instead of the 8-bit payload: stream6_kernel, rf_scan.hip.
-__global__ __launch_bounds__(256) void pack6_kernel(const uint4* __restrict__ data, uint32_t n_tiles, uint32_t nch, uint32_t* __restrict__ data6)
+// Positions behind the candidates' end (a length that is not a multiple of 16) hold the code 63, which such a corpus does not store (the builder's condition) and
+// whose table row the scans zero: an LCS column over it changes nothing, so the scans run whole chunks only.
+__global__ __launch_bounds__(256) void pack6_kernel(const uint4* __restrict__ data, uint32_t n_tiles, uint32_t nch, uint32_t len, uint32_t* __restrict__ data6)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t rows = (uint64_t)n_tiles * nch;  // chunk rows of 64 lanes
     for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (uint64_t)gridDim.x * 4) {
         const uint4 c = data[r * kWave + lane];
         const uint32_t dw[4] = {c.x, c.y, c.z, c.w};
+        const uint32_t col0 = (uint32_t)(r % nch) * kChunk;
         uint32_t w[3] = {0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t sym = (dw[j / 4] >> (8 * (j % 4))) & 63u;
+            const uint32_t sym = col0 + j < len ? (dw[j / 4] >> (8 * (j % 4))) & 63u : 63u;
             const int o = 6 * j;
             w[o / 32] |= sym << (o % 32);
             if (o % 32 > 26) w[o / 32 + 1] |= sym >> (32 - o % 32);
@@ -486,11 +489,13 @@ __global__ __launch_bounds__(256) void pack6_kernel(const uint4* __restrict__ da
         dst[2] = w[2];
     }
 }
-hipError_t launch_pack6(const uint8_t* data, uint32_t n_tiles, uint32_t nch, uint32_t* data6, hipStream_t stream)
+hipError_t launch_pack6(const uint8_t* data, uint32_t n_tiles, uint32_t len, uint32_t* data6, hipStream_t stream)
 {
+    const uint32_t nch = (len + kChunk - 1) / kChunk;
     if (n_tiles == 0 || nch == 0) return hipSuccess;
     const uint64_t rows = (uint64_t)n_tiles * nch;
-    hipLaunchKernelGGL(pack6_kernel, dim3((uint32_t)std::min<uint64_t>((rows + 3) / 4, 262144u)), dim3(256), 0, stream, reinterpret_cast<const uint4*>(data), n_tiles, nch, data6);
+    hipLaunchKernelGGL(pack6_kernel, dim3((uint32_t)std::min<uint64_t>((rows + 3) / 4, 262144u)), dim3(256), 0, stream, reinterpret_cast<const uint4*>(data), n_tiles, nch, len,
+                       data6);
     return hipGetLastError();
 }
 // the same over the EXACT tiles of a length-bucketed corpus (round 4): row t = the first 8 stored bytes of tile t's 64 lanes, whatever

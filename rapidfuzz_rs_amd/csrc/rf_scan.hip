@@ -862,7 +862,7 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             // the single-word LCS scans of a single-length corpus that keeps its payload at 6 bits per symbol too (ScanParams::data6): the asm scan over that
             // (whole chunks only: lengths that are multiples of 16; u32 results).  RF_PACK6=0 (no such payload) is the A/B switch.
             if ((std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value) && use_asm && use_stream_asm && p.data6 && !p.tiles &&
-                p.uniform_len % kChunk == 0 && stream_asm_serves(p))
+                stream_asm_serves(p))
                 return launch_stream_asm(std::is_same<State, Lcs32State>::value ? 6 : 5, p, stream, std::max(1, scan_grid_full(p.tile_end - p.tile_begin)));
             if (kAsmKind >= 0 && use_asm && use_stream_asm && stream_asm_serves(p)) {
                 uint32_t at = p.tile_begin;

@@ -2509,14 +2509,14 @@ def test_score_hint_is_sampled_first_on_large_corpora(every):
         assert passes > 0  # nine in ten within the hint: the sampled calls go on to the two passes
 
 
-@pytest.mark.parametrize("len2,qlen", [(64, 64), (57, 60), (16, 20), (100, 64), (7, 33), (64, 32)])
+@pytest.mark.parametrize("len2,qlen", [(64, 64), (57, 60), (16, 20), (100, 64), (7, 33), (64, 32), (57, 30), (100, 17), (7, 5)])
 def test_six_bit_payload_scans_equal_the_oracle(len2, qlen):
     """single-length corpora that store fewer than 64 distinct symbols keep their payload a second time at 6 bits per
     symbol (rf_pack.hip pack6_kernel) and the single-word LCS scans -- Indel, LCS -- with u32 results stream that through an asm scan of
     their own (stream_lcs6_uniform_kernel: 12 instead of 16 bytes per 16 columns) when the length is a whole number of chunks.
-    1 048 640+ candidates (the structure is built from 16384 tiles on); lengths 64 and 16 take it -- queries beyond 32 symbols on 64-bit words
-    (stream_lcs6_uniform_kernel), shorter ones on 32-bit words (stream_lcs6n_uniform_kernel) -- the
-    other shapes here (partial last chunk, f64 results, fuzz::ratio, 70 distinct symbols) must keep the 8-bit
+    1 048 640+ candidates (the structure is built from 16384 tiles on): queries beyond 32 symbols on 64-bit words (stream_lcs6_uniform_kernel), shorter
+    ones on 32-bit words (stream_lcs6n_uniform_kernel), which also take lengths that are not whole chunks (filled up with the code 63, whose table row
+    the scans zero: an LCS column over it is a no-op); f64 results, fuzz::ratio, longer queries on partial chunks and the 70-symbol corpus keep the 8-bit
     scans -- every op, planted near-duplicates, every value against the oracle."""
     import torch
 

@@ -313,7 +313,8 @@ class Lcs6Kind(Kind):
     a 21-cycle column: nothing on 8-bit bytes; both together: this kernel).  The table row address of column j is a shift and a mask instead of one SDWA shift:
     v_lshrrev_b32 in its LONG encoding (a 4-byte one next to the half-rate v_lshl_add_u64 issues at 4 cycles) + v_and_b32 with the literal 0x1f8, v_alignbit_b32
     for the two fields that straddle a dword (profiles/lcs_cycles_r05.txt: 21.0 cycles per column register-only, 25.1 as hipcc writes it).
-    Single-length corpora whose length is a multiple of 16 only (no partial chunks: the launcher keeps the others on the 8-bit kernels)."""
+    Single-length corpora; whole chunks only: a length that is not a multiple of 16 is filled up with the code 63 by the packer (corpora that store at most 63
+    symbols), whose table row the prologue zeroes (flags bit 3) -- an LCS column over it is a no-op."""
     chunk_dwords, no_partial, chunk_pitch = 3, True, 768
 
     def __init__(self, bits, bufs, nop_mask):
@@ -506,8 +507,14 @@ def kernel(K, uniform):
     if W == 1:
         L += [f"global_load_ubyte v6, v1, {S_SIGMA}", "v_lshlrev_b32 v7, 3, v1",
               f"global_load_dwordx2 v[8:9], v7, {S_PM}" if K.bits == 64 else f"global_load_dword v8, v7, {S_PM}",
-              "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6",
-              "ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
+              "s_waitcnt vmcnt(0)", f"v_lshlrev_b32 v6, {K.ks}, v6"]
+        if getattr(K, "no_partial", False):
+            # the 6-bit payload fills a partial last chunk up with the code 63 (flags bit 3: the corpus stores no such symbol): its table row is zero, so that an
+            # LCS column over it changes nothing -- whatever original symbol the renaming happens to give that rank
+            L += [f"s_bitcmp1_b32 {S_FLAGS}, 3", "s_cbranch_scc0 Lnofill_%=", f"v_cmp_eq_u32 vcc, {63 << K.ks}, v6", "v_cndmask_b32_e64 v8, v8, 0, vcc"]
+            L += ["v_cndmask_b32_e64 v9, v9, 0, vcc"] if K.bits == 64 else []
+            L += ["Lnofill_%=:"]
+        L += ["ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
     else:  # row i of the host table (W consecutive words) -> word w to plane w, row sigma(i)
         L += [f"global_load_ubyte v6, v1, {S_SIGMA}", f"v_mul_u32_u24 v7, {8 * W}, v1"]
         L += [f"global_load_dwordx2 v[{24 + 2 * w}:{25 + 2 * w}], v7, {S_PM}" + (f" offset:{8 * w}" if w else "") for w in range(W)]
