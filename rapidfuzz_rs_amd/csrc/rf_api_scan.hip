@@ -916,10 +916,10 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
     p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
     // the HBM-bound scans of a single-length corpus stream the 6-bit payload where there is one (Indel / LCS, one word, no early-out)
-    // (where the asm scan over it applies: u32 results, lengths that are whole chunks -- rf_scan.hip launch_state)
+    // (where the asm scan over it applies -- rf_scan.hip launch_state; f64 results through a table of the <= 256 values there are: rf_stream_asm.hip stream_asm_f64_table)
     // (lengths that are not whole chunks run their fill columns too: that pays on 32-bit words -- 57 symbols, query 30: 83.8 -> 100.7 Gpairs/s -- and not on the
     // issue-bound 64-bit column: 75.7 -> 74.6)
-    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && !f64_out && corpus->uniform && (corpus->uniform_len % kChunk == 0 || p.len1 <= 32)) ? corpus_data6(corpus, st) : nullptr;
+    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && corpus->uniform && (corpus->uniform_len % kChunk == 0 || p.len1 <= 32)) ? corpus_data6(corpus, st) : nullptr;
     if (p.data6) p.max_stored_sym = corpus_max_stored_symbol(corpus, st);  // (< 63: the scans may zero the table row of the fill code)
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
     static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)

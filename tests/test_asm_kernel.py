@@ -71,8 +71,9 @@ def test_whole_kernel_asm_scans_resources(tmp_path):
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
         body = lines[start:end]
         assert sum("ASMSTART" in l for l in body) == 1 and "ASMEND" in lines[end - 1]
-        assert sum("global_store_dword" in l for l in body) == 2  # the full-tile store and the masked one of a tile with padding lanes
+        lcs6 = "lcs6" in k  # (these also serve f64 results: a second pair of stores, 8 bytes wide, and the value table in LDS behind the pattern table)
+        assert sum("global_store_dword" in l for l in body) == (4 if lcs6 else 2)  # the full-tile store and the masked one of a tile with padding lanes
         meta = "\n".join(lines[end : end + 80])
         assert re.search(r"; ScratchSize: 0\b", meta) and re.search(rf"; Occupancy: {4 if words > 4 else 8}\b", meta), k
         assert int(re.search(r"; NumVgprs: (\d+)", meta).group(1)) == (104 if words > 4 else 64)
-        assert re.search(rf"\.amdhsa_group_segment_fixed_size {2048 * words}\b", meta), k
+        assert re.search(rf"\.amdhsa_group_segment_fixed_size {4096 if lcs6 else 2048 * words}\b", meta), k

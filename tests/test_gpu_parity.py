@@ -2516,8 +2516,8 @@ def test_six_bit_payload_scans_equal_the_oracle(len2, qlen):
     their own (stream_lcs6_uniform_kernel: 12 instead of 16 bytes per 16 columns) when the length is a whole number of chunks.
     1 048 640+ candidates (the structure is built from 16384 tiles on): queries beyond 32 symbols on 64-bit words (stream_lcs6_uniform_kernel), shorter
     ones on 32-bit words (stream_lcs6n_uniform_kernel), which also take lengths that are not whole chunks (filled up with the code 63, whose table row
-    the scans zero: an LCS column over it is a no-op); f64 results, fuzz::ratio, longer queries on partial chunks and the 70-symbol corpus keep the 8-bit
-    scans -- every op, planted near-duplicates, every value against the oracle."""
+    the scans zero: an LCS column over it is a no-op); longer queries on partial chunks and the 70-symbol corpus keep the 8-bit scans; the normalized
+    ops and fuzz::ratio take the same asm scans (their f64 value looked up in a host-built table) -- every op, planted near-duplicates, every value against the oracle."""
     import torch
 
     n = 16385 * 64 + 17
@@ -2542,6 +2542,12 @@ def test_six_bit_payload_scans_equal_the_oracle(len2, qlen):
                 else:
                     bad = np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
                 assert len(bad) == 0, (symbols, metric, opname, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
+            # the f64 results come out of the asm scans too (a table of the <= 256 values, rf_stream_asm.hip stream_asm_f64_table): loose cutoffs -- no
+            # early-out kernel -- are folded into that table
+            for op, cut in ((N.OP_NORMALIZED_SIMILARITY, 0.1), (N.OP_NORMALIZED_SIMILARITY, 0.3), (N.OP_NORMALIZED_SIMILARITY, 0.45), (N.OP_NORMALIZED_DISTANCE, 0.75), (N.OP_NORMALIZED_DISTANCE, 0.55)):
+                got, exp = bc.many(op, corpus, score_cutoff=cut), ob.rows(op, host, nthreads=8, score_cutoff=cut)
+                bad = np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
+                assert len(bad) == 0, (symbols, metric, op, cut, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
         # fuzz::RatioBatchComparator (fuzz.rs:141: the inner lcs_seq comparator's normalized similarity) rides the same scan
         got = rf.fuzz.RatioBatchComparator(q).similarity_many(corpus)
         assert np.array_equal(got, ORA["lcs_seq"].BatchComparator(q).rows(N.OP_NORMALIZED_SIMILARITY, host, nthreads=8))

@@ -39,13 +39,13 @@ else:
     corpus = rf.Corpus.from_device_rows(rows)
     del rows
 bc = getattr(rf.distance, metric).BatchComparator(q)
-is_f = metric in ("jaro", "jaro_winkler")
+is_f = metric in ("jaro", "jaro_winkler") or "+norm" in what  # (+norm: normalized_similarity, f64 results)
 out = torch.empty(n, dtype=torch.float64 if is_f else torch.int32, device="cuda")
 keys = torch.empty(64, dtype=torch.int64, device="cuda")
 if "+topk" in what:
     fn = lambda: bc.topk_keys_device(corpus, 16, keys, out=out if "+out" in what else None, **kw)
 else:
-    fn = lambda: bc.many(N.OP_SIMILARITY if is_f else N.OP_DISTANCE, corpus, out=out, **kw)
+    fn = lambda: bc.many(N.OP_NORMALIZED_SIMILARITY if "+norm" in what else (N.OP_SIMILARITY if is_f else N.OP_DISTANCE), corpus, out=out, **kw)
 for _ in range(int(os.environ.get("AB_WARMUP", 30))):
     fn()
 torch.cuda.synchronize()

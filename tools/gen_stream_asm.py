@@ -46,7 +46,7 @@ BAND = os.environ.get("RF_GEN_BAND", "1") == "1"  # 0: the multi-word kernels ru
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
         ("uniform_len", 4), ("uniform_tile_bytes", 4), ("len1", 4), ("fin_vS", 4), ("fin_vM", 4), ("fin_vR", 4), ("fin_flip", 4),
-        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4), ("band_k", 4), ("valid_w", 64), ("pad1", 4)]  # valid_w: (lo, hi) row masks of words 0..7; band_k: distances above it need not be exact (multi-word kernels)
+        ("fin_cflip", 4), ("valid_lo", 4), ("valid_hi", 4), ("flags", 4), ("band_k", 4), ("valid_w", 64), ("pad1", 4), ("vtab", 2048)]  # vtab: the f64 value of every u32 value 0..255 (the 6-bit LCS kernels, flags bit 4); valid_w: (lo, hi) row masks of words 0..7; band_k: distances above it need not be exact (multi-word kernels)
 # SGPR map
 S_DATA, S_TILES, S_ORIG, S_PM, S_SIGMA, S_OUT = "s[8:9]", "s[10:11]", "s[12:13]", "s[14:15]", "s[16:17]", "s[18:19]"
 (S_TBEGIN, S_TEND, S_N, S_ULEN, S_UBYTES, S_LEN1, S_VS, S_VM, S_VR, S_FLIP, S_CFLIP, S_VLO) = [f"s{i}" for i in range(20, 32)]
@@ -515,6 +515,12 @@ def kernel(K, uniform):
             L += ["v_cndmask_b32_e64 v9, v9, 0, vcc"] if K.bits == 64 else []
             L += ["Lnofill_%=:"]
         L += ["ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
+        if getattr(K, "no_partial", False):
+            # f64 results (flags bit 4: normalized_distance / normalized_similarity / fuzz::ratio): on a single-length corpus the value is a function of the u32
+            # distance alone, and the HOST tabulates it (StreamAsmArgs::vtab: the reference's own division and cutoff compare, 256 doubles in the kernarg block) --
+            # thread i stages entry i behind the pattern table; the epilogue is one ds_read_b64 and an 8-byte store
+            L += [f"s_bitcmp1_b32 {S_FLAGS}, 4", "s_cbranch_scc0 Lnovt_%=", f"global_load_dwordx2 v[12:13], v7, %[kp] offset:{off['vtab']}", "s_waitcnt vmcnt(0)",
+                  "ds_write_b64 v7, v[12:13] offset:2048", "Lnovt_%=:"]
     else:  # row i of the host table (W consecutive words) -> word w to plane w, row sigma(i)
         L += [f"global_load_ubyte v6, v1, {S_SIGMA}", f"v_mul_u32_u24 v7, {8 * W}, v1"]
         L += [f"global_load_dwordx2 v[{24 + 2 * w}:{25 + 2 * w}], v7, {S_PM}" + (f" offset:{8 * w}" if w else "") for w in range(W)]
@@ -583,6 +589,13 @@ def kernel(K, uniform):
         L += [f"s_waitcnt vmcnt({R - 1})", "Lixd_%=:"]
         # slot store (flags bit 1): index = slot, every lane stores (padding lanes own a slot of the temporary)
         L += [f"s_bitcmp1_b32 {S_FLAGS}, 1", "s_cbranch_scc0 Lnoslot_%=", f"v_add_u32 {V_IDX}, {S_SLOT0}, {V_LANE}", "Lnoslot_%=:"]
+    if getattr(K, "no_partial", False):  # f64 results: the value's double from the staged table (value <= 255: the launcher's condition)
+        L += [f"s_bitcmp1_b32 {S_FLAGS}, 4", "s_cbranch_scc0 Lu32_%=", "v_lshlrev_b32 v7, 3, v6", "ds_read_b64 v[6:7], v7 offset:2048",
+              f"v_cmp_gt_u32 vcc, {S_N}, {V_IDX}", f"v_lshl_add_u64 v[8:9], v[4:5], 3, {S_OUT}", "s_waitcnt lgkmcnt(0)",
+              "s_cmp_eq_u64 vcc, -1", "s_cbranch_scc0 Lpart8_%=",
+              "global_store_dwordx2 v[8:9], v[6:7], off", f"s_mov_b32 {S_AFTER}, 1", "s_branch Lstored_%=",
+              "Lpart8_%=:", f"s_and_saveexec_b64 {S_EXEC}, vcc", "global_store_dwordx2 v[8:9], v[6:7], off", f"s_mov_b64 exec, {S_EXEC}",
+              "s_waitcnt vmcnt(0)", f"s_mov_b32 {S_AFTER}, 0", "s_branch Lstored_%=", "Lu32_%=:"]
     L += [f"v_cmp_gt_u32 vcc, {S_N}, {V_IDX}" if uniform else f"v_cmp_ne_u32 vcc, -1, {V_IDX}",                 # real candidates only
           f"v_lshl_add_u64 v[8:9], v[4:5], 2, {S_OUT}",
           "s_cmp_eq_u64 vcc, -1", "s_cbranch_scc0 Lpart_%=",
