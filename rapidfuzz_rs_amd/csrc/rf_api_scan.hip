@@ -958,7 +958,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     bool tmp_owned = false;                 // d_tmp is this call's own stream-ordered allocation
     rf_corpus::GatherTmp* kept_tmp = nullptr;  // ... or this kept buffer of the corpus (valid while tmp_lock is held)
     std::unique_lock<std::mutex> tmp_lock;  // held while a kept temporary's scan + gather are enqueued
-    // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 12 bytes per
+    // (under a cutoff only the tiles of the passing length window write through orig[]; the gather is a fixed 10-12 bytes per
     // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
     const bool wide_window = (uint64_t)(p.tile_end - p.tile_begin) * 10 >= (uint64_t)corpus->n_tiles * 3;
     const bool by_runs = !by_origin && scan_runs_applies(corpus, p, raw);  // small-cutoff scans of a bucketed corpus: one single-length view per length run
@@ -994,6 +994,14 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                     if (e1 == hipSuccess) e1 = hipMemsetAsync(so, 0xFF, corpus->n * sizeof(uint32_t), st);
                 }
                 if (e1 == hipSuccess) e1 = launch_slot_maps(corpus->d_orig, (uint32_t)corpus->n_slots, so, si, st);
+                // (round 5) the window gather reads a slot's place inside its span from 2 bytes instead of the 4 of orig[] (RF_GATHER_OFF16=0: the A/B switch;
+                // no room for them: the gather reads orig[] as before)
+                static const bool use_off16 = [] { const char* e = getenv("RF_GATHER_OFF16"); return !e || atoi(e) != 0; }();
+                uint16_t* o16 = nullptr;
+                if (e1 == hipSuccess && table && use_off16) {
+                    if (hipMalloc((void**)&o16, corpus->n_slots * sizeof(uint16_t)) != hipSuccess) (void)hipGetLastError(), o16 = nullptr;
+                    if (o16) e1 = launch_slot_off16(corpus->d_orig, (uint32_t)corpus->n_slots, o16, st);
+                }
                 if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);  // (other streams may use the maps as soon as the lock is released)
                 if (list) (void)hipFree(list);
                 if (e1 != hipSuccess) {
@@ -1002,10 +1010,12 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                     if (so) (void)hipFree(so);
                     if (si) (void)hipFree(si);
                     if (table) (void)hipFree(table);
+                    if (o16) (void)hipFree(o16);
                     (void)hipGetLastError();
                 } else {
                     corpus->d_slot_of = so;
                     corpus->d_window_table = table;
+                    corpus->d_slot_off16 = o16;
                     corpus->gather_runs = n_runs;
                     corpus->gather_rows = n_rows;
                     corpus->d_slot_ident = si;
@@ -1090,7 +1100,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     if (p.long_scratch) (void)scratch_free(p.long_scratch, st);
     if (d_tmp) {
         if (e == hipSuccess)
-            e = corpus->d_window_table ? launch_window_gather(d_tmp, corpus->d_orig, corpus->d_window_table, corpus->gather_runs, corpus->gather_rows, d_out,
+            e = corpus->d_window_table ? launch_window_gather(d_tmp, corpus->d_orig, corpus->d_slot_off16, corpus->d_window_table, corpus->gather_runs, corpus->gather_rows, d_out,
                                                               (uint32_t)corpus->n, f64_out, st)
                                        : launch_gather_results(d_tmp, corpus->d_slot_of, d_out, (uint32_t)corpus->n, f64_out, st);
         if (tmp_owned) (void)scratch_free(d_tmp, st);

@@ -194,10 +194,12 @@ hipError_t launch_head8_plane_tiles(const uint8_t* data, const TileDesc* tiles, 
 // the coalesced gather (rf_pack.hip "window_gather_kernel"): windows of kGatherWindow original indices, at most kMaxGatherRuns runs
 constexpr uint32_t kGatherWindow = 4096;
 constexpr uint32_t kMaxGatherRuns = 512;
+constexpr uint32_t kGatherOff16Mod = 8192;  // the 2-byte slot offsets (launch_slot_off16): original index mod this -- one period holds a workgroup's span
 hipError_t launch_run_starts(const uint32_t* orig, uint32_t n_slots, uint32_t* list, uint32_t cap, uint32_t* count, hipStream_t stream);
 hipError_t launch_window_table(const uint32_t* orig, const uint32_t* runs, uint32_t n_runs, uint32_t n_rows, uint32_t* table, hipStream_t stream);
-hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uint32_t* table, uint32_t n_runs, uint32_t n_rows, void* out, uint32_t n, bool f64,
-                                hipStream_t stream);
+hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uint16_t* off16, const uint32_t* table, uint32_t n_runs, uint32_t n_rows, void* out, uint32_t n,
+                                bool f64, hipStream_t stream);  // off16 (launch_slot_off16) or, nullptr, orig
+hipError_t launch_slot_off16(const uint32_t* orig, uint32_t n_slots, uint16_t* off16, hipStream_t stream);
 hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void* out, uint32_t n, bool f64, hipStream_t stream);
 // exact selection over a device score vector (rf_select.hip)
 hipError_t launch_select_minmax(const void* s, bool f64, uint32_t n, bool desc, void* ctl, hipStream_t st);

@@ -304,7 +304,8 @@ hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void*
 // of one WINDOW of kGatherWindow consecutive original indices sit in one contiguous stretch of every run.  A table holds where
 // each window starts in each run (built once per corpus, by binary search: window_table_kernel); a workgroup then reads its
 // window's stretches of tmp and orig front to back, drops the values into an LDS image of the window at orig - base, and writes
-// the image out in one piece.  Same 12 bytes per candidate as gather_results_kernel, but that one issues 64 transactions per
+// the image out in one piece.  12 bytes per candidate like gather_results_kernel (10 with the 2-byte offsets of launch_slot_off16 in place of orig[]: round 5),
+// but that one issues 64 transactions per
 // wavefront load of tmp (64 candidates of 64 lengths), this one 2-3.  Corpora with more than kMaxGatherRuns runs keep the other.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void run_starts_kernel(const uint32_t* __restrict__ orig, uint32_t n_slots, uint32_t* __restrict__ list, uint32_t cap,
@@ -353,11 +354,12 @@ hipError_t launch_window_table(const uint32_t* orig, const uint32_t* runs, uint3
 }
 
 // kRows table windows per workgroup trip: 2 for u32 results, 1 for f64 (a 32 KiB image either way: 5 workgroups per CU)
-template <class T, uint32_t kRows, uint32_t kFlight>
-__global__ __launch_bounds__(256) void window_gather_kernel(const T* __restrict__ tmp, const uint32_t* __restrict__ orig, const uint32_t* __restrict__ table,
-                                                            uint32_t n_runs, uint32_t n_rows, T* __restrict__ out, uint32_t n)
+template <class T, uint32_t kRows, uint32_t kFlight, bool kOff16>
+__global__ __launch_bounds__(256) void window_gather_kernel(const T* __restrict__ tmp, const uint32_t* __restrict__ orig, const uint16_t* __restrict__ off16,
+                                                            const uint32_t* __restrict__ table, uint32_t n_runs, uint32_t n_rows, T* __restrict__ out, uint32_t n)
 {
     constexpr uint32_t kSpan = kRows * kGatherWindow;
+    static_assert(kSpan <= kGatherOff16Mod && kGatherOff16Mod % kSpan == 0, "a span lies inside one period of the 16-bit offsets");
     __shared__ T image[kSpan];
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     const uint32_t spans = (n + kSpan - 1) / kSpan;
@@ -373,6 +375,41 @@ __global__ __launch_bounds__(256) void window_gather_kernel(const T* __restrict_
                 const bool live = r0 + j < n_runs;
                 a[j] = live ? row0[r0 + j] : 0u;
                 b[j] = live ? row1[r0 + j] : 0u;
+            }
+            if (kOff16) {
+                // TWO slots per lane (an even-aligned pair: one dword of offsets, one 8- / 16-byte load of values) -- sub-dword lanes cost more per instruction than
+                // their bytes save (profiles/grid_sweep_r05.txt), dword lanes do not
+                uint32_t a2[kFlight], longest = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kFlight; ++j) {
+                    a2[j] = a[j] & ~1u;
+                    longest = max(longest, b[j] - a2[j]);
+                }
+                const uint32_t sub = base & (kGatherOff16Mod - 1);
+                for (uint32_t k = 2 * lane; k < longest + 2 * lane; k += 2 * kWave) {  // (uniform trip count)
+                    uint32_t o[kFlight];
+                    T v0[kFlight], v1[kFlight];
+#pragma unroll
+                    for (uint32_t j = 0; j < kFlight; ++j) {
+                        const uint32_t s0 = a2[j] + k;  // (even; slot s0 + 1 exists: the slot count is a multiple of 64)
+                        const bool in = s0 < b[j];
+                        o[j] = in ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(off16 + s0)) : 0xFFFFFFFFu;
+                        if (in) {
+                            typedef T Pair __attribute__((ext_vector_type(2)));
+                            const Pair v = __builtin_nontemporal_load(reinterpret_cast<const Pair*>(tmp + s0));  // (aligned: s0 is even)
+                            v0[j] = v.x;
+                            v1[j] = v.y;
+                        }
+                        if (s0 < a[j]) o[j] |= 0xFFFFu;             // the slot before the stretch
+                        if (s0 + 1 >= b[j]) o[j] |= 0xFFFF0000u;    // the slot behind it
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < kFlight; ++j) {
+                        if ((o[j] & 0xFFFFu) != 0xFFFFu) image[(o[j] & 0xFFFFu) - sub] = v0[j];
+                        if ((o[j] >> 16) != 0xFFFFu) image[(o[j] >> 16) - sub] = v1[j];
+                    }
+                }
+                continue;
             }
             uint32_t longest = 0;
 #pragma unroll
@@ -397,19 +434,40 @@ __global__ __launch_bounds__(256) void window_gather_kernel(const T* __restrict_
         __syncthreads();
     }
 }
-hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uint32_t* table, uint32_t n_runs, uint32_t n_rows, void* out, uint32_t n, bool f64,
-                                hipStream_t stream)
+hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uint16_t* off16, const uint32_t* table, uint32_t n_runs, uint32_t n_rows, void* out, uint32_t n,
+                                bool f64, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     // (measured, 100 M u32 results of 64 lengths, whole Indel step: 2 windows x 8 runs in flight 1.125 ms; 2 x 4: 1.155; 4 x 4: 1.19;
     // 4 x 8: 1.15; 1 x 4: 1.165; 2 x 16: 1.15; 1 x 8: 1.185 -- gather_results_kernel: 1.226)
     const uint32_t span = (f64 ? 1u : 2u) * kGatherWindow;
     const dim3 g(std::min<uint32_t>((n + span - 1) / span, (uint32_t)scan_max_grid())), b(256);
-    if (f64)
-        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8>), g, b, 0, stream, static_cast<const double*>(tmp), orig, table, n_runs, n_rows, static_cast<double*>(out), n);
-    else
-        hipLaunchKernelGGL((window_gather_kernel<uint32_t, 2, 8>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), orig, table, n_runs, n_rows,
+    if (f64 && off16)
+        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8, true>), g, b, 0, stream, static_cast<const double*>(tmp), orig, off16, table, n_runs, n_rows, static_cast<double*>(out), n);
+    else if (f64)
+        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8, false>), g, b, 0, stream, static_cast<const double*>(tmp), orig, off16, table, n_runs, n_rows, static_cast<double*>(out), n);
+    else if (off16)
+        hipLaunchKernelGGL((window_gather_kernel<uint32_t, 2, 8, true>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), orig, off16, table, n_runs, n_rows,
                            static_cast<uint32_t*>(out), n);
+    else
+        hipLaunchKernelGGL((window_gather_kernel<uint32_t, 2, 8, false>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), orig, off16, table, n_runs, n_rows,
+                           static_cast<uint32_t*>(out), n);
+    return hipGetLastError();
+}
+
+// off16[slot] = orig[slot] mod kGatherOff16Mod (0xFFFF on padding slots): all the window gather needs to know about a slot's candidate, since its span of
+// original indices is known -- 2 bytes per slot instead of the 4 of orig[] (once per corpus)
+__global__ __launch_bounds__(256) void slot_off16_kernel(const uint32_t* __restrict__ orig, uint32_t n_slots, uint16_t* __restrict__ off16)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += gridDim.x * blockDim.x) {
+        const uint32_t o = orig[s];
+        off16[s] = o == kPad ? (uint16_t)0xFFFFu : (uint16_t)(o & (kGatherOff16Mod - 1));
+    }
+}
+hipError_t launch_slot_off16(const uint32_t* orig, uint32_t n_slots, uint16_t* off16, hipStream_t stream)
+{
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(slot_off16_kernel, dim3(std::min<uint32_t>((n_slots + 255) / 256, 65536u)), dim3(256), 0, stream, orig, n_slots, off16);
     return hipGetLastError();
 }
 
