@@ -43,6 +43,7 @@
  *   RF_TILE_ORDER                 2         0..3: how a length-bucketed corpus' results reach original order
  *   RF_UNSCATTER_MIN              1048576   fewest candidates for the slot-ordered temporary + gather pass
  *   RF_GATHER_WINDOWS             1         0: gather_results_kernel instead of the window gather
+ *   RF_GATHER_XCD                 1         0: the window gather's spans go to workgroups round-robin instead of one eighth of them per XCD
  *   RF_GATHER_OFF16               1         0: the window gather reads orig[] (4 bytes per slot) instead of its 2-byte window offsets (+ 2 bytes per slot kept per corpus)
  *   RF_GATHER_SPAN / RF_GATHER_UNROLL   16384 / 8   window gather tuning
  *   RF_TOPK_VIA_SCORES            1         top-k (k <= 64) as scan + one pass over the scores: 0 never, 1 multi-word Levenshtein, 2 every shape with an asm scan

@@ -356,14 +356,21 @@ hipError_t launch_window_table(const uint32_t* orig, const uint32_t* runs, uint3
 // kRows table windows per workgroup trip: 2 for u32 results, 1 for f64 (a 32 KiB image either way: 5 workgroups per CU)
 template <class T, uint32_t kRows, uint32_t kFlight, bool kOff16>
 __global__ __launch_bounds__(256) void window_gather_kernel(const T* __restrict__ tmp, const uint32_t* __restrict__ orig, const uint16_t* __restrict__ off16,
-                                                            const uint32_t* __restrict__ table, uint32_t n_runs, uint32_t n_rows, T* __restrict__ out, uint32_t n)
+                                                            const uint32_t* __restrict__ table, uint32_t n_runs, uint32_t n_rows, T* __restrict__ out, uint32_t n,
+                                                            uint32_t xcd_deal)
 {
     constexpr uint32_t kSpan = kRows * kGatherWindow;
     static_assert(kSpan <= kGatherOff16Mod && kGatherOff16Mod % kSpan == 0, "a span lies inside one period of the 16-bit offsets");
     __shared__ T image[kSpan];
     const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     const uint32_t spans = (n + kSpan - 1) / kSpan;
-    for (uint32_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
+    // xcd_deal: workgroups go to the 8 XCDs round-robin, and neighbouring spans share the 128-byte lines their stretches begin and end in -- so XCD x walks the
+    // x-th eighth of the spans, neighbours at the same time, and those lines are fetched into one L2 once (round 5)
+    const uint32_t per_xcd = xcd_deal ? (spans + 7) / 8 : spans, stride = xcd_deal ? gridDim.x / 8 : gridDim.x;
+    const uint32_t first = xcd_deal ? (blockIdx.x & 7) * per_xcd : 0;
+    for (uint32_t j = xcd_deal ? blockIdx.x / 8 : blockIdx.x; j < per_xcd; j += stride) {
+        const uint32_t sp = first + j;
+        if (sp >= spans) break;
         const uint32_t base = sp * kSpan;
         const uint32_t* row0 = table + (size_t)(sp * kRows) * n_runs;
         const uint32_t* row1 = table + (size_t)min((sp + 1) * kRows, n_rows - 1) * n_runs;
@@ -441,17 +448,21 @@ hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uin
     // (measured, 100 M u32 results of 64 lengths, whole Indel step: 2 windows x 8 runs in flight 1.125 ms; 2 x 4: 1.155; 4 x 4: 1.19;
     // 4 x 8: 1.15; 1 x 4: 1.165; 2 x 16: 1.15; 1 x 8: 1.185 -- gather_results_kernel: 1.226)
     const uint32_t span = (f64 ? 1u : 2u) * kGatherWindow;
-    const dim3 g(std::min<uint32_t>((n + span - 1) / span, (uint32_t)scan_max_grid())), b(256);
+    static const bool use_deal = [] { const char* e = getenv("RF_GATHER_XCD"); return !e || atoi(e) != 0; }();
+    uint32_t grid = std::min<uint32_t>((n + span - 1) / span, (uint32_t)scan_max_grid());
+    const uint32_t deal = (use_deal && grid >= 64) ? 1u : 0u;
+    if (deal) grid = (grid + 7) / 8 * 8;
+    const dim3 g(grid), b(256);
     if (f64 && off16)
-        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8, true>), g, b, 0, stream, static_cast<const double*>(tmp), orig, off16, table, n_runs, n_rows, static_cast<double*>(out), n);
+        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8, true>), g, b, 0, stream, static_cast<const double*>(tmp), orig, off16, table, n_runs, n_rows, static_cast<double*>(out), n, deal);
     else if (f64)
-        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8, false>), g, b, 0, stream, static_cast<const double*>(tmp), orig, off16, table, n_runs, n_rows, static_cast<double*>(out), n);
+        hipLaunchKernelGGL((window_gather_kernel<double, 1, 8, false>), g, b, 0, stream, static_cast<const double*>(tmp), orig, off16, table, n_runs, n_rows, static_cast<double*>(out), n, deal);
     else if (off16)
         hipLaunchKernelGGL((window_gather_kernel<uint32_t, 2, 8, true>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), orig, off16, table, n_runs, n_rows,
-                           static_cast<uint32_t*>(out), n);
+                           static_cast<uint32_t*>(out), n, deal);
     else
         hipLaunchKernelGGL((window_gather_kernel<uint32_t, 2, 8, false>), g, b, 0, stream, static_cast<const uint32_t*>(tmp), orig, off16, table, n_runs, n_rows,
-                           static_cast<uint32_t*>(out), n);
+                           static_cast<uint32_t*>(out), n, deal);
     return hipGetLastError();
 }
 
