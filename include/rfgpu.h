@@ -43,6 +43,8 @@
  *   RF_TILE_ORDER                 2         0..3: how a length-bucketed corpus' results reach original order
  *   RF_UNSCATTER_MIN              1048576   fewest candidates for the slot-ordered temporary + gather pass
  *   RF_GATHER_WINDOWS             1         0: gather_results_kernel instead of the window gather
+ *   RF_NORM_TWO_STEP              1         0: normalized ops of the multi-word Levenshtein scans (queries of 65 .. 512 symbols) in the compiled f64 scan instead of
+ *                                           the u32 asm scan + one normalizing pass (+ 4 bytes per candidate kept per length-bucketed corpus: the lengths in original order)
  *   RF_GATHER_XCD                 1         0: the window gather's spans go to workgroups round-robin instead of one eighth of them per XCD
  *   RF_GATHER_OFF16               1         0: the window gather reads orig[] (4 bytes per slot) instead of its 2-byte window offsets (+ 2 bytes per slot kept per corpus)
  *   RF_GATHER_SPAN / RF_GATHER_UNROLL   16384 / 8   window gather tuning

@@ -995,6 +995,7 @@ void rf_corpus_free(rf_corpus* c)
     if (c->d_slot_ident) (void)hipFree(c->d_slot_ident);
     if (c->d_window_table) (void)hipFree(c->d_window_table);
     if (c->d_slot_off16) (void)hipFree(c->d_slot_off16);
+    if (c->d_len_of) (void)hipFree(c->d_len_of);
     for (const rf_corpus::GatherTmp& t : c->gather_tmp) {
         if (t.done) (void)hipEventDestroy(t.done);
         (void)hipFree(t.ptr);
@@ -1034,6 +1035,7 @@ uint64_t rf_corpus_device_bytes(const rf_corpus* c)
         if (c->d_slot_of) aux += (uint64_t)c->n * sizeof(uint32_t);
         if (c->d_window_table) aux += (uint64_t)c->gather_rows * c->gather_runs * sizeof(uint32_t);
         if (c->d_slot_off16) aux += (uint64_t)c->n_slots * sizeof(uint16_t);
+        if (c->d_len_of) aux += (uint64_t)c->n * sizeof(uint32_t);
         for (const auto& kv : c->topk_scratch)  // (candidate ways + root table + bound line + control block, and the score vector if any)
             aux += (uint64_t)64 * kv.second.seg_cap * sizeof(uint64_t) + 64 * kWave * sizeof(uint64_t) + 128 + 65 * 128 + (uint64_t)kv.second.scores_cap * sizeof(uint32_t);
     }

@@ -908,6 +908,57 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     if (s != RF_OK) return s;
 
     hipStream_t st = (hipStream_t)stream;
+    // normalized_distance / normalized_similarity of a multi-word Levenshtein scan: the u32 distance scan (the asm kernels with the
+    // Ukkonen band: 3.3 instead of 2.5 Gpairs/s at 256 x 256) into a temporary, then ONE pass that runs the very arithmetic of emit_fin (rf_device.hpp) on every
+    // distance -- dist / maximum, 1.0 - nd, the cutoff compare -- 12 bytes per candidate against a scan of >= 128 symbols each.  RF_NORM_TWO_STEP=0: the A/B switch.
+    static const bool norm_two_step = [] { const char* e = getenv("RF_NORM_TWO_STEP"); return !e || atoi(e) != 0; }();
+    if (norm_two_step && f64_out && raw == RAW_LEV && p.words >= 2 && p.words <= kMaxWords && !p.early && !p.long_words_pad && corpus == corpus_in && !corpus->borrowed &&
+        corpus->n_tiles >= 16 && (uint64_t)p.len1 + corpus->max_len < 0x7FFFFFFFu && (corpus->uniform || (corpus->d_orig && corpus->d_tiles))) {
+        // (length-bucketed corpora: the candidates' lengths in original order, 4 bytes each, built once per corpus from the tile descriptors)
+        const uint32_t* len_of = nullptr;
+        if (!corpus->uniform) {
+            std::lock_guard<std::mutex> lock(corpus->scratch_mu);
+            if (!corpus->d_len_of) {
+                uint32_t* l = nullptr;
+                hipError_t e1 = hipMalloc((void**)&l, corpus->n * sizeof(uint32_t));
+                if (e1 == hipSuccess) e1 = launch_len_of(corpus->d_tiles, corpus->n_tiles, corpus->d_orig, l, st);
+                if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);  // (other streams may use it as soon as the lock is released)
+                if (e1 != hipSuccess) {
+                    if (l) (void)hipFree(l);
+                    (void)hipGetLastError();  // (no room: the compiled f64 scan below, same values)
+                } else
+                    corpus->d_len_of = l;
+            }
+            len_of = corpus->d_len_of;
+        }
+        if (corpus->uniform || len_of) {
+            rf_args a = *args;
+            a.cutoff_usize = RF_NO_CUTOFF;
+            a.score_hint_usize = RF_NO_CUTOFF;
+            uint32_t* d_dist = nullptr;
+            RF_HIP(scratch_alloc((void**)&d_dist, corpus->n * sizeof(uint32_t), st));
+            const rf_status rs = run_many(c_in, corpus_in, RF_OP_DISTANCE, &a, d_dist, RF_MEM_DEVICE, st, false);
+            double* d_out = static_cast<double*>(out);
+            if (rs == RF_OK && out_mem == RF_MEM_HOST) {
+                const hipError_t ea = scratch_alloc((void**)&d_out, corpus->n * sizeof(double), st);
+                if (ea != hipSuccess) {
+                    scratch_free(d_dist, st);
+                    RF_HIP(ea);
+                }
+            }
+            hipError_t e = hipSuccess;
+            if (rs == RF_OK) e = launch_normalize(d_dist, len_of, corpus->uniform_len, d_out, (uint32_t)corpus->n, p.len1, p.fin_mS, p.fin_mM, p.op, p.has_cutoff, p.cutoff_f64, st);
+            scratch_free(d_dist, st);
+            if (rs == RF_OK && e == hipSuccess && out_mem == RF_MEM_HOST) {
+                e = hipMemcpyAsync(out, d_out, corpus->n * sizeof(double), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+            }
+            if (out_mem == RF_MEM_HOST && d_out != out) scratch_free(d_out, st);
+            if (rs != RF_OK) return rs;
+            RF_HIP(e);
+            return RF_OK;
+        }
+    }
     {
         uint32_t k1 = 0, factor = 1;
         if (corpus == corpus_in && hint_pass_applies(c, corpus, op, args, f64_out, &k1, &factor))

@@ -97,6 +97,7 @@ struct rf_corpus {
     mutable uint32_t max_stored_sym = 0xFFFFFFFFu;  // largest stored symbol of the payload, exact; 0xFFFFFFFF = not computed yet (corpus_max_stored_symbol)
     mutable uint32_t* d_slot_of = nullptr;     // candidate -> its slot
     mutable uint32_t* d_slot_ident = nullptr;  // slot -> slot, kPad on padding lanes (stands in for d_orig in such a launch)
+    mutable uint32_t* d_len_of = nullptr;      // candidate -> its length (original order): the normalizing pass of run_many's two-step path; built on first use
     mutable uint16_t* d_slot_off16 = nullptr;  // slot -> original index mod kGatherOff16Mod (0xFFFF: padding): what the window gather reads instead of d_orig
     mutable uint32_t* d_window_table = nullptr;  // the coalesced gather's table (rf_pack.hip window_table_kernel): gather_rows x gather_runs
     mutable uint32_t gather_runs = 0, gather_rows = 0;

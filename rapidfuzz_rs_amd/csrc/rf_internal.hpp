@@ -199,6 +199,10 @@ hipError_t launch_run_starts(const uint32_t* orig, uint32_t n_slots, uint32_t* l
 hipError_t launch_window_table(const uint32_t* orig, const uint32_t* runs, uint32_t n_runs, uint32_t n_rows, uint32_t* table, hipStream_t stream);
 hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uint16_t* off16, const uint32_t* table, uint32_t n_runs, uint32_t n_rows, void* out, uint32_t n,
                                 bool f64, hipStream_t stream);  // off16 (launch_slot_off16) or, nullptr, orig
+// u32 distances -> the f64 a normalized op returns (rf_pack.hip normalize_kernel: emit_fin's arithmetic with one maximum)
+hipError_t launch_normalize(const uint32_t* dist, const uint32_t* len_of, uint32_t uniform_len, double* out, uint32_t n, uint32_t len1, int32_t fin_mS, int32_t fin_mM, uint32_t op,
+                            uint32_t has_cutoff, double cutoff, hipStream_t stream);  // len_of: the candidates' lengths in original order, or nullptr = uniform_len
+hipError_t launch_len_of(const TileDesc* tiles, uint32_t n_tiles, const uint32_t* orig, uint32_t* len_of, hipStream_t stream);
 hipError_t launch_slot_off16(const uint32_t* orig, uint32_t n_slots, uint16_t* off16, hipStream_t stream);
 hipError_t launch_gather_results(const void* tmp, const uint32_t* slot_of, void* out, uint32_t n, bool f64, hipStream_t stream);
 // exact selection over a device score vector (rf_select.hip)

@@ -466,6 +466,54 @@ hipError_t launch_window_gather(const void* tmp, const uint32_t* orig, const uin
     return hipGetLastError();
 }
 
+// The f64 a normalized op returns for every u32 distance: exactly emit_fin's f64 branch (rf_device.hpp tile_fin / emit_fin; details/distance.rs:246-250, :273;
+// the cutoff compare of src/common.rs:43-45 / :83-85) -- run_many's two-step path for the multi-word Levenshtein scans.  The candidate's length comes from
+// len_of[] (original order; launch_len_of) or is the one length of a single-length corpus.
+__global__ __launch_bounds__(256) void normalize_kernel(const uint32_t* __restrict__ dist, const uint32_t* __restrict__ len_of, uint32_t uniform_len, double* __restrict__ out,
+                                                        uint32_t n, uint32_t len1, int32_t fin_mS, int32_t fin_mM, uint32_t op, uint32_t has_cutoff, double cutoff)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t d = __builtin_nontemporal_load(dist + i);
+        const uint32_t len2 = len_of ? __builtin_nontemporal_load(len_of + i) : uniform_len;
+        const uint32_t maximum = (uint32_t)fin_mS * (len1 + len2) + (uint32_t)fin_mM * max(len1, len2);
+        const double nd = maximum == 0 ? 0.0 : (double)d / (double)maximum;
+        double v;
+        bool keep;
+        if (op == RF_OP_NORMALIZED_DISTANCE) {
+            v = nd;
+            keep = !has_cutoff || v <= cutoff;
+        } else {
+            v = 1.0 - nd;
+            keep = !has_cutoff || v >= cutoff;
+        }
+        __builtin_nontemporal_store(keep ? v : __longlong_as_double(0x7FF8000000000000ll), out + i);
+    }
+}
+hipError_t launch_normalize(const uint32_t* dist, const uint32_t* len_of, uint32_t uniform_len, double* out, uint32_t n, uint32_t len1, int32_t fin_mS, int32_t fin_mM, uint32_t op,
+                            uint32_t has_cutoff, double cutoff, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(normalize_kernel, dim3(std::min<uint32_t>((n + 255) / 256, (uint32_t)scan_max_grid() * 4)), dim3(256), 0, stream, dist, len_of, uniform_len, out, n, len1,
+                       fin_mS, fin_mM, op, has_cutoff, cutoff);
+    return hipGetLastError();
+}
+// len_of[orig[slot]] = the length of the slot's tile, over the exact tiles and the one-length views of the mixed section (every candidate has a slot in one of them)
+__global__ __launch_bounds__(256) void len_of_kernel(const TileDesc* __restrict__ tiles, uint32_t n_tiles, const uint32_t* __restrict__ orig, uint32_t* __restrict__ len_of)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    for (uint32_t t = blockIdx.x * 4 + threadIdx.x / kWave; t < n_tiles; t += gridDim.x * 4) {
+        const TileDesc d = tiles[t];
+        const uint32_t o = orig[d.slot0 + lane];
+        if (o != kPad) len_of[o] = d.len;
+    }
+}
+hipError_t launch_len_of(const TileDesc* tiles, uint32_t n_tiles, const uint32_t* orig, uint32_t* len_of, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(len_of_kernel, dim3(std::min<uint32_t>((n_tiles + 3) / 4, 65536u)), dim3(256), 0, stream, tiles, n_tiles, orig, len_of);
+    return hipGetLastError();
+}
+
 // off16[slot] = orig[slot] mod kGatherOff16Mod (0xFFFF on padding slots): all the window gather needs to know about a slot's candidate, since its span of
 // original indices is known -- 2 bytes per slot instead of the 4 of orig[] (once per corpus)
 __global__ __launch_bounds__(256) void slot_off16_kernel(const uint32_t* __restrict__ orig, uint32_t n_slots, uint16_t* __restrict__ off16)

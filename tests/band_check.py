@@ -78,6 +78,12 @@ def check(tag, q, corpus, host=None, ragged=None):
         bad = same(got, exp)
         if len(bad):
             bad_ops.append((f"cutoff {cut}", len(bad), bad[:4].tolist(), got[bad[:4]].tolist(), exp[bad[:4]].tolist()))
+    # normalized ops under loose f64 cutoffs (no early-out kernel: single-length corpora take the u32 asm scan + one normalizing pass, rf_api_scan.hip run_many)
+    for opname, cut in (("normalized_distance", 0.9), ("normalized_distance", 0.7), ("normalized_similarity", 0.1), ("normalized_similarity", 0.35)):
+        got, exp = bc.many(OPS[opname], corpus, score_cutoff=cut), expect(OPS[opname], score_cutoff=cut)
+        bad = same(got, exp)
+        if len(bad):
+            bad_ops.append((f"{opname} cutoff {cut}", len(bad), bad[:4].tolist(), got[bad[:4]].tolist(), exp[bad[:4]].tolist()))
     # the in-scan / via-scores top-16 over the same scans
     exp = expect(N.OP_DISTANCE)
     order = np.lexsort((np.arange(len(exp)), exp))[:16]
