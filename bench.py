@@ -407,6 +407,14 @@ def main():
     # north star's 0.60 is about); what is MOVED is reported beside it and is what the traffic counters see)
     pack6 = (args.metric in ("indel", "lcs_seq") and args.mode == "many" and not args.ragged and not early and nq == 1 and args.query_len <= 64
              and (args.cand_len % 16 == 0 or (args.symbols < 63 and args.query_len <= 32)) and args.symbols < 64 and n >= (1 << 20) and os.environ.get("RF_PACK6", "1") != "0" and not c5 and world == 1)
+    # (the same on a length-bucketed corpus: the tiles kernels over the 6-bit image of the payload, 12 bytes per STARTED 16 symbols)
+    pack6_ragged = (args.metric in ("indel", "lcs_seq") and args.mode == "many" and args.ragged and not early and nq == 1 and args.query_len <= 64 and args.symbols < 64
+                    and n >= (1 << 20) and os.environ.get("RF_PACK6", "1") != "0" and not c5 and world == 1)
+    moved_bpp = None
+    if pack6:
+        moved_bpp = 12 * ((ln + 15) // 16) + out_bytes
+    elif pack6_ragged:
+        moved_bpp = 12 * sum((L + 15) // 16 for L in range(args.min_len, args.cand_len + 1)) / (args.cand_len - args.min_len + 1) + out_bytes
     pairs_per_gpu = pairs_per_step / world
     achieved = pairs_per_gpu * bytes_per_pair / (kernel_ms * 1e-3) / 1e9  # per GPU, GB/s
     survey_achieved = pairs_per_gpu * survey_bpp / (kernel_ms * 1e-3) / 1e9
@@ -462,8 +470,8 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_pair": bytes_per_pair,
             "survey_8d": {"bytes_per_pair": survey_bpp, "achieved": round(survey_achieved, 1), "frac": round(survey_achieved / HBM_PEAK_GBS, 4)},
-            **({"moved": {"bytes_per_pair": 12 * ((ln + 15) // 16) + out_bytes, "achieved": round(pairs_per_gpu * (12 * ((ln + 15) // 16) + out_bytes) / (kernel_ms * 1e-3) / 1e9, 1),
-                          "what": "the scan streams the 6-bit copy of the payload (12 bytes per 16 symbols)"}} if pack6 else {}),
+            **({"moved": {"bytes_per_pair": moved_bpp, "achieved": round(pairs_per_gpu * moved_bpp / (kernel_ms * 1e-3) / 1e9, 1),
+                          "what": "the scan streams the 6-bit copy of the payload (12 bytes per started 16 symbols)"}} if moved_bpp is not None else {}),
         },
     }
     if (args.metric in ("levenshtein", "indel", "lcs_seq", "osa") and args.query_len <= (512 if args.metric == "levenshtein" else 64) and not weights and not early

@@ -60,9 +60,10 @@
  *                                           mixed tiles together; the launch is the cost there); 0: always two launches
  *   RF_SCRATCH_CACHE_MB           1024      bound on the per-call scratch the library keeps parked between calls (its own stream-ordered
  *                                           allocator, rf_scratch.hip); 0: every block is released as soon as the work behind it is done
- *   RF_PACK6                      1         0: no 6-bit copy of the payload (single-length corpora of < 64 distinct symbols -- < 63 if the length is not a multiple of 16 -- keep
- *                                           one, + 75 % of the payload in HBM, built by the first Indel / LCS scan with u32 results: that scan then streams 12
- *                                           instead of 16 bytes per 16 symbols -- rf_stream_asm.hip stream_lcs6_uniform_kernel)
+ *   RF_PACK6                      1         0: no 6-bit copy of the payload (corpora of < 64 distinct symbols -- < 63 for a single-length corpus whose length is not a
+ *                                           multiple of 16 -- keep one, + 75 % of the payload in HBM, built by the first Indel / LCS / fuzz::ratio scan without an
+ *                                           early-out cutoff: that scan then streams 12 instead of 16 bytes per 16 symbols -- rf_stream_asm.hip
+ *                                           stream_lcs6[n]_uniform_kernel, and stream_lcs6[n]_tiles_kernel for length-bucketed corpora, u32 results)
  *   RF_PACK6_MIN_TILES            16384     fewest tiles of a corpus for which that copy is made
  *   RF_HINT_MIN_TILES             1024      fewest tiles of a corpus for which a per-candidate Levenshtein scan of a query beyond 64 symbols honours
  *                                           score_hint (pass under max(hint, 31), then only what it left unresolved: rf_hint.hip); 4294967295: never

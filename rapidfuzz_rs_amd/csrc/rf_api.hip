@@ -1030,7 +1030,7 @@ uint64_t rf_corpus_device_bytes(const rf_corpus* c)
         std::lock_guard<std::mutex> lock(c->scratch_mu);
         if (c->d_heads8) aux += ((uint64_t)(c->uniform ? c->n_tiles : c->n_exact) + 1) * kWave * 8;
         if (c->d_heads6) aux += ((uint64_t)(c->n_tiles + 1) / 2 + 1) * 3 * kWave * 4;
-        if (c->d_data6) aux += ((uint64_t)c->n_tiles * ((c->uniform_len + kChunk - 1) / kChunk) + 1) * kWave * 12;
+        if (c->d_data6) aux += ((c->uniform ? (uint64_t)c->n_tiles * ((c->uniform_len + kChunk - 1) / kChunk) : c->data_bytes / (kWave * kChunk)) + 1) * kWave * 12;
         if (c->d_slot_ident) aux += (uint64_t)c->n_slots * sizeof(uint32_t);
         if (c->d_slot_of) aux += (uint64_t)c->n * sizeof(uint32_t);
         if (c->d_window_table) aux += (uint64_t)c->gather_rows * c->gather_runs * sizeof(uint32_t);

@@ -466,21 +466,25 @@ const uint32_t* corpus_data6(const rf_corpus* corpus, hipStream_t st)
 {
     static const bool on = [] { const char* e = getenv("RF_PACK6"); return !e || atoi(e) != 0; }();
     static const uint32_t min_tiles = [] { const char* e = getenv("RF_PACK6_MIN_TILES"); return e ? (uint32_t)atoll(e) : 16384u; }();
-    if (!on || !corpus->uniform || corpus->borrowed || corpus->n_tiles < min_tiles || corpus->uniform_len == 0) return nullptr;
-    // (whole chunks: any 64 codes; a partial last chunk is filled up with the code 63, which must then be free)
-    if (corpus_max_stored_symbol(corpus, st) >= (corpus->uniform_len % kChunk == 0 ? 64u : 63u)) return nullptr;
+    if (!on || corpus->borrowed || corpus->n_tiles < min_tiles) return nullptr;
+    if (corpus->uniform ? corpus->uniform_len == 0 : (!corpus->d_tiles || corpus->data_bytes % (kWave * kChunk) != 0)) return nullptr;
+    // (whole chunks: any 64 codes; the partial last chunk of a single-length corpus is filled up with the code 63, which must then be free; bucketed corpora: the
+    // scans shift a partial chunk into place like the 8-bit kernels do, any 64 codes)
+    if (corpus_max_stored_symbol(corpus, st) >= ((!corpus->uniform || corpus->uniform_len % kChunk == 0) ? 64u : 63u)) return nullptr;
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);
     if (!corpus->d_data6 && !corpus->data6_tried) {
         corpus->data6_tried = true;
-        const uint32_t nch = (corpus->uniform_len + kChunk - 1) / kChunk;
-        const uint64_t rows = (uint64_t)corpus->n_tiles * nch;
+        // chunk rows of 64 lanes: tiles x chunks of a single-length corpus; a bucketed one's whole payload, row by row (the 6-bit image mirrors it at 3/4 of every offset)
+        const uint32_t nch = corpus->uniform ? (corpus->uniform_len + kChunk - 1) / kChunk : 1;
+        const uint64_t rows = corpus->uniform ? (uint64_t)corpus->n_tiles * nch : corpus->data_bytes / (kWave * kChunk);
         if (rows * kWave >= 0xFFFFFFFFull) return nullptr;
         uint32_t* d = nullptr;
         if (hipMalloc((void**)&d, (rows + 1) * kWave * 12) != hipSuccess) {  // (+ one chunk row: the scans prefetch past the last tile)
             (void)hipGetLastError();
             return nullptr;
         }
-        hipError_t e = launch_pack6(corpus->d_data, corpus->n_tiles, corpus->uniform_len, d, st);
+        hipError_t e = corpus->uniform ? launch_pack6(corpus->d_data, corpus->n_tiles, corpus->uniform_len, d, st)
+                                       : launch_pack6(corpus->d_data, (uint32_t)rows, (uint32_t)kChunk, d, st);  // (rows of one whole chunk each: nothing to fill)
         if (e == hipSuccess) e = hipMemsetAsync(d + rows * kWave * 3, 0, kWave * 12, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // (other streams may use it as soon as the lock is released)
         if (e != hipSuccess) {
@@ -970,7 +974,10 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     // (where the asm scan over it applies -- rf_scan.hip launch_state; f64 results through a table of the <= 256 values there are: rf_stream_asm.hip stream_asm_f64_table)
     // (lengths that are not whole chunks run their fill columns too: that pays on 32-bit words -- 57 symbols, query 30: 83.8 -> 100.7 Gpairs/s -- and not on the
     // issue-bound 64-bit column: 75.7 -> 74.6)
-    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && corpus->uniform && (corpus->uniform_len % kChunk == 0 || p.len1 <= 32)) ? corpus_data6(corpus, st) : nullptr;
+    // (bucketed corpora: the tiles kernels over the same payload, u32 results -- the ragged scans read 16-byte chunk rows for every started 16 symbols, and 12 here)
+    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && (corpus->uniform ? (corpus->uniform_len % kChunk == 0 || p.len1 <= 32) : (!f64_out && corpus->d_orig != nullptr)))
+                  ? corpus_data6(corpus, st)
+                  : nullptr;
     if (p.data6) p.max_stored_sym = corpus_max_stored_symbol(corpus, st);  // (< 63: the scans may zero the table row of the fill code)
     if (corpus->uniform) plan_band_filter(c, corpus, op, f64_out, &p, corpus->uniform_len);  // (bucketed corpora: per length run, launch_scan_runs)
     static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)

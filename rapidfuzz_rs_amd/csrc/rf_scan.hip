@@ -864,7 +864,10 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             if ((std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value) && use_asm && use_stream_asm && p.data6 && !p.tiles &&
                 stream_asm_serves(p))
                 return launch_stream_asm(std::is_same<State, Lcs32State>::value ? 6 : 5, p, stream, std::max(1, scan_grid_full(p.tile_end - p.tile_begin)));
-            if (kAsmKind >= 0 && use_asm && use_stream_asm && stream_asm_serves(p)) {
+            // ... and the same scans over the 6-bit payload of a length-bucketed corpus (tiles; u32 results)
+            constexpr bool kLcs1 = std::is_same<State, LcsState<1>>::value || std::is_same<State, Lcs32State>::value;
+            const int asm_kind = kAsmKind >= 0 ? kAsmKind : ((kLcs1 && p.data6 && p.tiles) ? (std::is_same<State, Lcs32State>::value ? 6 : 5) : -1);
+            if (asm_kind >= 0 && use_asm && use_stream_asm && stream_asm_serves(p)) {
                 uint32_t at = p.tile_begin;
                 for (int r = 0; r <= 2 && at < p.tile_end; ++r) {
                     const uint32_t zb = r < 2 ? std::min(std::max(p.zero_begin[r], at), p.tile_end) : p.tile_end;
@@ -873,7 +876,7 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                     if (zb > at) {
                         ScanParams q = p;
                         q.tile_begin = at, q.tile_end = zb;
-                        const hipError_t e = launch_stream_asm(kAsmKind, q, stream, std::max(1, scan_grid_full(zb - at)));
+                        const hipError_t e = launch_stream_asm(asm_kind, q, stream, std::max(1, scan_grid_full(zb - at)));
                         if (e != hipSuccess) return e;
                     }
                     if (ze > zb) {

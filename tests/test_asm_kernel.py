@@ -52,8 +52,8 @@ def test_compiler_never_touches_the_pinned_registers(tmp_path, source, kernel, p
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_whole_kernel_asm_scans_resources(tmp_path):
-    """rf_stream_asm.hip: the twenty-two whole-kernel asm scans (Levenshtein 64- / 32-bit, OSA, Levenshtein over 2 .. 8 words -- 2 .. 4 since round 4,
-    5 .. 8 since round 5 -- each x single-length / tile descriptors; the LCS scans over the 6-bit payload -- 64- and 32-bit words -- single-length only).  The wrapper hands the asm
+    """rf_stream_asm.hip: the twenty-four whole-kernel asm scans (Levenshtein 64- / 32-bit, OSA, Levenshtein over 2 .. 8 words -- 2 .. 4 since round 4,
+    5 .. 8 since round 5 -- each x single-length / tile descriptors; the LCS scans over the 6-bit payload -- 64- and 32-bit words -- x single-length / tiles).  The wrapper hands the asm
     body three operands and nothing else, so everything the launch relies on is visible in the compiler's metadata: no scratch, 64 VGPRs = 8 wavefronts
     per SIMD (104 = 4 for 5 .. 8 words), the pattern table (2 KiB per word) as the only LDS object, and a body that contains no compiler-generated code
     between its first and last instruction (ONE asm statement, then s_endpgm)."""
@@ -64,14 +64,14 @@ def test_whole_kernel_asm_scans_resources(tmp_path):
     text = out.read_text()
     lines = text.splitlines()
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2rf\d+stream_\w+_kernelENS_13StreamAsmArgsE:", l)]
-    assert len(starts) == 22
+    assert len(starts) == 24
     for start in starts:
         k = lines[start].split(":")[0]
         words = int(re.search(r"levw(\d)", k).group(1)) if "levw" in k else 1
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
         body = lines[start:end]
         assert sum("ASMSTART" in l for l in body) == 1 and "ASMEND" in lines[end - 1]
-        lcs6 = "lcs6" in k  # (these also serve f64 results: a second pair of stores, 8 bytes wide, and the value table in LDS behind the pattern table)
+        lcs6 = "lcs6" in k and "uniform" in k  # (these also serve f64 results: a second pair of stores, 8 bytes wide, and the value table in LDS behind the pattern table)
         assert sum("global_store_dword" in l for l in body) == (4 if lcs6 else 2)  # the full-tile store and the masked one of a tile with padding lanes
         meta = "\n".join(lines[end : end + 80])
         assert re.search(r"; ScratchSize: 0\b", meta) and re.search(rf"; Occupancy: {4 if words > 4 else 8}\b", meta), k

@@ -2554,6 +2554,50 @@ def test_six_bit_payload_scans_equal_the_oracle(len2, qlen):
         del corpus
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("qlen", [64, 33, 32, 9])
+def test_six_bit_payload_scans_of_a_bucketed_corpus_equal_the_oracle(qlen):
+    """VERDICT r4 item 5 by another road: a length-bucketed corpus of fewer than 64 distinct symbols keeps its whole payload a second time at 6 bits per symbol (the
+    image mirrors the 8-bit one at 3/4 of every offset) and the single-word LCS scans with u32 results -- Indel, LCS -- walk its tiles with
+    stream_lcs6_tiles_kernel / stream_lcs6n_tiles_kernel: 12 instead of 16 bytes per started 16 symbols; a tile's partial last chunk is shifted into place
+    as 6 k bits of the 96-bit value.  1.1 M candidates (the payload is built from 16384 tiles on; the results take the slot-ordered temporary + window gather),
+    lengths 0 .. 80 -- every tail length, zero-length tiles, candidates longer than the query -- planted near-duplicates, 62 symbols and, as the control, 70
+    (no 6-bit payload: the 8-bit scans); every op against the oracle."""
+    n = 1_100_000
+    rng = np.random.default_rng(qlen)
+    q = bytes(rng.integers(97, 123, size=qlen, dtype=np.uint8))
+    qa = np.frombuffer(q, dtype=np.uint8)
+    for symbols in (62, 70):
+        alphabet = np.concatenate([synth.ALNUM, np.arange(33, 41, dtype=np.uint8)])[:symbols]
+        lens = rng.integers(0, 81, size=n).astype(np.uint64)
+        lens[rng.integers(0, n, size=5000)] = 64
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        data = alphabet[rng.integers(0, symbols, size=int(offsets[-1]))]
+        for r in range(0, n, 997):  # the query itself, cut or continued to the candidate's length, with a few edits
+            ln = int(lens[r])
+            if ln:
+                row = np.resize(qa, ln).copy()
+                row[rng.integers(0, ln, size=r % 5)] = alphabet[7]
+                data[int(offsets[r]):int(offsets[r + 1])] = row
+        corpus = rf.Corpus.from_ragged(data, offsets)
+        for metric in ("indel", "lcs_seq"):
+            bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+            for opname, op in OPS.items():
+                got = bc.many(op, corpus)
+                exp = ob.many(op, data, offsets, nthreads=8)
+                if got.dtype == np.uint32:
+                    bad = np.nonzero(got != _expect_u32(exp))[0]
+                else:
+                    bad = np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
+                assert len(bad) == 0, (symbols, metric, opname, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
+            # a loose cutoff (no early-out kernel): the same scans, None from the finishing map
+            cut = qlen + 10
+            got, exp = bc.many(N.OP_DISTANCE, corpus, score_cutoff=cut), ob.many(N.OP_DISTANCE, data, offsets, nthreads=8, score_cutoff=cut)
+            assert np.array_equal(got, _expect_u32(exp)), (symbols, metric, "cutoff")
+        del corpus
+
+
 def test_full_size_osa_and_query32_properties():
     """VERDICT r2 item 1a, second half: osa1_asm_kernel and lev32_asm_kernel at BASELINE's full 100 M x 64 size (6 tiles per
     wavefront with the product grid), like test_full_size_c2_properties does for lev1_asm_kernel: an oracle-checked prefix plus

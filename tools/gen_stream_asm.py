@@ -366,12 +366,12 @@ def chunk_load(K, buf):
     return f"global_load_dwordx{n} v[{buf}:{buf + n - 1}], {V_OFF16}, {S_SRC} nt"
 
 
-def step(K, P, extra):
+def step(K, P, extra, uniform=True):
     """fetch + the 16 columns of ring phase P; labels carry the phase and the statement's unique id"""
     R, sfx = K.ring, f"p{P}_%="
     use, nxt, refill = K.bufs[P], K.bufs[(P + 1) % R], K.bufs[(P + R - 1) % R]
     L = [chunk_load(K, refill)]  # the chunk RING-1 steps ahead
-    if getattr(K, "no_partial", False):  # (every chunk is whole: the launcher's condition)
+    if getattr(K, "no_partial", False) and uniform:  # (every chunk is whole: the launcher's condition)
         late = extra if R > 2 else 0
         L += wait_vm(R - 1, extra, "f", sfx)
         for i in range(16):
@@ -387,15 +387,24 @@ def step(K, P, extra):
     late = extra if R > 2 else 0
     L += wait_vm(R - 2, late, "t", sfx)  # this chunk and the next one have arrived (only younger operations may still be out)
     L.append(f"s_mov_b32 {S_AFTER}, 0")
-    u = [use + i for i in range(4)]
-    L += [f"s_cmp_eq_u32 {S_R8}, 0", f"s_cbranch_scc1 Lq_{sfx}",
-          f"v_alignbit_b32 v{u[3]}, v{u[3]}, v{u[2]}, {S_SH}", f"v_alignbit_b32 v{u[2]}, v{u[2]}, v{u[1]}, {S_SH}",
-          f"v_alignbit_b32 v{u[1]}, v{u[1]}, v{u[0]}, {S_SH}", f"v_lshlrev_b32 v{u[0]}, {S_R8}, v{u[0]}", f"Lq_{sfx}:",
-          f"s_cmp_eq_u32 {S_Q}, 0", f"s_cbranch_scc1 Lsh_{sfx}", f"s_cmp_eq_u32 {S_Q}, 1", f"s_cbranch_scc0 Lq2_{sfx}",
-          f"v_mov_b32 v{u[3]}, v{u[2]}", f"v_mov_b32 v{u[2]}, v{u[1]}", f"v_mov_b32 v{u[1]}, v{u[0]}", f"v_mov_b32 v{u[0]}, 0", f"s_branch Lsh_{sfx}",
-          f"Lq2_{sfx}:", f"s_cmp_eq_u32 {S_Q}, 2", f"s_cbranch_scc0 Lq3_{sfx}",
-          f"v_mov_b32 v{u[3]}, v{u[1]}", f"v_mov_b32 v{u[2]}, v{u[0]}", f"v_mov_b32 v{u[1]}, 0", f"v_mov_b32 v{u[0]}, 0", f"s_branch Lsh_{sfx}",
-          f"Lq3_{sfx}:", f"v_mov_b32 v{u[3]}, v{u[0]}", f"v_mov_b32 v{u[2]}, 0", f"v_mov_b32 v{u[1]}, 0", f"v_mov_b32 v{u[0]}, 0", f"Lsh_{sfx}:"]
+    if getattr(K, "chunk_dwords", 4) == 3:
+        # the 6-bit payload: the chunk is a 96-bit value, k positions = 6 k bits (S_Q whole dwords, S_R8 bits: the phase's glue) -- at most 90
+        u = [use + i for i in range(3)]
+        L += [f"s_cmp_eq_u32 {S_R8}, 0", f"s_cbranch_scc1 Lq_{sfx}",
+              f"v_alignbit_b32 v{u[2]}, v{u[2]}, v{u[1]}, {S_SH}", f"v_alignbit_b32 v{u[1]}, v{u[1]}, v{u[0]}, {S_SH}", f"v_lshlrev_b32 v{u[0]}, {S_R8}, v{u[0]}", f"Lq_{sfx}:",
+              f"s_cmp_eq_u32 {S_Q}, 0", f"s_cbranch_scc1 Lsh_{sfx}", f"s_cmp_eq_u32 {S_Q}, 1", f"s_cbranch_scc0 Lq2_{sfx}",
+              f"v_mov_b32 v{u[2]}, v{u[1]}", f"v_mov_b32 v{u[1]}, v{u[0]}", f"v_mov_b32 v{u[0]}, 0", f"s_branch Lsh_{sfx}",
+              f"Lq2_{sfx}:", f"v_mov_b32 v{u[2]}, v{u[0]}", f"v_mov_b32 v{u[1]}, 0", f"v_mov_b32 v{u[0]}, 0", f"Lsh_{sfx}:"]
+    else:
+        u = [use + i for i in range(4)]
+        L += [f"s_cmp_eq_u32 {S_R8}, 0", f"s_cbranch_scc1 Lq_{sfx}",
+              f"v_alignbit_b32 v{u[3]}, v{u[3]}, v{u[2]}, {S_SH}", f"v_alignbit_b32 v{u[2]}, v{u[2]}, v{u[1]}, {S_SH}",
+              f"v_alignbit_b32 v{u[1]}, v{u[1]}, v{u[0]}, {S_SH}", f"v_lshlrev_b32 v{u[0]}, {S_R8}, v{u[0]}", f"Lq_{sfx}:",
+              f"s_cmp_eq_u32 {S_Q}, 0", f"s_cbranch_scc1 Lsh_{sfx}", f"s_cmp_eq_u32 {S_Q}, 1", f"s_cbranch_scc0 Lq2_{sfx}",
+              f"v_mov_b32 v{u[3]}, v{u[2]}", f"v_mov_b32 v{u[2]}, v{u[1]}", f"v_mov_b32 v{u[1]}, v{u[0]}", f"v_mov_b32 v{u[0]}, 0", f"s_branch Lsh_{sfx}",
+              f"Lq2_{sfx}:", f"s_cmp_eq_u32 {S_Q}, 2", f"s_cbranch_scc0 Lq3_{sfx}",
+              f"v_mov_b32 v{u[3]}, v{u[1]}", f"v_mov_b32 v{u[2]}, v{u[0]}", f"v_mov_b32 v{u[1]}, 0", f"v_mov_b32 v{u[0]}, 0", f"s_branch Lsh_{sfx}",
+              f"Lq3_{sfx}:", f"v_mov_b32 v{u[3]}, v{u[0]}", f"v_mov_b32 v{u[2]}, 0", f"v_mov_b32 v{u[1]}, 0", f"v_mov_b32 v{u[0]}, 0", f"Lsh_{sfx}:"]
     dispatch(1, 15, L, sfx)
     for k in range(1, 16):
         L += [f"Ls{k}_{sfx}:", "s_waitcnt lgkmcnt(0)"]
@@ -416,12 +425,14 @@ def step(K, P, extra):
     return L
 
 
-def tile_desc(tile_reg, uniform, fetch):
+def tile_desc(tile_reg, uniform, fetch, six=False):
     """descriptor of tile `tile_reg` into the fetch cursor (fbase, fn) or the process cursor (len2, nch, slot0)"""
     L = []
     if not uniform:
         L += [f"s_lshl_b32 {T1}, {tile_reg}, 4", "s_nop 0", f"s_load_dwordx4 {S_DESC}, {S_TILES}, {T1}", "s_waitcnt lgkmcnt(0)"]
         if fetch:
+            if six:  # the 6-bit payload mirrors the 8-bit one at 3/4 of every offset (tile payloads are whole KiB)
+                L += ["s_lshr_b64 s[60:61], s[60:61], 2", f"s_mul_hi_u32 {T2}, s60, 3", "s_mul_i32 s61, s61, 3", f"s_add_u32 s61, s61, {T2}", "s_mul_i32 s60, s60, 3"]
             L += [f"s_add_u32 {S_FBASE_LO}, s8, s60", f"s_addc_u32 {S_FBASE_HI}, s9, s61", f"s_add_u32 {S_FN}, s62, 15", f"s_lshr_b32 {S_FN}, {S_FN}, 4"]
         else:
             L += [f"s_mov_b32 {S_LEN2}, s62", f"s_mov_b32 {S_SLOT0}, s63", f"s_add_u32 {S_NCH}, s62, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4"]
@@ -460,6 +471,8 @@ def kernel(K, uniform):
         o += size
     L = []
     W = getattr(K, "W", 1)
+    six = getattr(K, "chunk_dwords", 4) == 3  # the 6-bit payload
+    whole = getattr(K, "no_partial", False) and uniform  # whole chunks only (single-length 6-bit payloads: filled up by the packer)
 
     def fetch_glue(tag):  # src = address of the chunk under the fetch cursor; advance the cursor (parks on the last valid chunk)
         G = [f"s_mul_i32 {T0}, {S_FC}, {K.chunk_pitch}" if hasattr(K, "chunk_pitch") else f"s_lshl_b32 {T0}, {S_FC}, 10",
@@ -467,7 +480,7 @@ def kernel(K, uniform):
              f"s_add_u32 {S_FC}, {S_FC}, 1", f"s_cmp_lt_u32 {S_FC}, {S_FN}", f"s_cbranch_scc1 Lfok_{tag}_%=",
              f"s_add_u32 {T0}, {S_FT}, {S_STRIDE}", f"s_cmp_lt_u32 {T0}, {S_TEND}", f"s_cbranch_scc0 Lfpark_{tag}_%=",
              f"s_mov_b32 {S_FT}, {T0}"]
-        G += tile_desc(S_FT, uniform, fetch=True)
+        G += tile_desc(S_FT, uniform, fetch=True, six=six)
         G += [f"s_mov_b32 {S_FC}, 0", f"s_branch Lfok_{tag}_%=", f"Lfpark_{tag}_%=:", f"s_sub_u32 {S_FC}, {S_FN}, 1", f"Lfok_{tag}_%=:"]
         return G
 
@@ -491,7 +504,7 @@ def kernel(K, uniform):
     cursors = [f"s_mov_b32 {S_FT}, {S_T}", f"s_mov_b32 {S_FC}, 0"]
     if uniform:
         cursors += [f"s_mov_b32 {S_LEN2}, {S_ULEN}", f"s_add_u32 {S_NCH}, {S_ULEN}, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4", f"s_mov_b32 {S_FN}, {S_NCH}"]
-    cursors += tile_desc(S_T, uniform, fetch=True)
+    cursors += tile_desc(S_T, uniform, fetch=True, six=six)
     if not uniform:
         cursors += [f"s_mov_b32 {S_LEN2}, s62", f"s_mov_b32 {S_SLOT0}, s63", f"s_mov_b32 {S_NCH}, {S_FN}"]
     prefetch = []  # the first RING-1 chunks of the stream
@@ -515,7 +528,7 @@ def kernel(K, uniform):
             L += ["v_cndmask_b32_e64 v9, v9, 0, vcc"] if K.bits == 64 else []
             L += ["Lnofill_%=:"]
         L += ["ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
-        if getattr(K, "no_partial", False):
+        if whole:
             # f64 results (flags bit 4: normalized_distance / normalized_similarity / fuzz::ratio): on a single-length corpus the value is a function of the u32
             # distance alone, and the HOST tabulates it (StreamAsmArgs::vtab: the reference's own division and cutoff compare, 256 doubles in the kernarg block) --
             # thread i stages entry i behind the pattern table; the epilogue is one ds_read_b64 and an 8-byte store
@@ -547,11 +560,15 @@ def kernel(K, uniform):
         L += fetch_glue(f"ph{P}")
         L += [f"s_lshl_b32 {T0}, {S_C}, 4", f"s_sub_u32 {T0}, {S_LEN2}, {T0}", f"s_mov_b32 {S_K}, 0",  # columns left in this tile
               f"s_cmp_ge_u32 {T0}, 16", f"s_cbranch_scc1 Lkok_{P}_%=",
-              f"s_sub_u32 {S_K}, 16, {T0}", f"s_lshr_b32 {S_Q}, {S_K}, 2", f"s_and_b32 {S_R8}, {S_K}, 3", f"s_lshl_b32 {S_R8}, {S_R8}, 3",
-              f"s_sub_u32 {S_SH}, 32, {S_R8}", f"Lkok_{P}_%=:"]
+              f"s_sub_u32 {S_K}, 16, {T0}"]
+        if six:  # k positions = 6 k bits of the 96-bit chunk
+            L += [f"s_mul_i32 {S_R8}, {S_K}, 6", f"s_lshr_b32 {S_Q}, {S_R8}, 5", f"s_and_b32 {S_R8}, {S_R8}, 31"]
+        else:
+            L += [f"s_lshr_b32 {S_Q}, {S_K}, 2", f"s_and_b32 {S_R8}, {S_K}, 3", f"s_lshl_b32 {S_R8}, {S_R8}, 3"]
+        L += [f"s_sub_u32 {S_SH}, 32, {S_R8}", f"Lkok_{P}_%=:"]
         if W > 1 and BAND:
             L += K.chunk_band()
-        L += step(K, P, extra)
+        L += step(K, P, extra, uniform)
         L += [f"s_add_u32 {S_C}, {S_C}, 1", f"s_cmp_lt_u32 {S_C}, {S_NCH}"]
         if P + 1 < R:
             L += [f"s_cbranch_scc1 Lphase{P + 1}_%=", f"s_mov_b32 {S_NEXT}, {P + 1}", "s_branch Lepi_%="]
@@ -589,7 +606,7 @@ def kernel(K, uniform):
         L += [f"s_waitcnt vmcnt({R - 1})", "Lixd_%=:"]
         # slot store (flags bit 1): index = slot, every lane stores (padding lanes own a slot of the temporary)
         L += [f"s_bitcmp1_b32 {S_FLAGS}, 1", "s_cbranch_scc0 Lnoslot_%=", f"v_add_u32 {V_IDX}, {S_SLOT0}, {V_LANE}", "Lnoslot_%=:"]
-    if getattr(K, "no_partial", False):  # f64 results: the value's double from the staged table (value <= 255: the launcher's condition)
+    if whole:  # f64 results: the value's double from the staged table (value <= 255: the launcher's condition)
         L += [f"s_bitcmp1_b32 {S_FLAGS}, 4", "s_cbranch_scc0 Lu32_%=", "v_lshlrev_b32 v7, 3, v6", "ds_read_b64 v[6:7], v7 offset:2048",
               f"v_cmp_gt_u32 vcc, {S_N}, {V_IDX}", f"v_lshl_add_u64 v[8:9], v[4:5], 3, {S_OUT}", "s_waitcnt lgkmcnt(0)",
               "s_cmp_eq_u64 vcc, -1", "s_cbranch_scc0 Lpart8_%=",
@@ -645,8 +662,6 @@ def main():
                + ', "vcc", "scc", "memory"')  # (queries of 257 .. 512 symbols: 104 VGPRs = 4 wavefronts per SIMD)
     for K in KINDS:
         for uniform in (True, False):
-            if getattr(K, "no_partial", False) and not uniform:
-                continue  # (single-length corpora only)
             out.append(f"// ---- {getattr(K, 'name6', K.name)}, {'single-length corpus (tile t at t * tile_bytes, slot = index)' if uniform else 'tile descriptors + orig[]'}: "
                        f"ring of {K.ring} at v{', v'.join(str(b) for b in K.bufs)}, look-ahead {K.la}")
             out += macro(f"RF_STREAM_{getattr(K, 'name6', K.name).upper()}_{'UNIFORM' if uniform else 'TILES'}_ASM", kernel(K, uniform))
