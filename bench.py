@@ -406,7 +406,7 @@ def main():
     # payload, 0.75 bytes per symbol -- rf_stream_asm.hip stream_lcs6_uniform_kernel.  `roofline` keeps the survey's byte-per-symbol figure (what the
     # north star's 0.60 is about); what is MOVED is reported beside it and is what the traffic counters see)
     pack6 = (args.metric in ("indel", "lcs_seq") and args.mode == "many" and not args.ragged and not early and nq == 1 and args.query_len <= 64
-             and (args.cand_len % 16 == 0 or (args.symbols < 63 and args.query_len <= 32)) and args.symbols < 64 and n >= (1 << 20) and os.environ.get("RF_PACK6", "1") != "0" and not c5 and world == 1)
+             and (args.cand_len % 16 == 0 or args.symbols < 63) and args.symbols < 64 and n >= (1 << 20) and os.environ.get("RF_PACK6", "1") != "0" and not c5 and world == 1)
     # (the same on a length-bucketed corpus: the tiles kernels over the 6-bit image of the payload, 12 bytes per STARTED 16 symbols)
     pack6_ragged = (args.metric in ("indel", "lcs_seq") and args.mode == "many" and args.ragged and not early and nq == 1 and args.query_len <= 64 and args.symbols < 64
                     and n >= (1 << 20) and os.environ.get("RF_PACK6", "1") != "0" and not c5 and world == 1)

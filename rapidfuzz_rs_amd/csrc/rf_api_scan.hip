@@ -972,10 +972,10 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;
     // the HBM-bound scans of a single-length corpus stream the 6-bit payload where there is one (Indel / LCS, one word, no early-out)
     // (where the asm scan over it applies -- rf_scan.hip launch_state; f64 results through a table of the <= 256 values there are: rf_stream_asm.hip stream_asm_f64_table)
-    // (lengths that are not whole chunks run their fill columns too: that pays on 32-bit words -- 57 symbols, query 30: 83.8 -> 100.7 Gpairs/s -- and not on the
-    // issue-bound 64-bit column: 75.7 -> 74.6)
+    // (lengths that are not whole chunks: the 32-bit column runs the packer's fill columns too -- 57 symbols, query 30: 83.8 -> 100.7 Gpairs/s; the issue-bound 64-bit
+    // column shifts the partial chunk into place and runs the real columns only)
     // (bucketed corpora: the tiles kernels over the same payload, u32 results -- the ragged scans read 16-byte chunk rows for every started 16 symbols, and 12 here)
-    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && (corpus->uniform ? (corpus->uniform_len % kChunk == 0 || p.len1 <= 32) : (!f64_out && corpus->d_orig != nullptr)))
+    p.data6 = (raw == RAW_LCS && p.words == 1 && !p.early && (corpus->uniform || (!f64_out && corpus->d_orig != nullptr)))
                   ? corpus_data6(corpus, st)
                   : nullptr;
     if (p.data6) p.max_stored_sym = corpus_max_stored_symbol(corpus, st);  // (< 63: the scans may zero the table row of the fill code)

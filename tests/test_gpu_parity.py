@@ -2516,7 +2516,7 @@ def test_six_bit_payload_scans_equal_the_oracle(len2, qlen):
     their own (stream_lcs6_uniform_kernel: 12 instead of 16 bytes per 16 columns) when the length is a whole number of chunks.
     1 048 640+ candidates (the structure is built from 16384 tiles on): queries beyond 32 symbols on 64-bit words (stream_lcs6_uniform_kernel), shorter
     ones on 32-bit words (stream_lcs6n_uniform_kernel), which also take lengths that are not whole chunks (filled up with the code 63, whose table row
-    the scans zero: an LCS column over it is a no-op); longer queries on partial chunks and the 70-symbol corpus keep the 8-bit scans; the normalized
+    the scans zero: an LCS column over it is a no-op), while the 64-bit scan shifts a partial last chunk into place; the 70-symbol corpus keeps the 8-bit scans; the normalized
     ops and fuzz::ratio take the same asm scans (their f64 value looked up in a host-built table) -- every op, planted near-duplicates, every value against the oracle."""
     import torch
 

@@ -14,7 +14,7 @@ cfg = {
     "lev256": ("levenshtein", 256, 256, {}), "lev128": ("levenshtein", 128, 128, {}), "lev192": ("levenshtein", 192, 192, {}), "indel256": ("indel", 256, 256, {}), "levrag": ("levenshtein", 64, 64, {}), "levragc3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "indelragc12": ("indel", 64, 64, {"score_cutoff": 12}), "indelrag": ("indel", 64, 64, {}), "osarag": ("osa", 64, 64, {}), "lev32rag": ("levenshtein", 32, 64, {}), "indel128": ("indel", 128, 64, {}), "lev64c3": ("levenshtein", 64, 64, {"score_cutoff": 3}), "jw": ("jaro_winkler", 64, 64, {}),
     "jaro": ("jaro", 64, 64, {}), "jwrag": ("jaro_winkler", 64, 64, {}), "jarorag": ("jaro", 64, 64, {}), "jwc9": ("jaro_winkler", 64, 64, {"score_cutoff": 0.9}),
     "jwragc9": ("jaro_winkler", 64, 64, {"score_cutoff": 0.9}), "lev256c8": ("levenshtein", 256, 256, {"score_cutoff": 8}),
-    "indel32": ("indel", 32, 64, {}), "indel32rag": ("indel", 32, 64, {}), "lev320": ("levenshtein", 320, 320, {}), "lev512": ("levenshtein", 512, 512, {}), "lev256c200": ("levenshtein", 256, 256, {"score_cutoff": 200}),
+    "indel57": ("indel", 60, 57, {}), "indel36": ("indel", 36, 36, {}), "indel32": ("indel", 32, 64, {}), "indel32rag": ("indel", 32, 64, {}), "lev320": ("levenshtein", 320, 320, {}), "lev512": ("levenshtein", 512, 512, {}), "lev256c200": ("levenshtein", 256, 256, {"score_cutoff": 200}),
 }
 import re as _re
 _m = _re.fullmatch(r"lev64c(\d+)", what.split("+")[0])

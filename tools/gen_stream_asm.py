@@ -315,11 +315,15 @@ class Lcs6Kind(Kind):
     for the two fields that straddle a dword (profiles/lcs_cycles_r05.txt: 21.0 cycles per column register-only, 25.1 as hipcc writes it).
     Single-length corpora; whole chunks only: a length that is not a multiple of 16 is filled up with the code 63 by the packer (corpora that store at most 63
     symbols), whose table row the prologue zeroes (flags bit 3) -- an LCS column over it is a no-op."""
-    chunk_dwords, no_partial, chunk_pitch = 3, True, 768
+    chunk_dwords, chunk_pitch = 3, 768
 
     def __init__(self, bits, bufs, nop_mask):
         Kind.__init__(self, f"lcs{bits}", bits, 8, bufs, (60, 61)[: bits // 32], nop_mask)
         self.name6 = "lcs6" if bits == 64 else "lcs6n"  # (n = narrow: queries of <= 32 symbols, 32-bit words)
+        # single-length corpora whose length is not a whole number of chunks: the 32-bit column waits for HBM, so it runs the packer's fill columns for free (whole
+        # chunks only, no shifting); the issue-bound 64-bit column shifts the partial chunk into place and runs the real columns only (measured with fill columns:
+        # 75.7 -> 74.6 Gpairs/s at 57 symbols, profiles/lcs_cycles_r05.txt)
+        self.no_partial = bits == 32
 
     def gather(self, j, use, nxt):
         base, jj = (use, j) if j < 16 else (nxt, j - 16)
@@ -472,7 +476,6 @@ def kernel(K, uniform):
     L = []
     W = getattr(K, "W", 1)
     six = getattr(K, "chunk_dwords", 4) == 3  # the 6-bit payload
-    whole = getattr(K, "no_partial", False) and uniform  # whole chunks only (single-length 6-bit payloads: filled up by the packer)
 
     def fetch_glue(tag):  # src = address of the chunk under the fetch cursor; advance the cursor (parks on the last valid chunk)
         G = [f"s_mul_i32 {T0}, {S_FC}, {K.chunk_pitch}" if hasattr(K, "chunk_pitch") else f"s_lshl_b32 {T0}, {S_FC}, 10",
@@ -528,7 +531,7 @@ def kernel(K, uniform):
             L += ["v_cndmask_b32_e64 v9, v9, 0, vcc"] if K.bits == 64 else []
             L += ["Lnofill_%=:"]
         L += ["ds_write_b64 v6, v[8:9]" if K.bits == 64 else "ds_write_b32 v6, v8"]
-        if whole:
+        if six and uniform:
             # f64 results (flags bit 4: normalized_distance / normalized_similarity / fuzz::ratio): on a single-length corpus the value is a function of the u32
             # distance alone, and the HOST tabulates it (StreamAsmArgs::vtab: the reference's own division and cutoff compare, 256 doubles in the kernarg block) --
             # thread i stages entry i behind the pattern table; the epilogue is one ds_read_b64 and an 8-byte store
@@ -606,7 +609,7 @@ def kernel(K, uniform):
         L += [f"s_waitcnt vmcnt({R - 1})", "Lixd_%=:"]
         # slot store (flags bit 1): index = slot, every lane stores (padding lanes own a slot of the temporary)
         L += [f"s_bitcmp1_b32 {S_FLAGS}, 1", "s_cbranch_scc0 Lnoslot_%=", f"v_add_u32 {V_IDX}, {S_SLOT0}, {V_LANE}", "Lnoslot_%=:"]
-    if whole:  # f64 results: the value's double from the staged table (value <= 255: the launcher's condition)
+    if six and uniform:  # f64 results: the value's double from the staged table (value <= 255: the launcher's condition)
         L += [f"s_bitcmp1_b32 {S_FLAGS}, 4", "s_cbranch_scc0 Lu32_%=", "v_lshlrev_b32 v7, 3, v6", "ds_read_b64 v[6:7], v7 offset:2048",
               f"v_cmp_gt_u32 vcc, {S_N}, {V_IDX}", f"v_lshl_add_u64 v[8:9], v[4:5], 3, {S_OUT}", "s_waitcnt lgkmcnt(0)",
               "s_cmp_eq_u64 vcc, -1", "s_cbranch_scc0 Lpart8_%=",
