@@ -2581,7 +2581,7 @@ def test_six_bit_payload_scans_of_a_bucketed_corpus_equal_the_oracle(qlen):
                 row[rng.integers(0, ln, size=r % 5)] = alphabet[7]
                 data[int(offsets[r]):int(offsets[r + 1])] = row
         corpus = rf.Corpus.from_ragged(data, offsets)
-        for metric in ("indel", "lcs_seq"):
+        for metric in ("indel", "lcs_seq", "levenshtein"):  # (Levenshtein: the control -- its scans keep the 8-bit payload)
             bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
             for opname, op in OPS.items():
                 got = bc.many(op, corpus)
