@@ -22,7 +22,7 @@ MATCH="rf::stream_lev64" P ragged_levenshtein "levenshtein:q64:n100000000:l64:cu
 MATCH="rf::window_gather" P ragged_gather "none" --ragged --metric indel
 MATCH="rf::jaro" P ragged_jaro_winkler "jaro_winkler:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric jaro_winkler
 MATCH="rf::head_filter" P ragged_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many:ragged" --ragged --min-len 57 --cutoff 3
-MATCH="rf::stream_kernel_occ8" P ragged_indel "indel:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric indel
+MATCH="rf::stream_lcs6" P ragged_indel "indel:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric indel
 MATCH="rf::stream_levw8" P levenshtein_512 "levenshtein:q512:n2500000:l512:cutNone:many" --query-len 512 --cand-len 512 --candidates 2500000
 MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
