@@ -42,6 +42,8 @@ ADDC = set(filter(None, os.environ.get("RF_GEN_ADDC", "").replace(" ", "").split
 VOP3_32 = os.environ.get("RF_GEN_VOP3_32", "0") == "1"
 VOP3_OSA = os.environ.get("RF_GEN_VOP3_OSA", "0") == "1"
 EARLY_FETCH = os.environ.get("RF_GEN_EARLY_FETCH", "1") == "1"  # 0: the first chunks are requested after the pattern table is staged (rounds 3-4: the A/B)
+DESC_PREFETCH = os.environ.get("RF_GEN_DESC_PREFETCH", "0") == "1"  # (experiment, round 5) tiles kernels: the NEXT tile's descriptor is requested at a tile's start
+S_PDESC = "s[56:59]"
 BAND = os.environ.get("RF_GEN_BAND", "1") == "1"  # 0: the multi-word kernels run every word in every column (round 4's kernels: the A/B)
 # kernarg block (struct StreamAsmArgs in rf_stream_asm.hip; static_asserts there hold the two together)
 ARGS = [("data", 8), ("tiles", 8), ("orig", 8), ("pm", 8), ("sigma", 8), ("out", 8), ("tile_begin", 4), ("tile_end", 4), ("n", 4),
@@ -440,6 +442,8 @@ def tile_desc(tile_reg, uniform, fetch, six=False):
             L += [f"s_add_u32 {S_FBASE_LO}, s8, s60", f"s_addc_u32 {S_FBASE_HI}, s9, s61", f"s_add_u32 {S_FN}, s62, 15", f"s_lshr_b32 {S_FN}, {S_FN}, 4"]
         else:
             L += [f"s_mov_b32 {S_LEN2}, s62", f"s_mov_b32 {S_SLOT0}, s63", f"s_add_u32 {S_NCH}, s62, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4"]
+        if DESC_PREFETCH and not fetch:  # the descriptor came in a tile ago (tile_start): no scalar round trip at the end of a tile
+            L = ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 {S_LEN2}, s58", f"s_mov_b32 {S_SLOT0}, s59", f"s_add_u32 {S_NCH}, s58, 15", f"s_lshr_b32 {S_NCH}, {S_NCH}, 4"]
     elif fetch:  # tile t at t * tile_bytes (64-bit product); chunk count fixed
         L += [f"s_mul_i32 {T1}, {tile_reg}, {S_UBYTES}", f"s_mul_hi_u32 {T2}, {tile_reg}, {S_UBYTES}",
               f"s_add_u32 {S_FBASE_LO}, s8, {T1}", f"s_addc_u32 {S_FBASE_HI}, s9, {T2}"]
@@ -463,6 +467,9 @@ def tile_start(K, uniform, sfx):
             L += [f"v_lshlrev_b32 v6, 2, {V_LANE}", f"global_load_dword {V_IDX}, v6, s[54:55]"]
         else:
             L.append(f"global_load_dword {V_IDX}, {V_OFF4}, s[54:55]")
+    if DESC_PREFETCH and not uniform:  # (the load shares lgkmcnt with the LDS gathers: the columns' counted waits over-wait by one operation until it lands)
+        L += [f"s_add_u32 {T0}, {S_T}, {S_STRIDE}", f"s_sub_u32 {T1}, {S_TEND}, 1", f"s_min_u32 {T0}, {T0}, {T1}", f"s_lshl_b32 {T0}, {T0}, 4",
+              f"s_load_dwordx4 {S_PDESC}, {S_TILES}, {T0}"]
     return L + K.state_init()
 
 
