@@ -34,6 +34,8 @@
  *   RF_ASM_BLOCK                  1         0: compiled multi-word scan instead of the asm multi-word scan (queries of 65..512 symbols)
  *   RF_EARLY_STATIC / RF_EARLY_LEAN / RF_NARROW_LOOK / RF_HEAD_TWO_PASS / RF_HEAD_LOOK_PASS
  *                                 1         0: the older form of the cutoff scans' first look
+ *   RF_LANE_COMPACT               1         0: the second pass of the head-plane cutoff scans walks the surviving TILES (64 lanes each, round 5) instead of the
+ *                                           surviving candidates gathered 64 to a wavefront (rf_sparse.hip; rf_filter_* then always takes its general path)
  *   RF_FIRST_CHECK                0 (auto)  4..16: column of the cutoff scans' first look
  *   RF_HEAD8_MIN                  16384     fewest tiles for which a corpus gets an 8-symbol head plane (0: never)
  *   RF_HEAD6                      1         0: no 6-bit head plane (single-length corpora of < 64 distinct symbols stream 6 instead of 8 bytes
@@ -169,6 +171,14 @@ typedef struct rf_args {
  * src/fuzz.rs:141, which normalises through the inner lcs_seq comparator (LCS/max(len1,len2)). */
 #define RF_FLAG_RATIO_INDEL_NORMALIZATION 0x1u
 
+/* rf_many_u32 / rf_many_f64 on a length-bucketed corpus: write the results in SLOT order -- out[s] belongs to candidate rf_corpus_slot_index()[s], `out` has
+ * rf_corpus_slot_count() entries (>= n; slots without a candidate hold unspecified values) -- instead of original order.  The packed corpus keeps candidates grouped
+ * by length, so original order costs a length-bucketed corpus either scattered stores or a gather pass over every result (a quarter of an HBM-bound scan:
+ * profiles/ragged_indel_r05.txt); a caller that keeps the slot map once (record linkage joins on an id anyway) skips it.  No reference analogue: the reference's
+ * loop has no order but the caller's.  A single-length corpus' slots are its indices (the flag changes nothing); a u32 query with overflow-class symbols and
+ * rf_stream_many_* refuse the flag with RF_ERR_UNSUPPORTED.  Values are those of the default call: tests/test_gpu_parity.py permutes and compares. */
+#define RF_FLAG_SLOT_ORDER 0x2u
+
 void rf_args_default(rf_args *a);
 
 typedef struct rf_comparator rf_comparator; /* = <metric>::BatchComparator<u8> */
@@ -240,6 +250,11 @@ size_t rf_corpus_count(const rf_corpus *c);          /* n */
 uint64_t rf_corpus_payload_bytes(const rf_corpus *c); /* sum of candidate lengths */
 uint64_t rf_corpus_device_bytes(const rf_corpus *c);  /* HBM held by the packed form */
 int rf_corpus_device(const rf_corpus *c);
+/* Slots (RF_FLAG_SLOT_ORDER, and the storage order rf_filter_* may report in): rf_corpus_slot_count = entries of a slot-ordered result vector (n for a
+ * single-length corpus; 64 per tile otherwise); rf_corpus_slot_index writes that many u32 to `out` (host or device memory): the original candidate index of every
+ * slot, 0xFFFFFFFF for a slot that holds no candidate.  Synchronous. */
+size_t rf_corpus_slot_count(const rf_corpus *c);
+rf_status rf_corpus_slot_index(const rf_corpus *c, uint32_t *out, rf_mem out_mem);
 /* Candidates over `char` / u32 elements: elems[offsets[i] .. offsets[i+1]) is candidate i (0xFFFFFFFF is reserved).
  * The corpus stores one byte per element -- the element's id in this corpus' own alphabet (the 254 most frequent
  * symbols; all rarer ones share one overflow id).  Every metric on this path only asks whether a candidate symbol
@@ -306,6 +321,29 @@ rf_status rf_one_u32(const rf_comparator *c, const uint8_t *s2, size_t len2, rf_
                      uint32_t *out, int *is_some);
 rf_status rf_one_f64(const rf_comparator *c, const uint8_t *s2, size_t len2, rf_op op, const rf_args *args, int device,
                      double *out, int *is_some);
+
+/* ---- thresholded one-vs-many: only the candidates within the cutoff ---------------------------------------------
+ * The reference returns Option<T> per candidate (src/common.rs:18-46, :83-85) and the caller of a dedup / record-linkage loop keeps the Somes:
+ *     corpus.iter().enumerate().filter_map(|(i, c)| scorer.<op>_with_args(c, &args).map(|v| (i, v)))
+ * rf_filter_u32 / rf_filter_f64 are that filter_map: the (index, score) pairs of every candidate whose result is not None, instead of an n-entry vector that is
+ * nearly all None (which is 0.4 of the 1.0 GB a cutoff-3 scan of 100 M candidates moves, and all of what crosses PCIe afterwards).  Metrics, ops, Args and values
+ * are exactly those of rf_many_u32 / rf_many_f64; without a cutoff every candidate qualifies.
+ *   index_base   added to every index (shards of one logical corpus)
+ *   capacity     entries `out_index` / `out_score` have room for (either may be NULL when capacity is 0: a pure count)
+ *   *out_count   (host) the number of candidates that passed -- ALWAYS the true number.  If it exceeds `capacity` the arrays hold `capacity` of the qualifying
+ *                pairs (valid, in the requested order among themselves, not necessarily the first ones) and the caller repeats the call with room for
+ *                *out_count: nothing is ever dropped silently.
+ *   order        RF_FILTER_BY_INDEX: ascending index.  RF_FILTER_BY_SCORE: best first (ascending for the distance ops, descending for the similarity ops),
+ *                ties by ascending index.  RF_FILTER_ANY: whatever the scan produces (storage order of the packed corpus: cheapest for length-bucketed corpora).
+ *   out_mem      where out_index / out_score live.  The call synchronizes `stream` either way (the count comes back to the host).
+ * How: cutoff scans that go through the head plane (Levenshtein / OSA, query <= 64, at most ~5 edits allowed, single-length corpora of >= 16384 tiles) hand the
+ * surviving candidates of their first pass straight to a compaction -- no dense vector exists at any point (rf_sparse.hip); every other shape scans into a
+ * device temporary (slot order for length-bucketed corpora: no gather pass) and compacts that (rf_filter.hip: order preserving, no atomics). */
+typedef enum rf_filter_order { RF_FILTER_BY_INDEX = 0, RF_FILTER_BY_SCORE = 1, RF_FILTER_ANY = 2 } rf_filter_order;
+rf_status rf_filter_u32(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint64_t index_base, uint64_t capacity,
+                        uint64_t *out_index, uint32_t *out_score, uint64_t *out_count, rf_mem out_mem, rf_filter_order order, void *stream);
+rf_status rf_filter_f64(const rf_comparator *c, const rf_corpus *corpus, rf_op op, const rf_args *args, uint64_t index_base, uint64_t capacity,
+                        uint64_t *out_index, double *out_score, uint64_t *out_count, rf_mem out_mem, rf_filter_order order, void *stream);
 
 /* ---- many queries x one corpus ------------------------------------------------------------------
  * The reference's user loop one level up: `for q in queries { let scorer = BatchComparator::new(q);

@@ -57,7 +57,12 @@ class Args:
 
     def ratio_indel_normalization(self, on: bool = True) -> "Args":
         """RatioBatchComparator only: the documented Indel ratio instead of the fuzz.rs:141 behaviour."""
-        return self._with(_flags=N.FLAG_RATIO_INDEL_NORMALIZATION if on else 0)
+        return self._with(_flags=(self._flags | N.FLAG_RATIO_INDEL_NORMALIZATION) if on else (self._flags & ~N.FLAG_RATIO_INDEL_NORMALIZATION))
+
+    def slot_order(self, on: bool = True) -> "Args":
+        """`*_many` only: results in the corpus' SLOT order (`corpus.slot_count` entries, `corpus.slot_index()` maps them back) --
+        a length-bucketed corpus then skips its gather pass (RF_FLAG_SLOT_ORDER)."""
+        return self._with(_flags=(self._flags | N.FLAG_SLOT_ORDER) if on else (self._flags & ~N.FLAG_SLOT_ORDER))
 
     def to_c(self, is_float: bool) -> N.RfArgs:
         a = N.RfArgs()
@@ -149,7 +154,7 @@ class BatchComparator:
         a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
         is_f = self.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
         ca = a.to_c(is_f)
-        n = len(corpus)
+        n = corpus.slot_count if (a._flags & N.FLAG_SLOT_ORDER) else len(corpus)
         fn = N.lib().rf_many_f64 if is_f else N.lib().rf_many_u32
         if out is not None and hasattr(out, "is_cuda") and out.is_cuda:
             import torch
@@ -203,6 +208,36 @@ class BatchComparator:
         N.check(fn(self._h, str(path).encode(), op, C.byref(ca), res.ctypes.data, res.size, int(segment_bytes),
                    default_device() if device is None else device))
         return res
+
+    def filter_many(self, op: int, corpus: Corpus, args: Optional[Args] = None, capacity: Optional[int] = None, order: int = N.FILTER_BY_INDEX, index_base: int = 0,
+                    device_out: bool = False, stream=None, *, score_cutoff=None, score_hint=None, weights=None, prefix_weight=None):
+        """The reference user's `corpus.iter().enumerate().filter_map(|(i, c)| scorer.<op>_with_args(c, &args).map(|v| (i, v)))` (rf_filter_u32 / rf_filter_f64):
+        (indices uint64[m], scores[m]) of the candidates whose result is not None, `order` = FILTER_BY_INDEX / FILTER_BY_SCORE / FILTER_ANY.  `capacity` bounds
+        the arrays; None = grow until everything fits (the call reports the true count, so at most one repeat).  With `device_out` the arrays are CUDA tensors."""
+        a = _mk_args(args, score_cutoff, score_hint, weights, prefix_weight)
+        is_f = self.FLOAT or op >= N.OP_NORMALIZED_DISTANCE
+        ca = a.to_c(is_f)
+        fn = N.lib().rf_filter_f64 if is_f else N.lib().rf_filter_u32
+        cap = int(capacity) if capacity is not None else max(1024, len(corpus) // 64)
+        while True:
+            cnt = C.c_uint64()
+            if device_out:
+                import torch
+
+                dev = torch.device("cuda", corpus.device)
+                idx = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+                sc = torch.empty(max(cap, 1), dtype=torch.float64 if is_f else torch.int32, device=dev)
+                st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+                N.check(fn(self._h, corpus._h, op, C.byref(ca), index_base, cap, idx.data_ptr(), sc.data_ptr(), C.byref(cnt), N.MEM_DEVICE, order, st))
+            else:
+                idx = np.empty(max(cap, 1), dtype=np.uint64)
+                sc = np.empty(max(cap, 1), dtype=np.float64 if is_f else np.uint32)
+                N.check(fn(self._h, corpus._h, op, C.byref(ca), index_base, cap, idx.ctypes.data, sc.ctypes.data, C.byref(cnt), N.MEM_HOST, order, stream))
+            if cnt.value <= cap or capacity is not None:
+                m = min(cnt.value, cap)
+                self.last_filter_count = int(cnt.value)  # (the true number of candidates within the cutoff, also when `capacity` was too small)
+                return idx[:m], sc[:m]
+            cap = int(cnt.value)
 
     def distance_many(self, corpus, args=None, **kw):
         return self.many(N.OP_DISTANCE, corpus, args, **kw)

@@ -119,6 +119,17 @@ class Corpus:
         N.check(N.lib().rf_corpus_pack_u32(data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, device, C.byref(h)))
         return cls(h.value, device)
 
+    @property
+    def slot_count(self) -> int:
+        """entries of a slot-ordered result vector (`Args.slot_order()`): len(self) for a single-length corpus, 64 per tile otherwise."""
+        return N.lib().rf_corpus_slot_count(self._h)
+
+    def slot_index(self) -> np.ndarray:
+        """uint32[slot_count]: the original candidate index of every slot, 0xFFFFFFFF where a slot holds no candidate (rf_corpus_slot_index)."""
+        out = np.empty(self.slot_count, dtype=np.uint32)
+        N.check(N.lib().rf_corpus_slot_index(self._h, out.ctypes.data, N.MEM_HOST))
+        return out
+
     def save(self, path: str) -> None:
         """Write the packed form to `path` (rf_corpus_save); `Corpus.load` maps it back without re-packing and
         `BatchComparator.stream_many` scans it segment by segment when it does not fit in HBM."""

@@ -554,6 +554,25 @@ void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->head_k = (uint32_t)K;
 }
 
+static size_t tile_list_words(uint32_t n_tiles) { return (2 * (size_t)n_tiles + 5 * 16384 + 8 + 63) / 64 * 64; }  // (a multiple of 256 bytes: what follows is 8-byte data)
+static size_t lane_buffer_bytes(uint32_t n_tiles)
+{
+    const size_t tiles2 = (size_t)n_tiles + 4;  // (pairs rounded up + the total)
+    return tiles2 * sizeof(uint64_t) + (tiles2 * sizeof(uint32_t) + 255) / 256 * 256 + lane_scan_temp_bytes(n_tiles + 4);
+}
+// the lane-compaction part of a tile-list buffer (corpus_tile_list): ScanParams::lane_mask / lane_prefix / lane_temp
+void corpus_lane_buffers(const rf_corpus* corpus, ScanParams* p)
+{
+    p->lane_mask = nullptr, p->lane_prefix = nullptr, p->lane_temp = nullptr, p->lane_temp_bytes = 0;
+    if (!p->tile_list_buf) return;
+    const size_t tiles2 = (size_t)corpus->n_tiles + 4;
+    uint8_t* base = reinterpret_cast<uint8_t*>(p->tile_list_buf + tile_list_words(corpus->n_tiles));
+    p->lane_mask = reinterpret_cast<uint64_t*>(base);
+    p->lane_prefix = reinterpret_cast<uint32_t*>(base + tiles2 * sizeof(uint64_t));
+    p->lane_temp = base + tiles2 * sizeof(uint64_t) + (tiles2 * sizeof(uint32_t) + 255) / 256 * 256;
+    p->lane_temp_bytes = lane_scan_temp_bytes(corpus->n_tiles + 4);
+}
+
 // this stream's tile list for head_filter_kernel (the caller holds corpus->filter_enqueue_mu); nullptr = none to be had, the
 // scan then filters inside the cutoff kernel
 uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
@@ -576,8 +595,9 @@ uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
         return lru.ptr;
     }
     uint32_t* ptr = nullptr;
-    // (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the packed list)
-    if (hipMalloc((void**)&ptr, (2 * (size_t)corpus->n_tiles + 5 * 16384 + 8) * sizeof(uint32_t)) != hipSuccess) {
+    // (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the packed list;
+    //  behind them what the lane compaction needs, rf_sparse.hip: a 64-bit mask and a running sum per tile + hipcub's scan scratch -- corpus_lane_buffers)
+    if (hipMalloc((void**)&ptr, tile_list_words(corpus->n_tiles) * sizeof(uint32_t) + lane_buffer_bytes(corpus->n_tiles)) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
@@ -659,7 +679,7 @@ static hipError_t launch_scan_runs(RawKind raw, const ScanParams& p, const rf_co
                 q.n_tiles = q.n_exact = b - a;
                 q.tile_begin = 0, q.tile_end = b - a;
                 q.n = (b - a) * (uint32_t)kWave;
-                q.run_orig = corpus->d_orig + (size_t)a * kWave;
+                q.run_orig = (p.slot_store ? p.orig : corpus->d_orig) + (size_t)a * kWave;  // (RF_FLAG_SLOT_ORDER: the slot -> slot map, results stay in slot order)
                 q.prefill_none = 0;
                 q.zero_begin[0] = q.zero_end[0] = q.zero_begin[1] = q.zero_end[1] = 0;
                 plan_band_filter(c, corpus, op, f64_out, &q, L);
@@ -912,11 +932,18 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     if (s != RF_OK) return s;
 
     hipStream_t st = (hipStream_t)stream;
+    // RF_FLAG_SLOT_ORDER (round 6): out[slot] instead of out[original index] -- a length-bucketed corpus then needs neither scattered stores nor the gather pass
+    // (rfgpu.h; rf_corpus_slot_index gives the map).  A single-length corpus' slots ARE its indices: nothing to do.
+    const bool want_slots = (args->flags & RF_FLAG_SLOT_ORDER) != 0 && !corpus->uniform && corpus->d_orig != nullptr;
+    if (want_slots && (corpus != corpus_in || corpus->borrowed || !corpus->n_slots)) {
+        set_error("RF_FLAG_SLOT_ORDER: not available for this corpus / query pair (a u32 query with overflow symbols, or a streamed segment)");
+        return RF_ERR_UNSUPPORTED;
+    }
     // normalized_distance / normalized_similarity of a multi-word Levenshtein scan: the u32 distance scan (the asm kernels with the
     // Ukkonen band: 3.3 instead of 2.5 Gpairs/s at 256 x 256) into a temporary, then ONE pass that runs the very arithmetic of emit_fin (rf_device.hpp) on every
     // distance -- dist / maximum, 1.0 - nd, the cutoff compare -- 12 bytes per candidate against a scan of >= 128 symbols each.  RF_NORM_TWO_STEP=0: the A/B switch.
     static const bool norm_two_step = [] { const char* e = getenv("RF_NORM_TWO_STEP"); return !e || atoi(e) != 0; }();
-    if (norm_two_step && f64_out && raw == RAW_LEV && p.words >= 2 && p.words <= kMaxWords && !p.early && !p.long_words_pad && corpus == corpus_in && !corpus->borrowed &&
+    if (norm_two_step && !want_slots && f64_out && raw == RAW_LEV && p.words >= 2 && p.words <= kMaxWords && !p.early && !p.long_words_pad && corpus == corpus_in && !corpus->borrowed &&
         corpus->n_tiles >= 16 && (uint64_t)p.len1 + corpus->max_len < 0x7FFFFFFFu && (corpus->uniform || (corpus->d_orig && corpus->d_tiles))) {
         // (length-bucketed corpora: the candidates' lengths in original order, 4 bytes each, built once per corpus from the tile descriptors)
         const uint32_t* len_of = nullptr;
@@ -965,7 +992,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     }
     {
         uint32_t k1 = 0, factor = 1;
-        if (corpus == corpus_in && hint_pass_applies(c, corpus, op, args, f64_out, &k1, &factor))
+        if (corpus == corpus_in && !want_slots && hint_pass_applies(c, corpus, op, args, f64_out, &k1, &factor))
             return run_many_hinted(c_in, corpus_in, c, corpus, args, static_cast<uint32_t*>(out), out_mem, st, k1, factor);
     }
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
@@ -983,7 +1010,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     static const bool jaro_priv = [] { const char* e = getenv("RF_JARO_PRIV"); return e && atoi(e) != 0; }();  // (off by default: rf_jaro.hip launch_jaro_word)
     if (jaro_priv && raw == RAW_JARO && corpus->uniform && !p.has_cutoff) p.max_stored_sym = corpus_max_stored_symbol(corpus, st);
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
-    const size_t out_bytes = corpus->n * elem;
+    const size_t out_bytes = (want_slots ? corpus->n_slots : corpus->n) * elem;
     void* d_out = out;
     if (out_mem == RF_MEM_HOST) RF_HIP(scratch_alloc(&d_out, out_bytes, st));  // (kept by the pool: no hipMalloc / hipFree pair -- and no device-wide sync -- per call)
     p.out = d_out;
@@ -1004,7 +1031,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     // (Jaro: when every exact tile takes the single-word kernel -- launch_jaro splits the tiles BY POSITION where the lengths pass
     // 64 symbols, which needs the length order)
     const bool jaro_word_only = raw == RAW_JARO && !p.has_cutoff && p.jaro_split >= corpus->n_exact && !p.jaro_long;
-    const bool by_origin = tile_order && corpus->d_tiles_by_origin && !corpus->borrowed && !p.early && !p.prefill_none && !p.band && !p.long_words_pad &&
+    const bool by_origin = tile_order && !want_slots && corpus->d_tiles_by_origin && !corpus->borrowed && !p.early && !p.prefill_none && !p.band && !p.long_words_pad &&
                            ((valu_bound && !p.out_f64) || jaro_word_only || (tile_order >= 3 && (raw == RAW_LEV || raw == RAW_LCS || raw == RAW_OSA))) &&
                            p.tile_begin == 0 && p.tile_end == corpus->n_tiles;
     if (by_origin) {
@@ -1020,7 +1047,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     // candidate of the WHOLE corpus, so it pays from a window of ~30 % of the tiles on: measured break-even, bench.py --ragged --cutoff)
     const bool wide_window = (uint64_t)(p.tile_end - p.tile_begin) * 10 >= (uint64_t)corpus->n_tiles * 3;
     const bool by_runs = !by_origin && scan_runs_applies(corpus, p, raw);  // small-cutoff scans of a bucketed corpus: one single-length view per length run
-    if (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && wide_window && !by_origin && !by_runs) {
+    if (want_slots || (unscatter_min && corpus->n >= unscatter_min && corpus->d_orig && !corpus->borrowed && corpus->n_slots && wide_window && !by_origin && !by_runs)) {
         {
             std::lock_guard<std::mutex> lock(corpus->scratch_mu);
             if (!corpus->d_slot_ident) {
@@ -1080,7 +1107,19 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                 }
             }
         }
-        if (corpus->d_slot_ident) {
+        if (want_slots) {
+            if (!corpus->d_slot_ident) {
+                if (out_mem == RF_MEM_HOST) scratch_free(d_out, st);
+                set_error("RF_FLAG_SLOT_ORDER: no device memory for the slot map");
+                return RF_ERR_OOM;
+            }
+            // the caller's vector IS the slot-ordered one: n_slots entries, no temporary, no gather
+            p.orig = corpus->d_slot_ident;
+            p.slot_store = 1;
+            p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
+            p.mixed_end = 0;
+            p.n = (uint32_t)corpus->n_slots;
+        } else if (corpus->d_slot_ident) {
         // the temporary: this stream's kept buffer (grown if this call needs f64 where u32 was kept); beyond 4 streams per corpus a
         // stream-ordered allocation for the call
         const size_t tmp_bytes = corpus->n_slots * elem;
@@ -1143,6 +1182,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     if (p.heads8) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
         p.tile_list_buf = corpus_tile_list(corpus, st);
+        corpus_lane_buffers(corpus, &p);
     }
     static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;  // one line per rf_many_* call on stderr: which path the plan took
     if (trace_plan)

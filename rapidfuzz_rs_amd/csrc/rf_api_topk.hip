@@ -154,6 +154,7 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
     if (p.heads8) {
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
         p.tile_list_buf = corpus_tile_list(corpus, st);
+        corpus_lane_buffers(corpus, &p);
     }
     hipError_t e = hipSuccess;
     // Sample pass: the top-k of ~1000 evenly spaced tiles costs 0.1 % of the scan and its k-th best key is a valid

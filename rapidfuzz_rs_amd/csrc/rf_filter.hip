@@ -1,0 +1,210 @@
+// rf_filter.hip -- compact (index, score) results of a thresholded scan (rf_filter_u32 / rf_filter_f64, round 6).
+//
+// reference: every `<op>_with_args` returns Option<T> (src/common.rs:18-46, :83-85) and the caller of a thresholded dedup / record-linkage loop keeps the Somes:
+//   corpus.iter().enumerate().filter_map(|(i, c)| scorer.distance_with_args(c, &args).map(|d| (i, d)))
+// These kernels are that filter_map over a device vector of results (None = 0xFFFFFFFF / NaN), ORDER PRESERVING and without atomics:
+//   count   one wavefront per segment of 1024 entries: how many Somes (coalesced rounds of 64 entries, one ballot each)
+//   sums    hipcub exclusive sum over the segments' counts (the last entry is the total)
+//   emit    the same walk again -- only over segments that hold a Some at all, so a sparse result costs ONE read of the vector -- each Some written at
+//           (its segment's sum + its rank inside the segment) while that is below the caller's capacity
+// An entry's index is its position, or map[position] (slot -> original index of a length-bucketed corpus, survivor number -> candidate of the lane-compacted cutoff
+// scans; 0xFFFFFFFF = no candidate there).  Then, where the caller's order asks for it, hipcub radix sorts over the (few) results, and a last kernel widens the
+// indices to u64 + index_base.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "rf_internal.hpp"
+
+namespace rf {
+
+namespace {
+
+constexpr uint32_t kSegRounds = 16, kSeg = kSegRounds * kWave;  // entries per wavefront segment
+
+__device__ __forceinline__ bool some(uint32_t v) { return v != RF_NONE_U32; }
+__device__ __forceinline__ bool some(double v) { return v == v; }
+
+// entries [0, m): m = min(m_bound, *m_dev) when m_dev is given.  map (nullable): entry -> index, kPad = not a candidate; entries below map_from are known to be
+// candidates (the exact tiles of a bucketed corpus have no padding lane), so the COUNT need not read the map there.
+template <class T>
+__global__ __launch_bounds__(256) void filter_count_kernel(const T* __restrict__ val, const uint32_t* __restrict__ map, uint32_t map_from, uint32_t m_bound,
+                                                           const uint32_t* __restrict__ m_dev, uint32_t n_seg, uint32_t* __restrict__ seg_cnt)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t s = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (s > n_seg) return;
+    const uint32_t m = m_dev ? min(m_bound, *m_dev) : m_bound;
+    uint32_t cnt = 0;
+    if (s < n_seg) {
+        const uint32_t base = s * kSeg;
+#pragma unroll 4
+        for (uint32_t r = 0; r < kSegRounds; ++r) {
+            const uint32_t e = base + r * kWave + lane;
+            bool sel = false;
+            if (e < m) {
+                sel = some(val[e]);
+                if (sel && map && e >= map_from) sel = map[e] != kPad;
+            }
+            cnt += (uint32_t)__popcll(__ballot(sel));
+        }
+    }
+    if (lane == 0) seg_cnt[s] = cnt;  // (seg_cnt[n_seg] = 0: the exclusive sum's last entry is the total)
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void filter_emit_kernel(const T* __restrict__ val, const uint32_t* __restrict__ map, uint32_t m_bound, const uint32_t* __restrict__ m_dev,
+                                                          uint32_t n_seg, const uint32_t* __restrict__ seg_sum, uint32_t capacity, uint32_t* __restrict__ out_idx,
+                                                          T* __restrict__ out_val)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t s = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (s >= n_seg) return;
+    uint32_t at = seg_sum[s];
+    const uint32_t end = seg_sum[s + 1];
+    if (end == at || at >= capacity) return;  // nothing here, or everything here lies beyond the capacity
+    const uint32_t m = m_dev ? min(m_bound, *m_dev) : m_bound;
+    const uint32_t base = s * kSeg;
+    for (uint32_t r = 0; r < kSegRounds && at < end; ++r) {
+        const uint32_t e = base + r * kWave + lane;
+        bool sel = false;
+        T v = T();
+        uint32_t idx = e;
+        if (e < m) {
+            v = val[e];
+            sel = some(v);
+            if (sel && map) {
+                idx = map[e];
+                sel = idx != kPad;
+            }
+        }
+        const uint64_t b = __ballot(sel);
+        const uint32_t pos = at + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (sel && pos < capacity) {
+            out_idx[pos] = idx;
+            out_val[pos] = v;
+        }
+        at += (uint32_t)__popcll(b);
+    }
+}
+
+// order-preserving keys of the scores (smaller = better): u32 -> the score, or its complement for the similarity ops; f64 -> the IEEE bits with the sign handled
+// (rf_topk_entry's map), complemented likewise
+__global__ void filter_keys_u32_kernel(const uint32_t* __restrict__ val, uint32_t n, bool desc, uint32_t* __restrict__ key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = desc ? ~val[i] : val[i];
+}
+__global__ void filter_keys_f64_kernel(const double* __restrict__ val, uint32_t n, bool desc, uint64_t* __restrict__ key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint64_t b = (uint64_t)__double_as_longlong(val[i]);
+        b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        key[i] = desc ? ~b : b;
+    }
+}
+// the caller's arrays: u64 indices (+ index_base) and the scores -- from the values, or (key != nullptr) decoded from their sort keys
+__global__ void filter_finish_u32_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, const uint32_t* __restrict__ key, bool desc, uint32_t n,
+                                         uint64_t index_base, uint64_t* __restrict__ out_index, uint32_t* __restrict__ out_val)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out_index[i] = index_base + idx[i];
+        out_val[i] = key ? (desc ? ~key[i] : key[i]) : val[i];
+    }
+}
+__global__ void filter_finish_f64_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ val, const uint64_t* __restrict__ key, bool desc, uint32_t n,
+                                         uint64_t index_base, uint64_t* __restrict__ out_index, double* __restrict__ out_val)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out_index[i] = index_base + idx[i];
+        if (key) {
+            uint64_t b = desc ? ~key[i] : key[i];
+            b = (b >> 63) ? (b & 0x7FFFFFFFFFFFFFFFull) : ~b;
+            out_val[i] = __longlong_as_double((long long)b);
+        } else {
+            out_val[i] = val[i];
+        }
+    }
+}
+
+}  // namespace
+
+uint32_t filter_segments(uint32_t m_bound) { return (m_bound + kSeg - 1) / kSeg; }
+size_t filter_scan_temp_bytes(uint32_t n_seg)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_seg + 1, nullptr);
+    return std::max<size_t>((bytes + 255) / 256 * 256, 256);
+}
+// seg: n_seg + 1 counts, overwritten by their exclusive sums (seg[n_seg] = the number of Somes)
+hipError_t launch_filter_compact(const void* val, bool f64, const uint32_t* map, uint32_t map_from, uint32_t m_bound, const uint32_t* m_dev, uint32_t* seg, void* temp,
+                                 size_t temp_bytes, uint32_t capacity, uint32_t* out_idx, void* out_val, hipStream_t st)
+{
+    const uint32_t n_seg = filter_segments(m_bound);
+    const dim3 b(256), g((n_seg + 1 + 3) / 4);
+    if (f64)
+        hipLaunchKernelGGL(filter_count_kernel<double>, g, b, 0, st, (const double*)val, map, map_from, m_bound, m_dev, n_seg, seg);
+    else
+        hipLaunchKernelGGL(filter_count_kernel<uint32_t>, g, b, 0, st, (const uint32_t*)val, map, map_from, m_bound, m_dev, n_seg, seg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, seg, seg, (int)n_seg + 1, st);
+    if (e != hipSuccess) return e;
+    if (capacity == 0 || n_seg == 0) return hipSuccess;
+    const dim3 g2((n_seg + 3) / 4);
+    if (f64)
+        hipLaunchKernelGGL(filter_emit_kernel<double>, g2, b, 0, st, (const double*)val, map, m_bound, m_dev, n_seg, seg, capacity, out_idx, (double*)out_val);
+    else
+        hipLaunchKernelGGL(filter_emit_kernel<uint32_t>, g2, b, 0, st, (const uint32_t*)val, map, m_bound, m_dev, n_seg, seg, capacity, out_idx, (uint32_t*)out_val);
+    return hipGetLastError();
+}
+
+// ---- ordering `count` compact results (all arrays on the device; the sorts are hipcub's stable radix sorts)
+size_t filter_sort_temp_bytes(uint32_t count)
+{
+    size_t a = 0, b = 0, c = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)count);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)count);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)count);
+    return std::max<size_t>((std::max(a, std::max(b, c)) + 255) / 256 * 256, 256);
+}
+// ascending index (results of a length-bucketed corpus arrive in slot order)
+hipError_t launch_filter_sort_by_index(const uint32_t* idx_in, const void* val_in, bool f64, uint32_t count, uint32_t* idx_out, void* val_out, void* temp, size_t temp_bytes,
+                                       hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    if (f64) return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, idx_in, idx_out, (const uint64_t*)val_in, (uint64_t*)val_out, (int)count, 0, 32, st);
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, idx_in, idx_out, (const uint32_t*)val_in, (uint32_t*)val_out, (int)count, 0, 32, st);
+}
+// best score first, ties by ascending index: (idx_in, val_in) must be in index order.  key_in / key_out: count u64 each; the scores come back out of key_out
+// (launch_filter_finish decodes them)
+hipError_t launch_filter_sort_by_score(const uint32_t* idx_in, const void* val_in, bool f64, bool desc, uint32_t count, void* key_in, void* key_out, uint32_t* idx_out,
+                                       void* temp, size_t temp_bytes, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    const dim3 b(256), g((count + 255) / 256);
+    if (f64) {
+        hipLaunchKernelGGL(filter_keys_f64_kernel, g, b, 0, st, (const double*)val_in, count, desc, (uint64_t*)key_in);
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint64_t*)key_in, (uint64_t*)key_out, idx_in, idx_out, (int)count, 0, 64, st);
+    }
+    hipLaunchKernelGGL(filter_keys_u32_kernel, g, b, 0, st, (const uint32_t*)val_in, count, desc, (uint32_t*)key_in);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)key_in, (uint32_t*)key_out, idx_in, idx_out, (int)count, 0, 32, st);
+}
+hipError_t launch_filter_finish(const uint32_t* idx, const void* val, const void* key, bool f64, bool desc, uint32_t count, uint64_t index_base, uint64_t* out_index,
+                                void* out_val, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    const dim3 b(256), g((count + 255) / 256);
+    if (f64)
+        hipLaunchKernelGGL(filter_finish_f64_kernel, g, b, 0, st, idx, (const double*)val, (const uint64_t*)key, desc, count, index_base, out_index, (double*)out_val);
+    else
+        hipLaunchKernelGGL(filter_finish_u32_kernel, g, b, 0, st, idx, (const uint32_t*)val, (const uint32_t*)key, desc, count, index_base, out_index, (uint32_t*)out_val);
+    return hipGetLastError();
+}
+
+}  // namespace rf

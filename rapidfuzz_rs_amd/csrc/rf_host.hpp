@@ -252,5 +252,6 @@ RF_LOCAL const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanPa
 RF_LOCAL void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op, bool f64_out, ScanParams* p, uint32_t len2);  // rf_api_scan.hip
 RF_LOCAL void corpus_tile_list_done(const rf_corpus* corpus, hipStream_t st);                                           // rf_api_scan.hip
 RF_LOCAL uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st);                                             // rf_api_scan.hip
+RF_LOCAL void corpus_lane_buffers(const rf_corpus* corpus, ScanParams* p);                                                // rf_api_scan.hip
 RF_LOCAL rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out, rf_mem out_mem, void* stream, bool f64_out);  // rf_api_scan.hip
 }  // extern "C"

@@ -109,6 +109,20 @@ struct ScanParams {
     uint32_t* tile_list_buf;
     const uint32_t* tile_list;
     const uint32_t* tile_list_count;
+    // LANE COMPACTION of the head-plane cutoff scans (round 6, rf_sparse.hip): head_filter_kernel leaves, per tile of its launch, the 64-bit mask of the LANES that
+    // passed its tests (lane_mask, indexed from tile_begin; dead lanes get their None there and then), an exclusive sum numbers the survivors (lane_prefix, one entry
+    // more than tiles: the total), and sparse_lean_kernel scans dense tiles of 64 survivors each, every lane reading its own candidate's chunk rows -- a corpus in
+    // which 2 % of the candidates share the query's head keeps 73 % of its TILES alive and 2 % of its lanes.  nullptr = the tile list above.
+    uint64_t* lane_mask;
+    uint32_t* lane_prefix;
+    void* lane_temp;                // hipcub's scan scratch
+    size_t lane_temp_bytes;
+    // ... and where the survivors' results go when the caller wants no dense vector (rf_filter_*): lane_val[g] (u32 or f64 by out_f64; None = beyond the cutoff) and
+    // lane_idx[g] = candidate index for survivor g < lane_cap; *lane_total = the number of survivors (may exceed lane_cap: the host then takes another road)
+    void* lane_val;
+    uint32_t* lane_idx;
+    uint32_t* lane_total;
+    uint32_t lane_cap;
     uint32_t exp_flags;             // measurement switches (bit 0: RF_EXP_NOHBM on the head-plane scans)
     uint32_t slot_store;            // 1: `orig` is the slot -> slot identity of the gather path (run_many: results into a slot-ordered temporary), so a kernel may
                                     // store lane l of a tile at out[slot0 + l] without reading it -- padding lanes included: the temporary has a slot for them and
@@ -173,6 +187,11 @@ hipError_t launch_hint_gather(const ScanParams& p, const uint32_t* run_first, ui
                               const uint32_t* run_tile_base, const uint64_t* run_data_base, const uint32_t* run_len, uint32_t n_tiles2, uint8_t* data2, TileDesc* tiles2,
                               uint32_t* orig2, hipStream_t st);
 hipError_t launch_band(const ScanParams& p, hipStream_t stream);  // rf_band.hip: exact tiles [tile_begin, tile_end)
+// rf_sparse.hip: the lane compaction of the head-plane cutoff scans (ScanParams::lane_mask)
+size_t lane_scan_temp_bytes(uint32_t tiles);
+hipError_t launch_lane_prefix(const ScanParams& p, uint32_t tiles2, hipStream_t stream);  // lane_prefix[0 .. tiles2] = exclusive sum of popcount(lane_mask[0 .. tiles2))
+hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, uint32_t tiles2, hipStream_t stream);  // state_kind: 0 LevState<1>, 1 Lev32State, 2 OsaState<1>
+bool head_two_pass_applies(RawKind raw, const ScanParams& p);  // rf_scan.hip: will launch_scan take head_filter_kernel + a second pass for this launch?
 hipError_t launch_scan_mixed(RawKind raw, const ScanParams& p, hipStream_t stream);  // p.mixed / tile_begin / tile_end: the mixed section
 hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid);
 hipError_t launch_wf(const ScanParams& p, hipStream_t stream);
@@ -220,6 +239,18 @@ hipError_t launch_core_clock(uint64_t* d_out, uint32_t sleeps, hipStream_t strea
 hipError_t launch_probe(RawKind raw, uint32_t len1, uint32_t mode, int blocks_per_cu, int iters, double* wave_columns_per_ns);  // rf_probe.hip
 hipError_t launch_histogram_rows(const uint8_t* rows, size_t n, uint32_t len, size_t stride, unsigned long long* hist,
                                  hipStream_t stream);
+// rf_filter.hip: order-preserving compaction of a result vector into (index, score) pairs, and their ordering (rf_api_filter.hip)
+uint32_t filter_segments(uint32_t m_bound);
+size_t filter_scan_temp_bytes(uint32_t n_seg);
+hipError_t launch_filter_compact(const void* val, bool f64, const uint32_t* map, uint32_t map_from, uint32_t m_bound, const uint32_t* m_dev, uint32_t* seg, void* temp,
+                                 size_t temp_bytes, uint32_t capacity, uint32_t* out_idx, void* out_val, hipStream_t st);
+size_t filter_sort_temp_bytes(uint32_t count);
+hipError_t launch_filter_sort_by_index(const uint32_t* idx_in, const void* val_in, bool f64, uint32_t count, uint32_t* idx_out, void* val_out, void* temp, size_t temp_bytes,
+                                       hipStream_t st);
+hipError_t launch_filter_sort_by_score(const uint32_t* idx_in, const void* val_in, bool f64, bool desc, uint32_t count, void* key_in, void* key_out, uint32_t* idx_out,
+                                       void* temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_filter_finish(const uint32_t* idx, const void* val, const void* key, bool f64, bool desc, uint32_t count, uint64_t index_base, uint64_t* out_index,
+                                void* out_val, hipStream_t st);
 int scan_grid(uint32_t n_tiles);       // the grid of short-running launches over n_tiles tiles
 int scan_grid_full(uint32_t n_tiles);  // the grid of full (no-cutoff) scans; >= scan_grid
 

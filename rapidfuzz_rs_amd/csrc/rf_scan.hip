@@ -215,7 +215,10 @@ __device__ __forceinline__ uint32_t widen24(uint32_t x)  // four 6-bit symbols o
 {
     return (x & 0x3Fu) | ((x << 2) & 0x3F00u) | ((x << 4) & 0x3F0000u) | ((x << 6) & 0x3F000000u);
 }
-template <class State, int kFirst, bool kPlane6>
+// kLanes (round 6): the pass leaves a LANE mask per tile (ScanParams::lane_mask) instead of a list of tiles, and writes the None of every candidate it decides,
+// whatever the rest of its tile does: what is left for the second pass is the surviving CANDIDATES, gathered 64 to a wavefront (rf_sparse.hip).  A lane survives when
+// its own symbols pass the band test AND its own first look passes -- both are necessary conditions per candidate.
+template <class State, int kFirst, bool kPlane6, bool kLanes = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
 {
     using Look = typename std::conditional<std::is_same<State, LevState<1>>::value, Lev32State,
@@ -275,6 +278,57 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
             const v4u cur = widen(packed);
             const uint32_t t0 = p.tile_begin + 2 * pr;
             uint64_t m = ~0ull;
+            if constexpr (kLanes) {
+                const bool tile_ok = lane < 32 || t0 + 1 < p.tile_end;  // (an odd tile count: the last pair's second half is the plane's pad row)
+                bool pa = tile_ok, pb = tile_ok;  // this lane's two candidates are still in the race
+                if (need) {
+                    pa = tile_ok && band_hits(lds_band, cur.x, cur.y) >= need;
+                    pb = tile_ok && band_hits(lds_band, cur.z, cur.w) >= need;
+                    m = __ballot(pa || pb);
+                }
+                uint64_t mask0 = 0, mask1 = 0;
+                if (m != 0) {
+                    Look a, b;
+                    a.init();
+                    b.init();
+                    process_chunk_full<Look, 0, kFirst, kLookPitch>(a, pm, make_uint4(cur.x, cur.y, 0u, 0u));
+                    process_chunk_full<Look, 0, kFirst, kLookPitch>(b, pm, make_uint4(cur.z, cur.w, 0u, 0u));
+                    const uint32_t ia = t0 * kWave + 2 * lane;  // (lanes 32..63 run on into tile t0 + 1)
+                    pa = pa && ia < p.n && may_pass(p, fin, a.bound_first(len1, kFirst, len2));
+                    pb = pb && ia + 1 < p.n && may_pass(p, fin, b.bound_first(len1, kFirst, len2));
+                    if (__ballot(pa || pb) != 0) {
+                        // bit k of a tile's mask = its candidate k, which sits in lane k / 2 (+ 32 for the pair's second tile), slot k & 1
+                        const int v = (pa ? 1 : 0) | (pb ? 2 : 0);
+                        const int s0 = __shfl(v, (int)(lane >> 1), kWave), s1 = __shfl(v, (int)(32 + (lane >> 1)), kWave);
+                        mask0 = __ballot((s0 >> (lane & 1)) & 1);
+                        mask1 = __ballot((s1 >> (lane & 1)) & 1);
+                    } else {
+                        pa = pb = false;
+                    }
+                } else {
+                    pa = pb = false;
+                }
+                if (lane == 0) {
+                    typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
+                    v2ull mm;
+                    mm.x = mask0, mm.y = mask1;
+                    *reinterpret_cast<v2ull*>(p.lane_mask + 2 * (size_t)pr) = mm;  // (an odd tile count: the second mask of the last pair is 0 -- its lanes lie beyond p.n)
+                }
+                if (p.out && !p.run_orig && tile_ok) {  // (a length run of a bucketed corpus: `out` is pre-filled with None)
+                    const uint32_t idx = t0 * kWave + 2 * lane;
+                    if (!pa && !pb && !p.out_f64 && idx + 1 < p.n) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.out) + idx) = make_uint2(RF_NONE_U32, RF_NONE_U32);
+                    } else {
+                        if (!pa && idx < p.n) emit_none(p, idx);
+                        if (!pb && idx + 1 < p.n) emit_none(p, idx + 1);
+                    }
+                }
+                if (pr_next >= pairs) break;
+                pr = pr_next;
+                packed = ahead;
+                ahead = ahead2;
+                continue;
+            }
             if (need) m = __ballot(band_hits(lds_band, cur.x, cur.y) >= need || band_hits(lds_band, cur.z, cur.w) >= need);
             if (m != 0) {
                 Look a, b;
@@ -311,7 +365,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
             ahead = ahead2;
         }
     }
-    if (lane == 0) buf[1 + gw] = kept;
+    if (!kLanes && lane == 0) buf[1 + gw] = kept;
 }
 
 // packing the segments: ONE launch, a workgroup per 256 segments.  Every workgroup adds up the counts in front of its block itself
@@ -841,6 +895,34 @@ int scan_max_grid_full()
     return device_cus() * per_cu;
 }
 
+// the A/B switches of the cutoff scans (read once per process)
+static bool env_on(const char* name)
+{
+    const char* e = getenv(name);
+    return !e || atoi(e) != 0;
+}
+static bool sw_early_static() { static const bool v = env_on("RF_EARLY_STATIC"); return v; }
+static bool sw_early_lean() { static const bool v = env_on("RF_EARLY_LEAN"); return v; }          // early_lean_kernel
+static bool sw_narrow_look() { static const bool v = env_on("RF_NARROW_LOOK"); return v; }        // the 32-bit first look of early_lean_kernel
+static bool sw_head_two_pass() { static const bool v = env_on("RF_HEAD_TWO_PASS"); return v; }    // head_filter_kernel + a second pass
+static bool sw_head_look_pass() { static const bool v = env_on("RF_HEAD_LOOK_PASS"); return v; }  // ... also where the band filter does not apply
+static bool sw_lane_compact() { static const bool v = env_on("RF_LANE_COMPACT"); return v; }      // the second pass over surviving LANES (rf_sparse.hip) instead of surviving tiles
+
+// Will launch_scan run this launch as head_filter_kernel + a second pass?  (The conditions of RF_EARLY_CASE below, for callers that must know before they
+// launch: rf_filter_* hands the second pass a compact result instead of a dense vector.)
+bool head_two_pass_applies(RawKind raw, const ScanParams& p)
+{
+    if ((raw != RAW_LEV && raw != RAW_OSA) || p.words != 1 || !p.early || p.band || p.long_words_pad || p.tile_step != 1) return false;
+    if (p.mixed && p.mixed_end > p.mixed_begin) return false;
+    if (!sw_early_static() || !sw_early_lean() || p.tiles || p.uniform_len < (uint32_t)kChunk || !p.heads8) return false;
+    if (p.first_check < 4 || p.first_check > 8 || (p.first_check & 1u)) return false;
+    const bool lev32 = raw == RAW_LEV && p.len1 <= 32;
+    const int32_t look_row = (int32_t)p.first_check + (int32_t)p.len1 - (int32_t)p.uniform_len;
+    if (!lev32 && (look_row < 1 || look_row > 32)) return false;
+    if (!(p.head_need ? sw_head_two_pass() : sw_head_look_pass())) return false;
+    return p.tile_list_buf != nullptr && p.tile_end > p.tile_begin;
+}
+
 template <class State>
 static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid)
 {
@@ -908,13 +990,10 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
             // and flags cost the short per-tile loop of a cutoff scan 83 scalar instructions and 34 branches per tile -- with
             // four SIMDs sharing one scalar unit about as much time as its 139 vector instructions (cutoff 3: 217 -> 237
             // Gpairs/s, top-16 237 -> 263).  RF_EARLY_STATIC=0 selects the run-time form for A/B.
-            static const bool early_static = [] { const char* e = getenv("RF_EARLY_STATIC"); return !e || atoi(e) != 0; }();
-            static const bool lean = [] { const char* e = getenv("RF_EARLY_LEAN"); return !e || atoi(e) != 0; }();  // A/B: early_lean_kernel
-            static const bool narrow_look = [] { const char* e = getenv("RF_NARROW_LOOK"); return !e || atoi(e) != 0; }();  // A/B: the 32-bit first look of early_lean_kernel
+            const bool early_static = sw_early_static(), lean = sw_early_lean(), narrow_look = sw_narrow_look();
             ScanParams pn = p;
             pn.narrow_look = narrow_look ? 1u : 0u;
-            static const bool two_pass = [] { const char* e = getenv("RF_HEAD_TWO_PASS"); return !e || atoi(e) != 0; }();  // A/B: head_filter_kernel + list
-            static const bool look_pass = [] { const char* e = getenv("RF_HEAD_LOOK_PASS"); return !e || atoi(e) != 0; }();  // A/B: the first look inside early_head8_kernel where the band filter does not apply
+            const bool two_pass = sw_head_two_pass(), look_pass = sw_head_look_pass();
 #ifdef RF_EXPERIMENTS  // measurement builds only (tools/build_stream_variant.sh): the shipping library has no switch that changes a result
             static const bool exp_nohbm = getenv("RF_EXP_NOHBM") != nullptr;  // every tile reads tile 0's head row (results are wrong on purpose)
             pn.exp_flags = exp_nohbm ? 1u : 0u;
@@ -937,6 +1016,19 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                         const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
                         const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: rf_api_scan.hip sizes the list buffer for that */ \
                         const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
+                        if (pn.lane_mask && pn.lane_prefix && sw_lane_compact()) {         \
+                            /* round 6: the second pass over the surviving LANES, 64 to a wavefront (rf_sparse.hip) */ \
+                            if (pn.heads6 && (p.tile_begin & 1u) == 0)                     \
+                                hipLaunchKernelGGL((head_filter_kernel<State, J, true, true>), dim3(fgrid), b, 0, stream, pn, nullptr, 0u); \
+                            else                                                           \
+                                hipLaunchKernelGGL((head_filter_kernel<State, J, false, true>), dim3(fgrid), b, 0, stream, pn, nullptr, 0u); \
+                            hipError_t el = hipGetLastError();                             \
+                            if (el == hipSuccess) el = launch_lane_prefix(pn, 2 * pairs, stream); \
+                            ScanParams p2 = pn;                                            \
+                            p2.heads8 = nullptr;                                           \
+                            if (el == hipSuccess) el = launch_sparse_lean(std::is_same<State, Lev32State>::value ? 1 : (std::is_same<State, OsaState<1>>::value ? 2 : 0), p2, 2 * pairs, stream); \
+                            return el;                                                     \
+                        }                                                                  \
                         if (pn.heads6 && (p.tile_begin & 1u) == 0)                         \
                             hipLaunchKernelGGL((head_filter_kernel<State, J, true>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap); \
                         else                                                               \

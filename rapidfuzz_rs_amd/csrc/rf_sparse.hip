@@ -1,0 +1,225 @@
+// rf_sparse.hip -- LANE COMPACTION of the head-plane cutoff scans (round 6; VERDICT r5 "make the cutoff path robust to survivors").
+//
+// reference: the cutoff only decides Some / None after the loops (levenshtein.rs:492-496, common.rs:43-45), so anything that proves a candidate beyond the cutoff
+// without changing a value that is within it is allowed.  The head-plane scans (rf_scan.hip head_filter_kernel) prove that for nearly every candidate of a random
+// corpus from its first 8 symbols; until round 5 what they handed on was a list of TILES with at least one lane left, and the second pass (early_lean_kernel) ran
+// such a tile with all 64 lanes.  On corpora whose candidates share prefixes with the query -- URLs, names, SKUs: 2 % of the candidates carrying the query's first
+// 8..12 symbols leave 1 - 0.98^64 = 73 % of the tiles alive -- that second pass read a 1 KiB chunk row and ran >= 16 columns on 64 lanes for one or two live ones.
+//
+// Now the first pass leaves a 64-bit LANE mask per tile (dead lanes get their None there and then), launch_lane_prefix numbers the surviving candidates in index
+// order (hipcub exclusive sum over the masks' popcounts: 8 bytes read per tile), and sparse_lean_kernel walks DENSE tiles: wavefront lane l of dense tile j takes
+// survivor 64 j + l -- a binary search in the sums for its tile, the n-th set bit of that tile's mask for its lane -- and reads its own candidate's chunk rows (one
+// 16-byte load per lane and chunk; neighbouring survivors of one tile share cache lines).  Columns run from 0 on the full-width state with a look at every chunk
+// end (wavefront ballot over the dense tile), chunks one ahead.  Results go where the caller wants them: out[candidate] (dense vector: the first pass has written
+// every other entry), a length run's run_orig[], the in-scan top-k lists, or -- rf_filter_*, no dense vector at all -- lane_val / lane_idx at the survivor's number.
+// Everything is exact for every input: a survivor is merely a candidate the first pass could not rule out.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "rf_device.hpp"
+
+namespace rf {
+
+namespace {
+
+struct PopcOp {
+    __host__ __device__ __forceinline__ uint32_t operator()(const uint64_t& m) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)__popcll(m);
+#else
+        return (uint32_t)__builtin_popcountll(m);
+#endif
+    }
+};
+using PopcIter = hipcub::TransformInputIterator<uint32_t, PopcOp, const uint64_t*>;
+
+// largest i in [0, hi) with a[i] <= x (a ascending, a[0] = 0)
+__device__ __forceinline__ uint32_t last_le(const uint32_t* __restrict__ a, uint32_t hi, uint32_t x)
+{
+    uint32_t lo = 0;
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (a[mid] <= x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+// position of the k-th (0-based) set bit of m (m has more than k set bits)
+__device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t k)
+{
+    uint32_t pos = 0;
+    uint32_t lo = (uint32_t)m, c = (uint32_t)__popc(lo);
+    uint32_t w = lo;
+    if (k >= c) {
+        k -= c;
+        pos = 32;
+        w = (uint32_t)(m >> 32);
+    }
+#pragma unroll
+    for (uint32_t half = 16; half >= 1; half >>= 1) {
+        const uint32_t part = w & ((1u << half) - 1u);
+        c = (uint32_t)__popc(part);
+        if (k >= c) {
+            k -= c;
+            pos += half;
+            w >>= half;
+        } else {
+            w = part;
+        }
+    }
+    return pos;
+}
+
+struct Source {
+    const uint4* src;  // this lane's first chunk
+    uint32_t idx;      // candidate index inside the launch's corpus (view): tile * 64 + lane
+    bool have;         // a survivor sits in this dense lane
+};
+
+template <class State>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(const ScanParams p, uint32_t tiles2)
+{
+    __shared__ typename State::Word lds_pm[256];
+    __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm[p.sigma[i]] = (typename State::Word)p.pm[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const bool topk = p.topk_k != 0;
+    WaveTopK best;
+    best.init();
+    uint64_t limit = ~0ull;
+    uint32_t tiles_done = 0;
+
+    const uint32_t total = uniform(p.lane_prefix[tiles2]);
+    if (p.lane_total && blockIdx.x == 0 && threadIdx.x == 0) *p.lane_total = total;
+    const uint32_t n_dense = (total + kWave - 1) / kWave;
+    const uint32_t len1 = p.len1, len2 = p.uniform_len;
+    const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+    const TileFin fin = tile_fin(p, len1, len2);
+    const uint32_t stride = gridDim.x * kWavesPerBlock;
+    auto locate = [&](uint32_t j) {
+        Source s;
+        const uint32_t g = j * kWave + lane;
+        s.have = g < total;
+        const uint32_t gg = s.have ? g : total - 1;  // (idle lanes of the last dense tile shadow its last survivor: defined bytes, no result)
+        const uint32_t ts = last_le(p.lane_prefix, tiles2, gg);
+        const uint32_t ls = nth_set_bit(p.lane_mask[ts], gg - p.lane_prefix[ts]);
+        const uint32_t t = p.tile_begin + ts;
+        s.idx = t * kWave + ls;
+        s.src = reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes) + ls;
+        return s;
+    };
+    uint32_t j = blockIdx.x * kWavesPerBlock + wave;
+    if (j < n_dense) {
+        Source cur = locate(j);
+        uint4 chunk = load_chunk(cur.src);
+        while (true) {
+            const uint32_t j_next = j + stride;
+            const bool has_next = j_next < n_dense;
+            // the next dense tile's sources and first chunks: requested before this tile's columns run
+            Source nxt = cur;
+            uint4 chunk_next = chunk;
+            if (has_next) {
+                nxt = locate(j_next);
+                chunk_next = load_chunk(nxt.src);
+            }
+            State st;
+            st.init();
+            bool dead = false;
+            for (uint32_t c = 0; c < nch; ++c) {
+                uint4 more = chunk;
+                if (c + 1 < nch) more = load_chunk(cur.src + (size_t)(c + 1) * kWave);  // one chunk ahead
+                const uint32_t cols = len2 - c * kChunk;
+                if (cols >= (uint32_t)kChunk)
+                    process_chunk_full<State>(st, lds_pm, chunk);
+                else
+                    process_chunk_tail<State>(st, lds_pm, chunk, cols);
+                const uint32_t jj = min(len2, (c + 1) * kChunk);
+                if (__ballot(cur.have && may_pass(p, fin, st.bound(len1, jj, len2))) == 0) {
+                    dead = true;  // no lane of this dense tile can pass the cutoff any more
+                    break;
+                }
+                chunk = more;
+            }
+            const uint32_t raw = st.result(len1, len2);
+            // where this lane's result goes
+            uint32_t oi = cur.idx;
+            bool real = cur.have && cur.idx < p.n;
+            if (p.run_orig && cur.have) {  // a length run of a bucketed corpus: the candidate's original index
+                oi = p.run_orig[cur.idx];
+                real = oi != kPad;
+            }
+            if (p.lane_val) {  // rf_filter_*: value (or None) and index at the survivor's own number
+                const uint32_t g = j * kWave + lane;
+                if (cur.have && g < p.lane_cap) {
+                    p.lane_idx[g] = real ? oi : kPad;
+                    if (dead || !real) {
+                        if (!p.out_f64)
+                            reinterpret_cast<uint32_t*>(p.lane_val)[g] = RF_NONE_U32;
+                        else
+                            reinterpret_cast<double*>(p.lane_val)[g] = __longlong_as_double(0x7FF8000000000000ll);
+                    } else {
+                        emit_fin(p, fin, raw, g, p.lane_val);
+                    }
+                }
+            } else if (p.out && real) {
+                if (dead) {
+                    if (!p.run_orig) emit_none(p, oi);  // (a run's vector is pre-filled)
+                } else {
+                    emit_fin(p, fin, raw, oi, p.out);
+                }
+            }
+            if (topk && !dead) {
+                bool keep;
+                const uint32_t v = usize_value(p, raw, len2, &keep, len1);
+                const uint64_t mine = ((uint64_t)(p.topk_desc ? ~v : v) << 32) | (p.key_index_base + oi);
+                if ((tiles_done++ & 7u) == 0) topk_refresh_bound(p, limit);
+                if (best.offer(mine, real && keep, p.topk_k, lane, limit)) topk_list_changed(p, best, lane, limit);
+            }
+            if (!has_next) break;
+            j = j_next;
+            cur = nxt;
+            chunk = chunk_next;
+        }
+    }
+    if (topk) topk_block_publish(p, best, lds_topk, wave, lane, limit);
+}
+
+}  // namespace
+
+size_t lane_scan_temp_bytes(uint32_t tiles)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, PopcIter(nullptr, PopcOp()), (uint32_t*)nullptr, (int)tiles + 3, nullptr);
+    return std::max<size_t>((bytes + 255) / 256 * 256, 256);
+}
+
+hipError_t launch_lane_prefix(const ScanParams& p, uint32_t tiles2, hipStream_t stream)
+{
+    size_t bytes = p.lane_temp_bytes;
+    return hipcub::DeviceScan::ExclusiveSum(p.lane_temp, bytes, PopcIter(p.lane_mask, PopcOp()), p.lane_prefix, (int)tiles2 + 1, stream);
+}
+
+hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, uint32_t tiles2, hipStream_t stream)
+{
+    // (the survivors' number is only known on the device: a fixed grid of 8 workgroups per CU, like early_lean_kernel over its list)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint32_t want = (uint32_t)cus * 8u, most = (tiles2 + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 g(std::max(1u, std::min(want, most))), b(kWave * kWavesPerBlock);
+    switch (state_kind) {
+    case 0: hipLaunchKernelGGL((sparse_lean_kernel<LevState<1>>), g, b, 0, stream, p, tiles2); break;
+    case 1: hipLaunchKernelGGL((sparse_lean_kernel<Lev32State>), g, b, 0, stream, p, tiles2); break;
+    case 2: hipLaunchKernelGGL((sparse_lean_kernel<OsaState<1>>), g, b, 0, stream, p, tiles2); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rf

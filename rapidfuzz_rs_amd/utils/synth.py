@@ -107,3 +107,66 @@ def rows_device_range(start: int, end: int, length: int, seed: int, device=None,
             rows = np.stack([planted_row(q, length, int(i)) for i in idx])
             out[torch.from_numpy(idx - start).to(dev)] = torch.from_numpy(rows).to(dev)
     return out
+
+
+# ---- corpora that are NOT iid-uniform (round 6) --------------------------------------------------------
+# The cutoff scans decide nearly every candidate of a random corpus from its first 8 symbols -- their best case.  Real dedup /
+# record-linkage corpora share prefixes with the query (URLs, names, SKUs), follow a Zipf law over their symbols and a log-normal
+# one over their lengths.  These models vary exactly what the plan layer looks at: head survivors, symbol counts, length histograms.
+def head_share_rows_host(rows: np.ndarray, q: bytes, share: float, seed: int, head_lo: int = 8, head_hi: int = 12) -> np.ndarray:
+    """In place: a fraction `share` of the rows get the query's first H symbols (H uniform in [head_lo, head_hi]), the rest of the
+    row stays random.  Returns the indices of those rows."""
+    rng = np.random.default_rng(seed)
+    n, ln = rows.shape
+    pick = np.nonzero(rng.random(n) < share)[0]
+    qa = np.frombuffer(q, dtype=np.uint8)
+    hi = min(head_hi, ln, len(qa))
+    lo = min(head_lo, hi)
+    h = rng.integers(lo, hi + 1, size=len(pick))
+    cols = np.arange(hi)[None, :] < h[:, None]
+    block = rows[pick, :hi]
+    rows[pick, :hi] = np.where(cols, qa[None, :hi], block)
+    return pick
+
+
+def head_share_rows_device(rows, q: bytes, share: float, seed: int, head_lo: int = 8, head_hi: int = 12, chunk: int = 1 << 24):
+    """The same on a torch uint8 CUDA tensor [n, len], chunk by chunk; returns the number of rows touched."""
+    import torch
+
+    n, ln = rows.shape
+    hi = min(head_hi, ln, len(q))
+    lo = min(head_lo, hi)
+    g = torch.Generator(device=rows.device)
+    g.manual_seed(seed)
+    qa = torch.frombuffer(bytearray(q[:hi]), dtype=torch.uint8).to(rows.device)
+    ar = torch.arange(hi, device=rows.device)
+    touched = 0
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        pick = torch.nonzero(torch.rand(e - s, device=rows.device, generator=g) < share).flatten()
+        if pick.numel() == 0:
+            continue
+        h = torch.randint(lo, hi + 1, (pick.numel(),), device=rows.device, generator=g)
+        cols = ar[None, :] < h[:, None]
+        block = rows[s:e][pick, :hi]
+        rows[s:e][pick, :hi] = torch.where(cols, qa[None, :], block)
+        touched += int(pick.numel())
+    return touched
+
+
+def zipf_alphabet_draw(rng: np.random.Generator, size, symbols: int = 62, s: float = 1.1) -> np.ndarray:
+    """`size` alphanumerics whose ranks follow a Zipf law with exponent `s` (rank r with weight r^-s)."""
+    w = 1.0 / np.arange(1, symbols + 1) ** s
+    return ALNUM[rng.choice(symbols, size=size, p=w / w.sum())]
+
+
+def lognormal_ragged_host(n: int, max_len: int, seed: int, median: float = 24.0, sigma: float = 0.5, min_len: int = 1, zipf_s: float = 0.0):
+    """n candidates with log-normal lengths (median `median`, shape `sigma`, clipped to [min_len, max_len]); symbols uniform or, with
+    zipf_s > 0, Zipf over the alphanumerics -> (data uint8, offsets uint64[n+1])."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.rint(rng.lognormal(np.log(median), sigma, size=n)), min_len, max_len).astype(np.int64)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+    total = int(offsets[-1])
+    data = zipf_alphabet_draw(rng, total, s=zipf_s) if zipf_s > 0 else ALNUM[rng.integers(0, 62, size=total)]
+    return data, offsets

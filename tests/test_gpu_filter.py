@@ -1,0 +1,263 @@
+"""GPU parity tests (`-m gpu`) of round 6: the lane compaction of the head-plane cutoff scans on corpora that share prefixes with the
+query, rf_filter_u32 / rf_filter_f64 (the reference user's filter_map over Option<T>: src/common.rs:18-46, :83-85) and RF_FLAG_SLOT_ORDER.
+The HIP path through the C ABI against the CPU oracle on the same seeded inputs; nothing here reads /root/reference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import rapidfuzz_rs_amd as rf
+from rapidfuzz_rs_amd import _native as N
+from rapidfuzz_rs_amd.utils import synth
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NONE32 = np.uint32(0xFFFFFFFF)
+U64MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+GPU = {"levenshtein": rf.distance.levenshtein, "indel": rf.distance.indel, "lcs_seq": rf.distance.lcs_seq, "jaro": rf.distance.jaro, "jaro_winkler": rf.distance.jaro_winkler, "osa": rf.distance.osa}
+ORA = {"levenshtein": o.levenshtein, "indel": o.indel, "lcs_seq": o.lcs_seq, "jaro": o.jaro, "jaro_winkler": o.jaro_winkler, "osa": o.osa}
+
+
+def _u32(x):
+    return np.where(x == U64MAX, NONE32, x.astype(np.uint32))
+
+
+def _same(got, exp):
+    if got.dtype == np.uint32:
+        return np.nonzero(got != _u32(exp))[0]
+    return np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))[0]
+
+
+def _some(exp):
+    """(indices, values) of the oracle's Somes"""
+    if exp.dtype == np.float64:
+        keep = np.nonzero(~np.isnan(exp))[0]
+        return keep.astype(np.uint64), exp[keep]
+    keep = np.nonzero(exp != U64MAX)[0]
+    return keep.astype(np.uint64), exp[keep].astype(np.uint32)
+
+
+def _prefix_corpus(n, ln, share, seed, qlen=64):
+    """n rows of `ln` alphanumerics; a fraction `share` start with the query's first 8..12 symbols (the rest random); ~400 planted near-duplicates whose edits
+    include insertions and deletions (which shift the tail against the query) -- alone in their tiles or among the prefix sharers"""
+    rng = np.random.default_rng(seed)
+    q = synth.ALNUM[rng.integers(0, 62, size=qlen)]
+    rows = synth.ALNUM[rng.integers(0, 62, size=(n, ln))]
+    synth.head_share_rows_host(rows, q.tobytes(), share, seed + 1)
+    other = np.uint8(126)
+    for j, idx in enumerate(rng.choice(n, size=400, replace=False)):
+        kind = j % 10
+        base = np.resize(q, ln + 4)
+        if kind <= 4:  # substitutions anywhere
+            row = base[:ln].copy()
+            row[rng.choice(ln, size=kind, replace=False)] = other
+        elif kind <= 6:  # d deletions inside the first 12 symbols
+            d = kind - 4
+            keep = np.ones(ln + 4, dtype=bool)
+            keep[rng.choice(12, size=d, replace=False)] = False
+            row = base[keep][:ln]
+        elif kind <= 8:  # d insertions inside the first 12 symbols
+            d = kind - 6
+            row = base.copy()
+            for p in sorted(rng.choice(12, size=d, replace=False)):
+                row = np.concatenate([row[:p], [other], row[p:]])
+            row = row[:ln]
+        else:  # a transposition in the head and one at the end
+            row = base[:ln].copy()
+            row[[2, 3]] = row[[3, 2]]
+            row[[ln - 2, ln - 1]] = row[[ln - 1, ln - 2]]
+        rows[idx] = row
+    return q.tobytes(), rows
+
+
+@pytest.mark.parametrize("share", [0.01, 0.2])
+def test_prefix_sharing_corpora_through_the_lane_compaction(share):
+    """2.1 M candidates (32 k tiles: the head plane, the band prefilter and the lane compaction all apply) of which 1 % / 20 % carry the
+    query's first 8..12 symbols -- at 1 % nearly half of the TILES hold a survivor of the first pass, at 20 % all of them.  Every value of cutoffs 0..6, Levenshtein
+    and OSA, u32 and normalized f64 results, the top-16, query lengths 64 / 60 / 30, against the oracle; then the same values with the second pass over surviving
+    tiles (RF_LANE_COMPACT=0, round 5's path) in a child process."""
+    if os.environ.get("RF_TEST_LANE_CHILD") is None and share == 0.01:
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "test_prefix_sharing_corpora_through_the_lane_compaction"],
+                           capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RF_TEST_LANE_CHILD="1", RF_LANE_COMPACT="0"))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+    n = 2_100_037  # (odd tile count, partial last tile)
+    for qlen, ln in ((64, 64), (60, 64), (30, 32)):
+        q, rows = _prefix_corpus(n, ln, share, seed=int(share * 1000) + qlen, qlen=qlen)
+        corpus = rf.Corpus.from_rows(rows)
+        for metric in ("levenshtein", "osa"):
+            bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+            full = ob.rows(N.OP_DISTANCE, rows, nthreads=8)
+            for cutoff in (0, 1, 2, 3, 4, 5, 6):
+                got = bc.distance_many(corpus, score_cutoff=cutoff)
+                exp = np.where(full <= np.uint64(cutoff), full, U64MAX)
+                bad = _same(got, exp)
+                assert len(bad) == 0, (metric, qlen, cutoff, bad[:5], got[bad[:5]], exp[bad[:5]])
+            for ncut in (0.05, 0.95):
+                op = N.OP_NORMALIZED_DISTANCE if ncut < 0.5 else N.OP_NORMALIZED_SIMILARITY
+                got = bc.many(op, corpus, score_cutoff=ncut)
+                exp = ob.rows(op, rows, nthreads=8, score_cutoff=ncut)
+                bad = _same(got, exp)
+                assert len(bad) == 0, (metric, qlen, ncut, bad[:5], got[bad[:5]], exp[bad[:5]])
+            order = np.lexsort((np.arange(n), full))
+            for cutoff in (3, 5):
+                s, i = bc.topk(corpus, 16, score_cutoff=cutoff)
+                want = [(int(full[j]), int(j)) for j in order[:16] if full[j] <= cutoff]
+                assert list(zip(s.tolist(), i.tolist())) == want, (metric, qlen, cutoff)
+        del corpus
+
+
+def _filter_check(bc, ob, op, corpus, exp, **kw):
+    """rf_filter_* in its three orders, host and device outputs, against the oracle's Somes"""
+    idx_e, val_e = _some(exp)
+    desc = op in (N.OP_SIMILARITY, N.OP_NORMALIZED_SIMILARITY)
+    for order in (N.FILTER_BY_INDEX, N.FILTER_BY_SCORE, N.FILTER_ANY):
+        idx, val = bc.filter_many(op, corpus, order=order, **kw)
+        assert bc.last_filter_count == len(idx_e), (order, bc.last_filter_count, len(idx_e))
+        if order == N.FILTER_BY_INDEX:
+            assert np.array_equal(idx, idx_e) and np.array_equal(val, val_e), (order, idx[:5], idx_e[:5])
+        else:
+            perm = np.argsort(idx, kind="stable")
+            assert np.array_equal(idx[perm], idx_e) and np.array_equal(val[perm], val_e), order
+            if order == N.FILTER_BY_SCORE:
+                key = -val_e.astype(np.float64) if desc else val_e.astype(np.float64)
+                want = np.lexsort((idx_e, key))
+                assert np.array_equal(idx, idx_e[want]) and np.array_equal(val, val_e[want])
+    # a capacity that is too small: the true count comes back, the entries delivered are valid pairs in order
+    if len(idx_e) > 3:
+        cap = len(idx_e) // 2
+        idx, val = bc.filter_many(op, corpus, capacity=cap, **kw)
+        assert bc.last_filter_count == len(idx_e) and len(idx) == cap
+        pos = np.searchsorted(idx_e, idx)
+        assert np.all(idx_e[pos] == idx) and np.array_equal(val_e[pos], val) and np.all(np.diff(idx.astype(np.int64)) > 0)
+    # device outputs, index_base
+    import torch
+
+    idx, val = bc.filter_many(op, corpus, device_out=True, index_base=1 << 33, **kw)
+    torch.cuda.synchronize()
+    idx = idx.cpu().numpy().astype(np.uint64)
+    val = val.cpu().numpy()
+    val = val.view(np.uint32) if val.dtype == np.int32 else val
+    assert np.array_equal(idx, idx_e + np.uint64(1 << 33)) and np.array_equal(val, val_e)
+    # a pure count
+    idx, _ = bc.filter_many(op, corpus, capacity=0, **kw)
+    assert len(idx) == 0 and bc.last_filter_count == len(idx_e)
+
+
+def test_filter_c1_shape_every_metric():
+    """BASELINE configs[0]'s shape (query 32 x 10 k ragged candidates of <= 64 symbols): the compact pairs equal np.nonzero(oracle != None) for every usize metric x
+    cutoffs, normalized ops, Jaro-Winkler >= 0.7 and fuzz::ratio."""
+    q = synth.query(32, 5)
+    data, offsets = synth.ragged_host(10_000, 64, seed=6)
+    rng = np.random.default_rng(7)
+    for r in rng.choice(10_000, size=60, replace=False):  # near-duplicates cut to the candidate's length
+        a, b = int(offsets[r]), int(offsets[r + 1])
+        row = np.resize(np.frombuffer(q, dtype=np.uint8), b - a).copy()
+        if len(row) > 2:
+            row[rng.integers(0, len(row), size=int(rng.integers(0, 4)))] = 122
+        data[a:b] = row
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    for metric in ("levenshtein", "osa", "indel", "lcs_seq"):
+        bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+        for cutoff in (0, 3, 12, 40, None):
+            kw = {} if cutoff is None else {"score_cutoff": cutoff}
+            _filter_check(bc, ob, N.OP_DISTANCE, corpus, ob.many(N.OP_DISTANCE, data, offsets, nthreads=8, **kw), **kw)
+        if metric != "levenshtein":  # (Q2: the reference's Levenshtein similarity above its cutoff is a wrapped value)
+            _filter_check(bc, ob, N.OP_SIMILARITY, corpus, ob.many(N.OP_SIMILARITY, data, offsets, nthreads=8, score_cutoff=20), score_cutoff=20)
+        _filter_check(bc, ob, N.OP_NORMALIZED_SIMILARITY, corpus, ob.many(N.OP_NORMALIZED_SIMILARITY, data, offsets, nthreads=8, score_cutoff=0.6), score_cutoff=0.6)
+    for metric in ("jaro", "jaro_winkler"):
+        bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+        _filter_check(bc, ob, N.OP_SIMILARITY, corpus, ob.many(N.OP_SIMILARITY, data, offsets, nthreads=8, score_cutoff=0.7), score_cutoff=0.7)
+        _filter_check(bc, ob, N.OP_DISTANCE, corpus, ob.many(N.OP_DISTANCE, data, offsets, nthreads=8, score_cutoff=0.3), score_cutoff=0.3)
+    bc, ob = rf.fuzz.RatioBatchComparator(q), o.fuzz.RatioBatchComparator(q)
+    _filter_check(bc, ob, N.OP_SIMILARITY, corpus, ob.many(N.OP_NORMALIZED_SIMILARITY, data, offsets, nthreads=8, score_cutoff=0.5), score_cutoff=0.5)
+    # an empty corpus, and a cutoff nothing passes
+    empty = rf.Corpus.from_list([])
+    idx, val = GPU["levenshtein"].BatchComparator(q).filter_many(N.OP_DISTANCE, empty, score_cutoff=3)
+    assert len(idx) == 0
+    idx, val = GPU["jaro"].BatchComparator(q).filter_many(N.OP_SIMILARITY, corpus, score_cutoff=1.5)
+    assert len(idx) == 0
+
+
+@pytest.mark.parametrize("share", [0.0, 0.05])
+def test_filter_large_single_length_corpus_takes_the_lane_compaction(share):
+    """2.1 M x 64 (the head-plane path): rf_filter under cutoffs 0..5 never builds the dense vector (rf_sparse.hip leaves the survivors' values at their numbers);
+    cutoffs beyond the head plane's reach, Indel, normalized ops and Jaro-Winkler >= 0.9 take the general road.  With 5 % prefix sharers the survivors of the
+    first pass outnumber the matches 250 : 1."""
+    n = 2_100_037
+    q, rows = _prefix_corpus(n, 64, share, seed=91)
+    corpus = rf.Corpus.from_rows(rows)
+    for metric in ("levenshtein", "osa"):
+        bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+        full = ob.rows(N.OP_DISTANCE, rows, nthreads=8)
+        for cutoff in (0, 2, 3, 5, 9, 30):
+            _filter_check(bc, ob, N.OP_DISTANCE, corpus, np.where(full <= np.uint64(cutoff), full, U64MAX), score_cutoff=cutoff)
+        _filter_check(bc, ob, N.OP_NORMALIZED_SIMILARITY, corpus, ob.rows(N.OP_NORMALIZED_SIMILARITY, rows, nthreads=8, score_cutoff=0.95), score_cutoff=0.95)
+    bc, ob = GPU["indel"].BatchComparator(q), ORA["indel"].BatchComparator(q)
+    _filter_check(bc, ob, N.OP_DISTANCE, corpus, ob.rows(N.OP_DISTANCE, rows, nthreads=8, score_cutoff=12), score_cutoff=12)
+    bc, ob = GPU["jaro_winkler"].BatchComparator(q), ORA["jaro_winkler"].BatchComparator(q)
+    _filter_check(bc, ob, N.OP_SIMILARITY, corpus, ob.rows(N.OP_SIMILARITY, rows, nthreads=8, score_cutoff=0.9), score_cutoff=0.9)
+    bc, ob = rf.fuzz.RatioBatchComparator(q), o.fuzz.RatioBatchComparator(q)
+    _filter_check(bc, ob, N.OP_SIMILARITY, corpus, ob.rows(N.OP_NORMALIZED_SIMILARITY, rows, nthreads=8, score_cutoff=0.9), score_cutoff=0.9)
+
+
+def test_filter_when_the_survivors_outgrow_their_room():
+    """Every candidate carries the query's head (share 1.0): the first pass keeps all 2.1 M lanes, more than the room the fast road gives its survivors
+    (max(n / 8, 4 x capacity)) -- the call must notice on the device-side count and take the general road: same pairs."""
+    n = 1_100_000
+    q, rows = _prefix_corpus(n, 64, 1.0, seed=17)
+    corpus = rf.Corpus.from_rows(rows)
+    bc, ob = GPU["levenshtein"].BatchComparator(q), ORA["levenshtein"].BatchComparator(q)
+    full = ob.rows(N.OP_DISTANCE, rows, nthreads=8)
+    exp = np.where(full <= np.uint64(3), full, U64MAX)
+    idx_e, val_e = _some(exp)
+    idx, val = bc.filter_many(N.OP_DISTANCE, corpus, score_cutoff=3, capacity=4096)
+    assert bc.last_filter_count == len(idx_e) and np.array_equal(idx, idx_e) and np.array_equal(val, val_e)
+    got = bc.distance_many(corpus, score_cutoff=3)
+    assert len(_same(got, exp)) == 0
+
+
+def test_filter_and_slot_order_on_a_length_bucketed_corpus():
+    """1.35 M candidates of lengths 1..70, log-normal (median 24) with Zipf symbols: (a) RF_FLAG_SLOT_ORDER -- results in slot order equal the default call's after
+    the caller's own permutation through rf_corpus_slot_index, for full scans (asm tiles kernels, the gather path's kernels), cutoff scans (length-run views) and
+    f64 metrics; (b) rf_filter_* over the slot-ordered temporary, every order."""
+    n = 1_350_000
+    data, offsets = synth.lognormal_ragged_host(n, 70, seed=3, median=24.0, sigma=0.5, zipf_s=1.1)
+    q = bytes(data[int(offsets[11]): int(offsets[11]) + 40]) + b"Zq"
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    slot_index = corpus.slot_index()
+    assert len(slot_index) == corpus.slot_count >= n
+    real = slot_index != NONE32
+    assert real.sum() == n and np.array_equal(np.sort(slot_index[real]), np.arange(n, dtype=np.uint32))
+    cases = [("levenshtein", N.OP_DISTANCE, {}), ("levenshtein", N.OP_DISTANCE, {"score_cutoff": 3}), ("levenshtein", N.OP_DISTANCE, {"score_cutoff": 20}),
+             ("osa", N.OP_DISTANCE, {}), ("indel", N.OP_DISTANCE, {}), ("indel", N.OP_NORMALIZED_SIMILARITY, {}), ("lcs_seq", N.OP_SIMILARITY, {"score_cutoff": 10}),
+             ("jaro_winkler", N.OP_SIMILARITY, {}), ("jaro", N.OP_SIMILARITY, {"score_cutoff": 0.8}), ("levenshtein", N.OP_NORMALIZED_DISTANCE, {"score_cutoff": 0.3})]
+    for metric, op, kw in cases:
+        bc, ob = GPU[metric].BatchComparator(q), ORA[metric].BatchComparator(q)
+        exp = ob.many(op, data, offsets, nthreads=8, **kw)
+        got = bc.many(op, corpus, **kw)
+        assert len(_same(got, exp)) == 0, (metric, op, kw)
+        slots = bc.many(op, corpus, rf.distance.levenshtein.Args().slot_order(), **kw)
+        assert len(slots) == corpus.slot_count
+        back = np.empty_like(got)
+        back[slot_index[real]] = slots[real]
+        assert len(_same(back, exp)) == 0, ("slot order", metric, op, kw)
+        if kw:
+            _filter_check(bc, ob, op, corpus, exp, **kw)
+    # the query > 64 symbols (multi-word scans) in slot order
+    q2 = (q * 3)[:100]
+    bc, ob = GPU["levenshtein"].BatchComparator(q2), ORA["levenshtein"].BatchComparator(q2)
+    exp = ob.many(N.OP_DISTANCE, data, offsets, nthreads=8)
+    slots = bc.many(N.OP_DISTANCE, corpus, rf.distance.levenshtein.Args().slot_order())
+    back = np.empty(n, dtype=np.uint32)
+    back[slot_index[real]] = slots[real]
+    assert len(_same(back, exp)) == 0
+    # a single-length corpus: slots are indices
+    rows = synth.rows_host(5000, 24, seed=4)
+    c2 = rf.Corpus.from_rows(rows)
+    assert c2.slot_count == 5000 and np.array_equal(c2.slot_index(), np.arange(5000, dtype=np.uint32))
+    a = GPU["indel"].BatchComparator(q).many(N.OP_DISTANCE, c2, rf.distance.indel.Args().slot_order())
+    assert np.array_equal(a, GPU["indel"].BatchComparator(q).many(N.OP_DISTANCE, c2))
