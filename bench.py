@@ -44,8 +44,15 @@ def parse():
     ap.add_argument("--near-dup-share", type=float, default=0.0,
                     help="this share of the candidates is the query with 0..8 random substitutions (the corpus a score_hint is for); the rest stays random")
     ap.add_argument("--topk", type=int, default=16)
-    ap.add_argument("--mode", default="many", choices=["many", "topk"],
-                    help="many: one score per candidate (configs[1]); topk: top-k only, no per-candidate output (configs[4])")
+    ap.add_argument("--head-share", type=float, default=0.0,
+                    help="fraction of the candidates that start with the query's first 8..12 symbols, the rest of the row random (shared prefixes: URLs, names, SKUs -- "
+                         "what survives the cutoff scans' first pass without being a match)")
+    ap.add_argument("--zipf", type=float, default=0.0, help="> 0: symbol ranks follow a Zipf law with this exponent instead of the uniform distribution")
+    ap.add_argument("--lognormal-median", type=float, default=0.0, help="--ragged: > 0: log-normal candidate lengths with this median (sigma 0.5), clipped to [--min-len, --cand-len]")
+    ap.add_argument("--capacity", type=int, default=1 << 20, help="--mode filter: room for (index, score) pairs")
+    ap.add_argument("--mode", default="many", choices=["many", "topk", "filter"],
+                    help="many: one score per candidate (configs[1]); topk: top-k only, no per-candidate output (configs[4]); filter: the (index, score) pairs of "
+                         "the candidates within the cutoff, rf_filter_* (the reference user's filter_map over Option<T>)")
     ap.add_argument("--plant-every", type=int, default=1_000_000, help="near-duplicates of the query planted 1-in-N (cutoff/top-k runs)")
     ap.add_argument("--weights", default=None, help="levenshtein WeightTable as ins,del,sub (e.g. 1,2,3: the generalized Wagner-Fischer kernel)")
     ap.add_argument("--symbols", type=int, default=62, help="alphabet size of the synthetic corpus (experiment knob, default alphanumeric)")
@@ -157,11 +164,14 @@ def main():
     t0 = time.time()
     index_base = rank * n
     if c5:  # this rank's slice of the ONE logical corpus (the same rows whatever the world size)
-        rows = synth.rows_device_range(shard_lo, shard_hi, ln, seed=0xC0FFEE05, device=dev, symbols=args.symbols, q=q, plant_every=args.plant_every)
+        rows = synth.rows_device_range(shard_lo, shard_hi, ln, seed=0xC0FFEE05, device=dev, symbols=args.symbols, q=q, plant_every=args.plant_every,
+                                       head_share=args.head_share)
         index_base = shard_lo
     else:
-        rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev, symbols=args.symbols)
-    if not c5 and (args.cutoff is not None or args.mode == "topk"):
+        rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev, symbols=args.symbols, zipf_s=args.zipf)
+        if args.head_share > 0:
+            synth.head_share_rows_device(rows, q, args.head_share, seed=0x5EED + rank)
+    if not c5 and (args.cutoff is not None or args.mode in ("topk", "filter")):
         # 1 in 10^6 candidates is the query with 0..5 random substitutions
         gen = torch.Generator(device=dev)
         gen.manual_seed(99 + rank)
@@ -203,7 +213,10 @@ def main():
             raise SystemExit("bench.py: --ragged is a single-GPU 'many' workload")
         gen = torch.Generator(device=dev)
         gen.manual_seed(0xC0FFEE07)
-        lens = torch.randint(args.min_len, ln + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
+        if args.lognormal_median > 0:
+            lens = torch.empty(n, device=dev, dtype=torch.float32).log_normal_(float(np.log(args.lognormal_median)), 0.5, generator=gen).round_().clamp_(args.min_len, ln).to(torch.int64)
+        else:
+            lens = torch.randint(args.min_len, ln + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
         offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         offsets[1:] = torch.cumsum(lens, 0)
         flat = torch.empty(int(offsets[-1].item()), dtype=torch.uint8, device=dev)
@@ -259,8 +272,22 @@ def main():
 
     last_topk = [None]
 
+    filt = None
+    if args.mode == "filter":
+        if world > 1 or force_dist or nq > 1:
+            raise SystemExit("bench.py: --mode filter is a single-GPU, single-query workload")
+        import ctypes
+
+        filt = {"idx": torch.empty(max(args.capacity, 1), dtype=torch.int64, device=dev),
+                "val": torch.empty(max(args.capacity, 1), dtype=torch.float64 if is_f64 else torch.int32, device=dev), "count": ctypes.c_uint64(0),
+                "fn": N.lib().rf_filter_f64 if is_f64 else N.lib().rf_filter_u32, "args": call_args.to_c(is_f64)}
+
     def step():
-        if nq > 1:
+        if filt is not None:
+            # (synchronizes: the count comes back to the host -- part of what the call is, and inside the timed region)
+            N.check(filt["fn"](scorer._h, corpus._h, N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE, ctypes.byref(filt["args"]), 0, args.capacity, filt["idx"].data_ptr(),
+                               filt["val"].data_ptr(), ctypes.byref(filt["count"]), N.MEM_DEVICE, N.FILTER_BY_INDEX, stream.cuda_stream))
+        elif nq > 1:
             mod.BatchComparator.many_multi(scorers, N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE, corpus, call_args, out=out, stream=stream.cuda_stream)
         elif is_f64:  # BASELINE.json configs[3]: similarity, f64 per candidate
             scorer.similarity_many(corpus, call_args, out=out, stream=stream.cuda_stream)
@@ -422,15 +449,20 @@ def main():
     what = f"{args.metric}::BatchComparator, 1 query len-{args.query_len} x "
     if c5:
         what += (f"{args.total_candidates} random alphanumeric len-{ln} candidates in ONE logical corpus split over {world} GPU(s), score_cutoff=3, "
-                 f"top-{args.topk} + all-gather + merge every step" + (", BASELINE.json configs[4]" if args.total_candidates == 1_000_000_000 else ""))
+                 f"top-{args.topk} + all-gather + merge every step" + (f", {args.head_share:.2%} of them starting with the query's first 8..12 symbols" if args.head_share > 0 else "")
+                 + (", BASELINE.json configs[4]" if args.total_candidates == 1_000_000_000 and args.head_share == 0 else ""))
     else:
         what += ((f"{n} random alphanumeric candidates with lengths uniform in [{args.min_len}, {args.cand_len}] (mean {mean_len:.2f}) per GPU, " if args.ragged
                   else f"{n} random alphanumeric len-{ln} candidates per GPU, ") + ("no cutoff" if args.cutoff is None else f"score_cutoff={args.cutoff}")
                  + (f", weights={weights}" if weights else "")
                  + (f", {args.near_dup_share:.0%} of them the query with 0..8 substitutions" if args.near_dup_share > 0 else "")
+                 + (f", {args.head_share:.2%} of them starting with the query's first 8..12 symbols" if args.head_share > 0 else "")
+                 + (f", Zipf({args.zipf}) symbols" if args.zipf > 0 else "")
+                 + (f", log-normal lengths (median {args.lognormal_median})" if args.ragged and args.lognormal_median > 0 else "")
                  + (f", score_hint={args.hint}" if args.hint is not None else "")
                  + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64
-                                                     and args.cutoff is None and not weights and not args.ragged and args.near_dup_share == 0 and args.hint is None) else ""))
+                                                     and args.cutoff is None and not weights and not args.ragged and args.near_dup_share == 0 and args.hint is None
+                                                     and args.head_share == 0 and args.zipf == 0 and args.mode == "many") else ""))
     result = {
         "metric": "Gpairs/s (1 query x N candidates, Levenshtein BatchComparator semantics)" if args.metric == "levenshtein" else f"Gpairs/s ({args.metric})",
         "value": round(gpairs, 3),
@@ -450,7 +482,8 @@ def main():
             "candidate_len": args.cand_len if not args.ragged else f"uniform in [{args.min_len}, {args.cand_len}], mean {mean_len:.3f}",
             "query_len": args.query_len,
             "queries": nq,
-            "output": ("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else f"top-{args.topk} only",
+            "output": (("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else
+                       (f"(index, score) pairs of the candidates within the cutoff, device-resident, room for {args.capacity}" if args.mode == "filter" else f"top-{args.topk} only")),
             "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if (world > 1 or force_dist) else "1 GPU",
             "ranks_joined": joined,
             **({"rccl_ranks": dist.get_world_size(), "collective": "ncclAllGather via torch.distributed (backend nccl = RCCL)"}
@@ -594,6 +627,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, q, host_sample)
     if ragged_sample is not None:
         result["cpu_baseline"] = cpu_baseline(args, q, None, ragged=ragged_sample)
+    if ragged_sample is not None and args.mode == "many":
         from oracle import oracle as o
 
         torch.cuda.synchronize()
@@ -611,6 +645,43 @@ def main():
             mism += int(bad.sum())
             checked += m
         result["parity"] = {"checked": checked, "mismatches": mism, "what": f"first candidates + every 1009-th of all {n}, vs oracle/"}
+    if filt is not None:
+        result["config"]["filter_count"] = int(filt["count"].value)
+        if host_sample is not None or ragged_sample is not None:
+            # parity of the compact pairs, in the same run: the pairs whose index lies in the first 2 M candidates must be exactly the oracle's Somes there,
+            # and every 1009-th candidate of the whole corpus must be in the list if and only if the oracle gives it a value (with that value)
+            from oracle import oracle as o
+
+            torch.cuda.synchronize()
+            m = int(min(filt["count"].value, args.capacity))
+            gi = filt["idx"][:m].cpu().numpy().astype(np.int64)
+            gv = filt["val"][:m].cpu().numpy()
+            gv = gv.view(np.uint32) if not is_f64 else gv
+            op = N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE
+            ob = getattr(o, args.metric).BatchComparator(q)
+            mism, checked = 0, 0
+            ordered = bool(np.all(np.diff(gi) > 0)) if m > 1 else True
+            if host_sample is not None:
+                chk = min(len(host_sample), 2_000_000)
+                legs = [(ob.rows(op, host_sample[:chk], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff), np.arange(chk)),
+                        (ob.rows(op, host_strided, nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff), np.arange(0, n, 1009))]
+            else:
+                chk = min(len(ragged_sample[1]) - 1, 2_000_000)
+                legs = [(ob.many(op, ragged_sample[0][: int(ragged_sample[1][chk])], ragged_sample[1][: chk + 1], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff), np.arange(chk)),
+                        (ob.many(op, ragged_strided[0], ragged_strided[1], nthreads=os.cpu_count() or 1, score_cutoff=args.cutoff), np.arange(0, n, 1009))]
+            for exp, index_of in legs:
+                keep = ~np.isnan(exp) if is_f64 else exp != np.uint64(2**64 - 1)
+                want_i = index_of[keep]
+                want_v = exp[keep] if is_f64 else exp[keep].astype(np.uint32)
+                sel = np.isin(gi, index_of)
+                if filt["count"].value <= args.capacity:
+                    mism += int(not (np.array_equal(gi[sel], want_i) and np.array_equal(gv[sel], want_v)))
+                else:  # the list is a subset: what it holds must be right
+                    pos = np.minimum(np.searchsorted(want_i, gi[sel]), max(len(want_i) - 1, 0))
+                    mism += int(not (len(want_i) > 0 or not sel.any()) or not (np.array_equal(want_i[pos], gi[sel]) and np.array_equal(want_v[pos], gv[sel])))
+                checked += len(index_of)
+            result["parity"] = {"checked": int(checked), "mismatches": mism + int(not ordered),
+                                "what": f"the (index, score) pairs inside the first {chk} candidates + every 1009-th of all {n} == the oracle's Somes there; indices ascending"}
     if host_sample is not None and args.mode == "many":
         # parity on the sample, in the same run
         from oracle import oracle as o
@@ -643,7 +714,8 @@ def main():
     if world > 1 or force_dist:
         dist.destroy_process_group()
     is_headline = (args.config in (None, "c2") and args.metric == "levenshtein" and n == 100_000_000 and args.cand_len == 64 and args.query_len == 64
-                   and args.cutoff is None and not weights and not args.ragged and args.mode == "many" and nq == 1 and world == 1 and not force_dist)
+                   and args.cutoff is None and not weights and not args.ragged and args.mode == "many" and nq == 1 and world == 1 and not force_dist
+                   and args.head_share == 0 and args.zipf == 0)
     if args.extras == "on" or (args.extras == "auto" and is_headline):
         # the headline's numbers are final at this point; give the GPU memory back before the legs start their own processes
         del corpus, out

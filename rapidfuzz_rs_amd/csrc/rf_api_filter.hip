@@ -36,7 +36,7 @@ struct ScratchSet {  // everything a call allocates, released in stream order on
 // The first road.  Returns RF_OK with *took = false when the launch would not go through the lane compaction (the caller then takes the second road).
 // On success: lane_val / lane_idx hold the survivors' results, *d_total (device) their number, cap2 the room they had.
 static rf_status filter_fast(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, bool f64_out, uint64_t capacity, hipStream_t st,
-                             ScratchSet& sc, bool* took, void** lane_val, uint32_t** lane_idx, uint32_t** d_total, uint32_t* cap2_out)
+                             ScratchSet& sc, bool* took, void** lane_val, uint32_t** lane_idx, uint32_t** d_total, uint32_t* cap2_out, std::unique_lock<std::mutex>* held)
 {
     *took = false;
     static const bool lane_compact = [] { const char* e = getenv("RF_LANE_COMPACT"); return !e || atoi(e) != 0; }();
@@ -55,7 +55,7 @@ static rf_status filter_fast(const rf_comparator* c_in, const rf_corpus* corpus_
     std::unique_lock<std::mutex> filter_lock(corpus->filter_enqueue_mu);
     p.tile_list_buf = corpus_tile_list(corpus, st);
     corpus_lane_buffers(corpus, &p);
-    if (!p.lane_mask || !head_two_pass_applies(raw, p)) return RF_OK;
+    if (!p.lane_list || !head_two_pass_applies(raw, p)) return RF_OK;
     // room for the survivors of the first pass (NOT the passers: a corpus that shares prefixes with the query has many more survivors than matches); a call whose
     // survivors do not fit takes the second road afterwards -- correct either way
     const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(corpus->n / 8, 4 * capacity), 1u << 16);
@@ -63,18 +63,17 @@ static rf_status filter_fast(const rf_comparator* c_in, const rf_corpus* corpus_
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     RF_HIP(sc.get(lane_val, (size_t)cap2 * elem));
     RF_HIP(sc.get((void**)lane_idx, (size_t)cap2 * sizeof(uint32_t)));
-    RF_HIP(sc.get((void**)d_total, sizeof(uint32_t)));
     p.lane_val = *lane_val;
     p.lane_idx = *lane_idx;
-    p.lane_total = *d_total;
+    *d_total = p.tile_list_buf + 1;  // (the survivors' number, left there by the pack kernel; `held` keeps other host threads of this stream off the buffer until
+                                     // everything that reads it has been enqueued)
     p.lane_cap = cap2;
     p.out = nullptr;
     p.prefill_none = 0;
     static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;
     if (trace_plan) std::fprintf(stderr, "[rf plan] filter: lane compaction, first_check=%u head_need=%u head_k=%u room for %u survivors\n", p.first_check, p.head_need, p.head_k, cap2);
     const hipError_t e = launch_scan(raw, p, st, nullptr);
-    corpus_tile_list_done(corpus, st);
-    filter_lock.unlock();
+    *held = std::move(filter_lock);
     if (e != hipSuccess) {
         set_error(std::string("filter scan launch: ") + hipGetErrorString(e));
         return RF_ERR_HIP;
@@ -120,13 +119,20 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
 
     uint32_t count = 0;
     bool in_index_order = true;
-    bool done = false;
+    bool done = false, delivered = false;
+    uint64_t* d_index64 = out_index;
+    void* d_score = out_score;
+    if (out_mem == RF_MEM_HOST && cap) {
+        RF_HIP(sc.get((void**)&d_index64, (size_t)cap * sizeof(uint64_t)));
+        RF_HIP(sc.get(&d_score, (size_t)cap * elem));
+    }
     // ---- the first road
     {
         bool took = false;
         void* lane_val = nullptr;
         uint32_t *lane_idx = nullptr, *d_total = nullptr, cap2 = 0;
-        if (const rf_status rs = filter_fast(c, corpus, op, args, f64_out, capacity, st, sc, &took, &lane_val, &lane_idx, &d_total, &cap2); rs != RF_OK) return rs;
+        std::unique_lock<std::mutex> held;
+        if (const rf_status rs = filter_fast(c, corpus, op, args, f64_out, capacity, st, sc, &took, &lane_val, &lane_idx, &d_total, &cap2, &held); rs != RF_OK) return rs;
         if (took) {
             const uint32_t n_seg = filter_segments(cap2);
             uint32_t* seg = nullptr;
@@ -135,13 +141,20 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
             RF_HIP(sc.get((void**)&seg, ((size_t)n_seg + 1) * sizeof(uint32_t)));
             RF_HIP(sc.get(&temp, temp_bytes));
             RF_HIP(launch_filter_compact(lane_val, f64_out, lane_idx, 0, cap2, d_total, seg, temp, temp_bytes, cap, d_idx, d_val, st));
+            // the survivors arrive in index order: unless the caller wants them by score, the widening runs before the host has seen the count (one
+            // synchronization per call instead of two)
+            const bool early_finish = order != RF_FILTER_BY_SCORE && cap != 0;
+            if (early_finish) RF_HIP(launch_filter_finish(d_idx, d_val, nullptr, f64_out, desc, cap, seg + n_seg, index_base, d_index64, d_score, st));
             uint32_t h[2] = {0, 0};
             RF_HIP(hipMemcpyAsync(&h[0], seg + n_seg, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             RF_HIP(hipMemcpyAsync(&h[1], d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            corpus_tile_list_done(corpus, st);
+            held.unlock();
             RF_HIP(hipStreamSynchronize(st));
             if (h[1] <= cap2) {  // every survivor had room: the count is the true one
                 count = h[0];
                 done = true;
+                delivered = early_finish;
             }  // (else: more survivors than room -- the second road)
         }
     }
@@ -163,53 +176,52 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
         RF_HIP(sc.get(&temp, temp_bytes));
         RF_HIP(launch_filter_compact(d_tmp, f64_out, slots ? corpus->d_orig : nullptr, slots ? corpus->n_exact * (uint32_t)kWave : 0u, (uint32_t)m, nullptr, seg, temp, temp_bytes,
                                      cap, d_idx, d_val, st));
+        in_index_order = !slots;
+        const bool early_finish = cap != 0 && (order == RF_FILTER_ANY || (order == RF_FILTER_BY_INDEX && in_index_order));
+        if (early_finish) RF_HIP(launch_filter_finish(d_idx, d_val, nullptr, f64_out, desc, cap, seg + n_seg, index_base, d_index64, d_score, st));
         RF_HIP(hipMemcpyAsync(&count, seg + n_seg, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         RF_HIP(hipStreamSynchronize(st));
-        in_index_order = !slots;
+        delivered = early_finish;
     }
     *out_count = count;
     const uint32_t have = std::min(count, cap);
     if (have == 0) return RF_OK;
-    // ---- order, widen, deliver
-    const bool by_index = !in_index_order && order != RF_FILTER_ANY;
-    const bool by_score = order == RF_FILTER_BY_SCORE;
-    const uint32_t* idx_now = d_idx;
-    const void* val_now = d_val;
-    const void* key_now = nullptr;
-    if (by_index || by_score) {
-        void* temp = nullptr;
-        const size_t temp_bytes = filter_sort_temp_bytes(have);
-        RF_HIP(sc.get(&temp, temp_bytes));
-        if (by_index) {
-            uint32_t* idx2 = nullptr;
-            void* val2 = nullptr;
-            RF_HIP(sc.get((void**)&idx2, (size_t)have * sizeof(uint32_t)));
-            RF_HIP(sc.get(&val2, (size_t)have * elem));
-            RF_HIP(launch_filter_sort_by_index(idx_now, val_now, f64_out, have, idx2, val2, temp, temp_bytes, st));
-            idx_now = idx2, val_now = val2;
+    if (!delivered) {
+        // ---- order, widen
+        const bool by_index = !in_index_order && order != RF_FILTER_ANY;
+        const bool by_score = order == RF_FILTER_BY_SCORE;
+        const uint32_t* idx_now = d_idx;
+        const void* val_now = d_val;
+        const void* key_now = nullptr;
+        if (by_index || by_score) {
+            void* temp = nullptr;
+            const size_t temp_bytes = filter_sort_temp_bytes(have);
+            RF_HIP(sc.get(&temp, temp_bytes));
+            if (by_index) {
+                uint32_t* idx2 = nullptr;
+                void* val2 = nullptr;
+                RF_HIP(sc.get((void**)&idx2, (size_t)have * sizeof(uint32_t)));
+                RF_HIP(sc.get(&val2, (size_t)have * elem));
+                RF_HIP(launch_filter_sort_by_index(idx_now, val_now, f64_out, have, idx2, val2, temp, temp_bytes, st));
+                idx_now = idx2, val_now = val2;
+            }
+            if (by_score) {
+                uint32_t* idx3 = nullptr;
+                void *key_in = nullptr, *key_out = nullptr;
+                RF_HIP(sc.get((void**)&idx3, (size_t)have * sizeof(uint32_t)));
+                RF_HIP(sc.get(&key_in, (size_t)have * sizeof(uint64_t)));
+                RF_HIP(sc.get(&key_out, (size_t)have * sizeof(uint64_t)));
+                RF_HIP(launch_filter_sort_by_score(idx_now, val_now, f64_out, desc, have, key_in, key_out, idx3, temp, temp_bytes, st));
+                idx_now = idx3, key_now = key_out;
+            }
         }
-        if (by_score) {
-            uint32_t* idx3 = nullptr;
-            void *key_in = nullptr, *key_out = nullptr;
-            RF_HIP(sc.get((void**)&idx3, (size_t)have * sizeof(uint32_t)));
-            RF_HIP(sc.get(&key_in, (size_t)have * sizeof(uint64_t)));
-            RF_HIP(sc.get(&key_out, (size_t)have * sizeof(uint64_t)));
-            RF_HIP(launch_filter_sort_by_score(idx_now, val_now, f64_out, desc, have, key_in, key_out, idx3, temp, temp_bytes, st));
-            idx_now = idx3, key_now = key_out;
-        }
+        RF_HIP(launch_filter_finish(idx_now, val_now, key_now, f64_out, desc, have, nullptr, index_base, d_index64, d_score, st));
     }
-    uint64_t* d_index64 = out_index;
-    void* d_score = out_score;
-    if (out_mem == RF_MEM_HOST) {
-        RF_HIP(sc.get((void**)&d_index64, (size_t)have * sizeof(uint64_t)));
-        RF_HIP(sc.get(&d_score, (size_t)have * elem));
-    }
-    RF_HIP(launch_filter_finish(idx_now, val_now, key_now, f64_out, desc, have, index_base, d_index64, d_score, st));
     if (out_mem == RF_MEM_HOST) {
         RF_HIP(hipMemcpyAsync(out_index, d_index64, (size_t)have * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         RF_HIP(hipMemcpyAsync(out_score, d_score, (size_t)have * elem, hipMemcpyDeviceToHost, st));
     }
-    RF_HIP(hipStreamSynchronize(st));
+    if (out_mem == RF_MEM_HOST || !delivered) RF_HIP(hipStreamSynchronize(st));
     return RF_OK;
 }
 

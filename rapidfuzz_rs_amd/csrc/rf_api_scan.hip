@@ -554,23 +554,14 @@ void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
     p->head_k = (uint32_t)K;
 }
 
-static size_t tile_list_words(uint32_t n_tiles) { return (2 * (size_t)n_tiles + 5 * 16384 + 8 + 63) / 64 * 64; }  // (a multiple of 256 bytes: what follows is 8-byte data)
-static size_t lane_buffer_bytes(uint32_t n_tiles)
-{
-    const size_t tiles2 = (size_t)n_tiles + 4;  // (pairs rounded up + the total)
-    return tiles2 * sizeof(uint64_t) + (tiles2 * sizeof(uint32_t) + 255) / 256 * 256 + lane_scan_temp_bytes(n_tiles + 4);
-}
-// the lane-compaction part of a tile-list buffer (corpus_tile_list): ScanParams::lane_mask / lane_prefix / lane_temp
+// words of a tile-list buffer: round 5's layout (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the
+// packed list) needs 2 n_tiles + 5 x 16384; the lane lists (rf_scan.hip lane_list_pack_kernel: 16-byte entries in the segments and in the packed list) four times the entries
+static size_t tile_list_words(uint32_t n_tiles) { return 8 * (size_t)n_tiles + 12 * 16384 + 64; }
+// the buffer serves the lane compaction (every buffer corpus_tile_list hands out does)
 void corpus_lane_buffers(const rf_corpus* corpus, ScanParams* p)
 {
-    p->lane_mask = nullptr, p->lane_prefix = nullptr, p->lane_temp = nullptr, p->lane_temp_bytes = 0;
-    if (!p->tile_list_buf) return;
-    const size_t tiles2 = (size_t)corpus->n_tiles + 4;
-    uint8_t* base = reinterpret_cast<uint8_t*>(p->tile_list_buf + tile_list_words(corpus->n_tiles));
-    p->lane_mask = reinterpret_cast<uint64_t*>(base);
-    p->lane_prefix = reinterpret_cast<uint32_t*>(base + tiles2 * sizeof(uint64_t));
-    p->lane_temp = base + tiles2 * sizeof(uint64_t) + (tiles2 * sizeof(uint32_t) + 255) / 256 * 256;
-    p->lane_temp_bytes = lane_scan_temp_bytes(corpus->n_tiles + 4);
+    (void)corpus;
+    p->lane_list = p->tile_list_buf ? 1u : 0u;
 }
 
 // this stream's tile list for head_filter_kernel (the caller holds corpus->filter_enqueue_mu); nullptr = none to be had, the
@@ -595,9 +586,7 @@ uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
         return lru.ptr;
     }
     uint32_t* ptr = nullptr;
-    // (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the packed list;
-    //  behind them what the lane compaction needs, rf_sparse.hip: a 64-bit mask and a running sum per tile + hipcub's scan scratch -- corpus_lane_buffers)
-    if (hipMalloc((void**)&ptr, tile_list_words(corpus->n_tiles) * sizeof(uint32_t) + lane_buffer_bytes(corpus->n_tiles)) != hipSuccess) {
+    if (hipMalloc((void**)&ptr, tile_list_words(corpus->n_tiles) * sizeof(uint32_t)) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }

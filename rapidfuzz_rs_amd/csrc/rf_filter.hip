@@ -105,19 +105,22 @@ __global__ void filter_keys_f64_kernel(const double* __restrict__ val, uint32_t 
     }
 }
 // the caller's arrays: u64 indices (+ index_base) and the scores -- from the values, or (key != nullptr) decoded from their sort keys
+// (n_dev: the number of results when only the device knows it yet -- min(n, *n_dev) entries are written)
 __global__ void filter_finish_u32_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, const uint32_t* __restrict__ key, bool desc, uint32_t n,
-                                         uint64_t index_base, uint64_t* __restrict__ out_index, uint32_t* __restrict__ out_val)
+                                         const uint32_t* __restrict__ n_dev, uint64_t index_base, uint64_t* __restrict__ out_index, uint32_t* __restrict__ out_val)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i < n) {
         out_index[i] = index_base + idx[i];
         out_val[i] = key ? (desc ? ~key[i] : key[i]) : val[i];
     }
 }
 __global__ void filter_finish_f64_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ val, const uint64_t* __restrict__ key, bool desc, uint32_t n,
-                                         uint64_t index_base, uint64_t* __restrict__ out_index, double* __restrict__ out_val)
+                                         const uint32_t* __restrict__ n_dev, uint64_t index_base, uint64_t* __restrict__ out_index, double* __restrict__ out_val)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i < n) {
         out_index[i] = index_base + idx[i];
         if (key) {
@@ -195,15 +198,16 @@ hipError_t launch_filter_sort_by_score(const uint32_t* idx_in, const void* val_i
     if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)key_in, (uint32_t*)key_out, idx_in, idx_out, (int)count, 0, 32, st);
 }
-hipError_t launch_filter_finish(const uint32_t* idx, const void* val, const void* key, bool f64, bool desc, uint32_t count, uint64_t index_base, uint64_t* out_index,
-                                void* out_val, hipStream_t st)
+// count_dev != nullptr: at most `count` results, *count_dev of them real (the host has not seen the count yet: the grid covers a guess, a grid-stride loop the rest)
+hipError_t launch_filter_finish(const uint32_t* idx, const void* val, const void* key, bool f64, bool desc, uint32_t count, const uint32_t* count_dev, uint64_t index_base,
+                                uint64_t* out_index, void* out_val, hipStream_t st)
 {
     if (count == 0) return hipSuccess;
     const dim3 b(256), g((count + 255) / 256);
     if (f64)
-        hipLaunchKernelGGL(filter_finish_f64_kernel, g, b, 0, st, idx, (const double*)val, (const uint64_t*)key, desc, count, index_base, out_index, (double*)out_val);
+        hipLaunchKernelGGL(filter_finish_f64_kernel, g, b, 0, st, idx, (const double*)val, (const uint64_t*)key, desc, count, count_dev, index_base, out_index, (double*)out_val);
     else
-        hipLaunchKernelGGL(filter_finish_u32_kernel, g, b, 0, st, idx, (const uint32_t*)val, (const uint32_t*)key, desc, count, index_base, out_index, (uint32_t*)out_val);
+        hipLaunchKernelGGL(filter_finish_u32_kernel, g, b, 0, st, idx, (const uint32_t*)val, (const uint32_t*)key, desc, count, count_dev, index_base, out_index, (uint32_t*)out_val);
     return hipGetLastError();
 }
 

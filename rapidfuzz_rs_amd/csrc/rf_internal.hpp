@@ -109,19 +109,15 @@ struct ScanParams {
     uint32_t* tile_list_buf;
     const uint32_t* tile_list;
     const uint32_t* tile_list_count;
-    // LANE COMPACTION of the head-plane cutoff scans (round 6, rf_sparse.hip): head_filter_kernel leaves, per tile of its launch, the 64-bit mask of the LANES that
-    // passed its tests (lane_mask, indexed from tile_begin; dead lanes get their None there and then), an exclusive sum numbers the survivors (lane_prefix, one entry
-    // more than tiles: the total), and sparse_lean_kernel scans dense tiles of 64 survivors each, every lane reading its own candidate's chunk rows -- a corpus in
-    // which 2 % of the candidates share the query's head keeps 73 % of its TILES alive and 2 % of its lanes.  nullptr = the tile list above.
-    uint64_t* lane_mask;
-    uint32_t* lane_prefix;
-    void* lane_temp;                // hipcub's scan scratch
-    size_t lane_temp_bytes;
+    // LANE COMPACTION of the head-plane cutoff scans (round 6, rf_sparse.hip): head_filter_kernel attaches to every tile it lists the 64-bit mask of the LANES that
+    // passed its tests (every other candidate gets its None there and then), the pack kernel numbers the survivors, and sparse_lean_kernel scans dense tiles of 64
+    // survivors each, every lane reading its own candidate's chunk rows -- a corpus in which 2 % of the candidates share the query's head keeps 73 % of its TILES
+    // alive and 2 % of its lanes.  lane_list = 1: tile_list_buf is large enough for the 16-byte entries (corpus_tile_list); 0 = round 5's tile list.
+    uint32_t lane_list;
     // ... and where the survivors' results go when the caller wants no dense vector (rf_filter_*): lane_val[g] (u32 or f64 by out_f64; None = beyond the cutoff) and
-    // lane_idx[g] = candidate index for survivor g < lane_cap; *lane_total = the number of survivors (may exceed lane_cap: the host then takes another road)
+    // lane_idx[g] = candidate index for survivor g < lane_cap (the number of survivors -- tile_list_buf[1] -- may exceed lane_cap: the host then takes another road)
     void* lane_val;
     uint32_t* lane_idx;
-    uint32_t* lane_total;
     uint32_t lane_cap;
     uint32_t exp_flags;             // measurement switches (bit 0: RF_EXP_NOHBM on the head-plane scans)
     uint32_t slot_store;            // 1: `orig` is the slot -> slot identity of the gather path (run_many: results into a slot-ordered temporary), so a kernel may
@@ -187,10 +183,8 @@ hipError_t launch_hint_gather(const ScanParams& p, const uint32_t* run_first, ui
                               const uint32_t* run_tile_base, const uint64_t* run_data_base, const uint32_t* run_len, uint32_t n_tiles2, uint8_t* data2, TileDesc* tiles2,
                               uint32_t* orig2, hipStream_t st);
 hipError_t launch_band(const ScanParams& p, hipStream_t stream);  // rf_band.hip: exact tiles [tile_begin, tile_end)
-// rf_sparse.hip: the lane compaction of the head-plane cutoff scans (ScanParams::lane_mask)
-size_t lane_scan_temp_bytes(uint32_t tiles);
-hipError_t launch_lane_prefix(const ScanParams& p, uint32_t tiles2, hipStream_t stream);  // lane_prefix[0 .. tiles2] = exclusive sum of popcount(lane_mask[0 .. tiles2))
-hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, uint32_t tiles2, hipStream_t stream);  // state_kind: 0 LevState<1>, 1 Lev32State, 2 OsaState<1>
+// rf_sparse.hip: the lane compaction of the head-plane cutoff scans (ScanParams::lane_list)
+hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, hipStream_t stream);  // state_kind: 0 LevState<1>, 1 Lev32State, 2 OsaState<1>; p.tile_list = the packed 16-byte entries
 bool head_two_pass_applies(RawKind raw, const ScanParams& p);  // rf_scan.hip: will launch_scan take head_filter_kernel + a second pass for this launch?
 hipError_t launch_scan_mixed(RawKind raw, const ScanParams& p, hipStream_t stream);  // p.mixed / tile_begin / tile_end: the mixed section
 hipError_t launch_long(RawKind raw, const ScanParams& p, hipStream_t stream, int grid);
@@ -249,8 +243,8 @@ hipError_t launch_filter_sort_by_index(const uint32_t* idx_in, const void* val_i
                                        hipStream_t st);
 hipError_t launch_filter_sort_by_score(const uint32_t* idx_in, const void* val_in, bool f64, bool desc, uint32_t count, void* key_in, void* key_out, uint32_t* idx_out,
                                        void* temp, size_t temp_bytes, hipStream_t st);
-hipError_t launch_filter_finish(const uint32_t* idx, const void* val, const void* key, bool f64, bool desc, uint32_t count, uint64_t index_base, uint64_t* out_index,
-                                void* out_val, hipStream_t st);
+hipError_t launch_filter_finish(const uint32_t* idx, const void* val, const void* key, bool f64, bool desc, uint32_t count, const uint32_t* count_dev, uint64_t index_base,
+                                uint64_t* out_index, void* out_val, hipStream_t st);
 int scan_grid(uint32_t n_tiles);       // the grid of short-running launches over n_tiles tiles
 int scan_grid_full(uint32_t n_tiles);  // the grid of full (no-cutoff) scans; >= scan_grid
 

@@ -215,7 +215,7 @@ __device__ __forceinline__ uint32_t widen24(uint32_t x)  // four 6-bit symbols o
 {
     return (x & 0x3Fu) | ((x << 2) & 0x3F00u) | ((x << 4) & 0x3F0000u) | ((x << 6) & 0x3F000000u);
 }
-// kLanes (round 6): the pass leaves a LANE mask per tile (ScanParams::lane_mask) instead of a list of tiles, and writes the None of every candidate it decides,
+// kLanes (round 6): the pass lists its surviving tiles WITH the mask of their surviving lanes (16-byte entries), and writes the None of every candidate it decides,
 // whatever the rest of its tile does: what is left for the second pass is the surviving CANDIDATES, gathered 64 to a wavefront (rf_sparse.hip).  A lane survives when
 // its own symbols pass the band test AND its own first look passes -- both are necessary conditions per candidate.
 template <class State, int kFirst, bool kPlane6, bool kLanes = false>
@@ -236,8 +236,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2, stride = gridDim.x * kWavesPerBlock;
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
-    uint32_t* seg = buf + 1 + 2 * (size_t)stride + (size_t)gw * cap;
-    uint32_t kept = 0;
+    // kLanes: [0] packed count | [1] survivors | 2 pad | G tile counts | G lane counts | G segments of `cap` 16-byte entries | the packed entries
+    uint32_t* seg = kLanes ? buf + 4 + 2 * (size_t)stride + (size_t)gw * cap * 4 : buf + 1 + 2 * (size_t)stride + (size_t)gw * cap;
+    uint32_t kept = 0, kept_lanes = 0;
     uint32_t pr = gw;
     if (pr < pairs) {
         const uint32_t len1 = p.len1, len2 = p.uniform_len;
@@ -279,8 +280,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
             const uint32_t t0 = p.tile_begin + 2 * pr;
             uint64_t m = ~0ull;
             if constexpr (kLanes) {
+                // the band test and the look per LANE: a lane survives when its own symbols pass both (each is a necessary condition per candidate)
                 const bool tile_ok = lane < 32 || t0 + 1 < p.tile_end;  // (an odd tile count: the last pair's second half is the plane's pad row)
-                bool pa = tile_ok, pb = tile_ok;  // this lane's two candidates are still in the race
+                bool pa = tile_ok, pb = tile_ok;
                 if (need) {
                     pa = tile_ok && band_hits(lds_band, cur.x, cur.y) >= need;
                     pb = tile_ok && band_hits(lds_band, cur.z, cur.w) >= need;
@@ -302,26 +304,36 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
                         const int s0 = __shfl(v, (int)(lane >> 1), kWave), s1 = __shfl(v, (int)(32 + (lane >> 1)), kWave);
                         mask0 = __ballot((s0 >> (lane & 1)) & 1);
                         mask1 = __ballot((s1 >> (lane & 1)) & 1);
-                    } else {
-                        pa = pb = false;
                     }
-                } else {
-                    pa = pb = false;
                 }
-                if (lane == 0) {
-                    typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
-                    v2ull mm;
-                    mm.x = mask0, mm.y = mask1;
-                    *reinterpret_cast<v2ull*>(p.lane_mask + 2 * (size_t)pr) = mm;  // (an odd tile count: the second mask of the last pair is 0 -- its lanes lie beyond p.n)
-                }
-                if (p.out && !p.run_orig && tile_ok) {  // (a length run of a bucketed corpus: `out` is pre-filled with None)
-                    const uint32_t idx = t0 * kWave + 2 * lane;
-                    if (!pa && !pb && !p.out_f64 && idx + 1 < p.n) {
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.out) + idx) = make_uint2(RF_NONE_U32, RF_NONE_U32);
-                    } else {
-                        if (!pa && idx < p.n) emit_none(p, idx);
-                        if (!pb && idx + 1 < p.n) emit_none(p, idx + 1);
+                if (p.out && !p.run_orig) {  // (a length run of a bucketed corpus: `out` is pre-filled with None)
+                    if ((mask0 | mask1) == 0) {  // the common case as before: the whole pair is None
+                        const uint32_t idx = t0 * kWave + 2 * lane;
+                        if (tile_ok) {
+                            if (!p.out_f64 && idx + 1 < p.n) {
+                                *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.out) + idx) = make_uint2(RF_NONE_U32, RF_NONE_U32);
+                            } else {
+                                if (idx < p.n) emit_none(p, idx);
+                                if (idx + 1 < p.n) emit_none(p, idx + 1);
+                            }
+                        }
+                    } else if (tile_ok) {  // a pair with survivors: the None of every OTHER candidate (the second pass writes the survivors')
+                        const uint32_t idx = t0 * kWave + 2 * lane;
+                        const bool sa = (m != 0) && pa, sb = (m != 0) && pb;
+                        if (!sa && idx < p.n) emit_none(p, idx);
+                        if (!sb && idx + 1 < p.n) emit_none(p, idx + 1);
                     }
+                }
+                // the list: one 16-byte entry per surviving tile -- tile, its lane mask, (filled in by the pack kernel) the survivors in front of it
+                if (mask0 != 0) {
+                    if (lane == 0) reinterpret_cast<uint4*>(seg)[kept] = make_uint4(t0, (uint32_t)mask0, (uint32_t)(mask0 >> 32), 0u);
+                    ++kept;
+                    kept_lanes += (uint32_t)__popcll(mask0);
+                }
+                if (mask1 != 0) {
+                    if (lane == 0) reinterpret_cast<uint4*>(seg)[kept] = make_uint4(t0 + 1, (uint32_t)mask1, (uint32_t)(mask1 >> 32), 0u);
+                    ++kept;
+                    kept_lanes += (uint32_t)__popcll(mask1);
                 }
                 if (pr_next >= pairs) break;
                 pr = pr_next;
@@ -365,7 +377,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
             ahead = ahead2;
         }
     }
-    if (!kLanes && lane == 0) buf[1 + gw] = kept;
+    if (lane == 0) {
+        if constexpr (kLanes) {
+            buf[4 + gw] = kept;
+            buf[4 + stride + gw] = kept_lanes;
+        } else {
+            buf[1 + gw] = kept;
+        }
+    }
 }
 
 // packing the segments: ONE launch, a workgroup per 256 segments.  Every workgroup adds up the counts in front of its block itself
@@ -408,6 +427,62 @@ __global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restric
         for (uint32_t j = 0; j < n; ++j) packed[at + j] = seg[j];
     }
     if (first + 256 >= G && threadIdx.x == 0) buf[0] = in_front + block_total;
+}
+
+// The same for the LANE lists of head_filter_kernel<..., kLanes = true> (round 6): 16-byte entries (tile, lane mask lo / hi, -), two counts per segment -- tiles and
+// surviving lanes -- and two running sums: an entry's last word becomes the number of survivors in front of it, which is what rf_sparse.hip searches.
+// buf: [0] packed entries | [1] survivors | 2 pad | G tile counts | G lane counts | G segments of `cap` entries | the packed entries
+__global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap)
+{
+    constexpr uint32_t kWaves = 256 / kWave;
+    __shared__ uint32_t own[kWaves], front[kWaves], own_l[kWaves], front_l[kWaves];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t first = blockIdx.x * 256, s = first + threadIdx.x;
+    uint32_t before = 0, before_l = 0;  // this thread's share of the counts in front of the block
+    for (uint32_t k = threadIdx.x; k < first; k += 256) {
+        before += buf[4 + k];
+        before_l += buf[4 + G + k];
+    }
+    const uint32_t n = s < G ? buf[4 + s] : 0u, nl = s < G ? buf[4 + G + s] : 0u;
+    uint32_t incl = n, incl_l = nl;  // inclusive scans inside the wavefront
+#pragma unroll
+    for (uint32_t d = 1; d < (uint32_t)kWave; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, kWave), vl = __shfl_up(incl_l, d, kWave);
+        if (lane >= d) incl += v, incl_l += vl;
+    }
+#pragma unroll
+    for (uint32_t d = kWave / 2; d >= 1; d >>= 1) {
+        before += __shfl_xor(before, d, kWave);
+        before_l += __shfl_xor(before_l, d, kWave);
+    }
+    if (lane == kWave - 1) own[wave] = incl, own_l[wave] = incl_l;
+    if (lane == 0) front[wave] = before, front_l[wave] = before_l;
+    __syncthreads();
+    uint32_t at = incl - n, lat = incl_l - nl, block_total = 0, block_total_l = 0, in_front = 0, in_front_l = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; ++w) {
+        in_front += front[w];
+        in_front_l += front_l[w];
+        if (w < wave) at += own[w], lat += own_l[w];
+        block_total += own[w];
+        block_total_l += own_l[w];
+    }
+    at += in_front;
+    lat += in_front_l;
+    if (s < G) {
+        const uint4* seg = reinterpret_cast<const uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)s * cap;
+        uint4* packed = reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)G * cap;
+        for (uint32_t j = 0; j < n; ++j) {
+            uint4 e = seg[j];
+            e.w = lat;
+            packed[at + j] = e;
+            lat += (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z);
+        }
+    }
+    if (first + 256 >= G && threadIdx.x == 0) {
+        buf[0] = in_front + block_total;
+        buf[1] = in_front_l + block_total_l;
+    }
 }
 
 // THE BAND PREFILTER (kHead8, p.head_need != 0: cutoffs that allow at most K = p.head_k <= 3 edits).  Any alignment of cost <= K
@@ -1016,17 +1091,20 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                         const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2;        \
                         const uint32_t fgrid = std::min<uint32_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock, std::min<uint32_t>((uint32_t)device_cus() * 16u, 4096u)); /* G <= 16 K: rf_api_scan.hip sizes the list buffer for that */ \
                         const uint32_t G = fgrid * kWavesPerBlock, cap = 2 * ((pairs + G - 1) / G); \
-                        if (pn.lane_mask && pn.lane_prefix && sw_lane_compact()) {         \
-                            /* round 6: the second pass over the surviving LANES, 64 to a wavefront (rf_sparse.hip) */ \
+                        if (pn.lane_list && sw_lane_compact()) {                          \
+                            /* round 6: the pass leaves LANE masks with its surviving tiles, the second pass walks the surviving lanes 64 to a wavefront (rf_sparse.hip) */ \
+                            const uint32_t cap4 = cap;                                     \
                             if (pn.heads6 && (p.tile_begin & 1u) == 0)                     \
-                                hipLaunchKernelGGL((head_filter_kernel<State, J, true, true>), dim3(fgrid), b, 0, stream, pn, nullptr, 0u); \
+                                hipLaunchKernelGGL((head_filter_kernel<State, J, true, true>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap4); \
                             else                                                           \
-                                hipLaunchKernelGGL((head_filter_kernel<State, J, false, true>), dim3(fgrid), b, 0, stream, pn, nullptr, 0u); \
-                            hipError_t el = hipGetLastError();                             \
-                            if (el == hipSuccess) el = launch_lane_prefix(pn, 2 * pairs, stream); \
+                                hipLaunchKernelGGL((head_filter_kernel<State, J, false, true>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap4); \
+                            hipLaunchKernelGGL(lane_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap4); \
                             ScanParams p2 = pn;                                            \
                             p2.heads8 = nullptr;                                           \
-                            if (el == hipSuccess) el = launch_sparse_lean(std::is_same<State, Lev32State>::value ? 1 : (std::is_same<State, OsaState<1>>::value ? 2 : 0), p2, 2 * pairs, stream); \
+                            p2.tile_list = p.tile_list_buf + 4 + 2 * (size_t)G + 4 * (size_t)G * cap4; \
+                            p2.tile_list_count = p.tile_list_buf;                          \
+                            hipError_t el = hipGetLastError();                             \
+                            if (el == hipSuccess) el = launch_sparse_lean(std::is_same<State, Lev32State>::value ? 1 : (std::is_same<State, OsaState<1>>::value ? 2 : 0), p2, stream); \
                             return el;                                                     \
                         }                                                                  \
                         if (pn.heads6 && (p.tile_begin & 1u) == 0)                         \

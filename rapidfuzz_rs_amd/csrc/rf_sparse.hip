@@ -6,15 +6,15 @@
 // such a tile with all 64 lanes.  On corpora whose candidates share prefixes with the query -- URLs, names, SKUs: 2 % of the candidates carrying the query's first
 // 8..12 symbols leave 1 - 0.98^64 = 73 % of the tiles alive -- that second pass read a 1 KiB chunk row and ran >= 16 columns on 64 lanes for one or two live ones.
 //
-// Now the first pass leaves a 64-bit LANE mask per tile (dead lanes get their None there and then), launch_lane_prefix numbers the surviving candidates in index
-// order (hipcub exclusive sum over the masks' popcounts: 8 bytes read per tile), and sparse_lean_kernel walks DENSE tiles: wavefront lane l of dense tile j takes
-// survivor 64 j + l -- a binary search in the sums for its tile, the n-th set bit of that tile's mask for its lane -- and reads its own candidate's chunk rows (one
-// 16-byte load per lane and chunk; neighbouring survivors of one tile share cache lines).  Columns run from 0 on the full-width state with a look at every chunk
+// Now the first pass attaches a 64-bit LANE mask to every tile it lists (every other candidate gets its None there and then; a tile without survivors costs the
+// pass exactly what it cost before), lane_list_pack_kernel (rf_scan.hip) packs the 16-byte entries and numbers the surviving candidates -- in index order, because
+// the list is -- and sparse_lean_kernel walks DENSE tiles: wavefront lane l of dense tile j takes survivor 64 j + l -- a binary search over the entries' running
+// sums for its tile, the n-th set bit of that tile's mask for its lane -- and reads its own candidate's chunk rows (one 16-byte load per lane and chunk;
+// neighbouring survivors of one tile share cache lines).  (A first version kept a mask for EVERY tile and a hipcub sum over all of them: one more store per tile
+// pair in the first pass's loop cost the random-corpus case 14 %, profiles/survivors_r06.txt.)  Columns run from 0 on the full-width state with a look at every chunk
 // end (wavefront ballot over the dense tile), chunks one ahead.  Results go where the caller wants them: out[candidate] (dense vector: the first pass has written
 // every other entry), a length run's run_orig[], the in-scan top-k lists, or -- rf_filter_*, no dense vector at all -- lane_val / lane_idx at the survivor's number.
 // Everything is exact for every input: a survivor is merely a candidate the first pass could not rule out.
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <type_traits>
 
@@ -24,25 +24,13 @@ namespace rf {
 
 namespace {
 
-struct PopcOp {
-    __host__ __device__ __forceinline__ uint32_t operator()(const uint64_t& m) const
-    {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return (uint32_t)__popcll(m);
-#else
-        return (uint32_t)__builtin_popcountll(m);
-#endif
-    }
-};
-using PopcIter = hipcub::TransformInputIterator<uint32_t, PopcOp, const uint64_t*>;
-
-// largest i in [0, hi) with a[i] <= x (a ascending, a[0] = 0)
-__device__ __forceinline__ uint32_t last_le(const uint32_t* __restrict__ a, uint32_t hi, uint32_t x)
+// largest e in [0, hi) with list[e].w <= x (the entries' running sums ascend, list[0].w = 0)
+__device__ __forceinline__ uint32_t last_le(const uint4* __restrict__ list, uint32_t hi, uint32_t x)
 {
     uint32_t lo = 0;
     while (hi - lo > 1) {
         const uint32_t mid = lo + (hi - lo) / 2;
-        if (a[mid] <= x)
+        if (list[mid].w <= x)
             lo = mid;
         else
             hi = mid;
@@ -82,7 +70,7 @@ struct Source {
 };
 
 template <class State>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(const ScanParams p, uint32_t tiles2)
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(const ScanParams p)
 {
     __shared__ typename State::Word lds_pm[256];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
@@ -96,8 +84,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
     uint64_t limit = ~0ull;
     uint32_t tiles_done = 0;
 
-    const uint32_t total = uniform(p.lane_prefix[tiles2]);
-    if (p.lane_total && blockIdx.x == 0 && threadIdx.x == 0) *p.lane_total = total;
+    const uint4* __restrict__ list = reinterpret_cast<const uint4*>(p.tile_list);  // (tile, lane mask lo, hi, survivors in front): lane_list_pack_kernel
+    const uint32_t entries = uniform(p.tile_list_count[0]), total = uniform(p.tile_list_count[1]);
     const uint32_t n_dense = (total + kWave - 1) / kWave;
     const uint32_t len1 = p.len1, len2 = p.uniform_len;
     const uint32_t nch = (len2 + kChunk - 1) / kChunk;
@@ -108,9 +96,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
         const uint32_t g = j * kWave + lane;
         s.have = g < total;
         const uint32_t gg = s.have ? g : total - 1;  // (idle lanes of the last dense tile shadow its last survivor: defined bytes, no result)
-        const uint32_t ts = last_le(p.lane_prefix, tiles2, gg);
-        const uint32_t ls = nth_set_bit(p.lane_mask[ts], gg - p.lane_prefix[ts]);
-        const uint32_t t = p.tile_begin + ts;
+        const uint4 e = list[last_le(list, entries, gg)];
+        const uint32_t ls = nth_set_bit(((uint64_t)e.z << 32) | e.y, gg - e.w);
+        const uint32_t t = e.x;
         s.idx = t * kWave + ls;
         s.src = reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes) + ls;
         return s;
@@ -193,30 +181,18 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
 
 }  // namespace
 
-size_t lane_scan_temp_bytes(uint32_t tiles)
-{
-    size_t bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, PopcIter(nullptr, PopcOp()), (uint32_t*)nullptr, (int)tiles + 3, nullptr);
-    return std::max<size_t>((bytes + 255) / 256 * 256, 256);
-}
-
-hipError_t launch_lane_prefix(const ScanParams& p, uint32_t tiles2, hipStream_t stream)
-{
-    size_t bytes = p.lane_temp_bytes;
-    return hipcub::DeviceScan::ExclusiveSum(p.lane_temp, bytes, PopcIter(p.lane_mask, PopcOp()), p.lane_prefix, (int)tiles2 + 1, stream);
-}
-
-hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, uint32_t tiles2, hipStream_t stream)
+hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, hipStream_t stream)
 {
     // (the survivors' number is only known on the device: a fixed grid of 8 workgroups per CU, like early_lean_kernel over its list)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const uint32_t want = (uint32_t)cus * 8u, most = (tiles2 + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t tiles = p.tile_end > p.tile_begin ? p.tile_end - p.tile_begin : 1u;
+    const uint32_t want = (uint32_t)cus * 8u, most = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 g(std::max(1u, std::min(want, most))), b(kWave * kWavesPerBlock);
     switch (state_kind) {
-    case 0: hipLaunchKernelGGL((sparse_lean_kernel<LevState<1>>), g, b, 0, stream, p, tiles2); break;
-    case 1: hipLaunchKernelGGL((sparse_lean_kernel<Lev32State>), g, b, 0, stream, p, tiles2); break;
-    case 2: hipLaunchKernelGGL((sparse_lean_kernel<OsaState<1>>), g, b, 0, stream, p, tiles2); break;
+    case 0: hipLaunchKernelGGL((sparse_lean_kernel<LevState<1>>), g, b, 0, stream, p); break;
+    case 1: hipLaunchKernelGGL((sparse_lean_kernel<Lev32State>), g, b, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((sparse_lean_kernel<OsaState<1>>), g, b, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -44,9 +44,10 @@ def plant_near_duplicates(rows: np.ndarray, q: bytes, every: int, seed: int, max
     return idx
 
 
-def rows_device(n: int, length: int, seed: int, device=None, chunk: int = 1 << 24, symbols: int = 62):
+def rows_device(n: int, length: int, seed: int, device=None, chunk: int = 1 << 24, symbols: int = 62, zipf_s: float = 0.0):
     """torch uint8 CUDA tensor [n, length] of alphanumerics, generated on the device in chunks (`symbols` < 62 draws
-    from the first `symbols` of 0-9A-Za-z: an experiment knob for the LDS gather cost)."""
+    from the first `symbols` of 0-9A-Za-z: an experiment knob for the LDS gather cost; zipf_s > 0: symbol ranks follow a Zipf law
+    with that exponent instead of the uniform one)."""
     import torch
 
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -55,9 +56,16 @@ def rows_device(n: int, length: int, seed: int, device=None, chunk: int = 1 << 2
     out = torch.empty((n, length), dtype=torch.uint8, device=dev)
     flat = out.view(-1)
     total = n * length
+    cdf = None
+    if zipf_s > 0:
+        w = 1.0 / torch.arange(1, symbols + 1, dtype=torch.float64, device=dev) ** zipf_s
+        cdf = torch.cumsum(w / w.sum(), 0).to(torch.float32)
     for s in range(0, total, chunk * 16):
         e = min(total, s + chunk * 16)
-        v = torch.randint(0, symbols, (e - s,), dtype=torch.uint8, device=dev, generator=g)
+        if cdf is not None:
+            v = torch.searchsorted(cdf, torch.rand(e - s, device=dev, generator=g)).clamp_(max=symbols - 1).to(torch.uint8)
+        else:
+            v = torch.randint(0, symbols, (e - s,), dtype=torch.uint8, device=dev, generator=g)
         # 0-9 -> '0'.., 10-35 -> 'A'.., 36-61 -> 'a'..
         v += 48 + 7 * (v >= 10).to(torch.uint8) + 6 * (v >= 36).to(torch.uint8)
         flat[s:e] = v
@@ -87,9 +95,10 @@ def planted_indices(start: int, end: int, every: int) -> np.ndarray:
 
 
 def rows_device_range(start: int, end: int, length: int, seed: int, device=None, symbols: int = 62, q: bytes = None,
-                      plant_every: int = 0, block: int = _BLOCK):
+                      plant_every: int = 0, block: int = _BLOCK, head_share: float = 0.0):
     """Rows [start, end) of the logical corpus (seed, length) as a torch uint8 CUDA tensor; with `q` and `plant_every`
-    every plant_every-th global row is a near-duplicate of q (planted_row)."""
+    every plant_every-th global row is a near-duplicate of q (planted_row); with head_share > 0 that fraction of the rows carries
+    the query's first 8..12 symbols (drawn block by block from the block's own seed: the same rows at every world size)."""
     import torch
 
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -99,6 +108,13 @@ def rows_device_range(start: int, end: int, length: int, seed: int, device=None,
         g.manual_seed(seed + 1000003 * b)
         v = torch.randint(0, symbols, (block, length), dtype=torch.uint8, device=dev, generator=g)
         v += 48 + 7 * (v >= 10).to(torch.uint8) + 6 * (v >= 36).to(torch.uint8)
+        if head_share > 0 and q is not None:
+            hh = min(12, length, len(q))
+            pick = torch.nonzero(torch.rand(block, device=dev, generator=g) < head_share).flatten()
+            h = torch.randint(min(8, hh), hh + 1, (block,), device=dev, generator=g)[pick]
+            qa = torch.frombuffer(bytearray(q[:hh]), dtype=torch.uint8).to(dev)
+            cols = torch.arange(hh, device=dev)[None, :] < h[:, None]
+            v[pick, :hh] = torch.where(cols, qa[None, :], v[pick, :hh])
         lo, hi = max(start, b * block), min(end, (b + 1) * block)
         out[lo - start : hi - start] = v[lo - b * block : hi - b * block]
     if q is not None and plant_every:
