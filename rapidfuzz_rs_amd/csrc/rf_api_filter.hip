@@ -10,6 +10,8 @@
 //     over it with the slot -> original index map.
 // Then the order the caller asked for (results of a slot-ordered temporary need a sort by index; by-score is a stable sort on top), the widening to u64 indices,
 // and one synchronization that brings the count home.
+#include <functional>
+
 #include "rf_host.hpp"
 
 extern "C" {
@@ -30,6 +32,45 @@ struct ScratchSet {  // everything a call allocates, released in stream order on
         return e;
     }
 };
+
+// What filter_small_kernel reports -- [0] results, [1] entries, [2] flag, [3] the call's sequence number -- lands in PINNED HOST memory the calling thread
+// spins on: no device-to-host copy command, no stream synchronization between the kernel's last store and the host seeing the count (measured on the
+// configs[4] shape at 100 M: 202 -> ~185 us per call; the count coming home is the one thing a filter call cannot enqueue and forget).  One 64-byte slot per
+// host thread, never freed.  nullptr (no pinned memory to be had): the callers copy and synchronize instead.
+struct ResultSlot {
+    volatile uint32_t* host = nullptr;
+    uint32_t seq = 0;
+};
+ResultSlot& result_slot()
+{
+    thread_local ResultSlot slot;
+    if (!slot.host) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+            std::memset(p, 0, 64);
+            slot.host = static_cast<volatile uint32_t*>(p);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return slot;
+}
+// wait for the kernel that carries `seq`; false = the stream drained (or failed) without it
+bool await_slot(ResultSlot& slot, hipStream_t st, uint32_t h[3])
+{
+    for (uint64_t spin = 0;; ++spin) {
+        if (__atomic_load_n(const_cast<uint32_t*>(&slot.host[3]), __ATOMIC_ACQUIRE) == slot.seq) break;
+        if ((spin & 0xFFF) == 0xFFF) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) (void)hipGetLastError();
+            if (__atomic_load_n(const_cast<uint32_t*>(&slot.host[3]), __ATOMIC_ACQUIRE) == slot.seq) break;
+            return false;
+        }
+    }
+    h[0] = slot.host[0], h[1] = slot.host[1], h[2] = slot.host[2];
+    return true;
+}
 
 }  // namespace
 
@@ -58,7 +99,7 @@ static rf_status filter_fast(const rf_comparator* c_in, const rf_corpus* corpus_
     if (!p.lane_list || !head_two_pass_applies(raw, p)) return RF_OK;
     // room for the survivors of the first pass (NOT the passers: a corpus that shares prefixes with the query has many more survivors than matches); a call whose
     // survivors do not fit takes the second road afterwards -- correct either way
-    const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(corpus->n / 8, 4 * capacity), 1u << 16);
+    const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(corpus->n / 4, 4 * capacity), 1u << 16);
     const uint32_t cap2 = (uint32_t)std::min<uint64_t>(corpus->n, want);
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     RF_HIP(sc.get(lane_val, (size_t)cap2 * elem));
@@ -100,7 +141,6 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
             if (const rf_status rs = plan(ce, corpus, op, args, f64_out, &p, &raw); rs != RF_OK) return rs;
     }
     if (corpus->n == 0) return RF_OK;
-    if (corpus->n >= 0xFFFFFFFFull || capacity > 0xFFFFFFFFull) capacity = std::min<uint64_t>(capacity, 0xFFFFFFFEull);
     DeviceGuard guard(corpus->device);
     if (!guard.ok) {
         set_error("cannot select the corpus' device");
@@ -109,24 +149,111 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
     hipStream_t st = (hipStream_t)stream;
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
     const bool desc = op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY;
+    const bool by_score = order == RF_FILTER_BY_SCORE;
     const uint32_t cap = (uint32_t)std::min<uint64_t>(capacity, corpus->n);
     ScratchSet sc{st, {}};
-    // the compact pairs before ordering / widening
-    uint32_t* d_idx = nullptr;
-    void* d_val = nullptr;
-    RF_HIP(sc.get((void**)&d_idx, (size_t)cap * sizeof(uint32_t)));
-    RF_HIP(sc.get(&d_val, (size_t)cap * elem));
-
-    uint32_t count = 0;
-    bool in_index_order = true;
-    bool done = false, delivered = false;
+    // where the caller's arrays are filled: in place (device memory) or in a device copy that goes home at the end
     uint64_t* d_index64 = out_index;
     void* d_score = out_score;
     if (out_mem == RF_MEM_HOST && cap) {
         RF_HIP(sc.get((void**)&d_index64, (size_t)cap * sizeof(uint64_t)));
         RF_HIP(sc.get(&d_score, (size_t)cap * elem));
     }
-    // ---- the first road
+    // what the last kernel of a road reports: [0] results, [1] entries it saw, [2] 1 = too many for one workgroup, [4] an auxiliary device word -- into the calling
+    // thread's pinned slot (the host spins on the sequence number) or, without pinned memory, into device words that are copied home behind a synchronization
+    ResultSlot& slot = result_slot();
+    uint32_t* d_res = nullptr;
+    if (!slot.host) RF_HIP(sc.get((void**)&d_res, 8 * sizeof(uint32_t)));
+    auto report_target = [&]() { return slot.host ? (++slot.seq, const_cast<uint32_t*>(slot.host)) : d_res; };
+    auto await_report = [&](uint32_t h[5]) -> rf_status {
+        if (slot.host) {
+            uint32_t h3[3];
+            if (!await_slot(slot, st, h3)) {
+                set_error("rf_filter: the stream finished without the result kernel's report");
+                return RF_ERR_HIP;
+            }
+            h[0] = h3[0], h[1] = h3[1], h[2] = h3[2], h[4] = slot.host[4];
+            return RF_OK;
+        }
+        RF_HIP(hipMemcpyAsync(h, d_res, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RF_HIP(hipStreamSynchronize(st));
+        return RF_OK;
+    };
+    uint32_t count = 0;
+    bool delivered = false;  // the caller's (device) arrays hold the pairs, in the order asked for
+
+    // general compaction of `bound` entries (or *dev of them) -> the (index, value) pairs of the Somes, then whatever the order needs; ends with the report
+    uint32_t* d_idx = nullptr;
+    void* d_val = nullptr;
+    auto general = [&](const void* e_val, const uint32_t* e_map, uint32_t e_map_from, uint32_t e_bound, const uint32_t* e_dev, bool in_index_order, const uint32_t* aux_dev,
+                       uint32_t h[5], const std::function<void()>& enqueued) -> rf_status {
+        if (!d_idx) {
+            RF_HIP(sc.get((void**)&d_idx, (size_t)std::max(cap, 1u) * sizeof(uint32_t)));
+            RF_HIP(sc.get(&d_val, (size_t)std::max(cap, 1u) * elem));
+        }
+        const uint32_t n_seg = filter_segments(e_bound);
+        uint32_t* seg = nullptr;
+        void* temp = nullptr;
+        const size_t temp_bytes = filter_scan_temp_bytes(n_seg);
+        RF_HIP(sc.get((void**)&seg, ((size_t)n_seg + 1) * sizeof(uint32_t)));
+        RF_HIP(sc.get(&temp, temp_bytes));
+        RF_HIP(launch_filter_compact(e_val, f64_out, e_map, e_map_from, e_bound, e_dev, seg, temp, temp_bytes, cap, d_idx, d_val, st));
+        const uint32_t* d_count = seg + n_seg;
+        const bool need_sort = cap && (by_score || (order == RF_FILTER_BY_INDEX && !in_index_order));
+        if (!need_sort) {
+            // the widening runs before the host has seen the count
+            if (cap) RF_HIP(launch_filter_finish(d_idx, d_val, nullptr, f64_out, desc, cap, d_count, index_base, d_index64, d_score, st));
+            uint32_t* target = report_target();  // (its own statement: the sequence number is read after the increment)
+            RF_HIP(launch_filter_report(d_count, aux_dev, target, slot.seq, st));
+        } else {
+            // few results (the usual case under a cutoff): ordered and widened by one workgroup; else ([2] = 1) hipcub's radix sorts below
+            uint32_t* target = report_target();
+            RF_HIP(launch_filter_small(d_val, f64_out, d_idx, cap, d_count, by_score, desc, cap, index_base, d_index64, d_score, target, slot.seq, aux_dev, st));
+        }
+        if (enqueued) enqueued();
+        if (const rf_status rs = await_report(h); rs != RF_OK) return rs;
+        if (!need_sort) {
+            count = h[0];
+            delivered = true;
+            return RF_OK;
+        }
+        count = h[1];  // (the entries that kernel saw = the Somes the compaction counted)
+        if (h[2] == 0) {
+            delivered = true;
+            return RF_OK;
+        }
+        const uint32_t have = std::min(count, cap);
+        const uint32_t* idx_now = d_idx;
+        const void* val_now = d_val;
+        const void* key_now = nullptr;
+        void* stemp = nullptr;
+        const size_t stemp_bytes = filter_sort_temp_bytes(have);
+        RF_HIP(sc.get(&stemp, stemp_bytes));
+        if (!in_index_order) {  // (by score too: ties go by index, and the sort by score is stable)
+            uint32_t* idx2 = nullptr;
+            void* val2 = nullptr;
+            RF_HIP(sc.get((void**)&idx2, (size_t)have * sizeof(uint32_t)));
+            RF_HIP(sc.get(&val2, (size_t)have * elem));
+            RF_HIP(launch_filter_sort_by_index(idx_now, val_now, f64_out, have, idx2, val2, stemp, stemp_bytes, st));
+            idx_now = idx2, val_now = val2;
+        }
+        if (by_score) {
+            uint32_t* idx3 = nullptr;
+            void *key_in = nullptr, *key_out = nullptr;
+            RF_HIP(sc.get((void**)&idx3, (size_t)have * sizeof(uint32_t)));
+            RF_HIP(sc.get(&key_in, (size_t)have * sizeof(uint64_t)));
+            RF_HIP(sc.get(&key_out, (size_t)have * sizeof(uint64_t)));
+            RF_HIP(launch_filter_sort_by_score(idx_now, val_now, f64_out, desc, have, key_in, key_out, idx3, stemp, stemp_bytes, st));
+            idx_now = idx3, key_now = key_out;
+        }
+        RF_HIP(launch_filter_finish(idx_now, val_now, key_now, f64_out, desc, have, nullptr, index_base, d_index64, d_score, st));
+        if (out_mem == RF_MEM_DEVICE) RF_HIP(hipStreamSynchronize(st));  // (the scratch behind the sorts is released when this call returns)
+        delivered = true;
+        return RF_OK;
+    };
+
+    // ---- the first road: the survivors of the lane compaction (NOT in index order: the first pass deals tiles to its wavefronts round-robin)
+    bool second_road = true;
     {
         bool took = false;
         void* lane_val = nullptr;
@@ -134,32 +261,39 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
         std::unique_lock<std::mutex> held;
         if (const rf_status rs = filter_fast(c, corpus, op, args, f64_out, capacity, st, sc, &took, &lane_val, &lane_idx, &d_total, &cap2, &held); rs != RF_OK) return rs;
         if (took) {
-            const uint32_t n_seg = filter_segments(cap2);
-            uint32_t* seg = nullptr;
-            void* temp = nullptr;
-            const size_t temp_bytes = filter_scan_temp_bytes(n_seg);
-            RF_HIP(sc.get((void**)&seg, ((size_t)n_seg + 1) * sizeof(uint32_t)));
-            RF_HIP(sc.get(&temp, temp_bytes));
-            RF_HIP(launch_filter_compact(lane_val, f64_out, lane_idx, 0, cap2, d_total, seg, temp, temp_bytes, cap, d_idx, d_val, st));
-            // the survivors arrive in index order: unless the caller wants them by score, the widening runs before the host has seen the count (one
-            // synchronization per call instead of two)
-            const bool early_finish = order != RF_FILTER_BY_SCORE && cap != 0;
-            if (early_finish) RF_HIP(launch_filter_finish(d_idx, d_val, nullptr, f64_out, desc, cap, seg + n_seg, index_base, d_index64, d_score, st));
-            uint32_t h[2] = {0, 0};
-            RF_HIP(hipMemcpyAsync(&h[0], seg + n_seg, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            RF_HIP(hipMemcpyAsync(&h[1], d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            corpus_tile_list_done(corpus, st);
-            held.unlock();
-            RF_HIP(hipStreamSynchronize(st));
-            if (h[1] <= cap2) {  // every survivor had room: the count is the true one
-                count = h[0];
-                done = true;
-                delivered = early_finish;
-            }  // (else: more survivors than room -- the second road)
+            uint32_t h[5] = {0, 0, 1, 0, 0};
+            auto release = [&]() {  // everything that reads the tile-list buffer has been enqueued
+                corpus_tile_list_done(corpus, st);
+                held.unlock();
+            };
+            second_road = false;
+            if (corpus->filter_last_survivors.load(std::memory_order_relaxed) <= filter_small_max() && cap) {
+                // few survivors last time: everything in one workgroup -- select, order, widen, count
+                uint32_t* target = report_target();
+                RF_HIP(launch_filter_small(lane_val, f64_out, lane_idx, cap2, d_total, by_score, desc, cap, index_base, d_index64, d_score, target, slot.seq, d_total, st));
+                release();
+                if (const rf_status rs = await_report(h); rs != RF_OK) return rs;
+                corpus->filter_last_survivors.store(h[4], std::memory_order_relaxed);
+                if (h[2] == 0) {
+                    count = h[0];
+                    delivered = true;
+                } else if (h[4] <= cap2) {  // more survivors than one workgroup orders: the general compaction over them (their number is known now)
+                    if (const rf_status rs = general(lane_val, lane_idx, 0, h[4], nullptr, false, nullptr, h, nullptr); rs != RF_OK) return rs;
+                } else {
+                    second_road = true;  // more survivors than room
+                }
+            } else {
+                if (const rf_status rs = general(lane_val, lane_idx, 0, cap2, d_total, false, d_total, h, release); rs != RF_OK) return rs;
+                corpus->filter_last_survivors.store(h[4], std::memory_order_relaxed);
+                if (h[4] > cap2) {  // more survivors than room: what was compacted is a part of them
+                    second_road = true;
+                    delivered = false;
+                }
+            }
         }
     }
-    // ---- the second road
-    if (!done) {
+    // ---- the second road: the scan into a device vector -- in slot order for a length-bucketed corpus: no gather pass
+    if (second_road) {
         const bool slots = !corpus->uniform && corpus->d_orig && !corpus->borrowed && corpus->n_slots && !c->wide && !corpus->wide;
         const size_t m = slots ? corpus->n_slots : corpus->n;
         void* d_tmp = nullptr;
@@ -168,60 +302,17 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
         if (slots) a.flags |= RF_FLAG_SLOT_ORDER;
         else a.flags &= ~RF_FLAG_SLOT_ORDER;
         if (const rf_status rs = run_many(c, corpus, op, &a, d_tmp, RF_MEM_DEVICE, stream, f64_out); rs != RF_OK) return rs;
-        const uint32_t n_seg = filter_segments((uint32_t)m);
-        uint32_t* seg = nullptr;
-        void* temp = nullptr;
-        const size_t temp_bytes = filter_scan_temp_bytes(n_seg);
-        RF_HIP(sc.get((void**)&seg, ((size_t)n_seg + 1) * sizeof(uint32_t)));
-        RF_HIP(sc.get(&temp, temp_bytes));
-        RF_HIP(launch_filter_compact(d_tmp, f64_out, slots ? corpus->d_orig : nullptr, slots ? corpus->n_exact * (uint32_t)kWave : 0u, (uint32_t)m, nullptr, seg, temp, temp_bytes,
-                                     cap, d_idx, d_val, st));
-        in_index_order = !slots;
-        const bool early_finish = cap != 0 && (order == RF_FILTER_ANY || (order == RF_FILTER_BY_INDEX && in_index_order));
-        if (early_finish) RF_HIP(launch_filter_finish(d_idx, d_val, nullptr, f64_out, desc, cap, seg + n_seg, index_base, d_index64, d_score, st));
-        RF_HIP(hipMemcpyAsync(&count, seg + n_seg, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        RF_HIP(hipStreamSynchronize(st));
-        delivered = early_finish;
+        uint32_t h[5] = {0, 0, 1, 0, 0};
+        if (const rf_status rs = general(d_tmp, slots ? corpus->d_orig : nullptr, slots ? corpus->n_exact * (uint32_t)kWave : 0u, (uint32_t)m, nullptr, !slots, nullptr, h, nullptr); rs != RF_OK)
+            return rs;
     }
     *out_count = count;
     const uint32_t have = std::min(count, cap);
-    if (have == 0) return RF_OK;
-    if (!delivered) {
-        // ---- order, widen
-        const bool by_index = !in_index_order && order != RF_FILTER_ANY;
-        const bool by_score = order == RF_FILTER_BY_SCORE;
-        const uint32_t* idx_now = d_idx;
-        const void* val_now = d_val;
-        const void* key_now = nullptr;
-        if (by_index || by_score) {
-            void* temp = nullptr;
-            const size_t temp_bytes = filter_sort_temp_bytes(have);
-            RF_HIP(sc.get(&temp, temp_bytes));
-            if (by_index) {
-                uint32_t* idx2 = nullptr;
-                void* val2 = nullptr;
-                RF_HIP(sc.get((void**)&idx2, (size_t)have * sizeof(uint32_t)));
-                RF_HIP(sc.get(&val2, (size_t)have * elem));
-                RF_HIP(launch_filter_sort_by_index(idx_now, val_now, f64_out, have, idx2, val2, temp, temp_bytes, st));
-                idx_now = idx2, val_now = val2;
-            }
-            if (by_score) {
-                uint32_t* idx3 = nullptr;
-                void *key_in = nullptr, *key_out = nullptr;
-                RF_HIP(sc.get((void**)&idx3, (size_t)have * sizeof(uint32_t)));
-                RF_HIP(sc.get(&key_in, (size_t)have * sizeof(uint64_t)));
-                RF_HIP(sc.get(&key_out, (size_t)have * sizeof(uint64_t)));
-                RF_HIP(launch_filter_sort_by_score(idx_now, val_now, f64_out, desc, have, key_in, key_out, idx3, temp, temp_bytes, st));
-                idx_now = idx3, key_now = key_out;
-            }
-        }
-        RF_HIP(launch_filter_finish(idx_now, val_now, key_now, f64_out, desc, have, nullptr, index_base, d_index64, d_score, st));
-    }
-    if (out_mem == RF_MEM_HOST) {
+    if (have && out_mem == RF_MEM_HOST) {
         RF_HIP(hipMemcpyAsync(out_index, d_index64, (size_t)have * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         RF_HIP(hipMemcpyAsync(out_score, d_score, (size_t)have * elem, hipMemcpyDeviceToHost, st));
+        RF_HIP(hipStreamSynchronize(st));
     }
-    if (out_mem == RF_MEM_HOST || !delivered) RF_HIP(hipStreamSynchronize(st));
     return RF_OK;
 }
 

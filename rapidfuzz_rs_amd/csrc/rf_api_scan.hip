@@ -556,7 +556,7 @@ void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
 
 // words of a tile-list buffer: round 5's layout (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the
 // packed list) needs 2 n_tiles + 5 x 16384; the lane lists (rf_scan.hip lane_list_pack_kernel: 16-byte entries in the segments and in the packed list) four times the entries
-static size_t tile_list_words(uint32_t n_tiles) { return 8 * (size_t)n_tiles + 12 * 16384 + 64; }
+static size_t tile_list_words(uint32_t n_tiles) { return 9 * (size_t)n_tiles + 12 * 16384 + 64; }  // (+ one word per dense tile: lane_list_pack_kernel's first[])
 // the buffer serves the lane compaction (every buffer corpus_tile_list hands out does)
 void corpus_lane_buffers(const rf_corpus* corpus, ScanParams* p)
 {

@@ -133,6 +133,85 @@ __global__ void filter_finish_f64_kernel(const uint32_t* __restrict__ idx, const
     }
 }
 
+// ---- the whole of it in ONE workgroup when the entries are few (the usual case behind the lane compaction: a cutoff of a few edits leaves hundreds of survivors
+// in 100 M candidates): select the Somes, order them -- by index, or by (score, index) -- with a bitonic sort in LDS, widen the indices, write the caller's arrays
+// and the count.  res: [0] the Somes, [1] the entries there were, [2] 1 = too many entries for this kernel (nothing written: the general road).
+constexpr uint32_t kSmallMax = 2048, kSmallThreads = 256;
+template <class T>
+__global__ __launch_bounds__(kSmallThreads) void filter_small_kernel(const T* __restrict__ val, const uint32_t* __restrict__ map, uint32_t m_bound, const uint32_t* __restrict__ m_dev,
+                                                                     bool by_score, bool desc, uint32_t capacity, uint64_t index_base, uint64_t* __restrict__ out_index,
+                                                                     T* __restrict__ out_val, uint32_t* __restrict__ res, uint32_t seq, const uint32_t* __restrict__ aux_dev)
+{
+    __shared__ uint64_t k1[kSmallMax];  // primary key: 0 (by index) or the order-preserving image of the score
+    __shared__ uint32_t k2[kSmallMax];  // secondary key: the index
+    __shared__ uint64_t pv[kSmallMax];  // the value's bits
+    __shared__ uint32_t n_some;
+    const uint32_t m_all = m_dev ? *m_dev : m_bound;
+    // res may be pinned HOST memory the caller spins on (rf_api_filter.hip): the words first, then -- system scope, release -- the call's sequence number
+    if (m_all > kSmallMax || m_all > m_bound) {
+        if (threadIdx.x == 0) {
+            res[0] = 0, res[1] = m_all, res[2] = 1, res[4] = aux_dev ? *aux_dev : 0u;
+            __hip_atomic_store(&res[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (threadIdx.x == 0) n_some = 0;
+    __syncthreads();
+    // the Somes, in whatever order the atomic hands out places: the sort below is what orders them
+    for (uint32_t e = threadIdx.x; e < m_all; e += kSmallThreads) {
+        const T v = val[e];
+        const uint32_t idx = map ? map[e] : e;
+        if (some(v) && idx != kPad) {
+            uint64_t a, bits;
+            if constexpr (sizeof(T) == 8) {
+                bits = (uint64_t)__double_as_longlong(v);
+                const uint64_t b = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+                a = by_score ? (desc ? ~b : b) : 0ull;
+            } else {
+                bits = v;
+                a = by_score ? (uint64_t)(desc ? ~(uint32_t)v : (uint32_t)v) : 0ull;
+            }
+            const uint32_t at = atomicAdd(&n_some, 1u);
+            k1[at] = a, k2[at] = idx, pv[at] = bits;
+        }
+    }
+    __syncthreads();
+    const uint32_t count = n_some;
+    uint32_t width = 1;  // the sort's width: the next power of two (hundreds of results at most, usually: a few dozen compare-exchange rounds)
+    while (width < count) width <<= 1;
+    for (uint32_t e = count + threadIdx.x; e < width; e += kSmallThreads) k1[e] = ~0ull, k2[e] = kPad, pv[e] = 0;  // padding sorts behind every result
+    __syncthreads();
+    // bitonic sort of `width` entries by (k1, k2) ascending
+    for (uint32_t k = 2; k <= width; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < width / 2; t += kSmallThreads) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;  // the pair (i, i + j) this thread compares
+                const bool up = (i & k) == 0;
+                const uint64_t a1 = k1[i], b1 = k1[l];
+                const uint32_t a2 = k2[i], b2 = k2[l];
+                const bool greater = a1 > b1 || (a1 == b1 && a2 > b2);
+                if (greater == up) {
+                    const uint64_t pa = pv[i], pb = pv[l];
+                    k1[i] = b1, k1[l] = a1, k2[i] = b2, k2[l] = a2, pv[i] = pb, pv[l] = pa;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t e = threadIdx.x; e < count && e < capacity; e += kSmallThreads) {
+        out_index[e] = index_base + k2[e];
+        if constexpr (sizeof(T) == 8)
+            out_val[e] = __longlong_as_double((long long)pv[e]);
+        else
+            out_val[e] = (uint32_t)pv[e];
+    }
+    __threadfence_system();  // (the caller's arrays are complete before the host can see the sequence number)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        res[0] = count, res[1] = m_all, res[2] = 0, res[4] = aux_dev ? *aux_dev : 0u;  // (aux: a device word that comes home with the report)
+        __hip_atomic_store(&res[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace
 
 uint32_t filter_segments(uint32_t m_bound) { return (m_bound + kSeg - 1) / kSeg; }
@@ -164,6 +243,30 @@ hipError_t launch_filter_compact(const void* val, bool f64, const uint32_t* map,
         hipLaunchKernelGGL(filter_emit_kernel<uint32_t>, g2, b, 0, st, (const uint32_t*)val, map, m_bound, m_dev, n_seg, seg, capacity, out_idx, (uint32_t*)out_val);
     return hipGetLastError();
 }
+
+// two device words to the report slot (count and an auxiliary word), for the roads that need no ordering kernel
+__global__ void filter_report_kernel(const uint32_t* __restrict__ a_dev, const uint32_t* __restrict__ aux_dev, uint32_t* __restrict__ res, uint32_t seq)
+{
+    res[0] = a_dev ? *a_dev : 0u, res[1] = res[0], res[2] = 0, res[4] = aux_dev ? *aux_dev : 0u;
+    __hip_atomic_store(&res[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_filter_report(const uint32_t* a_dev, const uint32_t* aux_dev, uint32_t* res, uint32_t seq, hipStream_t st)
+{
+    hipLaunchKernelGGL(filter_report_kernel, dim3(1), dim3(1), 0, st, a_dev, aux_dev, res, seq);
+    return hipGetLastError();
+}
+hipError_t launch_filter_small(const void* val, bool f64, const uint32_t* map, uint32_t m_bound, const uint32_t* m_dev, bool by_score, bool desc, uint32_t capacity,
+                               uint64_t index_base, uint64_t* out_index, void* out_val, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, hipStream_t st)
+{
+    if (f64)
+        hipLaunchKernelGGL(filter_small_kernel<double>, dim3(1), dim3(kSmallThreads), 0, st, (const double*)val, map, m_bound, m_dev, by_score, desc, capacity, index_base, out_index,
+                           (double*)out_val, res, seq, aux_dev);
+    else
+        hipLaunchKernelGGL(filter_small_kernel<uint32_t>, dim3(1), dim3(kSmallThreads), 0, st, (const uint32_t*)val, map, m_bound, m_dev, by_score, desc, capacity, index_base,
+                           out_index, (uint32_t*)out_val, res, seq, aux_dev);
+    return hipGetLastError();
+}
+uint32_t filter_small_max() { return kSmallMax; }
 
 // ---- ordering `count` compact results (all arrays on the device; the sorts are hipcub's stable radix sorts)
 size_t filter_sort_temp_bytes(uint32_t count)

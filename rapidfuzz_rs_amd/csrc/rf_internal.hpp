@@ -114,6 +114,7 @@ struct ScanParams {
     // survivors each, every lane reading its own candidate's chunk rows -- a corpus in which 2 % of the candidates share the query's head keeps 73 % of its TILES
     // alive and 2 % of its lanes.  lane_list = 1: tile_list_buf is large enough for the 16-byte entries (corpus_tile_list); 0 = round 5's tile list.
     uint32_t lane_list;
+    const uint32_t* lane_first;  // sparse_lean_kernel: per dense tile j the packed entry that holds survivor 64 j (lane_list_pack_kernel writes it)
     // ... and where the survivors' results go when the caller wants no dense vector (rf_filter_*): lane_val[g] (u32 or f64 by out_f64; None = beyond the cutoff) and
     // lane_idx[g] = candidate index for survivor g < lane_cap (the number of survivors -- tile_list_buf[1] -- may exceed lane_cap: the host then takes another road)
     void* lane_val;
@@ -238,6 +239,10 @@ uint32_t filter_segments(uint32_t m_bound);
 size_t filter_scan_temp_bytes(uint32_t n_seg);
 hipError_t launch_filter_compact(const void* val, bool f64, const uint32_t* map, uint32_t map_from, uint32_t m_bound, const uint32_t* m_dev, uint32_t* seg, void* temp,
                                  size_t temp_bytes, uint32_t capacity, uint32_t* out_idx, void* out_val, hipStream_t st);
+hipError_t launch_filter_small(const void* val, bool f64, const uint32_t* map, uint32_t m_bound, const uint32_t* m_dev, bool by_score, bool desc, uint32_t capacity,
+                               uint64_t index_base, uint64_t* out_index, void* out_val, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, hipStream_t st);  // everything in one workgroup when the entries are few
+hipError_t launch_filter_report(const uint32_t* a_dev, const uint32_t* aux_dev, uint32_t* res, uint32_t seq, hipStream_t st);
+uint32_t filter_small_max();
 size_t filter_sort_temp_bytes(uint32_t count);
 hipError_t launch_filter_sort_by_index(const uint32_t* idx_in, const void* val_in, bool f64, uint32_t count, uint32_t* idx_out, void* val_out, void* temp, size_t temp_bytes,
                                        hipStream_t st);

@@ -280,48 +280,43 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
             const uint32_t t0 = p.tile_begin + 2 * pr;
             uint64_t m = ~0ull;
             if constexpr (kLanes) {
-                // the band test and the look per LANE: a lane survives when its own symbols pass both (each is a necessary condition per candidate)
+                // Who survives the pass, per LANE.  With the band test on: whoever passes IT -- the look is not run here at all: on a random corpus one candidate in
+                // a thousand passes the band test and the second pass disposes of it at its first chunk end, while on a corpus that shares prefixes with the query the
+                // look (~150 instructions per pair, all lanes, whenever ONE lane passed the band test) made this streaming pass VALU-bound: 119 -> 236 us per 100 M at
+                // 1 % prefix sharers (profiles/survivors_r06.txt).  Without a band test (cutoffs of 4..5 edits): whoever passes the look, as before.
                 const bool tile_ok = lane < 32 || t0 + 1 < p.tile_end;  // (an odd tile count: the last pair's second half is the plane's pad row)
-                bool pa = tile_ok, pb = tile_ok;
+                const uint32_t ia = t0 * kWave + 2 * lane;              // (lanes 32..63 run on into tile t0 + 1)
+                bool pa = tile_ok && ia < p.n, pb = tile_ok && ia + 1 < p.n;
                 if (need) {
-                    pa = tile_ok && band_hits(lds_band, cur.x, cur.y) >= need;
-                    pb = tile_ok && band_hits(lds_band, cur.z, cur.w) >= need;
-                    m = __ballot(pa || pb);
-                }
-                uint64_t mask0 = 0, mask1 = 0;
-                if (m != 0) {
+                    pa = pa && band_hits(lds_band, cur.x, cur.y) >= need;
+                    pb = pb && band_hits(lds_band, cur.z, cur.w) >= need;
+                } else {
                     Look a, b;
                     a.init();
                     b.init();
                     process_chunk_full<Look, 0, kFirst, kLookPitch>(a, pm, make_uint4(cur.x, cur.y, 0u, 0u));
                     process_chunk_full<Look, 0, kFirst, kLookPitch>(b, pm, make_uint4(cur.z, cur.w, 0u, 0u));
-                    const uint32_t ia = t0 * kWave + 2 * lane;  // (lanes 32..63 run on into tile t0 + 1)
-                    pa = pa && ia < p.n && may_pass(p, fin, a.bound_first(len1, kFirst, len2));
-                    pb = pb && ia + 1 < p.n && may_pass(p, fin, b.bound_first(len1, kFirst, len2));
-                    if (__ballot(pa || pb) != 0) {
-                        // bit k of a tile's mask = its candidate k, which sits in lane k / 2 (+ 32 for the pair's second tile), slot k & 1
-                        const int v = (pa ? 1 : 0) | (pb ? 2 : 0);
-                        const int s0 = __shfl(v, (int)(lane >> 1), kWave), s1 = __shfl(v, (int)(32 + (lane >> 1)), kWave);
-                        mask0 = __ballot((s0 >> (lane & 1)) & 1);
-                        mask1 = __ballot((s1 >> (lane & 1)) & 1);
-                    }
+                    pa = pa && may_pass(p, fin, a.bound_first(len1, kFirst, len2));
+                    pb = pb && may_pass(p, fin, b.bound_first(len1, kFirst, len2));
                 }
-                if (p.out && !p.run_orig) {  // (a length run of a bucketed corpus: `out` is pre-filled with None)
-                    if ((mask0 | mask1) == 0) {  // the common case as before: the whole pair is None
-                        const uint32_t idx = t0 * kWave + 2 * lane;
-                        if (tile_ok) {
-                            if (!p.out_f64 && idx + 1 < p.n) {
-                                *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.out) + idx) = make_uint2(RF_NONE_U32, RF_NONE_U32);
-                            } else {
-                                if (idx < p.n) emit_none(p, idx);
-                                if (idx + 1 < p.n) emit_none(p, idx + 1);
-                            }
-                        }
-                    } else if (tile_ok) {  // a pair with survivors: the None of every OTHER candidate (the second pass writes the survivors')
-                        const uint32_t idx = t0 * kWave + 2 * lane;
-                        const bool sa = (m != 0) && pa, sb = (m != 0) && pb;
-                        if (!sa && idx < p.n) emit_none(p, idx);
-                        if (!sb && idx + 1 < p.n) emit_none(p, idx + 1);
+                m = __ballot(pa || pb);
+                uint64_t mask0 = 0, mask1 = 0;
+                if (m != 0) {
+                    // bit k of a tile's mask = its candidate k, which sits in lane k / 2 (+ 32 for the pair's second tile), slot k & 1
+                    const int v = (pa ? 1 : 0) | (pb ? 2 : 0);
+                    const int s0 = __shfl(v, (int)(lane >> 1), kWave), s1 = __shfl(v, (int)(32 + (lane >> 1)), kWave);
+                    mask0 = __ballot((s0 >> (lane & 1)) & 1);
+                    mask1 = __ballot((s1 >> (lane & 1)) & 1);
+                }
+                if (p.out && !p.run_orig && tile_ok) {  // (a length run of a bucketed corpus: `out` is pre-filled with None)
+                    // None for the whole pair, survivors included: one coalesced 8-byte store per lane whatever the masks say -- the second pass runs behind this
+                    // kernel and overwrites the survivors that pass (per-lane stores around the survivors cost the 1 % corpus 60 us per 100 M)
+                    const uint32_t idx = t0 * kWave + 2 * lane;
+                    if (!p.out_f64 && idx + 1 < p.n) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.out) + idx) = make_uint2(RF_NONE_U32, RF_NONE_U32);
+                    } else {
+                        if (idx < p.n) emit_none(p, idx);
+                        if (idx + 1 < p.n) emit_none(p, idx + 1);
                     }
                 }
                 // the list: one 16-byte entry per surviving tile -- tile, its lane mask, (filled in by the pack kernel) the survivors in front of it
@@ -431,8 +426,10 @@ __global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restric
 
 // The same for the LANE lists of head_filter_kernel<..., kLanes = true> (round 6): 16-byte entries (tile, lane mask lo / hi, -), two counts per segment -- tiles and
 // surviving lanes -- and two running sums: an entry's last word becomes the number of survivors in front of it, which is what rf_sparse.hip searches.
-// buf: [0] packed entries | [1] survivors | 2 pad | G tile counts | G lane counts | G segments of `cap` entries | the packed entries
-__global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap)
+// first[j] = the packed entry that holds survivor 64 j: where dense tile j of the second pass starts looking (every entry holds >= 1 survivor, so the 64 entries
+// from there on hold all of the tile's 64).
+// buf: [0] packed entries | [1] survivors | 2 pad | G tile counts | G lane counts | G segments of `cap` entries | the packed entries | first[]
+__global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap, uint32_t* __restrict__ first_of)
 {
     constexpr uint32_t kWaves = 256 / kWave;
     __shared__ uint32_t own[kWaves], front[kWaves], own_l[kWaves], front_l[kWaves];
@@ -476,7 +473,9 @@ __global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restric
             uint4 e = seg[j];
             e.w = lat;
             packed[at + j] = e;
-            lat += (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z);
+            const uint32_t c = (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z), k = (lat + kWave - 1) / kWave;  // (c <= 64: at most one multiple of 64 in [lat, lat + c))
+            if (k * kWave < lat + c) first_of[k] = at + j;
+            lat += c;
         }
     }
     if (first + 256 >= G && threadIdx.x == 0) {
@@ -1098,10 +1097,13 @@ static hipError_t launch_state(const ScanParams& p, hipStream_t stream, int grid
                                 hipLaunchKernelGGL((head_filter_kernel<State, J, true, true>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap4); \
                             else                                                           \
                                 hipLaunchKernelGGL((head_filter_kernel<State, J, false, true>), dim3(fgrid), b, 0, stream, pn, p.tile_list_buf, cap4); \
-                            hipLaunchKernelGGL(lane_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap4); \
+                            uint32_t* packed_at = p.tile_list_buf + 4 + 2 * (size_t)G + 4 * (size_t)G * cap4; \
+                            uint32_t* first_at = packed_at + 4 * (size_t)(2 * pairs + 2);   \
+                            hipLaunchKernelGGL(lane_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, p.tile_list_buf, G, cap4, first_at); \
                             ScanParams p2 = pn;                                            \
                             p2.heads8 = nullptr;                                           \
-                            p2.tile_list = p.tile_list_buf + 4 + 2 * (size_t)G + 4 * (size_t)G * cap4; \
+                            p2.tile_list = packed_at;                                      \
+                            p2.lane_first = first_at;                                      \
                             p2.tile_list_count = p.tile_list_buf;                          \
                             hipError_t el = hipGetLastError();                             \
                             if (el == hipSuccess) el = launch_sparse_lean(std::is_same<State, Lev32State>::value ? 1 : (std::is_same<State, OsaState<1>>::value ? 2 : 0), p2, stream); \

@@ -24,19 +24,6 @@ namespace rf {
 
 namespace {
 
-// largest e in [0, hi) with list[e].w <= x (the entries' running sums ascend, list[0].w = 0)
-__device__ __forceinline__ uint32_t last_le(const uint4* __restrict__ list, uint32_t hi, uint32_t x)
-{
-    uint32_t lo = 0;
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (list[mid].w <= x)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    return lo;
-}
 // position of the k-th (0-based) set bit of m (m has more than k set bits)
 __device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t k)
 {
@@ -74,19 +61,22 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
 {
     __shared__ typename State::Word lds_pm[256];
     __shared__ uint64_t lds_topk[kWavesPerBlock][kWave];
+    const uint4* __restrict__ list = reinterpret_cast<const uint4*>(p.tile_list);  // (tile, lane mask lo, hi, survivors in front): lane_list_pack_kernel
+    const uint32_t entries = uniform(p.tile_list_count[0]), total = uniform(p.tile_list_count[1]);
+    const uint32_t n_dense = (total + kWave - 1) / kWave;
+    const bool topk = p.topk_k != 0;
+    // (the survivors' number is only known here: the grid is sized for many, and a workgroup without a dense tile leaves before it stages the table -- unless the
+    // launch keeps top-k lists, whose selection counts the workgroups in)
+    if (!topk && blockIdx.x * kWavesPerBlock >= n_dense) return;
     for (int i = threadIdx.x; i < 256; i += kWave * kWavesPerBlock) lds_pm[p.sigma[i]] = (typename State::Word)p.pm[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
-    const bool topk = p.topk_k != 0;
     WaveTopK best;
     best.init();
     uint64_t limit = ~0ull;
     uint32_t tiles_done = 0;
 
-    const uint4* __restrict__ list = reinterpret_cast<const uint4*>(p.tile_list);  // (tile, lane mask lo, hi, survivors in front): lane_list_pack_kernel
-    const uint32_t entries = uniform(p.tile_list_count[0]), total = uniform(p.tile_list_count[1]);
-    const uint32_t n_dense = (total + kWave - 1) / kWave;
     const uint32_t len1 = p.len1, len2 = p.uniform_len;
     const uint32_t nch = (len2 + kChunk - 1) / kChunk;
     const TileFin fin = tile_fin(p, len1, len2);
@@ -96,9 +86,23 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
         const uint32_t g = j * kWave + lane;
         s.have = g < total;
         const uint32_t gg = s.have ? g : total - 1;  // (idle lanes of the last dense tile shadow its last survivor: defined bytes, no result)
-        const uint4 e = list[last_le(list, entries, gg)];
-        const uint32_t ls = nth_set_bit(((uint64_t)e.z << 32) | e.y, gg - e.w);
-        const uint32_t t = e.x;
+        // the 64 entries from first[j] on hold all 64 survivors of this dense tile (an entry holds at least one): one coalesced load, then the lane's own entry --
+        // the last one whose running sum is <= its survivor number -- by a binary search across the LANES (the sums ascend with the lane)
+        const uint32_t e0 = uniform(p.lane_first[j]);
+        const uint4 ent = list[min(e0 + lane, entries - 1)];
+        uint32_t lo = 0, hi = kWave;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t wm = (uint32_t)__shfl((int)ent.w, (int)mid, kWave);
+            if (wm <= gg)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t t = (uint32_t)__shfl((int)ent.x, (int)lo, kWave), mlo = (uint32_t)__shfl((int)ent.y, (int)lo, kWave), mhi = (uint32_t)__shfl((int)ent.z, (int)lo, kWave),
+                       w = (uint32_t)__shfl((int)ent.w, (int)lo, kWave);
+        const uint32_t ls = nth_set_bit(((uint64_t)mhi << 32) | mlo, gg - w);
         s.idx = t * kWave + ls;
         s.src = reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes) + ls;
         return s;
@@ -187,7 +191,8 @@ hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, hipStream_t s
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const uint32_t tiles = p.tile_end > p.tile_begin ? p.tile_end - p.tile_begin : 1u;
-    const uint32_t want = (uint32_t)cus * 8u, most = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    // (a wavefront per dense tile while they are few: a tile is a chain of dependent loads -- list entry, chunk rows -- and the workgroups beyond the survivors leave at once)
+    const uint32_t want = (uint32_t)cus * (p.topk_k ? 8u : 32u), most = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 g(std::max(1u, std::min(want, most))), b(kWave * kWavesPerBlock);
     switch (state_kind) {
     case 0: hipLaunchKernelGGL((sparse_lean_kernel<LevState<1>>), g, b, 0, stream, p); break;

@@ -206,7 +206,7 @@ def test_filter_large_single_length_corpus_takes_the_lane_compaction(share):
 
 def test_filter_when_the_survivors_outgrow_their_room():
     """Every candidate carries the query's head (share 1.0): the first pass keeps all 2.1 M lanes, more than the room the fast road gives its survivors
-    (max(n / 8, 4 x capacity)) -- the call must notice on the device-side count and take the general road: same pairs."""
+    (max(n / 4, 4 x capacity)) -- the call must notice on the device-side count and take the general road: same pairs."""
     n = 1_100_000
     q, rows = _prefix_corpus(n, 64, 1.0, seed=17)
     corpus = rf.Corpus.from_rows(rows)
