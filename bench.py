@@ -60,6 +60,9 @@ def parse():
                     help="c2 = BASELINE.json configs[1] (the default workload); c5 = configs[4]: 1 B candidates split over the ranks, "
                          "score_cutoff 3, top-16, all-gather every step")
     ap.add_argument("--total-candidates", type=int, default=1_000_000_000, help="size of the logical corpus of --config c5")
+    ap.add_argument("--shard", default="range", choices=["range", "dealt"],
+                    help="--config c5: how the logical corpus is split over the ranks -- contiguous ranges (parallel.shard_range) or dealt by parallel.shard_ragged (every "
+                         "length bucket to all ranks; local indices mapped to original ones before the exchange).  Same merged top-k either way (topk_checksum)")
     ap.add_argument("--settle-ms", type=float, default=200.0,
                     help="untimed steps run for this long BEFORE the W warm-up steps: after the idle set-up phase the GPU's clock takes "
                          "~15 back-to-back launches to ramp (profiles/clock_ramp_r02.txt); 0 = off.  Reported as config.settle_steps")
@@ -152,6 +155,12 @@ def main():
         args.cand_len, args.query_len, args.weights, args.fcutoff = 64, 64, None, None
         shard_lo, shard_hi = parallel.shard_range(args.total_candidates, rank, world)
         args.candidates = shard_hi - shard_lo
+        dealt_index = None
+        if args.shard == "dealt":
+            if args.total_candidates > 200_000_000:
+                raise SystemExit("bench.py: --shard dealt generates the whole logical corpus on every rank before it takes its share: --total-candidates <= 200 M")
+            dealt_index = parallel.shard_ragged(np.arange(args.total_candidates + 1, dtype=np.uint64) * np.uint64(args.cand_len), rank, world)
+            args.candidates = len(dealt_index)
     n, ln = args.candidates, args.cand_len
     q = synth.query(args.query_len, 0xC0FFEE05 if c5 else 0xC0FFEE02)
     mod = getattr(rf.distance, args.metric)
@@ -167,6 +176,14 @@ def main():
         rows = synth.rows_device_range(shard_lo, shard_hi, ln, seed=0xC0FFEE05, device=dev, symbols=args.symbols, q=q, plant_every=args.plant_every,
                                        head_share=args.head_share)
         index_base = shard_lo
+        if dealt_index is not None:  # this rank's DEALT share of the same logical corpus; its top-k keys carry local indices until step() maps them
+            del rows
+            whole = synth.rows_device_range(0, args.total_candidates, ln, seed=0xC0FFEE05, device=dev, symbols=args.symbols, q=q, plant_every=args.plant_every,
+                                            head_share=args.head_share)
+            dealt_t = torch.from_numpy(dealt_index.astype(np.int64)).to(dev)
+            rows = whole[dealt_t].contiguous()
+            del whole
+            index_base = 0
     else:
         rows = synth.rows_device(n, ln, seed=0xC0FFEE02 + 7919 * rank, device=dev, symbols=args.symbols, zipf_s=args.zipf)
         if args.head_share > 0:
@@ -304,6 +321,12 @@ def main():
                 # on the host, because a cross-queue wait enqueued on the scan stream costs a barrier packet every step
             scorer.topk_keys_device(corpus, args.topk, local_keys[buf], N.OP_DISTANCE, call_args, index_base=index_base,
                                     out=out if args.mode == "many" else None, stream=stream.cuda_stream)
+            if c5 and dealt_index is not None:
+                # a dealt shard: (distance, LOCAL index) keys -> (distance, original index); the map ascends, so the list stays sorted
+                kk = local_keys[buf]
+                live = kk != -1
+                loc = (kk & 0xFFFFFFFF).clamp_(max=n - 1)
+                local_keys[buf].copy_(torch.where(live, (kk & ~0xFFFFFFFF) | dealt_t[loc], kk))
             if world > 1 or force_dist:
                 if test_gloo:
                     host = [torch.empty(args.topk, dtype=torch.int64) for _ in range(world)]
@@ -484,7 +507,8 @@ def main():
             "queries": nq,
             "output": (("f64" if is_f64 else "u32") + " per candidate, device-resident" if args.mode == "many" else
                        (f"(index, score) pairs of the candidates within the cutoff, device-resident, room for {args.capacity}" if args.mode == "filter" else f"top-{args.topk} only")),
-            "parallelism": f"corpus sharded over {world} GPU(s), top-{args.topk} all-gather" if (world > 1 or force_dist) else "1 GPU",
+            "parallelism": (f"corpus sharded over {world} GPU(s)" + (" by parallel.shard_ragged (dealt)" if c5 and args.shard == "dealt" else "") + f", top-{args.topk} all-gather")
+                           if (world > 1 or force_dist) else "1 GPU",
             "ranks_joined": joined,
             **({"rccl_ranks": dist.get_world_size(), "collective": "ncclAllGather via torch.distributed (backend nccl = RCCL)"}
                if (world > 1 or force_dist) and not test_gloo else {}),
@@ -583,11 +607,36 @@ def main():
                 result["roofline"]["issue_bound"]["core_clock_ghz"] = {"skipped": str(exc)[:200]}
 
     ib = result["roofline"].get("issue_bound")
+    if ib and (pack6 or pack6_ragged):
+        #  rf_probe_issue_rate runs the COMPILED 8-bit LcsState column; these runs execute the whole-kernel asm scans over the 6-bit payload
+        # (rf_stream_asm.hip stream_lcs6[n]_*), whose column was measured register-only at 21.0 cycles (64-bit words) / 11.0 cycles (32-bit words: queries <= 32) --
+        # profiles/lcs_cycles_r05.txt.  The ceiling that applies is that column at the clock THIS run sampled under the scan (the package power cap holds it near
+        # 1.84 GHz here); beside it: what the scan moves against what a pure streaming read achieves on this part (~6.3 TB/s, tools/membw.hip).
+        col_cycles = 11.0 if args.query_len <= 32 else 21.0
+        clk = (ib.get("core_clock_ghz") or {}).get("under_scan")
+        if clk:
+            import ctypes as _ct
+
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            asm_ceiling = cus * 4 * clk / col_cycles * 64.0 / max(ln, 1)  # SIMDs x GHz / cycles per wave-column = wave-columns per ns -> Gpairs/s at this length
+            per_gpu = gpairs / world
+            ib["asm_column"] = {"cycles_per_column": col_cycles, "source": "profiles/lcs_cycles_r05.txt (register-only microbenchmark of the 6-bit asm column)",
+                                "ceiling_at_scan_clock": round(asm_ceiling, 2), "frac": round(per_gpu / asm_ceiling, 4)}
+            moved = result["roofline"].get("moved", {}).get("achieved")
+            if moved:
+                ib["asm_column"]["moved_frac_of_streaming_read"] = round(moved / 6300.0, 4)
+            # the compiled column's figures above describe a kernel this run did not execute: the asm column decides the label
+            ib["frac"] = ib["asm_column"]["frac"]
+            ib.pop("ratio_to_probe_at_scan_clock", None)
+            if ib["asm_column"]["frac"] < 0.8 and moved and moved / 6300.0 >= 0.75:
+                result["roofline"]["bound_note"] = "HBM on the 6-bit payload: the scan moves >= 0.75 of what a streaming read achieves on this part and sits below 0.8 of its column's issue ceiling"
     if ib and max(ib.get("frac", 0.0), ib.get("ratio_to_probe_at_scan_clock", 0.0)) >= 0.8:
         # a kernel this JSON itself shows at >= 0.8 of its measured VALU-issue ceiling is issue-bound, not HBM-bound.  `frac` stays
         # achieved / HBM peak (the north star's yardstick, and the contract's); `issue_bound.frac` is the fraction of the bound that binds.
         result["roofline"]["bound"] = "valu_issue"
         result["roofline"]["bound_note"] = "frac = algorithmic bytes / kernel time / HBM peak (the north star's yardstick); the binding limit is VALU issue: issue_bound.frac"
+        if ib.get("package_power_w_under_scan") and (ib.get("core_clock_ghz") or {}).get("under_scan", 9.9) < 2.0:
+            result["roofline"]["bound_note"] += f"; at a core clock the package power cap holds to {ib['core_clock_ghz']['under_scan']} GHz ({ib['package_power_w_under_scan']} W drawn)"
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,
@@ -774,7 +823,7 @@ def extra_configs(args):
             d = json.loads(lines[-1])
             rl = d["roofline"]
             leg.update({"value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
-                        "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_pair", "survey_8d") if k in rl},
+                        "roofline": {k: rl[k] for k in ("bound", "bound_note", "achieved", "peak", "unit", "frac", "kernel_ms", "algorithmic_bytes_per_pair", "survey_8d", "moved") if k in rl},
                         "parity": d.get("parity"), "cpu_baseline": {k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")} if "cpu_baseline" in d else None})
             par = d.get("parity") or {}
             leg["summary"] = (f"{d['value']} Gpairs/s, {d['ms_per_step']} ms/step, {rl['frac']} of HBM peak"

@@ -763,7 +763,7 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
         if (!p1.long_words_pad && p1.words <= (uint32_t)kMaxWords && p1.tile_end > p1.tile_begin) {  // (the sample runs the register-resident scan: queries of <= 512 symbols)
             if (const rf_status rs = comparator_device_pm(c, corpus->device, &p1.pm); rs != RF_OK) return rs;
             p1.out = d_out;
-            p1.prefill_none = 0;
+            p1.prefill_none = 1;  // (the count below reads out[]; a tile the cutoff kernel abandons without storing must read as None, not as stale bytes)
             p1.band = 0;  // (the compiled LevState<W> scan under the same cutoff: the same values, and it walks every tile_step-th tile)
             p1.mixed = nullptr, p1.mixed_begin = p1.mixed_end = 0;  // (the views of the mixed section are ordinary tiles to that kernel)
             p1.heads8 = nullptr, p1.heads6 = nullptr;
@@ -955,17 +955,17 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
             rf_args a = *args;
             a.cutoff_usize = RF_NO_CUTOFF;
             a.score_hint_usize = RF_NO_CUTOFF;
+            // (the temporaries are optional -- no room for them is not an error, the compiled f64 scan below needs none: same values)
             uint32_t* d_dist = nullptr;
-            RF_HIP(scratch_alloc((void**)&d_dist, corpus->n * sizeof(uint32_t), st));
-            const rf_status rs = run_many(c_in, corpus_in, RF_OP_DISTANCE, &a, d_dist, RF_MEM_DEVICE, st, false);
             double* d_out = static_cast<double*>(out);
-            if (rs == RF_OK && out_mem == RF_MEM_HOST) {
-                const hipError_t ea = scratch_alloc((void**)&d_out, corpus->n * sizeof(double), st);
-                if (ea != hipSuccess) {
-                    scratch_free(d_dist, st);
-                    RF_HIP(ea);
-                }
+            bool have_tmp = scratch_alloc((void**)&d_dist, corpus->n * sizeof(uint32_t), st) == hipSuccess;
+            if (have_tmp && out_mem == RF_MEM_HOST && scratch_alloc((void**)&d_out, corpus->n * sizeof(double), st) != hipSuccess) {
+                scratch_free(d_dist, st);
+                have_tmp = false;
             }
+            if (!have_tmp) (void)hipGetLastError();
+          if (have_tmp) {
+            const rf_status rs = run_many(c_in, corpus_in, RF_OP_DISTANCE, &a, d_dist, RF_MEM_DEVICE, st, false);
             hipError_t e = hipSuccess;
             if (rs == RF_OK) e = launch_normalize(d_dist, len_of, corpus->uniform_len, d_out, (uint32_t)corpus->n, p.len1, p.fin_mS, p.fin_mM, p.op, p.has_cutoff, p.cutoff_f64, st);
             scratch_free(d_dist, st);
@@ -977,12 +977,18 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
             if (rs != RF_OK) return rs;
             RF_HIP(e);
             return RF_OK;
+          }
         }
     }
     {
         uint32_t k1 = 0, factor = 1;
-        if (corpus == corpus_in && !want_slots && hint_pass_applies(c, corpus, op, args, f64_out, &k1, &factor))
-            return run_many_hinted(c_in, corpus_in, c, corpus, args, static_cast<uint32_t*>(out), out_mem, st, k1, factor);
+        if (corpus == corpus_in && !want_slots && hint_pass_applies(c, corpus, op, args, f64_out, &k1, &factor)) {
+            const rf_status rs = run_many_hinted(c_in, corpus_in, c, corpus, args, static_cast<uint32_t*>(out), out_mem, st, k1, factor);
+            if (rs != RF_ERR_OOM) return rs;
+            //  no room for the hinted passes' temporaries (masks, sums, dense tiles): not an error -- the plain scan below needs none and returns
+            // the same values (results never depend on the hint, levenshtein.rs:2153-2160)
+            (void)hipGetLastError();
+        }
     }
     p.heads8 = corpus_head8_plane(corpus, p, raw, st);
     p.heads6 = p.heads8 ? corpus_head6_plane(corpus, st) : nullptr;

@@ -38,15 +38,36 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const T* __restrict__
     uint32_t cnt = 0;
     if (s < n_seg) {
         const uint32_t base = s * kSeg;
+        constexpr uint32_t kPer = 16 / sizeof(T);  // entries per 16-byte load
+        if (base + kSeg <= m && !(map && base + kSeg > map_from)) {
+            // a whole segment that needs no map: 16 bytes per lane and load (counting does not care which lane sees which entry)
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            const v4u* src = reinterpret_cast<const v4u*>(val + base);
 #pragma unroll 4
-        for (uint32_t r = 0; r < kSegRounds; ++r) {
-            const uint32_t e = base + r * kWave + lane;
-            bool sel = false;
-            if (e < m) {
-                sel = some(val[e]);
-                if (sel && map && e >= map_from) sel = map[e] != kPad;
+            for (uint32_t r = 0; r < kSegRounds / kPer; ++r) {
+                const v4u v = __builtin_nontemporal_load(src + r * kWave + lane);
+                uint32_t mine;
+                if constexpr (sizeof(T) == 4) {
+                    mine = (v.x != RF_NONE_U32) + (v.y != RF_NONE_U32) + (v.z != RF_NONE_U32) + (v.w != RF_NONE_U32);
+                } else {  // a NaN: exponent all ones and a mantissa that is not zero
+                    const uint64_t a = ((uint64_t)v.y << 32) | v.x, b = ((uint64_t)v.w << 32) | v.z;
+                    mine = ((a & 0x7FFFFFFFFFFFFFFFull) <= 0x7FF0000000000000ull) + ((b & 0x7FFFFFFFFFFFFFFFull) <= 0x7FF0000000000000ull);
+                }
+                cnt += mine;
             }
-            cnt += (uint32_t)__popcll(__ballot(sel));
+#pragma unroll
+            for (uint32_t d = kWave / 2; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, kWave);
+        } else {
+#pragma unroll 4
+            for (uint32_t r = 0; r < kSegRounds; ++r) {
+                const uint32_t e = base + r * kWave + lane;
+                bool sel = false;
+                if (e < m) {
+                    sel = some(val[e]);
+                    if (sel && map && e >= map_from) sel = map[e] != kPad;
+                }
+                cnt += (uint32_t)__popcll(__ballot(sel));
+            }
         }
     }
     if (lane == 0) seg_cnt[s] = cnt;  // (seg_cnt[n_seg] = 0: the exclusive sum's last entry is the total)

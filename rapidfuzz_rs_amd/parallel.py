@@ -69,8 +69,16 @@ def allgather_topk(scores: np.ndarray, indices: np.ndarray, k: int, op: int = N.
 
     world = dist.get_world_size(group)
     m = len(scores)
+    scores = np.asarray(scores)
+    if scores.dtype.kind == "f":
+        #  both branches below carry u32 scores; an f64 score (Jaro / Jaro-Winkler / ratio, normalized_*) would be truncated, silently.  Those
+        # lists travel as order-preserving 64-bit keys: sharded_topk_entries / rf_topk_entries_device.
+        raise TypeError("allgather_topk merges u32 scores; f64-valued scorers exchange rf_topk_entry rows: use sharded_topk_entries")
     if dist.get_backend(group) == "nccl":
-        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # (the device the GROUP's collectives run on for this rank -- the caller's, else the one torch.distributed bound at init_process_group(device_id=...),
+        # else the current one; never a guess that can differ from the shard's GPU)
+        bound = getattr(dist.distributed_c10d._get_default_group() if group is None else group, "bound_device_id", None)
+        dev = torch.device(device) if device is not None else (bound if bound is not None else torch.device("cuda", torch.cuda.current_device()))
         desc = op in (N.OP_SIMILARITY, N.OP_NORMALIZED_SIMILARITY)
         host = np.full((k, 2), -1, dtype=np.int64)  # (empty entry: key = index = UINT64_MAX)
         s64 = scores.astype(np.int64)

@@ -1718,6 +1718,12 @@ def test_bench_c5_preset_same_answer_for_every_world_size():
     d2 = _bench_json(base + ["--gpus", "2"], dict(env, RF_BENCH_BACKEND="gloo"))
     assert d2["n_gpus"] == 2 and d2["parity"]["mismatches"] == 0
     assert d2["config"]["topk_checksum"] == d1["config"]["topk_checksum"] and d2["config"]["topk_best"] == d1["config"]["topk_best"]
+    #  the same logical corpus DEALT by parallel.shard_ragged -- every length bucket to all ranks, local indices mapped to original ones before
+    # the exchange -- at world sizes 1 and 2: the same merged top-k as the contiguous split
+    for gpus in (1, 2):
+        dd = _bench_json(base + ["--shard", "dealt"] + (["--gpus", "2"] if gpus == 2 else []), dict(env, RF_BENCH_BACKEND="gloo") if gpus == 2 else env)
+        assert dd["n_gpus"] == gpus and dd["parity"]["mismatches"] == 0 and "shard_ragged" in dd["config"]["parallelism"]
+        assert dd["config"]["topk_checksum"] == d1["config"]["topk_checksum"] and dd["config"]["topk_best"] == d1["config"]["topk_best"]
     # the real rank count of configs[4]: 8 ranks (sharing this box's one GPU, exchange over gloo) cut the same logical corpus
     # into 8 shards with 8 index bases and must merge to the same keys
     d8 = _bench_json(base + ["--gpus", "8"], dict(env, RF_BENCH_BACKEND="gloo"))
@@ -2281,7 +2287,7 @@ def test_topk_as_scan_plus_one_pass_forced_for_every_asm_shape():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
 
 
-@pytest.mark.parametrize("two_pass", ["1", "0"])
+@pytest.mark.parametrize("two_pass", ["1", "0", "tiles"])
 def test_head_plane_and_band_filter_forced_on_small_corpora(two_pass):
     """The head plane, the band prefilter and its tile list start at 2^14 tiles; RF_HEAD8_MIN=1 RF_BAND_FILTER=1 puts every
     single-length corpus of the cutoff / top-k / randomized parity tests (a few tiles, odd tile counts, fewer pairs than filter
@@ -2296,7 +2302,8 @@ def test_head_plane_and_band_filter_forced_on_small_corpora(two_pass):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
                         "(cutoff or topk or randomized) and not forced_on_small and not edits_in_the_head and not score_hint"],
                        capture_output=True, text=True, cwd=root,
-                       env=dict(os.environ, RF_HEAD8_MIN="1", RF_BAND_FILTER="1", RF_HEAD_TWO_PASS=two_pass, RF_TEST_HEAD_CHILD="1",
+                       env=dict(os.environ, RF_HEAD8_MIN="1", RF_BAND_FILTER="1", RF_HEAD_TWO_PASS="1" if two_pass == "tiles" else two_pass, RF_TEST_HEAD_CHILD="1",
+                                RF_LANE_COMPACT="0" if two_pass == "tiles" else "1",  # ("tiles": round 5's second pass over surviving tiles; "1": over surviving lanes, round 6)
                                 RF_RUN_MIN_TILES="1"))  # (RF_RUN_MIN_TILES=1: every length run of a ragged corpus as a single-length view, round 4)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
 
