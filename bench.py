@@ -256,13 +256,21 @@ def main():
             so = np.zeros(len(pick) + 1, dtype=np.uint64)
             so[1:] = np.cumsum([len(x) for x in parts])
             ragged_strided = (np.concatenate(parts), so)
-        corpus = rf.Corpus.from_ragged(h_data, h_off, device=local_rank)
+        t_pack = time.time()
+        corpus = rf.Corpus.from_ragged(h_data, h_off, device=local_rank)  # host arrays -> scannable: upload, length sort, scatter (rf_corpus_pack)
+        torch.cuda.synchronize()
+        t_pack = time.time() - t_pack
+        pack_payload = int(h_off[-1])
         del h_data, h_off
     else:
         if rank == 0 and not args.no_cpu_baseline and world == 1:  # the CPU baseline and the oracle parity leg run at N = 1 only
             host_sample = rows[:sample_rows].cpu().numpy()
             host_strided = rows[::1009].cpu().numpy()  # every 1009-th candidate of the WHOLE shard
-        corpus = rf.Corpus.from_device_rows(rows)
+        t_pack = time.time()
+        corpus = rf.Corpus.from_device_rows(rows)  # device rows -> packed tiles (rf_corpus_pack_rows_device)
+        torch.cuda.synchronize()
+        t_pack = time.time() - t_pack
+        pack_payload = n * ln
         del rows
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
@@ -513,6 +521,12 @@ def main():
             **({"rccl_ranks": dist.get_world_size(), "collective": "ncclAllGather via torch.distributed (backend nccl = RCCL)"}
                if (world > 1 or force_dist) and not test_gloo else {}),
             "setup_s": round(t_setup, 2),
+            # (what a corpus costs to build, apart from generating the synthetic data) pack_s: the library call that turns the input into a scannable
+            # corpus -- host arrays in (upload included) for --ragged, device rows in otherwise; accel_build_ms: what the FIRST scan spent beyond a settled one (head
+            # planes, the 6-bit payload, gather maps -- built on first use -- plus table upload and cold clocks)
+            "pack_s": round(t_pack, 4),
+            "pack_payload_gb_per_s": round(pack_payload / max(t_pack, 1e-9) / 1e9, 2),
+            "accel_build_ms": round(max(0.0, first_call_ms - ms_per_step), 3),
             "settle_steps": settle_steps,
             "first_call_ms": round(first_call_ms, 3),
             **({"test_backend": "gloo: ranks share one GPU, NOT a measurement"} if test_gloo else {}),

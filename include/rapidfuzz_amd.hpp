@@ -148,6 +148,21 @@ public:
         return many<double>(c, RF_OP_NORMALIZED_SIMILARITY, a.to_c());
     }
 
+    // ---- only the candidates within the cutoff: the reference user's `corpus.iter().enumerate().filter_map(|(i, c)| scorer.<op>_with_args(c, &args).map(|v| (i, v)))`
+    // as ONE device pass that never builds the n-entry vector of Nones (rf_filter_u32 / rf_filter_f64); pairs in ascending index order (or `order`)
+    std::vector<std::pair<uint64_t, usize_result>> distance_filter_many(const Corpus& c, const Args<usize_result>& a = {}, rf_filter_order order = RF_FILTER_BY_INDEX) const
+    {
+        return filter<usize_result>(c, RF_OP_DISTANCE, a.to_c(), order);
+    }
+    std::vector<std::pair<uint64_t, usize_result>> similarity_filter_many(const Corpus& c, const Args<usize_result>& a = {}, rf_filter_order order = RF_FILTER_BY_INDEX) const
+    {
+        return filter<usize_result>(c, RF_OP_SIMILARITY, a.to_c(), order);
+    }
+    std::vector<std::pair<uint64_t, double>> normalized_similarity_filter_many(const Corpus& c, const Args<double>& a = {}, rf_filter_order order = RF_FILTER_BY_INDEX) const
+    {
+        return filter<double>(c, RF_OP_NORMALIZED_SIMILARITY, a.to_c(), order);
+    }
+
     // ---- many queries x one corpus: res[j][i] = scorers[j].<op>_with_args(candidate_i, args), one call (rf_many_multi_*)
     static std::vector<std::vector<std::optional<usize_result>>> distance_many_multi(const std::vector<const BatchComparator*>& scorers,
                                                                                       const Corpus& c, const Args<usize_result>& a = {})
@@ -213,6 +228,27 @@ private:
                 if (out[i] != RF_NONE_U32) res[i] = out[i];
         }
         return res;
+    }
+    template <class T>
+    std::vector<std::pair<uint64_t, T>> filter(const Corpus& c, rf_op op, const rf_args& a, rf_filter_order order) const
+    {
+        uint64_t cap = std::max<uint64_t>(1024, c.size() / 64), n = 0;
+        for (;;) {  // (the device reports the true number of matches: at most one repeat)
+            std::vector<uint64_t> idx(cap);
+            std::vector<std::pair<uint64_t, T>> res;
+            if constexpr (std::is_floating_point_v<T>) {
+                std::vector<double> val(cap);
+                check(rf_filter_f64(h_, c.handle(), op, &a, 0, cap, idx.data(), val.data(), &n, RF_MEM_HOST, order, nullptr));
+                if (n > cap) { cap = n; continue; }
+                for (uint64_t i = 0; i < n; ++i) res.emplace_back(idx[i], val[i]);
+            } else {
+                std::vector<uint32_t> val(cap);
+                check(rf_filter_u32(h_, c.handle(), op, &a, 0, cap, idx.data(), val.data(), &n, RF_MEM_HOST, order, nullptr));
+                if (n > cap) { cap = n; continue; }
+                for (uint64_t i = 0; i < n; ++i) res.emplace_back(idx[i], (T)val[i]);
+            }
+            return res;
+        }
     }
     rf_comparator* h_ = nullptr;
 };

@@ -67,6 +67,10 @@
  *                                           early-out cutoff: that scan then streams 12 instead of 16 bytes per 16 symbols -- rf_stream_asm.hip
  *                                           stream_lcs6[n]_uniform_kernel, and stream_lcs6[n]_tiles_kernel for length-bucketed corpora, u32 results)
  *   RF_PACK6_MIN_TILES            16384     fewest tiles of a corpus for which that copy is made
+ *   RF_DEVICE_PACK_MIN            65536     fewest candidates for which rf_corpus_pack does its per-candidate work on the device (upload of the raw bytes + offsets, length
+ *                                           histogram, stable radix sort by length, one scatter kernel per destination tile: rf_pack_ragged.hip) instead of the host's
+ *                                           counting sort + byte scatter + one upload of the packed image; 0: always the host packer.  The same layout either way, byte
+ *                                           for byte (rf_corpus_layout_host is the specification; candidates beyond 65535 symbols always take the host packer)
  *   RF_HINT_MIN_TILES             1024      fewest tiles of a corpus for which a per-candidate Levenshtein scan of a query beyond 64 symbols honours
  *                                           score_hint (pass under max(hint, 31), then only what it left unresolved: rf_hint.hip); 4294967295: never
  *   RF_HINT_SAMPLE_MIN_TILES      16384     fewest tiles for which such a call first runs the hint pass over every (tiles / 512)-th tile and drops the hint when fewer
@@ -220,7 +224,8 @@ const uint64_t *rf_comparator_pm(const rf_comparator *c, size_t *block_count);
  * per-corpus permutation (frequency rank), which the kernels undo when they stage the PM table; results always
  * come back in the ORIGINAL candidate order and never depend on the renaming.
  *
- * rf_corpus_pack: ragged host input, candidate i = bytes[offsets[i] .. offsets[i+1]) (n+1 offsets).
+ * rf_corpus_pack: ragged host input, candidate i = bytes[offsets[i] .. offsets[i+1]) (n+1 offsets).  From 65536 candidates on the input is uploaded as it is
+ *   and length-bucketed on the device (100 M candidates of <= 64 symbols: host arrays to a scannable corpus in a fraction of a second, profiles/pack_r06.txt).
  * rf_corpus_pack_rows_device: n rows of `len` bytes already in device memory at d_rows + i*stride.
  * Inputs are borrowed for the duration of the call only.  n < 2^32 - 1 per corpus. */
 rf_status rf_corpus_pack(const uint8_t *bytes, const uint64_t *offsets, size_t n, int device, rf_corpus **out);

@@ -747,11 +747,326 @@ static rf_status corpus_from_layout(const HostLayout& L, size_t n, int device, r
     return RF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// rf_corpus_pack on the device (round 6): raw bytes + offsets go up as they are, the GPU does the per-candidate work (rf_pack_ragged.hip has the scheme);
+// what is left here is the part of the layout that is a function of the LENGTH HISTOGRAM alone -- the same arithmetic as build_layout steps 1-3, which stays the
+// specification (rf_corpus_layout_host) and which the device-packed corpus is held to byte for byte (tests/test_gpu_filter.py, through rf_corpus_save).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// pageable host memory -> device at the link's rate: worker threads copy slices into pinned staging buffers (kept per process) and enqueue them on streams of
+// their own -- hipMemcpy from pageable memory stages through ONE internal buffer on ONE thread (~12 GB/s here; this: the sum of the threads' memcpy rates, up to the link)
+struct Staging {
+    std::mutex mu;
+    std::vector<void*> bufs;  // pinned, kSlice bytes each
+    std::vector<hipStream_t> streams;
+    static constexpr size_t kSlice = 8u << 20, kPerThread = 2;
+};
+Staging& staging()
+{
+    static Staging* s = new Staging();
+    return *s;
+}
+hipError_t staged_upload(void* d_dst, const void* h_src, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    Staging& S = staging();
+    std::lock_guard<std::mutex> lock(S.mu);  // (one staged upload at a time per process: the threads would only fight over the link)
+    const size_t threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)16, (bytes + Staging::kSlice - 1) / Staging::kSlice}));
+    while (S.streams.size() < threads) {
+        hipStream_t st = nullptr;
+        if (const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); e != hipSuccess) return e;
+        S.streams.push_back(st);
+    }
+    while (S.bufs.size() < threads * Staging::kPerThread) {
+        void* p = nullptr;
+        if (const hipError_t e = hipHostMalloc(&p, Staging::kSlice, hipHostMallocDefault); e != hipSuccess) return e;
+        S.bufs.push_back(p);
+    }
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const size_t slices = (bytes + Staging::kSlice - 1) / Staging::kSlice;
+    std::vector<hipError_t> errs(threads, hipSuccess);
+    auto worker = [&](size_t t) {
+        (void)hipSetDevice(device);
+        hipEvent_t ev[Staging::kPerThread] = {nullptr, nullptr};
+        bool used[Staging::kPerThread] = {false, false};
+        for (auto& e : ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) errs[t] = hipErrorUnknown;
+        size_t turn = 0;
+        for (size_t s = t; s < slices && errs[t] == hipSuccess; s += threads, ++turn) {
+            const size_t b = turn % Staging::kPerThread;
+            if (used[b]) errs[t] = hipEventSynchronize(ev[b]);  // the copy that last read this staging buffer
+            if (errs[t] != hipSuccess) break;
+            const size_t off = s * Staging::kSlice, m = std::min(Staging::kSlice, bytes - off);
+            void* stage = S.bufs[t * Staging::kPerThread + b];
+            std::memcpy(stage, static_cast<const uint8_t*>(h_src) + off, m);
+            errs[t] = hipMemcpyAsync(static_cast<uint8_t*>(d_dst) + off, stage, m, hipMemcpyHostToDevice, S.streams[t]);
+            if (errs[t] == hipSuccess) errs[t] = hipEventRecord(ev[b], S.streams[t]);
+            used[b] = true;
+        }
+        if (errs[t] == hipSuccess) errs[t] = hipStreamSynchronize(S.streams[t]);
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    for (const hipError_t e : errs)
+        if (e != hipSuccess) return e;
+    return hipSuccess;
+}
+
+struct DeviceTemps {  // released on every way out
+    std::vector<void*> ptrs;
+    ~DeviceTemps()
+    {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    hipError_t get(void** p, size_t bytes)
+    {
+        const hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 256));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+}  // namespace
+
+// *declined = true: this corpus is the host packer's (too small to pay for the launches, a candidate beyond 65535 symbols, no room for the temporaries)
+static rf_status pack_ragged_device(const uint8_t* bytes, const uint64_t* offsets, size_t n, int device, rf_corpus** out, bool* declined)
+{
+    *declined = true;
+    static const size_t min_n = [] { const char* e = getenv("RF_DEVICE_PACK_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 16; }();  // 0: never
+    constexpr uint32_t kMaxLen = 0xFFFFu;
+    if (!min_n || n < min_n || n >= 0x7FFFFFFFull || !offsets) return RF_OK;
+    const uint64_t first = offsets[0], total = offsets[n];
+    if (total < first || (total > first && !bytes)) return RF_OK;  // (the host packer words the error)
+    PhaseTimer timer;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("rf_corpus_pack: cannot select device");
+        return RF_ERR_NO_DEVICE;
+    }
+    DeviceTemps tmp;
+    auto soft = [&](hipError_t e) {  // a temporary that cannot be had: the host packer, not an error
+        if (e == hipSuccess) return false;
+        (void)hipGetLastError();
+        return true;
+    };
+    uint8_t* d_bytes = nullptr;
+    uint64_t* d_off = nullptr;
+    uint32_t *d_keys = nullptr, *d_vals = nullptr, *d_keys2 = nullptr, *d_vals2 = nullptr, *d_status = nullptr;
+    unsigned long long *d_counts = nullptr, *d_hist = nullptr;
+    if (soft(tmp.get((void**)&d_bytes, total - first + 16)) || soft(tmp.get((void**)&d_off, (n + 1) * sizeof(uint64_t))) || soft(tmp.get((void**)&d_keys, n * 4)) ||
+        soft(tmp.get((void**)&d_vals, n * 4)) || soft(tmp.get((void**)&d_keys2, n * 4)) || soft(tmp.get((void**)&d_vals2, n * 4)) ||
+        soft(tmp.get((void**)&d_counts, ((size_t)kMaxLen + 1) * 8)) || soft(tmp.get((void**)&d_hist, 256 * 8)) || soft(tmp.get((void**)&d_status, 8)))
+        return RF_OK;
+    RF_HIP(hipMemsetAsync(d_counts, 0, ((size_t)kMaxLen + 1) * 8, nullptr));
+    RF_HIP(hipMemsetAsync(d_hist, 0, 256 * 8, nullptr));
+    RF_HIP(hipMemsetAsync(d_status, 0, 8, nullptr));
+    RF_HIP(hipMemsetAsync(d_bytes + (total - first), 0, 16, nullptr));
+    RF_HIP(hipStreamSynchronize(nullptr));
+    // ---- 1. the input, as it is
+    RF_HIP(staged_upload(d_off, offsets, (n + 1) * sizeof(uint64_t)));
+    RF_HIP(staged_upload(d_bytes, bytes + first, total - first));
+    timer.lap("device: upload bytes+offsets");
+    // ---- 2. lengths (sort keys), their histogram, validation; the byte sample behind the symbol renaming
+    RF_HIP(launch_ragged_lengths(d_off, (uint32_t)n, kMaxLen, d_keys, d_vals, d_counts, d_status, nullptr));
+    const uint64_t span = total - first, block = 1u << 16, stride = std::max<uint64_t>(1, span / (256ull << 20));
+    RF_HIP(launch_ragged_byte_hist(d_bytes, 0, span, stride, d_hist, nullptr));
+    std::vector<unsigned long long> counts((size_t)kMaxLen + 1);
+    uint64_t hist[256];
+    uint32_t status[2] = {0, 0};
+    RF_HIP(hipMemcpyAsync(status, d_status, 8, hipMemcpyDeviceToHost, nullptr));
+    RF_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, nullptr));
+    RF_HIP(hipStreamSynchronize(nullptr));
+    if (status[1] & 1u) {
+        set_error("rf_corpus_pack: offsets must be non-decreasing and candidates shorter than 4 GiB");
+        *declined = false;
+        return RF_ERR_INVALID_ARG;
+    }
+    if (status[1] & 2u) return RF_OK;  // a candidate beyond 65535 symbols: the host packer
+    const uint32_t max_len = status[0];
+    RF_HIP(hipMemcpy(counts.data(), d_counts, ((size_t)max_len + 1) * 8, hipMemcpyDeviceToHost));
+    (void)block;
+    timer.lap("device: lengths + histograms");
+    // ---- 3. the layout that follows from the histogram (build_layout steps 1-3, same arithmetic)
+    struct Group {
+        uint32_t len;
+        uint64_t count, slot0, off0, in_exact, pool0, start;
+    };
+    std::vector<Group> groups;
+    {
+        uint64_t at = 0;
+        for (uint32_t len = 0; len <= max_len; ++len)
+            if (counts[len]) {
+                groups.push_back(Group{len, counts[len], 0, 0, 0, 0, at});
+                at += counts[len];
+            }
+    }
+    const bool identity = groups.size() <= 1 && tile_bytes(max_len) <= 0xFFFFFFFFull;
+    static const bool no_mixed = getenv("RF_NO_MIXED_TILES") != nullptr;
+    std::vector<TileDesc> tiles;
+    uint64_t slots = 0, data_bytes = 0, pool_n = 0;
+    for (Group& g : groups) {
+        const bool all = identity || no_mixed;
+        const uint64_t nt = all ? (g.count + kWave - 1) / kWave : g.count / kWave;
+        g.in_exact = all ? g.count : nt * kWave;
+        g.slot0 = slots;
+        g.off0 = data_bytes;
+        for (uint64_t t = 0; t < nt; ++t) {
+            tiles.push_back(TileDesc{data_bytes, g.len, (uint32_t)slots});
+            slots += kWave;
+            data_bytes += tile_bytes(g.len);
+        }
+        g.pool0 = pool_n;
+        pool_n += g.count - g.in_exact;
+    }
+    const uint32_t n_exact = (uint32_t)tiles.size();
+    const uint64_t n_mixed = (pool_n + kWave - 1) / kWave;
+    std::vector<uint32_t> pool_len(n_mixed * kWave, 0u), pool_spos(n_mixed * kWave, 0u), pool_vslot0(n_mixed * kWave, 0u);
+    for (const Group& g : groups)
+        for (uint64_t k = 0; k < g.count - g.in_exact; ++k) {
+            pool_len[g.pool0 + k] = g.len;
+            pool_spos[g.pool0 + k] = (uint32_t)(g.start + g.in_exact + k);
+        }
+    std::vector<MixedDesc> mixed;
+    for (uint64_t m = 0; m < n_mixed; ++m) {
+        const uint64_t p0 = m * kWave, p1 = std::min<uint64_t>(pool_n, p0 + kWave);
+        const uint32_t lo = pool_len[p0], hi = pool_len[p1 - 1];
+        mixed.push_back(MixedDesc{data_bytes, hi, lo, (uint32_t)(m * kWave), 0});
+        uint32_t prev = 0xFFFFFFFFu, vslot0 = 0;
+        for (uint64_t q = p0; q < p1; ++q) {
+            if (pool_len[q] != prev) {  // one virtual exact tile per distinct length, sharing the payload block
+                prev = pool_len[q];
+                vslot0 = (uint32_t)slots;
+                tiles.push_back(TileDesc{data_bytes, prev, (uint32_t)slots});
+                slots += kWave;
+            }
+            pool_vslot0[q] = vslot0;
+        }
+        data_bytes += tile_bytes(hi);
+    }
+    if (slots >= 0xFFFFFFFFull || pool_n >= 0x80000000ull) {
+        set_error("rf_corpus_pack: too many candidates for one corpus");
+        *declined = false;
+        return RF_ERR_INVALID_ARG;
+    }
+    timer.lap("device: layout from the histogram");
+    // ---- 4. the corpus object and its buffers
+    rf_corpus* c = new (std::nothrow) rf_corpus();
+    if (!c) return RF_ERR_OOM;
+    *declined = false;
+    auto fail = [&](rf_status st) {
+        rf_corpus_free(c);
+        return st;
+    };
+    c->uid = g_corpus_uid.fetch_add(1);
+    c->device = device;
+    c->n = n;
+    c->payload_bytes = span;
+    c->n_tiles = (uint32_t)tiles.size();
+    c->n_exact = n_exact;
+    c->n_mixed = (uint32_t)mixed.size();
+    c->mixed = mixed;
+    c->max_len = max_len;
+    for (size_t t = 0; t < tiles.size(); ++t)
+        if (c->lengths.empty() || c->lengths.back() != tiles[t].len) {
+            c->lengths.push_back(tiles[t].len);
+            c->length_first_tile.push_back((uint32_t)t);
+        }
+    make_sigma(hist, c->sigma);
+    symbol_frequencies(hist, c->sym_freq);
+    const size_t packed_size = data_bytes + kTailPad;
+    RF_HIP_C(hipMalloc(&c->d_data, packed_size));
+    c->device_bytes = c->data_bytes = packed_size;
+    RF_HIP_C(hipMemsetAsync(c->d_data + data_bytes, 0, kTailPad, nullptr));
+    RF_HIP_C(hipMalloc(&c->d_sigma, 256));
+    RF_HIP_C(hipMemcpyAsync(c->d_sigma, c->sigma, 256, hipMemcpyHostToDevice, nullptr));
+    if (identity) {
+        c->uniform = true;
+        c->uniform_len = max_len;
+    } else {
+        RF_HIP_C(hipMalloc(&c->d_tiles, tiles.size() * sizeof(TileDesc)));
+        RF_HIP_C(hipMemcpyAsync(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, nullptr));
+        RF_HIP_C(hipMalloc(&c->d_orig, slots * sizeof(uint32_t)));
+        RF_HIP_C(hipMemsetAsync(c->d_orig, 0xFF, slots * sizeof(uint32_t), nullptr));  // (the views' lanes of other lengths stay kPad)
+        c->n_slots = slots;
+        c->device_bytes += tiles.size() * sizeof(TileDesc) + slots * sizeof(uint32_t);
+    }
+    if (c->n_mixed) {
+        RF_HIP_C(hipMalloc(&c->d_mixed, mixed.size() * sizeof(MixedDesc)));
+        RF_HIP_C(hipMemcpyAsync(c->d_mixed, mixed.data(), mixed.size() * sizeof(MixedDesc), hipMemcpyHostToDevice, nullptr));
+        RF_HIP_C(hipMalloc(&c->d_mixed_len, pool_len.size() * sizeof(uint32_t)));
+        RF_HIP_C(hipMemcpyAsync(c->d_mixed_len, pool_len.data(), pool_len.size() * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+        RF_HIP_C(hipMalloc(&c->d_mixed_orig, pool_len.size() * sizeof(uint32_t)));
+        c->device_bytes += mixed.size() * sizeof(MixedDesc) + 2 * pool_len.size() * sizeof(uint32_t);
+    }
+    // ---- 5. the order: (length, index) pairs sorted by length over the significant bits, stable
+    uint32_t bits = 1;
+    while (bits < 32 && (max_len >> bits)) ++bits;
+    void* d_sort_temp = nullptr;
+    const size_t sort_bytes = ragged_sort_temp_bytes((uint32_t)n);
+    RF_HIP_C(tmp.get(&d_sort_temp, sort_bytes));
+    RF_HIP_C(launch_ragged_sort(d_keys, d_keys2, d_vals, d_vals2, (uint32_t)n, bits, d_sort_temp, sort_bytes, nullptr));
+    // ---- 6. the scatter, by destination tile
+    std::vector<uint32_t> by_len((size_t)max_len + 1, 0u), g_start(groups.size()), g_slot0(groups.size()), g_in_exact(groups.size());
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        by_len[groups[gi].len] = (uint32_t)gi;
+        g_start[gi] = (uint32_t)groups[gi].start, g_slot0[gi] = (uint32_t)groups[gi].slot0, g_in_exact[gi] = (uint32_t)groups[gi].in_exact;
+    }
+    uint32_t *d_by_len = nullptr, *d_g = nullptr, *d_pool = nullptr;
+    const size_t G = std::max<size_t>(groups.size(), 1), P = pool_len.size();
+    RF_HIP_C(tmp.get((void**)&d_by_len, by_len.size() * 4));
+    RF_HIP_C(tmp.get((void**)&d_g, 3 * G * 4));
+    RF_HIP_C(tmp.get((void**)&d_pool, 2 * std::max<size_t>(P, 1) * 4));
+    RF_HIP_C(hipMemcpyAsync(d_by_len, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, nullptr));
+    if (!groups.empty()) {
+        RF_HIP_C(hipMemcpyAsync(d_g, g_start.data(), groups.size() * 4, hipMemcpyHostToDevice, nullptr));
+        RF_HIP_C(hipMemcpyAsync(d_g + G, g_slot0.data(), groups.size() * 4, hipMemcpyHostToDevice, nullptr));
+        RF_HIP_C(hipMemcpyAsync(d_g + 2 * G, g_in_exact.data(), groups.size() * 4, hipMemcpyHostToDevice, nullptr));
+    }
+    RF_HIP_C(launch_ragged_scatter_tiles(d_bytes, first, d_off, d_vals2, identity ? nullptr : c->d_tiles, max_len, n_exact, d_by_len, d_g, d_g + G, d_g + 2 * G, c->d_sigma, c->d_data,
+                                         c->d_orig, nullptr));
+    if (c->n_mixed) {
+        RF_HIP_C(hipMemcpyAsync(d_pool, pool_spos.data(), P * 4, hipMemcpyHostToDevice, nullptr));
+        RF_HIP_C(hipMemcpyAsync(d_pool + P, pool_vslot0.data(), P * 4, hipMemcpyHostToDevice, nullptr));
+        RF_HIP_C(launch_ragged_scatter_mixed(d_bytes, first, d_off, d_vals2, c->d_mixed, c->n_mixed, (uint32_t)pool_n, c->d_mixed_len, d_pool, d_pool + P, c->d_sigma, c->d_data, c->d_orig,
+                                             c->d_mixed_orig, nullptr));
+    }
+    // ---- 7. the second tile order (tiles_by_origin): the first original index of every exact tile comes home as one strided copy
+    if (!identity && n_exact >= 1024) {
+        std::vector<uint32_t> first_idx(n_exact);
+        RF_HIP_C(hipMemcpy2DAsync(first_idx.data(), sizeof(uint32_t), c->d_orig, kWave * sizeof(uint32_t), sizeof(uint32_t), n_exact, hipMemcpyDeviceToHost, nullptr));
+        RF_HIP_C(hipStreamSynchronize(nullptr));
+        std::vector<TileDesc> ordered = tiles;
+        uint32_t z = 0;
+        while (z < n_exact && tiles[z].len == 0) ++z;
+        std::vector<uint64_t> key(n_exact - z);  // (first original index, position): the sort of tiles_by_origin()
+        for (uint32_t i = 0; i < key.size(); ++i) key[i] = (uint64_t)first_idx[z + i] << 32 | (z + i);
+        std::sort(key.begin(), key.end());
+        for (uint32_t i = 0; i < key.size(); ++i) ordered[z + i] = tiles[(uint32_t)key[i]];
+        RF_HIP_C(hipMalloc(&c->d_tiles_by_origin, ordered.size() * sizeof(TileDesc)));
+        RF_HIP_C(hipMemcpy(c->d_tiles_by_origin, ordered.data(), ordered.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    }
+    RF_HIP_C(hipStreamSynchronize(nullptr));  // the input is only borrowed for the duration of the call; the temporaries go with `tmp`
+    timer.lap("device: sort + scatter + tile order");
+    *out = c;
+    return RF_OK;
+}
+
 rf_status rf_corpus_pack(const uint8_t* bytes, const uint64_t* offsets, size_t n, int device, rf_corpus** out)
 try {
     if (!out) {
         set_error("rf_corpus_pack: invalid argument");
         return RF_ERR_INVALID_ARG;
+    }
+    {   // large inputs: the per-candidate work on the device (RF_DEVICE_PACK_MIN=<candidates>, default 65536; 0 = always the host packer)
+        bool declined = true;
+        const rf_status sd = pack_ragged_device(bytes, offsets, n, device, out, &declined);
+        if (!declined) return sd;
     }
     HostLayout L;
     const rf_status s = build_layout(bytes, offsets, n, &L);

@@ -197,6 +197,19 @@ hipError_t launch_pack_rows(const uint8_t* rows, size_t n, uint32_t len, size_t 
                             uint32_t n_tiles, const uint8_t* sigma, hipStream_t stream);
 hipError_t launch_translate(const void* raw, uint32_t raw_elem, uint64_t n_bytes, const uint32_t* keys, const uint8_t* vals, uint32_t cap, uint8_t* out,
                             hipStream_t stream);
+// rf_pack_ragged.hip: the device half of rf_corpus_pack (ragged host input)
+hipError_t launch_ragged_lengths(const uint64_t* offsets, uint32_t n, uint32_t max_len_allowed, uint32_t* keys, uint32_t* vals, unsigned long long* counts, uint32_t* status,
+                                 hipStream_t st);  // status[0] = longest length, status[1]: bit 0 = offsets decrease, bit 1 = a candidate longer than max_len_allowed
+hipError_t launch_ragged_byte_hist(const uint8_t* bytes, uint64_t first, uint64_t total, uint64_t stride, unsigned long long* hist, hipStream_t st);
+size_t ragged_sort_temp_bytes(uint32_t n);
+hipError_t launch_ragged_sort(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, uint32_t bits, void* temp, size_t temp_bytes,
+                              hipStream_t st);
+hipError_t launch_ragged_scatter_tiles(const uint8_t* bytes, uint64_t first, const uint64_t* offsets, const uint32_t* sorted_idx, const TileDesc* tiles, uint32_t uniform_len, uint32_t n_exact,
+                                       const uint32_t* by_len, const uint32_t* g_start, const uint32_t* g_slot0, const uint32_t* g_in_exact, const uint8_t* sigma, uint8_t* packed,
+                                       uint32_t* orig, hipStream_t st);
+hipError_t launch_ragged_scatter_mixed(const uint8_t* bytes, uint64_t first, const uint64_t* offsets, const uint32_t* sorted_idx, const MixedDesc* mixed, uint32_t n_mixed, uint32_t pool_n,
+                                       const uint32_t* pool_len, const uint32_t* pool_spos, const uint32_t* pool_vslot0, const uint8_t* sigma, uint8_t* packed, uint32_t* orig,
+                                       uint32_t* mixed_orig, hipStream_t st);
 int scan_max_grid();
 // results of a ragged corpus in original order without scattered stores (rf_pack.hip): slot -> slot / candidate -> slot maps, and the gather
 hipError_t launch_slot_maps(const uint32_t* orig, uint32_t n_slots, uint32_t* slot_of, uint32_t* ident, hipStream_t stream);

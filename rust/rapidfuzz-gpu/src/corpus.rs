@@ -20,6 +20,16 @@ impl Corpus {
         check(unsafe { rf_corpus_pack(bytes.as_ptr(), offsets.as_ptr(), offsets.len() - 1, device, &mut h) })?;
         Ok(Corpus(h))
     }
+    /// Entries of a slot-ordered result vector (`RF_FLAG_SLOT_ORDER`): `len()` for a single-length corpus, 64 per tile otherwise.
+    pub fn slot_count(&self) -> usize {
+        unsafe { rf_corpus_slot_count(self.0) }
+    }
+    /// The original candidate index of every slot (`u32::MAX`: the slot holds no candidate): kept once by a caller that takes its results in slot order.
+    pub fn slot_index(&self) -> Result<Vec<u32>, Error> {
+        let mut out = vec![0u32; self.slot_count()];
+        check(unsafe { rf_corpus_slot_index(self.0, out.as_mut_ptr(), RF_MEM_HOST) })?;
+        Ok(out)
+    }
     /// `&str` candidates compared as `char`s (`BatchComparator::new(s.chars())`): one u32 per char, the corpus keeps its
     /// own alphabet.
     pub fn from_chars<'a, I: IntoIterator<Item = &'a str>>(candidates: I, device: i32) -> Result<Self, Error> {

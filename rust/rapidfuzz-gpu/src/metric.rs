@@ -238,6 +238,33 @@ pub(crate) fn many_f64(c: *const RfComparator, corpus: &crate::Corpus, op: c_int
     Ok(out.into_iter().map(|v| (!v.is_nan()).then_some(v)).collect())
 }
 
+/// What a thresholded scan keeps: the reference user's
+/// `corpus.iter().enumerate().filter_map(|(i, c)| scorer.<op>_with_args(c, &args).map(|v| (i, v)))` (src/common.rs:18-46, :83-85) as
+/// ONE device pass that never materialises the n-entry vector of `None`s (rf_filter_u32 / rf_filter_f64).  `order`: RF_FILTER_BY_INDEX /
+/// RF_FILTER_BY_SCORE / RF_FILTER_ANY.  The device reports the true number of matches; the call repeats once when the first guess was too small.
+pub(crate) fn filter_u32(c: *const RfComparator, corpus: &crate::Corpus, op: c_int, a: &RfArgs, order: c_int) -> Result<Vec<(u64, usize)>, Error> {
+    let mut cap = (corpus.len() / 64).max(1024) as u64;
+    loop {
+        let (mut idx, mut val, mut n) = (vec![0u64; cap as usize], vec![0u32; cap as usize], 0u64);
+        check(unsafe { rf_filter_u32(c, corpus.0, op, a, 0, cap, idx.as_mut_ptr(), val.as_mut_ptr(), &mut n, RF_MEM_HOST, order, std::ptr::null_mut()) })?;
+        if n <= cap {
+            return Ok(idx.into_iter().zip(val).take(n as usize).map(|(i, v)| (i, v as usize)).collect());
+        }
+        cap = n;
+    }
+}
+pub(crate) fn filter_f64(c: *const RfComparator, corpus: &crate::Corpus, op: c_int, a: &RfArgs, order: c_int) -> Result<Vec<(u64, f64)>, Error> {
+    let mut cap = (corpus.len() / 64).max(1024) as u64;
+    loop {
+        let (mut idx, mut val, mut n) = (vec![0u64; cap as usize], vec![0f64; cap as usize], 0u64);
+        check(unsafe { rf_filter_f64(c, corpus.0, op, a, 0, cap, idx.as_mut_ptr(), val.as_mut_ptr(), &mut n, RF_MEM_HOST, order, std::ptr::null_mut()) })?;
+        if n <= cap {
+            return Ok(idx.into_iter().zip(val).take(n as usize).collect());
+        }
+        cap = n;
+    }
+}
+
 /// The handle every BatchComparator wraps: `new`, `Clone`, `Drop`, the device-side sharded top-k.
 macro_rules! comparator_core {
     ($ty:ident, $metric:ident) => {
@@ -355,6 +382,14 @@ macro_rules! usize_metric {
                 }
                 pub fn normalized_similarity_many<C: SimilarityCutoff<f64>>(&self, corpus: &Corpus, args: &Args<f64, C>) -> Result<Vec<C::Output>, Error> {
                     Ok(many_f64(self.h, corpus, RF_OP_NORMALIZED_SIMILARITY, &args.lower(args.score_cutoff.cutoff()))?.into_iter().map(|v| args.score_cutoff.from_device(v)).collect())
+                }
+                /// The candidates within the cutoff as (index, distance) pairs, ascending index: `filter_map` over the corpus in one device pass.
+                pub fn distance_filter_many<C: DistanceCutoff<usize>>(&self, corpus: &Corpus, args: &Args<usize, C>) -> Result<Vec<(u64, usize)>, Error> {
+                    filter_u32(self.h, corpus, RF_OP_DISTANCE, &args.lower(args.score_cutoff.cutoff()), RF_FILTER_BY_INDEX)
+                }
+                /// ... and as (index, normalized similarity) pairs, best first.
+                pub fn normalized_similarity_filter_many<C: SimilarityCutoff<f64>>(&self, corpus: &Corpus, args: &Args<f64, C>) -> Result<Vec<(u64, f64)>, Error> {
+                    filter_f64(self.h, corpus, RF_OP_NORMALIZED_SIMILARITY, &args.lower(args.score_cutoff.cutoff()), RF_FILTER_BY_SCORE)
                 }
                 /// k best candidates by (distance, index); `index_base` makes shards of one logical corpus comparable.
                 pub fn topk<C: DistanceCutoff<usize>>(&self, corpus: &Corpus, k: u32, args: &Args<usize, C>, index_base: u64) -> Result<TopK, Error> {

@@ -43,6 +43,14 @@ int main(int argc, char** argv)
     Corpus corpus({"sitting", "mitten", "kitchen", ""});
     auto d = scorer.distance_many(corpus, distance::levenshtein::Args<size_t>{}.score_cutoff(2));
     EXPECT(!d[0] && *d[1] == 1 && *d[2] == 2 && !d[3]);
+    {   // the reference user's filter_map over Option<T>: only the candidates within the cutoff, as (index, distance) pairs (rf_filter_u32)
+        auto f = scorer.distance_filter_many(corpus, distance::levenshtein::Args<size_t>{}.score_cutoff(2));
+        EXPECT(f.size() == 2 && f[0].first == 1 && f[0].second == 1 && f[1].first == 2 && f[1].second == 2);
+        auto best = scorer.distance_filter_many(corpus, distance::levenshtein::Args<size_t>{}.score_cutoff(6), RF_FILTER_BY_SCORE);
+        EXPECT(best.size() == 4 && best[0].first == 1 && best[3].second == 6);
+        auto ns = scorer.normalized_similarity_filter_many(corpus, distance::levenshtein::Args<double>{}.score_cutoff(0.7));
+        EXPECT(ns.size() == 2 && ns[0].first == 1 && ns[1].first == 2);
+    }
     {
         distance::levenshtein::BatchComparator a("mitten"), b("kitchen"), c("");
         auto m = distance::levenshtein::BatchComparator::distance_many_multi({&scorer, &a, &b, &c}, corpus);

@@ -163,7 +163,7 @@ def test_every_environment_knob_is_documented_and_none_changes_results():
         if f.endswith((".hip", ".hpp")):
             txt = open(os.path.join(src, f)).read()
             txt = re.sub(r"#ifdef RF_EXPERIMENTS.*?#e(?:lse|ndif)", "", txt, flags=re.S)  # measurement builds only
-            names |= set(re.findall(r'getenv\("(\w+)"\)', txt)) | set(re.findall(r'env_or\("(\w+)"', txt))
+            names |= set(re.findall(r'getenv\("(\w+)"\)', txt)) | set(re.findall(r'env_or\("(\w+)"', txt)) | set(re.findall(r'env_on\("(\w+)"', txt))
     assert "RF_EXP_NOHBM" not in names
     missing = [n for n in sorted(names) if n not in hdr]
     assert not missing, f"environment variables read by the library but not documented in rfgpu.h: {missing}"

@@ -261,3 +261,52 @@ def test_filter_and_slot_order_on_a_length_bucketed_corpus():
     assert c2.slot_count == 5000 and np.array_equal(c2.slot_index(), np.arange(5000, dtype=np.uint32))
     a = GPU["indel"].BatchComparator(q).many(N.OP_DISTANCE, c2, rf.distance.indel.Args().slot_order())
     assert np.array_equal(a, GPU["indel"].BatchComparator(q).many(N.OP_DISTANCE, c2))
+
+
+def _saved(corpus, path):
+    corpus.save(str(path))
+    return open(path, "rb").read()
+
+
+@pytest.mark.parametrize("shape", ["ragged", "lognormal_zipf", "single_length", "long_tail", "offset_window"])
+def test_device_packer_equals_the_host_layout_byte_for_byte(shape, tmp_path):
+    """rf_corpus_pack does its per-candidate work on the device now (rf_pack_ragged.hip: length keys + histogram, stable radix sort by length,
+    one scatter kernel per destination tile).  The layout's specification stays the host packer (rf_corpus_layout_host / build_layout): the same input packed with
+    RF_DEVICE_PACK_MIN=0 (host) in a child process and on the device here must SAVE to identical files -- header, length table, tile descriptors, slot map, mixed
+    section, every payload byte (file format unchanged) -- and scan to the oracle's values."""
+    rng = np.random.default_rng(len(shape))
+    n = 300_011
+    if shape == "ragged":
+        data, offsets = synth.ragged_host(n, 70, seed=5, min_len=0)
+    elif shape == "lognormal_zipf":
+        data, offsets = synth.lognormal_ragged_host(n, 200, seed=6, median=30.0, sigma=0.7, zipf_s=1.2)
+    elif shape == "single_length":
+        data, offsets = synth.ragged_host(n, 48, seed=7, min_len=48)
+    elif shape == "long_tail":  # a few long candidates among short ones: leftovers of many lengths, several mixed tiles, partial last chunks
+        lens = np.where(rng.random(n) < 0.001, rng.integers(300, 3000, size=n), rng.integers(0, 40, size=n))
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+        data = rng.integers(0, 256, size=int(offsets[-1]), dtype=np.uint8)  # every byte value: the renaming sees all 256 symbols
+    else:  # offsets that do not start at 0 (a window into a larger buffer)
+        data, offsets = synth.ragged_host(n, 33, seed=8, min_len=1)
+        offsets = offsets + np.uint64(12345)
+        data = np.concatenate([rng.integers(48, 123, size=12345, dtype=np.uint8), data])
+    np.save(tmp_path / "data.npy", data)
+    np.save(tmp_path / "offsets.npy", offsets)
+    child = ("import sys, numpy as np; sys.path.insert(0, %r); import rapidfuzz_rs_amd as rf; "
+             "rf.Corpus.from_ragged(np.load(%r), np.load(%r)).save(%r)") % (ROOT, str(tmp_path / "data.npy"), str(tmp_path / "offsets.npy"), str(tmp_path / "host.rfc"))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RF_DEVICE_PACK_MIN="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    dev_file, host_file = _saved(corpus, tmp_path / "dev.rfc"), open(tmp_path / "host.rfc", "rb").read()
+    assert len(dev_file) == len(host_file)
+    if dev_file != host_file:
+        a, b = np.frombuffer(dev_file, dtype=np.uint8), np.frombuffer(host_file, dtype=np.uint8)
+        bad = np.nonzero(a != b)[0]
+        raise AssertionError(f"{len(bad)} bytes differ, first at {bad[:8]}")
+    q = bytes(data[int(offsets[7]): int(offsets[7]) + 40]) or b"abc"
+    for metric in ("levenshtein", "indel", "jaro_winkler"):
+        op = N.OP_SIMILARITY if metric == "jaro_winkler" else N.OP_DISTANCE
+        got = GPU[metric].BatchComparator(q).many(op, corpus)
+        exp = ORA[metric].BatchComparator(q).many(op, data, offsets, nthreads=8)
+        assert len(_same(got, exp)) == 0, metric
