@@ -70,6 +70,8 @@ def parse():
                     help="candidate lengths uniform in [1, --cand-len] instead of one fixed length (BASELINE.json configs[0]'s 'len <= 64' "
                          "distribution at scale): the corpus is packed from host arrays into exact-length tiles + mixed tiles")
     ap.add_argument("--min-len", type=int, default=1, help="--ragged: shortest candidate length (lengths uniform in [--min-len, --cand-len])")
+    ap.add_argument("--slot-order", action="store_true",
+                    help="--ragged: results in the corpus' SLOT order (RF_FLAG_SLOT_ORDER: no gather pass; rf_corpus_slot_index maps them back -- the parity leg does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="after the headline's timed region, run one short leg (own process, --extra-steps steps, own roofline + oracle parity) for "
@@ -277,8 +279,13 @@ def main():
     t_setup = time.time() - t0
 
     is_f64 = args.metric in ("jaro", "jaro_winkler")
-    out = torch.empty(n * nq, dtype=torch.float64 if is_f64 else torch.int32, device=dev)
+    n_out = corpus.slot_count if args.slot_order else n
+    out = torch.empty(n_out * nq, dtype=torch.float64 if is_f64 else torch.int32, device=dev)
     call_args = rf.Args()
+    if args.slot_order:
+        if nq > 1 or args.mode != "many" or world > 1 or force_dist:
+            raise SystemExit("bench.py: --slot-order is a single-GPU, single-query 'many' workload")
+        call_args = call_args.slot_order()
     if args.cutoff is not None:
         call_args = call_args.score_cutoff(args.cutoff)
     if args.hint is not None:
@@ -491,6 +498,7 @@ def main():
                  + (f", Zipf({args.zipf}) symbols" if args.zipf > 0 else "")
                  + (f", log-normal lengths (median {args.lognormal_median})" if args.ragged and args.lognormal_median > 0 else "")
                  + (f", score_hint={args.hint}" if args.hint is not None else "")
+                 + (", results in slot order (RF_FLAG_SLOT_ORDER)" if args.slot_order else "")
                  + (", BASELINE.json configs[1]" if (args.metric == "levenshtein" and n == 100_000_000 and ln == 64 and args.query_len <= 64
                                                      and args.cutoff is None and not weights and not args.ragged and args.near_dup_share == 0 and args.hint is None
                                                      and args.head_share == 0 and args.zipf == 0 and args.mode == "many") else ""))
@@ -695,7 +703,14 @@ def main():
 
         torch.cuda.synchronize()
         op = N.OP_SIMILARITY if is_f64 else N.OP_DISTANCE
-        got_all = out[:n].cpu().numpy()
+        if args.slot_order:  # the caller's own permutation: slot -> original index, once per corpus
+            slot_index = torch.from_numpy(corpus.slot_index().astype(np.int64)).to(dev)
+            real = slot_index != 0xFFFFFFFF
+            back = torch.empty(n, dtype=out.dtype, device=dev)
+            back[slot_index[real]] = out[:n_out][real]
+            got_all = back.cpu().numpy()
+        else:
+            got_all = out[:n].cpu().numpy()
         mism, checked = 0, 0
         for (d_, o_), sel in ((ragged_sample, slice(0, len(ragged_sample[1]) - 1)), (ragged_strided, slice(0, n, 1009))):
             m = min(len(o_) - 1, 2_000_000)

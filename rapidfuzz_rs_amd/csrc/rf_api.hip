@@ -1036,20 +1036,14 @@ static rf_status pack_ragged_device(const uint8_t* bytes, const uint64_t* offset
         RF_HIP_C(launch_ragged_scatter_mixed(d_bytes, first, d_off, d_vals2, c->d_mixed, c->n_mixed, (uint32_t)pool_n, c->d_mixed_len, d_pool, d_pool + P, c->d_sigma, c->d_data, c->d_orig,
                                              c->d_mixed_orig, nullptr));
     }
-    // ---- 7. the second tile order (tiles_by_origin): the first original index of every exact tile comes home as one strided copy
+    // ---- 7. the second tile order (tiles_by_origin): sorted on the device too (the host's std::sort of 1.5 M keys was most of what was left of the call)
     if (!identity && n_exact >= 1024) {
-        std::vector<uint32_t> first_idx(n_exact);
-        RF_HIP_C(hipMemcpy2DAsync(first_idx.data(), sizeof(uint32_t), c->d_orig, kWave * sizeof(uint32_t), sizeof(uint32_t), n_exact, hipMemcpyDeviceToHost, nullptr));
-        RF_HIP_C(hipStreamSynchronize(nullptr));
-        std::vector<TileDesc> ordered = tiles;
         uint32_t z = 0;
         while (z < n_exact && tiles[z].len == 0) ++z;
-        std::vector<uint64_t> key(n_exact - z);  // (first original index, position): the sort of tiles_by_origin()
-        for (uint32_t i = 0; i < key.size(); ++i) key[i] = (uint64_t)first_idx[z + i] << 32 | (z + i);
-        std::sort(key.begin(), key.end());
-        for (uint32_t i = 0; i < key.size(); ++i) ordered[z + i] = tiles[(uint32_t)key[i]];
-        RF_HIP_C(hipMalloc(&c->d_tiles_by_origin, ordered.size() * sizeof(TileDesc)));
-        RF_HIP_C(hipMemcpy(c->d_tiles_by_origin, ordered.data(), ordered.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+        RF_HIP_C(hipMalloc(&c->d_tiles_by_origin, tiles.size() * sizeof(TileDesc)));
+        RF_HIP_C(hipMemcpyAsync(c->d_tiles_by_origin, c->d_tiles, tiles.size() * sizeof(TileDesc), hipMemcpyDeviceToDevice, nullptr));
+        // (the candidates' sort buffers are free again: n >= n_exact entries each)
+        RF_HIP_C(launch_tiles_by_origin(c->d_orig, c->d_tiles, z, n_exact, d_keys, d_vals, d_keys2, d_vals2, d_sort_temp, sort_bytes, c->d_tiles_by_origin, nullptr));
     }
     RF_HIP_C(hipStreamSynchronize(nullptr));  // the input is only borrowed for the duration of the call; the temporaries go with `tmp`
     timer.lap("device: sort + scatter + tile order");

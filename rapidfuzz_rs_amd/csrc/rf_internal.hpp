@@ -202,6 +202,8 @@ hipError_t launch_ragged_lengths(const uint64_t* offsets, uint32_t n, uint32_t m
                                  hipStream_t st);  // status[0] = longest length, status[1]: bit 0 = offsets decrease, bit 1 = a candidate longer than max_len_allowed
 hipError_t launch_ragged_byte_hist(const uint8_t* bytes, uint64_t first, uint64_t total, uint64_t stride, unsigned long long* hist, hipStream_t st);
 size_t ragged_sort_temp_bytes(uint32_t n);
+hipError_t launch_tiles_by_origin(const uint32_t* orig, const TileDesc* tiles, uint32_t z, uint32_t n_exact, uint32_t* keys, uint32_t* vals, uint32_t* keys2, uint32_t* vals2,
+                                  void* temp, size_t temp_bytes, TileDesc* out, hipStream_t st);
 hipError_t launch_ragged_sort(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, uint32_t bits, void* temp, size_t temp_bytes,
                               hipStream_t st);
 hipError_t launch_ragged_scatter_tiles(const uint8_t* bytes, uint64_t first, const uint64_t* offsets, const uint32_t* sorted_idx, const TileDesc* tiles, uint32_t uniform_len, uint32_t n_exact,

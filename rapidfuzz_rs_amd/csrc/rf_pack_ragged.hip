@@ -141,7 +141,40 @@ __global__ __launch_bounds__(256) void ragged_scatter_mixed_kernel(const uint8_t
     }
 }
 
+// the second tile order (rf_api.hip tiles_by_origin): the non-empty exact tiles [z, n_exact) ordered by their first candidate's original index -- keys and places
+// here, a radix sort, then the descriptors gathered through the sorted places
+__global__ void tile_first_index_kernel(const uint32_t* __restrict__ orig, const TileDesc* __restrict__ tiles, uint32_t z, uint32_t count, uint32_t* __restrict__ keys,
+                                        uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        keys[i] = orig[tiles[z + i].slot0];
+        vals[i] = z + i;
+    }
+}
+__global__ void tile_gather_kernel(const TileDesc* __restrict__ tiles, const uint32_t* __restrict__ place, uint32_t z, uint32_t count, TileDesc* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[z + i] = tiles[place[i]];
+}
+
 }  // namespace
+
+// out = tiles with [z, n_exact) in origin order (out already holds a copy of tiles); keys / vals / keys2 / vals2: n_exact u32 each
+hipError_t launch_tiles_by_origin(const uint32_t* orig, const TileDesc* tiles, uint32_t z, uint32_t n_exact, uint32_t* keys, uint32_t* vals, uint32_t* keys2, uint32_t* vals2,
+                                  void* temp, size_t temp_bytes, TileDesc* out, hipStream_t st)
+{
+    if (n_exact <= z) return hipSuccess;
+    const uint32_t count = n_exact - z;
+    const dim3 b(256), g((count + 255) / 256);
+    hipLaunchKernelGGL(tile_first_index_kernel, g, b, 0, st, orig, tiles, z, count, keys, vals);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)count, 0, 32, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_gather_kernel, g, b, 0, st, tiles, vals2, z, count, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_ragged_lengths(const uint64_t* offsets, uint32_t n, uint32_t max_len_allowed, uint32_t* keys, uint32_t* vals, unsigned long long* counts, uint32_t* status,
                                  hipStream_t st)
