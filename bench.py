@@ -658,7 +658,9 @@ def main():
         result["roofline"]["bound"] = "valu_issue"
         result["roofline"]["bound_note"] = "frac = algorithmic bytes / kernel time / HBM peak (the north star's yardstick); the binding limit is VALU issue: issue_bound.frac"
         if ib.get("package_power_w_under_scan") and (ib.get("core_clock_ghz") or {}).get("under_scan", 9.9) < 2.0:
-            result["roofline"]["bound_note"] += f"; at a core clock the package power cap holds to {ib['core_clock_ghz']['under_scan']} GHz ({ib['package_power_w_under_scan']} W drawn)"
+            pw = ib["package_power_w_under_scan"]
+            drawn = f"{pw.get('now')} W of a {pw.get('cap')} W cap" if isinstance(pw, dict) else f"{pw} W"
+            result["roofline"]["bound_note"] += f"; at a core clock the package power cap holds to {ib['core_clock_ghz']['under_scan']} GHz ({drawn} drawn)"
 
     if last_topk[0] is not None:
         # keys are (distance << 32 | global index); distances < 2^31 so the signed sort above is the unsigned order,

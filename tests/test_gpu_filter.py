@@ -310,3 +310,90 @@ def test_device_packer_equals_the_host_layout_byte_for_byte(shape, tmp_path):
         got = GPU[metric].BatchComparator(q).many(op, corpus)
         exp = ORA[metric].BatchComparator(q).many(op, data, offsets, nthreads=8)
         assert len(_same(got, exp)) == 0, metric
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RF_FUZZ_SEEDS", "16"))))
+def test_randomized_corpus_models_vary_what_the_plan_looks_at(seed):
+    """the plan layer picks kernels from symbol counts, length histograms and survivor shares, and every earlier GPU-vs-oracle corpus was
+    iid-uniform with substitution-only near-duplicates.  Per seed: a symbol law (uniform 62 / Zipf / 2 symbols / all 256 bytes), a length law (one length / uniform /
+    log-normal / bimodal), a share of candidates that carry the query's head, near-duplicates made by insertions, deletions and substitutions; 150 k .. 1.2 M
+    candidates (so that the head plane, the 6-bit payload, the lane compaction, the device packer and the gather maps all come into play); then random metric x op
+    x cutoff calls through rf_many_*, rf_filter_* and RF_FLAG_SLOT_ORDER -- every value against the oracle."""
+    rng = np.random.default_rng(77_000 + seed)
+    n = int(rng.choice([150_000, 400_000, 1_200_000]))
+    law = str(rng.choice(["uniform", "zipf", "two", "bytes"]))
+    draw = {"uniform": lambda m: synth.ALNUM[rng.integers(0, 62, size=m)], "zipf": lambda m: synth.zipf_alphabet_draw(rng, m, s=float(rng.choice([0.8, 1.3]))),
+            "two": lambda m: np.frombuffer(b"ab", dtype=np.uint8)[rng.integers(0, 2, size=m)], "bytes": lambda m: rng.integers(0, 256, size=m, dtype=np.uint8)}[law]
+    length_law = str(rng.choice(["one", "uniform", "lognormal", "bimodal"]))
+    max_len = int(rng.choice([24, 64, 70, 130]))
+    if length_law == "one":
+        lens = np.full(n, int(rng.choice([16, 33, 48, 64])), dtype=np.int64)
+    elif length_law == "uniform":
+        lens = rng.integers(1, max_len + 1, size=n)
+    elif length_law == "lognormal":
+        lens = np.clip(np.rint(rng.lognormal(np.log(max_len / 3), 0.6, size=n)), 0, max_len).astype(np.int64)
+    else:
+        lens = np.where(rng.random(n) < 0.7, rng.integers(max_len - 4, max_len + 1, size=n), rng.integers(1, 9, size=n))
+    qlen = int(rng.choice([8, 30, 48, 64, max(8, int(lens.max()))]))
+    q = draw(qlen)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+    data = draw(int(offsets[-1]))
+    # the query's head on a share of the candidates (as far as they reach)
+    share = float(rng.choice([0.0, 0.01, 0.3]))
+    for i in np.nonzero(rng.random(n) < share)[0]:
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        h = min(b - a, int(rng.integers(8, 13)), qlen)
+        data[a: a + h] = q[:h]
+    # near-duplicates by insertions / deletions / substitutions, cut or padded to the slot's length (the corpus keeps its length law)
+    for i in rng.choice(n, size=300, replace=False):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        row = list(q)
+        for _ in range(int(rng.integers(0, 6))):
+            r, pos = int(rng.integers(0, 3)), int(rng.integers(0, len(row) + 1))
+            if r == 0:
+                row.insert(pos, int(draw(1)[0]))
+            elif row:
+                if r == 1:
+                    del row[min(pos, len(row) - 1)]
+                else:
+                    row[min(pos, len(row) - 1)] = int(draw(1)[0])
+        row = (row + list(draw(max(0, b - a - len(row)))))[: b - a]
+        data[a:b] = np.array(row, dtype=np.uint8)
+    corpus = rf.Corpus.from_ragged(data, offsets)
+    slot_index = corpus.slot_index()
+    real = slot_index != NONE32
+    qb = q.tobytes()
+    for _ in range(7):
+        metric = str(rng.choice(["levenshtein", "osa", "indel", "lcs_seq", "jaro_winkler"]))
+        is_float_metric = metric == "jaro_winkler"
+        op = str(rng.choice(["distance", "similarity", "normalized_similarity"]))
+        is_f = is_float_metric or op.startswith("normalized")
+        kw = {}
+        if rng.random() < 0.8:
+            if is_f:
+                kw["score_cutoff"] = float(rng.choice([0.1, 0.3, 0.7, 0.9, 0.97])) if op != "distance" else float(rng.choice([0.03, 0.1, 0.3]))
+            elif op == "distance":
+                kw["score_cutoff"] = int(rng.choice([0, 1, 2, 3, 4, 5, 8, 20, qlen]))
+            else:
+                kw["score_cutoff"] = int(rng.choice([1, qlen // 2, max(1, qlen - 3)]))
+        if metric == "levenshtein" and op == "similarity" and "score_cutoff" in kw:
+            continue  # quirk Q2
+        opn = {"distance": N.OP_DISTANCE, "similarity": N.OP_SIMILARITY, "normalized_similarity": N.OP_NORMALIZED_SIMILARITY}[op]
+        bc, ob = GPU[metric].BatchComparator(qb), ORA[metric].BatchComparator(qb)
+        exp = ob.many(opn, data, offsets, nthreads=8, **kw)
+        got = bc.many(opn, corpus, **kw)
+        bad = _same(got, exp)
+        assert len(bad) == 0, (seed, law, length_law, share, metric, op, kw, bad[:5], got[bad[:5]], exp[bad[:5]])
+        slots = bc.many(opn, corpus, rf.Args().slot_order(), **kw)
+        back = np.empty_like(got)
+        back[slot_index[real]] = slots[real]
+        assert len(_same(back, exp)) == 0, ("slot order", seed, metric, op, kw)
+        if kw:
+            idx_e, val_e = _some(exp)
+            order = int(rng.choice([N.FILTER_BY_INDEX, N.FILTER_BY_SCORE, N.FILTER_ANY]))
+            idx, val = bc.filter_many(opn, corpus, order=order, **kw)
+            perm = np.argsort(idx, kind="stable")
+            assert np.array_equal(idx[perm], idx_e) and np.array_equal(val[perm], val_e), ("filter", seed, metric, op, kw, order, len(idx), len(idx_e))
+            if order == N.FILTER_BY_INDEX:
+                assert np.all(np.diff(idx.astype(np.int64)) > 0)
