@@ -15,9 +15,14 @@ ROWS = [  # (file stem, label)
     ("ragged_osa", "ragged, OSA"),
     ("ragged_indel", "ragged, Indel"),
     ("ragged_jaro_winkler", "ragged, Jaro-Winkler (f64 out)"),
+    ("ragged_indel_slots", "ragged, Indel, results in slot order (`RF_FLAG_SLOT_ORDER`: no gather pass, round 6)"),
+    ("ragged_levenshtein_slots", "ragged, Levenshtein query 64, slot order"),
+    ("ragged_jaro_winkler_slots", "ragged, Jaro-Winkler, slot order"),
+    ("ragged_lognormal_indel", "ragged, log-normal lengths (median 24) and Zipf(1.1) symbols, Indel"),
     ("ragged_cutoff3", "ragged [1, 64], `score_cutoff = 3` (4 of 64 lengths inside the window; the rest is the None pre-fill)"),
     ("ragged57_cutoff3", "ragged, lengths uniform in [57, 64], `score_cutoff = 3` (half the corpus inside the window: length-run views, round 4)"),
     ("ragged57_osa_cutoff3", "the same, OSA"),
+    ("ragged57_filter_cutoff3", "the same corpus, Levenshtein, compact pairs (`--mode filter`: slot-ordered temporary + compaction)"),
     ("c3_levenshtein_256", "C3 Levenshtein, query 256 x 10 M len 256 (4-word asm scan, Ukkonen band: round 5)"),
     ("levenshtein_320", "query 320 x 4 M len 320 (5-word asm scan, round 5)"),
     ("levenshtein_512", "query 512 x 2.5 M len 512 (8-word asm scan, round 5)"),
@@ -35,6 +40,12 @@ ROWS = [  # (file stem, label)
     ("osa", "OSA"),
     ("c5_cutoff3_many", "C5 shape, 100 M: `score_cutoff = 3`, one u32 per candidate"),
     ("c5_cutoff3_topk", "C5 shape, 100 M: `score_cutoff = 3`, top-16 only"),
+    ("filter_cutoff3", "the same, compact (index, score) pairs only: `rf_filter_u32`, one host synchronization per call inside the step (`--mode filter`, round 6)"),
+    ("survivors1_cutoff3_many", "C5 shape, 1 % of the candidates carry the query's first 8..12 symbols (`--head-share 0.01`): one u32 per candidate (lane compaction, round 6; round 5's path: 137)"),
+    ("survivors1_cutoff3_topk", "the same, top-16 only (round 5's path: 143)"),
+    ("survivors1_cutoff3_filter", "the same, compact pairs"),
+    ("survivors5_cutoff3_many", "5 % prefix sharers, one u32 per candidate (round 5's path: 80)"),
+    ("zipf_cutoff3_many", "Zipf(1.1) symbols instead of uniform ones, `score_cutoff = 3`, one u32 per candidate"),
     ("c5_1B_world1", "C5 = BASELINE configs[4] at N = 1: 1 B candidates, cutoff 3, top-16 + RCCL gather + merge per step (`--config c5`)"),
     ("topk16_nocutoff", "top-16, no cutoff, no per-candidate output"),
     ("sharded_path_world1", "the sharded step at world size 1 (top-16 + per-candidate distances + all-gather + merge)"),
@@ -44,6 +55,7 @@ ROWS = [  # (file stem, label)
     ("osa_cutoff3", "OSA, `score_cutoff = 3`"),
     ("cutoff5_many", "Levenshtein, `score_cutoff = 5` (the first look as a streaming pass over the head plane)"),
     ("jw_cutoff0.9", "Jaro-Winkler, `score_cutoff = 0.9`"),
+    ("jw_filter0.9", "the same, compact pairs (`rf_filter_f64`)"),
     ("wf_weights_1_2_3", "Levenshtein weights (1,2,3), 20 M candidates (`wf_reg_kernel<64>`)"),
 ]
 

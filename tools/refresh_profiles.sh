@@ -3,11 +3,12 @@
 #   rocprofv3 kernel-trace + PMC summaries of every BASELINE.json config's dominant kernel, and one bench.py JSON line per config.
 # Results land in gpurun_out/profiles/; copy them into profiles/ afterwards.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 mkdir -p gpurun_out/profiles
 cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
 # ONLY=<substring> restricts the run to the profiles / bench lines whose tag contains it (e.g. ONLY=ragged)
-P() { tag=$1; key=$2; shift 2; [[ -n "${ONLY:-}" && $tag != *$ONLY* ]] && return; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
+# PROFILES="tag tag ..." restricts the rocprofv3 summaries (five passes each) to those tags; the bench lines always run
+P() { tag=$1; key=$2; shift 2; [[ -n "${ONLY:-}" && $tag != *$ONLY* ]] && return; [[ -n "${PROFILES:-}" && " $PROFILES " != *" $tag "* ]] && return; tools/profile_c2.sh ${tag}_$R "$key" "$@"; }
 MATCH="rf::stream_lev64" P c2_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many"
 MATCH="rf::head_filter" P c2_levenshtein_cutoff3 "levenshtein:q64:n100000000:l64:cut3:many" --cutoff 3
 MATCH="rf::stream_levw4" P c3_levenshtein_256 "levenshtein:q256:n10000000:l256:cutNone:many" --query-len 256 --cand-len 256 --candidates 10000000
@@ -25,6 +26,11 @@ MATCH="rf::head_filter" P ragged_cutoff3 "levenshtein:q64:n100000000:l64:cut3:ma
 MATCH="rf::stream_lcs6" P ragged_indel "indel:q64:n100000000:l64:cutNone:many:ragged" --ragged --metric indel
 MATCH="rf::stream_levw8" P levenshtein_512 "levenshtein:q512:n2500000:l512:cutNone:many" --query-len 512 --cand-len 512 --candidates 2500000
 MATCH="rf::scan_multi" P multi4_levenshtein "levenshtein:q64:n100000000:l64:cutNone:many:x4" --queries 4
+# round 6: the cutoff path on a corpus that shares prefixes with the query (lane compaction), the compact (index, score) result, slot-order results
+MATCH="rf::head_filter" P survivors1_cutoff3 "none" --cutoff 3 --head-share 0.01
+MATCH="sparse_lean" P survivors5_cutoff3_sparse "none" --cutoff 3 --head-share 0.05
+MATCH="rf::head_filter" P filter_cutoff3 "none" --cutoff 3 --mode filter
+MATCH="rf::stream_lcs6" P ragged_indel_slots "none" --ragged --metric indel --slot-order
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
 b() { name=$1; shift; [[ -n "${ONLY:-}" && $name != *$ONLY* ]] && return; python bench.py --traffic off --extras off "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
 # the default line exactly as the driver runs it (extra_configs legs, in-run traffic)
@@ -63,6 +69,18 @@ b osa_cutoff3 --metric osa --cutoff 3
 b cutoff5_many --cutoff 5
 b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
 b c3_cutoff8 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
+b filter_cutoff3 --cutoff 3 --mode filter
+b survivors1_cutoff3_many --cutoff 3 --head-share 0.01
+b survivors1_cutoff3_topk --cutoff 3 --head-share 0.01 --mode topk --no-cpu-baseline
+b survivors1_cutoff3_filter --cutoff 3 --head-share 0.01 --mode filter
+b survivors5_cutoff3_many --cutoff 3 --head-share 0.05
+b zipf_cutoff3_many --cutoff 3 --zipf 1.1
+b ragged_indel_slots --ragged --metric indel --slot-order
+b ragged_levenshtein_slots --ragged --slot-order
+b ragged_jaro_winkler_slots --ragged --metric jaro_winkler --slot-order
+b ragged_lognormal_indel --ragged --metric indel --lognormal-median 24 --zipf 1.1
+b ragged57_filter_cutoff3 --ragged --min-len 57 --cutoff 3 --mode filter
+b jw_filter0.9 --metric jaro_winkler --fcutoff 0.9 --mode filter
 if [ -n "${ONLY:-}" ]; then cp gpurun_out/*_$R.txt gpurun_out/*_$R.json gpurun_out/profiles/ 2>/dev/null; ls gpurun_out/profiles | wc -l; exit 0; fi
 RF_BENCH_FORCE_DIST=1 python bench.py --steps 20 --no-cpu-baseline --traffic off --extras off 2>/dev/null | tail -1 > gpurun_out/profiles/bench_sharded_path_world1.json
 python bench.py --config c5 --extras off 2>/dev/null | tail -1 > gpurun_out/profiles/bench_c5_1B_world1.json
