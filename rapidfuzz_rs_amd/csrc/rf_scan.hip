@@ -466,16 +466,37 @@ __global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restric
     }
     at += in_front;
     lat += in_front_l;
-    if (s < G) {
-        const uint4* seg = reinterpret_cast<const uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)s * cap;
-        uint4* packed = reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)G * cap;
-        for (uint32_t j = 0; j < n; ++j) {
-            uint4 e = seg[j];
-            e.w = lat;
-            packed[at + j] = e;
-            const uint32_t c = (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z), k = (lat + kWave - 1) / kWave;  // (c <= 64: at most one multiple of 64 in [lat, lat + c))
-            if (k * kWave < lat + c) first_of[k] = at + j;
-            lat += c;
+    // the copy, a WAVEFRONT per segment (round 6: one thread per segment copied its entries one dependent 16-byte load and store at a time -- with a few entries per
+    // segment nobody noticed, with 90 of them -- 5 % prefix sharers -- it was the longest kernel of the step): lanes take 64 consecutive entries, a wavefront scan of
+    // their survivor counts gives each entry its running sum
+    __shared__ uint32_t seg_at[256], seg_lat[256], seg_n[256];
+    seg_at[threadIdx.x] = at, seg_lat[threadIdx.x] = lat, seg_n[threadIdx.x] = n;
+    __syncthreads();
+    const uint4* segs = reinterpret_cast<const uint4*>(buf + 4 + 2 * (size_t)G);
+    uint4* packed = reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)G * cap;
+    for (uint32_t k = wave; k < 256 && first + k < G; k += kWaves) {
+        const uint4* seg = segs + (size_t)(first + k) * cap;
+        const uint32_t cnt = seg_n[k], at0 = seg_at[k];
+        uint32_t run = seg_lat[k];
+        for (uint32_t j0 = 0; j0 < cnt; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            uint4 e = make_uint4(0, 0, 0, 0);
+            if (j < cnt) e = seg[j];
+            const uint32_t c = (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z);
+            uint32_t inc = c;
+#pragma unroll
+            for (uint32_t d = 1; d < (uint32_t)kWave; d <<= 1) {
+                const uint32_t v = __shfl_up(inc, d, kWave);
+                if (lane >= d) inc += v;
+            }
+            const uint32_t mine = run + inc - c;  // survivors in front of this entry
+            if (j < cnt) {
+                e.w = mine;
+                packed[at0 + j] = e;
+                const uint32_t kk = (mine + kWave - 1) / kWave;  // (c <= 64: at most one multiple of 64 in [mine, mine + c))
+                if (kk * kWave < mine + c) first_of[kk] = at0 + j;
+            }
+            run += (uint32_t)__shfl((int)inc, kWave - 1, kWave);
         }
     }
     if (first + 256 >= G && threadIdx.x == 0) {

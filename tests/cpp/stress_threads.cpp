@@ -210,6 +210,59 @@ static Result entries(rf_metric m, const std::vector<uint8_t>& q, const rf_corpu
     return r;
 }
 
+// rf_filter_*: the (index, score) pairs of the candidates within the cutoff (round 6: pinned report slot per host thread, per-stream lane lists, slot-ordered temporaries)
+static Result filter_u32(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, const rf_args& a, rf_filter_order order, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    std::vector<uint64_t> idx(8192);
+    std::vector<uint32_t> val(8192);
+    uint64_t cnt = 0;
+    CHECK(rf_filter_u32(c, corpus, RF_OP_DISTANCE, &a, 7, idx.size(), idx.data(), val.data(), &cnt, RF_MEM_HOST, order, st));
+    rf_comparator_free(c);
+    Result r{cnt};
+    for (uint64_t i = 0; i < std::min<uint64_t>(cnt, idx.size()); ++i) {
+        r.push_back(idx[i]);
+        r.push_back(val[i]);
+    }
+    return r;
+}
+static Result filter_f64(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, const rf_args& a, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    std::vector<uint64_t> idx(8192);
+    std::vector<double> val(8192);
+    uint64_t cnt = 0;
+    CHECK(rf_filter_f64(c, corpus, RF_OP_SIMILARITY, &a, 0, idx.size(), idx.data(), val.data(), &cnt, RF_MEM_HOST, RF_FILTER_BY_SCORE, st));
+    rf_comparator_free(c);
+    Result r{cnt};
+    for (uint64_t i = 0; i < std::min<uint64_t>(cnt, idx.size()); ++i) {
+        uint64_t bits;
+        memcpy(&bits, &val[i], 8);
+        r.push_back(idx[i]);
+        r.push_back(bits);
+    }
+    return r;
+}
+static Result many_slots_u32(rf_metric m, const std::vector<uint8_t>& q, const rf_corpus* corpus, rf_args a, void* st)
+{
+    rf_comparator* c = nullptr;
+    CHECK(rf_comparator_new(m, q.data(), q.size(), &c));
+    a.flags |= RF_FLAG_SLOT_ORDER;
+    const size_t slots = rf_corpus_slot_count(corpus);
+    std::vector<uint32_t> out(slots, 0), map(slots, 0);
+    CHECK(rf_many_u32(c, corpus, RF_OP_DISTANCE, &a, out.data(), RF_MEM_HOST, st));
+    CHECK(rf_corpus_slot_index(corpus, map.data(), RF_MEM_HOST));
+    rf_comparator_free(c);
+    std::vector<uint32_t> back(rf_corpus_count(corpus) + 1, 0);  // the caller's own permutation: padding slots hold unspecified values and are skipped
+    for (size_t s2 = 0; s2 < slots; ++s2)
+        if (map[s2] != 0xFFFFFFFFu) back[map[s2]] = out[s2];
+    Result r((back.size() + 1) / 2, 0);
+    memcpy(r.data(), back.data(), back.size() * 4);
+    return r;
+}
+
 int main(int argc, char** argv)
 {
     bool warm = false, noreuse = false;
@@ -312,6 +365,14 @@ int main(int argc, char** argv)
             memcpy(r.data(), out.data(), out.size() * 4);
             return r;
         },
+        // 29..34 (round 6): compact results -- the lane-compacted road (uniform corpus, cutoff 3 / 1), the general road (cutoff beyond the head plane, a ragged corpus
+        // through its slot-ordered temporary, f64 scores by score) -- and per-candidate results in slot order
+        [&](const Corpora& c, void* st) { return filter_u32(RF_LEVENSHTEIN, d.q64, c.uniform, cutoff_u(3), RF_FILTER_BY_INDEX, st); },
+        [&](const Corpora& c, void* st) { return filter_u32(RF_OSA, d.q64, c.uniform, cutoff_u(1), RF_FILTER_BY_SCORE, st); },
+        [&](const Corpora& c, void* st) { return filter_u32(RF_LEVENSHTEIN, d.q64, c.uniform, cutoff_u(30), RF_FILTER_BY_INDEX, st); },
+        [&](const Corpora& c, void* st) { return filter_u32(RF_LEVENSHTEIN, d.q64, c.ragged, cutoff_u(3), RF_FILTER_BY_INDEX, st); },
+        [&](const Corpora& c, void* st) { return filter_f64(RF_JARO_WINKLER, d.q64, c.ragged, cutoff_f(0.8), st); },
+        [&](const Corpora& c, void* st) { return many_slots_u32(RF_INDEL, d.q64, c.ragged, none, st); },
     };
     std::vector<Result> expect;
     {
