@@ -423,6 +423,8 @@ static KeptSets& kept_sets()
 static rf_status stream_many(const rf_comparator* c, const char* path, rf_op op, const rf_args* args, void* out_host, size_t out_capacity,
                              bool f64_out, uint64_t segment_bytes, int device)
 {
+    const rf_args args_v = args ? sanitized_args(args, false) : rf_args{};  // (a streamed scan's segments have no slot order of their own to offer)
+    if (args) args = &args_v;
     if (!c || !path || !args || !out_host) {
         set_error("rf_stream_many: invalid argument");
         return RF_ERR_INVALID_ARG;

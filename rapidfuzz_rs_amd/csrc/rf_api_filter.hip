@@ -299,8 +299,8 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
         void* d_tmp = nullptr;
         RF_HIP(sc.get(&d_tmp, m * elem));
         rf_args a = *args;
-        if (slots) a.flags |= RF_FLAG_SLOT_ORDER;
-        else a.flags &= ~RF_FLAG_SLOT_ORDER;
+        a.flags &= ~kFlagSlotsInternal;
+        if (slots) a.flags |= kFlagSlotsInternal;  // (run_many's own switch: rf_host.hpp)
         if (const rf_status rs = run_many(c, corpus, op, &a, d_tmp, RF_MEM_DEVICE, stream, f64_out); rs != RF_OK) return rs;
         uint32_t h[5] = {0, 0, 1, 0, 0};
         if (const rf_status rs = general(d_tmp, slots ? corpus->d_orig : nullptr, slots ? corpus->n_exact * (uint32_t)kWave : 0u, (uint32_t)m, nullptr, !slots, nullptr, h, nullptr); rs != RF_OK)

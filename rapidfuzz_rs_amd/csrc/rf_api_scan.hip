@@ -923,7 +923,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     hipStream_t st = (hipStream_t)stream;
     // RF_FLAG_SLOT_ORDER (round 6): out[slot] instead of out[original index] -- a length-bucketed corpus then needs neither scattered stores nor the gather pass
     // (rfgpu.h; rf_corpus_slot_index gives the map).  A single-length corpus' slots ARE its indices: nothing to do.
-    const bool want_slots = (args->flags & RF_FLAG_SLOT_ORDER) != 0 && !corpus->uniform && corpus->d_orig != nullptr;
+    const bool want_slots = (args->flags & kFlagSlotsInternal) != 0 && !corpus->uniform && corpus->d_orig != nullptr;  // (set by rf_many_* from RF_FLAG_SLOT_ORDER: rf_host.hpp)
     if (want_slots && (corpus != corpus_in || corpus->borrowed || !corpus->n_slots)) {
         set_error("RF_FLAG_SLOT_ORDER: not available for this corpus / query pair (a u32 query with overflow symbols, or a streamed segment)");
         return RF_ERR_UNSUPPORTED;
@@ -1215,24 +1215,29 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
 rf_status rf_many_u32(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint32_t* out,
                       rf_mem out_mem, void* stream)
 try {
-    return run_many(c, corpus, op, args, out, out_mem, stream, false);
+    if (!args) return run_many(c, corpus, op, args, out, out_mem, stream, false);
+    const rf_args a = sanitized_args(args, true);
+    return run_many(c, corpus, op, &a, out, out_mem, stream, false);
 }
 RF_ABI_CATCH
 
 rf_status rf_many_f64(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, double* out,
                       rf_mem out_mem, void* stream)
 try {
-    return run_many(c, corpus, op, args, out, out_mem, stream, true);
+    if (!args) return run_many(c, corpus, op, args, out, out_mem, stream, true);
+    const rf_args a = sanitized_args(args, true);
+    return run_many(c, corpus, op, &a, out, out_mem, stream, true);
 }
 RF_ABI_CATCH
 
-static rf_status run_one(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args, int device, void* out,
+static rf_status run_one(const rf_comparator* c, const uint8_t* s2, size_t len2, rf_op op, const rf_args* args_in, int device, void* out,
                          int* is_some, bool f64_out)
 {
-    if (!c || !args || !out || !is_some || (len2 && !s2)) {
+    if (!c || !args_in || !out || !is_some || (len2 && !s2)) {
         set_error("rf_one: invalid argument");
         return RF_ERR_INVALID_ARG;
     }
+    const rf_args args_v = sanitized_args(args_in, false), *args = &args_v;
     const uint64_t offsets[2] = {0, len2};
     rf_corpus* corpus = nullptr;
     rf_status s = rf_corpus_pack(s2, offsets, 1, device, &corpus);
@@ -1270,13 +1275,14 @@ RF_ABI_CATCH
 // Queries whose recurrences fit one machine word and agree on the kernel family are fused kMaxMulti (then 2) at a
 // time into scan_multi_kernel launches, which read every candidate byte once per group; the rest go through the
 // single-query launch.  Either way row q of `out` is exactly what rf_many_* gives for cs[q].
-static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args,
+static rf_status run_many_multi(const rf_comparator* const* cs_in, uint32_t q, const rf_corpus* corpus, rf_op op, const rf_args* args_in,
                                 void* out, rf_mem out_mem, void* stream, bool f64_out)
 {
-    if (!cs_in || !corpus || !args) {
+    if (!cs_in || !corpus || !args_in) {
         set_error("null handle or args");
         return RF_ERR_INVALID_ARG;
     }
+    const rf_args args_v = sanitized_args(args_in, false), *args = &args_v;  // (rows of n entries: RF_FLAG_SLOT_ORDER is rf_many_*'s alone)
     if (q == 0 || corpus->n == 0) return RF_OK;
     if (!out) {
         set_error("null output");

@@ -12,6 +12,8 @@ static rf_status topk_core(const rf_comparator* c_in, const rf_corpus* corpus_in
                            uint32_t key_index_base, uint64_t* d_best /*device, k entries*/, uint32_t* out_all,
                            rf_mem out_all_mem, hipStream_t st, bool* desc)
 {
+    const rf_args args_v = args ? sanitized_args(args, false) : rf_args{};  // (RF_FLAG_SLOT_ORDER is rf_many_*'s alone: the scores here are n-entry vectors)
+    if (args) args = &args_v;
     Effective eff;
     if (const rf_status rs = make_effective(c_in, corpus_in, st, &eff); rs != RF_OK) return rs;
     const rf_comparator* c = eff.c;
@@ -288,6 +290,8 @@ static rf_status select_topk(const void* d_scores, bool f64, bool desc, uint32_t
 static rf_status topk_by_selection(const rf_comparator* c, const rf_corpus* corpus, rf_op op, const rf_args* args, uint64_t k, bool f64, void* out_all,
                                    rf_mem out_all_mem, hipStream_t st, std::vector<uint64_t>* keys, std::vector<uint32_t>* idx, bool* desc)
 {
+    const rf_args args_v = args ? sanitized_args(args, false) : rf_args{};
+    if (args) args = &args_v;
     const size_t elem = f64 ? sizeof(double) : sizeof(uint32_t);
     *desc = op == RF_OP_SIMILARITY || op == RF_OP_NORMALIZED_SIMILARITY;
     void* d_scores = out_all;

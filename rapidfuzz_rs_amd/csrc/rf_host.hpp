@@ -176,6 +176,17 @@ struct rf_corpus {
     const rf_corpus* parent = nullptr;            // set on such an image: scratch and locks live in the real corpus
 };
 constexpr uint8_t kOverflowId = 254, kAbsentId = 255;
+// RF_FLAG_SLOT_ORDER is honoured by rf_many_u32 / rf_many_f64 ONLY (their `out` is sized by rf_corpus_slot_count); every other entry point writes n-entry rows and must
+// never see it.  run_many therefore looks at an INTERNAL bit that only those two entry points (and rf_filter_*, for its own temporary) set; the bit is stripped from
+// whatever a caller passes in.
+constexpr uint32_t kFlagSlotsInternal = 0x40000000u;
+inline rf_args sanitized_args(const rf_args* a, bool slots_allowed)
+{
+    rf_args r = *a;
+    r.flags &= ~kFlagSlotsInternal;
+    if (slots_allowed && (r.flags & RF_FLAG_SLOT_ORDER)) r.flags |= kFlagSlotsInternal;
+    return r;
+}
 __attribute__((visibility("hidden"))) extern std::atomic<uint64_t> g_corpus_uid;
 
 // Symbol renaming.  Every column of every kernel gathers 64 table rows from LDS, one per lane, and LDS bank

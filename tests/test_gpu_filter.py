@@ -255,6 +255,18 @@ def test_filter_and_slot_order_on_a_length_bucketed_corpus():
     back = np.empty(n, dtype=np.uint32)
     back[slot_index[real]] = slots[real]
     assert len(_same(back, exp)) == 0
+    # the flag belongs to rf_many_* alone: top-k, many-queries and filter calls write n-entry rows / pairs and must ignore it
+    so = rf.distance.levenshtein.Args().slot_order()
+    bc = GPU["levenshtein"].BatchComparator(q)
+    s0, i0 = bc.topk(corpus, 7)
+    s1, i1 = bc.topk(corpus, 7, args=so)
+    assert np.array_equal(s0, s1) and np.array_equal(i0, i1)
+    rows0 = GPU["indel"].BatchComparator.many_multi([GPU["indel"].BatchComparator(q), GPU["indel"].BatchComparator(q[:20])], N.OP_DISTANCE, corpus)
+    rows1 = GPU["indel"].BatchComparator.many_multi([GPU["indel"].BatchComparator(q), GPU["indel"].BatchComparator(q[:20])], N.OP_DISTANCE, corpus, so)
+    assert rows0.shape == rows1.shape == (2, n) and np.array_equal(rows0, rows1)
+    f0 = bc.filter_many(N.OP_DISTANCE, corpus, score_cutoff=5)
+    f1 = bc.filter_many(N.OP_DISTANCE, corpus, so, score_cutoff=5)
+    assert np.array_equal(f0[0], f1[0]) and np.array_equal(f0[1], f1[1])
     # a single-length corpus: slots are indices
     rows = synth.rows_host(5000, 24, seed=4)
     c2 = rf.Corpus.from_rows(rows)
