@@ -12,7 +12,7 @@
 // sums for its tile, the n-th set bit of that tile's mask for its lane -- and reads its own candidate's chunk rows (one 16-byte load per lane and chunk;
 // neighbouring survivors of one tile share cache lines).  (A first version kept a mask for EVERY tile and a hipcub sum over all of them: one more store per tile
 // pair in the first pass's loop cost the random-corpus case 14 %, profiles/survivors_r06.txt.)  Columns run from 0 on the full-width state with a look at every chunk
-// end (wavefront ballot over the dense tile), chunks one ahead.  Results go where the caller wants them: out[candidate] (dense vector: the first pass has written
+// end (wavefront ballot over the dense tile), the next chunk fetched only by a tile that is still alive.  Results go where the caller wants them: out[candidate] (dense vector: the first pass has written
 // every other entry), a length run's run_orig[], the in-scan top-k lists, or -- rf_filter_*, no dense vector at all -- lane_val / lane_idx at the survivor's number.
 // Everything is exact for every input: a survivor is merely a candidate the first pass could not rule out.
 #include <algorithm>
@@ -125,8 +125,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
             st.init();
             bool dead = false;
             for (uint32_t c = 0; c < nch; ++c) {
-                uint4 more = chunk;
-                if (c + 1 < nch) more = load_chunk(cur.src + (size_t)(c + 1) * kWave);  // one chunk ahead
+                // (the next chunk is fetched only once this one has not killed the tile: a lane's 16 bytes pull a whole 128-byte line out of a row it shares with no
+                // other survivor, and nearly every survivor of a prefix-sharing corpus dies at its first chunk end -- fetching one chunk ahead doubled the traffic of a
+                // pass that is bound by exactly that, 5 % prefix sharers: 332 us per 100 M, profiles/survivors5_cutoff3_sparse_r06.txt)
                 const uint32_t cols = len2 - c * kChunk;
                 if (cols >= (uint32_t)kChunk)
                     process_chunk_full<State>(st, lds_pm, chunk);
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
                     dead = true;  // no lane of this dense tile can pass the cutoff any more
                     break;
                 }
-                chunk = more;
+                if (c + 1 < nch) chunk = load_chunk(cur.src + (size_t)(c + 1) * kWave);
             }
             const uint32_t raw = st.result(len1, len2);
             // where this lane's result goes
