@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t pairs = (p.tile_end - p.tile_begin + 1) / 2, stride = gridDim.x * kWavesPerBlock;
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
-    // kLanes: [0] packed count | [1] survivors | 2 pad | G tile counts | G lane counts | G segments of `cap` 16-byte entries | the packed entries
+    // kLanes: [0] packed count | [1] survivors | 2 pad | G (tile count, lane count) pairs | G segments of `cap` 16-byte entries | the packed entries
     uint32_t* seg = kLanes ? buf + 4 + 2 * (size_t)stride + (size_t)gw * cap * 4 : buf + 1 + 2 * (size_t)stride + (size_t)gw * cap;
     uint32_t kept = 0, kept_lanes = 0;
     uint32_t pr = gw;
@@ -374,8 +374,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void head_filter_kernel(cons
     }
     if (lane == 0) {
         if constexpr (kLanes) {
-            buf[4 + gw] = kept;
-            buf[4 + stride + gw] = kept_lanes;
+            reinterpret_cast<uint2*>(buf + 4)[gw] = make_uint2(kept, kept_lanes);  // (one 8-byte word per wavefront: the pack kernel adds them up in front of every block)
         } else {
             buf[1 + gw] = kept;
         }
@@ -395,6 +394,7 @@ __global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restric
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t first = blockIdx.x * 256, s = first + threadIdx.x;
     uint32_t before = 0;  // this thread's share of the counts in front of the block
+#pragma unroll 8
     for (uint32_t k = threadIdx.x; k < first; k += 256) before += buf[1 + k];
     const uint32_t n = s < G ? buf[1 + s] : 0u;
     uint32_t incl = n;  // inclusive scan of n inside the wavefront
@@ -428,19 +428,23 @@ __global__ __launch_bounds__(256) void tile_list_pack_kernel(uint32_t* __restric
 // surviving lanes -- and two running sums: an entry's last word becomes the number of survivors in front of it, which is what rf_sparse.hip searches.
 // first[j] = the packed entry that holds survivor 64 j: where dense tile j of the second pass starts looking (every entry holds >= 1 survivor, so the 64 entries
 // from there on hold all of the tile's 64).
-// buf: [0] packed entries | [1] survivors | 2 pad | G tile counts | G lane counts | G segments of `cap` entries | the packed entries | first[]
+// buf: [0] packed entries | [1] survivors | 2 pad | G (tile count, lane count) pairs | G segments of `cap` entries | the packed entries | first[]
 __global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restrict__ buf, uint32_t G, uint32_t cap, uint32_t* __restrict__ first_of)
 {
     constexpr uint32_t kWaves = 256 / kWave;
     __shared__ uint32_t own[kWaves], front[kWaves], own_l[kWaves], front_l[kWaves];
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t first = blockIdx.x * 256, s = first + threadIdx.x;
+    const uint2* __restrict__ counts = reinterpret_cast<const uint2*>(buf + 4);  // (tiles, surviving lanes) per segment
     uint32_t before = 0, before_l = 0;  // this thread's share of the counts in front of the block
-    for (uint32_t k = threadIdx.x; k < first; k += 256) {
-        before += buf[4 + k];
-        before_l += buf[4 + G + k];
+#pragma unroll 8
+    for (uint32_t k = threadIdx.x; k < first; k += 256) {  // (independent loads, eight in flight: the last block's chain is what the kernel takes)
+        const uint2 c2 = counts[k];
+        before += c2.x;
+        before_l += c2.y;
     }
-    const uint32_t n = s < G ? buf[4 + s] : 0u, nl = s < G ? buf[4 + G + s] : 0u;
+    const uint2 mine2 = s < G ? counts[s] : make_uint2(0u, 0u);
+    const uint32_t n = mine2.x, nl = mine2.y;
     uint32_t incl = n, incl_l = nl;  // inclusive scans inside the wavefront
 #pragma unroll
     for (uint32_t d = 1; d < (uint32_t)kWave; d <<= 1) {
@@ -466,54 +470,25 @@ __global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restric
     }
     at += in_front;
     lat += in_front_l;
-    // the copy, a WAVEFRONT per segment (round 6: one thread per segment copied its entries one dependent 16-byte load and store at a time -- with a few entries per
-    // segment nobody noticed, with 90 of them -- 5 % prefix sharers -- it was the longest kernel of the step): lanes take 64 consecutive entries, a wavefront scan of
-    // their survivor counts gives each entry its running sum
-    __shared__ uint32_t seg_at[256], seg_lat[256], seg_n[256];
-    seg_at[threadIdx.x] = at, seg_lat[threadIdx.x] = lat, seg_n[threadIdx.x] = n;
-    __syncthreads();
-    const uint4* segs = reinterpret_cast<const uint4*>(buf + 4 + 2 * (size_t)G);
-    uint4* packed = reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)G * cap;
-    // ... but SHORT segments (a random corpus leaves half a dozen entries in each) stay with their own thread: 256 of them in flight at once, where a wavefront would
-    // walk its 64 segments one memory round trip after another (measured: + 45 us on the random corpus' 170 us step)
-    constexpr uint32_t kShort = 8;
-    if (s < G && n <= kShort) {
-        const uint4* seg = segs + (size_t)s * cap;
+    // the copy: a thread per segment, FOUR entries' loads in flight at a time (one dependent 16-byte load and store per entry was the longest kernel of the step at
+    // 5 % prefix sharers, ~90 entries per segment; a wavefront per segment was tried and is no faster: it walks its 64 segments one memory round trip after another)
+    if (s < G) {
+        const uint4* seg = reinterpret_cast<const uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)s * cap;
+        uint4* packed = reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)G) + (size_t)G * cap;
         uint32_t run = lat;
-        for (uint32_t j = 0; j < n; ++j) {
-            uint4 e = seg[j];
+        auto place = [&](uint4 e, uint32_t j) {
             e.w = run;
             packed[at + j] = e;
-            const uint32_t c = (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z), kk = (run + kWave - 1) / kWave;
+            const uint32_t c = (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z), kk = (run + kWave - 1) / kWave;  // (c <= 64: at most one multiple of 64 in [run, run + c))
             if (kk * kWave < run + c) first_of[kk] = at + j;
             run += c;
+        };
+        uint32_t j = 0;
+        for (; j + 4 <= n; j += 4) {
+            const uint4 e0 = seg[j], e1 = seg[j + 1], e2 = seg[j + 2], e3 = seg[j + 3];
+            place(e0, j), place(e1, j + 1), place(e2, j + 2), place(e3, j + 3);
         }
-    }
-    for (uint32_t k = wave; k < 256 && first + k < G; k += kWaves) {
-        const uint4* seg = segs + (size_t)(first + k) * cap;
-        const uint32_t cnt = seg_n[k], at0 = seg_at[k];
-        if (cnt <= kShort) continue;  // (its own thread has copied it)
-        uint32_t run = seg_lat[k];
-        for (uint32_t j0 = 0; j0 < cnt; j0 += kWave) {
-            const uint32_t j = j0 + lane;
-            uint4 e = make_uint4(0, 0, 0, 0);
-            if (j < cnt) e = seg[j];
-            const uint32_t c = (uint32_t)__popc(e.y) + (uint32_t)__popc(e.z);
-            uint32_t inc = c;
-#pragma unroll
-            for (uint32_t d = 1; d < (uint32_t)kWave; d <<= 1) {
-                const uint32_t v = __shfl_up(inc, d, kWave);
-                if (lane >= d) inc += v;
-            }
-            const uint32_t mine = run + inc - c;  // survivors in front of this entry
-            if (j < cnt) {
-                e.w = mine;
-                packed[at0 + j] = e;
-                const uint32_t kk = (mine + kWave - 1) / kWave;  // (c <= 64: at most one multiple of 64 in [mine, mine + c))
-                if (kk * kWave < mine + c) first_of[kk] = at0 + j;
-            }
-            run += (uint32_t)__shfl((int)inc, kWave - 1, kWave);
-        }
+        for (; j < n; ++j) place(seg[j], j);
     }
     if (first + 256 >= G && threadIdx.x == 0) {
         buf[0] = in_front + block_total;
