@@ -55,6 +55,23 @@ ResultSlot& result_slot()
     }
     return slot;
 }
+// filter_select_kernel's workspace: per host thread and device, zeroed once (the kernel leaves it zeroed); rf_filter_* is synchronous per host thread, so one call at a
+// time uses it.  nullptr: no memory for it (the callers take the general compaction).
+void* select_workspace(int device)
+{
+    thread_local std::map<int, void*> ws;
+    auto it = ws.find(device);
+    if (it != ws.end()) return it->second;
+    void* p = nullptr;
+    if (hipMalloc(&p, filter_select_work_bytes()) != hipSuccess || hipMemset(p, 0, filter_select_work_bytes()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    ws[device] = p;
+    return p;
+}
+
 // wait for the kernel that carries `seq`; false = the stream drained (or failed) without it
 bool await_slot(ResultSlot& slot, hipStream_t st, uint32_t h[3])
 {
@@ -267,17 +284,19 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
                 held.unlock();
             };
             second_road = false;
-            if (corpus->filter_last_survivors.load(std::memory_order_relaxed) <= filter_small_max() && cap) {
-                // few survivors last time: everything in one workgroup -- select, order, widen, count
+            void* ws = cap ? select_workspace(corpus->device) : nullptr;
+            if (ws) {
+                // the Somes among the survivors -- few, under a cutoff -- selected by every workgroup, ordered, widened and counted by the last one to arrive: ONE kernel
+                // behind the scan, whatever the number of survivors
                 uint32_t* target = report_target();
-                RF_HIP(launch_filter_small(lane_val, f64_out, lane_idx, cap2, d_total, by_score, desc, cap, index_base, d_index64, d_score, target, slot.seq, d_total, st));
+                RF_HIP(launch_filter_select(lane_val, f64_out, lane_idx, cap2, d_total, by_score, desc, cap, index_base, d_index64, d_score, ws, target, slot.seq, d_total, st));
                 release();
                 if (const rf_status rs = await_report(h); rs != RF_OK) return rs;
                 corpus->filter_last_survivors.store(h[4], std::memory_order_relaxed);
                 if (h[2] == 0) {
                     count = h[0];
                     delivered = true;
-                } else if (h[4] <= cap2) {  // more survivors than one workgroup orders: the general compaction over them (their number is known now)
+                } else if (h[4] <= cap2) {  // more results than one workgroup orders: the general compaction over the survivors (their number is known now)
                     if (const rf_status rs = general(lane_val, lane_idx, 0, h[4], nullptr, false, nullptr, h, nullptr); rs != RF_OK) return rs;
                 } else {
                     second_road = true;  // more survivors than room
@@ -299,11 +318,26 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
         void* d_tmp = nullptr;
         RF_HIP(sc.get(&d_tmp, m * elem));
         rf_args a = *args;
-        a.flags &= ~kFlagSlotsInternal;
-        if (slots) a.flags |= kFlagSlotsInternal;  // (run_many's own switch: rf_host.hpp)
+        a.flags &= ~(kFlagSlotsInternal | kFlagWindowInternal);
+        // A cutoff's length window (plan(): the tiles outside [tile_begin, tile_end) are None by their length alone) is all this call has to look at in a slot-ordered
+        // temporary -- slot = 64 x tile + lane for exact tiles and views alike: neither the pre-fill nor the compaction touches the rest (ragged [1, 64] under a
+        // cutoff of 3 edits: 4 of 64 lengths)
+        size_t w0 = 0, w1 = m;
+        if (slots) {
+            a.flags |= kFlagSlotsInternal;  // (run_many's own switch: rf_host.hpp)
+            ScanParams pw;
+            RawKind raww = RAW_LEV;
+            if (plan(c, corpus, op, &a, f64_out, &pw, &raww) == RF_OK && pw.prefill_none) {
+                a.flags |= kFlagWindowInternal;
+                w0 = (size_t)pw.tile_begin * kWave, w1 = (size_t)pw.tile_end * kWave;
+            }
+        }
         if (const rf_status rs = run_many(c, corpus, op, &a, d_tmp, RF_MEM_DEVICE, stream, f64_out); rs != RF_OK) return rs;
         uint32_t h[5] = {0, 0, 1, 0, 0};
-        if (const rf_status rs = general(d_tmp, slots ? corpus->d_orig : nullptr, slots ? corpus->n_exact * (uint32_t)kWave : 0u, (uint32_t)m, nullptr, !slots, nullptr, h, nullptr); rs != RF_OK)
+        const uint32_t exact_slots = corpus->n_exact * (uint32_t)kWave;
+        if (const rf_status rs = general(static_cast<const uint8_t*>(d_tmp) + w0 * elem, slots ? corpus->d_orig + w0 : nullptr,
+                                         slots ? (uint32_t)(exact_slots > w0 ? exact_slots - w0 : 0) : 0u, (uint32_t)(w1 - w0), nullptr, !slots, nullptr, h, nullptr);
+            rs != RF_OK)
             return rs;
     }
     *out_count = count;

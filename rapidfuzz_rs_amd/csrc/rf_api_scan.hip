@@ -369,6 +369,18 @@ static size_t launch_scratch_bytes(const ScanParams& p, RawKind raw)
     return 0;
 }
 
+// RF_PACK_TIMING=1: what the structures a corpus builds on first use cost (stderr, one line each) -- bench.py's accel_build_ms, itemised
+struct AccelTimer {
+    const char* what;
+    bool on = getenv("RF_PACK_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit AccelTimer(const char* w) : what(w) {}
+    ~AccelTimer()
+    {
+        if (on) std::fprintf(stderr, "[rf accel] %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // The largest stored symbol of the payload (symbols are stored as their frequency rank: a 62-symbol corpus holds 0 .. 61), computed
 // exactly on first use -- one streaming pass -- and kept.  0xFFFFFFFF when it cannot be had.
 static uint32_t corpus_max_stored_symbol(const rf_corpus* corpus, hipStream_t st)
@@ -376,6 +388,7 @@ static uint32_t corpus_max_stored_symbol(const rf_corpus* corpus, hipStream_t st
     if (corpus->borrowed || corpus->wide || !corpus->d_data || corpus->data_bytes < 16) return 0xFFFFFFFFu;
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);
     if (corpus->max_stored_sym == 0xFFFFFFFFu) {
+        AccelTimer timer("largest stored symbol");
         uint32_t* d = nullptr;
         uint32_t v = 0;
         if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) {
@@ -411,6 +424,7 @@ const uint8_t* corpus_head8_plane(const rf_corpus* corpus, const ScanParams& p, 
         return nullptr;
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);
     if (!corpus->d_heads8) {
+        AccelTimer timer("head plane (8 symbols)");
         uint8_t* h = nullptr;
         if (hipMalloc((void**)&h, ((size_t)plane_tiles + 1) * kWave * 8) != hipSuccess) {  // (+ one row: head_filter_kernel reads tiles in pairs)
             (void)hipGetLastError();
@@ -440,6 +454,7 @@ const uint32_t* corpus_head6_plane(const rf_corpus* corpus, hipStream_t st)
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);
     if (!corpus->d_heads6 && !corpus->heads6_tried) {
         corpus->heads6_tried = true;
+        AccelTimer timer("head plane at 6 bits");
         uint32_t* h = nullptr;
         const size_t rows = ((size_t)corpus->n_tiles + 1) / 2 + 1;  // (+ one pair: the pass reads a pair ahead)
         if (hipMalloc((void**)&h, rows * 3 * kWave * sizeof(uint32_t)) != hipSuccess) {
@@ -474,6 +489,7 @@ const uint32_t* corpus_data6(const rf_corpus* corpus, hipStream_t st)
     std::lock_guard<std::mutex> lock(corpus->scratch_mu);
     if (!corpus->d_data6 && !corpus->data6_tried) {
         corpus->data6_tried = true;
+        AccelTimer timer("6-bit payload");
         // chunk rows of 64 lanes: tiles x chunks of a single-length corpus; a bucketed one's whole payload, row by row (the 6-bit image mirrors it at 3/4 of every offset)
         const uint32_t nch = corpus->uniform ? (corpus->uniform_len + kChunk - 1) / kChunk : 1;
         const uint64_t rows = corpus->uniform ? (uint64_t)corpus->n_tiles * nch : corpus->data_bytes / (kWave * kChunk);
@@ -634,7 +650,10 @@ static hipError_t launch_scan_runs(RawKind raw, const ScanParams& p, const rf_co
 {
     static const uint32_t min_run = [] { const char* e = getenv("RF_RUN_MIN_TILES"); return e ? (uint32_t)atoi(e) : 256u; }();
     hipError_t e = hipSuccess;
-    if (p.out && !p.topk_k) e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, (size_t)p.n * (p.out_f64 ? 2 : 1), st);
+    if (p.out && !p.topk_k) {
+        const size_t w = p.out_f64 ? 2 : 1, from = p.prefill_window ? (size_t)p.tile_begin * kWave : 0, count = p.prefill_window ? (size_t)(p.tile_end - p.tile_begin) * kWave : (size_t)p.n;
+        if (count) e = hipMemsetD32Async((hipDeviceptr_t)(reinterpret_cast<uint32_t*>(p.out) + from * w), (int)RF_NONE_U32, count * w, st);
+    }
     const uint32_t ex_begin = std::min(p.tile_begin, corpus->n_exact), ex_end = std::min(p.tile_end, corpus->n_exact);
     uint64_t off = 0;  // payload offset of the current length's first tile (exact tiles lie back to back in length order)
     uint32_t pend_a = 0, pend_b = 0;  // general launches are merged over neighbouring short runs
@@ -1046,6 +1065,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
         {
             std::lock_guard<std::mutex> lock(corpus->scratch_mu);
             if (!corpus->d_slot_ident) {
+                AccelTimer timer("slot maps + window table");
                 // once per corpus: the slot -> slot map the scans store through, and what the gather needs -- the window table
                 // (rf_pack.hip window_gather_kernel) when the slots are few enough ascending runs, else the candidate -> slot map
                 static const bool use_windows = [] { const char* e = getenv("RF_GATHER_WINDOWS"); return !e || atoi(e) != 0; }();
@@ -1114,6 +1134,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
             p.mixed = nullptr;  // views, not scan_kernel_mixed: one slot per candidate
             p.mixed_end = 0;
             p.n = (uint32_t)corpus->n_slots;
+            p.prefill_window = (args->flags & kFlagWindowInternal) ? 1u : 0u;
         } else if (corpus->d_slot_ident) {
         // the temporary: this stream's kept buffer (grown if this call needs f64 where u32 was kept); beyond 4 streams per corpus a
         // stream-ordered allocation for the call

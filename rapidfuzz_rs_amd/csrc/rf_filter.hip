@@ -233,6 +233,104 @@ __global__ __launch_bounds__(kSmallThreads) void filter_small_kernel(const T* __
     }
 }
 
+// ---- the same finish for MANY entries with few results (the survivors of the lane compaction: 100 k band-test survivors per 100 M random candidates, a few dozen of
+// them within the cutoff): every workgroup walks its share of the entries and appends the Somes it finds to a small workspace (one atomic per RESULT, not per entry),
+// the LAST workgroup to arrive (a ticket) orders them in LDS exactly like filter_small_kernel, writes the caller's arrays and the report, and leaves the workspace
+// zeroed for the next call.  More than kSmallMax results: report [2] = 1 and nothing written -- the general compaction takes over.
+struct SelectWork {
+    uint32_t count, done, pad[2];
+    uint32_t idx[kSmallMax];
+    uint64_t bits[kSmallMax];
+};
+template <class T>
+__global__ __launch_bounds__(kSmallThreads) void filter_select_kernel(const T* __restrict__ val, const uint32_t* __restrict__ map, uint32_t m_bound, const uint32_t* __restrict__ m_dev,
+                                                                      bool by_score, bool desc, uint32_t capacity, uint64_t index_base, uint64_t* __restrict__ out_index,
+                                                                      T* __restrict__ out_val, SelectWork* __restrict__ ws, uint32_t* __restrict__ res, uint32_t seq,
+                                                                      const uint32_t* __restrict__ aux_dev)
+{
+    __shared__ uint64_t k1[kSmallMax];
+    __shared__ uint32_t k2[kSmallMax];
+    __shared__ uint64_t pv[kSmallMax];
+    __shared__ uint32_t last;
+    const uint32_t m_all = m_dev ? *m_dev : m_bound, m = min(m_all, m_bound);
+    for (uint64_t e = (uint64_t)blockIdx.x * kSmallThreads + threadIdx.x; e < m; e += (uint64_t)gridDim.x * kSmallThreads) {
+        const T v = val[e];
+        if (some(v)) {
+            const uint32_t idx = map ? map[e] : (uint32_t)e;
+            if (idx != kPad) {
+                const uint32_t at = atomicAdd(&ws->count, 1u);
+                if (at < kSmallMax) {  // (agent-scope stores: the reader is a workgroup on another XCD, whose L2 is not coherent with this one's)
+                    uint64_t bits;
+                    if constexpr (sizeof(T) == 8)
+                        bits = (uint64_t)__double_as_longlong(v);
+                    else
+                        bits = v;
+                    __hip_atomic_store(&ws->idx[at], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ws->bits[at], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&ws->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const uint32_t count = __hip_atomic_load(&ws->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool too_many = count > kSmallMax || m_all > m_bound;  // (entries beyond the room the scan had: the caller takes another road)
+    if (!too_many) {
+        for (uint32_t e = threadIdx.x; e < count; e += kSmallThreads) {
+            const uint64_t bits = __hip_atomic_load(&ws->bits[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t a = 0;
+            if (by_score) {
+                if constexpr (sizeof(T) == 8) {
+                    const uint64_t b = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+                    a = desc ? ~b : b;
+                } else {
+                    a = (uint64_t)(desc ? ~(uint32_t)bits : (uint32_t)bits);
+                }
+            }
+            k1[e] = a, k2[e] = __hip_atomic_load(&ws->idx[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pv[e] = bits;
+        }
+        uint32_t width = 1;
+        while (width < count) width <<= 1;
+        for (uint32_t e = count + threadIdx.x; e < width; e += kSmallThreads) k1[e] = ~0ull, k2[e] = kPad, pv[e] = 0;
+        __syncthreads();
+        for (uint32_t k = 2; k <= width; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < width / 2; t += kSmallThreads) {
+                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const bool up = (i & k) == 0;
+                    const uint64_t a1 = k1[i], b1 = k1[l];
+                    const uint32_t a2 = k2[i], b2 = k2[l];
+                    const bool greater = a1 > b1 || (a1 == b1 && a2 > b2);
+                    if (greater == up) {
+                        const uint64_t pa = pv[i], pb = pv[l];
+                        k1[i] = b1, k1[l] = a1, k2[i] = b2, k2[l] = a2, pv[i] = pb, pv[l] = pa;
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t e = threadIdx.x; e < count && e < capacity; e += kSmallThreads) {
+            out_index[e] = index_base + k2[e];
+            if constexpr (sizeof(T) == 8)
+                out_val[e] = __longlong_as_double((long long)pv[e]);
+            else
+                out_val[e] = (uint32_t)pv[e];
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&ws->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for the next call on this host thread)
+        __hip_atomic_store(&ws->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        res[0] = too_many ? 0u : count, res[1] = m_all, res[2] = too_many ? 1u : 0u, res[4] = aux_dev ? *aux_dev : 0u;
+        __hip_atomic_store(&res[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace
 
 uint32_t filter_segments(uint32_t m_bound) { return (m_bound + kSeg - 1) / kSeg; }
@@ -288,6 +386,20 @@ hipError_t launch_filter_small(const void* val, bool f64, const uint32_t* map, u
     return hipGetLastError();
 }
 uint32_t filter_small_max() { return kSmallMax; }
+size_t filter_select_work_bytes() { return sizeof(SelectWork); }
+// ws: filter_select_work_bytes() of device memory, zeroed ONCE (the kernel leaves it zeroed); one call at a time per workspace
+hipError_t launch_filter_select(const void* val, bool f64, const uint32_t* map, uint32_t m_bound, const uint32_t* m_dev, bool by_score, bool desc, uint32_t capacity,
+                                uint64_t index_base, uint64_t* out_index, void* out_val, void* ws, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, hipStream_t st)
+{
+    const uint32_t grid = std::max(1u, std::min((m_bound + 8 * kSmallThreads - 1) / (8 * kSmallThreads), 2048u));
+    if (f64)
+        hipLaunchKernelGGL(filter_select_kernel<double>, dim3(grid), dim3(kSmallThreads), 0, st, (const double*)val, map, m_bound, m_dev, by_score, desc, capacity, index_base, out_index,
+                           (double*)out_val, (SelectWork*)ws, res, seq, aux_dev);
+    else
+        hipLaunchKernelGGL(filter_select_kernel<uint32_t>, dim3(grid), dim3(kSmallThreads), 0, st, (const uint32_t*)val, map, m_bound, m_dev, by_score, desc, capacity, index_base,
+                           out_index, (uint32_t*)out_val, (SelectWork*)ws, res, seq, aux_dev);
+    return hipGetLastError();
+}
 
 // ---- ordering `count` compact results (all arrays on the device; the sorts are hipcub's stable radix sorts)
 size_t filter_sort_temp_bytes(uint32_t count)

@@ -180,10 +180,12 @@ constexpr uint8_t kOverflowId = 254, kAbsentId = 255;
 // never see it.  run_many therefore looks at an INTERNAL bit that only those two entry points (and rf_filter_*, for its own temporary) set; the bit is stripped from
 // whatever a caller passes in.
 constexpr uint32_t kFlagSlotsInternal = 0x40000000u;
+// ... and (rf_filter_* only, with the bit above): the caller reads nothing outside the slots of the cutoff's length window, so nothing there needs its None
+constexpr uint32_t kFlagWindowInternal = 0x20000000u;
 inline rf_args sanitized_args(const rf_args* a, bool slots_allowed)
 {
     rf_args r = *a;
-    r.flags &= ~kFlagSlotsInternal;
+    r.flags &= ~(kFlagSlotsInternal | kFlagWindowInternal);
     if (slots_allowed && (r.flags & RF_FLAG_SLOT_ORDER)) r.flags |= kFlagSlotsInternal;
     return r;
 }

@@ -126,6 +126,7 @@ struct ScanParams {
                                     // the gather never looks there.  A hint: kernels that do not know it read `orig` as always (stream_body and the asm tiles kernels honour it)
     uint32_t xcd_deal;              // 1: workgroup w takes the tiles of virtual workgroup (w % 8) * (grid / 8) + w / 8: consecutive tiles stay on one XCD (one L2)
     uint32_t prefill_none;          // tiles outside the range are all None: out is pre-filled with RF_NONE_U32
+    uint32_t prefill_window;        // 1: pre-fill ONLY the slots of the tiles [tile_begin, tile_end) (slot-ordered results whose reader looks nowhere else: rf_filter_*)
     uint32_t jaro_split;   // first EXACT tile that needs the multi-word jaro path (n_exact = none)
     uint32_t jaro_split2;  // the same for the one-length views of the mixed section, tiles [n_exact, n_tiles)
     uint32_t jaro_long;    // 1: some string exceeds 512 symbols: the multi-word tiles run jaro_long_kernel (flags in long_scratch)
@@ -258,6 +259,9 @@ hipError_t launch_filter_small(const void* val, bool f64, const uint32_t* map, u
                                uint64_t index_base, uint64_t* out_index, void* out_val, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, hipStream_t st);  // everything in one workgroup when the entries are few
 hipError_t launch_filter_report(const uint32_t* a_dev, const uint32_t* aux_dev, uint32_t* res, uint32_t seq, hipStream_t st);
 uint32_t filter_small_max();
+size_t filter_select_work_bytes();
+hipError_t launch_filter_select(const void* val, bool f64, const uint32_t* map, uint32_t m_bound, const uint32_t* m_dev, bool by_score, bool desc, uint32_t capacity,
+                                uint64_t index_base, uint64_t* out_index, void* out_val, void* ws, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, hipStream_t st);
 size_t filter_sort_temp_bytes(uint32_t count);
 hipError_t launch_filter_sort_by_index(const uint32_t* idx_in, const void* val_in, bool f64, uint32_t count, uint32_t* idx_out, void* val_out, void* temp, size_t temp_bytes,
                                        hipStream_t st);

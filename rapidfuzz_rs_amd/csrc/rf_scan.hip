@@ -1288,7 +1288,9 @@ hipError_t launch_scan(RawKind raw, const ScanParams& p_in, hipStream_t stream, 
     if (grid_used) *grid_used = grid;
     if (p.prefill_none && p.out) {  // candidates outside the cutoff's length window (plan()): None without being read
         // (for f64 outputs two all-ones words per entry: a NaN, which is all "None" promises)
-        const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p.out, (int)RF_NONE_U32, (size_t)p.n * (p.out_f64 ? 2 : 1), stream);
+        // (prefill_window: the reader looks at the window's own slots only -- 64 per tile, exact tiles and views alike)
+        const size_t w = p.out_f64 ? 2 : 1, from = p.prefill_window ? (size_t)p.tile_begin * kWave : 0, count = p.prefill_window ? (size_t)(p.tile_end - p.tile_begin) * kWave : (size_t)p.n;
+        const hipError_t e = count ? hipMemsetD32Async((hipDeviceptr_t)(reinterpret_cast<uint32_t*>(p.out) + from * w), (int)RF_NONE_U32, count * w, stream) : hipSuccess;
         if (e != hipSuccess) return e;
     }
     // long query, small distance cutoff: one word down the diagonal (rf_band.hip); exact tiles and one-length views alike

@@ -73,6 +73,8 @@ def table():
         s8 = r.get("survey_8d", {"achieved": r["achieved"], "frac": r["frac"]})
         ib = r.get("issue_bound")
         ceil = f'{ib["ceiling"]:.1f} ({ib["frac"]:.2f})' if ib and ib["ceiling"] < 1e4 else "-"
+        if ib and "asm_column" in ib:  # (the 6-bit LCS scans: the asm column's own ceiling at the clock sampled under the scan, not the compiled 8-bit column's)
+            ceil = f'{ib["asm_column"]["ceiling_at_scan_clock"]:.1f} ({ib["asm_column"]["frac"]:.2f})'
         cpu = d.get("cpu_baseline")
         par = d.get("parity")
         out.append(f'| {label} | {d["value"]:.2f} | {r["achieved"]:.0f} ({r["frac"]:.3f}) | {s8["achieved"]:.0f} ({s8["frac"]:.3f}) | {ceil} | '
