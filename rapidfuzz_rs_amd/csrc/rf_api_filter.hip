@@ -289,7 +289,8 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
                 // the Somes among the survivors -- few, under a cutoff -- selected by every workgroup, ordered, widened and counted by the last one to arrive: ONE kernel
                 // behind the scan, whatever the number of survivors
                 uint32_t* target = report_target();
-                RF_HIP(launch_filter_select(lane_val, f64_out, lane_idx, cap2, d_total, by_score, desc, cap, index_base, d_index64, d_score, ws, target, slot.seq, d_total, st));
+                RF_HIP(launch_filter_select(lane_val, f64_out, lane_idx, cap2, d_total, by_score, desc, cap, index_base, d_index64, d_score, ws, target, slot.seq, d_total,
+                                            corpus->filter_last_survivors.load(std::memory_order_relaxed), st));
                 release();
                 if (const rf_status rs = await_report(h); rs != RF_OK) return rs;
                 corpus->filter_last_survivors.store(h[4], std::memory_order_relaxed);

@@ -918,6 +918,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
         set_error("null handle or args");
         return RF_ERR_INVALID_ARG;
     }
+    AccelTimer call_timer("rf_many call (host side)");
     Effective eff;
     if (const rf_status rs = make_effective(c_in, corpus_in, (hipStream_t)stream, &eff); rs != RF_OK) return rs;
     const rf_comparator* c = eff.c;
@@ -1159,6 +1160,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
             }
         if (!d_tmp && ea == hipSuccess) {
             if (corpus->gather_tmp.size() < 4) {
+                AccelTimer timer("gather temporary");
                 ea = hipMalloc(&d_tmp, tmp_bytes);
                 if (ea == hipSuccess) {
                     hipEvent_t ev = nullptr;

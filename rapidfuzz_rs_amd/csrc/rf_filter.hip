@@ -389,9 +389,12 @@ uint32_t filter_small_max() { return kSmallMax; }
 size_t filter_select_work_bytes() { return sizeof(SelectWork); }
 // ws: filter_select_work_bytes() of device memory, zeroed ONCE (the kernel leaves it zeroed); one call at a time per workspace
 hipError_t launch_filter_select(const void* val, bool f64, const uint32_t* map, uint32_t m_bound, const uint32_t* m_dev, bool by_score, bool desc, uint32_t capacity,
-                                uint64_t index_base, uint64_t* out_index, void* out_val, void* ws, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, hipStream_t st)
+                                uint64_t index_base, uint64_t* out_index, void* out_val, void* ws, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, uint32_t expected,
+                                hipStream_t st)
 {
-    const uint32_t grid = std::max(1u, std::min((m_bound + 8 * kSmallThreads - 1) / (8 * kSmallThreads), 2048u));
+    // (every workgroup takes a ticket on ONE address when it is done: 2048 of them cost the call 75 us.  The grid follows the number of entries the caller expects --
+    // the previous call's -- between 32 and 512 workgroups; a workgroup strides over whatever there is)
+    const uint32_t grid = std::max(32u, std::min((std::min(expected, m_bound) + 8 * kSmallThreads - 1) / (8 * kSmallThreads), 512u));
     if (f64)
         hipLaunchKernelGGL(filter_select_kernel<double>, dim3(grid), dim3(kSmallThreads), 0, st, (const double*)val, map, m_bound, m_dev, by_score, desc, capacity, index_base, out_index,
                            (double*)out_val, (SelectWork*)ws, res, seq, aux_dev);

@@ -261,7 +261,7 @@ hipError_t launch_filter_report(const uint32_t* a_dev, const uint32_t* aux_dev, 
 uint32_t filter_small_max();
 size_t filter_select_work_bytes();
 hipError_t launch_filter_select(const void* val, bool f64, const uint32_t* map, uint32_t m_bound, const uint32_t* m_dev, bool by_score, bool desc, uint32_t capacity,
-                                uint64_t index_base, uint64_t* out_index, void* out_val, void* ws, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, hipStream_t st);
+                                uint64_t index_base, uint64_t* out_index, void* out_val, void* ws, uint32_t* res, uint32_t seq, const uint32_t* aux_dev, uint32_t expected, hipStream_t st);
 size_t filter_sort_temp_bytes(uint32_t count);
 hipError_t launch_filter_sort_by_index(const uint32_t* idx_in, const void* val_in, bool f64, uint32_t count, uint32_t* idx_out, void* val_out, void* temp, size_t temp_bytes,
                                        hipStream_t st);
