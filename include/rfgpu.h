@@ -180,7 +180,7 @@ typedef struct rf_args {
  * by length, so original order costs a length-bucketed corpus either scattered stores or a gather pass over every result (a quarter of an HBM-bound scan:
  * profiles/ragged_indel_r05.txt); a caller that keeps the slot map once (record linkage joins on an id anyway) skips it.  No reference analogue: the reference's
  * loop has no order but the caller's.  A single-length corpus' slots are its indices (the flag changes nothing); for a u32 query with overflow-class symbols
- * rf_many_* refuses the flag with RF_ERR_UNSUPPORTED for such a query; every other entry point (rf_many_multi_*, rf_topk_*, rf_stream_many_*, rf_one_*, rf_filter_*) ignores it.  Values are those of the default call: tests/test_gpu_parity.py permutes and compares. */
+ * rf_many_* refuses the flag with RF_ERR_UNSUPPORTED for such a query; every other entry point (rf_many_multi_*, rf_topk_*, rf_stream_many_*, rf_one_*, rf_filter_*) ignores it.  Values are those of the default call: tests/test_gpu_filter.py permutes and compares. */
 #define RF_FLAG_SLOT_ORDER 0x2u
 
 void rf_args_default(rf_args *a);
