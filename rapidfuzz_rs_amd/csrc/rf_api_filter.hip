@@ -119,8 +119,8 @@ static rf_status filter_fast(const rf_comparator* c_in, const rf_corpus* corpus_
     const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(corpus->n / 4, 4 * capacity), 1u << 16);
     const uint32_t cap2 = (uint32_t)std::min<uint64_t>(corpus->n, want);
     const size_t elem = f64_out ? sizeof(double) : sizeof(uint32_t);
-    RF_HIP(sc.get(lane_val, (size_t)cap2 * elem));
-    RF_HIP(sc.get((void**)lane_idx, (size_t)cap2 * sizeof(uint32_t)));
+    RF_HIP(sc.get(lane_val, (size_t)cap2 * (elem + sizeof(uint32_t))));  // (one block: values, then indices -- every scratch block is a lock and an event per call)
+    *lane_idx = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(*lane_val) + (size_t)cap2 * elem);
     p.lane_val = *lane_val;
     p.lane_idx = *lane_idx;
     *d_total = p.tile_list_buf + 1;  // (the survivors' number, left there by the pack kernel; `held` keeps other host threads of this stream off the buffer until
@@ -149,15 +149,15 @@ static rf_status run_filter(const rf_comparator* c, const rf_corpus* corpus, rf_
         return RF_ERR_INVALID_ARG;
     }
     *out_count = 0;
-    {   // argument errors of the scan itself (metric x op x output type) before anything runs
+    if (corpus->n == 0) {  // argument errors of the scan itself (metric x op x output type) even when there is nothing to scan; otherwise the roads below report them
         ScanParams p;
         RawKind raw = RAW_LEV;
         const rf_comparator* ce = nullptr;
         ComparatorRef hold;
         if (resolve(c, corpus, &ce, &hold) == RF_OK)
             if (const rf_status rs = plan(ce, corpus, op, args, f64_out, &p, &raw); rs != RF_OK) return rs;
+        return RF_OK;
     }
-    if (corpus->n == 0) return RF_OK;
     DeviceGuard guard(corpus->device);
     if (!guard.ok) {
         set_error("cannot select the corpus' device");
