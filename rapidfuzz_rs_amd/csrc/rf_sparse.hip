@@ -193,7 +193,8 @@ hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, hipStream_t s
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const uint32_t tiles = p.tile_end > p.tile_begin ? p.tile_end - p.tile_begin : 1u;
     // (a wavefront per dense tile while they are few: a tile is a chain of dependent loads -- list entry, chunk rows -- and the workgroups beyond the survivors leave at once)
-    const uint32_t want = (uint32_t)cus * (p.topk_k ? 8u : 32u), most = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    // (a length run of a bucketed corpus is one of several launches of its call and a fraction of the corpus: the smaller grid, or the empty workgroups of eight runs add up)
+    const uint32_t want = (uint32_t)cus * ((p.topk_k || p.run_orig) ? 8u : 32u), most = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 g(std::max(1u, std::min(want, most))), b(kWave * kWavesPerBlock);
     switch (state_kind) {
     case 0: hipLaunchKernelGGL((sparse_lean_kernel<LevState<1>>), g, b, 0, stream, p); break;
