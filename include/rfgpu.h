@@ -32,6 +32,7 @@
  *   RF_ASM_STREAM                 1         0: compiled scans instead of the whole-kernel asm scans (rf_stream_asm.hip)
  *   RF_ASM_CHUNK                  1         0: compiled chunk instead of the hybrid asm chunks (in-scan top-k, Jaro)
  *   RF_ASM_BLOCK                  1         0: compiled multi-word scan instead of the asm multi-word scan (queries of 65..512 symbols)
+ *   RF_ASM_BAND                   1         0: the compiled column everywhere in the small-band kernel instead of the asm block for full 8-column diagonal runs (rf_band_asm.inc)
  *   RF_EARLY_STATIC / RF_EARLY_LEAN / RF_NARROW_LOOK / RF_HEAD_TWO_PASS / RF_HEAD_LOOK_PASS
  *                                 1         0: the older form of the cutoff scans' first look
  *   RF_LANE_COMPACT               1         0: the second pass of the head-plane cutoff scans walks the surviving TILES (64 lanes each, round 5) instead of the

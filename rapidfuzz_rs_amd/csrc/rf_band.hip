@@ -18,6 +18,7 @@
 // break_score (levenshtein.rs:519-523, :568-570), and candidates whose length differs from the query's by more than k are
 // None without being read.
 #include "rf_device.hpp"
+#include "rf_band_asm.inc"
 
 namespace rf {
 
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void band_kernel(const ScanP
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uniform(threadIdx.x / kWave);
     const uint32_t len1 = p.len1, k = p.band_k;
+    const uint32_t pitch_bytes = stride * 4u;
+    const bool asm_run = p.band_asm != 0;  // (RF_ASM_BAND=0: the compiled column everywhere, the A/B switch)
     for (uint32_t t = p.tile_begin + blockIdx.x * kWavesPerBlock + wave; t < p.tile_end; t += gridDim.x * kWavesPerBlock) {
         const TileView tv = load_tile<kUniform>(p, t);
         const uint32_t len2 = tv.len;
@@ -103,8 +106,22 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void band_kernel(const ScanP
                 const uint32_t b0 = (uint32_t)run * 8, j0 = c * kChunk + b0;
                 if (b0 >= cols || dead) break;  // wavefront-uniform
                 if (b0 + 8 <= cols && j0 + 8 <= first) {
+                    if (asm_run) {
+                        // the eight columns as one asm block (tools/gen_band_asm.py: 23 VALU per column against the ~30 hipcc writes); the diagonal bits come back
+                        // as a shift register
+                        uint32_t vpl = (uint32_t)vp, vph = (uint32_t)(vp >> 32), vnl = (uint32_t)vn, vnh = (uint32_t)(vn >> 32), acc = 0;
+                        asm volatile(RF_BAND_RUN8_ASM
+                                     : [vpl] "+v"(vpl), [vph] "+v"(vph), [vnl] "+v"(vnl), [vnh] "+v"(vnh), [acc] "+v"(acc)
+                                     : [dw0] "v"(dws[run * 2]), [dw1] "v"(dws[run * 2 + 1]), [pitch] "v"(pitch_bytes), [v0] "s"(uniform(v))
+                                     : RF_BAND_RUN8_CLOBBERS);
+                        vp = ((uint64_t)vph << 32) | vpl;
+                        vn = ((uint64_t)vnh << 32) | vnl;
+                        diag_hits += (uint32_t)__popc(acc & 0xFFu);
+                        v += 8;
+                    } else {
 #pragma unroll
-                    for (int kb = 0; kb < 8; ++kb) column((dws[run * 2 + kb / 4] >> (8 * (kb % 4))) & 0xFFu, j0 + kb, true);
+                        for (int kb = 0; kb < 8; ++kb) column((dws[run * 2 + kb / 4] >> (8 * (kb % 4))) & 0xFFu, j0 + kb, true);
+                    }
                     score = k + (j0 + 8) - diag_hits;           // :561: the running total of the diagonal walk
                 } else {
 #pragma unroll
@@ -139,12 +156,15 @@ hipError_t launch_band(const ScanParams& p, hipStream_t stream)
     // 8 or 16 per CU 76.7 Gpairs/s, 24: 72.7, 32: 67.8, 64: 55.5)
     const int band_grid = std::max(1, std::min(scan_grid(p.tile_end - p.tile_begin), (scan_max_grid() + 1) / 2));
     const dim3 g(band_grid), b(kWave * kWavesPerBlock);
+    static const bool use_asm = [] { const char* e = getenv("RF_ASM_BAND"); return !e || atoi(e) != 0; }();
+    ScanParams pa = p;
+    pa.band_asm = use_asm ? 1u : 0u;
     auto kern = p.tiles ? band_kernel<false> : band_kernel<true>;
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, g, b, lds, stream, p);
+    hipLaunchKernelGGL(kern, g, b, lds, stream, pa);
     return hipGetLastError();
 }
 

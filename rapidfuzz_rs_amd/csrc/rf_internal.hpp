@@ -152,6 +152,7 @@ struct ScanParams {
     uint32_t narrow_look;           // early_lean_kernel: run the columns before the first look on 32-bit words (set by the launcher)
     // band_kernel (rf_band.hip): long query, raw distance cutoff band_k with 2 * band_k + 1 <= 64; band = 1 selects it
     uint32_t band, band_k;
+    uint32_t band_asm;              // 1: full eight-column diagonal runs as one asm block (rf_band_asm.inc; set by the launcher)
     // the multi-word asm scans (rf_stream_asm.hip, tools/gen_stream_asm.py BlockKind): raw distances above trim_k1 - 1 need not be exact (they must come out above
     // it), which narrows the Ukkonen band the kernels trim their word-columns to; 0 = no bound beyond max(len1, len2)
     uint32_t trim_k1;

@@ -36,6 +36,12 @@ def test_jaro_asm_include_is_the_generators_output(tmp_path):
     assert out.read_text() == open(os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc", "rf_jaro_chunk_asm.inc")).read()
 
 
+def test_band_asm_include_is_the_generators_output(tmp_path):
+    out = tmp_path / "band.inc"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_band_asm.py"), str(out)], check=True)
+    assert out.read_text() == open(os.path.join(ROOT, "rapidfuzz_rs_amd", "csrc", "rf_band_asm.inc")).read()
+
+
 def test_stream_asm_include_is_the_generators_output(tmp_path):
     """rapidfuzz_rs_amd/csrc/rf_stream_asm.inc (the whole-kernel asm bodies of the no-cutoff Levenshtein / OSA / LCS scans) is generated
     and, since round 6, NOT tracked (100 k lines that tripled the history per generator change): the Makefile writes it from
