@@ -143,6 +143,62 @@ def sharded_topk(scorer, shard_corpus, k: int, shard_start: int, op: int = N.OP_
     return allgather_topk(s, i, k, op, group=group, device=device)
 
 
+def allgather_filter(indices: np.ndarray, scores: np.ndarray, by_score: bool = False, descending: bool = False, group=None, device=None):
+    """The exchange step of a sharded rf_filter: every rank's (global index, score) survivors, concatenated on every rank in the order one
+    rf_filter call over the whole corpus gives -- ascending index (each global index lives on exactly one rank), or (score, index) with
+    `by_score` (`descending` for the similarity ops).  Two collectives: the counts (8 bytes per rank), then the survivors padded to the
+    longest list (16 bytes each): a thresholded scan's survivors are few by construction, so this is latency, like the top-k exchange."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    indices = np.ascontiguousarray(indices, dtype=np.uint64)
+    is_f = np.asarray(scores).dtype.kind == "f"
+    scores = np.ascontiguousarray(scores, dtype=np.float64 if is_f else np.uint32)
+    assert len(indices) == len(scores)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", device if device is not None else torch.cuda.current_device()) if nccl else torch.device("cpu")
+    mine = torch.tensor([len(indices)], dtype=torch.int64, device=dev)
+    counts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    if longest == 0:
+        return indices[:0], scores[:0]
+    payload = torch.zeros((longest, 2), dtype=torch.int64)
+    payload[: len(indices), 0] = torch.from_numpy(indices.view(np.int64))
+    payload[: len(indices), 1] = torch.from_numpy(scores.view(np.int64) if is_f else scores.astype(np.int64))  # (f64 scores travel as their bits)
+    payload = payload.to(dev)
+    everyone = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(everyone, payload, group=group)
+    parts = [e[:c].cpu().numpy() for e, c in zip(everyone, counts)]
+    g = np.concatenate(parts) if parts else np.zeros((0, 2), dtype=np.int64)
+    gi = np.ascontiguousarray(g[:, 0]).view(np.uint64)
+    gs = np.ascontiguousarray(g[:, 1]).view(np.float64) if is_f else g[:, 1].astype(np.uint32)
+    if by_score:
+        key = gs.astype(np.float64) if is_f else gs.astype(np.int64)
+        order = np.lexsort((gi, -key if descending else key))
+    else:
+        order = np.argsort(gi, kind="stable")
+    return gi[order], gs[order]
+
+
+def sharded_filter(scorer, shard_corpus, op: int, shard_start: int = 0, args=None, shard_index=None, order: int = N.FILTER_BY_INDEX, group=None,
+                   device=None, **kw):
+    """One rank's share of a distributed thresholded scan (rf_filter_u32 / rf_filter_f64 per shard, then `allgather_filter`): every rank
+    returns the same (global indices, scores) -- what `filter_many` over the unsharded corpus returns.  Global index = shard_start + local
+    for a contiguous shard (`shard_range`), shard_index[local] for a dealt one (`shard_ragged`); FILTER_ANY comes back in index order."""
+    if shard_index is not None:
+        idx, sc = scorer.filter_many(op, shard_corpus, args, order=N.FILTER_ANY, index_base=0, **kw)
+        idx = np.asarray(shard_index, dtype=np.uint64)[np.asarray(idx, dtype=np.int64)]
+    else:
+        idx, sc = scorer.filter_many(op, shard_corpus, args, order=N.FILTER_ANY, index_base=shard_start, **kw)
+    desc = op in (N.OP_SIMILARITY, N.OP_NORMALIZED_SIMILARITY)
+    if device is None and hasattr(shard_corpus, "device"):
+        device = shard_corpus.device
+    return allgather_filter(np.asarray(idx), np.asarray(sc), by_score=(order == N.FILTER_BY_SCORE), descending=desc, group=group, device=device)
+
+
 def merge_keys_device(all_keys, k: int, out, stream=None):
     """Device-side merge of all-gathered rf_topk_keys_device lists (CUDA int64 tensors): the k smallest keys of
     `all_keys` into `out`, best first, -1 = empty; asynchronous on torch's current stream."""

@@ -4,6 +4,7 @@ only exchange on the path, the k-entry all-gather + merge, through each of its f
 
   1. parallel.sharded_topk            host lists (scores, global indices), all_gather of 2k+1 words per rank
   2. parallel.sharded_topk_entries    16-byte device entries, all_gather_into_tensor + rf_topk_merge_entries_device (u32 and f64 scores)
+  2b. parallel.sharded_filter         every rank's rf_filter survivors (global index, score), counts + padded all_gather (u32 and f64 scores)
   3. rf_topk_allgather_merge          raw ncclComm_t (ncclGetUniqueId on rank 0, broadcast, ncclCommInitRank on every rank)
   4. rf_topk_allgather_merge_entries  the same for 16-byte entries
 
@@ -62,6 +63,11 @@ def main():
     got["entries_lev_cut3"] = parallel.decode_entries(e, N.OP_DISTANCE, False)
     e = parallel.sharded_topk_entries(jw, shard, k, lo, N.OP_SIMILARITY)
     got["entries_jw"] = parallel.decode_entries(e, N.OP_SIMILARITY, True)
+    # 2b. thresholded scans: every rank's rf_filter survivors, gathered (parallel.sharded_filter)
+    fi, fs = parallel.sharded_filter(lev, shard, N.OP_DISTANCE, shard_start=lo, device=None if gloo else local, score_cutoff=3)
+    got["filter_lev_cut3"] = [(int(b), int(a)) for a, b in zip(fi, fs)]
+    fi, fs = parallel.sharded_filter(jw, shard, N.OP_SIMILARITY, shard_start=lo, order=N.FILTER_BY_SCORE, device=None if gloo else local, score_cutoff=0.8)
+    got["filter_jw_08_by_score"] = [(float(b), int(a)) for a, b in zip(fi, fs)]
     if not gloo:
         # 3./4. the exchange below Python: a communicator made by hand on the RCCL torch has loaded
         libs = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
@@ -113,7 +119,10 @@ def main():
         s = jw.similarity_many(whole)
         order = np.lexsort((np.arange(n_total), -s))
         exp_jw = [(float(s[i]), int(i)) for i in order[:k]]
-        want = {"host_nocut": exp_nocut, "host_cut3": exp_cut3, "host_hint2": exp_nocut, "entries_lev_cut3": exp_cut3, "entries_jw": exp_jw,
+        keep = np.nonzero(d <= 3)[0]
+        exp_filter = [(int(d[i]), int(i)) for i in keep]
+        exp_filter_jw = [(float(s[i]), int(i)) for i in order if s[i] >= 0.8]
+        want = {"filter_lev_cut3": exp_filter, "filter_jw_08_by_score": exp_filter_jw, "host_nocut": exp_nocut, "host_cut3": exp_cut3, "host_hint2": exp_nocut, "entries_lev_cut3": exp_cut3, "entries_jw": exp_jw,
                 "raw_keys_cut3": exp_cut3, "raw_entries_jw": exp_jw}
         for name, val in got.items():
             good = [tuple(x) for x in val] == want[name]

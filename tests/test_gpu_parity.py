@@ -2873,7 +2873,7 @@ def test_ranks_script_two_ranks_sharing_one_gpu_over_gloo():
     multi-GPU test below runs alive on the 1-GPU boxes of this pool."""
     d = _run_ranks_script(2, {"RF_TEST_BACKEND": "gloo", "RF_TEST_N": "600000"}, 29655)
     assert d["ok"] and d["ranks"] == 2 and d["same_on_every_rank"] and all(d["checks"].values()), d
-    assert set(d["checks"]) == {"host_nocut", "host_cut3", "host_hint2", "entries_lev_cut3", "entries_jw"}
+    assert set(d["checks"]) == {"host_nocut", "host_cut3", "host_hint2", "entries_lev_cut3", "entries_jw", "filter_lev_cut3", "filter_jw_08_by_score"}
 
 
 def test_real_ranks_over_rccl_when_the_box_has_two_gpus():

@@ -221,3 +221,65 @@ def test_sharded_topk_over_a_dealt_ragged_corpus_gloo_world2():
     es, ei = _oracle_topk(d, k, None)
     for r in range(world):
         assert ret[r][0] == es.tolist() and ret[r][1] == ei.tolist()
+
+
+def _filter_worker(rank, world, port, q, data, offsets, cutoff, dealt, by_score, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = len(offsets) - 1
+        if dealt:
+            idx = parallel.shard_ragged(offsets, rank, world)
+            start = 0
+        else:
+            a, b = parallel.shard_range(n, rank, world)
+            idx, start = np.arange(a, b, dtype=np.uint64), a
+        d_r, o_r = parallel.take_ragged(data, offsets, idx)
+
+        class _OracleScorer:  # what a rank's BatchComparator.filter_many returns on a GPU box: (index_base + LOCAL indices, scores), any order
+            FLOAT = False
+            _s1 = q
+
+            @staticmethod
+            def filter_many(op, corpus, args=None, order=N.FILTER_ANY, index_base=0, score_cutoff=None):
+                d = o.levenshtein.BatchComparator(q).many(op, corpus[0], corpus[1], score_cutoff=score_cutoff)
+                keep = np.nonzero(d != np.uint64(2**64 - 1))[0][::-1]  # (deliberately not in index order)
+                return keep.astype(np.uint64) + np.uint64(index_base), d[keep].astype(np.uint32)
+
+        gi, gs = parallel.sharded_filter(_OracleScorer, (d_r, o_r), N.OP_DISTANCE, shard_start=start, shard_index=idx if dealt else None,
+                                         order=N.FILTER_BY_SCORE if by_score else N.FILTER_BY_INDEX, score_cutoff=cutoff)
+        ret[rank] = (gi.tolist(), gs.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dealt,by_score,cutoff", [(False, False, 35), (True, False, 35), (True, True, 36), (False, True, 0)])
+def test_sharded_filter_gloo_world2(dealt, by_score, cutoff):
+    """sharded_filter: both ranks end with filter_many's answer over the WHOLE corpus -- the candidates within the cutoff with their original
+    indices, in index or (score, index) order -- whether the shards are contiguous ranges or shard_ragged's dealt index sets; a cutoff nothing
+    passes gives two empty arrays (the padded exchange has nothing to send)."""
+    import torch.multiprocessing as mp
+
+    q = synth.query(40, 21)
+    data, offsets = synth.ragged_host(3001, 64, seed=22)
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_filter_worker, args=(r, world, port, q, data, offsets, cutoff, dealt, by_score, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    d = o.levenshtein.BatchComparator(q).many(N.OP_DISTANCE, data, offsets, score_cutoff=cutoff)
+    keep = np.nonzero(d != np.uint64(2**64 - 1))[0]
+    if by_score:
+        keep = keep[np.lexsort((keep, d[keep].astype(np.int64)))]
+    if cutoff:
+        assert len(keep) > 10
+    for r in range(world):
+        assert ret[r][0] == keep.tolist() and ret[r][1] == d[keep].astype(np.int64).tolist()
