@@ -1312,6 +1312,7 @@ void rf_corpus_free(rf_corpus* c)
     for (const rf_corpus::TileList& t : c->tile_lists) {
         (void)hipFree(t.ptr);
         (void)hipEventDestroy(t.done);
+        if (t.band_report) (void)hipHostFree(const_cast<uint32_t*>(t.band_report));
     }
     if (c->d_mixed) (void)hipFree(c->d_mixed);
     if (c->d_mixed_len) (void)hipFree(c->d_mixed_len);

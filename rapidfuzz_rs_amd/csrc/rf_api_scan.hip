@@ -572,7 +572,7 @@ void plan_band_filter(const rf_comparator* c, const rf_corpus* corpus, rf_op op,
 
 // words of a tile-list buffer: round 5's layout (packed count, <= 16 K per-wavefront counts and offsets, their segments -- n_tiles + 2 per wavefront of rounding --, the
 // packed list) needs 2 n_tiles + 5 x 16384; the lane lists (rf_scan.hip lane_list_pack_kernel: 16-byte entries in the segments and in the packed list) four times the entries
-static size_t tile_list_words(uint32_t n_tiles) { return 9 * (size_t)n_tiles + 12 * 16384 + 64; }  // (+ one word per dense tile: lane_list_pack_kernel's first[])
+static size_t tile_list_words(uint32_t n_tiles) { return 9 * (size_t)n_tiles + 12 * 16384 + 64; }  // (the last 4 words: launch_band's count of hand-over candidates, zero between launches)  // (+ one word per dense tile: lane_list_pack_kernel's first[])
 // the buffer serves the lane compaction (every buffer corpus_tile_list hands out does)
 void corpus_lane_buffers(const rf_corpus* corpus, ScanParams* p)
 {
@@ -606,6 +606,7 @@ uint32_t* corpus_tile_list(const rf_corpus* corpus, hipStream_t st)
         (void)hipGetLastError();
         return nullptr;
     }
+    if (hipMemsetAsync(ptr + tile_list_words(corpus->n_tiles) - 4, 0, 4 * sizeof(uint32_t), st) != hipSuccess) (void)hipGetLastError();
     hipEvent_t done = nullptr;
     if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
@@ -1197,10 +1198,48 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
         RF_HIP(ea);
     }
     std::unique_lock<std::mutex> filter_lock;  // held while a filter pass and the scan over its list are enqueued
-    if (p.heads8) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
+    // (... and the small-band scans of a single-length corpus: tiles with a few lanes left are listed for a dense second pass, rf_band.hip launch_band)
+    const bool band_lists = p.band && raw == RAW_LEV && corpus->uniform && !p.tiles && !want_slots && p.tile_step == 1 && !by_runs;
+    if (p.heads8 || band_lists) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
         p.tile_list_buf = corpus_tile_list(corpus, st);
         corpus_lane_buffers(corpus, &p);
+        if (band_lists && p.tile_list_buf) {
+            p.band_defer_seen = p.tile_list_buf + tile_list_words(corpus->n_tiles) - 4;
+            // Which form this launch takes.  Handing tiles over pays when many tiles hold a few near candidates; on a corpus with none, or with most lanes of most tiles
+            // near, it buys nothing and costs the list kernels and ~3 % of the first pass' columns.  The second pass of this stream's LAST hand-over launch left what it
+            // listed in pinned memory (E tiles, S lanes, of N tiles at column a); read here without waiting -- whatever launch it is from, it only steers speed:
+            //   columns saved ~ E (L - a) - S / 64 L   against   N a + (tiles alive at a) (L - a)  of the plain launch
+            // (tiles alive at a: the listed ones, or -- when the listed ones sit right at the lane limit, so that most live tiles are above it -- all of them).
+            // Below 25 % the plain kernel runs, and every 16th launch looks again.  RF_BAND_DEFER_ADAPT=0: always hand over.
+            static const bool adapt = [] { const char* e = getenv("RF_BAND_DEFER_ADAPT"); return !e || atoi(e) != 0; }();
+            rf_corpus::TileList& tl = corpus->tile_lists.front();  // (corpus_tile_list moved this stream's list to the front)
+            if (!tl.band_report) {
+                void* hp = nullptr;
+                if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+                    std::memset(hp, 0, 64);
+                    tl.band_report = static_cast<volatile uint32_t*>(hp);
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            p.band_report = const_cast<uint32_t*>(tl.band_report);
+            if (adapt && tl.band_report) {
+                bool pays = false;
+                if (tl.band_report[3] != 0) {
+                    const double E = tl.band_report[0], S = tl.band_report[1], N = tl.band_report[2], a = tl.band_report[4], lanes_max = tl.band_report[5];
+                    const double L = corpus->uniform_len, rest = L > a ? L - a : 0.0;
+                    const double saved = E * rest - S / 64.0 * L;
+                    const bool at_the_limit = E > 0 && S / E > 0.75 * lanes_max;
+                    const double plain = N * a + (at_the_limit ? N : E) * rest;
+                    pays = saved > 0.25 * plain;  // (the estimate runs ~15 points above what is measured: gathered chunk loads, the list kernels)
+                }
+                // (no report yet: the stream's FIRST launch hands over, the ones enqueued behind it before its report is in do not -- a host that enqueues ahead
+                // would otherwise send a dozen launches down a road nobody has measured)
+                const bool look = (tl.band_plain_calls++ & 15u) == 0;
+                if (!pays && !look) p.band_defer_seen = nullptr;  // (launch_band: the plain kernel)
+            }
+        }
     }
     static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;  // one line per rf_many_* call on stderr: which path the plan took
     if (trace_plan)

@@ -993,6 +993,32 @@ __device__ __forceinline__ void process_chunk_tail(State& st, const typename Sta
     }
 }
 
+// position of the k-th (0-based) set bit of m (m has more than k set bits)
+__device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t k)
+{
+    uint32_t pos = 0;
+    uint32_t lo = (uint32_t)m, c = (uint32_t)__popc(lo);
+    uint32_t w = lo;
+    if (k >= c) {
+        k -= c;
+        pos = 32;
+        w = (uint32_t)(m >> 32);
+    }
+#pragma unroll
+    for (uint32_t half = 16; half >= 1; half >>= 1) {
+        const uint32_t part = w & ((1u << half) - 1u);
+        c = (uint32_t)__popc(part);
+        if (k >= c) {
+            k -= c;
+            pos += half;
+            w >>= half;
+        } else {
+            w = part;
+        }
+    }
+    return pos;
+}
+
 struct TileView {
     const uint4* src;  // wavefront-uniform base of the tile payload
     uint32_t len, slot0;

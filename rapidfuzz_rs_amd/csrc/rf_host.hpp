@@ -157,6 +157,9 @@ struct rf_corpus {
         uint32_t* ptr;
         hipEvent_t done;  // recorded behind the last scan that walked the list (corpus_tile_list_done): a take-over waits for THIS, never
                           // for the stream handle -- its owner may have destroyed the stream long ago, and the runtime crashes on a dead handle
+        volatile uint32_t* band_report = nullptr;  // pinned, 64 bytes: what this stream's last hand-over launch of the small-band scan listed (rf_band.hip band_sparse_kernel
+                                                   // writes it; run_many reads it, without waiting, to choose the next launch's form); nullptr = no pinned memory
+        uint32_t band_plain_calls = 0;             // launches since that choice last fell on the plain kernel
     };
     mutable std::vector<TileList> tile_lists;
     mutable std::mutex filter_enqueue_mu;

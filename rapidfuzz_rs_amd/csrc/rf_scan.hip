@@ -496,6 +496,12 @@ __global__ __launch_bounds__(256) void lane_list_pack_kernel(uint32_t* __restric
     }
 }
 
+hipError_t launch_lane_list_pack(uint32_t* buf, uint32_t G, uint32_t cap, uint32_t* first_of, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lane_list_pack_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, buf, G, cap, first_of);
+    return hipGetLastError();
+}
+
 // THE BAND PREFILTER (kHead8, p.head_need != 0: cutoffs that allow at most K = p.head_k <= 3 edits).  Any alignment of cost <= K
 // stays within K of the main diagonal, and every candidate symbol it does not MATCH costs at least one edit (a substitution or an
 // insertion; an OSA transposition costs one for two symbols that both equal a query symbol one off their path position, which is

@@ -409,3 +409,71 @@ def test_randomized_corpus_models_vary_what_the_plan_looks_at(seed):
             assert np.array_equal(idx[perm], idx_e) and np.array_equal(val[perm], val_e), ("filter", seed, metric, op, kw, order, len(idx), len(idx_e))
             if order == N.FILTER_BY_INDEX:
                 assert np.all(np.diff(idx.astype(np.int64)) > 0)
+
+
+def _band_rows(n, len2, q, share, seed):
+    """n rows of len2 symbols around query q (its own length may differ by a few): a fraction `share` near the query -- the query resized to len2 with 0..12
+    substitutions, or with an insertion / deletion near the front (the rest of the row then runs ONE off the diagonal), or equal to it for the first 20..120 symbols
+    and random from there on (in the band for a while, out of it long before the end) -- the others random."""
+    rng = np.random.default_rng(seed)
+    qa = np.frombuffer(q, dtype=np.uint8)
+    rows = synth.ALNUM[rng.integers(0, 62, size=(n, len2))]
+    near = np.nonzero(rng.random(n) < share)[0]
+    for j, i in enumerate(near):
+        kind = j % 8
+        base = np.resize(qa, len2 + 2)
+        if kind <= 3:
+            row = base[:len2].copy()
+            k = int(rng.integers(0, 13))
+            if k:
+                row[rng.integers(0, len2, size=k)] = synth.ALNUM[rng.integers(0, 62, size=k)]
+        elif kind == 4:  # one symbol missing near the front
+            cut = int(rng.integers(0, 30))
+            row = np.delete(base, cut)[:len2].copy()
+        elif kind == 5:  # one symbol more near the front
+            at = int(rng.integers(0, 30))
+            row = np.insert(base, at, np.uint8(35))[:len2].copy()
+        else:  # the query's head, then noise
+            row = rows[i].copy()
+            h = int(rng.integers(20, 121))
+            row[:h] = base[:h]
+        rows[i] = row
+    return np.ascontiguousarray(rows)
+
+
+@pytest.mark.parametrize("share", [0.02, 0.3, 0.5, 0.9])
+def test_small_band_scan_hands_sparse_tiles_to_a_dense_second_pass(share):
+    """rf_band.hip launch_band on a single-length corpus: a tile with few lanes left within the band at a chunk end (column 2k + 8, rounded up) is listed (tile, lane mask) and its lanes finish in
+    band_sparse_kernel, 64 survivors to a wavefront (the reference's hyrroe2003_small_band_with_pm, levenshtein.rs:509-617, decides per candidate,
+    so who shares a wavefront with whom must not show).  Near-duplicate shares from 2 % (nearly every tile listed with one or two lanes) to 90 % (nearly none listed),
+    candidates that leave the band after the hand-over, queries shorter / longer than the rows, every cutoff range of the band kernel, n not a multiple of 64."""
+    import torch
+
+    for qlen, len2, n in ((256, 256, 150_011), (250, 256, 9_001), (300, 296, 9_001), (130, 128, 5_003)):
+        q = synth.query(qlen, 0xBA2D + qlen)
+        rows = _band_rows(n, len2, q, share, seed=qlen * 7 + int(share * 100))
+        corpus = rf.Corpus.from_device_rows(torch.from_numpy(rows).cuda())
+        bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
+        for k in (4, 8, 17, 31):
+            got = bc.distance_many(corpus, score_cutoff=k)
+            exp = ob.rows(N.OP_DISTANCE, rows, nthreads=8, score_cutoff=k)
+            bad = _same(got, exp)
+            assert len(bad) == 0, (share, qlen, len2, k, bad[:5], got[bad[:5]], exp[bad[:5]])
+            if qlen == 256 and k == 8:
+                assert (got != NONE32).sum() > 0.3 * share * n  # (the near-duplicates are found)
+        # the hinted scan runs the same band launch as its first pass (rf_api_scan.hip run_many_hinted)
+        got = bc.distance_many(corpus, score_hint=8)
+        exp = ob.rows(N.OP_DISTANCE, rows, nthreads=8)
+        assert len(_same(got, exp)) == 0, (share, qlen, len2, "hint")
+
+
+@pytest.mark.parametrize("env", [{"RF_BAND_DEFER": "0"}, {"RF_BAND_DEFER_AFTER": "0", "RF_BAND_DEFER_ADAPT": "0"},
+                                 {"RF_BAND_DEFER_AT": "16", "RF_BAND_DEFER_MAX": "63", "RF_BAND_DEFER_AFTER": "0", "RF_BAND_DEFER_ADAPT": "0"},
+                                 {"RF_BAND_DEFER_AT": "64", "RF_BAND_DEFER_MAX": "20", "RF_BAND_DEFER_AFTER": "0", "RF_BAND_DEFER_ADAPT": "0"},
+                                 {"RF_ASM_BAND": "0", "RF_BAND_DEFER_AFTER": "3", "RF_BAND_DEFER_ADAPT": "0"}])
+def test_small_band_hand_over_switches(env):
+    """The same test with the hand-over off, from the launch's first candidate tile on and whatever the last launch listed (by default a launch runs its first
+    1024 such tiles in place -- only the 150 011-row corpus above hands anything over -- and a stream whose last hand-over launch saved little takes the plain kernel), at column 16 for every tile with a lane left, at column 64, and on the compiled column (the switches are read once per process)."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "test_small_band_scan_hands_sparse_tiles"],
+                       capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **env))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]

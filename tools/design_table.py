@@ -32,6 +32,8 @@ ROWS = [  # (file stem, label)
     ("hint16_neardup50", "50 % near-duplicates, `score_hint = 16` (the hint is wrong for half the corpus: slower than no hint)"),
     ("q128_levenshtein", "query 128 x 20 M len 128 (2-word asm scan)"),
     ("c3_cutoff8", "C3 corpus, `score_cutoff = 8`"),
+    ("c3_cutoff8_neardup1", "the same, 1 % of the candidates near the query (tiles with a lane or two left are handed to the dense second pass)"),
+    ("c3_cutoff8_neardup50", "the same, 50 % near the query"),
     ("c4_indel", "C4 Indel (asm scan over the 6-bit payload, round 5)"),
     ("q32_indel", "same corpus, Indel, query 32 (32-bit words over the 6-bit payload, round 5)"),
     ("c4_lcs_seq", "C4 LCS"),
