@@ -477,3 +477,51 @@ def test_small_band_hand_over_switches(env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "test_small_band_scan_hands_sparse_tiles"],
                        capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **env))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RF_FUZZ_SEEDS", "8"))))
+def test_randomized_small_band_on_single_length_corpora(seed):
+    """Randomized form of the test above (forced in the fuzz runs with RF_BAND_DEFER_AFTER=0 RF_BAND_DEFER_ADAPT=0): query 65..600 symbols, rows a few symbols shorter
+    or longer (beyond the cutoff too: the length test), 4- and 62-symbol alphabets, any share of near candidates, cutoffs 0..31 and one score_hint per corpus."""
+    import torch
+
+    rng = np.random.default_rng(0xBA2D0000 + seed)
+    for _ in range(3):
+        qlen = int(rng.choice([65, 96, 128, 200, 256, 257, 300, 600, int(rng.integers(65, 600))]))
+        len2 = max(1, qlen + int(rng.integers(-12, 13)))
+        n = int(rng.choice([3_000, 70_001, 140_000]))
+        share = float(rng.choice([0.0, 0.003, 0.05, 0.4, 0.6, 1.0]))
+        alpha = synth.ALNUM if rng.random() < 0.6 else synth.ALNUM[:4]
+        qa = alpha[rng.integers(0, len(alpha), size=qlen)]
+        rows = alpha[rng.integers(0, len(alpha), size=(n, len2))]
+        near = np.nonzero(rng.random(n) < share)[0]
+        base = np.resize(qa, len2 + 3)
+        for j, i in enumerate(near):
+            kind = j % 6
+            if kind <= 2:
+                row = base[:len2].copy()
+                e = int(rng.integers(0, 20))
+                if e:
+                    row[rng.integers(0, len2, size=e)] = alpha[rng.integers(0, len(alpha), size=e)]
+            elif kind == 3:
+                row = np.delete(base, int(rng.integers(0, min(40, len2))))[:len2].copy()
+            elif kind == 4:
+                row = np.insert(base, int(rng.integers(0, min(40, len2))), alpha[0])[:len2].copy()
+            else:
+                row = rows[i].copy()
+                h = int(rng.integers(1, len2 + 1))
+                row[:h] = base[:h]
+            rows[i] = row
+        rows = np.ascontiguousarray(rows)
+        corpus = rf.Corpus.from_device_rows(torch.from_numpy(rows).cuda())
+        q = qa.tobytes()
+        bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
+        for k in sorted(set(int(x) for x in rng.choice([0, 1, 3, 8, 12, 16, 25, 31], size=3))):
+            got = bc.distance_many(corpus, score_cutoff=k)
+            exp = ob.rows(N.OP_DISTANCE, rows, nthreads=8, score_cutoff=k)
+            bad = _same(got, exp)
+            assert len(bad) == 0, (seed, qlen, len2, n, share, len(alpha), k, bad[:5], got[bad[:5]], exp[bad[:5]])
+        hint = int(rng.choice([0, 4, 16, 40]))
+        got = bc.distance_many(corpus, score_hint=hint)
+        exp = ob.rows(N.OP_DISTANCE, rows, nthreads=8)
+        assert len(_same(got, exp)) == 0, (seed, qlen, len2, n, share, "hint", hint)
