@@ -69,8 +69,8 @@ b osa_cutoff3 --metric osa --cutoff 3
 b cutoff5_many --cutoff 5
 b jw_cutoff0.9 --metric jaro_winkler --fcutoff 0.9
 b c3_cutoff8 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8
-b c3_cutoff8_neardup1 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8 --near-dup-share 0.01 --no-cpu-baseline
-b c3_cutoff8_neardup50 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8 --near-dup-share 0.5 --no-cpu-baseline
+b c3_cutoff8_neardup1 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8 --near-dup-share 0.01
+b c3_cutoff8_neardup50 --query-len 256 --cand-len 256 --candidates 10000000 --cutoff 8 --near-dup-share 0.5
 b filter_cutoff3 --cutoff 3 --mode filter
 b survivors1_cutoff3_many --cutoff 3 --head-share 0.01
 b survivors1_cutoff3_topk --cutoff 3 --head-share 0.01 --mode topk --no-cpu-baseline
