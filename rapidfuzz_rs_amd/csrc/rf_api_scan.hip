@@ -776,7 +776,12 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
     // tile step) and count: with fewer than 70 % of the candidates that matter resolved (break-even is ~73 %) the hint is dropped and the plain scan runs.  Costs
     // one more stream synchronization.
     static const uint32_t sample_min = [] { const char* e = getenv("RF_HINT_SAMPLE_MIN_TILES"); return e ? (uint32_t)atoll(e) : 16384u; }();
-    if (corpus->n_tiles >= sample_min) {
+    // (round 6: the sample is skipped while the hint has been proving itself on this corpus -- the pass itself counts what it left unresolved, and that count comes to
+    // the host anyway; a hinted call in the steady state then synchronizes once.  A hint that turns bad costs ONE call its first pass, RF_HINT_TRUST=0: sample always.)
+    static const bool trust_on = [] { const char* e = getenv("RF_HINT_TRUST"); return !e || atoi(e) != 0; }();
+    const uint32_t trust = corpus->hint_trust.load(std::memory_order_relaxed);
+    const bool trusted = trust_on && trust != 0 && (trust & 15u) != 0;
+    if (corpus->n_tiles >= sample_min && !trusted) {
         ScanParams p1;
         RawKind raw1 = RAW_LEV;
         if (const rf_status rs = plan(c, corpus, op, &a1, false, &p1, &raw1); rs != RF_OK) return rs;
@@ -810,6 +815,7 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
             static const bool trace_sample = getenv("RF_TRACE_PLAN") != nullptr;
             if (trace_sample) std::fprintf(stderr, "[rf plan] hint sample: %u of %u sampled candidates within max(hint, 31) = %u, ~%.2f of the candidates that matter\n", acc[1], acc[0], k1, resolved);
             if (resolved < 0.70) {
+                corpus->hint_trust.store(0, std::memory_order_relaxed);
                 const rf_status rs = run_many(c_in, corpus_in, op, &a2, d_out, RF_MEM_DEVICE, st, false);
                 if (rs != RF_OK) return rs;
                 if (out_mem == RF_MEM_HOST) {
@@ -864,6 +870,11 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
     tile_base[R] = (uint32_t)tiles2_64;
     static const bool trace_plan = getenv("RF_TRACE_PLAN") != nullptr;
     if (trace_plan) std::fprintf(stderr, "[rf plan] hint pass: k1=%u, %llu dense tiles (%llu bytes) of %u left for the full scan\n", k1, (unsigned long long)tiles2_64, (unsigned long long)bytes2, corpus->n_tiles);
+    // what the pass left, for the next hinted call on this corpus: at most 30 % unresolved (the sample's own line) and the hint keeps its credit
+    if ((uint64_t)run_prefix[R] * 10 <= (uint64_t)corpus->n * 3)
+        corpus->hint_trust.store(std::min<uint32_t>(trust + 1, 0x7FFFFFFFu), std::memory_order_relaxed);
+    else
+        corpus->hint_trust.store(0, std::memory_order_relaxed);
     if ((uint64_t)run_prefix[R] * 4 > (uint64_t)corpus->n * 3) {
         // the hint was wrong for more than three quarters of the corpus: gathering them costs more than scanning the few resolved ones again
         if (const rf_status rs = run_many(c_in, corpus_in, op, &a2, d_out, RF_MEM_DEVICE, st, false); rs != RF_OK) return rs;
@@ -873,15 +884,18 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
         uint64_t* d_data_base = nullptr;
         uint8_t* d_data2 = nullptr;
         TileDesc* d_tiles2 = nullptr;
-        RF_HIP(sc.get((void**)&d_tile_base, (R + 1) * sizeof(uint32_t)));
-        RF_HIP(sc.get((void**)&d_run_len, R * sizeof(uint32_t)));
-        RF_HIP(sc.get((void**)&d_data_base, R * sizeof(uint64_t)));
+        // (the three small tables in one block and one copy: every scratch block is a lock and an event, every copy from pageable memory a staged transfer)
+        std::vector<uint64_t> tables(R + (2 * (size_t)R + 1 + 1) / 2);  // R x u64 data_base | (R + 1) x u32 tile_base | R x u32 run_len
+        std::memcpy(tables.data(), data_base.data(), R * sizeof(uint64_t));
+        std::memcpy(reinterpret_cast<uint32_t*>(tables.data() + R), tile_base.data(), (R + 1) * sizeof(uint32_t));
+        std::memcpy(reinterpret_cast<uint32_t*>(tables.data() + R) + (R + 1), run_len.data(), R * sizeof(uint32_t));
+        RF_HIP(sc.get((void**)&d_data_base, tables.size() * sizeof(uint64_t)));
+        d_tile_base = reinterpret_cast<uint32_t*>(d_data_base + R);
+        d_run_len = d_tile_base + (R + 1);
         RF_HIP(sc.get((void**)&d_data2, bytes2 + kTailPad));
         RF_HIP(sc.get((void**)&d_tiles2, (size_t)n_tiles2 * sizeof(TileDesc)));
         RF_HIP(sc.get((void**)&d_orig2, (size_t)n_tiles2 * kWave * sizeof(uint32_t)));
-        RF_HIP(hipMemcpyAsync(d_tile_base, tile_base.data(), (R + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        RF_HIP(hipMemcpyAsync(d_run_len, run_len.data(), R * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        RF_HIP(hipMemcpyAsync(d_data_base, data_base.data(), R * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        RF_HIP(hipMemcpyAsync(d_data_base, tables.data(), tables.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         RF_HIP(hipMemsetAsync(d_data2 + bytes2, 0, kTailPad, st));  // (the scans prefetch one chunk row past the last tile)
         RF_HIP(launch_hint_gather(p, d_run_first, R, d_run_prefix, d_prefix, d_mask, d_tile_base, d_data_base, d_run_len, n_tiles2, d_data2, d_tiles2, d_orig2, st));
         // ---- pass 2: a general corpus of exact tiles whose orig[] holds ORIGINAL candidate indices: results land in the caller's vector

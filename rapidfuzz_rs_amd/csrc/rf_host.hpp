@@ -164,6 +164,7 @@ struct rf_corpus {
     mutable std::vector<TileList> tile_lists;
     mutable std::mutex filter_enqueue_mu;
     mutable std::atomic<uint32_t> filter_last_survivors{0};  // rf_filter_*: how many candidates the last lane-compacted call's first pass left (few: one workgroup finishes the call)
+    mutable std::atomic<uint32_t> hint_trust{0};  // score_hint scans (run_many_hinted): consecutive hinted calls whose first pass resolved >= 70 % of this corpus -- while it counts, the sample (a launch and a host synchronization) is taken on every 16th call only
     // u32 ("char") corpora: the stored byte is the symbol's id in THIS corpus' alphabet.  Ids 0..253 are the 254 most
     // frequent symbols, kOverflowId lumps every rarer symbol together, kAbsentId is never stored (see resolve()).
     bool wide = false;

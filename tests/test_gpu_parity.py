@@ -2514,6 +2514,7 @@ def test_score_hint_is_sampled_first_on_large_corpora(every):
         assert passes == 0, passes  # half the corpus is random: every sample says the hint is not worth it
     else:
         assert passes > 0  # nine in ten within the hint: the sampled calls go on to the two passes
+        assert sampled < passes, (sampled, passes)  # ... and a corpus on which the hint has proven itself is sampled on every 16th call only (rf_corpus::hint_trust)
 
 
 @pytest.mark.parametrize("len2,qlen", [(64, 64), (57, 60), (16, 20), (100, 64), (7, 33), (64, 32), (57, 30), (100, 17), (7, 5)])
