@@ -826,6 +826,75 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
             }
         }
     }
+    // ---- round 6, single-length corpora whose first pass is the band kernel (k1 <= 31) and whose hint is credible (sampled just now, or trusted): the pass LISTS the
+    // lanes it answers None (tile + lane mask, rf_band.hip band_list_kernel), lane_list_pack_kernel numbers them, and the caller's own multi-word scan walks them 64 to a
+    // wavefront (rf_sparse.hip sparse_words_kernel) -- no mark pass, no sums, no host in between, no copy of the payload (whose reads the second pass now does itself).
+    // What the pass left comes back through pinned memory and is read by the NEXT such call (more than 30 % unresolved: the credit is gone and that call takes the road
+    // below, with its sample and its count on the host).  RF_HINT_LISTS=0: the road below always.
+    static const bool lists_on = [] { const char* e = getenv("RF_HINT_LISTS"); return !e || atoi(e) != 0; }();
+    const bool sampled_ok = corpus->n_tiles >= sample_min && !trusted;  // (a sample that said no has returned above)
+    if (lists_on && (trusted || sampled_ok) && corpus->uniform && !corpus->borrowed && k1 <= 31 && c->words >= 2 && c->words <= (size_t)kMaxWords &&
+        corpus->uniform_len >= (uint32_t)kChunk) {
+        const uint32_t len1 = (uint32_t)c->s1.size(), gap = len1 > corpus->uniform_len ? len1 - corpus->uniform_len : corpus->uniform_len - len1;
+        ScanParams p1, p2;
+        RawKind raw1 = RAW_LEV, raw2 = RAW_LEV;
+        if (gap <= k1 && plan(c, corpus, op, &a1, false, &p1, &raw1) == RF_OK && plan(c, corpus, op, &a2, false, &p2, &raw2) == RF_OK && raw1 == RAW_LEV && raw2 == RAW_LEV &&
+            p1.band && !p1.tiles && p1.tile_end > p1.tile_begin && !p2.band && !p2.long_words_pad && !p2.tiles && p2.words >= 2 && p2.words <= (uint32_t)kMaxWords &&
+            p2.tile_begin == p1.tile_begin && p2.tile_end == p1.tile_end) {
+            if (const rf_status rs = comparator_device_pm(c, corpus->device, &p1.pm); rs != RF_OK) return rs;
+            p2.pm = p1.pm;
+            std::unique_lock<std::mutex> list_lock(corpus->filter_enqueue_mu);
+            uint32_t* buf = corpus_tile_list(corpus, st);
+            uint32_t *packed_at = nullptr, *first_at = nullptr;
+            p1.tile_list_buf = buf;
+            bool go = buf != nullptr && band_list_geometry(p1, &packed_at, &first_at);
+            volatile uint32_t* report = nullptr;
+            if (go) {
+                rf_corpus::TileList& tl = corpus->tile_lists.front();  // (corpus_tile_list moved this stream's list to the front)
+                if (!tl.band_report) {
+                    void* hp = nullptr;
+                    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+                        std::memset(hp, 0, 64);
+                        tl.band_report = static_cast<volatile uint32_t*>(hp);
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                }
+                report = tl.band_report;
+                if (report && report[10] != 0) {  // the last such call on this stream: did its first pass leave more than 30 % of the corpus?
+                    const uint64_t left = report[8], of = report[9];
+                    report[10] = 0;
+                    if (left * 10 > of * 3) {
+                        corpus->hint_trust.store(0, std::memory_order_relaxed);
+                        go = false;
+                    }
+                }
+            }
+            if (go) {
+                p1.out = d_out;
+                p1.lane_list = 1;
+                p1.band_list = 1;
+                RF_HIP(launch_scan(raw1, p1, st, nullptr));  // (its None pre-fill if any, band_list_kernel, lane_list_pack_kernel)
+                p2.out = d_out;
+                p2.prefill_none = 0;
+                p2.tile_list = packed_at;
+                p2.lane_first = first_at;
+                p2.tile_list_count = buf;
+                p2.band_report = const_cast<uint32_t*>(report);
+                RF_HIP(launch_sparse_words(p2, st));
+                corpus_tile_list_done(corpus, st);
+                list_lock.unlock();
+                corpus->hint_trust.store(std::min<uint32_t>(trust + 1, 0x7FFFFFFFu), std::memory_order_relaxed);
+                static const bool trace_lists = getenv("RF_TRACE_PLAN") != nullptr;
+                if (trace_lists) std::fprintf(stderr, "[rf plan] hint lists: k1=%u, the band pass lists what it leaves, %u-word scan over the list\n", k1, p2.words);
+                if (out_mem == RF_MEM_HOST) {
+                    RF_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+                    RF_HIP(hipStreamSynchronize(st));
+                }
+                return RF_OK;
+            }
+        }
+    }
     // ---- pass 1
     if (const rf_status rs = run_many(c_in, corpus_in, op, &a1, d_out, RF_MEM_DEVICE, st, false); rs != RF_OK) return rs;
     // ---- the caller's own scan, planned for the corpus and re-aimed at the dense tiles below

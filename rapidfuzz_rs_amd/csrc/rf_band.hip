@@ -27,7 +27,7 @@ constexpr uint32_t band_row_dwords(uint32_t words) { return 2 * words + 5; }  //
 // One tile down the band: the 64 lanes' candidates (this lane's chunk c at src + c * kWave) against the staged table.  Returns 0 when the lanes' results have been
 // written; kDefer: at column p.band_defer_at a tile with few lanes left within break_score gives up -- the lanes that are out get their None, the mask of the others
 // is returned (nothing written for them) and the caller lists it for band_sparse_kernel.
-template <bool kDefer>
+template <bool kDefer, bool kList = false>
 __device__ __forceinline__ uint64_t band_tile(const ScanParams& p, const uint32_t* lds_band, uint32_t stride, uint32_t pitch_bytes, bool asm_run, const uint4* src,
                                               uint32_t len2, bool valid, uint32_t idx, bool& open)
 {
@@ -146,6 +146,7 @@ __device__ __forceinline__ uint64_t band_tile(const ScanParams& p, const uint32_
         else
             emit_usize(p, score, len2, idx);
     }
+    if constexpr (kList) return __ballot(valid && (dead || score > k));  // (score_hint's first pass: the lanes it answered None -- the second pass' work list)
     return handed;
 }
 
@@ -165,7 +166,7 @@ __device__ __forceinline__ void band_stage_table(const ScanParams& p, uint32_t* 
 
 // kDefer (single-length corpora, round 6): tiles that still hold a few live lanes at column p.band_defer_at are LISTED (tile, lane mask: the 16-byte entries of
 // rf_scan.hip's lane lists, one segment of `cap` entries per wavefront, counts at buf + 4) instead of being run to the end for those few.
-template <bool kUniform, bool kDefer>
+template <bool kUniform, bool kDefer, bool kList = false>
 __device__ __forceinline__ void band_kernel_body(const ScanParams& p, uint32_t* __restrict__ buf, uint32_t cap)
 {
     extern __shared__ uint32_t lds_band[];  // 256 rows x band_row_dwords(words)
@@ -178,7 +179,7 @@ __device__ __forceinline__ void band_kernel_body(const ScanParams& p, uint32_t* 
     const uint32_t pitch_bytes = stride * 4u;
     const bool asm_run = p.band_asm != 0;  // (RF_ASM_BAND=0: the compiled column everywhere, the A/B switch)
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave, n_waves = gridDim.x * kWavesPerBlock;
-    uint4* seg = kDefer ? reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)n_waves) + (size_t)gw * cap : nullptr;
+    uint4* seg = (kDefer || kList) ? reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)n_waves) + (size_t)gw * cap : nullptr;
     uint32_t kept = 0, kept_lanes = 0;
     bool open = false;  // this wavefront has seen the launch's count of hand-over candidates reached
     for (uint32_t t = p.tile_begin + gw; t < p.tile_end; t += n_waves) {
@@ -193,8 +194,8 @@ __device__ __forceinline__ void band_kernel_body(const ScanParams& p, uint32_t* 
             if (valid) emit_none(p, idx);
             continue;
         }
-        const uint64_t left = band_tile<kDefer>(p, lds_band, stride, pitch_bytes, asm_run, tv.src + lane, len2, valid, idx, open);
-        if constexpr (kDefer) {
+        const uint64_t left = band_tile<kDefer, kList>(p, lds_band, stride, pitch_bytes, asm_run, tv.src + lane, len2, valid, idx, open);
+        if constexpr (kDefer || kList) {
             if (left != 0) {
                 if (lane == 0) seg[kept] = make_uint4(t, (uint32_t)left, (uint32_t)(left >> 32), 0u);
                 ++kept;
@@ -202,7 +203,7 @@ __device__ __forceinline__ void band_kernel_body(const ScanParams& p, uint32_t* 
             }
         }
     }
-    if constexpr (kDefer) {
+    if constexpr (kDefer || kList) {
         if (lane == 0) reinterpret_cast<uint2*>(buf + 4)[gw] = make_uint2(kept, kept_lanes);
     }
 }
@@ -219,6 +220,13 @@ __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void band_defer_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
 {
     band_kernel_body<true, true>(p, buf, cap);
+}
+
+// score_hint's first pass over a single-length corpus (rf_api_scan.hip run_many_hinted): the plain kernel, and every tile that holds lanes it answered None goes on the
+// wavefront's list with their mask -- the work list of the caller's own scan (rf_sparse.hip sparse_words_kernel)
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void band_list_kernel(const ScanParams p, uint32_t* __restrict__ buf, uint32_t cap)
+{
+    band_kernel_body<true, false, true>(p, buf, cap);
 }
 
 // The second pass of a deferring launch: DENSE tiles of the listed lanes, 64 to a wavefront (rf_sparse.hip has the scheme: the packed entries carry the survivors'
@@ -297,6 +305,19 @@ hipError_t launch_band(const ScanParams& p, hipStream_t stream)
     // -- four-symbol alphabets -- the tile is simply not sparse yet at that column and runs on in place.)
     const uint32_t defer_at = defer_at_env ? defer_at_env : std::min(64u, std::max(16u, (p.band_k + 8u + 15u) / 16u * 16u));
     const uint32_t G = (uint32_t)band_grid * kWavesPerBlock, n_tiles = p.tile_end - p.tile_begin;
+    if (p.band_list) {  // (the caller has checked band_list_geometry() and holds the list buffer; it launches the second pass itself)
+        if (!p.tile_list_buf || p.tiles || G > 16384u) return hipErrorInvalidValue;
+        const uint32_t cap = (n_tiles + G - 1) / G;
+        if (lds > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(band_list_kernel, g, b, lds, stream, pa, p.tile_list_buf, cap);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        uint32_t* packed_at = p.tile_list_buf + 4 + 2 * (size_t)G + 4 * (size_t)G * cap;
+        return launch_lane_list_pack(p.tile_list_buf, G, cap, packed_at + 4 * ((size_t)n_tiles + 2), stream);
+    }
     const bool defer = defer_on && defer_at && p.lane_list && p.tile_list_buf && p.band_defer_seen && !p.tiles && !p.run_orig && G <= 16384u && p.uniform_len >= defer_at + 64u &&
                        p.len1 >= defer_at + 64u + p.band_k;
     if (defer) {
@@ -331,6 +352,19 @@ hipError_t launch_band(const ScanParams& p, hipStream_t stream)
     }
     hipLaunchKernelGGL(kern, g, b, lds, stream, pa);
     return hipGetLastError();
+}
+
+// where a band_list launch over p's tiles leaves its packed list and first[] inside p.tile_list_buf (false: such a launch does not fit the buffer's 16 K segments)
+bool band_list_geometry(const ScanParams& p, uint32_t** packed_at, uint32_t** first_at)
+{
+    if (p.tile_end <= p.tile_begin || !p.tile_list_buf) return false;
+    const uint32_t n_tiles = p.tile_end - p.tile_begin;
+    const int band_grid = std::max(1, std::min(scan_grid(n_tiles), (scan_max_grid() + 1) / 2));
+    const uint32_t G = (uint32_t)band_grid * kWavesPerBlock, cap = (n_tiles + G - 1) / G;
+    if (G > 16384u) return false;
+    *packed_at = p.tile_list_buf + 4 + 2 * (size_t)G + 4 * (size_t)G * cap;
+    *first_at = *packed_at + 4 * ((size_t)n_tiles + 2);
+    return true;
 }
 
 }  // namespace rf

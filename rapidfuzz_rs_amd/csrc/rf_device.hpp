@@ -1019,6 +1019,39 @@ __device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t k)
     return pos;
 }
 
+// A dense tile of listed lanes (rf_scan.hip lane_list_pack_kernel: 16-byte entries (tile, lane mask lo, hi, listed lanes in front), first[j] = the entry that holds lane
+// 64 j): which (tile, lane) does wavefront lane `lane` of dense tile j take?  The 64 entries from first[j] on hold all 64 (an entry holds at least one): one coalesced
+// load, the lane's own entry by a binary search across the LANES (the running sums ascend with the lane), its candidate as the n-th set bit of that entry's mask.
+// Idle lanes of the last dense tile shadow the last listed lane (defined bytes; `have` false).
+struct DenseLane {
+    uint32_t tile, lane_in_tile;
+    bool have;
+};
+__device__ __forceinline__ DenseLane dense_lane_source(const uint4* __restrict__ list, uint32_t entries, uint32_t total, const uint32_t* __restrict__ first_of, uint32_t j,
+                                                       uint32_t lane)
+{
+    DenseLane s;
+    const uint32_t g = j * kWave + lane;
+    s.have = g < total;
+    const uint32_t gg = s.have ? g : total - 1;
+    const uint32_t e0 = uniform(first_of[j]);
+    const uint4 ent = list[min(e0 + lane, entries - 1)];
+    uint32_t lo = 0, hi = kWave;
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t wm = (uint32_t)__shfl((int)ent.w, (int)mid, kWave);
+        if (wm <= gg)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t mlo = (uint32_t)__shfl((int)ent.y, (int)lo, kWave), mhi = (uint32_t)__shfl((int)ent.z, (int)lo, kWave), w = (uint32_t)__shfl((int)ent.w, (int)lo, kWave);
+    s.tile = (uint32_t)__shfl((int)ent.x, (int)lo, kWave);
+    s.lane_in_tile = nth_set_bit(((uint64_t)mhi << 32) | mlo, gg - w);
+    return s;
+}
+
 struct TileView {
     const uint4* src;  // wavefront-uniform base of the tile payload
     uint32_t len, slot0;

@@ -156,6 +156,7 @@ struct ScanParams {
     uint32_t band_defer_at, band_defer_max, band_defer_after;  // != 0 (set by the launcher): a tile with <= band_defer_max lanes within break_score at column band_defer_at is listed for band_sparse_kernel, once the launch has seen band_defer_after of them
     uint32_t* band_defer_seen;      // that count (the last words of the stream's tile-list buffer; band_sparse_kernel zeroes it again)
     uint32_t* band_report;          // pinned host words (or nullptr): band_sparse_kernel leaves [0] tiles listed, [1] lanes listed, [2] tiles of the launch, [3] 1, [4] band_defer_at, [5] band_defer_max
+    uint32_t band_list;             // 1 (score_hint, first pass): the band launch lists every tile that holds lanes it answered None, with their mask (tile_list_buf), for launch_sparse_words
     // the multi-word asm scans (rf_stream_asm.hip, tools/gen_stream_asm.py BlockKind): raw distances above trim_k1 - 1 need not be exact (they must come out above
     // it), which narrows the Ukkonen band the kernels trim their word-columns to; 0 = no bound beyond max(len1, len2)
     uint32_t trim_k1;
@@ -189,8 +190,10 @@ hipError_t launch_hint_gather(const ScanParams& p, const uint32_t* run_first, ui
                               const uint32_t* run_tile_base, const uint64_t* run_data_base, const uint32_t* run_len, uint32_t n_tiles2, uint8_t* data2, TileDesc* tiles2,
                               uint32_t* orig2, hipStream_t st);
 hipError_t launch_band(const ScanParams& p, hipStream_t stream);  // rf_band.hip: exact tiles [tile_begin, tile_end)
+bool band_list_geometry(const ScanParams& p, uint32_t** packed_at, uint32_t** first_at);  // rf_band.hip: where a p.band_list launch leaves its packed list / first[] in p.tile_list_buf
 // rf_sparse.hip: the lane compaction of the head-plane cutoff scans (ScanParams::lane_list)
 hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, hipStream_t stream);  // state_kind: 0 LevState<1>, 1 Lev32State, 2 OsaState<1>; p.tile_list = the packed 16-byte entries
+hipError_t launch_sparse_words(const ScanParams& p, hipStream_t stream);  // rf_sparse.hip: the multi-word Levenshtein scan (p.words = 2..8, single-length corpus) over the listed lanes
 bool head_two_pass_applies(RawKind raw, const ScanParams& p);  // rf_scan.hip: will launch_scan take head_filter_kernel + a second pass for this launch?
 hipError_t launch_lane_list_pack(uint32_t* buf, uint32_t G, uint32_t cap, uint32_t* first_of, hipStream_t stream);  // rf_scan.hip lane_list_pack_kernel over G segments of `cap` entries
 hipError_t launch_scan_mixed(RawKind raw, const ScanParams& p, hipStream_t stream);  // p.mixed / tile_begin / tile_end: the mixed section

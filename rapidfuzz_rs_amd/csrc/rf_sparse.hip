@@ -158,6 +158,69 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_lean_kernel(cons
     if (topk) topk_block_publish(p, best, lds_topk, wave, lane, limit);
 }
 
+// The second pass of a score_hint scan of a single-length corpus (round 6; rf_api_scan.hip run_many_hinted): the candidates the band pass left unresolved -- listed by
+// that pass itself, tile and lane mask (rf_band.hip band_list_kernel) -- run the caller's own multi-word scan 64 to a wavefront, each lane reading its own candidate's chunk
+// rows.  No host in between: the number of dense tiles is read here.  (Round 5 marked the lanes in a pass of its own, summed them, brought the sums to the host to size
+// dense tiles, copied the payload into them and scanned the copy: the copy moved what this kernel's loads move, once more.)
+template <class State>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void sparse_words_kernel(const ScanParams p)
+{
+    constexpr int W = State::kWords;
+    __shared__ typename State::Word lds_pm[256 * W];
+    const uint4* __restrict__ list = reinterpret_cast<const uint4*>(p.tile_list);
+    const uint32_t entries = uniform(p.tile_list_count[0]), total = uniform(p.tile_list_count[1]);
+    const uint32_t n_dense = (total + kWave - 1) / kWave;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.band_report) {  // what the first pass left, for the host's bookkeeping of the hint (read there without waiting)
+        __hip_atomic_store(p.band_report + 8, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.band_report + 9, p.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.band_report + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (blockIdx.x * kWavesPerBlock >= n_dense) return;
+    for (int i = threadIdx.x; i < 256 * W; i += kWave * kWavesPerBlock) lds_pm[(uint32_t)p.sigma[i / W] * W + i % W] = (typename State::Word)p.pm[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    const uint32_t len1 = p.len1, len2 = p.uniform_len;
+    const uint32_t nch = (len2 + kChunk - 1) / kChunk;
+    const TileFin fin = tile_fin(p, len1, len2);
+    const bool early = State::kCanPrune && p.early != 0;
+    for (uint32_t j = blockIdx.x * kWavesPerBlock + wave; j < n_dense; j += gridDim.x * kWavesPerBlock) {
+        const DenseLane dl = dense_lane_source(list, entries, total, p.lane_first, j, lane);
+        const uint4* src = reinterpret_cast<const uint4*>(p.data + (uint64_t)dl.tile * p.uniform_tile_bytes) + dl.lane_in_tile;
+        const uint32_t idx = dl.tile * kWave + dl.lane_in_tile;
+        const bool valid = dl.have && idx < p.n;
+        State st;
+        st.init();
+        bool dead = false;
+        uint4 cur = nch ? load_chunk(src) : make_uint4(0, 0, 0, 0);
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint4 nxt = cur;
+            if (c + 1 < nch) nxt = load_chunk(src + (size_t)(c + 1) * kWave);
+            const uint32_t cols = len2 - c * kChunk;
+            if constexpr (has_band<State>::value) st.set_band(len1, len2, p.trim_k1 ? p.trim_k1 - 1u : 0xFFFFFFFFu, c);
+            if (cols >= (uint32_t)kChunk)
+                process_chunk_full<State>(st, lds_pm, cur);
+            else
+                process_chunk_tail<State>(st, lds_pm, cur, cols);
+            if (early) {
+                const uint32_t jj = min(len2, (c + 1) * kChunk);
+                if (__ballot(valid && may_pass(p, fin, st.bound(len1, jj, len2))) == 0) {
+                    dead = true;  // no lane of this dense tile can pass the caller's cutoff any more
+                    break;
+                }
+            }
+            cur = nxt;
+        }
+        const uint32_t raw = st.result(len1, len2);
+        if (p.out && valid) {
+            if (dead)
+                emit_none(p, idx);
+            else
+                emit_fin(p, fin, raw, idx, p.out);
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, hipStream_t stream)
@@ -174,6 +237,25 @@ hipError_t launch_sparse_lean(int state_kind, const ScanParams& p, hipStream_t s
     case 0: hipLaunchKernelGGL((sparse_lean_kernel<LevState<1>>), g, b, 0, stream, p); break;
     case 1: hipLaunchKernelGGL((sparse_lean_kernel<Lev32State>), g, b, 0, stream, p); break;
     case 2: hipLaunchKernelGGL((sparse_lean_kernel<OsaState<1>>), g, b, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_words(const ScanParams& p, hipStream_t stream)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint32_t tiles = p.tile_end > p.tile_begin ? p.tile_end - p.tile_begin : 1u;
+    const dim3 g(std::max(1u, std::min((uint32_t)cus * 16u, (tiles + kWavesPerBlock - 1) / kWavesPerBlock))), b(kWave * kWavesPerBlock);
+    switch (p.words) {
+    case 2: hipLaunchKernelGGL((sparse_words_kernel<LevState<2>>), g, b, 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((sparse_words_kernel<LevState<3>>), g, b, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((sparse_words_kernel<LevState<4>>), g, b, 0, stream, p); break;
+    case 5: hipLaunchKernelGGL((sparse_words_kernel<LevState<5>>), g, b, 0, stream, p); break;
+    case 6: hipLaunchKernelGGL((sparse_words_kernel<LevState<6>>), g, b, 0, stream, p); break;
+    case 7: hipLaunchKernelGGL((sparse_words_kernel<LevState<7>>), g, b, 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((sparse_words_kernel<LevState<8>>), g, b, 0, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

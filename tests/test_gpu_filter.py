@@ -411,7 +411,7 @@ def test_randomized_corpus_models_vary_what_the_plan_looks_at(seed):
                 assert np.all(np.diff(idx.astype(np.int64)) > 0)
 
 
-def _band_rows(n, len2, q, share, seed):
+def _band_rows(n, len2, q, share, seed, kinds=8):
     """n rows of len2 symbols around query q (its own length may differ by a few): a fraction `share` near the query -- the query resized to len2 with 0..12
     substitutions, or with an insertion / deletion near the front (the rest of the row then runs ONE off the diagonal), or equal to it for the first 20..120 symbols
     and random from there on (in the band for a while, out of it long before the end) -- the others random."""
@@ -420,7 +420,7 @@ def _band_rows(n, len2, q, share, seed):
     rows = synth.ALNUM[rng.integers(0, 62, size=(n, len2))]
     near = np.nonzero(rng.random(n) < share)[0]
     for j, i in enumerate(near):
-        kind = j % 8
+        kind = j % kinds  # (kinds = 6: no head-then-noise rows)
         base = np.resize(qa, len2 + 2)
         if kind <= 3:
             row = base[:len2].copy()
@@ -522,6 +522,38 @@ def test_randomized_small_band_on_single_length_corpora(seed):
             bad = _same(got, exp)
             assert len(bad) == 0, (seed, qlen, len2, n, share, len(alpha), k, bad[:5], got[bad[:5]], exp[bad[:5]])
         hint = int(rng.choice([0, 4, 16, 40]))
-        got = bc.distance_many(corpus, score_hint=hint)
         exp = ob.rows(N.OP_DISTANCE, rows, nthreads=8)
-        assert len(_same(got, exp)) == 0, (seed, qlen, len2, n, share, "hint", hint)
+        for _rep in range(2):  # (the second call finds the hint credited where the first resolved >= 70 %: the list road of run_many_hinted)
+            got = bc.distance_many(corpus, score_hint=hint)
+            assert len(_same(got, exp)) == 0, (seed, qlen, len2, n, share, "hint", hint, _rep)
+
+
+@pytest.mark.parametrize("share", [0.75, 0.97])
+def test_score_hint_scan_walks_the_list_its_band_pass_leaves(share):
+    """A credible score_hint on a single-length corpus (rf_api_scan.hip run_many_hinted, round 6): the band pass lists the lanes it answers None and the caller's own
+    multi-word scan walks that list (rf_sparse.hip sparse_words_kernel) -- from the second hinted call on, once the first has shown the hint to resolve >= 70 % of the
+    corpus.  Results never depend on the hint (levenshtein.rs:2153-2160): hints x cutoffs on both sides of max(hint, 31) x weights, queries of 2..8 words, rows a few
+    symbols off the query's length, every value against the un-hinted oracle; RF_TRACE_PLAN (child process) shows that the list road was taken."""
+    import torch
+
+    if os.environ.get("RF_TRACE_PLAN") is None:
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:xdist", "-s", "-k",
+                            f"test_score_hint_scan_walks_the_list and {share}"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RF_TRACE_PLAN="1"))
+        assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+        assert (r.stdout + r.stderr).count("[rf plan] hint lists:") >= 8
+        return
+    for qlen, len2, n in ((256, 256, 120_011), (130, 128, 70_003), (300, 305, 70_003), (500, 512, 66_000)):
+        q = synth.query(qlen, 0x4157 + qlen)
+        rows = _band_rows(n, len2, q, share, seed=qlen + int(share * 1000), kinds=6)
+        corpus = rf.Corpus.from_device_rows(torch.from_numpy(rows).cuda())
+        bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
+        for weights in (None, (2, 2, 2)):
+            f = 1 if weights is None else 2
+            kw = {} if weights is None else {"weights": rf.WeightTable(*weights)}
+            okw = {} if weights is None else {"weights": weights}
+            for cutoff in (None, 40 * f, 200 * f):
+                exp = _u32(ob.rows(N.OP_DISTANCE, rows, nthreads=8, score_cutoff=cutoff, **okw))
+                for hint in (8 * f, 0, 31 * f, 16 * f):
+                    got = bc.many(N.OP_DISTANCE, corpus, score_cutoff=cutoff, score_hint=hint, **kw)
+                    bad = np.nonzero(got != exp)[0]
+                    assert len(bad) == 0, (share, qlen, len2, weights, cutoff, hint, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
