@@ -49,7 +49,7 @@ b c3_levenshtein_256 --query-len 256 --cand-len 256 --candidates 10000000
 b levenshtein_512 --query-len 512 --cand-len 512 --candidates 2500000
 b levenshtein_320 --query-len 320 --cand-len 320 --candidates 4000000
 b hint16_neardup99 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.99 --hint 16 --no-cpu-baseline
-b hint16_neardup90 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --hint 16 --no-cpu-baseline
+b hint16_neardup90 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --hint 16
 b hint16_neardup50 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.5 --hint 16 --no-cpu-baseline
 b nohint_neardup90 --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --no-cpu-baseline
 b c4_indel --metric indel
