@@ -150,8 +150,9 @@ typedef enum rf_mem { RF_MEM_HOST = 0, RF_MEM_DEVICE = 1 } rf_mem;
  *                  under the cutoff max(hint, 31) (the one-word band kernel, or the banded multi-word scans), then only the candidates
  *                  that left unresolved are gathered into dense tiles and scanned under the caller's own cutoff (rf_hint.hip) -- a
  *                  corpus of near-duplicates costs the band pass, an unrelated one the full scan + a few percent (corpora of >= 16384 tiles sample the
- *                  band pass first and drop a hint that is wrong for more than 30 % of the candidates).  Such a call synchronizes `stream`
- *                  once or twice between the passes (RF_MEM_DEVICE too).
+ *                  band pass first and drop a hint that is wrong for more than 30 % of the candidates).  Such a call may synchronize `stream`
+ *                  once or twice between the passes (RF_MEM_DEVICE too); on a single-length corpus whose last hinted scans resolved >= 70 % of
+ *                  it, a hint of <= 31 runs without any: the band pass lists what it leaves and the caller's scan walks the list.
  *                  rf_topk_u32 with RF_OP_DISTANCE and no cutoff: the scan first runs under the
  *                  cutoff `hint` (a cutoff scan costs a fraction of a full one) and the k best are final if k candidates pass,
  *                  otherwise the hint doubles (past a quarter of the longest possible distance the plain scan runs).

@@ -926,6 +926,7 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
     std::vector<uint32_t> cnt(R);
     for (uint32_t r = 0; r < R; ++r) cnt[r] = run_prefix[r + 1] - run_prefix[r];
     std::vector<uint32_t> tile_base(R + 1, 0u), run_len(R);
+    std::vector<uint64_t> tables;  // (what goes up to the device, in one copy; lives as long as the other staging vectors of this call)
     std::vector<uint64_t> data_base(R, 0ull);
     uint64_t bytes2 = 0, tiles2_64 = 0;
     for (uint32_t r = 0; r < R; ++r) {
@@ -954,7 +955,7 @@ static rf_status run_many_hinted(const rf_comparator* c_in, const rf_corpus* cor
         uint8_t* d_data2 = nullptr;
         TileDesc* d_tiles2 = nullptr;
         // (the three small tables in one block and one copy: every scratch block is a lock and an event, every copy from pageable memory a staged transfer)
-        std::vector<uint64_t> tables(R + (2 * (size_t)R + 1 + 1) / 2);  // R x u64 data_base | (R + 1) x u32 tile_base | R x u32 run_len
+        tables.assign(R + (2 * (size_t)R + 1 + 1) / 2, 0);  // R x u64 data_base | (R + 1) x u32 tile_base | R x u32 run_len
         std::memcpy(tables.data(), data_base.data(), R * sizeof(uint64_t));
         std::memcpy(reinterpret_cast<uint32_t*>(tables.data() + R), tile_base.data(), (R + 1) * sizeof(uint32_t));
         std::memcpy(reinterpret_cast<uint32_t*>(tables.data() + R) + (R + 1), run_len.data(), R * sizeof(uint32_t));
