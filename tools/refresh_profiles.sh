@@ -31,6 +31,10 @@ MATCH="rf::head_filter" P survivors1_cutoff3 "none" --cutoff 3 --head-share 0.01
 MATCH="sparse_lean" P survivors5_cutoff3_sparse "none" --cutoff 3 --head-share 0.05
 MATCH="rf::head_filter" P filter_cutoff3 "none" --cutoff 3 --mode filter
 MATCH="rf::stream_lcs6" P ragged_indel_slots "none" --ragged --metric indel --slot-order
+# ... long queries on corpora of near-duplicates: the band pass that lists what it leaves, the scan over that list (per-lane chunk loads: what do the counters say they cost?)
+MATCH="rf::band_list" P hint16_neardup90_band "none" --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --hint 16
+MATCH="sparse_words" P hint16_neardup90_sparse "none" --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.9 --hint 16
+MATCH="rf::band_sparse" P c3_cutoff8_neardup1_sparse "none" --query-len 256 --cand-len 256 --candidates 10000000 --near-dup-share 0.01 --cutoff 8
 sed -i "s#gpurun_out/#profiles/#g" gpurun_out/traffic.json; cp gpurun_out/traffic.json gpurun_out/profiles/traffic.json
 b() { name=$1; shift; [[ -n "${ONLY:-}" && $name != *$ONLY* ]] && return; python bench.py --traffic off --extras off "$@" 2>/dev/null | tail -1 > gpurun_out/profiles/bench_$name.json; }
 # the default line exactly as the driver runs it (extra_configs legs, in-run traffic)
