@@ -51,7 +51,7 @@
  *                                           lanes left to a dense second pass (rf_band.hip launch_band)
  *   RF_BAND_DEFER_AT              0 (auto)  column (a multiple of 16) at which a tile may be handed over; auto: k + 8 rounded up, 16..64
  *   RF_BAND_DEFER_MAX             44        most lanes still within the band for a tile to be handed over
- *   RF_BAND_DEFER_AFTER           1024      such tiles a launch runs in place before it starts handing over (a handful is cheaper where it is)
+ *   RF_BAND_DEFER_AFTER           0         such tiles a launch runs in place before it starts handing over (counted in one device word; 0: no count)
  *   RF_BAND_DEFER_ADAPT           1         0: every such launch hands over; 1: by what the stream's last hand-over launch listed (the plain kernel where that saved
  *                                           less than a quarter of the columns, looking again every 16th launch)
  *   RF_TILE_ORDER                 2         0..3: how a length-bucketed corpus' results reach original order

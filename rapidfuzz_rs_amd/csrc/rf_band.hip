@@ -181,7 +181,7 @@ __device__ __forceinline__ void band_kernel_body(const ScanParams& p, uint32_t* 
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave, n_waves = gridDim.x * kWavesPerBlock;
     uint4* seg = (kDefer || kList) ? reinterpret_cast<uint4*>(buf + 4 + 2 * (size_t)n_waves) + (size_t)gw * cap : nullptr;
     uint32_t kept = 0, kept_lanes = 0;
-    bool open = false;  // this wavefront has seen the launch's count of hand-over candidates reached
+    bool open = p.band_defer_after == 0;  // this wavefront has seen the launch's count of hand-over candidates reached (0: nothing to count)
     for (uint32_t t = p.tile_begin + gw; t < p.tile_end; t += n_waves) {
         const TileView tv = load_tile<kUniform>(p, t);
         const uint32_t len2 = tv.len;
@@ -295,11 +295,13 @@ hipError_t launch_band(const ScanParams& p, hipStream_t stream)
     // them holds a few -- and each ran all its columns on 64 lanes for those few.  With a list buffer at hand the first launch gives such a tile up at column
     // band_defer_at (a random candidate is past break_score by then) unless most of its lanes are still in, and band_sparse_kernel runs the listed lanes 64 to a
     // wavefront from column 0.  RF_BAND_DEFER=0 switches it off, RF_BAND_DEFER_AT / RF_BAND_DEFER_MAX move the column and the lane count (default k + 8 rounded up to a whole chunk / 44),
-    // RF_BAND_DEFER_AFTER the number of such tiles a launch runs in place first (1024).
+    // RF_BAND_DEFER_AFTER the number of such tiles a launch runs in place first (0).
     static const bool defer_on = [] { const char* e = getenv("RF_BAND_DEFER"); return !e || atoi(e) != 0; }();
     static const uint32_t defer_at_env = [] { const char* e = getenv("RF_BAND_DEFER_AT"); return e ? ((uint32_t)atoi(e) + 15u) / 16u * 16u : 0u; }();
     static const uint32_t defer_max = [] { const char* e = getenv("RF_BAND_DEFER_MAX"); return e ? (uint32_t)atoi(e) : 44u; }();
-    static const uint32_t defer_after = [] { const char* e = getenv("RF_BAND_DEFER_AFTER"); return e ? (uint32_t)atoi(e) : 1024u; }();
+    // (0 since the launch form follows the last launch's report, rf_api_scan.hip: a corpus with a handful of near candidates takes the plain kernel on 15 launches of 16,
+    // and counting cost the others one same-address atomic per wavefront -- 16 K of them at the start of the launch, 250 -> 190 us at 1 % near candidates)
+    static const uint32_t defer_after = [] { const char* e = getenv("RF_BAND_DEFER_AFTER"); return e ? (uint32_t)atoi(e) : 0u; }();
     // (the column: a candidate unrelated to the query adds nearly one to its score per column from k on and is out past break_score = 2k (+ the length difference):
     // k + 8 columns see the random lanes off, rounded up to a chunk end -- 16 at k = 8, 48 at the k = 31 of a hinted scan's first pass.  Where they last longer
     // -- four-symbol alphabets -- the tile is simply not sparse yet at that column and runs on in place.)

@@ -470,10 +470,9 @@ def test_small_band_scan_hands_sparse_tiles_to_a_dense_second_pass(share):
 @pytest.mark.parametrize("env", [{"RF_BAND_DEFER": "0"}, {"RF_BAND_DEFER_AFTER": "0", "RF_BAND_DEFER_ADAPT": "0"},
                                  {"RF_BAND_DEFER_AT": "16", "RF_BAND_DEFER_MAX": "63", "RF_BAND_DEFER_AFTER": "0", "RF_BAND_DEFER_ADAPT": "0"},
                                  {"RF_BAND_DEFER_AT": "64", "RF_BAND_DEFER_MAX": "20", "RF_BAND_DEFER_AFTER": "0", "RF_BAND_DEFER_ADAPT": "0"},
-                                 {"RF_ASM_BAND": "0", "RF_BAND_DEFER_AFTER": "3", "RF_BAND_DEFER_ADAPT": "0"}])
+                                 {"RF_ASM_BAND": "0", "RF_BAND_DEFER_AFTER": "3", "RF_BAND_DEFER_ADAPT": "0"}, {"RF_BAND_DEFER_AFTER": "1024"}])
 def test_small_band_hand_over_switches(env):
-    """The same test with the hand-over off, from the launch's first candidate tile on and whatever the last launch listed (by default a launch runs its first
-    1024 such tiles in place -- only the 150 011-row corpus above hands anything over -- and a stream whose last hand-over launch saved little takes the plain kernel), at column 16 for every tile with a lane left, at column 64, and on the compiled column (the switches are read once per process)."""
+    """The same test with the hand-over off, whatever the last launch listed (by default a stream whose last hand-over launch saved little takes the plain kernel), at column 16 for every tile with a lane left, at column 64, and on the compiled column (the switches are read once per process)."""
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "test_small_band_scan_hands_sparse_tiles"],
                        capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **env))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
