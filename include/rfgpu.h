@@ -43,6 +43,8 @@
  *                                           per candidate through the band prefilter; costs 6 more bytes per candidate of HBM)
  *   RF_BAND_FILTER                -1 (auto) 0 / 1: band prefilter of the head-plane scans never / whenever applicable
  *   RF_NO_BAND                    unset     set: multi-word scan + early-out instead of the band kernel
+ *   RF_NORM_BAND                  1         0: normalized_* of a long-query Levenshtein scan under an f64 cutoff that leaves <= 31 raw edits runs the compiled f64
+ *                                           early-out scan instead of the small-band kernel under the implied raw cutoff + a normalizing pass
  *   RF_HINT_LISTS                 1         0: a credible score_hint scan of a single-length corpus marks, sums, sizes on the host, copies and re-scans what its band
  *                                           pass left (round 5) instead of letting that pass list it for a scan over the list (rf_sparse.hip sparse_words_kernel)
  *   RF_HINT_TRUST                 1         0: every score_hint scan of a large corpus samples it first (a launch and a host synchronization); 1: not while the

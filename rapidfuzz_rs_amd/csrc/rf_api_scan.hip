@@ -1037,7 +1037,23 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     // Ukkonen band: 3.3 instead of 2.5 Gpairs/s at 256 x 256) into a temporary, then ONE pass that runs the very arithmetic of emit_fin (rf_device.hpp) on every
     // distance -- dist / maximum, 1.0 - nd, the cutoff compare -- 12 bytes per candidate against a scan of >= 128 symbols each.  RF_NORM_TWO_STEP=0: the A/B switch.
     static const bool norm_two_step = [] { const char* e = getenv("RF_NORM_TWO_STEP"); return !e || atoi(e) != 0; }();
-    if (norm_two_step && !want_slots && f64_out && raw == RAW_LEV && p.words >= 2 && p.words <= kMaxWords && !p.early && !p.long_words_pad && corpus == corpus_in && !corpus->borrowed &&
+    // (round 6) ... and under an f64 cutoff that leaves at most 31 raw edits -- normalized_similarity >= 0.9 of a 256-symbol query: 25 -- the u32 scan runs under THAT
+    // cutoff, i.e. the small-band kernel (rf_band.hip: 75 Gpairs/s where the compiled f64 early-out scan walks four words per column), and the normalizing pass decides
+    // Some / None from the exact distance as before.  The raw cutoff is the largest distance the f64 test can pass for the longest candidate, plus one edit of slack for
+    // the rounding of c x maximum: whatever the band answers None is beyond it, and None stays None (details/distance.rs:246-250, :273; common.rs:43-45).
+    // RF_NORM_BAND=0: the compiled f64 scan.
+    static const bool norm_band = [] { const char* e = getenv("RF_NORM_BAND"); return !e || atoi(e) != 0; }();
+    uint64_t norm_raw_cut = RF_NO_CUTOFF;
+    if (norm_band && f64_out && raw == RAW_LEV && p.has_cutoff && p.finish == FIN_LEV && p.factor >= 1 && c->words >= 2 &&
+        (op == RF_OP_NORMALIZED_DISTANCE || op == RF_OP_NORMALIZED_SIMILARITY)) {
+        const double c_nd = op == RF_OP_NORMALIZED_DISTANCE ? p.cutoff_f64 : 1.0 - p.cutoff_f64;
+        const double maximum = (double)p.factor * (double)std::max<uint64_t>(p.len1, corpus->max_len);  // (FIN_LEV: maximum = factor x the longer string, ascending in len2)
+        if (c_nd >= 0.0 && c_nd * maximum < 32.0 * (double)p.factor) {
+            const uint64_t k_units = (uint64_t)std::floor(c_nd * maximum) + p.factor;
+            if (k_units / p.factor <= 31) norm_raw_cut = k_units;
+        }
+    }
+    if (norm_two_step && !want_slots && f64_out && raw == RAW_LEV && p.words >= 2 && p.words <= kMaxWords && (!p.early || norm_raw_cut != RF_NO_CUTOFF) && !p.long_words_pad && corpus == corpus_in && !corpus->borrowed &&
         corpus->n_tiles >= 16 && (uint64_t)p.len1 + corpus->max_len < 0x7FFFFFFFu && (corpus->uniform || (corpus->d_orig && corpus->d_tiles))) {
         // (length-bucketed corpora: the candidates' lengths in original order, 4 bytes each, built once per corpus from the tile descriptors)
         const uint32_t* len_of = nullptr;
@@ -1058,7 +1074,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
         }
         if (corpus->uniform || len_of) {
             rf_args a = *args;
-            a.cutoff_usize = RF_NO_CUTOFF;
+            a.cutoff_usize = norm_raw_cut;  // (RF_NO_CUTOFF unless the f64 cutoff leaves <= 31 raw edits)
             a.score_hint_usize = RF_NO_CUTOFF;
             // (the temporaries are optional -- no room for them is not an error, the compiled f64 scan below needs none: same values)
             uint32_t* d_dist = nullptr;

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(const uint32_t* __restri
             v = 1.0 - nd;
             keep = !has_cutoff || v >= cutoff;
         }
+        if (d == RF_NONE_U32) keep = false;  // (the u32 scan ran under a raw cutoff and answered None: beyond anything the f64 test can pass -- run_many's norm_raw_cut)
         __builtin_nontemporal_store(keep ? v : __longlong_as_double(0x7FF8000000000000ll), out + i);
     }
 }

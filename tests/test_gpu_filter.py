@@ -435,7 +435,7 @@ def _band_rows(n, len2, q, share, seed, kinds=8):
             row = np.insert(base, at, np.uint8(35))[:len2].copy()
         else:  # the query's head, then noise
             row = rows[i].copy()
-            h = int(rng.integers(20, 121))
+            h = min(int(rng.integers(20, 121)), len2)
             row[:h] = base[:h]
         rows[i] = row
     return np.ascontiguousarray(rows)
@@ -520,6 +520,12 @@ def test_randomized_small_band_on_single_length_corpora(seed):
             exp = ob.rows(N.OP_DISTANCE, rows, nthreads=8, score_cutoff=k)
             bad = _same(got, exp)
             assert len(bad) == 0, (seed, qlen, len2, n, share, len(alpha), k, bad[:5], got[bad[:5]], exp[bad[:5]])
+        # the normalized ops under an f64 cutoff that leaves few raw edits ride the same kernel (run_many's norm_raw_cut) -- or, beyond 31 edits, the compiled f64 scan
+        for op, cut in ((N.OP_NORMALIZED_SIMILARITY, 1.0 - float(rng.random()) * 0.16), (N.OP_NORMALIZED_DISTANCE, float(rng.choice([0.0, float(rng.random()) * 0.16, 25 / max(qlen, len2)])))):
+            got = bc.many(op, corpus, score_cutoff=cut)
+            exp = ob.rows(op, rows, nthreads=8, score_cutoff=cut)
+            bad = _same(got, exp)
+            assert len(bad) == 0, (seed, qlen, len2, n, share, len(alpha), op, cut, bad[:5], got[bad[:5]], exp[bad[:5]])
         hint = int(rng.choice([0, 4, 16, 40]))
         exp = ob.rows(N.OP_DISTANCE, rows, nthreads=8)
         for _rep in range(2):  # (the second call finds the hint credited where the first resolved >= 70 %: the list road of run_many_hinted)
@@ -556,3 +562,53 @@ def test_score_hint_scan_walks_the_list_its_band_pass_leaves(share):
                     got = bc.many(N.OP_DISTANCE, corpus, score_cutoff=cutoff, score_hint=hint, **kw)
                     bad = np.nonzero(got != exp)[0]
                     assert len(bad) == 0, (share, qlen, len2, weights, cutoff, hint, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
+
+
+@pytest.mark.parametrize("kind", ["single_length", "ragged"])
+def test_normalized_cutoffs_of_long_queries_through_the_band_kernel(kind):
+    """normalized_distance / normalized_similarity of a Levenshtein scan with a query beyond 64 symbols under an f64 cutoff that leaves <= 31 raw edits (run_many's
+    norm_raw_cut): the u32 scan under the implied raw cutoff (the small-band kernel) + the normalizing pass.  Some / None and every value must be the oracle's f64
+    (details/distance.rs:246-250, :273; common.rs:43-45) -- cutoffs on both sides of the 31-edit line, exactly on representable quotients (k / maximum), 0 and 1,
+    unit and (2, 2, 2) weights, rows shorter and longer than the query; the child process repeats it on the compiled f64 scan (RF_NORM_BAND=0)."""
+    import torch
+
+    if os.environ.get("RF_NORM_BAND") is None:
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", f"test_normalized_cutoffs_of_long_queries and {kind}"],
+                           capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RF_NORM_BAND="0"))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+    rng = np.random.default_rng(77)
+    for qlen in (100, 256, 300):
+        q = synth.query(qlen, 0x4E02 + qlen)
+        qa = np.frombuffer(q, dtype=np.uint8)
+        if kind == "single_length":
+            len2 = qlen + int(rng.integers(-6, 7))
+            rows = _band_rows(50_003, len2, q, 0.3, seed=qlen)
+            corpus = rf.Corpus.from_device_rows(torch.from_numpy(rows).cuda())
+            data, offsets = rows.reshape(-1), np.arange(0, (len(rows) + 1) * len2, len2, dtype=np.uint64)
+        else:
+            cands = []
+            for i in range(30_000):
+                ln = int(rng.integers(max(1, qlen - 40), qlen + 41))
+                if i % 3 == 0:
+                    row = np.resize(qa, ln).copy()
+                    e = int(rng.integers(0, 25))
+                    if e:
+                        row[rng.integers(0, ln, size=e)] = synth.ALNUM[rng.integers(0, 62, size=e)]
+                else:
+                    row = synth.ALNUM[rng.integers(0, 62, size=ln)]
+                cands.append(row.tobytes())
+            data, offsets = rf.ragged(cands)
+            corpus = rf.Corpus.from_ragged(data, offsets)
+        bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
+        longest = max(qlen, int(np.diff(offsets).max()))
+        for weights in (None, (2, 2, 2)):
+            kw = {} if weights is None else {"weights": rf.WeightTable(*weights)}
+            okw = {} if weights is None else {"weights": weights}
+            for opname, op in (("normalized_distance", N.OP_NORMALIZED_DISTANCE), ("normalized_similarity", N.OP_NORMALIZED_SIMILARITY)):
+                cuts = [0.0, 1.0, 0.02, 0.05, 0.1, 0.12, 0.2, 8 / longest, 9 / longest, 31 / longest, 32 / longest, float(rng.random()) * 0.15]
+                for c in cuts:
+                    cut = c if opname == "normalized_distance" else 1.0 - c
+                    got = bc.many(op, corpus, score_cutoff=cut, **kw)
+                    exp = ob.many(op, data, offsets, nthreads=8, score_cutoff=cut, **okw)
+                    bad = _same(got, exp)
+                    assert len(bad) == 0, (kind, qlen, weights, opname, cut, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
