@@ -396,7 +396,25 @@ def test_randomized_corpus_models_vary_what_the_plan_looks_at(seed):
         exp = ob.many(opn, data, offsets, nthreads=8, **kw)
         got = bc.many(opn, corpus, **kw)
         bad = _same(got, exp)
-        assert len(bad) == 0, (seed, law, length_law, share, metric, op, kw, bad[:5], got[bad[:5]], exp[bad[:5]])
+        if len(bad) and metric in ("lcs_seq", "indel") and qlen > 64 and kw.get("score_cutoff") is not None:
+            # Quirk Q8 (tests/test_gpu_parity.py _check_many has the rule): under a cutoff the reference's banded multi-word LCS can lose a match at the band's
+            # edge; the device is exact -- where the two differ the device must hold the reference's UNCUT value, and the oracle, run on that one pair, must
+            # show the defect's precondition (rfo_last_lcs_q8_edges).  The entries are taken out of the comparison of this call and of the ones below.
+            uncut_raw = ob.many(opn, data, offsets, nthreads=8)
+            uncut = _u32(uncut_raw) if got.dtype == np.uint32 else uncut_raw
+            excused = []
+            for i in bad:
+                if got[i] != uncut[i]:
+                    continue
+                cand = np.ascontiguousarray(data[int(offsets[i]) : int(offsets[i + 1])])
+                ob.many(opn, cand, np.array([0, len(cand)], dtype=np.uint64), nthreads=1, **kw)
+                if o.last_lcs_q8_edges() > 0:
+                    excused.append(int(i))
+            if excused:
+                exp = exp.copy()
+                exp[excused] = uncut_raw[excused]
+                bad = _same(got, exp)
+        assert len(bad) == 0, (seed, law, length_law, share, metric, op, kw, qlen, bad[:5], got[bad[:5]], exp[bad[:5]])
         slots = bc.many(opn, corpus, rf.Args().slot_order(), **kw)
         back = np.empty_like(got)
         back[slot_index[real]] = slots[real]
