@@ -240,8 +240,9 @@ def main():
         offsets[1:] = torch.cumsum(lens, 0)
         flat = torch.empty(int(offsets[-1].item()), dtype=torch.uint8, device=dev)
         col = torch.arange(ln, device=dev)[None, :]
-        for a in range(0, n, 1 << 23):  # (boolean indexing in slabs: one mask over all n x ln symbols overflows torch's index arithmetic)
-            b = min(n, a + (1 << 23))
+        slab = max(1, min(1 << 23, (1 << 30) // max(1, ln)))  # (boolean indexing in slabs: a mask of 2^31 symbols overflows torch's index arithmetic)
+        for a in range(0, n, slab):
+            b = min(n, a + slab)
             flat[int(offsets[a].item()) : int(offsets[b].item())] = rows[a:b][col < lens[a:b, None]]  # row-major: candidate a's symbols, then a + 1's, ...
         del rows, col
         mean_len = float(offsets[-1].item()) / n

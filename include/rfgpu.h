@@ -51,6 +51,9 @@
  *                                           corpus' last hinted scans resolved >= 70 % of it (every 16th call looks again)
  *   RF_BAND_DEFER                 1         0: the small-band scan of a single-length corpus runs every tile to its end on 64 lanes instead of handing tiles with few
  *                                           lanes left to a dense second pass (rf_band.hip launch_band)
+ *   RF_BAND_RUNS                  1         0: the small-band scan of a length-bucketed corpus is one launch over its tiles; 1: its long runs of one length are walked
+ *                                           as single-length corpora of their own (with the hand-over above) while that pays, the rest by the tiles kernel
+ *   RF_BAND_RUN_MIN_TILES         32768     fewest tiles of one length for such a run (its launch sequence costs ~70 us whatever its size)
  *   RF_BAND_DEFER_AT              0 (auto)  column (a multiple of 16) at which a tile may be handed over; auto: k + 8 rounded up, 16..64
  *   RF_BAND_DEFER_MAX             44        most lanes still within the band for a tile to be handed over
  *   RF_BAND_DEFER_AFTER           0         such tiles a launch runs in place before it starts handing over (counted in one device word; 0: no count)

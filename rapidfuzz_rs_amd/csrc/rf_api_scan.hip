@@ -717,6 +717,85 @@ static hipError_t launch_scan_runs(RawKind raw, const ScanParams& p, const rf_co
     return e;
 }
 
+// The small-band scan of a LENGTH-BUCKETED corpus (round 6): band_kernel<false> walks tiles, and a tile that holds one candidate near the query runs all its columns on
+// 64 lanes.  The hand-over of sparse tiles to a dense second pass (rf_band.hip launch_band) is written for single-length corpora -- tile t at t * tile_bytes -- and the
+// exact tiles of ONE length of a bucketed corpus are exactly that, except that a slot's result belongs at out[orig[slot]] (ScanParams::run_orig, as in launch_scan_runs
+// above).  So every long run of exact tiles inside the launch's window goes through launch_band as a single-length corpus of its own (its own list, pack and second pass,
+// one after the other on the stream's list buffer); short runs, lengths too short to hand anything over and the one-length views keep the tiles kernel.
+static hipError_t launch_band_runs(RawKind raw, const ScanParams& p, const rf_corpus* corpus, hipStream_t st, bool longest_only)
+{
+    // (a run's launch sequence -- first pass, list pack, second pass with a dense tile walking all its columns alone -- is ~70 us whatever its size: 13 runs of 770 k
+    // candidates with 1 % near the query took 0.96 ms where one launch over the tiles takes 0.90; from ~2 M candidates per run on the hand-over wins)
+    static const uint32_t min_run = [] { const char* e = getenv("RF_BAND_RUN_MIN_TILES"); return e ? (uint32_t)atoi(e) : 32768u; }();
+    hipError_t e = hipSuccess;
+    auto qualifies = [&](uint32_t L, uint32_t tiles) {
+        const uint32_t gap = p.len1 > L ? p.len1 - L : L - p.len1;
+        return gap <= p.band_k && L >= 80u && tiles >= min_run && tile_bytes(L) <= 0xFFFFFFFFull;  // (80: nothing is handed over below defer_at + 64 columns)
+    };
+    size_t longest = (size_t)-1;
+    if (longest_only) {
+        uint32_t most = 0;
+        const uint32_t xb = std::min(p.tile_begin, corpus->n_exact), xe = std::min(p.tile_end, corpus->n_exact);
+        for (size_t i = 0; i < corpus->lengths.size(); ++i) {
+            const uint32_t first = corpus->length_first_tile[i];
+            if (first >= corpus->n_exact) break;
+            const uint32_t end = std::min(i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles, corpus->n_exact);
+            const uint32_t a = std::max(first, xb), b = std::min(end, xe);
+            if (b > a && qualifies(corpus->lengths[i], b - a) && b - a > most) most = b - a, longest = i;
+        }
+    }
+    if (p.prefill_none && p.out) {  // (launch_scan's own pre-fill of the candidates outside the cutoff's length window, once for all the launches below)
+        const size_t w = p.out_f64 ? 2 : 1, from = p.prefill_window ? (size_t)p.tile_begin * kWave : 0, count = p.prefill_window ? (size_t)(p.tile_end - p.tile_begin) * kWave : (size_t)p.n;
+        if (count) e = hipMemsetD32Async((hipDeviceptr_t)(reinterpret_cast<uint32_t*>(p.out) + from * w), (int)RF_NONE_U32, count * w, st);
+    }
+    auto plain = [&](uint32_t a, uint32_t b) {  // the tiles kernel over [a, b): no lists
+        if (e != hipSuccess || b <= a) return;
+        ScanParams q = p;
+        q.tile_begin = a, q.tile_end = b;
+        q.prefill_none = 0;
+        q.lane_list = 0, q.tile_list_buf = nullptr, q.band_defer_seen = nullptr, q.band_report = nullptr;
+        e = launch_scan(raw, q, st, nullptr);
+    };
+    const uint32_t ex_begin = std::min(p.tile_begin, corpus->n_exact), ex_end = std::min(p.tile_end, corpus->n_exact);
+    uint64_t off = 0;  // payload offset of the current length's first tile (exact tiles lie back to back in length order)
+    uint32_t pend_a = 0, pend_b = 0;
+    for (size_t i = 0; i < corpus->lengths.size() && e == hipSuccess; ++i) {
+        const uint32_t first = corpus->length_first_tile[i];
+        if (first >= corpus->n_exact) break;
+        const uint32_t end = std::min(i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles, corpus->n_exact);
+        const uint32_t L = corpus->lengths[i];
+        const uint32_t a = std::max(first, ex_begin), b = std::min(end, ex_end);
+        if (b > a) {
+            if (qualifies(L, b - a) && (!longest_only || i == longest)) {
+                plain(pend_a, pend_b);
+                pend_a = pend_b = 0;
+                ScanParams q = p;
+                q.tiles = nullptr, q.orig = nullptr;
+                q.mixed = nullptr, q.mixed_begin = q.mixed_end = 0;
+                q.data = p.data + off + (uint64_t)(a - first) * tile_bytes(L);
+                q.uniform_len = L;
+                q.uniform_tile_bytes = (uint32_t)tile_bytes(L);
+                q.n_tiles = q.n_exact = b - a;
+                q.tile_begin = 0, q.tile_end = b - a;
+                q.n = (b - a) * (uint32_t)kWave;
+                q.run_orig = (p.slot_store ? p.orig : corpus->d_orig) + (size_t)a * kWave;
+                q.prefill_none = 0;
+                e = launch_scan(raw, q, st, nullptr);
+            } else {
+                if (pend_b != a) {
+                    plain(pend_a, pend_b);
+                    pend_a = a;
+                }
+                pend_b = b;
+            }
+        }
+        off += (uint64_t)(end - first) * tile_bytes(L);
+    }
+    plain(pend_a, pend_b);
+    plain(std::max(p.tile_begin, corpus->n_exact), std::max(p.tile_end, std::max(p.tile_begin, corpus->n_exact)));  // the one-length views of the mixed section
+    return e;
+}
+
 rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op op, const rf_args* args, void* out, rf_mem out_mem, void* stream, bool f64_out);
 // score_hint on a per-candidate scan of a long query (reference: levenshtein.rs:1069-1088, the band of max(hint, 31) doubled until the
 // distance fits -- results never depend on the hint, :2153-2160).  rf_hint.hip has the scheme: pass 1 over everything under the cutoff k1 = max(hint, 31)
@@ -1300,11 +1379,16 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     std::unique_lock<std::mutex> filter_lock;  // held while a filter pass and the scan over its list are enqueued
     // (... and the small-band scans of a single-length corpus: tiles with a few lanes left are listed for a dense second pass, rf_band.hip launch_band)
     const bool band_lists = p.band && raw == RAW_LEV && corpus->uniform && !p.tiles && !want_slots && p.tile_step == 1 && !by_runs;
-    if (p.heads8 || band_lists) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
+    // (... and of a bucketed corpus: its long length runs are walked as single-length corpora of their own, launch_band_runs.  RF_BAND_RUNS=0: one launch over the tiles)
+    static const bool band_runs_on = [] { const char* e = getenv("RF_BAND_RUNS"); return !e || atoi(e) != 0; }();
+    const bool band_runs = band_runs_on && p.band && raw == RAW_LEV && !corpus->uniform && p.tiles == corpus->d_tiles && corpus->d_orig != nullptr && !want_slots &&
+                           p.tile_step == 1 && !by_runs && !by_origin && !p.topk_k;
+    int band_runs_mode = 2;  // 2: every long run through launch_band, 1: the longest one only, 0: none (one launch over the tiles)
+    if (p.heads8 || band_lists || band_runs) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
         p.tile_list_buf = corpus_tile_list(corpus, st);
         corpus_lane_buffers(corpus, &p);
-        if (band_lists && p.tile_list_buf) {
+        if ((band_lists || band_runs) && p.tile_list_buf) {
             p.band_defer_seen = p.tile_list_buf + tile_list_words(corpus->n_tiles) - 4;
             // Which form this launch takes.  Handing tiles over pays when many tiles hold a few near candidates; on a corpus with none, or with most lanes of most tiles
             // near, it buys nothing and costs the list kernels and ~3 % of the first pass' columns.  The second pass of this stream's LAST hand-over launch left what it
@@ -1328,7 +1412,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                 bool pays = false;
                 if (tl.band_report[3] != 0) {
                     const double E = tl.band_report[0], S = tl.band_report[1], N = tl.band_report[2], a = tl.band_report[4], lanes_max = tl.band_report[5];
-                    const double L = corpus->uniform_len, rest = L > a ? L - a : 0.0;
+                    const double L = tl.band_report[6], rest = L > a ? L - a : 0.0;  // (the length of the launch that reported: a bucketed corpus' last run)
                     const double saved = E * rest - S / 64.0 * L;
                     const bool at_the_limit = E > 0 && S / E > 0.75 * lanes_max;
                     const double plain = N * a + (at_the_limit ? N : E) * rest;
@@ -1338,6 +1422,9 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                 // would otherwise send a dozen launches down a road nobody has measured)
                 const bool look = (tl.band_plain_calls++ & 15u) == 0;
                 if (!pays && !look) p.band_defer_seen = nullptr;  // (launch_band: the plain kernel)
+                // (a bucketed corpus pays for the hand-over with a launch sequence PER length run -- 13 runs of 770 k candidates: 626 instead of 183 us on random
+                // rows: all runs only while it pays; a look peels off the longest run alone, the rest stays one launch over the tiles)
+                band_runs_mode = pays ? 2 : (look ? 1 : 0);
             }
         }
     }
@@ -1347,7 +1434,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
                              "tiles=[%u,%u) of %u prefill=%u data6=%d\n",
                      (int)raw, p.words, p.early, p.first_check, p.band, p.heads8 != nullptr, p.head_need, p.head_k, p.tile_list_buf != nullptr, (int)by_runs, (int)by_origin,
                      d_tmp != nullptr, p.tile_begin, p.tile_end, corpus->n_tiles, p.prefill_none, p.data6 != nullptr);
-    hipError_t e = by_runs ? launch_scan_runs(raw, p, c, corpus, op, f64_out, st) : launch_scan(raw, p, st, nullptr);
+    hipError_t e = by_runs ? launch_scan_runs(raw, p, c, corpus, op, f64_out, st) : (band_runs && band_runs_mode != 0 && p.band_defer_seen ? launch_band_runs(raw, p, corpus, st, band_runs_mode == 1) : launch_scan(raw, p, st, nullptr));
     if (filter_lock.owns_lock()) {
         if (p.tile_list_buf) corpus_tile_list_done(corpus, st);
         filter_lock.unlock();

@@ -188,7 +188,11 @@ __device__ __forceinline__ void band_kernel_body(const ScanParams& p, uint32_t* 
         const uint32_t slot = tv.slot0 + lane;
         uint32_t idx = slot;
         if (!kUniform) idx = p.orig[slot];
-        const bool valid = kUniform ? slot < p.n : idx != kPad;
+        bool valid = kUniform ? slot < p.n : idx != kPad;
+        if (kUniform && p.run_orig) {  // a length run of a bucketed corpus walked as a single-length corpus of its own: the slot's original index
+            idx = p.run_orig[slot];
+            valid = idx != kPad;
+        }
         const uint32_t diff = len1 > len2 ? len1 - len2 : len2 - len1;
         if (diff > k) {  // levenshtein.rs:1389-1391: the distance is at least the length difference
             if (valid) emit_none(p, idx);
@@ -241,9 +245,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void band_sparse_kernel(cons
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (p.band_defer_seen) *p.band_defer_seen = 0;  // (the first pass' count of hand-over candidates: zero again for this stream's next launch)
         if (p.band_report) {  // what the first pass listed, for the host's choice of the next launch's form (rf_api_scan.hip run_many; read there without waiting)
-            const uint32_t words[6] = {entries, total, p.tile_end - p.tile_begin, 1u, p.band_defer_at, p.band_defer_max};
+            const uint32_t words[7] = {entries, total, p.tile_end - p.tile_begin, 1u, p.band_defer_at, p.band_defer_max, p.uniform_len};
 #pragma unroll
-            for (int i = 0; i < 6; ++i) __hip_atomic_store(p.band_report + i, words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int i = 0; i < 7; ++i) __hip_atomic_store(p.band_report + i, words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (blockIdx.x * kWavesPerBlock >= n_dense) return;  // (the survivors' number is only known here)
@@ -272,10 +276,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void band_sparse_kernel(cons
         const uint32_t t = (uint32_t)__shfl((int)ent.x, (int)lo, kWave), mlo = (uint32_t)__shfl((int)ent.y, (int)lo, kWave), mhi = (uint32_t)__shfl((int)ent.z, (int)lo, kWave),
                        w = (uint32_t)__shfl((int)ent.w, (int)lo, kWave);
         const uint32_t ls = nth_set_bit(((uint64_t)mhi << 32) | mlo, gg - w);
-        const uint32_t idx = t * kWave + ls;
+        uint32_t idx = t * kWave + ls;
+        bool valid = have && idx < p.n;
+        if (p.run_orig) {
+            idx = p.run_orig[idx];
+            valid = have && idx != kPad;
+        }
         const uint4* src = reinterpret_cast<const uint4*>(p.data + (uint64_t)t * p.uniform_tile_bytes) + ls;
         bool unused = false;
-        (void)band_tile<false>(p, lds_band, stride, pitch_bytes, asm_run, src, p.uniform_len, have && idx < p.n, idx, unused);
+        (void)band_tile<false>(p, lds_band, stride, pitch_bytes, asm_run, src, p.uniform_len, valid, idx, unused);
     }
 }
 
@@ -320,7 +329,7 @@ hipError_t launch_band(const ScanParams& p, hipStream_t stream)
         uint32_t* packed_at = p.tile_list_buf + 4 + 2 * (size_t)G + 4 * (size_t)G * cap;
         return launch_lane_list_pack(p.tile_list_buf, G, cap, packed_at + 4 * ((size_t)n_tiles + 2), stream);
     }
-    const bool defer = defer_on && defer_at && p.lane_list && p.tile_list_buf && p.band_defer_seen && !p.tiles && !p.run_orig && G <= 16384u && p.uniform_len >= defer_at + 64u &&
+    const bool defer = defer_on && defer_at && p.lane_list && p.tile_list_buf && p.band_defer_seen && !p.tiles && G <= 16384u && p.uniform_len >= defer_at + 64u &&
                        p.len1 >= defer_at + 64u + p.band_k;
     if (defer) {
         const uint32_t cap = (n_tiles + G - 1) / G;  // the tiles one wavefront walks

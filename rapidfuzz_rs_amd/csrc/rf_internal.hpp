@@ -155,7 +155,7 @@ struct ScanParams {
     uint32_t band_asm;              // 1: full eight-column diagonal runs as one asm block (rf_band_asm.inc; set by the launcher)
     uint32_t band_defer_at, band_defer_max, band_defer_after;  // != 0 (set by the launcher): a tile with <= band_defer_max lanes within break_score at column band_defer_at is listed for band_sparse_kernel, once the launch has seen band_defer_after of them
     uint32_t* band_defer_seen;      // that count (the last words of the stream's tile-list buffer; band_sparse_kernel zeroes it again)
-    uint32_t* band_report;          // pinned host words (or nullptr): band_sparse_kernel leaves [0] tiles listed, [1] lanes listed, [2] tiles of the launch, [3] 1, [4] band_defer_at, [5] band_defer_max
+    uint32_t* band_report;          // pinned host words (or nullptr): band_sparse_kernel leaves [0] tiles listed, [1] lanes listed, [2] tiles of the launch, [3] 1, [4] band_defer_at, [5] band_defer_max, [6] the launch's candidate length; [8..10]: sparse_words_kernel's (lanes listed, candidates, 1)
     uint32_t band_list;             // 1 (score_hint, first pass): the band launch lists every tile that holds lanes it answered None, with their mask (tile_list_buf), for launch_sparse_words
     // the multi-word asm scans (rf_stream_asm.hip, tools/gen_stream_asm.py BlockKind): raw distances above trim_k1 - 1 need not be exact (they must come out above
     // it), which narrows the Ukkonen band the kernels trim their word-columns to; 0 = no bound beyond max(len1, len2)

@@ -630,3 +630,73 @@ def test_normalized_cutoffs_of_long_queries_through_the_band_kernel(kind):
                     exp = ob.many(op, data, offsets, nthreads=8, score_cutoff=cut, **okw)
                     bad = _same(got, exp)
                     assert len(bad) == 0, (kind, qlen, weights, opname, cut, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
+
+
+def _bucketed_long_corpus(q, seed, per_length=20_000, share=0.05):
+    """lengths len(q) - 6 .. len(q) + 6 with `per_length` candidates each (long runs of exact tiles), two sparsely populated lengths and leftovers for the mixed section;
+    `share` of the candidates near the query (substitutions, one insertion or deletion near the front, or the query's head and noise), in original order shuffled"""
+    rng = np.random.default_rng(seed)
+    qa = np.frombuffer(q, dtype=np.uint8)
+    qlen = len(qa)
+    lens = np.concatenate([np.full(per_length + int(rng.integers(0, 64)), L) for L in range(qlen - 6, qlen + 7)] + [np.full(700, qlen - 20), np.full(90, qlen + 30), np.full(40, 3)])
+    rng.shuffle(lens)
+    cands = []
+    for i, ln in enumerate(lens):
+        ln = int(ln)
+        if rng.random() < share:
+            kind = i % 4
+            base = np.resize(qa, ln + 2)
+            if kind == 0:
+                row = base[:ln].copy()
+                e = int(rng.integers(0, 14))
+                if e:
+                    row[rng.integers(0, ln, size=e)] = synth.ALNUM[rng.integers(0, 62, size=e)]
+            elif kind == 1:
+                row = np.delete(base, int(rng.integers(0, min(30, ln))))[:ln].copy()
+            elif kind == 2:
+                row = np.insert(base, int(rng.integers(0, min(30, ln))), np.uint8(35))[:ln].copy()
+            else:
+                row = synth.ALNUM[rng.integers(0, 62, size=ln)]
+                h = min(int(rng.integers(10, 121)), ln)
+                row[:h] = base[:h]
+        else:
+            row = synth.ALNUM[rng.integers(0, 62, size=ln)]
+        cands.append(row.tobytes())
+    return rf.ragged(cands)
+
+
+@pytest.mark.parametrize("env", [None, {"RF_BAND_RUNS": "0"}, {"RF_BAND_RUN_MIN_TILES": "256"}, {"RF_BAND_RUN_MIN_TILES": "256", "RF_BAND_DEFER_ADAPT": "0"},
+                                 {"RF_BAND_RUN_MIN_TILES": "256", "RF_UNSCATTER_MIN": "1", "RF_BAND_DEFER_ADAPT": "0"}, {"RF_BAND_RUN_MIN_TILES": "1", "RF_BAND_DEFER_ADAPT": "0"},
+                                 {"RF_BAND_RUN_MIN_TILES": "1", "RF_BAND_DEFER_ADAPT": "0", "RF_BAND_DEFER_MAX": "63", "RF_DEVICE_PACK_MIN": "1"}])
+def test_small_band_scan_of_a_bucketed_corpus_walks_its_long_runs_as_single_length_corpora(env):
+    """rf_api_scan.hip launch_band_runs: the long runs of exact tiles of a length-bucketed corpus go through launch_band as single-length corpora of their own (results
+    through run_orig), with the hand-over of sparse tiles; short runs and the one-length views keep band_kernel<false>.  Query 200 / 300, 13 long runs + two short ones +
+    leftovers, 5 % and 60 % near candidates, distance cutoffs across the band kernel's range and the normalized ops that ride it -- against the oracle.  Runs of one length
+    count from 32768 tiles on (their launch sequence has a fixed price), so the in-process case is the tiles kernel; the child processes lower the line: runs of 312 tiles
+    with the launch form following the last report and always handing over, through the slot-ordered temporary + gather, every run a run, every tile with a lane left
+    handed over; and the runs off."""
+    if env is not None:
+        if os.environ.get("RF_TEST_CHILD") == "1":
+            pytest.skip("the child runs the in-process case only")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "test_small_band_scan_of_a_bucketed_corpus and None"],
+                           capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RF_TEST_CHILD="1", **env))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
+        return
+    for qlen, share in ((200, 0.05), (300, 0.6)):
+        q = synth.query(qlen, 0xB0C2 + qlen)
+        data, offsets = _bucketed_long_corpus(q, seed=qlen, share=share)
+        corpus = rf.Corpus.from_ragged(data, offsets)
+        bc, ob = rf.distance.levenshtein.BatchComparator(q), o.levenshtein.BatchComparator(q)
+        for k in (2, 8, 17, 31):
+            for _rep in range(2):  # (the second call may take the other launch form: the stream's last report)
+                got = bc.distance_many(corpus, score_cutoff=k)
+                exp = ob.many(N.OP_DISTANCE, data, offsets, nthreads=8, score_cutoff=k)
+                bad = _same(got, exp)
+                assert len(bad) == 0, (qlen, share, k, _rep, len(bad), bad[:5], got[bad[:5]], exp[bad[:5]])
+        for op, cut in ((N.OP_NORMALIZED_SIMILARITY, 0.95), (N.OP_NORMALIZED_DISTANCE, 0.08)):
+            got = bc.many(op, corpus, score_cutoff=cut)
+            exp = ob.many(op, data, offsets, nthreads=8, score_cutoff=cut)
+            assert len(_same(got, exp)) == 0, (qlen, share, op, cut)
+        idx, val = bc.filter_many(N.OP_DISTANCE, corpus, score_cutoff=8)
+        idx_e, val_e = _some(ob.many(N.OP_DISTANCE, data, offsets, nthreads=8, score_cutoff=8))
+        assert np.array_equal(idx, idx_e) and np.array_equal(val, val_e)
