@@ -1355,7 +1355,7 @@ uint64_t rf_corpus_device_bytes(const rf_corpus* c)
     }
     {
         std::lock_guard<std::mutex> lock(c->filter_enqueue_mu);
-        aux += (uint64_t)c->tile_lists.size() * (2 * (uint64_t)c->n_tiles + 5 * 16384 + 8) * sizeof(uint32_t);
+        aux += (uint64_t)c->tile_lists.size() * (9 * (uint64_t)c->n_tiles + 12 * 16384 + 64) * sizeof(uint32_t);  // (rf_api_scan.hip tile_list_words: the lane lists' 16-byte entries since round 6)
     }
     return c->device_bytes + aux;
 }
