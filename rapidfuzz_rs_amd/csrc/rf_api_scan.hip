@@ -722,16 +722,31 @@ static hipError_t launch_scan_runs(RawKind raw, const ScanParams& p, const rf_co
 // exact tiles of ONE length of a bucketed corpus are exactly that, except that a slot's result belongs at out[orig[slot]] (ScanParams::run_orig, as in launch_scan_runs
 // above).  So every long run of exact tiles inside the launch's window goes through launch_band as a single-length corpus of its own (its own list, pack and second pass,
 // one after the other on the stream's list buffer); short runs, lengths too short to hand anything over and the one-length views keep the tiles kernel.
+// (a run's launch sequence -- first pass, list pack, second pass with a dense tile walking all its columns alone -- is ~70 us whatever its size: 13 runs of 770 k
+// candidates with 1 % near the query took 0.96 ms where one launch over the tiles takes 0.90; from ~2 M candidates per run on the hand-over wins)
+static bool band_run_qualifies(const ScanParams& p, uint32_t L, uint32_t tiles)
+{
+    static const uint32_t min_run = [] { const char* e = getenv("RF_BAND_RUN_MIN_TILES"); return e ? (uint32_t)atoi(e) : 32768u; }();
+    const uint32_t gap = p.len1 > L ? p.len1 - L : L - p.len1;
+    return gap <= p.band_k && L >= 80u && tiles >= min_run && tile_bytes(L) <= 0xFFFFFFFFull;  // (80: nothing is handed over below defer_at + 64 columns)
+}
+// does the launch's window hold a run of exact tiles that launch_band_runs would walk on its own?  (No: one launch over the tiles, as ever.)
+static bool band_has_long_run(const ScanParams& p, const rf_corpus* corpus)
+{
+    const uint32_t xb = std::min(p.tile_begin, corpus->n_exact), xe = std::min(p.tile_end, corpus->n_exact);
+    for (size_t i = 0; i < corpus->lengths.size(); ++i) {
+        const uint32_t first = corpus->length_first_tile[i];
+        if (first >= corpus->n_exact) break;
+        const uint32_t end = std::min(i + 1 < corpus->lengths.size() ? corpus->length_first_tile[i + 1] : corpus->n_tiles, corpus->n_exact);
+        const uint32_t a = std::max(first, xb), b = std::min(end, xe);
+        if (b > a && band_run_qualifies(p, corpus->lengths[i], b - a)) return true;
+    }
+    return false;
+}
 static hipError_t launch_band_runs(RawKind raw, const ScanParams& p, const rf_corpus* corpus, hipStream_t st, bool longest_only)
 {
-    // (a run's launch sequence -- first pass, list pack, second pass with a dense tile walking all its columns alone -- is ~70 us whatever its size: 13 runs of 770 k
-    // candidates with 1 % near the query took 0.96 ms where one launch over the tiles takes 0.90; from ~2 M candidates per run on the hand-over wins)
-    static const uint32_t min_run = [] { const char* e = getenv("RF_BAND_RUN_MIN_TILES"); return e ? (uint32_t)atoi(e) : 32768u; }();
     hipError_t e = hipSuccess;
-    auto qualifies = [&](uint32_t L, uint32_t tiles) {
-        const uint32_t gap = p.len1 > L ? p.len1 - L : L - p.len1;
-        return gap <= p.band_k && L >= 80u && tiles >= min_run && tile_bytes(L) <= 0xFFFFFFFFull;  // (80: nothing is handed over below defer_at + 64 columns)
-    };
+    auto qualifies = [&](uint32_t L, uint32_t tiles) { return band_run_qualifies(p, L, tiles); };
     size_t longest = (size_t)-1;
     if (longest_only) {
         uint32_t most = 0;
@@ -1382,7 +1397,7 @@ rf_status run_many(const rf_comparator* c_in, const rf_corpus* corpus_in, rf_op 
     // (... and of a bucketed corpus: its long length runs are walked as single-length corpora of their own, launch_band_runs.  RF_BAND_RUNS=0: one launch over the tiles)
     static const bool band_runs_on = [] { const char* e = getenv("RF_BAND_RUNS"); return !e || atoi(e) != 0; }();
     const bool band_runs = band_runs_on && p.band && raw == RAW_LEV && !corpus->uniform && p.tiles == corpus->d_tiles && corpus->d_orig != nullptr && !want_slots &&
-                           p.tile_step == 1 && !by_runs && !by_origin && !p.topk_k;
+                           p.tile_step == 1 && !by_runs && !by_origin && !p.topk_k && band_has_long_run(p, corpus);
     int band_runs_mode = 2;  // 2: every long run through launch_band, 1: the longest one only, 0: none (one launch over the tiles)
     if (p.heads8 || band_lists || band_runs) {  // (the head-plane scans: band prefilter or first look as a streaming pass, then the cutoff scan over its list)
         filter_lock = std::unique_lock<std::mutex>(corpus->filter_enqueue_mu);
